@@ -1,0 +1,23 @@
+# Build of the MI355X engine. `make` = the shipped gfx950 library; `make emu` = test-only emulator build.
+ROCM ?= /opt/rocm
+HIPCC ?= $(ROCM)/bin/hipcc
+CXX_EMU ?= $(ROCM)/lib/llvm/bin/clang++
+CSRC := piper_amd/csrc
+SRCS := $(CSRC)/engine.cpp $(CSRC)/pe_api.cpp $(CSRC)/weights.cpp $(CSRC)/onnx_reader.cpp
+HDRS := $(CSRC)/engine.h $(CSRC)/kernels.h $(CSRC)/pe_rt.h $(CSRC)/weights.h include/piper_hip.h
+LIB := piper_amd/libpiper_hip.so
+EMULIB := tests/emu/libpiper_hip_emu.so
+
+all: $(LIB)
+
+$(LIB): $(SRCS) $(HDRS)
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -x hip $(SRCS) -o $@ -Wno-unused-result
+
+emu: $(EMULIB)
+
+$(EMULIB): $(SRCS) $(HDRS) tests/emu/hip_emu.cpp tests/emu/hip_emu.h
+	$(CXX_EMU) -DPE_EMU -O2 -g -std=c++17 -fPIC -shared -Itests/emu $(SRCS) tests/emu/hip_emu.cpp -o $@
+
+clean:
+	rm -f $(LIB) $(EMULIB)
+.PHONY: all emu clean

@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""Throughput of the synthesis hot path on MI355X.
+
+A "step" is one pass of the hot path over one batch of synthetic input: by default ONE utterance
+of 128 phoneme ids through the en_US-lessac-medium architecture (BASELINE.json configs[1]), i.e.
+what one piper::synthesize() call does. Inputs (ids, duration noise) are resident in HBM when the
+timed region starts; the timed region is the device pipeline only (`pe_run`), including its one
+4-byte host read-back of the frame count. N>1: one process per GPU, every rank synthesizes its own
+utterances (weak scaling), voice weights parsed on rank 0 and broadcast over RCCL.
+
+Prints ONE JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP32_MATRIX_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--preset", default="medium")
+    ap.add_argument("--ids", type=int, default=128, help="phoneme ids per utterance")
+    ap.add_argument("--batch", type=int, default=1, help="utterances per step (per GPU)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import torch
+    from piper_amd import weights as W
+    from piper_amd.engine import Engine
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    cfg = W.preset(args.preset)
+    # ---- voice weights: rank 0 builds the blob, RCCL broadcast to the others
+    if rank == 0:
+        wts = W.synthetic_weights(cfg, 1234)
+        blob = W.pack_blob(cfg, wts)
+    else:
+        wts, blob = None, None
+    t_bcast = 0.0
+    if world > 1:
+        n = torch.tensor([len(blob) if rank == 0 else 0], dtype=torch.int64, device="cuda")
+        dist.broadcast(n, 0)
+        buf = torch.empty(int(n.item()), dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            buf.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dist.broadcast(buf, 0)
+        torch.cuda.synchronize()
+        t_bcast = time.perf_counter() - t0
+        if rank != 0:
+            blob = buf.cpu().numpy().tobytes()
+    eng = Engine(blob=blob, device=local_rank)
+
+    # ---- synthetic input, resident in HBM before timing
+    B, T = args.batch, args.ids
+    id_max = min(cfg.n_vocab - 1, 129)
+    id_lists = [W.synthetic_phoneme_ids(T, rank * B + i, id_max=id_max) for i in range(B)]
+    scales = (0.667, 1.0, 0.8)
+    rng = np.random.default_rng(1234 + rank)
+    noise_w = rng.standard_normal((B, 2, T)).astype(np.float32)   # fixes the durations; z noise is drawn on device
+    eng.set_seed(1234 + rank)
+    eng.upload(id_lists, scales, noise_w=noise_w)
+
+    def sync():
+        eng.fetch(False, False)          # stream sync, no copies
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        eng.run()
+    sync()
+    frames = eng.fetch(False, False).frames
+    samples_per_step = int(frames.sum()) * eng.hop
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.run()
+    sync()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    total_samples = samples_per_step * args.steps
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        s = torch.tensor([total_samples], dtype=torch.float64, device="cuda")
+        dist.all_reduce(s, op=dist.ReduceOp.SUM)
+        total_samples = float(s.item())
+
+    # ---- host-buffer (PCIe-inclusive) rate of the full C-ABI call, for DESIGN.md -- never `value`
+    t1 = time.perf_counter()
+    n_api = max(3, min(10, args.steps))
+    for _ in range(n_api):
+        r_api = eng.synthesize_batch(id_lists, scales, noise_w=noise_w)
+    api_rate = sum(p.size for p in r_api.pcm) * n_api / (time.perf_counter() - t1)
+
+    # ---- roofline of the dominant stage: HIP events on the engine's stream around each stage
+    eng.upload(id_lists, scales, noise_w=noise_w)
+    eng.profile_enable(True)
+    eng.profile_reset()
+    nprof = max(3, min(10, args.steps))
+    for _ in range(nprof):
+        eng.run()
+    sync()
+    rows = eng.profile()
+    eng.profile_enable(False)
+    stage_ms = {r["name"]: r["ms"] / nprof for r in rows}
+    stage_tf = {r["name"]: (r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0) for r in rows}
+    dom = max(rows, key=lambda r: r["ms"])
+    achieved = stage_tf[dom["name"]]
+
+    out = None
+    if rank == 0:
+        value = total_samples / elapsed
+        out = {
+            "metric": "audio samples/sec",
+            "value": value,
+            "unit": "samples/s",
+            "x_realtime": value / cfg.sample_rate,
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic (seeded random-weight voice of the named architecture, synthetic phoneme ids)",
+            "config": {"workload": f"{args.preset} VITS voice ({cfg.sample_rate} Hz), {B} utterance(s) x {T} "
+                                   f"phoneme ids per step per GPU, scales 0.667/1.0/0.8",
+                       "frames_per_step": int(frames.sum()), "samples_per_step": samples_per_step,
+                       "parallelism": f"utterance-parallel x{world}, RCCL weight broadcast"},
+            "roofline": {"bound": "mfma", "kernel": "conv_mfma_kernel (stage: %s)" % dom["name"],
+                         "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
+                         "stage_ms": stage_ms, "stage_tflops": stage_tf},
+            "host_api_samples_per_s": api_rate,
+            "weight_broadcast_s": t_bcast,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, wts, id_lists[0], scales, noise_w[0], args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(cfg, wts, ids, scales, noise_w, budget_s):
+    """The oracle (a torch-CPU port of the reference graph, bit-identical to the reference's PyTorch
+    module on the goldens) timed on this box's host cores over a bounded sample: repeated B=1
+    synthesis of the same utterance, like piper.cpp's sequential loop."""
+    import torch
+    from oracle import vits_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    wt = O.to_torch(wts)
+    rng = np.random.default_rng(99)
+    nz = rng.standard_normal((cfg.inter, 16 * len(ids) + 64)).astype(np.float32)
+    O.synthesize(wt, cfg, ids, scales, noise_w, nz)           # warm-up
+    n, samples, t0 = 0, 0, time.perf_counter()
+    while True:
+        r = O.synthesize(wt, cfg, ids, scales, noise_w, nz)
+        samples += r["audio"].size
+        n += 1
+        dt = time.perf_counter() - t0
+        if dt >= budget_s or n >= 200:
+            break
+    return {"value": samples / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "x_realtime": samples / dt / cfg.sample_rate,
+            "sample": f"{n} sequential B=1 syntheses of the same {len(ids)}-id utterance in {dt:.1f} s "
+                      f"(torch CPU fp32, {cores} threads)"}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,108 @@
+/* piper_hip.h -- C ABI of the MI355X-native VITS synthesis engine (libpiper_hip.so).
+ *
+ * This is the drop-in boundary for the ONNX Runtime session that the reference's
+ * piper::synthesize() drives (reference src/cpp/piper.cpp:337-441). Each entry point names the
+ * reference interface it replaces. Plain pointers and sizes only; all functions return 0 on success
+ * and a non-zero code on failure, with the message available from pe_last_error() (the reference
+ * throws Ort::Exception / std::runtime_error at the same places; the C++ shim in
+ * piper_amd/csrc/piper.hpp re-throws std::runtime_error).
+ *
+ * Threading: like the reference an engine handle is not thread-safe; use one
+ * handle per thread / per GPU. Output buffers returned by pe_synthesize* are owned by the engine and
+ * stay valid until the next call on the same handle.
+ */
+#ifndef PIPER_HIP_H_
+#define PIPER_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct pe_engine pe_engine;
+
+/* Optional injected N(0,1) draws for the two sampling sites of the graph (reference
+ * vits/models.py:111 and :718; ONNX RandomNormalLike nodes). NULL pointers -> the engine's own
+ * counter-based generator (seed: pe_set_seed). Host pointers.
+ *   noise_w: [B][2][w_stride]        column t is used for phoneme id t
+ *   noise_z: [B][inter][z_stride]    column f is used for frame f (z_stride >= frames) */
+typedef struct pe_noise {
+  const float* noise_w;
+  int64_t w_stride;
+  const float* noise_z;
+  int64_t z_stride;
+} pe_noise;
+
+/* Result views of the last synthesis call (engine-owned host memory). */
+typedef struct pe_result {
+  int32_t batch;
+  const int64_t* sample_offsets; /* [batch+1] prefix offsets into audio / pcm */
+  const float* audio;            /* float waveform in [-1,1], what Ort "output" [1,1,1,S] held (piper.cpp:397-400) */
+  const int16_t* pcm;            /* peak-normalised int16 as piper.cpp:410-431 / util.py:5-12 produce */
+  const int32_t* frames;         /* [batch] spectrogram frames per utterance (S = frames * hop) */
+  double infer_seconds;          /* wall time of the device pipeline, the reference's inferSeconds (piper.cpp:385-395) */
+} pe_result;
+
+/* Replaces Ort::Env + SessionOptions + Ort::Session(model path) in loadModel()
+ * (piper.cpp:262-306): parses the voice .onnx (export_onnx.py graph), packs the weights for the
+ * MFMA kernels and uploads them to GPU `device`. */
+int pe_create(const char* onnx_path, int device, pe_engine** out);
+
+/* Same from an in-memory weight blob (PEBLOB01, see piper_amd/weights.py). This is also what the
+ * other ranks of a multi-GPU job call after the RCCL broadcast of rank 0's blob. */
+int pe_create_from_blob(const void* blob, size_t nbytes, int device, pe_engine** out);
+
+/* .onnx -> PEBLOB01 in host memory (no GPU needed). Free with pe_free(). */
+int pe_onnx_to_blob(const char* onnx_path, void** blob, size_t* nbytes);
+void pe_free(void* p);
+
+/* Replaces session.onnx.Run() for one utterance (piper.cpp:386-388) with the inputs of
+ * piper.cpp:342-377: ids = "input"[1,T] (int64), scales = {noise_scale, length_scale, noise_w},
+ * sid = "sid" or -1 for single-speaker voices. */
+int pe_synthesize(pe_engine* e, const int64_t* ids, int64_t n_ids, const float scales[3], int64_t sid,
+                  const pe_noise* noise, pe_result* result);
+
+/* Batched form: B independent utterances, each computed exactly as a B=1 Run() would (no cross-talk
+ * through padding). ids are concatenated; offsets[B+1] delimit them; sids may be NULL. */
+int pe_synthesize_batch(pe_engine* e, const int64_t* ids, const int64_t* offsets, int32_t batch,
+                        const float scales[3], const int64_t* sids, const pe_noise* noise, pe_result* result);
+
+/* Split form of the batched call, for callers that keep inputs resident in HBM between steps
+ * (bench.py): upload = host->HBM copy of ids/noise, run = device pipeline only, fetch = HBM->host. */
+int pe_upload(pe_engine* e, const int64_t* ids, const int64_t* offsets, int32_t batch, const float scales[3],
+              const int64_t* sids, const pe_noise* noise);
+int pe_run(pe_engine* e);
+int pe_fetch(pe_engine* e, int want_audio, int want_pcm, pe_result* result);
+
+/* Integer per-id durations (ceil(w), reference models.py:703) of the last call, concatenated like ids. */
+int pe_get_durations(pe_engine* e, int32_t* out, int64_t capacity, int64_t* n);
+
+/* Voice facts the caller needs (sample rate from the architecture header of a blob, hop size, ...). */
+int pe_get_info(pe_engine* e, int32_t* sample_rate, int32_t* hop, int32_t* n_speakers, int32_t* n_symbols,
+                int64_t* weight_bytes);
+
+void pe_set_seed(pe_engine* e, uint64_t seed);
+
+/* Stage timing (HIP events on the engine's stream): rows text_encoder, duration_predictor,
+ * regulate+flow, hifigan, post+pcm. ms/flops/launches accumulate until pe_profile_reset(). */
+int pe_profile_enable(pe_engine* e, int on);
+int pe_profile_reset(pe_engine* e);
+int pe_profile_rows(pe_engine* e);
+int pe_profile_get(pe_engine* e, int row, const char** name, double* ms, double* flops, int64_t* launches);
+
+/* The HIP stream (hipStream_t) the engine launches on, for callers that bracket it with their own events. */
+void* pe_stream(pe_engine* e);
+
+/* Test hook: copy an internal per-stage tensor of utterance b (x_enc, stats, xg, logw, z, audio). */
+int pe_debug_tensor(pe_engine* e, const char* name, int32_t b, float* out, int64_t capacity, int32_t* rows,
+                    int32_t* cols);
+
+const char* pe_last_error(void);
+void pe_destroy(pe_engine* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PIPER_HIP_H_ */

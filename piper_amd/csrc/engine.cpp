@@ -1,0 +1,853 @@
+#include "engine.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace pe {
+
+static inline int rup(int v, int m) { return (v + m - 1) / m * m; }
+
+// tile configurations of conv_mfma_kernel: {WM, WN, MT, NT}
+enum { CFG_A = 0, CFG_B = 1, CFG_C = 2, CFG_S = 3, CFG_G = 4 };
+static const int CFG_BM[] = {128, 64, 32, 64, 128};
+static const int CFG_BN[] = {128, 128, 256, 64, 64};
+
+// ------------------------------------------------------------------------------------------------
+// setup
+// ------------------------------------------------------------------------------------------------
+
+float* Engine::dev_copy(const std::vector<float>& v) {
+  void* d = nullptr;
+  size_t n = std::max<size_t>(v.size(), 1) * sizeof(float);
+  PE_HIP(hipMalloc(&d, n));
+  if (!v.empty()) PE_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+  owned_.push_back(d);
+  weight_bytes_ += v.size() * sizeof(float);
+  return static_cast<float*>(d);
+}
+
+float* Engine::dev_tensor(const WeightSet& ws, const std::string& name) { return dev_copy(ws.get(name).data); }
+
+// Packs a dense [rows][Cin][ntaps] matrix into the A-operand order of conv_mfma_kernel:
+//   [mtile][chunk][tap][kk = 0..15][lane = 0..63] with lane -> row = mtile*32 + (lane&31),
+//   ci = chunk*32 + 2*kk + (lane>>5). With gate=true the 32-row tiles alternate between the tanh
+//   half (rows [0,split)) and the sigmoid half (rows [split,2*split)) so that one wave owns both.
+PackedConv Engine::pack_matrix(const std::vector<float>& W, int rows, int Cin, int ntaps,
+                               const std::vector<float>* bias, int dil, int padl, bool gate, int split) {
+  PackedConv pc;
+  pc.rows = rows;
+  pc.Cin = Cin;
+  pc.ntaps = ntaps;
+  pc.dil = dil;
+  pc.padl = padl;
+  pc.nchunks = (Cin + KC - 1) / KC;
+  pc.gate = gate;
+  pc.split = split;
+  int vt = gate ? 2 * ((split + 31) / 32) : (rows + 31) / 32;
+  if (gate) pc.cfg = (vt % 4 == 0) ? CFG_A : CFG_B;
+  else pc.cfg = (vt % 4 == 0) ? CFG_A : (vt % 2 == 0 ? CFG_B : CFG_C);
+  const int tiles_per_block = CFG_BM[pc.cfg] / 32;
+  pc.mtiles = rup(vt, tiles_per_block);
+  std::vector<float> P((size_t)pc.mtiles * pc.nchunks * ntaps * (KC / 2) * 64, 0.f);
+  for (int mt = 0; mt < pc.mtiles; ++mt)
+    for (int c = 0; c < pc.nchunks; ++c)
+      for (int tap = 0; tap < ntaps; ++tap)
+        for (int kk = 0; kk < KC / 2; ++kk)
+          for (int lane = 0; lane < 64; ++lane) {
+            int r = lane & 31, row;
+            if (gate) {
+              int q = mt >> 1, ch = q * 32 + r;
+              row = (ch < split) ? ((mt & 1) ? split + ch : ch) : -1;
+            } else {
+              row = mt * 32 + r;
+              if (row >= rows) row = -1;
+            }
+            int ci = c * KC + 2 * kk + (lane >> 5);
+            float v = 0.f;
+            if (row >= 0 && ci < Cin) v = W[((size_t)row * Cin + ci) * ntaps + tap];
+            P[((((size_t)mt * pc.nchunks + c) * ntaps + tap) * (KC / 2) + kk) * 64 + lane] = v;
+          }
+  pc.wp = dev_copy(P);
+  pc.bias = bias ? dev_copy(*bias) : nullptr;
+  pc.macs_per_col = (double)rows * Cin * ntaps;
+  return pc;
+}
+
+// Conv1d weight [Cout][Cin][K] -> packed. in_rev / out_rev fold a channel Flip (modules.py:385-391)
+// into the weights: in_rev reverses the input-channel order, out_rev the output rows (and bias).
+PackedConv Engine::pack_conv(const WeightSet& ws, const std::string& wname, const std::string& bname, int dil,
+                             int padl_override, bool gate, int in_rev, int out_rev) {
+  const HostTensor& w = ws.get(wname);
+  if (w.dims.size() != 3) throw std::runtime_error(wname + ": expected a rank-3 conv weight");
+  const int Co = (int)w.dims[0], Ci = (int)w.dims[1], K = (int)w.dims[2];
+  std::vector<float> W(w.data.size());
+  for (int o = 0; o < Co; ++o)
+    for (int i = 0; i < Ci; ++i)
+      for (int k = 0; k < K; ++k) {
+        const int so = out_rev ? Co - 1 - o : o, si = in_rev ? Ci - 1 - i : i;
+        W[((size_t)o * Ci + i) * K + k] = w.data[((size_t)so * Ci + si) * K + k];
+      }
+  std::vector<float> bias;
+  bool has_b = !bname.empty() && ws.has(bname);
+  if (has_b) {
+    bias = ws.get(bname).data;
+    if ((int)bias.size() != Co) throw std::runtime_error(bname + ": bias size mismatch");
+    if (out_rev) std::reverse(bias.begin(), bias.end());
+  }
+  // "same" padding: get_padding (commons.py:17-18) == (K-1)*dil/2 ; FFN._same_padding left pad (K-1)/2
+  const int padl = padl_override >= 0 ? padl_override : (K - 1) * dil / 2;
+  return pack_matrix(W, Co, Ci, K, has_b ? &bias : nullptr, dil, padl, gate, gate ? Co / 2 : 0);
+}
+
+PackedConv Engine::pack_qkv(const WeightSet& ws, const std::string& prefix) {
+  // conv_q / conv_k / conv_v (attentions.py:216-218) share their input: one GEMM with 3H rows.
+  std::vector<float> W, bias;
+  int H = 0;
+  for (const char* n : {"conv_q", "conv_k", "conv_v"}) {
+    const HostTensor& w = ws.get(prefix + "." + n + ".weight");
+    const HostTensor& b = ws.get(prefix + "." + n + ".bias");
+    H = (int)w.dims[0];
+    W.insert(W.end(), w.data.begin(), w.data.end());
+    bias.insert(bias.end(), b.data.begin(), b.data.end());
+  }
+  return pack_matrix(W, 3 * H, H, 1, &bias, 1, 0, false, 0);
+}
+
+// ConvTranspose1d weight [Cin][Cout][K] with K == 2*stride, padding (K-stride)/2 (models.py:321-332):
+// polyphase GEMM rows (co*stride + phase), two taps: tap0 reads x[j-1] with W[ci][co][phase+stride],
+// tap1 reads x[j] with W[ci][co][phase]; output t = j*stride + phase - pad.
+PackedConv Engine::pack_convT(const WeightSet& ws, const std::string& prefix, int stride) {
+  const HostTensor& w = ws.get(prefix + ".weight");
+  const int Ci = (int)w.dims[0], Co = (int)w.dims[1], K = (int)w.dims[2];
+  if (K != 2 * stride || ((K - stride) & 1))
+    throw std::runtime_error(prefix + ": ConvTranspose1d with kernel != 2*stride is not supported");
+  const int rows = Co * stride;
+  std::vector<float> W((size_t)rows * Ci * 2);
+  for (int co = 0; co < Co; ++co)
+    for (int ph = 0; ph < stride; ++ph)
+      for (int ci = 0; ci < Ci; ++ci) {
+        const size_t row = (size_t)co * stride + ph;
+        W[(row * Ci + ci) * 2 + 0] = w.data[((size_t)ci * Co + co) * K + ph + stride];
+        W[(row * Ci + ci) * 2 + 1] = w.data[((size_t)ci * Co + co) * K + ph];
+      }
+  std::vector<float> bias = ws.get(prefix + ".bias").data;
+  PackedConv pc = pack_matrix(W, rows, Ci, 2, &bias, 1, 1, false, 0);
+  pc.up = stride;
+  pc.padT = (K - stride) / 2;
+  return pc;
+}
+
+DdsW Engine::load_dds(const WeightSet& ws, const std::string& p) {
+  DdsW d;
+  for (int i = 0; i < arch_[A_DDSLAYERS]; ++i) {
+    const std::string s = std::to_string(i);
+    d.dw_w.push_back(dev_tensor(ws, p + ".convs_sep." + s + ".weight"));
+    d.dw_b.push_back(dev_tensor(ws, p + ".convs_sep." + s + ".bias"));
+    d.c1x1.push_back(pack_conv(ws, p + ".convs_1x1." + s + ".weight", p + ".convs_1x1." + s + ".bias", 1, -1,
+                               false, 0, 0));
+    d.g1.push_back(dev_tensor(ws, p + ".norms_1." + s + ".gamma"));
+    d.b1.push_back(dev_tensor(ws, p + ".norms_1." + s + ".beta"));
+    d.g2.push_back(dev_tensor(ws, p + ".norms_2." + s + ".gamma"));
+    d.b2.push_back(dev_tensor(ws, p + ".norms_2." + s + ".beta"));
+  }
+  return d;
+}
+
+Engine::Engine(const WeightSet& ws, int device) : device_(device) {
+  memcpy(arch_, ws.arch, sizeof(arch_));
+  PE_HIP(hipSetDevice(device_));
+  PE_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  H_ = arch_[A_HIDDEN]; C_ = arch_[A_INTER]; FC_ = arch_[A_FILTER]; nh_ = arch_[A_NHEADS];
+  nlayers_ = arch_[A_NLAYERS]; ksz_ = arch_[A_KSIZE]; window_ = arch_[A_WINDOW]; U_ = arch_[A_UPINIT];
+  gin_ = arch_[A_GIN]; nspk_ = arch_[A_NSPK];
+  if (H_ <= 0 || C_ <= 0 || nh_ <= 0 || H_ % nh_ || (C_ & 1)) throw std::runtime_error("bad architecture header");
+  dk_ = H_ / nh_;
+  if (dk_ > 128) throw std::runtime_error("head dimension > 128 is not supported");
+  hop_ = 1;
+  for (int i = 0; i < arch_[A_NUPS]; ++i) hop_ *= arch_[A_UPR0 + i];
+
+  // ---- text encoder
+  emb_ = dev_tensor(ws, "enc_p.emb.weight");
+  const int padl_ffn = (ksz_ - 1) / 2;    // attentions.py:419-427
+  for (int l = 0; l < nlayers_; ++l) {
+    const std::string s = std::to_string(l), a = "enc_p.encoder.attn_layers." + s,
+                      f = "enc_p.encoder.ffn_layers." + s;
+    EncLayer e;
+    e.qkv = pack_qkv(ws, a);
+    e.o = pack_conv(ws, a + ".conv_o.weight", a + ".conv_o.bias", 1, -1, false, 0, 0);
+    e.relk = dev_tensor(ws, a + ".emb_rel_k");
+    e.relv = dev_tensor(ws, a + ".emb_rel_v");
+    e.g1 = dev_tensor(ws, "enc_p.encoder.norm_layers_1." + s + ".gamma");
+    e.b1 = dev_tensor(ws, "enc_p.encoder.norm_layers_1." + s + ".beta");
+    e.f1 = pack_conv(ws, f + ".conv_1.weight", f + ".conv_1.bias", 1, padl_ffn, false, 0, 0);
+    e.f2 = pack_conv(ws, f + ".conv_2.weight", f + ".conv_2.bias", 1, padl_ffn, false, 0, 0);
+    e.g2 = dev_tensor(ws, "enc_p.encoder.norm_layers_2." + s + ".gamma");
+    e.b2 = dev_tensor(ws, "enc_p.encoder.norm_layers_2." + s + ".beta");
+    enc_.push_back(e);
+  }
+  enc_proj_ = pack_conv(ws, "enc_p.proj.weight", "enc_p.proj.bias", 1, -1, false, 0, 0);
+
+  // ---- duration predictor (reverse path)
+  dp_pre_ = pack_conv(ws, "dp.pre.weight", "dp.pre.bias", 1, -1, false, 0, 0);
+  dp_dds_ = load_dds(ws, "dp.convs");
+  dp_proj_ = pack_conv(ws, "dp.proj.weight", "dp.proj.bias", 1, -1, false, 0, 0);
+  for (int i = arch_[A_DPFLOWS] - 1; i >= 1; --i) {     // dp.flows.{7,5,3} (models.py:108-110)
+    const std::string p = "dp.flows." + std::to_string(2 * i + 1);
+    CFlow cf;
+    cf.pre_w = dev_tensor(ws, p + ".pre.weight");
+    cf.pre_b = dev_tensor(ws, p + ".pre.bias");
+    cf.dds = load_dds(ws, p + ".convs");
+    cf.proj = pack_conv(ws, p + ".proj.weight", p + ".proj.bias", 1, -1, false, 0, 0);
+    if (cf.proj.rows != 3 * arch_[A_NBINS] - 1 || arch_[A_NBINS] != 10)
+      throw std::runtime_error("spline with num_bins != 10 is not supported");
+    cflows_.push_back(cf);
+  }
+  {
+    const HostTensor& m = ws.get("dp.flows.0.m");
+    const HostTensor& lg = ws.get("dp.flows.0.logs");
+    // After the (odd number of) Flip/ConvFlow pairs and the final Flip, logical channel 0 is ...
+    // tracked in run(); here only the scalars of ElementwiseAffine channel 0 are needed.
+    ea_m0_ = m.data[0];
+    ea_es0_ = std::exp(-lg.data[0]);
+  }
+
+  // ---- coupling flow, execution order = reversed module order, Flip folded into weights
+  {
+    const int nf = arch_[A_FLOWN], half = C_ / 2, wnl = arch_[A_WNLAYERS], wnk = arch_[A_WNK];
+    int flips = 0;
+    for (int f = nf - 1; f >= 0; --f) {
+      ++flips;                                   // the Flip that precedes this layer in reverse
+      const bool odd = flips & 1;
+      const std::string p = "flow.flows." + std::to_string(2 * f);
+      Rcl r;
+      // odd parity: x0 = reversed upper half of the physical tensor, x1 = reversed lower half
+      r.in_off = odd ? half : 0;
+      r.out_off = odd ? 0 : half;
+      r.pre = pack_conv(ws, p + ".pre.weight", p + ".pre.bias", 1, -1, false, odd, 0);
+      for (int i = 0; i < wnl; ++i) {
+        const std::string s = std::to_string(i);
+        r.in.push_back(pack_conv(ws, p + ".enc.in_layers." + s + ".weight", p + ".enc.in_layers." + s + ".bias",
+                                 1, -1, true, 0, 0));
+        r.rs.push_back(pack_conv(ws, p + ".enc.res_skip_layers." + s + ".weight",
+                                 p + ".enc.res_skip_layers." + s + ".bias", 1, -1, false, 0, 0));
+        (void)wnk;
+      }
+      r.post = pack_conv(ws, p + ".post.weight", p + ".post.bias", 1, -1, false, 0, odd);
+      rcls_.push_back(r);
+      if (gin_) {
+        const HostTensor& cw = ws.get(p + ".enc.cond_layer.weight");
+        cond_wn_.push_back(CondW{dev_copy(cw.data), dev_tensor(ws, p + ".enc.cond_layer.bias"), (int)cw.dims[0]});
+      }
+    }
+    if (flips & 1) throw std::runtime_error("odd number of flow layers is not supported");
+  }
+
+  // ---- HiFiGAN
+  dec_pre_ = pack_conv(ws, "dec.conv_pre.weight", "dec.conv_pre.bias", 1, -1, false, 0, 0);
+  {
+    const int nk = arch_[A_NRB], nd = arch_[A_NDIL];
+    int ch = U_;
+    for (int i = 0; i < arch_[A_NUPS]; ++i) {
+      UpStage st;
+      st.rate = arch_[A_UPR0 + i];
+      st.up = pack_convT(ws, "dec.ups." + std::to_string(i), st.rate);
+      ch = U_ >> (i + 1);
+      st.ch = ch;
+      for (int j = 0; j < nk; ++j) {
+        const std::string rb = "dec.resblocks." + std::to_string(i * nk + j);
+        std::vector<PackedConv> cv;
+        for (int d = 0; d < nd; ++d) {
+          const int dil = arch_[A_RBDIL0 + j * MAX_DIL + d];
+          const std::string s = std::to_string(d);
+          if (arch_[A_RESBLOCK] == 1) {
+            cv.push_back(pack_conv(ws, rb + ".convs1." + s + ".weight", rb + ".convs1." + s + ".bias", dil, -1,
+                                   false, 0, 0));
+            cv.push_back(pack_conv(ws, rb + ".convs2." + s + ".weight", rb + ".convs2." + s + ".bias", 1, -1,
+                                   false, 0, 0));
+          } else {
+            cv.push_back(pack_conv(ws, rb + ".convs." + s + ".weight", rb + ".convs." + s + ".bias", dil, -1,
+                                   false, 0, 0));
+          }
+        }
+        st.rb.push_back(cv);
+      }
+      ups_.push_back(st);
+    }
+    const HostTensor& pw = ws.get("dec.conv_post.weight");
+    post_w_ = dev_copy(pw.data);
+    post_cin_ = (int)pw.dims[1];
+    if ((int)pw.dims[0] != 1 || post_cin_ != ch) throw std::runtime_error("dec.conv_post shape mismatch");
+  }
+
+  // ---- speaker conditioning
+  if (nspk_ > 1) {
+    if (!gin_) throw std::runtime_error("multi-speaker voice without gin_channels");
+    emb_g_ = dev_tensor(ws, "emb_g.weight");
+    const HostTensor& dw = ws.get("dp.cond.weight");
+    cond_dp_ = CondW{dev_copy(dw.data), dev_tensor(ws, "dp.cond.bias"), (int)dw.dims[0]};
+    const HostTensor& cw = ws.get("dec.cond.weight");
+    cond_dec_ = CondW{dev_copy(cw.data), dev_tensor(ws, "dec.cond.bias"), (int)cw.dims[0]};
+    cond_off_dp_ = 0;
+    int off = cond_dp_.rows;
+    for (auto& c : cond_wn_) { cond_off_wn_.push_back(off); off += c.rows; }
+    cond_off_dec_ = off;
+    off += cond_dec_.rows;
+    cond_bs_ = off;
+  }
+
+  static const char* rows[] = {"text_encoder", "duration_predictor", "regulate+flow", "hifigan", "post+pcm"};
+  for (auto n : rows) prof_.push_back(ProfileRow{n});
+  PE_HIP(hipEventCreate(&ev0_));
+  PE_HIP(hipEventCreate(&ev1_));
+  PE_HIP(hipHostMalloc((void**)&h_frames_, 4096 * sizeof(int)));
+}
+
+Engine::~Engine() {
+  hipStreamSynchronize(stream_);
+  for (void* p : owned_) hipFree(p);
+  if (wsA_) hipFree(wsA_);
+  if (wsB_) hipFree(wsB_);
+  if (h_audio_) hipHostFree(h_audio_);
+  if (h_pcm_) hipHostFree(h_pcm_);
+  if (h_frames_) hipHostFree(h_frames_);
+  if (ev0_) hipEventDestroy(ev0_);
+  if (ev1_) hipEventDestroy(ev1_);
+  hipStreamDestroy(stream_);
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspaces
+// ------------------------------------------------------------------------------------------------
+
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(char* b) : base(b) {}
+  template <class T> T* take(size_t n) {
+    off = (off + 255) / 256 * 256;
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+void Engine::ensure_stage_a(int B, int Tmax) {
+  const int Ts = rup(Tmax, 64);
+  bool grow = false;
+  if ((size_t)B > capA_B_) { capA_B_ = B; grow = true; }
+  if ((size_t)Ts > capA_T_) { capA_T_ = Ts; grow = true; }
+  Ts_ = (int)capA_T_;
+  const size_t Bc = capA_B_, T = capA_T_;
+  auto carve = [&](char* base) -> size_t {
+    Carver c(base);
+    d_ids_ = c.take<int>(Bc * T);
+    d_tlens_ = c.take<int>(Bc);
+    d_sids_ = c.take<int>(Bc);
+    d_dur_ = c.take<int>(Bc * T);
+    d_cum_ = c.take<int>(Bc * T);
+    d_frames_ = c.take<int>(Bc);
+    absmax_ = c.take<unsigned>(Bc);
+    x_ = c.take<float>(Bc * H_ * T);
+    y_ = c.take<float>(Bc * H_ * T);
+    qkv_ = c.take<float>(Bc * 3 * H_ * T);
+    att_ = c.take<float>(Bc * H_ * T);
+    ffh_ = c.take<float>(Bc * FC_ * T);
+    stats_ = c.take<float>(Bc * 2 * C_ * T);
+    xg_ = c.take<float>(Bc * H_ * T);
+    dh_ = c.take<float>(Bc * H_ * T);
+    dy_ = c.take<float>(Bc * H_ * T);
+    dy2_ = c.take<float>(Bc * H_ * T);
+    hproj_ = c.take<float>(Bc * 32 * T);
+    z2_ = c.take<float>(Bc * 2 * T);
+    logw_ = c.take<float>(Bc * T);
+    noise_w_ = c.take<float>(Bc * 2 * T);
+    cond_ = c.take<float>(Bc * (size_t)std::max(cond_bs_, 1));
+    return c.off + 256;
+  };
+  if (grow || !wsA_) {
+    PE_HIP(hipStreamSynchronize(stream_));
+    if (wsA_) PE_HIP(hipFree(wsA_));
+    if (wsB_) { PE_HIP(hipFree(wsB_)); wsB_ = nullptr; }   // stage-B sizes depend on the batch capacity
+    capB_F_ = 0;
+    wsA_bytes_ = carve(nullptr);
+    PE_HIP(hipMalloc((void**)&wsA_, wsA_bytes_));
+  }
+  carve(wsA_);
+}
+
+void Engine::ensure_stage_b(int Fmax) {
+  const int Fs = rup(Fmax, 64);
+  bool grow = false;
+  if ((size_t)Fs > capB_F_) { capB_F_ = Fs; grow = true; }
+  Fs_ = (int)capB_F_;
+  const size_t Bc = capA_B_, F = capB_F_;
+  // largest [channels x length] activation of the generator
+  size_t hmax = (size_t)U_ * F;
+  {
+    size_t L = F;
+    for (auto& st : ups_) { L *= st.rate; hmax = std::max(hmax, (size_t)st.ch * L); }
+  }
+  Ss_ = (long)F * hop_;
+  auto carve = [&](char* base) -> size_t {
+    Carver c(base);
+    zp_ = c.take<float>(Bc * C_ * F);
+    fh_ = c.take<float>(Bc * H_ * F);
+    facts_ = c.take<float>(Bc * H_ * F);
+    fskip_ = c.take<float>(Bc * H_ * F);
+    noise_z_ = c.take<float>(Bc * C_ * F);
+    for (int i = 0; i < 5; ++i) hb_[i] = c.take<float>(Bc * hmax);
+    audio_ = c.take<float>(Bc * (size_t)Ss_);
+    pcm_ = c.take<int16_t>(Bc * (size_t)Ss_);
+    return c.off + 256;
+  };
+  if (grow || !wsB_) {
+    PE_HIP(hipStreamSynchronize(stream_));
+    if (wsB_) PE_HIP(hipFree(wsB_));
+    wsB_bytes_ = carve(nullptr);
+    PE_HIP(hipMalloc((void**)&wsB_, wsB_bytes_));
+  }
+  carve(wsB_);
+}
+
+// ------------------------------------------------------------------------------------------------
+// launch helpers
+// ------------------------------------------------------------------------------------------------
+
+void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int len_mul, int Lmax, int epi,
+                  float in_slope, int act, View res, View out2, int mode, float alpha, const float* bias2,
+                  int bias2_bs) {
+  ConvP p;
+  p.x = x.p; p.x_bs = x.bs; p.x_cs = x.cs;
+  p.wp = pc.wp; p.bias = pc.bias;
+  p.bias2 = bias2; p.bias2_bs = bias2_bs;
+  p.out = out.p; p.o_bs = out.bs; p.o_cs = out.cs;
+  p.res = res.p; p.r_bs = res.bs; p.r_cs = res.cs;
+  p.out2 = out2.p; p.o2_bs = out2.bs; p.o2_cs = out2.cs;
+  p.lens = lens; p.len_mul = len_mul;
+  p.Cin = pc.Cin; p.rows = pc.rows; p.nchunks = pc.nchunks;
+  p.ntaps = pc.ntaps; p.dil = pc.dil; p.padl = pc.padl;
+  p.xhalo = (pc.ntaps - 1) * pc.dil;
+  p.in_slope = in_slope;
+  p.epi = epi; p.act = act;
+  p.split = (epi == EPI_GATE) ? pc.split : (epi == EPI_WNRS ? (pc.rows > H_ ? H_ : 0) : 0);
+  p.up = pc.up; p.padT = pc.padT;
+  p.mode = mode; p.alpha = alpha;
+  if ((epi == EPI_GATE) != pc.gate) throw std::runtime_error("internal: gate epilogue/packing mismatch");
+
+  const int ncols = (epi == EPI_CONVT) ? Lmax + 1 : Lmax;
+  int cfg = pc.cfg;
+  // small problems: trade tile size for more workgroups (B=1 encoder / first generator stages)
+  {
+    const long blocks = (long)((ncols + CFG_BN[cfg] - 1) / CFG_BN[cfg]) * (pc.mtiles * 32 / CFG_BM[cfg]) * B_;
+    if (blocks < 192) {
+      if (cfg == CFG_A) cfg = pc.gate ? CFG_G : CFG_S;
+      else if (cfg == CFG_B && !pc.gate) cfg = CFG_S;
+    }
+  }
+  const int BM = CFG_BM[cfg], BN = CFG_BN[cfg];
+  dim3 grid((ncols + BN - 1) / BN, pc.mtiles * 32 / BM, B_);
+  const size_t smem = (size_t)KC * (BN + p.xhalo) * sizeof(float);
+  if (smem > 64 * 1024) throw std::runtime_error("conv halo too large for the LDS tile");
+  switch (cfg) {
+    case CFG_A: PE_LAUNCH((conv_mfma_kernel<2, 2, 2, 2>), grid, dim3(256), smem, stream_, p); break;
+    case CFG_B: PE_LAUNCH((conv_mfma_kernel<1, 4, 2, 1>), grid, dim3(256), smem, stream_, p); break;
+    case CFG_C: PE_LAUNCH((conv_mfma_kernel<1, 4, 1, 2>), grid, dim3(256), smem, stream_, p); break;
+    case CFG_S: PE_LAUNCH((conv_mfma_kernel<2, 2, 1, 1>), grid, dim3(256), smem, stream_, p); break;
+    default:    PE_LAUNCH((conv_mfma_kernel<2, 2, 2, 1>), grid, dim3(256), smem, stream_, p); break;
+  }
+}
+
+void Engine::layer_norm(int mode, View in, View res, View out, const float* g, const float* b,
+                        const float* dw_w, const float* dw_b, int dw_k, int dw_dil, int C, const int* lens,
+                        int Lmax) {
+  LnP p;
+  p.in = in.p; p.i_bs = in.bs; p.i_cs = in.cs;
+  p.res = res.p; p.r_bs = res.bs; p.r_cs = res.cs;
+  p.out = out.p; p.o_bs = out.bs; p.o_cs = out.cs;
+  p.gamma = g; p.beta = b;
+  p.dw_w = dw_w; p.dw_b = dw_b; p.dw_k = dw_k; p.dw_dil = dw_dil;
+  p.lens = lens; p.C = C;
+  dim3 grid((Lmax + 31) / 32, B_);
+  if (mode == 0) PE_LAUNCH(ln_kernel<0>, grid, dim3(256), 0, stream_, p);
+  else if (mode == 1) PE_LAUNCH(ln_kernel<1>, grid, dim3(256), 0, stream_, p);
+  else PE_LAUNCH(ln_kernel<2>, grid, dim3(256), 0, stream_, p);
+}
+
+// DDSConv.forward (modules.py:117-129) in place on x; tmp1/tmp2 are [B][H][Ts] scratch.
+void Engine::dds(const DdsW& d, View x, View t1, View t2) {
+  int dil = 1;
+  for (size_t i = 0; i < d.c1x1.size(); ++i) {
+    layer_norm(2, x, View{nullptr, 0, 0}, t1, d.g1[i], d.b1[i], d.dw_w[i], d.dw_b[i], ksz_, dil, H_, d_tlens_, Tmax_);
+    conv(d.c1x1[i], t1, t2, d_tlens_, 1, Tmax_, EPI_STORE);
+    layer_norm(1, t2, x, x, d.g2[i], d.b2[i], nullptr, nullptr, 0, 0, H_, d_tlens_, Tmax_);
+    dil *= ksz_;
+  }
+}
+
+void Engine::set_profile(bool on) { prof_on_ = on; }
+void Engine::reset_profile() {
+  for (auto& r : prof_) { r.ms = 0; r.flops = 0; r.launches = 0; }
+}
+void Engine::prof_begin() {
+  if (prof_on_) PE_HIP(hipEventRecord(ev0_, stream_));
+}
+void Engine::prof_end(int row, double flops) {
+  if (!prof_on_) return;
+  PE_HIP(hipEventRecord(ev1_, stream_));
+  PE_HIP(hipEventSynchronize(ev1_));
+  float ms = 0;
+  PE_HIP(hipEventElapsedTime(&ms, ev0_, ev1_));
+  prof_[row].ms += ms;
+  prof_[row].flops += flops;
+  prof_[row].launches += 1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// the synthesis call
+// ------------------------------------------------------------------------------------------------
+
+void Engine::upload(const int64_t* ids, const int64_t* offsets, int B, const float scales[3],
+                    const int64_t* sids, const NoiseIn* noise) {
+  if (B <= 0 || B > 4096) throw std::runtime_error("batch size must be in [1, 4096]");
+  PE_HIP(hipSetDevice(device_));
+  B_ = B;
+  id_off_.assign(offsets, offsets + B + 1);
+  tlens_h_.resize(B);
+  int Tmax = 0;
+  for (int b = 0; b < B; ++b) {
+    const int64_t T = offsets[b + 1] - offsets[b];
+    if (T <= 0) throw std::runtime_error("empty phoneme id sequence");
+    if (T > 8192) throw std::runtime_error("phoneme id sequence longer than 8192");
+    tlens_h_[b] = (int)T;
+    Tmax = std::max(Tmax, (int)T);
+  }
+  Tmax_ = Tmax;
+  ensure_stage_a(B, Tmax);
+  const int Ts = Ts_;
+  std::vector<int> idbuf((size_t)B * Ts, 0);
+  for (int b = 0; b < B; ++b)
+    for (int t = 0; t < tlens_h_[b]; ++t) {
+      const int64_t id = ids[offsets[b] + t];
+      if (id < 0 || id >= arch_[A_NVOCAB])
+        throw std::runtime_error("phoneme id " + std::to_string(id) + " outside [0, num_symbols)");
+      idbuf[(size_t)b * Ts + t] = (int)id;
+    }
+  PE_HIP(hipMemcpyAsync(d_ids_, idbuf.data(), idbuf.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
+  PE_HIP(hipMemcpyAsync(d_tlens_, tlens_h_.data(), B * sizeof(int), hipMemcpyHostToDevice, stream_));
+  std::vector<int> sidbuf(B, 0);
+  if (nspk_ > 1)
+    for (int b = 0; b < B; ++b) {
+      const int64_t s = sids ? sids[b] : 0;
+      if (s < 0 || s >= nspk_) throw std::runtime_error("speaker id outside [0, num_speakers)");
+      sidbuf[b] = (int)s;
+    }
+  PE_HIP(hipMemcpyAsync(d_sids_, sidbuf.data(), B * sizeof(int), hipMemcpyHostToDevice, stream_));
+  scales_[0] = scales[0]; scales_[1] = scales[1]; scales_[2] = scales[2];
+  have_noise_w_ = noise && noise->noise_w;
+  have_noise_z_ = noise && noise->noise_z;
+  h_noise_z_ = have_noise_z_ ? noise->noise_z : nullptr;
+  h_noise_z_stride_ = have_noise_z_ ? noise->z_stride : 0;
+  if (have_noise_w_) {
+    if (noise->w_stride < Tmax) throw std::runtime_error("noise_w stride shorter than the longest utterance");
+    std::vector<float> nb((size_t)B * 2 * Ts, 0.f);
+    for (int b = 0; b < B; ++b)
+      for (int c = 0; c < 2; ++c)
+        memcpy(&nb[((size_t)b * 2 + c) * Ts], noise->noise_w + ((size_t)b * 2 + c) * noise->w_stride,
+               tlens_h_[b] * sizeof(float));
+    PE_HIP(hipMemcpyAsync(noise_w_, nb.data(), nb.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
+  }
+  PE_HIP(hipStreamSynchronize(stream_));   // host staging buffers go out of scope
+  ++call_;
+}
+
+void Engine::run() {
+  PE_HIP(hipSetDevice(device_));
+  const int B = B_, Ts = Ts_, T = Tmax_;
+  const long bsH = (long)H_ * Ts;
+  auto V = [&](float* p, int ch) { return View{p, (long)ch * Ts, Ts}; };
+  const View x = V(x_, H_), y = V(y_, H_), qkv = V(qkv_, 3 * H_), att = V(att_, H_), ffh = V(ffh_, FC_),
+             stats = V(stats_, 2 * C_), xg = V(xg_, H_), dh = V(dh_, H_), dy = V(dy_, H_), dy2 = V(dy2_, H_),
+             hproj = V(hproj_, 32);
+  const View none{nullptr, 0, 0};
+  (void)bsH;
+  double tsum = 0;
+  for (int b = 0; b < B; ++b) tsum += tlens_h_[b];
+
+  // ================= speaker conditioning vectors
+  const float *cb_dp = nullptr, *cb_dec = nullptr;
+  if (nspk_ > 1) {
+    auto cond = [&](const CondW& c, int off) {
+      PE_LAUNCH(cond_kernel, dim3((c.rows + 127) / 128, B), dim3(128), 0, stream_, emb_g_, gin_, d_sids_, c.w, c.b,
+                c.rows, cond_ + off, cond_bs_);
+    };
+    cond(cond_dp_, cond_off_dp_);
+    for (size_t i = 0; i < cond_wn_.size(); ++i) cond(cond_wn_[i], cond_off_wn_[i]);
+    cond(cond_dec_, cond_off_dec_);
+    cb_dp = cond_ + cond_off_dp_;
+    cb_dec = cond_ + cond_off_dec_;
+  }
+
+  // ================= text encoder (models.py:198-209, attentions.py:60-74)
+  prof_begin();
+  double fl = 0;
+  PE_LAUNCH(embed_kernel, dim3((T + 63) / 64, B), dim3(64), 0, stream_, d_ids_, Ts, d_tlens_, emb_, H_,
+            std::sqrt((float)H_), x_, (long)H_ * Ts, Ts);
+  for (auto& e : enc_) {
+    conv(e.qkv, x, qkv, d_tlens_, 1, T, EPI_STORE);
+    AttnP ap;
+    ap.qkv = qkv_; ap.q_bs = (long)3 * H_ * Ts; ap.q_cs = Ts;
+    ap.relk = e.relk; ap.relv = e.relv;
+    ap.out = att_; ap.o_bs = (long)H_ * Ts; ap.o_cs = Ts;
+    ap.lens = d_tlens_; ap.H = H_; ap.dk = dk_; ap.window = window_; ap.Ts = Ts;
+    ap.qscale = 1.0f / std::sqrt((float)dk_);
+    const size_t smem = ((size_t)dk_ * ATT_QB + (size_t)ATT_QB * Ts + (size_t)dk_ * (ATT_JB + 1)) * sizeof(float);
+    if (smem > 64 * 1024) throw std::runtime_error("utterance too long for the attention score tile");
+    PE_LAUNCH(attn_kernel, dim3((T + ATT_QB - 1) / ATT_QB, nh_, B), dim3(256), smem, stream_, ap);
+    conv(e.o, att, y, d_tlens_, 1, T, EPI_RESADD, 1.f, ACT_NONE, x);
+    layer_norm(0, y, none, x, e.g1, e.b1, nullptr, nullptr, 0, 0, H_, d_tlens_, T);
+    conv(e.f1, x, ffh, d_tlens_, 1, T, EPI_STORE, 1.f, ACT_RELU);
+    conv(e.f2, ffh, y, d_tlens_, 1, T, EPI_RESADD, 1.f, ACT_NONE, x);
+    layer_norm(0, y, none, x, e.g2, e.b2, nullptr, nullptr, 0, 0, H_, d_tlens_, T);
+    fl += 2.0 * tsum * (e.qkv.macs_per_col + e.o.macs_per_col + e.f1.macs_per_col + e.f2.macs_per_col);
+    for (int b = 0; b < B; ++b) fl += 2.0 * 2.0 * (double)tlens_h_[b] * tlens_h_[b] * H_;
+  }
+  conv(enc_proj_, x, stats, d_tlens_, 1, T, EPI_STORE);
+  fl += 2.0 * tsum * enc_proj_.macs_per_col;
+  prof_end(0, fl);
+
+  // ================= stochastic duration predictor, reverse (models.py:63-71,108-117)
+  prof_begin();
+  fl = 0;
+  conv(dp_pre_, x, dh, d_tlens_, 1, T, EPI_STORE, 1.f, ACT_NONE, none, none, 0, 1.f, cb_dp, cond_bs_);
+  dds(dp_dds_, dh, dy, dy2);
+  conv(dp_proj_, dh, xg, d_tlens_, 1, T, EPI_STORE);
+  fl += 2.0 * tsum * (2 + arch_[A_DDSLAYERS]) * dp_pre_.macs_per_col;
+  // z = noise * noise_scale_w   [B][2][Ts]
+  if (!have_noise_w_) {
+    const long n = (long)B * 2 * Ts;
+    PE_LAUNCH(randn_kernel, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, stream_, noise_w_, n, seed_,
+              call_ * 2ull);
+  }
+  PE_HIP(hipMemcpyAsync(z2_, noise_w_, (size_t)B * 2 * Ts * sizeof(float), hipMemcpyDeviceToDevice, stream_));
+  {
+    const long n = (long)B * 2 * Ts;
+    PE_LAUNCH(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream_, z2_, n, scales_[2]);
+  }
+  // Flip is folded into which physical channel is x0 (conditioning) and which is x1 (transformed):
+  // logical = physical when an even number of flips has been applied.
+  int flips = 0;
+  for (auto& cf : cflows_) {
+    ++flips;
+    const int c0 = (flips & 1) ? 1 : 0;     // physical channel holding logical x0
+    const int c1 = 1 - c0;
+    PE_LAUNCH(cf_pre_kernel, dim3((T + 63) / 64, H_, B), dim3(64), 0, stream_, z2_ + (long)c0 * Ts, (long)2 * Ts,
+              cf.pre_w, cf.pre_b, xg_, (long)H_ * Ts, Ts, dh_, (long)H_ * Ts, Ts, d_tlens_, H_);
+    dds(cf.dds, dh, dy, dy2);
+    conv(cf.proj, dh, hproj, d_tlens_, 1, T, EPI_STORE);
+    PE_LAUNCH(spline_inverse_kernel, dim3((T + 63) / 64, B), dim3(64), 0, stream_, hproj_, (long)32 * Ts, Ts,
+              z2_ + (long)c1 * Ts, (long)2 * Ts, d_tlens_, 1.0f / std::sqrt((float)H_));
+    fl += 2.0 * tsum * (arch_[A_DDSLAYERS] * dp_pre_.macs_per_col + cf.proj.macs_per_col);
+  }
+  ++flips;   // the Flip before ElementwiseAffine
+  {
+    const int c0 = (flips & 1) ? 1 : 0;     // physical channel holding logical channel 0 = logw
+    PE_LAUNCH(duration_kernel, dim3(B), dim3(256), 0, stream_, z2_ + (long)c0 * Ts, (long)2 * Ts, ea_m0_, ea_es0_,
+              scales_[1], d_tlens_, d_dur_, d_cum_, Ts, d_frames_, logw_);
+  }
+  PE_HIP(hipMemcpyAsync(h_frames_, d_frames_, B * sizeof(int), hipMemcpyDeviceToHost, stream_));
+  PE_HIP(hipStreamSynchronize(stream_));      // the only data-dependent shape: F
+  prof_end(1, fl);
+  frames_h_.assign(h_frames_, h_frames_ + B);
+  int Fmax = 1;
+  double fsum = 0;
+  for (int b = 0; b < B; ++b) { Fmax = std::max(Fmax, frames_h_[b]); fsum += frames_h_[b]; }
+  Fmax_ = Fmax;
+  ensure_stage_b(Fmax);
+  const int Fs = Fs_;
+
+  // ================= length regulator + prior noise + coupling flow (models.py:705-719)
+  prof_begin();
+  fl = 0;
+  if (have_noise_z_) {
+    // rows of the caller's [B][C][z_stride] buffer -> [B][C][Fs]
+    if (h_noise_z_stride_ < Fmax) throw std::runtime_error("noise_z stride shorter than the frame count");
+    for (int b = 0; b < B; ++b)
+      for (int c = 0; c < C_; ++c)
+        PE_HIP(hipMemcpyAsync(noise_z_ + ((size_t)b * C_ + c) * Fs,
+                              h_noise_z_ + ((size_t)b * C_ + c) * h_noise_z_stride_,
+                              frames_h_[b] * sizeof(float), hipMemcpyHostToDevice, stream_));
+  } else {
+    const long n = (long)B * C_ * Fs;
+    PE_LAUNCH(randn_kernel, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, stream_, noise_z_, n, seed_,
+              call_ * 2ull + 1ull);
+  }
+  {
+    RegP rp;
+    rp.stats = stats_; rp.s_bs = (long)2 * C_ * Ts; rp.s_cs = Ts;
+    rp.cum = d_cum_; rp.d_bs = Ts; rp.tlens = d_tlens_; rp.frames = d_frames_;
+    rp.noise = noise_z_; rp.n_bs = (long)C_ * Fs; rp.n_cs = Fs;
+    rp.noise_scale = scales_[0];
+    rp.out = zp_; rp.o_bs = (long)C_ * Fs; rp.o_cs = Fs; rp.C = C_;
+    PE_LAUNCH(regulate_kernel, dim3((Fmax + 63) / 64, B), dim3(64), 0, stream_, rp);
+  }
+  auto VF = [&](float* p, int ch) { return View{p, (long)ch * Fs, Fs}; };
+  const View fh = VF(fh_, H_), facts = VF(facts_, H_), fskip = VF(fskip_, H_);
+  const int half = C_ / 2;
+  for (size_t ri = 0; ri < rcls_.size(); ++ri) {
+    Rcl& r = rcls_[ri];
+    const View x0{zp_ + (long)r.in_off * Fs, (long)C_ * Fs, Fs};
+    const View x1{zp_ + (long)r.out_off * Fs, (long)C_ * Fs, Fs};
+    conv(r.pre, x0, fh, d_frames_, 1, Fmax, EPI_STORE);
+    const int nl = (int)r.in.size();
+    for (int i = 0; i < nl; ++i) {
+      const float* b2 = nspk_ > 1 ? cond_ + cond_off_wn_[ri] + (long)i * 2 * H_ : nullptr;
+      conv(r.in[i], fh, facts, d_frames_, 1, Fmax, EPI_GATE, 1.f, ACT_NONE, none, none, 0, 1.f, b2, cond_bs_);
+      conv(r.rs[i], facts, fh, d_frames_, 1, Fmax, EPI_WNRS, 1.f, ACT_NONE, none, fskip, i == 0 ? 1 : 0);
+      fl += 2.0 * fsum * (r.in[i].macs_per_col + r.rs[i].macs_per_col);
+    }
+    conv(r.post, fskip, x1, d_frames_, 1, Fmax, EPI_SUBFROM);
+    fl += 2.0 * fsum * (r.pre.macs_per_col + r.post.macs_per_col);
+    (void)half;
+  }
+  prof_end(2, fl);
+
+  // ================= HiFiGAN generator (models.py:348-368)
+  prof_begin();
+  fl = 0;
+  {
+    View cur{hb_[0], (long)U_ * Fs, Fs};
+    conv(dec_pre_, View{zp_, (long)C_ * Fs, Fs}, cur, d_frames_, 1, Fmax, EPI_STORE, 1.f, ACT_NONE, none, none, 0, 1.f,
+         cb_dec, cond_bs_);
+    fl += 2.0 * fsum * dec_pre_.macs_per_col;
+    int mult = 1;
+    int cur_buf = 0;
+    const int nk = arch_[A_NRB];
+    const float inv_nk = 1.0f / (float)nk;
+    for (auto& st : ups_) {
+      // pick the five working buffers for this stage: u, ta, tb, tc, xs (all != cur)
+      int ids[5], n = 0;
+      for (int i = 0; i < 5 && n < 4; ++i)
+        if (i != cur_buf) ids[n++] = i;
+      const int Lin = mult;            // length multiplier of the input
+      mult *= st.rate;
+      const long Ls = (long)Fs * mult;
+      auto VS = [&](int bi) { return View{hb_[bi], (long)st.ch * Ls, (int)Ls}; };
+      const View u = VS(ids[0]), ta = VS(ids[1]), tb = VS(ids[2]), tc = VS(ids[3]);
+      // leaky_relu(0.1) -> ConvTranspose1d
+      conv(st.up, cur, u, d_frames_, Lin, Fmax * Lin, EPI_CONVT, 0.1f);
+      fl += 2.0 * fsum * Lin * st.up.macs_per_col;
+      // xs accumulates into the buffer that held the stage input (free once the up-conv is done)
+      const View xs{hb_[cur_buf], (long)st.ch * Ls, (int)Ls};
+      const int Lmax = Fmax * mult;
+      for (int j = 0; j < nk; ++j) {
+        const int accmode = nk == 1 ? 3 : (j == 0 ? 0 : (j == nk - 1 ? 2 : 1));
+        auto& cv = st.rb[j];
+        if (arch_[A_RESBLOCK] == 1) {
+          // ResBlock1 (modules.py:301-314): x = x + c2(lrelu(c1(lrelu(x)))) three times
+          View xin = u;
+          const int np = (int)cv.size() / 2;
+          for (int d = 0; d < np; ++d) {
+            conv(cv[2 * d], xin, tb, d_frames_, mult, Lmax, EPI_STORE, 0.1f);
+            if (d < np - 1) {
+              const View nxt = (d & 1) ? tc : ta;
+              conv(cv[2 * d + 1], tb, nxt, d_frames_, mult, Lmax, EPI_RESADD, 0.1f, ACT_NONE, xin);
+              xin = nxt;
+            } else {
+              conv(cv[2 * d + 1], tb, xs, d_frames_, mult, Lmax, EPI_ACCUM, 0.1f, ACT_NONE, xin, none, accmode, inv_nk);
+            }
+            fl += 2.0 * fsum * mult * (cv[2 * d].macs_per_col + cv[2 * d + 1].macs_per_col);
+          }
+        } else {
+          // ResBlock2 (modules.py:355-364): x = x + c(lrelu(x)) for each dilation
+          View xin = u;
+          const int nc = (int)cv.size();
+          for (int d = 0; d < nc; ++d) {
+            if (d < nc - 1) {
+              const View nxt = (d & 1) ? tc : ta;
+              conv(cv[d], xin, nxt, d_frames_, mult, Lmax, EPI_RESADD, 0.1f, ACT_NONE, xin);
+              xin = nxt;
+            } else {
+              conv(cv[d], xin, xs, d_frames_, mult, Lmax, EPI_ACCUM, 0.1f, ACT_NONE, xin, none, accmode, inv_nk);
+            }
+            fl += 2.0 * fsum * mult * cv[d].macs_per_col;
+          }
+        }
+      }
+      cur = xs;      // same buffer index cur_buf, new shape
+    }
+    prof_end(3, fl);
+
+    // ================= conv_post + tanh + peak, int16 (models.py:364-366; piper.cpp:410-431)
+    prof_begin();
+    PE_HIP(hipMemsetAsync(absmax_, 0, B * sizeof(unsigned), stream_));
+    const int K = 7, Lmax = Fmax * hop_;
+    const size_t smem = ((size_t)post_cin_ * K + (size_t)post_cin_ * (256 + K - 1)) * sizeof(float);
+    PE_LAUNCH(conv_post_kernel, dim3((Lmax + 255) / 256, B), dim3(256), smem, stream_, cur.p, cur.bs, cur.cs, post_w_,
+              post_cin_, K, 0.01f, d_frames_, hop_, audio_, Ss_, absmax_);
+    PE_LAUNCH(pcm16_kernel, dim3((Lmax + 255) / 256, B), dim3(256), 0, stream_, audio_, Ss_, absmax_, d_frames_, hop_,
+              pcm_, Ss_);
+    prof_end(4, 2.0 * fsum * hop_ * post_cin_ * K);
+  }
+  sample_off_.assign(B + 1, 0);
+  for (int b = 0; b < B; ++b) sample_off_[b + 1] = sample_off_[b] + (int64_t)frames_h_[b] * hop_;
+}
+
+void Engine::download(bool want_audio, bool want_pcm) {
+  const size_t total = (size_t)sample_off_[B_];
+  if (want_audio) {
+    if (total > h_audio_cap_) {
+      if (h_audio_) PE_HIP(hipHostFree(h_audio_));
+      h_audio_cap_ = total + total / 2;
+      PE_HIP(hipHostMalloc((void**)&h_audio_, h_audio_cap_ * sizeof(float)));
+    }
+    for (int b = 0; b < B_; ++b)
+      PE_HIP(hipMemcpyAsync(h_audio_ + sample_off_[b], audio_ + (size_t)b * Ss_,
+                            (size_t)(sample_off_[b + 1] - sample_off_[b]) * sizeof(float), hipMemcpyDeviceToHost,
+                            stream_));
+  }
+  if (want_pcm) {
+    if (total > h_pcm_cap_) {
+      if (h_pcm_) PE_HIP(hipHostFree(h_pcm_));
+      h_pcm_cap_ = total + total / 2;
+      PE_HIP(hipHostMalloc((void**)&h_pcm_, h_pcm_cap_ * sizeof(int16_t)));
+    }
+    for (int b = 0; b < B_; ++b)
+      PE_HIP(hipMemcpyAsync(h_pcm_ + sample_off_[b], pcm_ + (size_t)b * Ss_,
+                            (size_t)(sample_off_[b + 1] - sample_off_[b]) * sizeof(int16_t), hipMemcpyDeviceToHost,
+                            stream_));
+  }
+  PE_HIP(hipStreamSynchronize(stream_));
+}
+
+const std::vector<int32_t>& Engine::durations_host() {
+  std::vector<int> tmp((size_t)B_ * Ts_);
+  PE_HIP(hipMemcpy(tmp.data(), d_dur_, tmp.size() * sizeof(int), hipMemcpyDeviceToHost));
+  dur_h_.clear();
+  for (int b = 0; b < B_; ++b)
+    for (int t = 0; t < tlens_h_[b]; ++t) dur_h_.push_back(tmp[(size_t)b * Ts_ + t]);
+  return dur_h_;
+}
+
+// Per-stage tensors for parity debugging (tests only): name in {x_enc, stats, logw, z_p, audio}.
+void Engine::debug_tensor(const std::string& name, int b, std::vector<float>& out, int* rows, int* cols) {
+  PE_HIP(hipStreamSynchronize(stream_));
+  const float* src = nullptr;
+  int R = 0, Cn = 0;
+  long stride = 0;
+  if (name == "x_enc") { src = x_ + (size_t)b * H_ * Ts_; R = H_; Cn = tlens_h_[b]; stride = Ts_; }
+  else if (name == "stats") { src = stats_ + (size_t)b * 2 * C_ * Ts_; R = 2 * C_; Cn = tlens_h_[b]; stride = Ts_; }
+  else if (name == "xg") { src = xg_ + (size_t)b * H_ * Ts_; R = H_; Cn = tlens_h_[b]; stride = Ts_; }
+  else if (name == "logw") { src = logw_ + (size_t)b * Ts_; R = 1; Cn = tlens_h_[b]; stride = Ts_; }
+  else if (name == "z") { src = zp_ + (size_t)b * C_ * Fs_; R = C_; Cn = frames_h_[b]; stride = Fs_; }
+  else if (name == "audio") { src = audio_ + (size_t)b * Ss_; R = 1; Cn = frames_h_[b] * hop_; stride = Ss_; }
+  else throw std::runtime_error("unknown debug tensor " + name);
+  out.resize((size_t)R * Cn);
+  for (int r = 0; r < R; ++r)
+    PE_HIP(hipMemcpy(out.data() + (size_t)r * Cn, src + (size_t)r * stride, Cn * sizeof(float), hipMemcpyDeviceToHost));
+  *rows = R;
+  *cols = Cn;
+}
+
+}  // namespace pe

@@ -1,0 +1,189 @@
+// Host engine: owns the packed voice weights in HBM, the workspaces, one HIP stream, and issues the
+// kernel sequence that replaces Ort::Session::Run() inside piper::synthesize
+// (reference src/cpp/piper.cpp:386-388).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "pe_rt.h"
+#include "weights.h"
+
+namespace pe {
+
+struct PackedConv {
+  float* wp = nullptr;      // device, packed for conv_mfma_kernel
+  float* bias = nullptr;    // device or null
+  int rows = 0;             // GEMM rows (real)
+  int mtiles = 0;           // packed 32-row tiles (padded to the block tile)
+  int Cin = 0, nchunks = 0, ntaps = 1, dil = 1, padl = 0;
+  int cfg = 0;              // tile configuration id
+  bool gate = false;
+  int split = 0;
+  int up = 0, padT = 0;     // conv-transpose
+  double macs_per_col = 0;  // algorithmic MACs per output column (for roofline accounting)
+};
+
+struct DdsW {               // one DDSConv (modules.py:81-129)
+  std::vector<float*> dw_w, dw_b, g1, b1, g2, b2;
+  std::vector<PackedConv> c1x1;
+};
+
+struct ProfileRow {
+  const char* name;
+  double ms = 0;
+  double flops = 0;
+  long launches = 0;
+};
+
+struct NoiseIn {            // optional injected N(0,1) draws (parity tests); host pointers
+  const float* noise_w = nullptr;  // [B][2][w_stride]
+  int64_t w_stride = 0;
+  const float* noise_z = nullptr;  // [B][inter][z_stride]
+  int64_t z_stride = 0;
+};
+
+class Engine {
+ public:
+  Engine(const WeightSet& ws, int device);
+  ~Engine();
+
+  // Phase 1: copy inputs to HBM. ids: concatenated phoneme ids, offsets[B+1].
+  void upload(const int64_t* ids, const int64_t* offsets, int B, const float scales[3],
+              const int64_t* sids, const NoiseIn* noise);
+  // Phase 2: the whole device pipeline (one host read-back of B frame counts in the middle).
+  void run();
+  // Phase 3: results to host (pinned buffers owned by the engine, valid until the next upload()).
+  void download(bool want_audio, bool want_pcm);
+
+  int batch() const { return B_; }
+  const std::vector<int64_t>& sample_offsets() const { return sample_off_; }
+  const float* audio_host() const { return h_audio_; }
+  const int16_t* pcm_host() const { return h_pcm_; }
+  const std::vector<int32_t>& durations_host();   // concatenated per id, same offsets as ids
+  const std::vector<int32_t>& frames_host() const { return frames_h_; }
+  void debug_tensor(const std::string& name, int b, std::vector<float>& out, int* rows, int* cols);
+
+  void set_seed(uint64_t s) { seed_ = s; }
+  void set_profile(bool on);
+  const std::vector<ProfileRow>& profile() const { return prof_; }
+  void reset_profile();
+  hipStream_t stream() const { return stream_; }
+  const int32_t* arch() const { return arch_; }
+  int sample_rate() const { return arch_[A_SR]; }
+  int hop() const { return hop_; }
+  size_t weight_bytes() const { return weight_bytes_; }
+
+ private:
+  // ---- setup
+  float* dev_copy(const std::vector<float>& v);
+  float* dev_tensor(const WeightSet& ws, const std::string& name);
+  PackedConv pack_conv(const WeightSet& ws, const std::string& wname, const std::string& bname, int dil,
+                       int padl_override, bool gate, int in_rev, int out_rev);
+  PackedConv pack_qkv(const WeightSet& ws, const std::string& prefix);
+  PackedConv pack_convT(const WeightSet& ws, const std::string& prefix, int stride);
+  PackedConv pack_matrix(const std::vector<float>& W, int rows, int Cin, int ntaps,
+                         const std::vector<float>* bias, int dil, int padl, bool gate, int split);
+  DdsW load_dds(const WeightSet& ws, const std::string& prefix);
+  void ensure_stage_a(int B, int Tmax);
+  void ensure_stage_b(int Fmax);
+
+  // ---- launches
+  struct View { float* p; long bs; int cs; };
+  void conv(const PackedConv& pc, View x, View out, const int* lens, int len_mul, int Lmax, int epi,
+            float in_slope = 1.f, int act = 0, View res = View{nullptr, 0, 0},
+            View out2 = View{nullptr, 0, 0}, int mode = 0, float alpha = 1.f, const float* bias2 = nullptr,
+            int bias2_bs = 0);
+  void layer_norm(int mode, View in, View res, View out, const float* g, const float* b, const float* dw_w,
+                  const float* dw_b, int dw_k, int dw_dil, int C, const int* lens, int Lmax);
+  void dds(const DdsW& d, View x, View tmp1, View tmp2);
+  void prof_begin();
+  void prof_end(int row, double flops);
+
+  int32_t arch_[ARCH_INTS];
+  int device_ = 0;
+  hipStream_t stream_ = nullptr;
+  int H_, C_, FC_, nh_, dk_, nlayers_, ksz_, window_, hop_, U_;
+  std::vector<void*> owned_;          // device allocations to free
+  size_t weight_bytes_ = 0;
+
+  // weights
+  float* emb_ = nullptr;
+  float* emb_g_ = nullptr;
+  struct EncLayer {
+    PackedConv qkv, o, f1, f2;
+    float *relk, *relv, *g1, *b1, *g2, *b2;
+  };
+  std::vector<EncLayer> enc_;
+  PackedConv enc_proj_;
+  PackedConv dp_pre_, dp_proj_;
+  DdsW dp_dds_;
+  struct CFlow {
+    float *pre_w, *pre_b;
+    DdsW dds;
+    PackedConv proj;
+  };
+  std::vector<CFlow> cflows_;
+  float ea_m0_ = 0, ea_es0_ = 1;
+  struct Rcl {
+    PackedConv pre, post;
+    std::vector<PackedConv> in, rs;
+    int in_off, out_off;             // channel offsets of x0 / x1 in the physical (unflipped) layout
+  };
+  std::vector<Rcl> rcls_;            // in execution order
+  PackedConv dec_pre_;
+  struct UpStage {
+    PackedConv up;
+    int rate, ch;
+    std::vector<std::vector<PackedConv>> rb;   // [resblock][conv] (ResBlock1: c1_0,c2_0,c1_1,...)
+  };
+  std::vector<UpStage> ups_;
+  float* post_w_ = nullptr;
+  int post_cin_ = 0;
+  // speaker conditioning (all per-utterance bias vectors, see cond_kernel)
+  struct CondW { float* w; float* b; int rows; };
+  CondW cond_dp_{nullptr, nullptr, 0}, cond_dec_{nullptr, nullptr, 0};
+  std::vector<CondW> cond_wn_;
+  int gin_ = 0, nspk_ = 1;
+
+  // per-call state
+  int B_ = 0, Tmax_ = 0, Ts_ = 0, Fmax_ = 0, Fs_ = 0;
+  float scales_[3] = {0.667f, 1.0f, 0.8f};
+  bool have_noise_w_ = false, have_noise_z_ = false;
+  std::vector<int64_t> id_off_;
+  std::vector<int32_t> tlens_h_, frames_h_, dur_h_;
+  std::vector<int64_t> sample_off_;
+  uint64_t seed_ = 1234, call_ = 0;
+  const float* h_noise_z_ = nullptr;
+  int64_t h_noise_z_stride_ = 0;
+
+  // workspaces
+  size_t capA_B_ = 0, capA_T_ = 0, capB_F_ = 0;
+  char* wsA_ = nullptr; size_t wsA_bytes_ = 0;
+  char* wsB_ = nullptr; size_t wsB_bytes_ = 0;
+  int *d_ids_ = nullptr, *d_tlens_ = nullptr, *d_sids_ = nullptr, *d_dur_ = nullptr, *d_cum_ = nullptr,
+      *d_frames_ = nullptr;
+  float *x_ = nullptr, *y_ = nullptr, *qkv_ = nullptr, *att_ = nullptr, *ffh_ = nullptr, *stats_ = nullptr,
+        *xg_ = nullptr, *dh_ = nullptr, *dy_ = nullptr, *dy2_ = nullptr, *hproj_ = nullptr, *z2_ = nullptr,
+        *logw_ = nullptr, *noise_w_ = nullptr, *cond_ = nullptr;
+  int cond_bs_ = 0;
+  std::vector<int> cond_off_wn_;
+  int cond_off_dp_ = 0, cond_off_dec_ = 0;
+  float *zp_ = nullptr, *fh_ = nullptr, *facts_ = nullptr, *fskip_ = nullptr, *noise_z_ = nullptr;
+  float* hb_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  float* audio_ = nullptr;
+  int16_t* pcm_ = nullptr;
+  unsigned* absmax_ = nullptr;
+  long Ss_ = 0;
+  // host pinned
+  float* h_audio_ = nullptr; size_t h_audio_cap_ = 0;
+  int16_t* h_pcm_ = nullptr; size_t h_pcm_cap_ = 0;
+  int* h_frames_ = nullptr;
+
+  // profiling
+  bool prof_on_ = false;
+  std::vector<ProfileRow> prof_;
+  hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+};
+
+}  // namespace pe

@@ -1,0 +1,645 @@
+// Device kernels of the synthesis path (gfx950 / CDNA4). Activations are fp32, channels-first
+// [B][C][Lstride] with a per-utterance valid length: every kernel treats columns >= len[b] as
+// non-existent (read as zero, never written), which reproduces the reference's B=1 zero padding
+// and x_mask semantics for every utterance of a batch.
+//
+// Reference arithmetic each kernel implements is cited per kernel (paths relative to
+// /root/reference/src/python/piper_train/vits/).
+#pragma once
+#include "pe_rt.h"
+
+namespace pe {
+
+static constexpr int KC = 32;           // input channels staged per K-chunk of the conv GEMM
+
+enum Epi { EPI_STORE = 0, EPI_RESADD = 1, EPI_GATE = 2, EPI_WNRS = 3, EPI_SUBFROM = 4,
+           EPI_ACCUM = 5, EPI_CONVT = 6 };
+enum Act { ACT_NONE = 0, ACT_RELU = 1 };
+
+struct ConvP {
+  const float* x; long x_bs; int x_cs;          // input  x[b][ci][t]
+  const float* wp;                              // packed weights (engine.cpp: pack_conv)
+  const float* bias;                            // per output channel or null
+  const float* bias2; int bias2_bs;             // per-utterance extra bias (speaker cond) or null
+  float* out; long o_bs; int o_cs;
+  const float* res; long r_bs; int r_cs;        // residual input (may alias out)
+  float* out2; long o2_bs; int o2_cs;           // second output (WN skip accumulator)
+  const int* lens; int len_mul;                 // valid input length = lens[b]*len_mul
+  int Cin, rows;                                // real input channels; GEMM rows (Cout, or Cout*up)
+  int nchunks;                                  // ceil(Cin/KC)
+  int ntaps, dil, padl;                         // tap k reads x[t + k*dil - padl]
+  int xhalo;                                    // (ntaps-1)*dil
+  float in_slope;                               // leaky-relu slope applied to x while staging (1 = none)
+  int epi, act;
+  int split;                                    // GATE: H ; WNRS: rows < split go to h, rest to skip
+  int up, padT;                                 // CONVT: stride and padding
+  int mode;                                     // ACCUM: 0 first,1 middle,2 last,3 only ; WNRS: 1 = first layer
+  float alpha;                                  // ACCUM last/only: scale
+};
+
+// Conv1d / ConvTranspose1d as an implicit GEMM on the f32 matrix cores.
+//   D[row][col] = sum_{ci,k} W[row][ci][k] * act(x[ci][col + k*dil - padl])
+// rows -> MFMA M (weights are the A operand, read pre-packed straight from global/L2, one
+// coalesced dword per lane per MFMA), cols (time) -> MFMA N (activations are the B operand, staged
+// once per K-chunk through LDS with the dilation halo, so each tap is just a shifted LDS read).
+// v_mfma_f32_32x32x2_f32 keeps the reference's fp32 arithmetic exactly (k-ordered fmaf chain).
+// Covers: every Conv1d of attentions.py / modules.py / models.py with groups=1, and (EPI_CONVT)
+// the polyphase form of Generator.ups ConvTranspose1d (models.py:321-332) where k = 2*stride.
+template <int WM, int WN, int MT, int NT>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
+  constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+  static_assert(WM * WN == 4, "4 waves per block");
+  PE_DYN_SMEM(float, xs);
+  const int b = blockIdx.z;
+  const int L = p.lens[b] * p.len_mul;
+  const int ncols = (p.epi == EPI_CONVT) ? L + 1 : L;
+  const int n0 = blockIdx.x * BN;
+  if (n0 >= ncols) return;
+  const int m0 = blockIdx.y * BM;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wm = wv / WN, wn = wv % WN;
+  const int XW = BN + p.xhalo;
+  const int l31 = lane & 31, lhi = lane >> 5;
+
+  f32x16 acc[MT][NT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const float* xb = p.x + (long)b * p.x_bs;
+  const int tbase = n0 - p.padl;
+  const int mtile0 = m0 / 32 + wm * MT;
+  const float slope = p.in_slope;
+
+  for (int c = 0; c < p.nchunks; ++c) {
+    // ---- stage x[c*KC .. +KC)[tbase .. tbase+XW) into LDS (zero outside [0,L) and beyond Cin)
+    for (int r = wv; r < KC; r += 4) {
+      const int ci = c * KC + r;
+      const bool rowok = ci < p.Cin;
+      const float* xr = xb + (long)ci * p.x_cs;
+      for (int col = lane; col < XW; col += 64) {
+        const int t = tbase + col;
+        float v = 0.f;
+        if (rowok && t >= 0 && t < L) {
+          v = xr[t];
+          v = v > 0.f ? v : v * slope;
+        }
+        xs[r * XW + col] = v;
+      }
+    }
+    __syncthreads();
+    for (int tap = 0; tap < p.ntaps; ++tap) {
+      const int toff = tap * p.dil + wn * NT * 32 + l31;
+      const float* wt = p.wp + ((((long)mtile0 * p.nchunks + c) * p.ntaps + tap) * (KC / 2)) * 64 + lane;
+      const long wstride_mt = (long)p.nchunks * p.ntaps * (KC / 2) * 64;
+#pragma unroll 4
+      for (int kk = 0; kk < KC / 2; ++kk) {
+        float a[MT], bv[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) a[i] = wt[i * wstride_mt + kk * 64];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bv[j] = xs[(2 * kk + lhi) * XW + toff + j * 32];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[i][j] = pe_mfma_32x32x2(a[i], bv[j], acc[i][j]);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue
+  const float* bias2 = p.bias2 ? p.bias2 + (long)b * p.bias2_bs : nullptr;
+  float* ob = p.out + (long)b * p.o_bs;
+  if (p.epi == EPI_GATE) {
+    // commons.py:99-106 fused_add_tanh_sigmoid_multiply: rows come in (tanh tile, sigmoid tile) pairs
+#pragma unroll
+    for (int i = 0; i + 1 < MT; i += 2) {
+      const int q = (mtile0 + i) >> 1;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int col = n0 + (wn * NT + j) * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ch = q * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          if (ch < p.split && col < ncols) {
+            float ta = acc[i][j][r] + p.bias[ch];
+            float sa = acc[i + 1][j][r] + p.bias[p.split + ch];
+            if (bias2) { ta += bias2[ch]; sa += bias2[p.split + ch]; }
+            ob[(long)ch * p.o_cs + col] = tanhf(ta) * (1.f / (1.f + expf(-sa)));
+          }
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+      const int col = n0 + (wn * NT + j) * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (mtile0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (row >= p.rows || col >= ncols) continue;
+        float v = acc[i][j][r];
+        if (p.epi == EPI_CONVT) {
+          const int co = row / p.up, ph = row - co * p.up;
+          const int t = col * p.up + ph - p.padT;
+          if (t >= 0 && t < L * p.up) ob[(long)co * p.o_cs + t] = v + (p.bias ? p.bias[co] : 0.f);
+          continue;
+        }
+        if (p.bias) v += p.bias[row];
+        if (bias2) v += bias2[row];
+        switch (p.epi) {
+          case EPI_STORE:
+            if (p.act == ACT_RELU) v = v > 0.f ? v : 0.f;
+            ob[(long)row * p.o_cs + col] = v;
+            break;
+          case EPI_RESADD:
+            ob[(long)row * p.o_cs + col] = p.res[(long)b * p.r_bs + (long)row * p.r_cs + col] + v;
+            break;
+          case EPI_WNRS:   // modules.py:201-208
+            if (row < p.split) {
+              float* h = ob + (long)row * p.o_cs + col;
+              *h = *h + v;
+            } else {
+              float* s = p.out2 + (long)b * p.o2_bs + (long)(row - p.split) * p.o2_cs + col;
+              *s = (p.mode == 1) ? v : *s + v;
+            }
+            break;
+          case EPI_SUBFROM: {  // modules.py:464 x1 = (x1 - m) * mask
+            float* d = ob + (long)row * p.o_cs + col;
+            *d = *d - v;
+          } break;
+          case EPI_ACCUM: {    // models.py:356-363 MRF: xs (+)= resblock(x); x = xs / num_kernels
+            v += p.res[(long)b * p.r_bs + (long)row * p.r_cs + col];
+            float* d = ob + (long)row * p.o_cs + col;
+            if (p.mode == 0) *d = v;
+            else if (p.mode == 1) *d = *d + v;
+            else if (p.mode == 2) *d = (*d + v) * p.alpha;
+            else *d = v * p.alpha;
+          } break;
+          default: break;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Text-encoder embedding: x[b][h][t] = emb[id][h] * sqrt(H)  (models.py:199-200)
+__global__ void embed_kernel(const int* ids, int ids_bs, const int* lens, const float* emb, int H,
+                             float scale, float* out, long o_bs, int o_cs) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= lens[b]) return;
+  const int id = ids[b * ids_bs + t];
+  const float* e = emb + (long)id * H;
+  float* o = out + (long)b * o_bs + t;
+  for (int h = 0; h < H; ++h) o[(long)h * o_cs] = e[h] * scale;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Windowed relative-position multi-head self-attention (attentions.py:225-272, 292-348).
+// qkv: [B][3H][Ts] rows [0,H)=q, [H,2H)=k, [2H,3H)=v. The reference's pad/reshape "relative to
+// absolute" trick is evaluated directly as a band: logits[i][j] += q_i . rel_k[j-i+w] and
+// out_i += sum_r p[i][i+r] rel_v[r+w] for |r| <= w. Masked keys (>= len) get weight exactly 0, which is
+// what the reference's -1e4 fill yields in fp32.
+struct AttnP {
+  const float* qkv; long q_bs; int q_cs;
+  const float* relk; const float* relv;     // [2w+1][dk]
+  float* out; long o_bs; int o_cs;
+  const int* lens;
+  int H, dk, window, Ts;                    // Ts: score row stride (>= max len, multiple of 64)
+  float qscale;
+};
+static constexpr int ATT_QB = 16, ATT_JB = 64;
+
+__global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
+  PE_DYN_SMEM(float, sm);
+  const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * ATT_QB;
+  const int T = p.lens[b];
+  if (i0 >= T) return;
+  const int dk = p.dk, tid = threadIdx.x;
+  float* qs = sm;                          // [dk][QB]
+  float* S = qs + dk * ATT_QB;             // [QB][Ts]
+  float* kt = S + ATT_QB * p.Ts;           // [dk][JB+1]
+  const float* qb = p.qkv + (long)b * p.q_bs + (long)(h * dk) * p.q_cs;
+  const float* kb = qb + (long)p.H * p.q_cs;
+  const float* vb = kb + (long)p.H * p.q_cs;
+  for (int e = tid; e < dk * ATT_QB; e += 256) {
+    const int d = e / ATT_QB, i = e % ATT_QB;
+    qs[e] = (i0 + i < T) ? qb[(long)d * p.q_cs + i0 + i] * p.qscale : 0.f;
+  }
+  // ---- scores
+  const int si = tid >> 4, sj = tid & 15;
+  for (int j0 = 0; j0 < T; j0 += ATT_JB) {
+    __syncthreads();
+    for (int e = tid; e < dk * ATT_JB; e += 256) {
+      const int d = e / ATT_JB, jj = e % ATT_JB;
+      kt[d * (ATT_JB + 1) + jj] = (j0 + jj < T) ? kb[(long)d * p.q_cs + j0 + jj] : 0.f;
+    }
+    __syncthreads();
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    for (int d = 0; d < dk; ++d) {
+      const float q = qs[d * ATT_QB + si];
+      const float* kr = kt + d * (ATT_JB + 1) + sj;
+      s0 = fmaf(q, kr[0], s0);
+      s1 = fmaf(q, kr[16], s1);
+      s2 = fmaf(q, kr[32], s2);
+      s3 = fmaf(q, kr[48], s3);
+    }
+    float* Sr = S + si * p.Ts + j0 + sj;
+    Sr[0] = s0; Sr[16] = s1; Sr[32] = s2; Sr[48] = s3;
+  }
+  __syncthreads();
+  const int nrel = 2 * p.window + 1;
+  if (tid < ATT_QB * nrel) {
+    const int i = tid / nrel, r = tid % nrel;
+    const int j = i0 + i + r - p.window;
+    if (i0 + i < T && j >= 0 && j < T) {
+      float s = 0.f;
+      for (int d = 0; d < dk; ++d) s = fmaf(qs[d * ATT_QB + i], p.relk[r * dk + d], s);
+      S[i * p.Ts + j] += s;
+    }
+  }
+  __syncthreads();
+  // ---- softmax over valid keys: row si by the 16 lanes sj
+  {
+    float* Sr = S + si * p.Ts;
+    float mx = -3.0e38f;
+    for (int j = sj; j < T; j += 16) mx = fmaxf(mx, Sr[j]);
+    for (int m = 8; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m));
+    float sum = 0.f;
+    for (int j = sj; j < T; j += 16) {
+      const float e = expf(Sr[j] - mx);
+      Sr[j] = e;
+      sum += e;
+    }
+    for (int m = 8; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
+    const float inv = 1.f / sum;
+    const int Tpad = (T + ATT_JB - 1) / ATT_JB * ATT_JB;
+    for (int j = sj; j < Tpad; j += 16) Sr[j] = (j < T) ? Sr[j] * inv : 0.f;
+  }
+  // ---- P.V (+ relative values)
+  const int pi = tid >> 5, pd = tid & 31;
+  constexpr int MAXDD = 4;                  // dk <= 128
+  float o[2][MAXDD];
+  for (int a = 0; a < 2; ++a)
+    for (int c = 0; c < MAXDD; ++c) o[a][c] = 0.f;
+  const int ndd = (dk + 31) / 32;
+  for (int j0 = 0; j0 < T; j0 += ATT_JB) {
+    __syncthreads();
+    for (int e = tid; e < dk * ATT_JB; e += 256) {
+      const int d = e / ATT_JB, jj = e % ATT_JB;
+      kt[d * (ATT_JB + 1) + jj] = (j0 + jj < T) ? vb[(long)d * p.q_cs + j0 + jj] : 0.f;
+    }
+    __syncthreads();
+    for (int jj = 0; jj < ATT_JB; ++jj) {
+      const float p0 = S[pi * p.Ts + j0 + jj], p1 = S[(pi + 8) * p.Ts + j0 + jj];
+      for (int c = 0; c < ndd; ++c) {
+        const int d = pd + 32 * c;
+        const float v = d < dk ? kt[d * (ATT_JB + 1) + jj] : 0.f;
+        o[0][c] = fmaf(p0, v, o[0][c]);
+        o[1][c] = fmaf(p1, v, o[1][c]);
+      }
+    }
+  }
+  for (int a = 0; a < 2; ++a) {
+    const int i = pi + 8 * a;
+    if (i0 + i >= T) continue;
+    for (int c = 0; c < ndd; ++c) {
+      const int d = pd + 32 * c;
+      if (d >= dk) continue;
+      float acc = o[a][c];
+      for (int r = 0; r < nrel; ++r) {
+        const int j = i0 + i + r - p.window;
+        if (j >= 0 && j < T) acc = fmaf(S[i * p.Ts + j], p.relv[r * dk + d], acc);
+      }
+      p.out[(long)b * p.o_bs + (long)(h * dk + d) * p.o_cs + i0 + i] = acc;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LayerNorm over channels (modules.py:23-26) with the fusions the graph needs:
+//   MODE 0: out = LN(in)                                   (encoder norm_layers_1/2; in = x + y)
+//   MODE 1: out = res + gelu(LN(in))                       (DDSConv second half, modules.py:123-128)
+//   MODE 2: out = gelu(LN(dwconv_k(in; dil) + b))          (DDSConv first half, modules.py:120-123)
+struct LnP {
+  const float* in; long i_bs; int i_cs;
+  const float* res; long r_bs; int r_cs;
+  float* out; long o_bs; int o_cs;
+  const float* gamma; const float* beta;
+  const float* dw_w; const float* dw_b; int dw_k, dw_dil;
+  const int* lens;
+  int C;
+};
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+
+template <int MODE>
+__global__ __launch_bounds__(256) void ln_kernel(LnP p) {
+  __shared__ float red[8][33];
+  const int b = blockIdx.y, L = p.lens[b];
+  const int t0 = blockIdx.x * 32;
+  if (t0 >= L) return;
+  const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int t = t0 + col;
+  const bool ok = t < L;
+  const float* ib = p.in + (long)b * p.i_bs;
+  auto val = [&](int c) -> float {
+    if (MODE == 2) {
+      float s = p.dw_b[c];
+      const float* xr = ib + (long)c * p.i_cs;
+      const int pad = (p.dw_k - 1) / 2 * p.dw_dil;
+      for (int k = 0; k < p.dw_k; ++k) {
+        const int tt = t + k * p.dw_dil - pad;
+        if (tt >= 0 && tt < L) s = fmaf(p.dw_w[c * p.dw_k + k], xr[tt], s);
+      }
+      return s;
+    }
+    return ib[(long)c * p.i_cs + t];
+  };
+  float s = 0.f;
+  if (ok) for (int c = rg; c < p.C; c += 8) s += val(c);
+  red[rg][col] = s;
+  __syncthreads();
+  float mean = 0.f;
+  for (int g = 0; g < 8; ++g) mean += red[g][col];
+  mean /= (float)p.C;
+  __syncthreads();
+  float q = 0.f;
+  if (ok) for (int c = rg; c < p.C; c += 8) { const float d = val(c) - mean; q = fmaf(d, d, q); }
+  red[rg][col] = q;
+  __syncthreads();
+  float var = 0.f;
+  for (int g = 0; g < 8; ++g) var += red[g][col];
+  const float rstd = 1.f / sqrtf(var / (float)p.C + 1e-5f);
+  if (!ok) return;
+  for (int c = rg; c < p.C; c += 8) {
+    float y = (val(c) - mean) * rstd * p.gamma[c] + p.beta[c];
+    if (MODE >= 1) y = gelu_erf(y);
+    if (MODE == 1) y += p.res[(long)b * p.r_bs + (long)c * p.r_cs + t];
+    p.out[(long)b * p.o_bs + (long)c * p.o_cs + t] = y;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// ConvFlow.pre (1 -> H channels, 1x1) fused with DDSConv's "x = x + g" (modules.py:504-505,118-119):
+//   h[c][t] = w[c] * z0[t] + b[c] + g[c][t]
+__global__ void cf_pre_kernel(const float* z0, long z_bs, const float* w, const float* bia,
+                              const float* g, long g_bs, int g_cs, float* out, long o_bs, int o_cs,
+                              const int* lens, int H) {
+  const int b = blockIdx.z, c = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= lens[b] || c >= H) return;
+  out[(long)b * o_bs + (long)c * o_cs + t] =
+      fmaf(w[c], z0[(long)b * z_bs + t], bia[c]) + g[(long)b * g_bs + (long)c * g_cs + t];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Inverse piecewise rational-quadratic spline with linear tails, 10 bins, bound 5
+// (transforms.py:50-98 unconstrained_rational_quadratic_spline(inverse=True) over :101-191;
+// the per-position parameters are ConvFlow.proj's 29 outputs, modules.py:508-517).
+// One thread per (utterance, position). z1 is transformed in place; z0 is the untouched half.
+__global__ void spline_inverse_kernel(const float* hproj, long h_bs, int h_cs, float* z1, long z_bs,
+                                      const int* lens, float inv_sqrt_h) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= lens[b]) return;
+  constexpr int NB = 10;
+  constexpr float TB = 5.0f, MINB = 1e-3f, MIND = 1e-3f;
+  const float x = z1[(long)b * z_bs + t];
+  if (!(x >= -TB && x <= TB)) return;            // identity outside the interval
+  const float* hp = hproj + (long)b * h_bs + t;
+  float uw[NB], uh[NB], dv[NB + 1];
+  float mw = -3.0e38f, mh = -3.0e38f;
+  for (int i = 0; i < NB; ++i) {
+    uw[i] = hp[(long)i * h_cs] * inv_sqrt_h;
+    uh[i] = hp[(long)(NB + i) * h_cs] * inv_sqrt_h;
+    mw = fmaxf(mw, uw[i]);
+    mh = fmaxf(mh, uh[i]);
+  }
+  float sw = 0.f, sh = 0.f;
+  for (int i = 0; i < NB; ++i) {
+    uw[i] = expf(uw[i] - mw); sw += uw[i];
+    uh[i] = expf(uh[i] - mh); sh += uh[i];
+  }
+  // derivatives: min + softplus(u), boundary u = log(exp(1-min)-1) -> derivative exactly ~1
+  const float ucst = logf(expf(1.f - MIND) - 1.f);
+  for (int i = 0; i <= NB; ++i) {
+    const float u = (i == 0 || i == NB) ? ucst : hp[(long)(2 * NB + i - 1) * h_cs];
+    dv[i] = MIND + (u > 20.f ? u : log1pf(expf(u)));
+  }
+  // cumulative widths / heights scaled to [-TB, TB], end knots pinned
+  float cw[NB + 1], ch[NB + 1];
+  cw[0] = -TB; ch[0] = -TB;
+  float aw = 0.f, ah = 0.f;
+  for (int i = 0; i < NB; ++i) {
+    aw += MINB + (1.f - MINB * NB) * (uw[i] / sw);
+    ah += MINB + (1.f - MINB * NB) * (uh[i] / sh);
+    cw[i + 1] = 2.f * TB * aw - TB;
+    ch[i + 1] = 2.f * TB * ah - TB;
+  }
+  cw[NB] = TB; ch[NB] = TB;
+  // searchsorted on heights (transforms.py:44-47): last edge + 1e-6
+  int bin = -1;
+  for (int i = 0; i <= NB; ++i) {
+    const float e = (i == NB) ? ch[i] + 1e-6f : ch[i];
+    bin += (x >= e) ? 1 : 0;
+  }
+  bin = bin < 0 ? 0 : (bin > NB - 1 ? NB - 1 : bin);
+  float in_cw = 0.f, in_w = 0.f, in_ch = 0.f, in_h = 0.f, d0 = 0.f, d1 = 0.f;
+  for (int i = 0; i < NB; ++i)
+    if (i == bin) {
+      in_cw = cw[i]; in_w = cw[i + 1] - cw[i];
+      in_ch = ch[i]; in_h = ch[i + 1] - ch[i];
+      d0 = dv[i]; d1 = dv[i + 1];
+    }
+  const float delta = in_h / in_w;
+  const float y = x - in_ch;
+  const float s = d0 + d1 - 2.f * delta;
+  const float a = y * s + in_h * (delta - d0);
+  const float bq = in_h * d0 - y * s;
+  const float c = -delta * y;
+  const float disc = bq * bq - 4.f * a * c;
+  const float root = (2.f * c) / (-bq - sqrtf(disc));
+  z1[(long)b * z_bs + t] = root * in_w + in_cw;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ElementwiseAffine reverse + durations (modules.py:407-409; models.py:702-704):
+//   logw = (z0 - m0) * exp(-logs0); w = exp(logw) * length_scale; d = ceil(w);
+//   cum = inclusive prefix sum; frames = max(sum d, 1).   One block per utterance.
+__global__ __launch_bounds__(256) void duration_kernel(const float* z0, long z_bs, float m0, float es0,
+                                                       float length_scale, const int* lens, int* dur,
+                                                       int* cum, int d_bs, int* frames, float* logw_out) {
+  __shared__ int part[256];
+  const int b = blockIdx.x, T = lens[b], tid = threadIdx.x;
+  const int per = (T + 255) / 256;
+  const int lo = tid * per, hi = (lo + per < T) ? lo + per : T;
+  int s = 0;
+  for (int t = lo; t < hi; ++t) {
+    const float logw = (z0[(long)b * z_bs + t] - m0) * es0;
+    const float w = expf(logw) * length_scale;
+    float c = ceilf(w);
+    c = c < 0.f ? 0.f : (c > 1.0e6f ? 1.0e6f : c);
+    const int d = (int)c;
+    dur[b * d_bs + t] = d;
+    if (logw_out) logw_out[(long)b * d_bs + t] = logw;
+    s += d;
+  }
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int i = 0; i < 256; ++i) { const int v = part[i]; part[i] = run; run += v; }
+    frames[b] = run < 1 ? 1 : run;
+  }
+  __syncthreads();
+  int run = part[tid];
+  for (int t = lo; t < hi; ++t) {
+    run += dur[b * d_bs + t];
+    cum[b * d_bs + t] = run;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Length regulator + prior sample (models.py:705-718, commons.py:116-129). The reference multiplies
+// by a one-hot path matrix; the same result is a gather: frame f takes id i with cum[i-1] <= f < cum[i].
+//   z_p[c][f] = m_p[c][i] + noise[c][f] * exp(logs_p[c][i]) * noise_scale
+struct RegP {
+  const float* stats; long s_bs; int s_cs;     // [B][2C][Ts]: m_p rows [0,C), logs_p rows [C,2C)
+  const int* cum; int d_bs;
+  const int* tlens; const int* frames;
+  const float* noise; long n_bs; int n_cs;     // [B][C][>=F] or null
+  float noise_scale;
+  float* out; long o_bs; int o_cs;
+  int C;
+};
+__global__ void regulate_kernel(RegP p) {
+  const int b = blockIdx.y;
+  const int f = blockIdx.x * blockDim.x + threadIdx.x;
+  const int F = p.frames[b], T = p.tlens[b];
+  if (f >= F) return;
+  const int* cum = p.cum + b * p.d_bs;
+  int lo = 0, hi = T;                      // first i with cum[i] > f
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (cum[mid] > f) hi = mid; else lo = mid + 1;
+  }
+  const bool hit = lo < T;                 // false only when every duration is 0 (frames clamped to 1)
+  const float* sb = p.stats + (long)b * p.s_bs + lo;
+  for (int c = 0; c < p.C; ++c) {
+    const float m = hit ? sb[(long)c * p.s_cs] : 0.f;
+    const float lg = hit ? sb[(long)(p.C + c) * p.s_cs] : 0.f;
+    const float nz = p.noise ? p.noise[(long)b * p.n_bs + (long)c * p.n_cs + f] : 0.f;
+    p.out[(long)b * p.o_bs + (long)c * p.o_cs + f] = m + nz * expf(lg) * p.noise_scale;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generator tail (models.py:364-366): leaky_relu(0.01) -> conv_post (k=7, no bias, 1 output channel)
+// -> tanh, fused with the per-utterance max|x| that the int16 conversion needs (piper.cpp:410-418).
+__global__ __launch_bounds__(256) void conv_post_kernel(const float* x, long x_bs, int x_cs, const float* w,
+                                                        int Cin, int K, float slope, const int* lens,
+                                                        int len_mul, float* audio, long a_bs,
+                                                        unsigned* absmax) {
+  PE_DYN_SMEM(float, sm);                    // w[Cin*K] then tile[Cin][256+K-1]
+  const int b = blockIdx.y, L = lens[b] * len_mul;
+  const int t0 = blockIdx.x * 256;
+  if (t0 >= L) return;
+  float* ws = sm;
+  float* tile = sm + Cin * K;
+  const int W = 256 + K - 1, pad = (K - 1) / 2, tid = threadIdx.x;
+  for (int e = tid; e < Cin * K; e += 256) ws[e] = w[e];
+  for (int c = 0; c < Cin; ++c)
+    for (int col = tid; col < W; col += 256) {
+      const int t = t0 + col - pad;
+      float v = (t >= 0 && t < L) ? x[(long)b * x_bs + (long)c * x_cs + t] : 0.f;
+      tile[c * W + col] = v > 0.f ? v : v * slope;
+    }
+  __syncthreads();
+  const int t = t0 + tid;
+  float v = 0.f;
+  if (t < L) {
+    float s = 0.f;
+    for (int c = 0; c < Cin; ++c)
+      for (int k = 0; k < K; ++k) s = fmaf(ws[c * K + k], tile[c * W + tid + k], s);
+    v = tanhf(s);
+    audio[(long)b * a_bs + t] = v;
+  }
+  float m = fabsf(v);
+  for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if ((tid & 63) == 0) atomicMax(absmax + b, __float_as_uint(m));
+}
+
+// float -> int16 exactly as piper.cpp:420-431 (scale 32767/max(0.01,peak), clamp, truncate)
+__global__ void pcm16_kernel(const float* audio, long a_bs, const unsigned* absmax, const int* lens,
+                             int len_mul, short* pcm, long p_bs) {
+  const int b = blockIdx.y, L = lens[b] * len_mul;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= L) return;
+  const float peak = fmaxf(0.01f, __uint_as_float(absmax[b]));
+  const float scale = 32767.0f / peak;
+  float v = audio[(long)b * a_bs + t] * scale;
+  v = fminf(fmaxf(v, -32768.0f), 32767.0f);
+  pcm[(long)b * p_bs + t] = (short)v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Counter-based N(0,1) generator for the two sampling sites (models.py:111 and :718) when the caller
+// does not inject noise: Philox-4x32-10 keyed by the engine seed, Box-Muller on the four outputs.
+__device__ __forceinline__ void philox4x32(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
+                                           unsigned k1, unsigned* o) {
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+__global__ void randn_kernel(float* out, long n, unsigned long long seed, unsigned long long stream) {
+  const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  unsigned r[4];
+  philox4x32((unsigned)(i4 >> 2), (unsigned)((unsigned long long)(i4 >> 2) >> 32), (unsigned)stream,
+             (unsigned)(stream >> 32), (unsigned)seed, (unsigned)(seed >> 32), r);
+  float g[4];
+  for (int h = 0; h < 2; ++h) {
+    const float u1 = ((float)r[2 * h] + 1.0f) * 2.3283064365386963e-10f;   // (0,1]
+    const float u2 = (float)r[2 * h + 1] * 2.3283064365386963e-10f;
+    const float rad = sqrtf(-2.f * logf(u1));
+    g[2 * h] = rad * cosf(6.283185307179586f * u2);
+    g[2 * h + 1] = rad * sinf(6.283185307179586f * u2);
+  }
+  for (int k = 0; k < 4 && i4 + k < n; ++k) out[i4 + k] = g[k];
+}
+
+__global__ void scale_kernel(float* x, long n, float s) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] *= s;
+}
+
+// Speaker conditioning (models.py:692-696 emb_g; :66-68 dp.cond; modules.py:188-199 WN.cond_layer;
+// models.py:349-351 dec.cond): g is a length-1 sequence, so every 1x1 cond conv reduces to a
+// per-utterance bias vector  out[b][r] = W[r][:] . emb_g[sid_b] + bias[r].
+__global__ void cond_kernel(const float* emb_g, int gin, const int* sids, const float* w, const float* bias,
+                            int rows, float* out, int o_bs) {
+  const int b = blockIdx.y;
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const float* g = emb_g + (long)sids[b] * gin;
+  float s = bias ? bias[r] : 0.f;
+  for (int i = 0; i < gin; ++i) s = fmaf(w[(long)r * gin + i], g[i], s);
+  out[(long)b * o_bs + r] = s;
+}
+
+}  // namespace pe

@@ -1,0 +1,34 @@
+// Runtime header for the engine: HIP on gfx950. (-DPE_EMU swaps in tests/emu/hip_emu.h, a
+// test-only functional emulator used to check kernel index logic without a GPU; the shipped
+// library is never built that way.)
+#pragma once
+
+#ifdef PE_EMU
+#include "hip_emu.h"
+#define PE_LAUNCH(kernel, grid, block, smem, stream, ...) \
+  emu::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })
+#define PE_DYN_SMEM(type, name) type* name = reinterpret_cast<type*>(emu::dyn_smem)
+#define pe_mfma_32x32x2(a, b, c) emu_mfma_32x32x2((a), (b), (c))
+#define pe_mfma_16x16x4(a, b, c) emu_mfma_16x16x4((a), (b), (c))
+#else
+#include <hip/hip_runtime.h>
+#define PE_LAUNCH(kernel, grid, block, smem, stream, ...) \
+  hipLaunchKernelGGL(kernel, (grid), (block), (smem), (stream), __VA_ARGS__)
+#define PE_DYN_SMEM(type, name) \
+  extern __shared__ __attribute__((aligned(16))) unsigned char pe_dyn_smem_raw[]; \
+  type* name = reinterpret_cast<type*>(pe_dyn_smem_raw)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define pe_mfma_32x32x2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define pe_mfma_16x16x4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+#endif
+
+#include <stdexcept>
+#include <string>
+
+#define PE_HIP(expr)                                                                         \
+  do {                                                                                       \
+    hipError_t pe_e_ = (expr);                                                               \
+    if (pe_e_ != hipSuccess)                                                                 \
+      throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(pe_e_));        \
+  } while (0)

@@ -1,0 +1,185 @@
+"""Python handle on the HIP engine (C ABI in include/piper_hip.h).
+
+This is the host-side twin of what ``onnxruntime.InferenceSession`` is to the reference's
+``PiperVoice`` (reference src/python_run/piper/voice.py:24-55,140-185): ``run()`` takes the same
+feed (``input``, ``scales``, optional ``sid``) and returns the float waveform; everything is
+computed on the GPU by libpiper_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib as L
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+class Synthesis:
+    """Result of one (batched) synthesis call. Arrays are copies (the C side reuses its buffers)."""
+
+    def __init__(self, audio: List[np.ndarray], pcm: List[np.ndarray], frames: np.ndarray, infer_seconds: float):
+        self.audio = audio
+        self.pcm = pcm
+        self.frames = frames
+        self.infer_seconds = infer_seconds
+
+
+class Engine:
+    def __init__(self, *, onnx_path: Optional[str] = None, blob: Optional[bytes] = None, device: int = 0,
+                 lib: Optional[C.CDLL] = None):
+        self._lib = lib if lib is not None else L.get_lib()
+        self._h = C.c_void_p()
+        if (onnx_path is None) == (blob is None):
+            raise ValueError("give exactly one of onnx_path / blob")
+        if onnx_path is not None:
+            rc = self._lib.pe_create(str(onnx_path).encode(), device, C.byref(self._h))
+        else:
+            self._blob = bytes(blob)
+            rc = self._lib.pe_create_from_blob(self._blob, len(self._blob), device, C.byref(self._h))
+        self._check(rc)
+        sr, hop, nspk, nsym, wb = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
+        self._check(self._lib.pe_get_info(self._h, C.byref(sr), C.byref(hop), C.byref(nspk), C.byref(nsym),
+                                          C.byref(wb)))
+        self.sample_rate, self.hop, self.num_speakers, self.num_symbols = sr.value, hop.value, nspk.value, nsym.value
+        self.weight_bytes = wb.value
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise EngineError(self._lib.pe_last_error().decode(errors="replace"))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.pe_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- helpers
+    @staticmethod
+    def _pack(id_lists: Sequence[Sequence[int]]):
+        offs = np.zeros(len(id_lists) + 1, np.int64)
+        for i, s in enumerate(id_lists):
+            offs[i + 1] = offs[i] + len(s)
+        ids = np.concatenate([np.asarray(s, np.int64).reshape(-1) for s in id_lists]) if id_lists else \
+            np.zeros(0, np.int64)
+        return np.ascontiguousarray(ids), offs
+
+    def _noise(self, noise_w, noise_z, keep):
+        if noise_w is None and noise_z is None:
+            return None
+        n = L.PeNoise()
+        if noise_w is not None:
+            a = np.ascontiguousarray(noise_w, np.float32)      # [B][2][stride]
+            keep.append(a)
+            n.noise_w = a.ctypes.data_as(C.POINTER(C.c_float))
+            n.w_stride = a.shape[-1]
+        if noise_z is not None:
+            a = np.ascontiguousarray(noise_z, np.float32)      # [B][inter][stride]
+            keep.append(a)
+            n.noise_z = a.ctypes.data_as(C.POINTER(C.c_float))
+            n.z_stride = a.shape[-1]
+        keep.append(n)
+        return C.byref(n)
+
+    def _collect(self, res: L.PeResult, want_audio=True, want_pcm=True) -> Synthesis:
+        B = res.batch
+        offs = np.ctypeslib.as_array(res.sample_offsets, (B + 1,)).copy()
+        frames = np.ctypeslib.as_array(res.frames, (B,)).copy()
+        total = int(offs[-1])
+        audio, pcm = [], []
+        if want_audio and total:
+            a = np.ctypeslib.as_array(res.audio, (total,))
+            audio = [a[offs[i]:offs[i + 1]].copy() for i in range(B)]
+        if want_pcm and total:
+            p = np.ctypeslib.as_array(res.pcm, (total,))
+            pcm = [p[offs[i]:offs[i + 1]].copy() for i in range(B)]
+        return Synthesis(audio, pcm, frames, res.infer_seconds)
+
+    # ---- API
+    def synthesize_batch(self, id_lists, scales=(0.667, 1.0, 0.8), sids=None, noise_w=None, noise_z=None) -> Synthesis:
+        ids, offs = self._pack(id_lists)
+        sc = (C.c_float * 3)(*[float(s) for s in scales])
+        keep: list = []
+        nz = self._noise(noise_w, noise_z, keep)
+        sid_arr = None
+        if sids is not None:
+            sid_np = np.ascontiguousarray(sids, np.int64)
+            keep.append(sid_np)
+            sid_arr = sid_np.ctypes.data_as(C.POINTER(C.c_int64))
+        res = L.PeResult()
+        self._check(self._lib.pe_synthesize_batch(
+            self._h, ids.ctypes.data_as(C.POINTER(C.c_int64)), offs.ctypes.data_as(C.POINTER(C.c_int64)),
+            len(id_lists), sc, sid_arr, nz, C.byref(res)))
+        return self._collect(res)
+
+    def synthesize(self, ids, scales=(0.667, 1.0, 0.8), sid=None, noise_w=None, noise_z=None) -> Synthesis:
+        nw = None if noise_w is None else np.asarray(noise_w, np.float32)[None]
+        nz = None if noise_z is None else np.asarray(noise_z, np.float32)[None]
+        return self.synthesize_batch([ids], scales, None if sid is None else [sid], nw, nz)
+
+    def upload(self, id_lists, scales=(0.667, 1.0, 0.8), sids=None, noise_w=None, noise_z=None):
+        ids, offs = self._pack(id_lists)
+        sc = (C.c_float * 3)(*[float(s) for s in scales])
+        keep: list = []
+        nz = self._noise(noise_w, noise_z, keep)
+        sid_arr = None
+        if sids is not None:
+            sid_np = np.ascontiguousarray(sids, np.int64)
+            keep.append(sid_np)
+            sid_arr = sid_np.ctypes.data_as(C.POINTER(C.c_int64))
+        self._keep = keep          # noise_z is read during run()
+        self._check(self._lib.pe_upload(self._h, ids.ctypes.data_as(C.POINTER(C.c_int64)),
+                                        offs.ctypes.data_as(C.POINTER(C.c_int64)), len(id_lists), sc, sid_arr, nz))
+
+    def run(self):
+        self._check(self._lib.pe_run(self._h))
+
+    def fetch(self, want_audio=True, want_pcm=True) -> Synthesis:
+        res = L.PeResult()
+        self._check(self._lib.pe_fetch(self._h, int(want_audio), int(want_pcm), C.byref(res)))
+        return self._collect(res, want_audio, want_pcm)
+
+    def durations(self) -> np.ndarray:
+        n = C.c_int64()
+        self._check(self._lib.pe_get_durations(self._h, None, 0, C.byref(n)))
+        out = np.zeros(n.value, np.int32)
+        self._check(self._lib.pe_get_durations(self._h, out.ctypes.data_as(C.POINTER(C.c_int32)), out.size,
+                                               C.byref(n)))
+        return out
+
+    def set_seed(self, seed: int):
+        self._lib.pe_set_seed(self._h, int(seed))
+
+    def profile_enable(self, on=True):
+        self._check(self._lib.pe_profile_enable(self._h, int(on)))
+
+    def profile_reset(self):
+        self._check(self._lib.pe_profile_reset(self._h))
+
+    def profile(self):
+        rows = []
+        for i in range(self._lib.pe_profile_rows(self._h)):
+            name, ms, fl, n = C.c_char_p(), C.c_double(), C.c_double(), C.c_int64()
+            self._check(self._lib.pe_profile_get(self._h, i, C.byref(name), C.byref(ms), C.byref(fl), C.byref(n)))
+            rows.append({"name": name.value.decode(), "ms": ms.value, "flops": fl.value, "launches": n.value})
+        return rows
+
+    @property
+    def stream(self) -> int:
+        return int(self._lib.pe_stream(self._h) or 0)
+
+    def debug_tensor(self, name: str, b: int = 0, capacity: int = 1 << 24) -> np.ndarray:
+        out = np.zeros(capacity, np.float32)
+        r, c = C.c_int32(), C.c_int32()
+        self._check(self._lib.pe_debug_tensor(self._h, name.encode(), b, out.ctypes.data_as(C.POINTER(C.c_float)),
+                                              capacity, C.byref(r), C.byref(c)))
+        return out[: r.value * c.value].reshape(r.value, c.value).copy()

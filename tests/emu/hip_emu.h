@@ -1,0 +1,162 @@
+// TEST INFRASTRUCTURE ONLY -- a single-threaded functional emulator of the small HIP subset the
+// piper_amd kernels use, so that kernel index arithmetic, LDS staging, barriers, shuffles and the
+// f32 MFMA fragment layouts can be checked on a machine without a GPU.
+//
+// It is NOT a CPU fallback of the product: the shipped library (libpiper_hip.so) is built by hipcc
+// for gfx950 and never contains this file; only tests/ build and load the emulated variant
+// (libpiper_hip_emu.so, -DPE_EMU). Nothing in piper_amd/ loads it.
+//
+// Model: one block at a time; every HIP thread of the block is a fiber (hand-rolled x86-64 context
+// switch); __syncthreads() and the wave-collective operations (shuffles, MFMA) are rendezvous
+// points handled by a round-robin scheduler. MFMA fragment layouts follow
+// /opt/skills/guides/cdna_hip_programming.md section 3 (f32 32x32x2 and 16x16x4 forms).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <chrono>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct emu_idx3 { unsigned x, y, z; };
+extern emu_idx3 threadIdx, blockIdx, blockDim, gridDim;
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+struct emu_event { double t; };
+typedef emu_event* hipEvent_t;
+#define hipSuccess 0
+#define hipMemcpyHostToDevice 1
+#define hipMemcpyDeviceToHost 2
+#define hipMemcpyDeviceToDevice 3
+#define hipMemcpyDefault 4
+#define hipStreamNonBlocking 1
+
+namespace emu {
+extern char* dyn_smem;
+void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body);
+void wave_sync();    // all live lanes of the calling fiber's wave
+void block_sync();
+int lane();
+int wave();
+float* wave_f(int slot);   // 64-float scratch rows owned by the calling wave (slots 0..3)
+}  // namespace emu
+
+inline void __syncthreads() { emu::block_sync(); }
+
+// ---- wave collectives -------------------------------------------------------------------------
+template <class T>
+inline T emu_exchange(T v, int src_lane) {
+  static_assert(sizeof(T) == 4, "emu shuffles are 32-bit");
+  float* s = emu::wave_f(0);
+  memcpy(&s[emu::lane()], &v, 4);
+  emu::wave_sync();
+  T r;
+  memcpy(&r, &s[src_lane & 63], 4);
+  emu::wave_sync();
+  return r;
+}
+template <class T> inline T __shfl_xor(T v, int m, int = 64) { return emu_exchange(v, emu::lane() ^ m); }
+template <class T> inline T __shfl_down(T v, int d, int = 64) {
+  int s = emu::lane() + d;
+  return emu_exchange(v, s > 63 ? emu::lane() : s);
+}
+template <class T> inline T __shfl(T v, int src, int = 64) { return emu_exchange(v, src); }
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f32_32x32x2_f32: lane l gives A[i=l&31][k=l>>5], B[k=l>>5][j=l&31];
+// D col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5); k-ordered fmaf chain.
+inline f32x16 emu_mfma_32x32x2(float a, float b, f32x16 c) {
+  float* sa = emu::wave_f(1);
+  float* sb = emu::wave_f(2);
+  int l = emu::lane();
+  sa[l] = a;
+  sb[l] = b;
+  emu::wave_sync();
+  int j = l & 31;
+  for (int r = 0; r < 16; ++r) {
+    int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+    float acc = c[r];
+    acc = fmaf(sa[i], sb[j], acc);
+    acc = fmaf(sa[32 + i], sb[32 + j], acc);
+    c[r] = acc;
+  }
+  emu::wave_sync();
+  return c;
+}
+// v_mfma_f32_16x16x4_f32: A[l&15][k=l>>4], B[k=l>>4][l&15]; D col = l&15, row = (l>>4)*4 + r.
+inline f32x4 emu_mfma_16x16x4(float a, float b, f32x4 c) {
+  float* sa = emu::wave_f(1);
+  float* sb = emu::wave_f(2);
+  int l = emu::lane();
+  sa[l] = a;
+  sb[l] = b;
+  emu::wave_sync();
+  int j = l & 15;
+  for (int r = 0; r < 4; ++r) {
+    int i = (l >> 4) * 4 + r;
+    float acc = c[r];
+    for (int k = 0; k < 4; ++k) acc = fmaf(sa[k * 16 + i], sb[k * 16 + j], acc);
+    c[r] = acc;
+  }
+  emu::wave_sync();
+  return c;
+}
+
+// ---- atomics (single-threaded: plain read-modify-write) ------------------------------------------
+template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <class T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }
+
+// ---- device math ---------------------------------------------------------------------------------
+inline float __expf(float x) { return expf(x); }
+inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+inline float __fdividef(float a, float b) { return a / b; }
+
+// ---- host runtime --------------------------------------------------------------------------------
+inline hipError_t hipMalloc(void** p, size_t n) {
+  *p = aligned_alloc(256, (n + 255) / 256 * 256);
+  return *p ? 0 : 2;
+}
+inline hipError_t hipFree(void* p) { free(p); return 0; }
+inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMalloc(p, n); }
+inline hipError_t hipHostFree(void* p) { free(p); return 0; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return 0; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
+inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return 0; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return 0; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+inline hipError_t hipDeviceSynchronize() { return 0; }
+inline hipError_t hipSetDevice(int) { return 0; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return 0; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return 0; }
+inline hipError_t hipGetLastError() { return 0; }
+inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+inline double emu_now() {
+  return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new emu_event{0}; return 0; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = emu_now(); return 0; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+  *ms = (float)((b->t - a->t) * 1e3);
+  return 0;
+}

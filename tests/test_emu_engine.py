@@ -1,0 +1,63 @@
+"""CPU tests of the engine's HOST logic and kernel index arithmetic through the test-only HIP
+emulator build (tests/emu/libpiper_hip_emu.so: same sources compiled with -DPE_EMU, fibers instead of
+GPU threads, emulated f32 MFMA fragment layouts). This is a development check, not a product path:
+piper_amd never loads the emulator. The real parity tests are tests/test_gpu_parity.py (-m gpu)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import vits_oracle as O
+from piper_amd import _lib as L
+from piper_amd import weights as W
+from piper_amd.engine import Engine, EngineError
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU = os.path.join(ROOT, "tests", "emu", "libpiper_hip_emu.so")
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    if not os.path.exists(EMU):
+        subprocess.check_call(["make", "-C", ROOT, "emu"])
+    return L.bind(EMU)
+
+
+def _noise(cfg, B, T, seed):
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal((B, 2, T)).astype(np.float32),
+            rng.standard_normal((B, cfg.inter, 32 * T + 64)).astype(np.float32))
+
+
+def test_emulated_pipeline_matches_golden(emu_lib):
+    g = np.load(os.path.join(ROOT, "tests", "golden", "tiny_noise.npz"))
+    cfg = W.preset("tiny")
+    w = W.synthetic_weights(cfg, int(g["weight_seed"]))
+    eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
+    T = len(g["ids"])
+    nw, nz = _noise(cfg, 1, T, int(g["noise_seed"]))
+    r = eng.synthesize(g["ids"], tuple(g["scales"]), noise_w=nw[0], noise_z=nz[0])
+    assert np.array_equal(eng.durations(), g["durations"])
+    assert np.max(np.abs(r.audio[0] - g["audio"])) < 1e-4
+    ref = O.audio_float_to_int16(g["audio"])
+    assert np.max(np.abs(r.pcm[0].astype(np.int32) - ref.astype(np.int32))) <= 4
+
+
+def test_emulated_ragged_batch_and_errors(emu_lib):
+    cfg = W.preset("tiny")
+    w = W.synthetic_weights(cfg, 1234)
+    eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
+    Ts = [3, 12]
+    ids = [W.synthetic_phoneme_ids(T, i, id_max=cfg.n_vocab - 1) for i, T in enumerate(Ts)]
+    nw, nz = _noise(cfg, 2, max(Ts), 5)
+    scales = (0.3, 0.8, 0.5)
+    rb = eng.synthesize_batch(ids, scales, noise_w=nw, noise_z=nz)
+    for i in range(2):
+        o = O.synthesize(w, cfg, ids[i], scales, nw[i], nz[i])
+        assert rb.audio[i].shape == o["audio"].shape
+        assert np.max(np.abs(rb.audio[i] - o["audio"])) < 1e-4
+    with pytest.raises(EngineError):
+        eng.synthesize([1, 0, 999, 2])
+    with pytest.raises(EngineError):
+        Engine(blob=b"not a blob at all" * 40, lib=emu_lib)
