@@ -178,12 +178,26 @@ def cpu_baseline(cfg, wts, ids, scales, noise_w, budget_s):
     synthesis of the same utterance, like piper.cpp's sequential loop."""
     import torch
     from oracle import vits_oracle as O
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
+    ncpu = os.cpu_count() or 1
     wt = O.to_torch(wts)
     rng = np.random.default_rng(99)
     nz = rng.standard_normal((cfg.inter, 16 * len(ids) + 64)).astype(np.float32)
-    O.synthesize(wt, cfg, ids, scales, noise_w, nz)           # warm-up
+    # torch's intra-op pool degrades badly when oversubscribed on many-core hosts: pick the thread
+    # count that synthesizes this utterance fastest (bounded probe), then time the sample with it
+    best, cores = None, 1
+    for th in sorted({1, 8, 16, 32, min(64, ncpu)}):
+        if th > ncpu:
+            continue
+        torch.set_num_threads(th)
+        O.synthesize(wt, cfg, ids, scales, noise_w, nz)       # warm-up at this setting
+        t = time.perf_counter()
+        O.synthesize(wt, cfg, ids, scales, noise_w, nz)
+        t = time.perf_counter() - t
+        if best is None or t < best:
+            best, cores = t, th
+        if t > 20:
+            break
+    torch.set_num_threads(cores)
     n, samples, t0 = 0, 0, time.perf_counter()
     while True:
         r = O.synthesize(wt, cfg, ids, scales, noise_w, nz)
@@ -195,7 +209,7 @@ def cpu_baseline(cfg, wts, ids, scales, noise_w, budget_s):
     return {"value": samples / dt, "unit": "samples/s", "cores": cores, "kind": "port",
             "x_realtime": samples / dt / cfg.sample_rate,
             "sample": f"{n} sequential B=1 syntheses of the same {len(ids)}-id utterance in {dt:.1f} s "
-                      f"(torch CPU fp32, {cores} threads)"}
+                      f"(torch CPU fp32, {cores} threads chosen by a probe over 1..64 on a {ncpu}-core host)"}
 
 
 if __name__ == "__main__":

@@ -12,7 +12,7 @@ static inline int rup(int v, int m) { return (v + m - 1) / m * m; }
 // tile configurations of conv_mfma_kernel: {WM, WN, MT, NT}
 enum { CFG_A = 0, CFG_B = 1, CFG_C = 2, CFG_S = 3, CFG_G = 4 };
 static const int CFG_BM[] = {128, 64, 32, 64, 128};
-static const int CFG_BN[] = {128, 128, 256, 64, 64};
+static const int CFG_BN[] = {128, 128, 128, 64, 64};
 
 // ------------------------------------------------------------------------------------------------
 // setup
@@ -164,7 +164,7 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
   gin_ = arch_[A_GIN]; nspk_ = arch_[A_NSPK];
   if (H_ <= 0 || C_ <= 0 || nh_ <= 0 || H_ % nh_ || (C_ & 1)) throw std::runtime_error("bad architecture header");
   dk_ = H_ / nh_;
-  if (dk_ > 128) throw std::runtime_error("head dimension > 128 is not supported");
+  if (dk_ > 128 || (dk_ & 1)) throw std::runtime_error("head dimension must be even and <= 128");
   hop_ = 1;
   for (int i = 0; i < arch_[A_NUPS]; ++i) hop_ *= arch_[A_UPR0 + i];
 
@@ -297,6 +297,18 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
     cond_bs_ = off;
   }
 
+#ifndef PE_EMU
+  {
+    // allow > 64 KiB of dynamic LDS (gfx950: 160 KiB per workgroup)
+    const int lim = 160 * 1024;
+    const void* ks[] = {(const void*)conv_mfma_kernel<2, 2, 2, 2, 8, false>, (const void*)conv_mfma_kernel<1, 4, 2, 1, 16, false>,
+                        (const void*)conv_mfma_kernel<1, 4, 1, 1, 16, false>, (const void*)conv_mfma_kernel<2, 2, 1, 1, 16, false>,
+                        (const void*)conv_mfma_kernel<2, 2, 2, 1, 16, false>, (const void*)conv_mfma_kernel<2, 2, 2, 2, 8, true>,
+                        (const void*)conv_mfma_kernel<1, 4, 2, 1, 16, true>, (const void*)conv_mfma_kernel<2, 2, 2, 1, 16, true>};
+    for (const void* k : ks) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    PE_HIP(hipFuncSetAttribute((const void*)attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+  }
+#endif
   static const char* rows[] = {"text_encoder", "duration_predictor", "regulate+flow", "hifigan", "post+pcm"};
   for (auto n : rows) prof_.push_back(ProfileRow{n});
   PE_HIP(hipEventCreate(&ev0_));
@@ -438,24 +450,39 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
 
   const int ncols = (epi == EPI_CONVT) ? Lmax + 1 : Lmax;
   int cfg = pc.cfg;
-  // small problems: trade tile size for more workgroups (B=1 encoder / first generator stages)
-  {
-    const long blocks = (long)((ncols + CFG_BN[cfg] - 1) / CFG_BN[cfg]) * (pc.mtiles * 32 / CFG_BM[cfg]) * B_;
-    if (blocks < 192) {
-      if (cfg == CFG_A) cfg = pc.gate ? CFG_G : CFG_S;
-      else if (cfg == CFG_B && !pc.gate) cfg = CFG_S;
-    }
+  const long blocks = (long)((ncols + CFG_BN[cfg] - 1) / CFG_BN[cfg]) * (pc.mtiles * 32 / CFG_BM[cfg]) * B_;
+  if (blocks < 160 && p.xhalo <= 32) {
+    // few columns (one utterance through encoder / duration predictor / flow): split K across the waves
+    const int MT = (pc.gate || pc.mtiles % 2 == 0) ? 2 : 1;
+    dim3 grid((ncols + 31) / 32, pc.mtiles / MT, B_);
+    const size_t smem = std::max<size_t>((size_t)4 * KC * (32 + p.xhalo), (size_t)4 * MT * 16 * 64) * sizeof(float);
+    if (pc.gate) PE_LAUNCH((conv_splitk_kernel<2, true>), grid, dim3(256), smem, stream_, p);
+    else if (MT == 2) PE_LAUNCH((conv_splitk_kernel<2, false>), grid, dim3(256), smem, stream_, p);
+    else PE_LAUNCH((conv_splitk_kernel<1, false>), grid, dim3(256), smem, stream_, p);
+    return;
+  }
+  if (blocks < 192) {   // medium-small: smaller tiles, more workgroups
+    if (cfg == CFG_A) cfg = pc.gate ? CFG_G : CFG_S;
+    else if (cfg == CFG_B && !pc.gate) cfg = CFG_S;
   }
   const int BM = CFG_BM[cfg], BN = CFG_BN[cfg];
   dim3 grid((ncols + BN - 1) / BN, pc.mtiles * 32 / BM, B_);
-  const size_t smem = (size_t)KC * (BN + p.xhalo) * sizeof(float);
-  if (smem > 64 * 1024) throw std::runtime_error("conv halo too large for the LDS tile");
+  if (p.xhalo > 128) throw std::runtime_error("conv halo (kernel-1)*dilation > 128 is not supported");
+  const size_t smem = (size_t)2 * KC * (BN + p.xhalo) * sizeof(float);
+  if (pc.gate) {
+    switch (cfg) {
+      case CFG_A: PE_LAUNCH((conv_mfma_kernel<2, 2, 2, 2, 8, true>), grid, dim3(256), smem, stream_, p); break;
+      case CFG_B: PE_LAUNCH((conv_mfma_kernel<1, 4, 2, 1, 16, true>), grid, dim3(256), smem, stream_, p); break;
+      default:    PE_LAUNCH((conv_mfma_kernel<2, 2, 2, 1, 16, true>), grid, dim3(256), smem, stream_, p); break;
+    }
+    return;
+  }
   switch (cfg) {
-    case CFG_A: PE_LAUNCH((conv_mfma_kernel<2, 2, 2, 2>), grid, dim3(256), smem, stream_, p); break;
-    case CFG_B: PE_LAUNCH((conv_mfma_kernel<1, 4, 2, 1>), grid, dim3(256), smem, stream_, p); break;
-    case CFG_C: PE_LAUNCH((conv_mfma_kernel<1, 4, 1, 2>), grid, dim3(256), smem, stream_, p); break;
-    case CFG_S: PE_LAUNCH((conv_mfma_kernel<2, 2, 1, 1>), grid, dim3(256), smem, stream_, p); break;
-    default:    PE_LAUNCH((conv_mfma_kernel<2, 2, 2, 1>), grid, dim3(256), smem, stream_, p); break;
+    case CFG_A: PE_LAUNCH((conv_mfma_kernel<2, 2, 2, 2, 8, false>), grid, dim3(256), smem, stream_, p); break;
+    case CFG_B: PE_LAUNCH((conv_mfma_kernel<1, 4, 2, 1, 16, false>), grid, dim3(256), smem, stream_, p); break;
+    case CFG_C: PE_LAUNCH((conv_mfma_kernel<1, 4, 1, 1, 16, false>), grid, dim3(256), smem, stream_, p); break;
+    case CFG_S: PE_LAUNCH((conv_mfma_kernel<2, 2, 1, 1, 16, false>), grid, dim3(256), smem, stream_, p); break;
+    default:    PE_LAUNCH((conv_mfma_kernel<2, 2, 2, 1, 16, false>), grid, dim3(256), smem, stream_, p); break;
   }
 }
 
@@ -469,7 +496,8 @@ void Engine::layer_norm(int mode, View in, View res, View out, const float* g, c
   p.gamma = g; p.beta = b;
   p.dw_w = dw_w; p.dw_b = dw_b; p.dw_k = dw_k; p.dw_dil = dw_dil;
   p.lens = lens; p.C = C;
-  dim3 grid((Lmax + 31) / 32, B_);
+  if (C > LN_COLS * 32) throw std::runtime_error("LayerNorm over more than 256 channels is not supported");
+  dim3 grid((Lmax + LN_COLS - 1) / LN_COLS, B_);
   if (mode == 0) PE_LAUNCH(ln_kernel<0>, grid, dim3(256), 0, stream_, p);
   else if (mode == 1) PE_LAUNCH(ln_kernel<1>, grid, dim3(256), 0, stream_, p);
   else PE_LAUNCH(ln_kernel<2>, grid, dim3(256), 0, stream_, p);
@@ -600,10 +628,12 @@ void Engine::run() {
     ap.qkv = qkv_; ap.q_bs = (long)3 * H_ * Ts; ap.q_cs = Ts;
     ap.relk = e.relk; ap.relv = e.relv;
     ap.out = att_; ap.o_bs = (long)H_ * Ts; ap.o_cs = Ts;
-    ap.lens = d_tlens_; ap.H = H_; ap.dk = dk_; ap.window = window_; ap.Ts = Ts;
+    ap.lens = d_tlens_; ap.H = H_; ap.dk = dk_; ap.window = window_;
+    ap.SP = rup(T, 64) + 1;
     ap.qscale = 1.0f / std::sqrt((float)dk_);
-    const size_t smem = ((size_t)dk_ * ATT_QB + (size_t)ATT_QB * Ts + (size_t)dk_ * (ATT_JB + 1)) * sizeof(float);
-    if (smem > 64 * 1024) throw std::runtime_error("utterance too long for the attention score tile");
+    const int VS = dk_ + 1 + (dk_ & 1);
+    const size_t smem = ((size_t)ATT_QB * ap.SP + (size_t)ATT_KCH * VS) * sizeof(float);
+    if (smem > 160 * 1024) throw std::runtime_error("utterance too long for the attention score tile");
     PE_LAUNCH(attn_kernel, dim3((T + ATT_QB - 1) / ATT_QB, nh_, B), dim3(256), smem, stream_, ap);
     conv(e.o, att, y, d_tlens_, 1, T, EPI_RESADD, 1.f, ACT_NONE, x);
     layer_norm(0, y, none, x, e.g1, e.b1, nullptr, nullptr, 0, 0, H_, d_tlens_, T);

@@ -37,19 +37,88 @@ struct ConvP {
   float alpha;                                  // ACCUM last/only: scale
 };
 
+// ---- shared epilogue of the conv GEMM kernels: one accumulator element (row, col) of utterance b.
+// Every non-transposed mode is the same straight-line form
+//     dst = alpha * ( old*use_old + (res*use_res + (acc + bias)*sign) )
+// with per-launch uniform flags, which keeps the unrolled epilogue small:
+//   STORE  : dst=out                         RESADD : +res            SUBFROM: old - v  (modules.py:464)
+//   ACCUM  : MRF sum/scale (models.py:356-363)       WNRS: rows<split h += v, else skip (+)= v (modules.py:201-208)
+struct EpiFlags {
+  float sign, alpha;
+  bool use_res, use_old, relu;
+};
+__device__ __forceinline__ EpiFlags epi_flags(const ConvP& p) {
+  EpiFlags f{1.f, 1.f, false, false, false};
+  switch (p.epi) {
+    case EPI_STORE: f.relu = p.act == ACT_RELU; break;
+    case EPI_RESADD: f.use_res = true; break;
+    case EPI_SUBFROM: f.sign = -1.f; f.use_old = true; break;
+    case EPI_ACCUM:
+      f.use_res = true;
+      f.use_old = (p.mode == 1 || p.mode == 2);
+      if (p.mode >= 2) f.alpha = p.alpha;
+      break;
+    default: break;
+  }
+  return f;
+}
+__device__ __forceinline__ void conv_store(const ConvP& p, const EpiFlags& f, int b, int row, int col, float v, int L) {
+  if (p.epi == EPI_CONVT) {
+    const int co = row / p.up, ph = row - co * p.up;
+    const int t = col * p.up + ph - p.padT;
+    if (t >= 0 && t < L * p.up) p.out[(long)b * p.o_bs + (long)co * p.o_cs + t] = v + (p.bias ? p.bias[co] : 0.f);
+    return;
+  }
+  if (p.bias) v += p.bias[row];
+  if (p.bias2) v += p.bias2[(long)b * p.bias2_bs + row];
+  float* d = p.out + (long)b * p.o_bs + (long)row * p.o_cs + col;
+  bool use_old = f.use_old;
+  if (p.epi == EPI_WNRS) {
+    if (row < p.split) use_old = true;
+    else {
+      d = p.out2 + (long)b * p.o2_bs + (long)(row - p.split) * p.o2_cs + col;
+      use_old = p.mode != 1;
+    }
+  }
+  v *= f.sign;
+  if (f.use_res) v += p.res[(long)b * p.r_bs + (long)row * p.r_cs + col];
+  if (use_old) v += *d;
+  v *= f.alpha;
+  if (f.relu) v = v > 0.f ? v : 0.f;
+  *d = v;
+}
+// commons.py:99-106 fused_add_tanh_sigmoid_multiply on a (tanh-tile, sigmoid-tile) accumulator pair
+__device__ __forceinline__ void conv_store_gate(const ConvP& p, int b, int ch, int col, float ta, float sa) {
+  ta += p.bias[ch];
+  sa += p.bias[p.split + ch];
+  if (p.bias2) {
+    const float* b2 = p.bias2 + (long)b * p.bias2_bs;
+    ta += b2[ch];
+    sa += b2[p.split + ch];
+  }
+  p.out[(long)b * p.o_bs + (long)ch * p.o_cs + col] = tanhf(ta) * (1.f / (1.f + expf(-sa)));
+}
+
 // Conv1d / ConvTranspose1d as an implicit GEMM on the f32 matrix cores.
 //   D[row][col] = sum_{ci,k} W[row][ci][k] * act(x[ci][col + k*dil - padl])
-// rows -> MFMA M (weights are the A operand, read pre-packed straight from global/L2, one
-// coalesced dword per lane per MFMA), cols (time) -> MFMA N (activations are the B operand, staged
-// once per K-chunk through LDS with the dilation halo, so each tap is just a shifted LDS read).
-// v_mfma_f32_32x32x2_f32 keeps the reference's fp32 arithmetic exactly (k-ordered fmaf chain).
-// Covers: every Conv1d of attentions.py / modules.py / models.py with groups=1, and (EPI_CONVT)
-// the polyphase form of Generator.ups ConvTranspose1d (models.py:321-332) where k = 2*stride.
-template <int WM, int WN, int MT, int NT>
+// rows -> MFMA M, cols (time) -> MFMA N, K = (ci, tap). v_mfma_f32_32x32x2_f32 keeps the reference's
+// fp32 arithmetic exactly (k-ordered fmaf chain).
+//   * B operand (activations): one [KC x (BN+halo)] slab per K-chunk in LDS, double-buffered; the next
+//     chunk is fetched into registers while the current one feeds the MFMAs, so a dilated tap is just
+//     a shifted LDS read and the pre-activation (leaky-relu) is applied once per element.
+//   * A operand (weights): pre-packed at load time in fragment order, so a wave reads its 32x2 slice
+//     as ONE coalesced dword per lane straight from L2; the 16 fragments of the next (chunk,tap) unit
+//     are prefetched into a second register set (ping-pong) while the current unit's MFMAs issue.
+// Covers every groups=1 Conv1d of attentions.py / modules.py / models.py and (EPI_CONVT) the polyphase
+// form of Generator.ups ConvTranspose1d (models.py:321-332) where k = 2*stride.
+template <int WM, int WN, int MT, int NT, int KS, bool GATE>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+  constexpr int NCOL = (BN + 128 + 63) / 64;     // staging columns per lane (halo <= 128)
+  constexpr int NSUB = (KC / 2) / KS;             // A prefetch sets per (chunk, tap)
   static_assert(WM * WN == 4, "4 waves per block");
-  PE_DYN_SMEM(float, xs);
+  static_assert(NSUB * KS == KC / 2, "KS must divide KC/2");
+  PE_DYN_SMEM(float, xs);                         // 2 x [KC][XW]
   const int b = blockIdx.z;
   const int L = p.lens[b] * p.len_mul;
   const int ncols = (p.epi == EPI_CONVT) ? L + 1 : L;
@@ -73,69 +142,102 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
   const int tbase = n0 - p.padl;
   const int mtile0 = m0 / 32 + wm * MT;
   const float slope = p.in_slope;
+  const int ntaps = p.ntaps, nchunks = p.nchunks;
+  const int nunits = nchunks * ntaps * NSUB;
+  const long wstride_mt = (long)nchunks * ntaps * (KC / 2) * 64;
+  const float* wbase = p.wp + (long)mtile0 * wstride_mt + lane;
 
-  for (int c = 0; c < p.nchunks; ++c) {
-    // ---- stage x[c*KC .. +KC)[tbase .. tbase+XW) into LDS (zero outside [0,L) and beyond Cin)
-    for (int r = wv; r < KC; r += 4) {
-      const int ci = c * KC + r;
+  float xr[KC / 4][NCOL];
+  auto load_x = [&](int c) {
+#pragma unroll
+    for (int rr = 0; rr < KC / 4; ++rr) {
+      const int ci = c * KC + wv + 4 * rr;
       const bool rowok = ci < p.Cin;
-      const float* xr = xb + (long)ci * p.x_cs;
-      for (int col = lane; col < XW; col += 64) {
+      const float* xrow = xb + (long)ci * p.x_cs;
+#pragma unroll
+      for (int cc = 0; cc < NCOL; ++cc) {
+        const int col = lane + 64 * cc;
         const int t = tbase + col;
         float v = 0.f;
-        if (rowok && t >= 0 && t < L) {
-          v = xr[t];
+        if (rowok && col < XW && t >= 0 && t < L) v = xrow[t];
+        xr[rr][cc] = v;
+      }
+    }
+  };
+  auto store_x = [&](int buf) {
+    float* dst = xs + buf * KC * XW;
+#pragma unroll
+    for (int rr = 0; rr < KC / 4; ++rr)
+#pragma unroll
+      for (int cc = 0; cc < NCOL; ++cc) {
+        const int col = lane + 64 * cc;
+        if (col < XW) {
+          float v = xr[rr][cc];
           v = v > 0.f ? v : v * slope;
+          dst[(wv + 4 * rr) * XW + col] = v;
         }
-        xs[r * XW + col] = v;
       }
+  };
+  auto load_a = [&](int u, float (&a)[KS][MT]) {
+    const float* wt = wbase + (long)u * KS * 64;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[kk][i] = wt[i * wstride_mt + kk * 64];
+  };
+  auto mma = [&](int tap, int sub, const float (&a)[KS][MT], const float* xbuf) {
+    const float* xp = xbuf + (lhi + 2 * KS * sub) * XW + tap * p.dil + wn * NT * 32 + l31;
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk) {
+      float bv[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bv[j] = xp[2 * kk * XW + j * 32];
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = pe_mfma_32x32x2(a[kk][i], bv[j], acc[i][j]);
     }
-    __syncthreads();
-    for (int tap = 0; tap < p.ntaps; ++tap) {
-      const int toff = tap * p.dil + wn * NT * 32 + l31;
-      const float* wt = p.wp + ((((long)mtile0 * p.nchunks + c) * p.ntaps + tap) * (KC / 2)) * 64 + lane;
-      const long wstride_mt = (long)p.nchunks * p.ntaps * (KC / 2) * 64;
-#pragma unroll 4
-      for (int kk = 0; kk < KC / 2; ++kk) {
-        float a[MT], bv[NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) a[i] = wt[i * wstride_mt + kk * 64];
-#pragma unroll
-        for (int j = 0; j < NT; ++j) bv[j] = xs[(2 * kk + lhi) * XW + toff + j * 32];
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-          for (int j = 0; j < NT; ++j) acc[i][j] = pe_mfma_32x32x2(a[i], bv[j], acc[i][j]);
-      }
+  };
+  // one (chunk, tap) unit: prefetch the next unit's A set, run this unit's MFMAs, and at chunk
+  // boundaries move the prefetched x slab into the other LDS buffer
+  auto step = [&](int u, float (&cur)[KS][MT], float (&nxt)[KS][MT]) {
+    const int ut = u / NSUB, sub = u - ut * NSUB;
+    const int c = ut / ntaps, tap = ut - c * ntaps;
+    if (tap == 0 && sub == 0 && c + 1 < nchunks) load_x(c + 1);
+    if (u + 1 < nunits) load_a(u + 1, nxt);
+    mma(tap, sub, cur, xs + (c & 1) * KC * XW);
+    if (tap == ntaps - 1 && sub == NSUB - 1 && c + 1 < nchunks) {
+      store_x((c + 1) & 1);
+      __syncthreads();
     }
-    __syncthreads();
+  };
+
+  float aA[KS][MT], aB[KS][MT];
+  load_x(0);
+  load_a(0, aA);
+  store_x(0);
+  __syncthreads();
+  for (int u = 0; u < nunits; u += 2) {
+    step(u, aA, aB);
+    if (u + 1 < nunits) step(u + 1, aB, aA);
   }
 
   // ---- epilogue
-  const float* bias2 = p.bias2 ? p.bias2 + (long)b * p.bias2_bs : nullptr;
-  float* ob = p.out + (long)b * p.o_bs;
-  if (p.epi == EPI_GATE) {
-    // commons.py:99-106 fused_add_tanh_sigmoid_multiply: rows come in (tanh tile, sigmoid tile) pairs
+  if constexpr (GATE) {
+    static_assert(!GATE || MT == 2, "gate epilogue pairs two M tiles");
+    const int q = mtile0 >> 1;
 #pragma unroll
-    for (int i = 0; i + 1 < MT; i += 2) {
-      const int q = (mtile0 + i) >> 1;
+    for (int j = 0; j < NT; ++j) {
+      const int col = n0 + (wn * NT + j) * 32 + l31;
 #pragma unroll
-      for (int j = 0; j < NT; ++j) {
-        const int col = n0 + (wn * NT + j) * 32 + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ch = q * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-          if (ch < p.split && col < ncols) {
-            float ta = acc[i][j][r] + p.bias[ch];
-            float sa = acc[i + 1][j][r] + p.bias[p.split + ch];
-            if (bias2) { ta += bias2[ch]; sa += bias2[p.split + ch]; }
-            ob[(long)ch * p.o_cs + col] = tanhf(ta) * (1.f / (1.f + expf(-sa)));
-          }
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int ch = q * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (ch < p.split && col < ncols) conv_store_gate(p, b, ch, col, acc[0][j][r], acc[MT - 1][j][r]);
       }
     }
     return;
   }
+  const EpiFlags ef = epi_flags(p);
 #pragma unroll
   for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -144,49 +246,143 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = (mtile0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        if (row >= p.rows || col >= ncols) continue;
-        float v = acc[i][j][r];
-        if (p.epi == EPI_CONVT) {
-          const int co = row / p.up, ph = row - co * p.up;
-          const int t = col * p.up + ph - p.padT;
-          if (t >= 0 && t < L * p.up) ob[(long)co * p.o_cs + t] = v + (p.bias ? p.bias[co] : 0.f);
-          continue;
-        }
-        if (p.bias) v += p.bias[row];
-        if (bias2) v += bias2[row];
-        switch (p.epi) {
-          case EPI_STORE:
-            if (p.act == ACT_RELU) v = v > 0.f ? v : 0.f;
-            ob[(long)row * p.o_cs + col] = v;
-            break;
-          case EPI_RESADD:
-            ob[(long)row * p.o_cs + col] = p.res[(long)b * p.r_bs + (long)row * p.r_cs + col] + v;
-            break;
-          case EPI_WNRS:   // modules.py:201-208
-            if (row < p.split) {
-              float* h = ob + (long)row * p.o_cs + col;
-              *h = *h + v;
-            } else {
-              float* s = p.out2 + (long)b * p.o2_bs + (long)(row - p.split) * p.o2_cs + col;
-              *s = (p.mode == 1) ? v : *s + v;
-            }
-            break;
-          case EPI_SUBFROM: {  // modules.py:464 x1 = (x1 - m) * mask
-            float* d = ob + (long)row * p.o_cs + col;
-            *d = *d - v;
-          } break;
-          case EPI_ACCUM: {    // models.py:356-363 MRF: xs (+)= resblock(x); x = xs / num_kernels
-            v += p.res[(long)b * p.r_bs + (long)row * p.r_cs + col];
-            float* d = ob + (long)row * p.o_cs + col;
-            if (p.mode == 0) *d = v;
-            else if (p.mode == 1) *d = *d + v;
-            else if (p.mode == 2) *d = (*d + v) * p.alpha;
-            else *d = v * p.alpha;
-          } break;
-          default: break;
-        }
+        if (row < p.rows && col < ncols) conv_store(p, ef, b, row, col, acc[i][j][r], L);
       }
     }
+  }
+}
+
+// Same GEMM for launches that would otherwise fill only a few CUs (one utterance through the text
+// encoder / duration predictor / flow: 128..500 columns): one 32*MT x 32 output tile per workgroup
+// and the workgroup's four waves split the K-chunks between them (wave w takes chunks w, w+4, ...),
+// each with a private x slab in LDS and the same A ping-pong; partial tiles are summed through LDS in
+// a fixed order (deterministic) and wave-striped through the shared epilogue.
+template <int MT, bool GATE>
+__global__ __launch_bounds__(256) void conv_splitk_kernel(ConvP p) {
+  constexpr int BN = 32;
+  constexpr int NCOL = 1;                         // private slab: 32 + halo <= 64 columns
+  PE_DYN_SMEM(float, sm);                         // max(4 x [KC][XW], 4 x MT x 16 x 64)
+  const int b = blockIdx.z;
+  const int L = p.lens[b] * p.len_mul;
+  const int ncols = (p.epi == EPI_CONVT) ? L + 1 : L;
+  const int n0 = blockIdx.x * BN;
+  if (n0 >= ncols) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int XW = BN + p.xhalo;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int mtile0 = blockIdx.y * MT;
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+
+  const float* xb = p.x + (long)b * p.x_bs;
+  const int tbase = n0 - p.padl;
+  const float slope = p.in_slope;
+  const int ntaps = p.ntaps, nchunks = p.nchunks;
+  const long wstride_mt = (long)nchunks * ntaps * (KC / 2) * 64;
+  const float* wbase = p.wp + (long)mtile0 * wstride_mt + lane;
+  float* xw = sm + wv * KC * XW;                  // this wave's slab
+  const int myc = (nchunks - wv + 3) / 4;         // chunks wv, wv+4, ...
+  const int nunits = myc * ntaps;
+
+  float xr[KC][NCOL];
+  auto load_x = [&](int c) {
+#pragma unroll
+    for (int r = 0; r < KC; ++r) {
+      const int ci = c * KC + r;
+      const bool rowok = ci < p.Cin;
+      const float* xrow = xb + (long)ci * p.x_cs;
+#pragma unroll
+      for (int cc = 0; cc < NCOL; ++cc) {
+        const int col = lane + 64 * cc;
+        const int t = tbase + col;
+        float v = 0.f;
+        if (rowok && col < XW && t >= 0 && t < L) v = xrow[t];
+        xr[r][cc] = v;
+      }
+    }
+  };
+  auto store_x = [&]() {
+#pragma unroll
+    for (int r = 0; r < KC; ++r)
+#pragma unroll
+      for (int cc = 0; cc < NCOL; ++cc) {
+        const int col = lane + 64 * cc;
+        if (col < XW) {
+          float v = xr[r][cc];
+          v = v > 0.f ? v : v * slope;
+          xw[r * XW + col] = v;
+        }
+      }
+  };
+  auto load_a = [&](int u, float (&a)[KC / 2][MT]) {
+    const int k = u / ntaps, tap = u - k * ntaps;
+    const int c = wv + 4 * k;
+    const float* wt = wbase + ((long)c * ntaps + tap) * (KC / 2) * 64;
+#pragma unroll
+    for (int kk = 0; kk < KC / 2; ++kk)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) a[kk][i] = wt[i * wstride_mt + kk * 64];
+  };
+  auto mma = [&](int tap, const float (&a)[KC / 2][MT]) {
+    const float* xp = xw + lhi * XW + tap * p.dil + l31;
+#pragma unroll
+    for (int kk = 0; kk < KC / 2; ++kk) {
+      const float bv = xp[2 * kk * XW];
+#pragma unroll
+      for (int i = 0; i < MT; ++i) acc[i] = pe_mfma_32x32x2(a[kk][i], bv, acc[i]);
+    }
+  };
+  auto step = [&](int u, float (&cur)[KC / 2][MT], float (&nxt)[KC / 2][MT]) {
+    const int k = u / ntaps, tap = u - k * ntaps;
+    if (tap == 0) {               // new chunk: its slab was prefetched during the previous chunk
+      PE_WAVE_SYNC();             // all lanes done reading the previous slab
+      store_x();
+      PE_WAVE_SYNC();
+      if (k + 1 < myc) load_x(wv + 4 * (k + 1));
+    }
+    if (u + 1 < nunits) load_a(u + 1, nxt);
+    mma(tap, cur);
+  };
+  float aA[KC / 2][MT], aB[KC / 2][MT];
+  if (nunits > 0) {
+    load_x(wv);
+    load_a(0, aA);
+  }
+  for (int u = 0; u < nunits; u += 2) {
+    step(u, aA, aB);
+    if (u + 1 < nunits) step(u + 1, aB, aA);
+  }
+  // ---- cross-wave reduction through LDS (fixed order w = 0..3)
+  __syncthreads();
+  float* red = sm;                                // [4 waves][MT*16 slots][64 lanes]
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(wv * MT * 16 + i * 16 + r) * 64 + lane] = acc[i][r];
+  __syncthreads();
+  const int col = n0 + l31;
+  if constexpr (GATE) {
+    for (int r = wv; r < 16; r += 4) {
+      float ta = 0.f, sa = 0.f;
+      for (int w = 0; w < 4; ++w) {
+        ta += red[(w * MT * 16 + r) * 64 + lane];
+        sa += red[(w * MT * 16 + (MT - 1) * 16 + r) * 64 + lane];
+      }
+      const int ch = (mtile0 >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      if (ch < p.split && col < ncols) conv_store_gate(p, b, ch, col, ta, sa);
+    }
+    return;
+  }
+  for (int s = wv; s < MT * 16; s += 4) {
+    float v = 0.f;
+    for (int w = 0; w < 4; ++w) v += red[(w * MT * 16 + s) * 64 + lane];
+    const int i = s >> 4, r = s & 15;
+    const int row = (mtile0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+    if (row < p.rows && col < ncols) conv_store(p, epi_flags(p), b, row, col, v, L);
   }
 }
 
@@ -214,113 +410,131 @@ struct AttnP {
   const float* relk; const float* relv;     // [2w+1][dk]
   float* out; long o_bs; int o_cs;
   const int* lens;
-  int H, dk, window, Ts;                    // Ts: score row stride (>= max len, multiple of 64)
+  int H, dk, window;
+  int SP;                                   // score row stride in LDS: odd, >= round_up(max len, 64)
   float qscale;
 };
-static constexpr int ATT_QB = 16, ATT_JB = 64;
+static constexpr int ATT_QB = 32;           // queries per workgroup (one MFMA tile)
+static constexpr int ATT_KCH = 64;          // keys staged per V chunk
+static constexpr int ATT_MAXDK = 128;
 
+// One workgroup = 32 queries of one (utterance, head); 4 waves.
+//   1. S = (q/sqrt(dk)) k^T on the f32 MFMAs: wave w owns key tiles w, w+4, ...; both operands are read
+//      from global memory directly in fragment order (q and k rows are contiguous along time).
+//   2. banded relative-key logits, softmax over the valid keys (8 lanes per query row).
+//   3. O^T = V P^T on the MFMAs (V chunk transposed through LDS so the A fragment is contiguous; P read
+//      from the score slab with an odd stride), wave w owns channel tiles w, w+4, ...; banded
+//      relative-value term added before the coalesced store.
 __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
   PE_DYN_SMEM(float, sm);
   const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * ATT_QB;
   const int T = p.lens[b];
   if (i0 >= T) return;
-  const int dk = p.dk, tid = threadIdx.x;
-  float* qs = sm;                          // [dk][QB]
-  float* S = qs + dk * ATT_QB;             // [QB][Ts]
-  float* kt = S + ATT_QB * p.Ts;           // [dk][JB+1]
+  const int dk = p.dk, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int SP = p.SP, VS = dk + 1 + (dk & 1);       // odd strides -> conflict-free column reads
+  float* S = sm;                                      // [32][SP]
+  float* Vt = S + ATT_QB * SP;                        // [KCH][VS]
   const float* qb = p.qkv + (long)b * p.q_bs + (long)(h * dk) * p.q_cs;
   const float* kb = qb + (long)p.H * p.q_cs;
   const float* vb = kb + (long)p.H * p.q_cs;
-  for (int e = tid; e < dk * ATT_QB; e += 256) {
-    const int d = e / ATT_QB, i = e % ATT_QB;
-    qs[e] = (i0 + i < T) ? qb[(long)d * p.q_cs + i0 + i] * p.qscale : 0.f;
-  }
-  // ---- scores
-  const int si = tid >> 4, sj = tid & 15;
-  for (int j0 = 0; j0 < T; j0 += ATT_JB) {
-    __syncthreads();
-    for (int e = tid; e < dk * ATT_JB; e += 256) {
-      const int d = e / ATT_JB, jj = e % ATT_JB;
-      kt[d * (ATT_JB + 1) + jj] = (j0 + jj < T) ? kb[(long)d * p.q_cs + j0 + jj] : 0.f;
+  const int nkt = (T + 31) / 32;
+  const int nk2 = dk / 2;                             // MFMA k-steps over channels (dk even)
+
+  // ---- 1. scores
+  {
+    float qf[ATT_MAXDK / 2];
+    const bool qok = i0 + l31 < T;
+#pragma unroll
+    for (int s2 = 0; s2 < ATT_MAXDK / 2; ++s2)
+      qf[s2] = (s2 < nk2 && qok) ? qb[(long)(2 * s2 + lhi) * p.q_cs + i0 + l31] * p.qscale : 0.f;
+    for (int kt = wv; kt < nkt; kt += 4) {
+      const int j = kt * 32 + l31;
+      const bool kok = j < T;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 8
+      for (int s2 = 0; s2 < ATT_MAXDK / 2; ++s2) {
+        if (s2 < nk2) {
+          const float kf = kok ? kb[(long)(2 * s2 + lhi) * p.q_cs + j] : 0.f;
+          acc = pe_mfma_32x32x2(qf[s2], kf, acc);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) S[((r & 3) + 8 * (r >> 2) + 4 * lhi) * SP + kt * 32 + l31] = acc[r];
     }
-    __syncthreads();
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-    for (int d = 0; d < dk; ++d) {
-      const float q = qs[d * ATT_QB + si];
-      const float* kr = kt + d * (ATT_JB + 1) + sj;
-      s0 = fmaf(q, kr[0], s0);
-      s1 = fmaf(q, kr[16], s1);
-      s2 = fmaf(q, kr[32], s2);
-      s3 = fmaf(q, kr[48], s3);
-    }
-    float* Sr = S + si * p.Ts + j0 + sj;
-    Sr[0] = s0; Sr[16] = s1; Sr[32] = s2; Sr[48] = s3;
   }
   __syncthreads();
+  // ---- 2a. relative-key band: S[i][i+r-w] += (q_i/sqrt(dk)) . rel_k[r]
   const int nrel = 2 * p.window + 1;
-  if (tid < ATT_QB * nrel) {
-    const int i = tid / nrel, r = tid % nrel;
+  for (int e = tid; e < ATT_QB * nrel; e += 256) {
+    const int i = e % ATT_QB, r = e / ATT_QB;
     const int j = i0 + i + r - p.window;
     if (i0 + i < T && j >= 0 && j < T) {
       float s = 0.f;
-      for (int d = 0; d < dk; ++d) s = fmaf(qs[d * ATT_QB + i], p.relk[r * dk + d], s);
-      S[i * p.Ts + j] += s;
+      for (int d = 0; d < dk; ++d) s = fmaf(qb[(long)d * p.q_cs + i0 + i] * p.qscale, p.relk[r * dk + d], s);
+      S[i * SP + j] += s;
     }
   }
   __syncthreads();
-  // ---- softmax over valid keys: row si by the 16 lanes sj
+  // ---- 2b. softmax over valid keys: row = tid/8, 8 adjacent lanes per row
   {
-    float* Sr = S + si * p.Ts;
+    const int i = tid >> 3, sj = tid & 7;
+    float* Sr = S + i * SP;
     float mx = -3.0e38f;
-    for (int j = sj; j < T; j += 16) mx = fmaxf(mx, Sr[j]);
-    for (int m = 8; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m));
+    for (int j = sj; j < T; j += 8) mx = fmaxf(mx, Sr[j]);
+    for (int m = 4; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m));
     float sum = 0.f;
-    for (int j = sj; j < T; j += 16) {
+    for (int j = sj; j < T; j += 8) {
       const float e = expf(Sr[j] - mx);
       Sr[j] = e;
       sum += e;
     }
-    for (int m = 8; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
+    for (int m = 4; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
     const float inv = 1.f / sum;
-    const int Tpad = (T + ATT_JB - 1) / ATT_JB * ATT_JB;
-    for (int j = sj; j < Tpad; j += 16) Sr[j] = (j < T) ? Sr[j] * inv : 0.f;
+    const int Tpad = (T + ATT_KCH - 1) / ATT_KCH * ATT_KCH;
+    for (int j = sj; j < Tpad; j += 8) Sr[j] = (j < T) ? Sr[j] * inv : 0.f;
   }
-  // ---- P.V (+ relative values)
-  const int pi = tid >> 5, pd = tid & 31;
-  constexpr int MAXDD = 4;                  // dk <= 128
-  float o[2][MAXDD];
-  for (int a = 0; a < 2; ++a)
-    for (int c = 0; c < MAXDD; ++c) o[a][c] = 0.f;
-  const int ndd = (dk + 31) / 32;
-  for (int j0 = 0; j0 < T; j0 += ATT_JB) {
-    __syncthreads();
-    for (int e = tid; e < dk * ATT_JB; e += 256) {
-      const int d = e / ATT_JB, jj = e % ATT_JB;
-      kt[d * (ATT_JB + 1) + jj] = (j0 + jj < T) ? vb[(long)d * p.q_cs + j0 + jj] : 0.f;
-    }
-    __syncthreads();
-    for (int jj = 0; jj < ATT_JB; ++jj) {
-      const float p0 = S[pi * p.Ts + j0 + jj], p1 = S[(pi + 8) * p.Ts + j0 + jj];
-      for (int c = 0; c < ndd; ++c) {
-        const int d = pd + 32 * c;
-        const float v = d < dk ? kt[d * (ATT_JB + 1) + jj] : 0.f;
-        o[0][c] = fmaf(p0, v, o[0][c]);
-        o[1][c] = fmaf(p1, v, o[1][c]);
+  // ---- 3. O^T[d][q] = sum_key V[d][key] P[q][key]
+  const int ndt = (dk + 31) / 32;
+  f32x16 oacc;                                        // this wave's channel tile (wv < ndt), one tile per wave pass
+  for (int dt0 = 0; dt0 < ndt; dt0 += 4) {
+    const int dt = dt0 + wv;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
+    for (int j0 = 0; j0 < T; j0 += ATT_KCH) {
+      __syncthreads();                                // previous chunk consumed / softmax finished
+      for (int e = tid; e < dk * ATT_KCH; e += 256) {
+        const int d = e / ATT_KCH, jj = e % ATT_KCH;
+        Vt[jj * VS + d] = (j0 + jj < T) ? vb[(long)d * p.q_cs + j0 + jj] : 0.f;
+      }
+      __syncthreads();
+      if (dt < ndt) {
+        const int d = dt * 32 + l31;
+#pragma unroll 8
+        for (int s2 = 0; s2 < ATT_KCH / 2; ++s2) {
+          const int key = 2 * s2 + lhi;
+          const float a = d < dk ? Vt[key * VS + d] : 0.f;
+          const float pb = S[l31 * SP + j0 + key];
+          oacc = pe_mfma_32x32x2(a, pb, oacc);
+        }
       }
     }
-  }
-  for (int a = 0; a < 2; ++a) {
-    const int i = pi + 8 * a;
-    if (i0 + i >= T) continue;
-    for (int c = 0; c < ndd; ++c) {
-      const int d = pd + 32 * c;
-      if (d >= dk) continue;
-      float acc = o[a][c];
-      for (int r = 0; r < nrel; ++r) {
-        const int j = i0 + i + r - p.window;
-        if (j >= 0 && j < T) acc = fmaf(S[i * p.Ts + j], p.relv[r * dk + d], acc);
+    if (dt < ndt) {
+      const int q = i0 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (d < dk && q < T) {
+          float acc = oacc[r];
+          for (int rr = 0; rr < nrel; ++rr) {         // relative-value band
+            const int j = q + rr - p.window;
+            if (j >= 0 && j < T) acc = fmaf(S[l31 * SP + j], p.relv[rr * dk + d], acc);
+          }
+          p.out[(long)b * p.o_bs + (long)(h * dk + d) * p.o_cs + q] = acc;
+        }
       }
-      p.out[(long)b * p.o_bs + (long)(h * dk + d) * p.o_cs + i0 + i] = acc;
     }
   }
 }
@@ -330,6 +544,8 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
 //   MODE 0: out = LN(in)                                   (encoder norm_layers_1/2; in = x + y)
 //   MODE 1: out = res + gelu(LN(in))                       (DDSConv second half, modules.py:123-128)
 //   MODE 2: out = gelu(LN(dwconv_k(in; dil) + b))          (DDSConv first half, modules.py:120-123)
+// One workgroup = 8 time columns x all channels; thread (col = tid&7, rl = tid>>3) keeps channels
+// rl, rl+32, ... in registers (C <= 256), so the input is read (and the depthwise conv evaluated) once.
 struct LnP {
   const float* in; long i_bs; int i_cs;
   const float* res; long r_bs; int r_cs;
@@ -339,53 +555,71 @@ struct LnP {
   const int* lens;
   int C;
 };
+static constexpr int LN_COLS = 8, LN_NV = 8;
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 
 template <int MODE>
 __global__ __launch_bounds__(256) void ln_kernel(LnP p) {
-  __shared__ float red[8][33];
+  __shared__ float red[4][LN_COLS];
   const int b = blockIdx.y, L = p.lens[b];
-  const int t0 = blockIdx.x * 32;
+  const int t0 = blockIdx.x * LN_COLS;
   if (t0 >= L) return;
-  const int col = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int col = threadIdx.x & 7, rl = threadIdx.x >> 3, wv = threadIdx.x >> 6;
   const int t = t0 + col;
   const bool ok = t < L;
   const float* ib = p.in + (long)b * p.i_bs;
-  auto val = [&](int c) -> float {
-    if (MODE == 2) {
-      float s = p.dw_b[c];
-      const float* xr = ib + (long)c * p.i_cs;
-      const int pad = (p.dw_k - 1) / 2 * p.dw_dil;
-      for (int k = 0; k < p.dw_k; ++k) {
-        const int tt = t + k * p.dw_dil - pad;
-        if (tt >= 0 && tt < L) s = fmaf(p.dw_w[c * p.dw_k + k], xr[tt], s);
-      }
-      return s;
-    }
-    return ib[(long)c * p.i_cs + t];
-  };
+  float v[LN_NV];
   float s = 0.f;
-  if (ok) for (int c = rg; c < p.C; c += 8) s += val(c);
-  red[rg][col] = s;
-  __syncthreads();
-  float mean = 0.f;
-  for (int g = 0; g < 8; ++g) mean += red[g][col];
-  mean /= (float)p.C;
-  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < LN_NV; ++k) {
+    const int c = rl + 32 * k;
+    float x = 0.f;
+    if (ok && c < p.C) {
+      if (MODE == 2) {
+        x = p.dw_b[c];
+        const float* xr = ib + (long)c * p.i_cs;
+        const int pad = (p.dw_k - 1) / 2 * p.dw_dil;
+        for (int kk = 0; kk < p.dw_k; ++kk) {
+          const int tt = t + kk * p.dw_dil - pad;
+          if (tt >= 0 && tt < L) x = fmaf(p.dw_w[c * p.dw_k + kk], xr[tt], x);
+        }
+      } else {
+        x = ib[(long)c * p.i_cs + t];
+      }
+    }
+    v[k] = x;
+    s += x;
+  }
+  // reduce over rl: lanes differing in bits 3..5 within the wave, then across the 4 waves
+  auto block_sum = [&](float x) -> float {
+    x += __shfl_xor(x, 8);
+    x += __shfl_xor(x, 16);
+    x += __shfl_xor(x, 32);
+    __syncthreads();
+    if ((threadIdx.x & 63) < LN_COLS) red[wv][col] = x;
+    __syncthreads();
+    return red[0][col] + red[1][col] + red[2][col] + red[3][col];
+  };
+  const float mean = block_sum(s) / (float)p.C;
   float q = 0.f;
-  if (ok) for (int c = rg; c < p.C; c += 8) { const float d = val(c) - mean; q = fmaf(d, d, q); }
-  red[rg][col] = q;
-  __syncthreads();
-  float var = 0.f;
-  for (int g = 0; g < 8; ++g) var += red[g][col];
-  const float rstd = 1.f / sqrtf(var / (float)p.C + 1e-5f);
+#pragma unroll
+  for (int k = 0; k < LN_NV; ++k) {
+    const int c = rl + 32 * k;
+    if (c < p.C) { const float d = v[k] - mean; q = fmaf(d, d, q); }
+  }
+  const float var = block_sum(q) / (float)p.C;
+  const float rstd = 1.f / sqrtf(var + 1e-5f);
   if (!ok) return;
-  for (int c = rg; c < p.C; c += 8) {
-    float y = (val(c) - mean) * rstd * p.gamma[c] + p.beta[c];
-    if (MODE >= 1) y = gelu_erf(y);
-    if (MODE == 1) y += p.res[(long)b * p.r_bs + (long)c * p.r_cs + t];
-    p.out[(long)b * p.o_bs + (long)c * p.o_cs + t] = y;
+#pragma unroll
+  for (int k = 0; k < LN_NV; ++k) {
+    const int c = rl + 32 * k;
+    if (c < p.C) {
+      float y = (v[k] - mean) * rstd * p.gamma[c] + p.beta[c];
+      if (MODE >= 1) y = gelu_erf(y);
+      if (MODE == 1) y += p.res[(long)b * p.r_bs + (long)c * p.r_cs + t];
+      p.out[(long)b * p.o_bs + (long)c * p.o_cs + t] = y;
+    }
   }
 }
 

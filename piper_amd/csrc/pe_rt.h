@@ -10,6 +10,7 @@
 #define PE_DYN_SMEM(type, name) type* name = reinterpret_cast<type*>(emu::dyn_smem)
 #define pe_mfma_32x32x2(a, b, c) emu_mfma_32x32x2((a), (b), (c))
 #define pe_mfma_16x16x4(a, b, c) emu_mfma_16x16x4((a), (b), (c))
+#define PE_WAVE_SYNC() emu::wave_sync()
 #else
 #include <hip/hip_runtime.h>
 #define PE_LAUNCH(kernel, grid, block, smem, stream, ...) \
@@ -21,6 +22,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define pe_mfma_32x32x2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define pe_mfma_16x16x4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// lanes of a wave run in lockstep and LDS accesses of one wave complete in order: only the compiler
+// must not reorder across this point
+#define PE_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 #endif
 
 #include <stdexcept>
