@@ -11,7 +11,7 @@ EMULIB := tests/emu/libpiper_hip_emu.so
 all: $(LIB)
 
 $(LIB): $(SRCS) $(HDRS)
-	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -x hip $(SRCS) -o $@ -Wno-unused-result
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -x hip $(SRCS) -o $@ -Wno-unused-result -Wno-unused-value
 
 emu: $(EMULIB)
 

@@ -3,6 +3,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 namespace pe {
@@ -306,6 +308,9 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
                         (const void*)conv_mfma_kernel<2, 2, 2, 1, 16, false>, (const void*)conv_mfma_kernel<2, 2, 2, 2, 8, true>,
                         (const void*)conv_mfma_kernel<1, 4, 2, 1, 16, true>, (const void*)conv_mfma_kernel<2, 2, 2, 1, 16, true>};
     for (const void* k : ks) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    const void* ks2[] = {(const void*)conv_splitk_kernel<2, true, 8>, (const void*)conv_splitk_kernel<2, true, 4>,
+                         (const void*)conv_splitk_kernel<1, false, 8>, (const void*)conv_splitk_kernel<1, false, 4>};
+    for (const void* k : ks2) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     PE_HIP(hipFuncSetAttribute((const void*)attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
   }
 #endif
@@ -314,10 +319,12 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
   PE_HIP(hipEventCreate(&ev0_));
   PE_HIP(hipEventCreate(&ev1_));
   PE_HIP(hipHostMalloc((void**)&h_frames_, 4096 * sizeof(int)));
+  if (const char* ng = getenv("PIPER_HIP_NO_GRAPH")) use_graphs_ = !(ng[0] && ng[0] != '0');
 }
 
 Engine::~Engine() {
   hipStreamSynchronize(stream_);
+  drop_graphs();
   for (void* p : owned_) hipFree(p);
   if (wsA_) hipFree(wsA_);
   if (wsB_) hipFree(wsB_);
@@ -376,10 +383,12 @@ void Engine::ensure_stage_a(int B, int Tmax) {
     logw_ = c.take<float>(Bc * T);
     noise_w_ = c.take<float>(Bc * 2 * T);
     cond_ = c.take<float>(Bc * (size_t)std::max(cond_bs_, 1));
+    d_rng_ = c.take<unsigned long long>(4);
     return c.off + 256;
   };
   if (grow || !wsA_) {
     PE_HIP(hipStreamSynchronize(stream_));
+    drop_graphs();
     if (wsA_) PE_HIP(hipFree(wsA_));
     if (wsB_) { PE_HIP(hipFree(wsB_)); wsB_ = nullptr; }   // stage-B sizes depend on the batch capacity
     capB_F_ = 0;
@@ -416,6 +425,7 @@ void Engine::ensure_stage_b(int Fmax) {
   };
   if (grow || !wsB_) {
     PE_HIP(hipStreamSynchronize(stream_));
+    drop_graphs();
     if (wsB_) PE_HIP(hipFree(wsB_));
     wsB_bytes_ = carve(nullptr);
     PE_HIP(hipMalloc((void**)&wsB_, wsB_bytes_));
@@ -453,12 +463,17 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
   const long blocks = (long)((ncols + CFG_BN[cfg] - 1) / CFG_BN[cfg]) * (pc.mtiles * 32 / CFG_BM[cfg]) * B_;
   if (blocks < 160 && p.xhalo <= 32) {
     // few columns (one utterance through encoder / duration predictor / flow): split K across the waves
-    const int MT = (pc.gate || pc.mtiles % 2 == 0) ? 2 : 1;
+    const int MT = pc.gate ? 2 : 1;
+    const int NW = pc.nchunks >= 5 ? 8 : 4;
     dim3 grid((ncols + 31) / 32, pc.mtiles / MT, B_);
-    const size_t smem = std::max<size_t>((size_t)4 * KC * (32 + p.xhalo), (size_t)4 * MT * 16 * 64) * sizeof(float);
-    if (pc.gate) PE_LAUNCH((conv_splitk_kernel<2, true>), grid, dim3(256), smem, stream_, p);
-    else if (MT == 2) PE_LAUNCH((conv_splitk_kernel<2, false>), grid, dim3(256), smem, stream_, p);
-    else PE_LAUNCH((conv_splitk_kernel<1, false>), grid, dim3(256), smem, stream_, p);
+    const size_t smem = std::max<size_t>((size_t)NW * KC * (32 + p.xhalo), (size_t)NW * MT * 16 * 64) * sizeof(float);
+    if (pc.gate) {
+      if (NW == 8) PE_LAUNCH((conv_splitk_kernel<2, true, 8>), grid, dim3(512), smem, stream_, p);
+      else PE_LAUNCH((conv_splitk_kernel<2, true, 4>), grid, dim3(256), smem, stream_, p);
+    } else {
+      if (NW == 8) PE_LAUNCH((conv_splitk_kernel<1, false, 8>), grid, dim3(512), smem, stream_, p);
+      else PE_LAUNCH((conv_splitk_kernel<1, false, 4>), grid, dim3(256), smem, stream_, p);
+    }
     return;
   }
   if (blocks < 192) {   // medium-small: smaller tiles, more workgroups
@@ -507,9 +522,9 @@ void Engine::layer_norm(int mode, View in, View res, View out, const float* g, c
 void Engine::dds(const DdsW& d, View x, View t1, View t2) {
   int dil = 1;
   for (size_t i = 0; i < d.c1x1.size(); ++i) {
-    layer_norm(2, x, View{nullptr, 0, 0}, t1, d.g1[i], d.b1[i], d.dw_w[i], d.dw_b[i], ksz_, dil, H_, d_tlens_, Tmax_);
-    conv(d.c1x1[i], t1, t2, d_tlens_, 1, Tmax_, EPI_STORE);
-    layer_norm(1, t2, x, x, d.g2[i], d.b2[i], nullptr, nullptr, 0, 0, H_, d_tlens_, Tmax_);
+    layer_norm(2, x, View{nullptr, 0, 0}, t1, d.g1[i], d.b1[i], d.dw_w[i], d.dw_b[i], ksz_, dil, H_, d_tlens_, Tg_);
+    conv(d.c1x1[i], t1, t2, d_tlens_, 1, Tg_, EPI_STORE);
+    layer_norm(1, t2, x, x, d.g2[i], d.b2[i], nullptr, nullptr, 0, 0, H_, d_tlens_, Tg_);
     dil *= ksz_;
   }
 }
@@ -586,13 +601,19 @@ void Engine::upload(const int64_t* ids, const int64_t* offsets, int B, const flo
                tlens_h_[b] * sizeof(float));
     PE_HIP(hipMemcpyAsync(noise_w_, nb.data(), nb.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
   }
-  PE_HIP(hipStreamSynchronize(stream_));   // host staging buffers go out of scope
   ++call_;
+  {
+    const unsigned long long st[2] = {seed_, call_};
+    PE_HIP(hipMemcpyAsync(d_rng_, st, sizeof(st), hipMemcpyHostToDevice, stream_));
+  }
+  PE_HIP(hipStreamSynchronize(stream_));   // host staging buffers go out of scope
 }
 
-void Engine::run() {
-  PE_HIP(hipSetDevice(device_));
-  const int B = B_, Ts = Ts_, T = Tmax_;
+// Everything up to the frame counts: speaker vectors, text encoder, duration predictor, durations.
+// Grids are sized by the bucketed maximum length Tg_; kernels bound themselves by the device-side
+// per-utterance lengths, so the same captured graph serves every batch of that bucket.
+void Engine::issue_stage_a() {
+  const int B = B_, Ts = Ts_, T = Tg_;
   const long bsH = (long)H_ * Ts;
   auto V = [&](float* p, int ch) { return View{p, (long)ch * Ts, Ts}; };
   const View x = V(x_, H_), y = V(y_, H_), qkv = V(qkv_, 3 * H_), att = V(att_, H_), ffh = V(ffh_, FC_),
@@ -604,7 +625,7 @@ void Engine::run() {
   for (int b = 0; b < B; ++b) tsum += tlens_h_[b];
 
   // ================= speaker conditioning vectors
-  const float *cb_dp = nullptr, *cb_dec = nullptr;
+  const float* cb_dp = nullptr;
   if (nspk_ > 1) {
     auto cond = [&](const CondW& c, int off) {
       PE_LAUNCH(cond_kernel, dim3((c.rows + 127) / 128, B), dim3(128), 0, stream_, emb_g_, gin_, d_sids_, c.w, c.b,
@@ -614,13 +635,12 @@ void Engine::run() {
     for (size_t i = 0; i < cond_wn_.size(); ++i) cond(cond_wn_[i], cond_off_wn_[i]);
     cond(cond_dec_, cond_off_dec_);
     cb_dp = cond_ + cond_off_dp_;
-    cb_dec = cond_ + cond_off_dec_;
   }
 
   // ================= text encoder (models.py:198-209, attentions.py:60-74)
   prof_begin();
   double fl = 0;
-  PE_LAUNCH(embed_kernel, dim3((T + 63) / 64, B), dim3(64), 0, stream_, d_ids_, Ts, d_tlens_, emb_, H_,
+  PE_LAUNCH(embed_kernel, dim3((T + 63) / 64, (H_ + 15) / 16, B), dim3(64), 0, stream_, d_ids_, Ts, d_tlens_, emb_, H_,
             std::sqrt((float)H_), x_, (long)H_ * Ts, Ts);
   for (auto& e : enc_) {
     conv(e.qkv, x, qkv, d_tlens_, 1, T, EPI_STORE);
@@ -632,7 +652,7 @@ void Engine::run() {
     ap.SP = rup(T, 64) + 1;
     ap.qscale = 1.0f / std::sqrt((float)dk_);
     const int VS = dk_ + 1 + (dk_ & 1);
-    const size_t smem = ((size_t)ATT_QB * ap.SP + (size_t)ATT_KCH * VS) * sizeof(float);
+    const size_t smem = ((size_t)ATT_QB * ap.SP + (size_t)ATT_KCH * VS + (size_t)dk_ * ATT_QB) * sizeof(float);
     if (smem > 160 * 1024) throw std::runtime_error("utterance too long for the attention score tile");
     PE_LAUNCH(attn_kernel, dim3((T + ATT_QB - 1) / ATT_QB, nh_, B), dim3(256), smem, stream_, ap);
     conv(e.o, att, y, d_tlens_, 1, T, EPI_RESADD, 1.f, ACT_NONE, x);
@@ -657,8 +677,7 @@ void Engine::run() {
   // z = noise * noise_scale_w   [B][2][Ts]
   if (!have_noise_w_) {
     const long n = (long)B * 2 * Ts;
-    PE_LAUNCH(randn_kernel, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, stream_, noise_w_, n, seed_,
-              call_ * 2ull);
+    PE_LAUNCH(randn_kernel, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, stream_, noise_w_, n, d_rng_, 0);
   }
   PE_HIP(hipMemcpyAsync(z2_, noise_w_, (size_t)B * 2 * Ts * sizeof(float), hipMemcpyDeviceToDevice, stream_));
   {
@@ -687,22 +706,24 @@ void Engine::run() {
               scales_[1], d_tlens_, d_dur_, d_cum_, Ts, d_frames_, logw_);
   }
   PE_HIP(hipMemcpyAsync(h_frames_, d_frames_, B * sizeof(int), hipMemcpyDeviceToHost, stream_));
-  PE_HIP(hipStreamSynchronize(stream_));      // the only data-dependent shape: F (SURVEY.md section 8a row 5)
   prof_end(1, fl);
-  frames_h_.assign(h_frames_, h_frames_ + B);
-  int Fmax = 1;
+}
+
+// Length regulator, prior sample, coupling flow, HiFiGAN, int16 conversion -- sized by the bucketed
+// maximum frame count Fg_.
+void Engine::issue_stage_b() {
+  const int B = B_, Ts = Ts_, Fmax = Fg_, Fs = Fs_;
+  const View none{nullptr, 0, 0};
   double fsum = 0;
-  for (int b = 0; b < B; ++b) { Fmax = std::max(Fmax, frames_h_[b]); fsum += frames_h_[b]; }
-  Fmax_ = Fmax;
-  ensure_stage_b(Fmax);
-  const int Fs = Fs_;
+  for (int b = 0; b < B; ++b) fsum += frames_h_[b];
+  const float* cb_dec = nspk_ > 1 ? cond_ + cond_off_dec_ : nullptr;
+  double fl = 0;
 
   // ================= length regulator + prior noise + coupling flow (models.py:705-719)
   prof_begin();
-  fl = 0;
   if (have_noise_z_) {
     // rows of the caller's [B][C][z_stride] buffer -> [B][C][Fs]
-    if (h_noise_z_stride_ < Fmax) throw std::runtime_error("noise_z stride shorter than the frame count");
+    if (h_noise_z_stride_ < Fmax_) throw std::runtime_error("noise_z stride shorter than the frame count");
     for (int b = 0; b < B; ++b)
       for (int c = 0; c < C_; ++c)
         PE_HIP(hipMemcpyAsync(noise_z_ + ((size_t)b * C_ + c) * Fs,
@@ -710,8 +731,7 @@ void Engine::run() {
                               frames_h_[b] * sizeof(float), hipMemcpyHostToDevice, stream_));
   } else {
     const long n = (long)B * C_ * Fs;
-    PE_LAUNCH(randn_kernel, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, stream_, noise_z_, n, seed_,
-              call_ * 2ull + 1ull);
+    PE_LAUNCH(randn_kernel, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, stream_, noise_z_, n, d_rng_, 1);
   }
   {
     RegP rp;
@@ -720,7 +740,7 @@ void Engine::run() {
     rp.noise = noise_z_; rp.n_bs = (long)C_ * Fs; rp.n_cs = Fs;
     rp.noise_scale = scales_[0];
     rp.out = zp_; rp.o_bs = (long)C_ * Fs; rp.o_cs = Fs; rp.C = C_;
-    PE_LAUNCH(regulate_kernel, dim3((Fmax + 63) / 64, B), dim3(64), 0, stream_, rp);
+    PE_LAUNCH(regulate_kernel, dim3((Fmax + 63) / 64, (C_ + 15) / 16, B), dim3(64), 0, stream_, rp);
   }
   auto VF = [&](float* p, int ch) { return View{p, (long)ch * Fs, Fs}; };
   const View fh = VF(fh_, H_), facts = VF(facts_, H_), fskip = VF(fskip_, H_);
@@ -819,6 +839,66 @@ void Engine::run() {
     PE_LAUNCH(pcm16_kernel, dim3((Lmax + 255) / 256, B), dim3(256), 0, stream_, audio_, Ss_, absmax_, d_frames_, hop_,
               pcm_, Ss_);
     prof_end(4, 2.0 * fsum * hop_ * post_cin_ * K);
+  }
+}
+
+// hipGraph cache: the kernel sequence of a stage is captured once per shape bucket and replayed;
+// one utterance is ~160 short launches, which would otherwise be bound by host launch rate.
+void Engine::run_stage(char which, const std::string& key) {
+#ifndef PE_EMU
+  if (use_graphs_ && !prof_on_) {
+    auto it = graphs_.find(key);
+    if (it == graphs_.end()) {
+      hipGraph_t g = nullptr;
+      PE_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+      try {
+        if (which == 'A') issue_stage_a(); else issue_stage_b();
+      } catch (...) {
+        hipStreamEndCapture(stream_, &g);
+        if (g) hipGraphDestroy(g);
+        throw;
+      }
+      PE_HIP(hipStreamEndCapture(stream_, &g));
+      hipGraphExec_t ex = nullptr;
+      PE_HIP(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+      PE_HIP(hipGraphDestroy(g));
+      if (graphs_.size() > 64) drop_graphs();
+      it = graphs_.emplace(key, ex).first;
+    }
+    PE_HIP(hipGraphLaunch((hipGraphExec_t)it->second, stream_));
+    return;
+  }
+#endif
+  (void)key;
+  if (which == 'A') issue_stage_a(); else issue_stage_b();
+}
+
+void Engine::drop_graphs() {
+#ifndef PE_EMU
+  for (auto& kv : graphs_) hipGraphExecDestroy((hipGraphExec_t)kv.second);
+#endif
+  graphs_.clear();
+}
+
+void Engine::run() {
+  PE_HIP(hipSetDevice(device_));
+  const int B = B_;
+  Tg_ = std::min(rup(Tmax_, 32), Ts_);
+  char key[160];
+  snprintf(key, sizeof(key), "A|%d|%d|%d|%a|%a|%d", B, Tg_, Ts_, scales_[1], scales_[2], (int)have_noise_w_);
+  run_stage('A', key);
+  PE_HIP(hipStreamSynchronize(stream_));      // the only data-dependent shape: F (SURVEY.md section 8a row 5)
+  frames_h_.assign(h_frames_, h_frames_ + B);
+  int Fmax = 1;
+  for (int b = 0; b < B; ++b) Fmax = std::max(Fmax, frames_h_[b]);
+  Fmax_ = Fmax;
+  ensure_stage_b(rup(Fmax, 32));
+  Fg_ = std::min(rup(Fmax, 32), Fs_);
+  if (have_noise_z_) {
+    issue_stage_b();                           // host-injected noise (tests): not graph-captured
+  } else {
+    snprintf(key, sizeof(key), "B|%d|%d|%d|%d|%a", B, Fg_, Fs_, Ts_, scales_[0]);
+    run_stage('B', key);
   }
   sample_off_.assign(B + 1, 0);
   for (int b = 0; b < B; ++b) sample_off_[b + 1] = sample_off_[b] + (int64_t)frames_h_[b] * hop_;

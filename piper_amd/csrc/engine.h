@@ -3,6 +3,7 @@
 // (reference src/cpp/piper.cpp:386-388).
 #pragma once
 #include <cstdint>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -65,6 +66,7 @@ class Engine {
   void debug_tensor(const std::string& name, int b, std::vector<float>& out, int* rows, int* cols);
 
   void set_seed(uint64_t s) { seed_ = s; }
+  void set_use_graphs(bool on) { use_graphs_ = on; }
   void set_profile(bool on);
   const std::vector<ProfileRow>& profile() const { return prof_; }
   void reset_profile();
@@ -97,6 +99,10 @@ class Engine {
   void layer_norm(int mode, View in, View res, View out, const float* g, const float* b, const float* dw_w,
                   const float* dw_b, int dw_k, int dw_dil, int C, const int* lens, int Lmax);
   void dds(const DdsW& d, View x, View tmp1, View tmp2);
+  void issue_stage_a();
+  void issue_stage_b();
+  void run_stage(char which, const std::string& key);
+  void drop_graphs();
   void prof_begin();
   void prof_end(int row, double flops);
 
@@ -147,7 +153,10 @@ class Engine {
   int gin_ = 0, nspk_ = 1;
 
   // per-call state
-  int B_ = 0, Tmax_ = 0, Ts_ = 0, Fmax_ = 0, Fs_ = 0;
+  int B_ = 0, Tmax_ = 0, Ts_ = 0, Fmax_ = 0, Fs_ = 0, Tg_ = 0, Fg_ = 0;
+  bool use_graphs_ = true;
+  std::map<std::string, void*> graphs_;       // hipGraphExec_t per (stage, shape bucket, scales)
+  unsigned long long* d_rng_ = nullptr;       // {seed, call counter} read by randn_kernel
   float scales_[3] = {0.667f, 1.0f, 0.8f};
   bool have_noise_w_ = false, have_noise_z_ = false;
   std::vector<int64_t> id_off_;

@@ -254,14 +254,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
 
 // Same GEMM for launches that would otherwise fill only a few CUs (one utterance through the text
 // encoder / duration predictor / flow: 128..500 columns): one 32*MT x 32 output tile per workgroup
-// and the workgroup's four waves split the K-chunks between them (wave w takes chunks w, w+4, ...),
+// and the workgroup's NW (4 or 8) waves split the K-chunks between them (wave w takes chunks w, w+NW, ...),
 // each with a private x slab in LDS and the same A ping-pong; partial tiles are summed through LDS in
 // a fixed order (deterministic) and wave-striped through the shared epilogue.
-template <int MT, bool GATE>
-__global__ __launch_bounds__(256) void conv_splitk_kernel(ConvP p) {
+template <int MT, bool GATE, int NW>
+__global__ __launch_bounds__(64 * NW) void conv_splitk_kernel(ConvP p) {
   constexpr int BN = 32;
   constexpr int NCOL = 1;                         // private slab: 32 + halo <= 64 columns
-  PE_DYN_SMEM(float, sm);                         // max(4 x [KC][XW], 4 x MT x 16 x 64)
+  PE_DYN_SMEM(float, sm);                         // max(NW x [KC][XW], NW x MT x 16 x 64)
   const int b = blockIdx.z;
   const int L = p.lens[b] * p.len_mul;
   const int ncols = (p.epi == EPI_CONVT) ? L + 1 : L;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void conv_splitk_kernel(ConvP p) {
   const long wstride_mt = (long)nchunks * ntaps * (KC / 2) * 64;
   const float* wbase = p.wp + (long)mtile0 * wstride_mt + lane;
   float* xw = sm + wv * KC * XW;                  // this wave's slab
-  const int myc = (nchunks - wv + 3) / 4;         // chunks wv, wv+4, ...
+  const int myc = (nchunks - wv + NW - 1) / NW;   // chunks wv, wv+NW, ...
   const int nunits = myc * ntaps;
 
   float xr[KC][NCOL];
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void conv_splitk_kernel(ConvP p) {
   };
   auto load_a = [&](int u, float (&a)[KC / 2][MT]) {
     const int k = u / ntaps, tap = u - k * ntaps;
-    const int c = wv + 4 * k;
+    const int c = wv + NW * k;
     const float* wt = wbase + ((long)c * ntaps + tap) * (KC / 2) * 64;
 #pragma unroll
     for (int kk = 0; kk < KC / 2; ++kk)
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256) void conv_splitk_kernel(ConvP p) {
       PE_WAVE_SYNC();             // all lanes done reading the previous slab
       store_x();
       PE_WAVE_SYNC();
-      if (k + 1 < myc) load_x(wv + 4 * (k + 1));
+      if (k + 1 < myc) load_x(wv + NW * (k + 1));
     }
     if (u + 1 < nunits) load_a(u + 1, nxt);
     mma(tap, cur);
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void conv_splitk_kernel(ConvP p) {
   }
   // ---- cross-wave reduction through LDS (fixed order w = 0..3)
   __syncthreads();
-  float* red = sm;                                // [4 waves][MT*16 slots][64 lanes]
+  float* red = sm;                                // [NW waves][MT*16 slots][64 lanes]
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -366,9 +366,9 @@ __global__ __launch_bounds__(256) void conv_splitk_kernel(ConvP p) {
   __syncthreads();
   const int col = n0 + l31;
   if constexpr (GATE) {
-    for (int r = wv; r < 16; r += 4) {
+    for (int r = wv; r < 16; r += NW) {
       float ta = 0.f, sa = 0.f;
-      for (int w = 0; w < 4; ++w) {
+      for (int w = 0; w < NW; ++w) {
         ta += red[(w * MT * 16 + r) * 64 + lane];
         sa += red[(w * MT * 16 + (MT - 1) * 16 + r) * 64 + lane];
       }
@@ -377,9 +377,9 @@ __global__ __launch_bounds__(256) void conv_splitk_kernel(ConvP p) {
     }
     return;
   }
-  for (int s = wv; s < MT * 16; s += 4) {
+  for (int s = wv; s < MT * 16; s += NW) {
     float v = 0.f;
-    for (int w = 0; w < 4; ++w) v += red[(w * MT * 16 + s) * 64 + lane];
+    for (int w = 0; w < NW; ++w) v += red[(w * MT * 16 + s) * 64 + lane];
     const int i = s >> 4, r = s & 15;
     const int row = (mtile0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
     if (row < p.rows && col < ncols) conv_store(p, epi_flags(p), b, row, col, v, L);
@@ -390,13 +390,16 @@ __global__ __launch_bounds__(256) void conv_splitk_kernel(ConvP p) {
 // Text-encoder embedding: x[b][h][t] = emb[id][h] * sqrt(H)  (models.py:199-200)
 __global__ void embed_kernel(const int* ids, int ids_bs, const int* lens, const float* emb, int H,
                              float scale, float* out, long o_bs, int o_cs) {
-  const int b = blockIdx.y;
+  const int b = blockIdx.z;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= lens[b]) return;
   const int id = ids[b * ids_bs + t];
   const float* e = emb + (long)id * H;
   float* o = out + (long)b * o_bs + t;
-  for (int h = 0; h < H; ++h) o[(long)h * o_cs] = e[h] * scale;
+  const int h0 = blockIdx.y * 16;
+#pragma unroll
+  for (int k = 0; k < 16; ++k)
+    if (h0 + k < H) o[(long)(h0 + k) * o_cs] = e[h0 + k] * scale;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -435,6 +438,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
   const int SP = p.SP, VS = dk + 1 + (dk & 1);       // odd strides -> conflict-free column reads
   float* S = sm;                                      // [32][SP]
   float* Vt = S + ATT_QB * SP;                        // [KCH][VS]
+  float* Qs = Vt + ATT_KCH * VS;                      // [dk][32], scaled by 1/sqrt(dk)
   const float* qb = p.qkv + (long)b * p.q_bs + (long)(h * dk) * p.q_cs;
   const float* kb = qb + (long)p.H * p.q_cs;
   const float* vb = kb + (long)p.H * p.q_cs;
@@ -442,24 +446,26 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
   const int nk2 = dk / 2;                             // MFMA k-steps over channels (dk even)
 
   // ---- 1. scores
+  for (int e = tid; e < dk * ATT_QB; e += 256) {
+    const int d = e >> 5, i = e & 31;
+    Qs[e] = (i0 + i < T) ? qb[(long)d * p.q_cs + i0 + i] * p.qscale : 0.f;
+  }
+  __syncthreads();
   {
-    float qf[ATT_MAXDK / 2];
-    const bool qok = i0 + l31 < T;
-#pragma unroll
-    for (int s2 = 0; s2 < ATT_MAXDK / 2; ++s2)
-      qf[s2] = (s2 < nk2 && qok) ? qb[(long)(2 * s2 + lhi) * p.q_cs + i0 + l31] * p.qscale : 0.f;
     for (int kt = wv; kt < nkt; kt += 4) {
       const int j = kt * 32 + l31;
       const bool kok = j < T;
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll 8
-      for (int s2 = 0; s2 < ATT_MAXDK / 2; ++s2) {
-        if (s2 < nk2) {
-          const float kf = kok ? kb[(long)(2 * s2 + lhi) * p.q_cs + j] : 0.f;
-          acc = pe_mfma_32x32x2(qf[s2], kf, acc);
-        }
+      for (int s0 = 0; s0 < nk2; s0 += 16) {           // 16 independent K-fragment loads in flight
+        float kf[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          kf[u] = (kok && s0 + u < nk2) ? kb[(long)(2 * (s0 + u) + lhi) * p.q_cs + j] : 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u)
+          if (s0 + u < nk2) acc = pe_mfma_32x32x2(Qs[(2 * (s0 + u) + lhi) * ATT_QB + l31], kf[u], acc);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) S[((r & 3) + 8 * (r >> 2) + 4 * lhi) * SP + kt * 32 + l31] = acc[r];
@@ -473,7 +479,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
     const int j = i0 + i + r - p.window;
     if (i0 + i < T && j >= 0 && j < T) {
       float s = 0.f;
-      for (int d = 0; d < dk; ++d) s = fmaf(qb[(long)d * p.q_cs + i0 + i] * p.qscale, p.relk[r * dk + d], s);
+      for (int d = 0; d < dk; ++d) s = fmaf(Qs[d * ATT_QB + i], p.relk[r * dk + d], s);
       S[i * SP + j] += s;
     }
   }
@@ -505,9 +511,18 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
     for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
     for (int j0 = 0; j0 < T; j0 += ATT_KCH) {
       __syncthreads();                                // previous chunk consumed / softmax finished
-      for (int e = tid; e < dk * ATT_KCH; e += 256) {
-        const int d = e / ATT_KCH, jj = e % ATT_KCH;
-        Vt[jj * VS + d] = (j0 + jj < T) ? vb[(long)d * p.q_cs + j0 + jj] : 0.f;
+      {
+        // thread -> (key jj = tid&63, channel group tid>>6): 8 independent row loads per pass
+        const int jj = tid & 63;
+        const bool jok = j0 + jj < T;
+        for (int d0 = (tid >> 6) * 8; d0 < dk; d0 += 32) {
+          float vv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) vv[u] = (jok && d0 + u < dk) ? vb[(long)(d0 + u) * p.q_cs + j0 + jj] : 0.f;
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (d0 + u < dk) Vt[jj * VS + d0 + u] = vv[u];
+        }
       }
       __syncthreads();
       if (dt < ndt) {
@@ -757,7 +772,7 @@ struct RegP {
   int C;
 };
 __global__ void regulate_kernel(RegP p) {
-  const int b = blockIdx.y;
+  const int b = blockIdx.z;
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   const int F = p.frames[b], T = p.tlens[b];
   if (f >= F) return;
@@ -769,7 +784,9 @@ __global__ void regulate_kernel(RegP p) {
   }
   const bool hit = lo < T;                 // false only when every duration is 0 (frames clamped to 1)
   const float* sb = p.stats + (long)b * p.s_bs + lo;
-  for (int c = 0; c < p.C; ++c) {
+  const int c0 = blockIdx.y * 16;
+#pragma unroll 8
+  for (int c = c0; c < c0 + 16 && c < p.C; ++c) {
     const float m = hit ? sb[(long)c * p.s_cs] : 0.f;
     const float lg = hit ? sb[(long)(p.C + c) * p.s_cs] : 0.f;
     const float nz = p.noise ? p.noise[(long)b * p.n_bs + (long)c * p.n_cs + f] : 0.f;
@@ -792,12 +809,26 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* x, long x_b
   float* tile = sm + Cin * K;
   const int W = 256 + K - 1, pad = (K - 1) / 2, tid = threadIdx.x;
   for (int e = tid; e < Cin * K; e += 256) ws[e] = w[e];
-  for (int c = 0; c < Cin; ++c)
-    for (int col = tid; col < W; col += 256) {
-      const int t = t0 + col - pad;
-      float v = (t >= 0 && t < L) ? x[(long)b * x_bs + (long)c * x_cs + t] : 0.f;
-      tile[c * W + col] = v > 0.f ? v : v * slope;
+  {
+    // rows handled 8 at a time so 8 (x2 with the halo column) independent loads are in flight per thread
+    const float* xb = x + (long)b * x_bs;
+    for (int c0 = 0; c0 < Cin; c0 += 8) {
+      float v0[8], v1[8];
+      const int ta = t0 + tid - pad, tb = ta + 256;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const bool cok = c0 + k < Cin;
+        v0[k] = (cok && ta >= 0 && ta < L) ? xb[(long)(c0 + k) * x_cs + ta] : 0.f;
+        v1[k] = (cok && tid + 256 < W && tb >= 0 && tb < L) ? xb[(long)(c0 + k) * x_cs + tb] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (c0 + k < Cin) {
+          tile[(c0 + k) * W + tid] = v0[k] > 0.f ? v0[k] : v0[k] * slope;
+          if (tid + 256 < W) tile[(c0 + k) * W + tid + 256] = v1[k] > 0.f ? v1[k] : v1[k] * slope;
+        }
     }
+  }
   __syncthreads();
   const int t = t0 + tid;
   float v = 0.f;
@@ -840,9 +871,12 @@ __device__ __forceinline__ void philox4x32(unsigned c0, unsigned c1, unsigned c2
   }
   o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
 }
-__global__ void randn_kernel(float* out, long n, unsigned long long seed, unsigned long long stream) {
+// state = {seed, call counter} in device memory (so a captured graph draws fresh noise on replay);
+// site 0 = duration noise, 1 = prior noise.
+__global__ void randn_kernel(float* out, long n, const unsigned long long* state, int site) {
   const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i4 >= n) return;
+  const unsigned long long seed = state[0], stream = state[1] * 2ull + (unsigned long long)site;
   unsigned r[4];
   philox4x32((unsigned)(i4 >> 2), (unsigned)((unsigned long long)(i4 >> 2) >> 32), (unsigned)stream,
              (unsigned)(stream >> 32), (unsigned)seed, (unsigned)(seed >> 32), r);
