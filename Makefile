@@ -16,7 +16,7 @@ $(LIB): $(SRCS) $(HDRS)
 emu: $(EMULIB)
 
 $(EMULIB): $(SRCS) $(HDRS) tests/emu/hip_emu.cpp tests/emu/hip_emu.h
-	$(CXX_EMU) -DPE_EMU -O2 -g -std=c++17 -fPIC -shared -Itests/emu $(SRCS) tests/emu/hip_emu.cpp -o $@
+	$(CXX_EMU) -DPE_EMU -O2 -g -std=c++17 -Wno-psabi -fPIC -shared -Itests/emu $(SRCS) tests/emu/hip_emu.cpp -o $@
 
 clean:
 	rm -f $(LIB) $(EMULIB)

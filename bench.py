@@ -62,18 +62,12 @@ def main():
         wts, blob = None, None
     t_bcast = 0.0
     if world > 1:
-        n = torch.tensor([len(blob) if rank == 0 else 0], dtype=torch.int64, device="cuda")
-        dist.broadcast(n, 0)
-        buf = torch.empty(int(n.item()), dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            buf.copy_(torch.frombuffer(bytearray(blob), dtype=torch.uint8))
+        from piper_amd.dist import broadcast_blob
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        dist.broadcast(buf, 0)
+        blob = broadcast_blob(blob, 0, torch.device("cuda", local_rank))   # RCCL over xGMI
         torch.cuda.synchronize()
         t_bcast = time.perf_counter() - t0
-        if rank != 0:
-            blob = buf.cpu().numpy().tobytes()
     eng = Engine(blob=blob, device=local_rank)
 
     # ---- synthetic input, resident in HBM before timing

@@ -1,0 +1,108 @@
+"""Multi-GPU synthesis: one process per GPU, utterances sharded across ranks, no data-path
+collective. The only communication is at load time: rank 0 parses the voice
+(.onnx -> weight blob) and broadcasts the blob to the other ranks over RCCL (torch.distributed's
+"nccl" backend on ROCm, xGMI on an MI355X node); every rank then builds its own engine from the blob.
+Results are gathered to rank 0 in the caller's order.
+
+The reference has no multi-device path at all (piper.cpp loops over phrases sequentially); this is
+the MI355X-native extension BASELINE.json's configs[3] asks for."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+
+def shard_indices(costs: Sequence[int], world: int) -> List[List[int]]:
+    """Deterministic longest-processing-time assignment of utterances to ranks by cost (phoneme-id
+    count, a proxy for frames): every rank computes the same table. Returns per-rank index lists,
+    each sorted in the original order."""
+    order = sorted(range(len(costs)), key=lambda i: (-int(costs[i]), i))
+    load = [0] * world
+    out: List[List[int]] = [[] for _ in range(world)]
+    for i in order:
+        r = min(range(world), key=lambda k: (load[k], k))
+        out[r].append(i)
+        load[r] += int(costs[i])
+    return [sorted(x) for x in out]
+
+
+def broadcast_blob(blob: Optional[bytes], src: int = 0, device=None) -> bytes:
+    """Broadcast the weight blob from rank `src`. With the nccl backend the payload travels GPU to GPU
+    (RCCL over xGMI); with gloo (CPU tests) through host memory."""
+    import torch
+    import torch.distributed as dist
+    rank = dist.get_rank()
+    backend = dist.get_backend()
+    dev = torch.device("cpu")
+    if backend == "nccl":
+        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    n = torch.tensor([len(blob) if rank == src else 0], dtype=torch.int64, device=dev)
+    dist.broadcast(n, src)
+    if rank == src:
+        buf = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev)
+    else:
+        buf = torch.empty(int(n.item()), dtype=torch.uint8, device=dev)
+    dist.broadcast(buf, src)
+    return blob if rank == src else buf.cpu().numpy().tobytes()
+
+
+def onnx_to_blob(onnx_path: str, lib=None) -> bytes:
+    from . import _lib as L
+    lib = lib if lib is not None else L.get_lib()
+    blob, n = C.c_void_p(), C.c_size_t()
+    if lib.pe_onnx_to_blob(str(onnx_path).encode(), C.byref(blob), C.byref(n)):
+        raise RuntimeError(lib.pe_last_error().decode(errors="replace"))
+    try:
+        return C.string_at(blob, n.value)
+    finally:
+        lib.pe_free(blob)
+
+
+class ShardedSynthesizer:
+    """Utterance-parallel synthesis over the ranks of an initialised torch.distributed group."""
+
+    def __init__(self, onnx_path: Optional[str] = None, blob: Optional[bytes] = None, device: Optional[int] = None,
+                 lib=None):
+        import torch.distributed as dist
+        from .engine import Engine
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        if self.rank == 0:
+            if blob is None:
+                if onnx_path is None:
+                    raise ValueError("rank 0 needs onnx_path or blob")
+                blob = onnx_to_blob(onnx_path, lib)
+        blob = broadcast_blob(blob if self.rank == 0 else None, 0)
+        if device is None:
+            import torch
+            device = torch.cuda.current_device() if dist.get_backend() == "nccl" else 0
+        self.engine = Engine(blob=blob, device=device, lib=lib)
+
+    def synthesize(self, id_lists: Sequence[Sequence[int]], scales=(0.667, 1.0, 0.8), sids=None,
+                   noise_w=None, noise_z=None) -> Optional[List[np.ndarray]]:
+        """Every rank passes the same id_lists; returns the int16 PCM of every utterance on rank 0
+        (None elsewhere). Optional injected noise is indexed like id_lists."""
+        import torch.distributed as dist
+        shards = shard_indices([len(x) for x in id_lists], self.world)
+        mine = shards[self.rank]
+        local = []
+        if mine:
+            kw = {}
+            if sids is not None:
+                kw["sids"] = [sids[i] for i in mine]
+            if noise_w is not None:
+                kw["noise_w"] = np.ascontiguousarray(np.asarray(noise_w)[mine])
+            if noise_z is not None:
+                kw["noise_z"] = np.ascontiguousarray(np.asarray(noise_z)[mine])
+            r = self.engine.synthesize_batch([id_lists[i] for i in mine], scales, **kw)
+            local = r.pcm
+        gathered = [None] * self.world if self.rank == 0 else None
+        dist.gather_object(list(zip(mine, local)), gathered, dst=0)
+        if self.rank != 0:
+            return None
+        out: List[Optional[np.ndarray]] = [None] * len(id_lists)
+        for part in gathered:
+            for i, pcm in part:
+                out[i] = pcm
+        return out  # type: ignore[return-value]

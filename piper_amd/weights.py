@@ -159,6 +159,12 @@ def preset(name: str, **over) -> ArchConfig:
                        resblock=1, rb_kernel_sizes=(3, 7, 11),
                        rb_dilations=((1, 3, 5), (1, 3, 5), (1, 3, 5)),
                        up_rates=(8, 8, 2, 2), up_kernel_sizes=(16, 16, 4, 4), sample_rate=16000)
+    elif name == "tiny-high-ms":
+        c = ArchConfig(n_vocab=40, hidden=32, inter=32, filter=64, n_layers=2, up_initial=64,
+                       resblock=1, rb_kernel_sizes=(3, 7, 11),
+                       rb_dilations=((1, 3, 5), (1, 3, 5), (1, 3, 5)),
+                       up_rates=(8, 8, 2, 2), up_kernel_sizes=(16, 16, 4, 4), n_speakers=4, gin=16,
+                       sample_rate=16000)
     elif name == "tiny-ms":
         c = ArchConfig(n_vocab=40, hidden=32, inter=32, filter=64, n_layers=2, up_initial=64,
                        n_speakers=4, gin=16, sample_rate=16000)

@@ -171,3 +171,32 @@ def test_pcm_peak_normalised_like_reference():
     assert np.max(np.abs(r.pcm[0].astype(np.int32))) == 32767
     from oracle import vits_oracle as O
     assert np.max(np.abs(O.audio_float_to_int16(r.audio[0]).astype(np.int32) - r.pcm[0].astype(np.int32))) <= 1
+
+
+def test_piper_voice_loads_reference_export_and_matches_oracle(tmp_path):
+    """The drop-in path end to end: a .onnx written by the reference's export code + its .onnx.json ->
+    PiperVoice.load (pe_create parses the file on the host, packs, uploads) -> synthesize_ids_to_raw."""
+    import json
+    import wave
+    from oracle import vits_oracle as O
+    from piper_amd.voice import PiperVoice
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    voice = PiperVoice.load(os.path.join(gold, "tinyhms_voice.onnx"))
+    assert voice.config.num_speakers == 4 and voice.config.sample_rate == 16000
+    cfg = W.preset("tiny-high-ms")
+    w = W.synthetic_weights(cfg, 1234)
+    ids = W.synthetic_phoneme_ids(20, 1, id_max=cfg.n_vocab - 1).tolist()
+    raw = voice.synthesize_ids_to_raw(ids, speaker_id=3, noise_scale=0.0, noise_w=0.0)
+    pcm = np.frombuffer(raw, np.int16)
+    o = O.synthesize(w, cfg, ids, (0.0, 1.0, 0.0), sid=3)
+    assert pcm.shape == o["pcm"].shape and pcm_rms(pcm, o["pcm"]) <= RMS_TOL
+    # mirror of the reference's only test (src/cpp/test.cpp:15-60): text -> WAV, file must not be tiny
+    tv = PiperVoice.load(os.path.join(gold, "tiny_voice.onnx"))
+    path = str(tmp_path / "test.wav")
+    with wave.open(path, "wb") as wf:
+        tv.synthesize("This is a test.", wf, sentence_silence=0.1)
+    assert os.path.getsize(path) >= 10000
+    with wave.open(path, "rb") as wf:
+        assert (wf.getframerate(), wf.getsampwidth(), wf.getnchannels()) == (16000, 2, 1)
+    batch = tv.synthesize_ids_batch_to_raw([ids, ids[:9] + [2]], noise_scale=0.0, noise_w=0.0)
+    assert len(batch) == 2 and len(batch[0]) > len(batch[1]) > 0

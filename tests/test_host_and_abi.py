@@ -1,0 +1,111 @@
+"""CPU tests of the boundary: the C-ABI library loads and exports every symbol of
+include/piper_hip.h, the .onnx loader (host code, no GPU) recovers the canonical weights from files
+written by the reference's own export path, the voice config and phoneme-id logic match the
+reference's known-answer data. No compute calls."""
+import ctypes as C
+import dataclasses
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+from piper_amd import _lib as L
+from piper_amd import weights as W
+from piper_amd.config import PhonemeType, PiperConfig
+from piper_amd.voice import BOS, EOS, PAD, PiperVoice, phonemes_to_ids_cpp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    if not os.path.exists(L.LIB_PATH):
+        import subprocess
+        subprocess.check_call(["make", "-C", ROOT, "all"])
+    return L.get_lib()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    header = open(os.path.join(ROOT, "include", "piper_hip.h")).read()
+    declared = set(re.findall(r"\b(pe_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(L.SYMBOLS)
+    for s in declared:
+        assert hasattr(lib, s), s
+
+
+def _onnx_to_blob(lib, path):
+    blob, n = C.c_void_p(), C.c_size_t()
+    rc = lib.pe_onnx_to_blob(path.encode(), C.byref(blob), C.byref(n))
+    if rc:
+        raise RuntimeError(lib.pe_last_error().decode())
+    data = C.string_at(blob, n.value)
+    lib.pe_free(blob)
+    return data
+
+
+@pytest.mark.parametrize("stem,preset", [("tiny_voice", "tiny"), ("tinyhms_voice", "tiny-high-ms")])
+def test_onnx_loader_recovers_canonical_weights(lib, stem, preset):
+    """Files produced by the reference's export path (oracle/make_voice.py): text embedding named
+    'sid', anonymous weight-norm-folded flow weights, folded exp(-logs), ResBlock1/2, speaker cond."""
+    cfg2, w2 = W.unpack_blob(_onnx_to_blob(lib, os.path.join(GOLD, stem + ".onnx")))
+    cfg = W.preset(preset)
+    assert dataclasses.replace(cfg2, sample_rate=cfg.sample_rate) == cfg      # rate lives in the .json
+    w = W.synthetic_weights(cfg, 1234)
+    assert set(w2) == set(w)
+    for k in w:
+        assert w2[k].shape == w[k].shape, k
+        assert np.max(np.abs(w2[k] - w[k])) <= 1e-6, k      # weight_norm fold g*v/|v| rounding only
+
+
+def test_onnx_loader_errors(lib, tmp_path):
+    with pytest.raises(RuntimeError, match="cannot open"):
+        _onnx_to_blob(lib, str(tmp_path / "missing.onnx"))
+    junk = tmp_path / "junk.onnx"
+    junk.write_bytes(b"\x00\x01garbage" * 100)
+    with pytest.raises(RuntimeError):
+        _onnx_to_blob(lib, str(junk))
+    good = open(os.path.join(GOLD, "tiny_voice.onnx"), "rb").read()
+    cut = tmp_path / "cut.onnx"
+    cut.write_bytes(good[: len(good) // 2])
+    with pytest.raises(RuntimeError):
+        _onnx_to_blob(lib, str(cut))
+
+
+def test_blob_parser_rejects_bad_input(lib):
+    h = C.c_void_p()
+    bad = b"PEBLOB01" + b"\x00" * 64
+    assert lib.pe_create_from_blob(bad, len(bad), 0, C.byref(h)) != 0
+    assert b"blob" in lib.pe_last_error() or b"truncated" in lib.pe_last_error()
+
+
+def test_config_parse_matches_reference_rules():
+    conf = json.load(open(os.path.join(GOLD, "tiny_voice.onnx.json")))
+    c = PiperConfig.from_dict(conf)
+    assert (c.sample_rate, c.num_speakers, c.num_symbols) == (16000, 1, 40)
+    assert (c.noise_scale, c.length_scale, c.noise_w) == (0.667, 1, 0.8)
+    assert c.phoneme_type == PhonemeType.TEXT
+    minimal = {"num_symbols": 5, "num_speakers": 1, "audio": {"sample_rate": 22050}, "espeak": {"voice": "en-us"},
+               "phoneme_id_map": {"_": [0], "^": [1], "$": [2]}}
+    d = PiperConfig.from_dict(minimal)         # defaults of config.py:41-52
+    assert (d.noise_scale, d.length_scale, d.noise_w, d.phoneme_type) == (0.667, 1.0, 0.8, PhonemeType.ESPEAK)
+    with pytest.raises(KeyError):
+        PiperConfig.from_dict({"num_symbols": 5})
+
+
+def test_phonemes_to_ids_against_reference_fixture():
+    """etc/test_sentences/test_en-us.jsonl pins the C++ rule [^, _, (id, _)*, $]."""
+    g = json.load(open(os.path.join(GOLD, "phoneme_ids_en-us.json"), encoding="utf-8"))
+    assert len(g["rows"]) >= 3
+    for row in g["rows"]:
+        assert phonemes_to_ids_cpp(row["phonemes"], g["phoneme_id_map"]) == row["phoneme_ids"]
+    # the Python runtime's variant (voice.py:72-87) drops the PAD after BOS
+    v = PiperVoice(session=None, config=PiperConfig(0, 1, 16000, "en-us", 1.0, 0.667, 0.8, g["phoneme_id_map"],
+                                                    PhonemeType.ESPEAK))
+    row = g["rows"][0]
+    py = v.phonemes_to_ids(row["phonemes"])
+    assert py == [row["phoneme_ids"][0]] + row["phoneme_ids"][2:]
+    assert v.phonemes_to_ids(["☃"]) == g["phoneme_id_map"][BOS] + g["phoneme_id_map"][EOS]   # unknown skipped
+    assert PAD in g["phoneme_id_map"] and EOS in g["phoneme_id_map"]
