@@ -3,8 +3,8 @@ ROCM ?= /opt/rocm
 HIPCC ?= $(ROCM)/bin/hipcc
 CXX_EMU ?= $(ROCM)/lib/llvm/bin/clang++
 CSRC := piper_amd/csrc
-SRCS := $(CSRC)/engine.cpp $(CSRC)/pe_api.cpp $(CSRC)/weights.cpp $(CSRC)/onnx_reader.cpp
-HDRS := $(CSRC)/engine.h $(CSRC)/kernels.h $(CSRC)/pe_rt.h $(CSRC)/weights.h include/piper_hip.h
+SRCS := $(CSRC)/engine.cpp $(CSRC)/pe_api.cpp $(CSRC)/weights.cpp $(CSRC)/onnx_reader.cpp $(CSRC)/piper_shim.cpp
+HDRS := include/piper.hpp $(CSRC)/engine.h $(CSRC)/kernels.h $(CSRC)/pe_rt.h $(CSRC)/weights.h include/piper_hip.h
 LIB := piper_amd/libpiper_hip.so
 EMULIB := tests/emu/libpiper_hip_emu.so
 
@@ -18,6 +18,12 @@ emu: $(EMULIB)
 $(EMULIB): $(SRCS) $(HDRS) tests/emu/hip_emu.cpp tests/emu/hip_emu.h
 	$(CXX_EMU) -DPE_EMU -O2 -g -std=c++17 -Wno-psabi -fPIC -shared -Itests/emu $(SRCS) tests/emu/hip_emu.cpp -o $@
 
+# C++ callers of the piper:: API (mirror of the reference's test.cpp)
+tests/cpp/test_piper: tests/cpp/test_piper.cpp $(LIB) include/piper.hpp
+	g++ -O1 -std=c++17 -Iinclude tests/cpp/test_piper.cpp -o $@ -Lpiper_amd -lpiper_hip -Wl,-rpath,'$$ORIGIN/../../piper_amd'
+tests/cpp/test_piper_emu: tests/cpp/test_piper.cpp $(EMULIB) include/piper.hpp
+	g++ -O1 -std=c++17 -Iinclude tests/cpp/test_piper.cpp -o $@ -Ltests/emu -lpiper_hip_emu -Wl,-rpath,'$$ORIGIN/../emu'
+
 clean:
-	rm -f $(LIB) $(EMULIB)
+	rm -f $(LIB) $(EMULIB) tests/cpp/test_piper tests/cpp/test_piper_emu
 .PHONY: all emu clean

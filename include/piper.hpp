@@ -1,0 +1,145 @@
+// piper.hpp -- the reference's C++ API surface for the synthesis path, re-hosted on the MI355X engine.
+//
+// Same namespace, type names, function names, argument meaning and error behaviour (std::runtime_error)
+// as the reference's src/cpp/piper.hpp:20-128 + piper.cpp:337, so existing callers (the reference's
+// main.cpp loop, test.cpp) compile against it unchanged in spirit. What changed:
+//   * ModelSession no longer wraps Ort::Session/Env/Options; it holds an opaque pe_engine* (piper_hip.h);
+//   * the vendored nlohmann json / utf8 / piper-phonemize headers are not needed by this header
+//     (config parsing uses a small built-in JSON reader; Phoneme/PhonemeId are defined here with the
+//     reference's types: char32_t / int64_t);
+//   * `useCuda` selects the GPU path; false is rejected (this library has no CPU path);
+//   * espeak-ng / libtashkeel phonemisation stays host-side and is not linked: voices with
+//     "phoneme_type": "text" are phonemised natively (code points), eSpeak voices need ids from the
+//     caller (synthesize()) or a build with the reference's piper-phonemize.
+#ifndef PIPER_H_
+#define PIPER_H_
+
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <memory>
+#include <optional>
+#include <ostream>
+#include <string>
+#include <vector>
+
+struct pe_engine;
+
+namespace piper {
+
+typedef char32_t Phoneme;      // piper-phonemize/phoneme_ids.hpp
+typedef int64_t PhonemeId;
+typedef int64_t SpeakerId;
+
+struct eSpeakConfig {
+  std::string voice = "en-us";
+};
+
+struct PiperConfig {
+  std::string eSpeakDataPath;
+  bool useESpeak = true;
+  bool useTashkeel = false;
+  std::optional<std::string> tashkeelModelPath;
+};
+
+enum PhonemeType { eSpeakPhonemes, TextPhonemes };
+
+struct PhonemizeConfig {
+  PhonemeType phonemeType = eSpeakPhonemes;
+  std::optional<std::map<Phoneme, std::vector<Phoneme>>> phonemeMap;
+  std::map<Phoneme, std::vector<PhonemeId>> phonemeIdMap;
+
+  PhonemeId idPad = 0;  // padding (optionally interspersed)
+  PhonemeId idBos = 1;  // beginning of sentence
+  PhonemeId idEos = 2;  // end of sentence
+  bool interspersePad = true;
+
+  eSpeakConfig eSpeak;
+};
+
+struct SynthesisConfig {
+  // VITS inference settings
+  float noiseScale = 0.667f;
+  float lengthScale = 1.0f;
+  float noiseW = 0.8f;
+
+  // Audio settings
+  int sampleRate = 22050;
+  int sampleWidth = 2;  // 16-bit
+  int channels = 1;     // mono
+
+  // Speaker id from 0 to numSpeakers - 1
+  std::optional<SpeakerId> speakerId;
+
+  // Extra silence
+  float sentenceSilenceSeconds = 0.2f;
+  std::optional<std::map<piper::Phoneme, float>> phonemeSilenceSeconds;
+};
+
+struct ModelConfig {
+  int numSpeakers = 1;
+  std::optional<std::map<std::string, SpeakerId>> speakerIdMap;   // speaker name -> id
+};
+
+// Was: Ort::Session + allocator + options + env (reference piper.hpp:78-85).
+struct ModelSession {
+  pe_engine* engine = nullptr;
+  int device = 0;
+  ModelSession() = default;
+  ModelSession(const ModelSession&) = delete;
+  ModelSession& operator=(const ModelSession&) = delete;
+  ~ModelSession();
+};
+
+struct SynthesisResult {
+  double inferSeconds = 0;
+  double audioSeconds = 0;
+  double realTimeFactor = 0;
+};
+
+struct Voice {
+  std::string configText;        // raw .onnx.json (the reference keeps the parsed json root)
+  PhonemizeConfig phonemizeConfig;
+  SynthesisConfig synthesisConfig;
+  ModelConfig modelConfig;
+  ModelSession session;
+};
+
+// True if the string is a single UTF-8 codepoint
+bool isSingleCodepoint(std::string s);
+
+// Get the first UTF-8 codepoint of a string
+Phoneme getCodepoint(std::string s);
+
+// Get version of Piper
+std::string getVersion();
+
+// Must be called before using textTo* functions
+void initialize(PiperConfig &config);
+
+// Clean up
+void terminate(PiperConfig &config);
+
+// Load Onnx model and JSON config file
+void loadVoice(PiperConfig &config, std::string modelPath, std::string modelConfigPath, Voice &voice,
+               std::optional<SpeakerId> &speakerId, bool useCuda);
+
+// Phoneme ids to WAV audio: appends to audioBuffer (never clears it), fills result like piper.cpp:385-406
+void synthesize(std::vector<PhonemeId> &phonemeIds, SynthesisConfig &synthesisConfig, ModelSession &session,
+                std::vector<int16_t> &audioBuffer, SynthesisResult &result);
+
+// Phonemes -> ids with the piper-phonemize rule used at piper.cpp:555 (BOS, PAD, (id.., PAD)*, EOS)
+void phonemes_to_ids(const std::vector<Phoneme> &phonemes, const PhonemizeConfig &config,
+                     std::vector<PhonemeId> &phonemeIds, std::map<Phoneme, std::size_t> &missingPhonemes);
+
+// Phonemize text and synthesize audio
+void textToAudio(PiperConfig &config, Voice &voice, std::string text, std::vector<int16_t> &audioBuffer,
+                 SynthesisResult &result, const std::function<void()> &audioCallback);
+
+// Phonemize text and synthesize audio to WAV file
+void textToWavFile(PiperConfig &config, Voice &voice, std::string text, std::ostream &audioFile,
+                   SynthesisResult &result);
+
+}  // namespace piper
+
+#endif  // PIPER_H_

@@ -71,7 +71,8 @@ def export(preset: str, out_prefix: str, seed: int = 1234):
                                         "input_lengths": {0: "batch_size"},
                                         "output": {0: "batch_size", 1: "time"}})
     # voice config with the schema of etc/test_voice.onnx.json; a `text` voice over printable ASCII
-    chars = [chr(c) for c in range(32, 127) if chr(c) not in "_^$"][: cfg.n_vocab - 3]
+    pool = " abcdefghijklmnopqrstuvwxyz.,!?'-;:" + "".join(chr(c) for c in range(48, 91))
+    chars = list(dict.fromkeys(pool))[: cfg.n_vocab - 3]
     id_map = {"_": [0], "^": [1], "$": [2]}
     id_map.update({ch: [3 + i] for i, ch in enumerate(chars)})
     conf = {"audio": {"sample_rate": cfg.sample_rate}, "espeak": {"voice": "en-us"}, "phoneme_type": "text",

@@ -200,3 +200,16 @@ def test_piper_voice_loads_reference_export_and_matches_oracle(tmp_path):
         assert (wf.getframerate(), wf.getsampwidth(), wf.getnchannels()) == (16000, 2, 1)
     batch = tv.synthesize_ids_batch_to_raw([ids, ids[:9] + [2]], noise_scale=0.0, noise_w=0.0)
     assert len(batch) == 2 and len(batch[0]) > len(batch[1]) > 0
+
+
+def test_cpp_piper_api_on_gpu(tmp_path):
+    """tests/cpp/test_piper.cpp (mirror of the reference's src/cpp/test.cpp) against libpiper_hip.so."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", root, "tests/cpp/test_piper"], stdout=subprocess.DEVNULL)
+    wav = str(tmp_path / "t.wav")
+    out = subprocess.run([os.path.join(root, "tests", "cpp", "test_piper"),
+                          os.path.join(root, "tests", "golden", "tiny_voice.onnx"), wav],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr + out.stdout
+    assert out.stdout.startswith("OK ") and os.path.getsize(wav) >= 10000

@@ -109,3 +109,22 @@ def test_phonemes_to_ids_against_reference_fixture():
     assert py == [row["phoneme_ids"][0]] + row["phoneme_ids"][2:]
     assert v.phonemes_to_ids(["☃"]) == g["phoneme_id_map"][BOS] + g["phoneme_id_map"][EOS]   # unknown skipped
     assert PAD in g["phoneme_id_map"] and EOS in g["phoneme_id_map"]
+
+
+def test_cpp_piper_api_on_emulator(tmp_path):
+    """The reference-compatible C++ API (include/piper.hpp: loadVoice / textToWavFile / synthesize /
+    phonemes_to_ids) compiled against the emulator build: host logic only (JSON config parsing, UTF-8,
+    phrase/silence handling, WAV header, error propagation). The same program runs on the GPU in
+    tests/test_gpu_parity.py."""
+    import subprocess
+    import wave
+    subprocess.check_call(["make", "-C", ROOT, "emu", "tests/cpp/test_piper_emu"], stdout=subprocess.DEVNULL)
+    wav = str(tmp_path / "t.wav")
+    out = subprocess.run([os.path.join(ROOT, "tests", "cpp", "test_piper_emu"),
+                          os.path.join(GOLD, "tiny_voice.onnx"), wav], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.startswith("OK ") and "rate=16000" in out.stdout and "speakers=1" in out.stdout
+    assert "pid=7 missing=1" in out.stdout          # a, b mapped (+PADs), the snowman counted as missing
+    with wave.open(wav, "rb") as wf:
+        assert (wf.getframerate(), wf.getsampwidth(), wf.getnchannels()) == (16000, 2, 1)
+        assert wf.getnframes() * 2 + 44 == os.path.getsize(wav) >= 10000
