@@ -85,9 +85,11 @@ int pe_get_info(pe_engine* e, int32_t* sample_rate, int32_t* hop, int32_t* n_spe
 
 void pe_set_seed(pe_engine* e, uint64_t seed);
 
-/* Stage timing (HIP events on the engine's stream): rows text_encoder, duration_predictor,
- * regulate+flow, hifigan, post+pcm. ms/flops/launches accumulate until pe_profile_reset(). */
-int pe_profile_enable(pe_engine* e, int on);
+/* Timing with HIP events on the engine's stream. level 1: one pair per pipeline stage (rows
+ * text_encoder, duration_predictor, regulate+flow, hifigan, post+pcm). level 2: additionally one pair
+ * around every conv / attention / layer-norm launch (rows named after the kernel), with the launch's
+ * algorithmic FLOPs. ms/flops/launches accumulate until pe_profile_reset(); 0 switches it off. */
+int pe_profile_enable(pe_engine* e, int level);
 int pe_profile_reset(pe_engine* e);
 int pe_profile_rows(pe_engine* e);
 int pe_profile_get(pe_engine* e, int row, const char** name, double* ms, double* flops, int64_t* launches);

@@ -460,6 +460,14 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
 
   const int ncols = (epi == EPI_CONVT) ? Lmax + 1 : Lmax;
   int cfg = pc.cfg;
+  double kflops = 0;
+  if (prof_level_ >= 2) {
+    // algorithmic FLOPs of this launch: 2 * MACs per output column * valid columns over the batch
+    const std::vector<int32_t>& lh = (lens == d_tlens_) ? tlens_h_ : frames_h_;
+    double cols = 0;
+    for (int b = 0; b < B_; ++b) cols += (double)lh[b] * len_mul;
+    kflops = 2.0 * pc.macs_per_col * cols;
+  }
   const long blocks = (long)((ncols + CFG_BN[cfg] - 1) / CFG_BN[cfg]) * (pc.mtiles * 32 / CFG_BM[cfg]) * B_;
   if (blocks < 160 && p.xhalo <= 32) {
     // few columns (one utterance through encoder / duration predictor / flow): split K across the waves
@@ -467,6 +475,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     const int NW = pc.nchunks >= 5 ? 8 : 4;
     dim3 grid((ncols + 31) / 32, pc.mtiles / MT, B_);
     const size_t smem = std::max<size_t>((size_t)NW * KC * (32 + p.xhalo), (size_t)NW * MT * 16 * 64) * sizeof(float);
+    const int kh = kbegin(prof_level_ >= 2 ? krow("conv_splitk_kernel") : 0, kflops);
     if (pc.gate) {
       if (NW == 8) PE_LAUNCH((conv_splitk_kernel<2, true, 8>), grid, dim3(512), smem, stream_, p);
       else PE_LAUNCH((conv_splitk_kernel<2, true, 4>), grid, dim3(256), smem, stream_, p);
@@ -474,6 +483,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
       if (NW == 8) PE_LAUNCH((conv_splitk_kernel<1, false, 8>), grid, dim3(512), smem, stream_, p);
       else PE_LAUNCH((conv_splitk_kernel<1, false, 4>), grid, dim3(256), smem, stream_, p);
     }
+    kend(kh);
     return;
   }
   if (blocks < 192) {   // medium-small: smaller tiles, more workgroups
@@ -484,12 +494,16 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
   dim3 grid((ncols + BN - 1) / BN, pc.mtiles * 32 / BM, B_);
   if (p.xhalo > 128) throw std::runtime_error("conv halo (kernel-1)*dilation > 128 is not supported");
   const size_t smem = (size_t)2 * KC * (BN + p.xhalo) * sizeof(float);
+  static const char* knames[] = {"conv_mfma_kernel<2,2,2,2>", "conv_mfma_kernel<1,4,2,1>", "conv_mfma_kernel<1,4,1,1>",
+                                 "conv_mfma_kernel<2,2,1,1>", "conv_mfma_kernel<2,2,2,1>"};
+  const int kh = kbegin(prof_level_ >= 2 ? krow(knames[cfg]) : 0, kflops);
   if (pc.gate) {
     switch (cfg) {
       case CFG_A: PE_LAUNCH((conv_mfma_kernel<2, 2, 2, 2, 8, true>), grid, dim3(256), smem, stream_, p); break;
       case CFG_B: PE_LAUNCH((conv_mfma_kernel<1, 4, 2, 1, 16, true>), grid, dim3(256), smem, stream_, p); break;
       default:    PE_LAUNCH((conv_mfma_kernel<2, 2, 2, 1, 16, true>), grid, dim3(256), smem, stream_, p); break;
     }
+    kend(kh);
     return;
   }
   switch (cfg) {
@@ -499,6 +513,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     case CFG_S: PE_LAUNCH((conv_mfma_kernel<2, 2, 1, 1, 16, false>), grid, dim3(256), smem, stream_, p); break;
     default:    PE_LAUNCH((conv_mfma_kernel<2, 2, 2, 1, 16, false>), grid, dim3(256), smem, stream_, p); break;
   }
+  kend(kh);
 }
 
 void Engine::layer_norm(int mode, View in, View res, View out, const float* g, const float* b,
@@ -513,9 +528,11 @@ void Engine::layer_norm(int mode, View in, View res, View out, const float* g, c
   p.lens = lens; p.C = C;
   if (C > LN_COLS * 32) throw std::runtime_error("LayerNorm over more than 256 channels is not supported");
   dim3 grid((Lmax + LN_COLS - 1) / LN_COLS, B_);
+  const int kh = kbegin(prof_level_ >= 2 ? krow("ln_kernel") : 0, 0.0);
   if (mode == 0) PE_LAUNCH(ln_kernel<0>, grid, dim3(256), 0, stream_, p);
   else if (mode == 1) PE_LAUNCH(ln_kernel<1>, grid, dim3(256), 0, stream_, p);
   else PE_LAUNCH(ln_kernel<2>, grid, dim3(256), 0, stream_, p);
+  kend(kh);
 }
 
 // DDSConv.forward (modules.py:117-129) in place on x; tmp1/tmp2 are [B][H][Ts] scratch.
@@ -529,8 +546,51 @@ void Engine::dds(const DdsW& d, View x, View t1, View t2) {
   }
 }
 
-void Engine::set_profile(bool on) { prof_on_ = on; }
+void Engine::set_profile(int level) {
+  prof_level_ = level;
+  prof_on_ = level > 0;
+}
+int Engine::krow(const char* name) {
+  for (size_t i = 5; i < prof_.size(); ++i)
+    if (!strcmp(prof_[i].name, name)) return (int)i;
+  prof_.push_back(ProfileRow{name});
+  return (int)prof_.size() - 1;
+}
+int Engine::kbegin(int row, double flops) {
+  if (prof_level_ < 2) return -1;
+  hipEvent_t a, b;
+  if (ev_pool_.size() >= 2) {
+    a = ev_pool_.back(); ev_pool_.pop_back();
+    b = ev_pool_.back(); ev_pool_.pop_back();
+  } else {
+    PE_HIP(hipEventCreate(&a));
+    PE_HIP(hipEventCreate(&b));
+  }
+  PE_HIP(hipEventRecord(a, stream_));
+  kev_.push_back(KEvent{row, flops, a, b});
+  return (int)kev_.size() - 1;
+}
+void Engine::kend(int h) {
+  if (h >= 0) PE_HIP(hipEventRecord(kev_[h].b, stream_));
+}
+const std::vector<ProfileRow>& Engine::profile() {
+  if (!kev_.empty()) {
+    PE_HIP(hipStreamSynchronize(stream_));
+    for (auto& k : kev_) {
+      float ms = 0;
+      PE_HIP(hipEventElapsedTime(&ms, k.a, k.b));
+      prof_[k.row].ms += ms;
+      prof_[k.row].flops += k.flops;
+      prof_[k.row].launches += 1;
+      ev_pool_.push_back(k.a);
+      ev_pool_.push_back(k.b);
+    }
+    kev_.clear();
+  }
+  return prof_;
+}
 void Engine::reset_profile() {
+  profile();
   for (auto& r : prof_) { r.ms = 0; r.flops = 0; r.launches = 0; }
 }
 void Engine::prof_begin() {
@@ -654,7 +714,11 @@ void Engine::issue_stage_a() {
     const int VS = dk_ + 1 + (dk_ & 1);
     const size_t smem = ((size_t)ATT_QB * ap.SP + (size_t)ATT_KCH * VS + (size_t)dk_ * ATT_QB) * sizeof(float);
     if (smem > 160 * 1024) throw std::runtime_error("utterance too long for the attention score tile");
+    double afl = 0;
+    for (int b = 0; b < B; ++b) afl += 4.0 * (double)tlens_h_[b] * tlens_h_[b] * H_;
+    const int kh = kbegin(prof_level_ >= 2 ? krow("attn_kernel") : 0, afl);
     PE_LAUNCH(attn_kernel, dim3((T + ATT_QB - 1) / ATT_QB, nh_, B), dim3(256), smem, stream_, ap);
+    kend(kh);
     conv(e.o, att, y, d_tlens_, 1, T, EPI_RESADD, 1.f, ACT_NONE, x);
     layer_norm(0, y, none, x, e.g1, e.b1, nullptr, nullptr, 0, 0, H_, d_tlens_, T);
     conv(e.f1, x, ffh, d_tlens_, 1, T, EPI_STORE, 1.f, ACT_RELU);

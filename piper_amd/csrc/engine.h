@@ -67,8 +67,10 @@ class Engine {
 
   void set_seed(uint64_t s) { seed_ = s; }
   void set_use_graphs(bool on) { use_graphs_ = on; }
-  void set_profile(bool on);
-  const std::vector<ProfileRow>& profile() const { return prof_; }
+  // level 0 off; 1 = one HIP-event pair per pipeline stage; 2 = additionally one pair around every
+  // conv/attention/layer-norm launch (per-kernel rows after the five stage rows)
+  void set_profile(int level);
+  const std::vector<ProfileRow>& profile();
   void reset_profile();
   hipStream_t stream() const { return stream_; }
   const int32_t* arch() const { return arch_; }
@@ -191,8 +193,16 @@ class Engine {
 
   // profiling
   bool prof_on_ = false;
+  int prof_level_ = 0;
   std::vector<ProfileRow> prof_;
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
+  // level-2 per-launch timing: event pairs recorded without host syncs, resolved in profile()
+  struct KEvent { int row; double flops; hipEvent_t a, b; };
+  std::vector<KEvent> kev_;
+  std::vector<hipEvent_t> ev_pool_;
+  int kbegin(int row, double flops);
+  void kend(int h);
+  int krow(const char* name);
 };
 
 }  // namespace pe

@@ -181,7 +181,7 @@ void pe_set_seed(pe_engine* e, uint64_t seed) {
 }
 
 int pe_profile_enable(pe_engine* e, int on) {
-  return guard([&] { e->eng->set_profile(on != 0); });
+  return guard([&] { e->eng->set_profile(on); });
 }
 int pe_profile_reset(pe_engine* e) {
   return guard([&] { e->eng->reset_profile(); });

@@ -159,8 +159,8 @@ class Engine:
     def set_seed(self, seed: int):
         self._lib.pe_set_seed(self._h, int(seed))
 
-    def profile_enable(self, on=True):
-        self._check(self._lib.pe_profile_enable(self._h, int(on)))
+    def profile_enable(self, level=1):
+        self._check(self._lib.pe_profile_enable(self._h, int(level)))
 
     def profile_reset(self):
         self._check(self._lib.pe_profile_reset(self._h))
