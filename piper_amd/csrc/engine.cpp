@@ -320,6 +320,7 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
   PE_HIP(hipEventCreate(&ev1_));
   PE_HIP(hipHostMalloc((void**)&h_frames_, 4096 * sizeof(int)));
   if (const char* ng = getenv("PIPER_HIP_NO_GRAPH")) use_graphs_ = !(ng[0] && ng[0] != '0');
+  if (const char* t = getenv("PIPER_HIP_TPB")) tpb_override_ = atoi(t);     // tuning / test knob
 }
 
 Engine::~Engine() {
@@ -456,6 +457,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
   p.split = (epi == EPI_GATE) ? pc.split : (epi == EPI_WNRS ? (pc.rows > H_ ? H_ : 0) : 0);
   p.up = pc.up; p.padT = pc.padT;
   p.mode = mode; p.alpha = alpha;
+  p.tpb = 1;
   if ((epi == EPI_GATE) != pc.gate) throw std::runtime_error("internal: gate epilogue/packing mismatch");
 
   const int ncols = (epi == EPI_CONVT) ? Lmax + 1 : Lmax;
@@ -491,7 +493,13 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     else if (cfg == CFG_B && !pc.gate) cfg = CFG_S;
   }
   const int BM = CFG_BM[cfg], BN = CFG_BN[cfg];
-  dim3 grid((ncols + BN - 1) / BN, pc.mtiles * 32 / BM, B_);
+  const int ntile = (ncols + BN - 1) / BN, mblocks = pc.mtiles * 32 / BM;
+  // tiles per workgroup: keep >= ~2 workgroups per CU in flight, give the rest to the in-kernel pipeline
+  int tpb = (int)(((long)ntile * mblocks * B_ + 511) / 512);
+  tpb = tpb < 1 ? 1 : (tpb > 8 ? 8 : tpb);
+  if (tpb_override_ > 0) tpb = tpb_override_;
+  p.tpb = tpb;
+  dim3 grid((ntile + tpb - 1) / tpb, mblocks, B_);
   if (p.xhalo > 128) throw std::runtime_error("conv halo (kernel-1)*dilation > 128 is not supported");
   const size_t smem = (size_t)2 * KC * (BN + p.xhalo) * sizeof(float);
   static const char* knames[] = {"conv_mfma_kernel<2,2,2,2>", "conv_mfma_kernel<1,4,2,1>", "conv_mfma_kernel<1,4,1,1>",

@@ -35,6 +35,7 @@ struct ConvP {
   int up, padT;                                 // CONVT: stride and padding
   int mode;                                     // ACCUM: 0 first,1 middle,2 last,3 only ; WNRS: 1 = first layer
   float alpha;                                  // ACCUM last/only: scale
+  int tpb;                                      // conv_mfma_kernel: column tiles walked by one workgroup
 };
 
 // ---- shared epilogue of the conv GEMM kernels: one accumulator element (row, col) of utterance b.
@@ -112,18 +113,24 @@ __device__ __forceinline__ void conv_store_gate(const ConvP& p, int b, int ch, i
 // Covers every groups=1 Conv1d of attentions.py / modules.py / models.py and (EPI_CONVT) the polyphase
 // form of Generator.ups ConvTranspose1d (models.py:321-332) where k = 2*stride.
 template <int WM, int WN, int MT, int NT, int KS, bool GATE>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
   constexpr int NCOL = (BN + 128 + 63) / 64;     // staging columns per lane (halo <= 128)
   constexpr int NSUB = (KC / 2) / KS;             // A prefetch sets per (chunk, tap)
   static_assert(WM * WN == 4, "4 waves per block");
   static_assert(NSUB * KS == KC / 2, "KS must divide KC/2");
+  static_assert(!GATE || MT == 2, "gate epilogue pairs two M tiles");
   PE_DYN_SMEM(float, xs);                         // 2 x [KC][XW]
   const int b = blockIdx.z;
   const int L = p.lens[b] * p.len_mul;
   const int ncols = (p.epi == EPI_CONVT) ? L + 1 : L;
-  const int n0 = blockIdx.x * BN;
-  if (n0 >= ncols) return;
+  // a workgroup walks p.tpb consecutive column tiles: the x slab of the next (tile, chunk) and the A
+  // fragments of the next unit are in flight while the current unit's MFMAs issue, and the previous
+  // tile's epilogue stores drain under the next tile's MFMAs
+  const int tile0 = blockIdx.x * p.tpb;
+  const int ntile_all = (ncols + BN - 1) / BN;
+  if (tile0 >= ntile_all) return;
+  const int ntl = (ntile_all - tile0) < p.tpb ? (ntile_all - tile0) : p.tpb;
   const int m0 = blockIdx.y * BM;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv / WN, wn = wv % WN;
@@ -131,24 +138,19 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
   const int l31 = lane & 31, lhi = lane >> 5;
 
   f32x16 acc[MT][NT];
-#pragma unroll
-  for (int i = 0; i < MT; ++i)
-#pragma unroll
-    for (int j = 0; j < NT; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
   const float* xb = p.x + (long)b * p.x_bs;
-  const int tbase = n0 - p.padl;
   const int mtile0 = m0 / 32 + wm * MT;
   const float slope = p.in_slope;
   const int ntaps = p.ntaps, nchunks = p.nchunks;
   const int nunits = nchunks * ntaps * NSUB;
+  const int nslabs = ntl * nchunks;
   const long wstride_mt = (long)nchunks * ntaps * (KC / 2) * 64;
   const float* wbase = p.wp + (long)mtile0 * wstride_mt + lane;
 
   float xr[KC / 4][NCOL];
-  auto load_x = [&](int c) {
+  auto load_x = [&](int s) {
+    const int tl = s / nchunks, c = s - tl * nchunks;
+    const int tbase = (tile0 + tl) * BN - p.padl;
 #pragma unroll
     for (int rr = 0; rr < KC / 4; ++rr) {
       const int ci = c * KC + wv + 4 * rr;
@@ -198,16 +200,18 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
         for (int j = 0; j < NT; ++j) acc[i][j] = pe_mfma_32x32x2(a[kk][i], bv[j], acc[i][j]);
     }
   };
-  // one (chunk, tap) unit: prefetch the next unit's A set, run this unit's MFMAs, and at chunk
-  // boundaries move the prefetched x slab into the other LDS buffer
-  auto step = [&](int u, float (&cur)[KS][MT], float (&nxt)[KS][MT]) {
+  // one (chunk, tap, sub) unit of tile tl: prefetch the next unit's A set (wrapping to the next tile),
+  // run this unit's MFMAs, and at chunk boundaries move the prefetched x slab into the other LDS buffer
+  auto step = [&](int tl, int u, float (&cur)[KS][MT], float (&nxt)[KS][MT]) {
     const int ut = u / NSUB, sub = u - ut * NSUB;
     const int c = ut / ntaps, tap = ut - c * ntaps;
-    if (tap == 0 && sub == 0 && c + 1 < nchunks) load_x(c + 1);
+    const int s = tl * nchunks + c;
+    if (tap == 0 && sub == 0 && s + 1 < nslabs) load_x(s + 1);
     if (u + 1 < nunits) load_a(u + 1, nxt);
-    mma(tap, sub, cur, xs + (c & 1) * KC * XW);
-    if (tap == ntaps - 1 && sub == NSUB - 1 && c + 1 < nchunks) {
-      store_x((c + 1) & 1);
+    else if (tl + 1 < ntl) load_a(0, nxt);
+    mma(tap, sub, cur, xs + (s & 1) * KC * XW);
+    if (tap == ntaps - 1 && sub == NSUB - 1 && s + 1 < nslabs) {
+      store_x((s + 1) & 1);
       __syncthreads();
     }
   };
@@ -217,36 +221,51 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvP p) {
   load_a(0, aA);
   store_x(0);
   __syncthreads();
-  for (int u = 0; u < nunits; u += 2) {
-    step(u, aA, aB);
-    if (u + 1 < nunits) step(u + 1, aB, aA);
-  }
-
-  // ---- epilogue
-  if constexpr (GATE) {
-    static_assert(!GATE || MT == 2, "gate epilogue pairs two M tiles");
-    const int q = mtile0 >> 1;
-#pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int col = n0 + (wn * NT + j) * 32 + l31;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int ch = q * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        if (ch < p.split && col < ncols) conv_store_gate(p, b, ch, col, acc[0][j][r], acc[MT - 1][j][r]);
-      }
-    }
-    return;
-  }
   const EpiFlags ef = epi_flags(p);
+  for (int tl = 0; tl < ntl; ++tl) {
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
+    for (int i = 0; i < MT; ++i)
 #pragma unroll
-    for (int j = 0; j < NT; ++j) {
-      const int col = n0 + (wn * NT + j) * 32 + l31;
+      for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = (mtile0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        if (row < p.rows && col < ncols) conv_store(p, ef, b, row, col, acc[i][j][r], L);
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int u = 0; u < nunits; u += 2) {
+      step(tl, u, aA, aB);
+      if (u + 1 < nunits) step(tl, u + 1, aB, aA);
+    }
+    if (nunits & 1) {     // odd unit count: the next tile's first A set was prefetched into aB
+#pragma unroll
+      for (int kk = 0; kk < KS; ++kk)
+#pragma unroll
+        for (int i = 0; i < MT; ++i) aA[kk][i] = aB[kk][i];
+    }
+    // ---- epilogue of this tile
+    const int n0 = (tile0 + tl) * BN;
+    if constexpr (GATE) {
+      const int q = mtile0 >> 1;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int col = n0 + (wn * NT + j) * 32 + l31;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          int ch = q * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          PE_OPAQUE(ch);
+          if (ch < p.split && col < ncols) conv_store_gate(p, b, ch, col, acc[0][j][r], acc[MT - 1][j][r]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+          const int col = n0 + (wn * NT + j) * 32 + l31;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            int row = (mtile0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+            PE_OPAQUE(row);
+            if (row < p.rows && col < ncols) conv_store(p, ef, b, row, col, acc[i][j][r], L);
+          }
+        }
       }
     }
   }

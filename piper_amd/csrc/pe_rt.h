@@ -11,6 +11,7 @@
 #define pe_mfma_32x32x2(a, b, c) emu_mfma_32x32x2((a), (b), (c))
 #define pe_mfma_16x16x4(a, b, c) emu_mfma_16x16x4((a), (b), (c))
 #define PE_WAVE_SYNC() emu::wave_sync()
+#define PE_OPAQUE(x) ((void)0)
 #else
 #include <hip/hip_runtime.h>
 #define PE_LAUNCH(kernel, grid, block, smem, stream, ...) \
@@ -25,6 +26,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // lanes of a wave run in lockstep and LDS accesses of one wave complete in order: only the compiler
 // must not reorder across this point
 #define PE_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+// hides a loop-invariant value from LICM (keeps per-element epilogue addresses from being hoisted into
+// hundreds of registers across the tile loop)
+#define PE_OPAQUE(x) asm volatile("" : "+v"(x))
 #endif
 
 #include <stdexcept>

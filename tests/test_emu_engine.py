@@ -61,3 +61,20 @@ def test_emulated_ragged_batch_and_errors(emu_lib):
         eng.synthesize([1, 0, 999, 2])
     with pytest.raises(EngineError):
         Engine(blob=b"not a blob at all" * 40, lib=emu_lib)
+
+
+def test_emulated_multi_tile_conv_pipeline(emu_lib, monkeypatch):
+    """conv_mfma_kernel walking several column tiles per workgroup (PIPER_HIP_TPB knob) must give the
+    same waveform as one tile per workgroup."""
+    cfg = W.preset("tiny-high")
+    w = W.synthetic_weights(cfg, 1234)
+    ids = W.synthetic_phoneme_ids(10, 0, id_max=cfg.n_vocab - 1)
+    outs = []
+    for tpb in ("1", "3"):
+        monkeypatch.setenv("PIPER_HIP_TPB", tpb)
+        eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
+        outs.append(eng.synthesize(ids, (0.0, 1.0, 0.0)).audio[0])
+        eng.close()
+    assert outs[0].shape == outs[1].shape and np.array_equal(outs[0], outs[1])
+    o = O.synthesize(w, cfg, ids, (0.0, 1.0, 0.0))
+    assert np.max(np.abs(outs[1] - o["audio"])) < 1e-4
