@@ -501,7 +501,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
   p.tpb = tpb;
   dim3 grid((ntile + tpb - 1) / tpb, mblocks, B_);
   if (p.xhalo > 128) throw std::runtime_error("conv halo (kernel-1)*dilation > 128 is not supported");
-  const size_t smem = (size_t)2 * KC * (BN + p.xhalo) * sizeof(float);
+  const size_t smem = (size_t)2 * KC * ((BN + 128 + 63) / 64 * 64) * sizeof(float);
   static const char* knames[] = {"conv_mfma_kernel<2,2,2,2>", "conv_mfma_kernel<1,4,2,1>", "conv_mfma_kernel<1,4,1,1>",
                                  "conv_mfma_kernel<2,2,1,1>", "conv_mfma_kernel<2,2,2,1>"};
   const int kh = kbegin(prof_level_ >= 2 ? krow(knames[cfg]) : 0, kflops);

@@ -120,7 +120,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
   static_assert(WM * WN == 4, "4 waves per block");
   static_assert(NSUB * KS == KC / 2, "KS must divide KC/2");
   static_assert(!GATE || MT == 2, "gate epilogue pairs two M tiles");
-  PE_DYN_SMEM(float, xs);                         // 2 x [KC][XW]
+  constexpr int XS = NCOL * 64;                   // LDS row stride (compile time: taps become immediates)
+  PE_DYN_SMEM(float, xs);                         // 2 x [KC][XS]
   const int b = blockIdx.z;
   const int L = p.lens[b] * p.len_mul;
   const int ncols = (p.epi == EPI_CONVT) ? L + 1 : L;
@@ -134,7 +135,6 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
   const int m0 = blockIdx.y * BM;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wm = wv / WN, wn = wv % WN;
-  const int XW = BN + p.xhalo;
   const int l31 = lane & 31, lhi = lane >> 5;
 
   f32x16 acc[MT][NT];
@@ -148,36 +148,30 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
   const float* wbase = p.wp + (long)mtile0 * wstride_mt + lane;
 
   float xr[KC / 4][NCOL];
+  // Branch-free staging: rows are read through buffer descriptors (hardware range check returns 0 for
+  // the halo, the tail and padded channels) and the LDS rows are NCOL*64 wide so every lane stores
+  // unconditionally.
+  const int wvu = PE_UNIFORM(wv);
   auto load_x = [&](int s) {
     const int tl = s / nchunks, c = s - tl * nchunks;
-    const int tbase = (tile0 + tl) * BN - p.padl;
+    const int tbase = (tile0 + tl) * BN - p.padl + lane;
 #pragma unroll
     for (int rr = 0; rr < KC / 4; ++rr) {
-      const int ci = c * KC + wv + 4 * rr;
-      const bool rowok = ci < p.Cin;
-      const float* xrow = xb + (long)ci * p.x_cs;
+      const int ci = c * KC + wvu + 4 * rr;
+      const pe_rowsrc row = pe_make_row(xb + (long)ci * p.x_cs, ci < p.Cin ? L : 0);
 #pragma unroll
-      for (int cc = 0; cc < NCOL; ++cc) {
-        const int col = lane + 64 * cc;
-        const int t = tbase + col;
-        float v = 0.f;
-        if (rowok && col < XW && t >= 0 && t < L) v = xrow[t];
-        xr[rr][cc] = v;
-      }
+      for (int cc = 0; cc < NCOL; ++cc) xr[rr][cc] = pe_row_load(row, tbase + 64 * cc);
     }
   };
   auto store_x = [&](int buf) {
-    float* dst = xs + buf * KC * XW;
+    float* dst = xs + buf * KC * XS + wv * XS + lane;
 #pragma unroll
     for (int rr = 0; rr < KC / 4; ++rr)
 #pragma unroll
       for (int cc = 0; cc < NCOL; ++cc) {
-        const int col = lane + 64 * cc;
-        if (col < XW) {
-          float v = xr[rr][cc];
-          v = v > 0.f ? v : v * slope;
-          dst[(wv + 4 * rr) * XW + col] = v;
-        }
+        float v = xr[rr][cc];
+        v = v > 0.f ? v : v * slope;
+        dst[4 * rr * XS + 64 * cc] = v;
       }
   };
   auto load_a = [&](int u, float (&a)[KS][MT]) {
@@ -188,12 +182,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
       for (int i = 0; i < MT; ++i) a[kk][i] = wt[i * wstride_mt + kk * 64];
   };
   auto mma = [&](int tap, int sub, const float (&a)[KS][MT], const float* xbuf) {
-    const float* xp = xbuf + (lhi + 2 * KS * sub) * XW + tap * p.dil + wn * NT * 32 + l31;
+    const float* xp = xbuf + (lhi + 2 * KS * sub) * XS + tap * p.dil + wn * NT * 32 + l31;
 #pragma unroll
     for (int kk = 0; kk < KS; ++kk) {
       float bv[NT];
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bv[j] = xp[2 * kk * XW + j * 32];
+      for (int j = 0; j < NT; ++j) bv[j] = xp[2 * kk * XS + j * 32];
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -209,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
     if (tap == 0 && sub == 0 && s + 1 < nslabs) load_x(s + 1);
     if (u + 1 < nunits) load_a(u + 1, nxt);
     else if (tl + 1 < ntl) load_a(0, nxt);
-    mma(tap, sub, cur, xs + (s & 1) * KC * XW);
+    mma(tap, sub, cur, xs + (s & 1) * KC * XS);
     if (tap == ntaps - 1 && sub == NSUB - 1 && s + 1 < nslabs) {
       store_x((s + 1) & 1);
       __syncthreads();
@@ -309,19 +303,13 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk_kernel(ConvP p) {
 
   float xr[KC][NCOL];
   auto load_x = [&](int c) {
+    c = PE_UNIFORM(c);
 #pragma unroll
     for (int r = 0; r < KC; ++r) {
       const int ci = c * KC + r;
-      const bool rowok = ci < p.Cin;
-      const float* xrow = xb + (long)ci * p.x_cs;
+      const pe_rowsrc row = pe_make_row(xb + (long)ci * p.x_cs, ci < p.Cin ? L : 0);
 #pragma unroll
-      for (int cc = 0; cc < NCOL; ++cc) {
-        const int col = lane + 64 * cc;
-        const int t = tbase + col;
-        float v = 0.f;
-        if (rowok && col < XW && t >= 0 && t < L) v = xrow[t];
-        xr[r][cc] = v;
-      }
+      for (int cc = 0; cc < NCOL; ++cc) xr[r][cc] = pe_row_load(row, tbase + lane + 64 * cc);
     }
   };
   auto store_x = [&]() {

@@ -12,6 +12,11 @@
 #define pe_mfma_16x16x4(a, b, c) emu_mfma_16x16x4((a), (b), (c))
 #define PE_WAVE_SYNC() emu::wave_sync()
 #define PE_OPAQUE(x) ((void)0)
+#define PE_UNIFORM(x) (x)
+// bounds-checked row load: element idx of a row of n floats, 0 outside [0, n)
+struct pe_rowsrc { const float* p; int n; };
+inline pe_rowsrc pe_make_row(const float* row, int n) { return pe_rowsrc{row, n}; }
+inline float pe_row_load(const pe_rowsrc& r, int idx) { return (idx >= 0 && idx < r.n) ? r.p[idx] : 0.f; }
 #else
 #include <hip/hip_runtime.h>
 #define PE_LAUNCH(kernel, grid, block, smem, stream, ...) \
@@ -29,6 +34,18 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // hides a loop-invariant value from LICM (keeps per-element epilogue addresses from being hoisted into
 // hundreds of registers across the tile loop)
 #define PE_OPAQUE(x) asm volatile("" : "+v"(x))
+// makes a wave-uniform value provably uniform (SGPR) for the compiler
+#define PE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+// Bounds-checked row load through a buffer descriptor: the hardware range check returns 0 for any
+// element outside [0, n) (negative indices wrap to huge unsigned offsets), so halo / tail / padded-channel
+// reads need no clamps, selects or branches. `row` and `n` must be wave-uniform.
+typedef __amdgpu_buffer_rsrc_t pe_rowsrc;
+__device__ __forceinline__ pe_rowsrc pe_make_row(const float* row, int n) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(row), 0, n * 4, 0x00020000);
+}
+__device__ __forceinline__ float pe_row_load(pe_rowsrc r, int idx) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, idx * 4, 0, 0));
+}
 #endif
 
 #include <stdexcept>
