@@ -88,6 +88,70 @@ __device__ __forceinline__ void conv_store(const ConvP& p, const EpiFlags& f, in
   if (f.relu) v = v > 0.f ? v : 0.f;
   *d = v;
 }
+// One 32x32 accumulator tile (16 values per lane) through the epilogue in two phases: first every
+// operand the epilogue reads (bias, residual, previous value) is fetched for all 16 elements, then the
+// results are computed and stored -- so the 16 read-modify-write chains overlap instead of serialising
+// on memory latency (out/res may alias, which otherwise forces load-wait-store order per element).
+__device__ __forceinline__ void conv_store_tile(const ConvP& p, const EpiFlags& f, int b, int row0, int col,
+                                                const f32x16& acc, int lhi, int L, int ncols) {
+  if (p.epi == EPI_CONVT) {
+    float bb[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      PE_OPAQUE(row);
+      bb[r] = (p.bias && row < p.rows) ? p.bias[row / p.up] : 0.f;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      PE_OPAQUE(row);
+      const int co = row / p.up, ph = row - co * p.up;
+      const int t = col * p.up + ph - p.padT;
+      if (row < p.rows && col < ncols && t >= 0 && t < L * p.up)
+        p.out[(long)b * p.o_bs + (long)co * p.o_cs + t] = acc[r] + bb[r];
+    }
+    return;
+  }
+  float add[16], old[16];
+  const bool colok = col < ncols;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+    PE_OPAQUE(row);
+    const bool ok = colok && row < p.rows;
+    float a = 0.f, o = 0.f;
+    if (ok) {
+      if (p.bias) a = p.bias[row];
+      if (p.bias2) a += p.bias2[(long)b * p.bias2_bs + row];
+      const float* d = p.out + (long)b * p.o_bs + (long)row * p.o_cs + col;
+      bool use_old = f.use_old;
+      if (p.epi == EPI_WNRS) {
+        if (row < p.split) use_old = true;
+        else {
+          d = p.out2 + (long)b * p.o2_bs + (long)(row - p.split) * p.o2_cs + col;
+          use_old = p.mode != 1;
+        }
+      }
+      if (use_old) o = *d;
+      if (f.use_res) o += p.res[(long)b * p.r_bs + (long)row * p.r_cs + col];
+    }
+    add[r] = a;
+    old[r] = o;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+    PE_OPAQUE(row);
+    if (colok && row < p.rows) {
+      float* d = p.out + (long)b * p.o_bs + (long)row * p.o_cs + col;
+      if (p.epi == EPI_WNRS && row >= p.split) d = p.out2 + (long)b * p.o2_bs + (long)(row - p.split) * p.o2_cs + col;
+      float v = ((acc[r] + add[r]) * f.sign + old[r]) * f.alpha;
+      if (f.relu) v = v > 0.f ? v : 0.f;
+      *d = v;
+    }
+  }
+}
 // commons.py:99-106 fused_add_tanh_sigmoid_multiply on a (tanh-tile, sigmoid-tile) accumulator pair
 __device__ __forceinline__ void conv_store_gate(const ConvP& p, int b, int ch, int col, float ta, float sa) {
   ta += p.bias[ch];
@@ -251,15 +315,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int col = n0 + (wn * NT + j) * 32 + l31;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            int row = (mtile0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-            PE_OPAQUE(row);
-            if (row < p.rows && col < ncols) conv_store(p, ef, b, row, col, acc[i][j][r], L);
-          }
-        }
+        for (int j = 0; j < NT; ++j)
+          conv_store_tile(p, ef, b, (mtile0 + i) * 32, n0 + (wn * NT + j) * 32 + l31, acc[i][j], lhi, L, ncols);
       }
     }
   }
