@@ -88,40 +88,22 @@ __device__ __forceinline__ void conv_store(const ConvP& p, const EpiFlags& f, in
   if (f.relu) v = v > 0.f ? v : 0.f;
   *d = v;
 }
-// One 32x32 accumulator tile (16 values per lane) through the epilogue in two phases: first every
-// operand the epilogue reads (bias, residual, previous value) is fetched for all 16 elements, then the
-// results are computed and stored -- so the 16 read-modify-write chains overlap instead of serialising
-// on memory latency (out/res may alias, which otherwise forces load-wait-store order per element).
-__device__ __forceinline__ void conv_store_tile(const ConvP& p, const EpiFlags& f, int b, int row0, int col,
-                                                const f32x16& acc, int lhi, int L, int ncols) {
-  if (p.epi == EPI_CONVT) {
-    float bb[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-      PE_OPAQUE(row);
-      bb[r] = (p.bias && row < p.rows) ? p.bias[row / p.up] : 0.f;
-    }
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-      PE_OPAQUE(row);
-      const int co = row / p.up, ph = row - co * p.up;
-      const int t = col * p.up + ph - p.padT;
-      if (row < p.rows && col < ncols && t >= 0 && t < L * p.up)
-        p.out[(long)b * p.o_bs + (long)co * p.o_cs + t] = acc[r] + bb[r];
-    }
-    return;
-  }
-  float add[16], old[16];
+// One 32x32 accumulator tile (16 values per lane) goes through the epilogue in two phases: epi_fetch
+// reads every operand the epilogue needs (bias, residual, previous value) for all 16 elements, epi_finish
+// computes and stores. Splitting them (a) lets the 16 read-modify-write chains overlap instead of
+// serialising on memory latency (out/res may alias, which otherwise forces load-wait-store per element)
+// and (b) lets the kernel issue the fetch BEFORE the tile's MFMAs so the latency hides under them.
+__device__ __forceinline__ void epi_fetch(const ConvP& p, const EpiFlags& f, int b, int row0, int col, int lhi,
+                                          int ncols, float (&add)[16], float (&old)[16]) {
   const bool colok = col < ncols;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
     PE_OPAQUE(row);
-    const bool ok = colok && row < p.rows;
     float a = 0.f, o = 0.f;
-    if (ok) {
+    if (p.epi == EPI_CONVT) {
+      if (p.bias && row < p.rows) a = p.bias[row / p.up];
+    } else if (colok && row < p.rows) {
       if (p.bias) a = p.bias[row];
       if (p.bias2) a += p.bias2[(long)b * p.bias2_bs + row];
       const float* d = p.out + (long)b * p.o_bs + (long)row * p.o_cs + col;
@@ -139,17 +121,27 @@ __device__ __forceinline__ void conv_store_tile(const ConvP& p, const EpiFlags& 
     add[r] = a;
     old[r] = o;
   }
+}
+__device__ __forceinline__ void epi_finish(const ConvP& p, const EpiFlags& f, int b, int row0, int col, int lhi, int L,
+                                           int ncols, const f32x16& acc, const float (&add)[16],
+                                           const float (&old)[16]) {
+  const bool colok = col < ncols;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
     PE_OPAQUE(row);
-    if (colok && row < p.rows) {
-      float* d = p.out + (long)b * p.o_bs + (long)row * p.o_cs + col;
-      if (p.epi == EPI_WNRS && row >= p.split) d = p.out2 + (long)b * p.o2_bs + (long)(row - p.split) * p.o2_cs + col;
-      float v = ((acc[r] + add[r]) * f.sign + old[r]) * f.alpha;
-      if (f.relu) v = v > 0.f ? v : 0.f;
-      *d = v;
+    if (!(colok && row < p.rows)) continue;
+    if (p.epi == EPI_CONVT) {
+      const int co = row / p.up, ph = row - co * p.up;
+      const int t = col * p.up + ph - p.padT;
+      if (t >= 0 && t < L * p.up) p.out[(long)b * p.o_bs + (long)co * p.o_cs + t] = acc[r] + add[r];
+      continue;
     }
+    float* d = p.out + (long)b * p.o_bs + (long)row * p.o_cs + col;
+    if (p.epi == EPI_WNRS && row >= p.split) d = p.out2 + (long)b * p.o2_bs + (long)(row - p.split) * p.o2_cs + col;
+    float v = ((acc[r] + add[r]) * f.sign + old[r]) * f.alpha;
+    if (f.relu) v = v > 0.f ? v : 0.f;
+    *d = v;
   }
 }
 // commons.py:99-106 fused_add_tanh_sigmoid_multiply on a (tanh-tile, sigmoid-tile) accumulator pair
@@ -280,13 +272,24 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
   store_x(0);
   __syncthreads();
   const EpiFlags ef = epi_flags(p);
+  // wave tiles of <= 2 MFMA tiles fetch their epilogue operands before the MFMAs (32 registers at most)
+  constexpr bool PREF = !GATE && MT * NT <= 2;
+  float eadd[PREF ? MT : 1][PREF ? NT : 1][16], eold[PREF ? MT : 1][PREF ? NT : 1][16];
   for (int tl = 0; tl < ntl; ++tl) {
+    const int n0 = (tile0 + tl) * BN;
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if constexpr (PREF) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          epi_fetch(p, ef, b, (mtile0 + i) * 32, n0 + (wn * NT + j) * 32 + l31, lhi, ncols, eadd[i][j], eold[i][j]);
+    }
     for (int u = 0; u < nunits; u += 2) {
       step(tl, u, aA, aB);
       if (u + 1 < nunits) step(tl, u + 1, aB, aA);
@@ -298,7 +301,6 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
         for (int i = 0; i < MT; ++i) aA[kk][i] = aB[kk][i];
     }
     // ---- epilogue of this tile
-    const int n0 = (tile0 + tl) * BN;
     if constexpr (GATE) {
       const int q = mtile0 >> 1;
 #pragma unroll
@@ -315,8 +317,16 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
 #pragma unroll
       for (int i = 0; i < MT; ++i) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-          conv_store_tile(p, ef, b, (mtile0 + i) * 32, n0 + (wn * NT + j) * 32 + l31, acc[i][j], lhi, L, ncols);
+        for (int j = 0; j < NT; ++j) {
+          const int row0 = (mtile0 + i) * 32, col = n0 + (wn * NT + j) * 32 + l31;
+          if constexpr (PREF) {
+            epi_finish(p, ef, b, row0, col, lhi, L, ncols, acc[i][j], eadd[i][j], eold[i][j]);
+          } else {
+            float add[16], old[16];
+            epi_fetch(p, ef, b, row0, col, lhi, ncols, add, old);
+            epi_finish(p, ef, b, row0, col, lhi, L, ncols, acc[i][j], add, old);
+          }
+        }
       }
     }
   }

@@ -111,8 +111,11 @@ def test_ragged_batch_equals_single_utterance_calls():
         assert rb.audio[i].shape == o["audio"].shape
         assert np.max(np.abs(rb.audio[i] - o["audio"])) < TIGHT_AUDIO_TOL
         assert pcm_rms(rb.pcm[i], o["pcm"]) <= RMS_TOL
+        # the same utterance alone: identical up to float summation order (the launcher may pick a
+        # different tile shape / split-K variant for a different batch size)
         r1 = eng.synthesize(ids, scales, noise_w=nw[i], noise_z=nz[i])
-        assert np.array_equal(r1.pcm[0], rb.pcm[i])
+        assert r1.pcm[0].shape == rb.pcm[i].shape
+        assert np.max(np.abs(r1.pcm[0].astype(np.int32) - rb.pcm[i].astype(np.int32))) <= 2
 
 
 def test_zero_noise_is_deterministic_and_matches_oracle():
