@@ -12,9 +12,9 @@ namespace pe {
 static inline int rup(int v, int m) { return (v + m - 1) / m * m; }
 
 // tile configurations of conv_mfma_kernel: {WM, WN, MT, NT}
-enum { CFG_A = 0, CFG_B = 1, CFG_C = 2, CFG_S = 3, CFG_G = 4 };
-static const int CFG_BM[] = {128, 64, 32, 64, 128};
-static const int CFG_BN[] = {128, 128, 128, 64, 64};
+enum { CFG_A = 0, CFG_B = 1, CFG_C = 2, CFG_S = 3, CFG_G = 4, CFG_C2 = 5, CFG_B2 = 6 };
+static const int CFG_BM[] = {128, 64, 32, 64, 128, 32, 64};
+static const int CFG_BN[] = {128, 128, 128, 64, 64, 256, 256};
 
 // ------------------------------------------------------------------------------------------------
 // setup
@@ -306,6 +306,7 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
     const void* ks[] = {(const void*)conv_mfma_kernel<2, 2, 2, 2, 8, false>, (const void*)conv_mfma_kernel<1, 4, 2, 1, 16, false>,
                         (const void*)conv_mfma_kernel<1, 4, 1, 1, 16, false>, (const void*)conv_mfma_kernel<2, 2, 1, 1, 16, false>,
                         (const void*)conv_mfma_kernel<2, 2, 2, 1, 16, false>, (const void*)conv_mfma_kernel<2, 2, 2, 2, 8, true>,
+                        (const void*)conv_mfma_kernel<1, 4, 1, 2, 16, false>, (const void*)conv_mfma_kernel<1, 4, 2, 2, 8, false>,
                         (const void*)conv_mfma_kernel<1, 4, 2, 1, 16, true>, (const void*)conv_mfma_kernel<2, 2, 2, 1, 16, true>};
     for (const void* k : ks) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     const void* ks2[] = {(const void*)conv_splitk_kernel<2, true, 8>, (const void*)conv_splitk_kernel<2, true, 4>,
@@ -321,6 +322,7 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
   PE_HIP(hipHostMalloc((void**)&h_frames_, 4096 * sizeof(int)));
   if (const char* ng = getenv("PIPER_HIP_NO_GRAPH")) use_graphs_ = !(ng[0] && ng[0] != '0');
   if (const char* t = getenv("PIPER_HIP_TPB")) tpb_override_ = atoi(t);     // tuning / test knob
+  if (const char* t = getenv("PIPER_HIP_WIDE_MIN")) wide_min_blocks_ = atol(t);
 }
 
 Engine::~Engine() {
@@ -491,19 +493,29 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
   if (blocks < 192) {   // medium-small: smaller tiles, more workgroups
     if (cfg == CFG_A) cfg = pc.gate ? CFG_G : CFG_S;
     else if (cfg == CFG_B && !pc.gate) cfg = CFG_S;
+  } else if (!pc.gate && blocks >= wide_min_blocks_) {
+    // plenty of columns (late generator stages): twice the columns per wave halves the weight-fragment
+    // loads and the per-workgroup prologue/epilogue overhead per MFMA
+    if (cfg == CFG_C) cfg = CFG_C2;
+    else if (cfg == CFG_B) cfg = CFG_B2;
   }
   const int BM = CFG_BM[cfg], BN = CFG_BN[cfg];
   const int ntile = (ncols + BN - 1) / BN, mblocks = pc.mtiles * 32 / BM;
-  // tiles per workgroup: keep >= ~2 workgroups per CU in flight, give the rest to the in-kernel pipeline
-  int tpb = (int)(((long)ntile * mblocks * B_ + 511) / 512);
-  tpb = tpb < 1 ? 1 : (tpb > 8 ? 8 : tpb);
+  // Column tiles walked by one workgroup. Measured on MI355X (profiles/r01_tpb_sweep.txt): with 2-3
+  // workgroups resident per CU, one tile per workgroup (latency hidden across workgroups) beats walking
+  // several tiles with the in-kernel prefetch pipeline at every batch size, so the default is 1; the
+  // multi-tile path stays available through PIPER_HIP_TPB.
+  int tpb = 1;
   if (tpb_override_ > 0) tpb = tpb_override_;
   p.tpb = tpb;
   dim3 grid((ntile + tpb - 1) / tpb, mblocks, B_);
   if (p.xhalo > 128) throw std::runtime_error("conv halo (kernel-1)*dilation > 128 is not supported");
-  const size_t smem = (size_t)2 * KC * ((BN + 128 + 63) / 64 * 64) * sizeof(float);
+  // one x slab when the workgroup only ever stages one (single chunk, single tile): more workgroups per CU
+  const int nbuf = (tpb == 1 && pc.nchunks == 1) ? 1 : 2;
+  const size_t smem = (size_t)nbuf * KC * ((BN + 128 + 63) / 64 * 64) * sizeof(float);
   static const char* knames[] = {"conv_mfma_kernel<2,2,2,2>", "conv_mfma_kernel<1,4,2,1>", "conv_mfma_kernel<1,4,1,1>",
-                                 "conv_mfma_kernel<2,2,1,1>", "conv_mfma_kernel<2,2,2,1>"};
+                                 "conv_mfma_kernel<2,2,1,1>", "conv_mfma_kernel<2,2,2,1>", "conv_mfma_kernel<1,4,1,2>",
+                                 "conv_mfma_kernel<1,4,2,2>"};
   const int kh = kbegin(prof_level_ >= 2 ? krow(knames[cfg]) : 0, kflops);
   if (pc.gate) {
     switch (cfg) {
@@ -519,6 +531,8 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     case CFG_B: PE_LAUNCH((conv_mfma_kernel<1, 4, 2, 1, 16, false>), grid, dim3(256), smem, stream_, p); break;
     case CFG_C: PE_LAUNCH((conv_mfma_kernel<1, 4, 1, 1, 16, false>), grid, dim3(256), smem, stream_, p); break;
     case CFG_S: PE_LAUNCH((conv_mfma_kernel<2, 2, 1, 1, 16, false>), grid, dim3(256), smem, stream_, p); break;
+    case CFG_C2: PE_LAUNCH((conv_mfma_kernel<1, 4, 1, 2, 16, false>), grid, dim3(256), smem, stream_, p); break;
+    case CFG_B2: PE_LAUNCH((conv_mfma_kernel<1, 4, 2, 2, 8, false>), grid, dim3(256), smem, stream_, p); break;
     default:    PE_LAUNCH((conv_mfma_kernel<2, 2, 2, 1, 16, false>), grid, dim3(256), smem, stream_, p); break;
   }
   kend(kh);
