@@ -45,13 +45,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    dev_index = local_rank % max(ndev, 1)
+    torch.cuda.set_device(dev_index)
     dist = None
+    # "nccl" is RCCL on ROCm. PIPER_BENCH_BACKEND=gloo exists only to smoke-test the multi-process path on
+    # a single-GPU box (ranks then share the GPU and the collectives run on host tensors).
+    backend = os.environ.get("PIPER_BENCH_BACKEND", "nccl")
+    cdev = torch.device("cuda", dev_index) if backend == "nccl" else torch.device("cpu")
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=cdev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     cfg = W.preset(args.preset)
     # ---- voice weights: rank 0 builds the blob, RCCL broadcast to the others
@@ -65,10 +73,10 @@ def main():
         from piper_amd.dist import broadcast_blob
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        blob = broadcast_blob(blob, 0, torch.device("cuda", local_rank))   # RCCL over xGMI
+        blob = broadcast_blob(blob, 0, cdev)   # RCCL over xGMI
         torch.cuda.synchronize()
         t_bcast = time.perf_counter() - t0
-    eng = Engine(blob=blob, device=local_rank)
+    eng = Engine(blob=blob, device=dev_index)
 
     # ---- synthetic input, resident in HBM before timing
     B, T = args.batch, args.ids
@@ -101,10 +109,10 @@ def main():
     elapsed = time.perf_counter() - t0
     total_samples = samples_per_step * args.steps
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        s = torch.tensor([total_samples], dtype=torch.float64, device="cuda")
+        s = torch.tensor([total_samples], dtype=torch.float64, device=cdev)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         total_samples = float(s.item())
 
