@@ -303,11 +303,12 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
   {
     // allow > 64 KiB of dynamic LDS (gfx950: 160 KiB per workgroup)
     const int lim = 160 * 1024;
-    const void* ks[] = {(const void*)conv_mfma_kernel<2, 2, 2, 2, 8, false>, (const void*)conv_mfma_kernel<1, 4, 2, 1, 16, false>,
-                        (const void*)conv_mfma_kernel<1, 4, 1, 1, 16, false>, (const void*)conv_mfma_kernel<2, 2, 1, 1, 16, false>,
-                        (const void*)conv_mfma_kernel<2, 2, 2, 1, 16, false>, (const void*)conv_mfma_kernel<2, 2, 2, 2, 8, true>,
-                        (const void*)conv_mfma_kernel<1, 4, 1, 2, 16, false>, (const void*)conv_mfma_kernel<1, 4, 2, 2, 8, false>,
-                        (const void*)conv_mfma_kernel<1, 4, 2, 1, 16, true>, (const void*)conv_mfma_kernel<2, 2, 2, 1, 16, true>};
+#define PE_K2(WM, WN, MT, NT, KS, G) (const void*)conv_mfma_kernel<WM, WN, MT, NT, KS, G, 64>, (const void*)conv_mfma_kernel<WM, WN, MT, NT, KS, G, 128>
+    const void* ks[] = {PE_K2(2, 2, 2, 2, 8, false), PE_K2(1, 4, 2, 1, 16, false), PE_K2(1, 4, 1, 1, 16, false),
+                        PE_K2(2, 2, 1, 1, 16, false), PE_K2(2, 2, 2, 1, 16, false), PE_K2(1, 4, 1, 2, 16, false),
+                        PE_K2(1, 4, 2, 2, 8, false), PE_K2(2, 2, 2, 2, 8, true), PE_K2(1, 4, 2, 1, 16, true),
+                        PE_K2(2, 2, 2, 1, 16, true)};
+#undef PE_K2
     for (const void* k : ks) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     const void* ks2[] = {(const void*)conv_splitk_kernel<2, true, 8>, (const void*)conv_splitk_kernel<2, true, 4>,
                          (const void*)conv_splitk_kernel<1, false, 8>, (const void*)conv_splitk_kernel<1, false, 4>};
@@ -323,6 +324,8 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
   if (const char* ng = getenv("PIPER_HIP_NO_GRAPH")) use_graphs_ = !(ng[0] && ng[0] != '0');
   if (const char* t = getenv("PIPER_HIP_TPB")) tpb_override_ = atoi(t);     // tuning / test knob
   if (const char* t = getenv("PIPER_HIP_WIDE_MIN")) wide_min_blocks_ = atol(t);
+  if (const char* t = getenv("PIPER_HIP_SMALL")) small_tiles_ = atoi(t) != 0;
+  if (const char* t = getenv("PIPER_HIP_ABL")) abl_ = atoi(t);              // timing ablations, results invalid
 }
 
 Engine::~Engine() {
@@ -460,6 +463,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
   p.up = pc.up; p.padT = pc.padT;
   p.mode = mode; p.alpha = alpha;
   p.tpb = 1;
+  p.abl = abl_;
   if ((epi == EPI_GATE) != pc.gate) throw std::runtime_error("internal: gate epilogue/packing mismatch");
 
   const int ncols = (epi == EPI_CONVT) ? Lmax + 1 : Lmax;
@@ -490,7 +494,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     kend(kh);
     return;
   }
-  if (blocks < 192) {   // medium-small: smaller tiles, more workgroups
+  if (blocks < 192 || small_tiles_) {   // medium-small: smaller tiles, more workgroups
     if (cfg == CFG_A) cfg = pc.gate ? CFG_G : CFG_S;
     else if (cfg == CFG_B && !pc.gate) cfg = CFG_S;
   } else if (!pc.gate && blocks >= wide_min_blocks_) {
@@ -512,29 +516,35 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
   if (p.xhalo > 128) throw std::runtime_error("conv halo (kernel-1)*dilation > 128 is not supported");
   // one x slab when the workgroup only ever stages one (single chunk, single tile): more workgroups per CU
   const int nbuf = (tpb == 1 && pc.nchunks == 1) ? 1 : 2;
-  const size_t smem = (size_t)nbuf * KC * ((BN + 128 + 63) / 64 * 64) * sizeof(float);
+  const int HALO = p.xhalo <= 64 ? 64 : 128;
+  const size_t smem = (size_t)nbuf * KC * ((BN + HALO + 63) / 64 * 64) * sizeof(float);
   static const char* knames[] = {"conv_mfma_kernel<2,2,2,2>", "conv_mfma_kernel<1,4,2,1>", "conv_mfma_kernel<1,4,1,1>",
                                  "conv_mfma_kernel<2,2,1,1>", "conv_mfma_kernel<2,2,2,1>", "conv_mfma_kernel<1,4,1,2>",
                                  "conv_mfma_kernel<1,4,2,2>"};
   const int kh = kbegin(prof_level_ >= 2 ? krow(knames[cfg]) : 0, kflops);
+#define PE_CONV_LAUNCH(WM, WN, MT, NT, KS, G)                                                                  \
+  do {                                                                                                         \
+    if (HALO == 64) PE_LAUNCH((conv_mfma_kernel<WM, WN, MT, NT, KS, G, 64>), grid, dim3(256), smem, stream_, p); \
+    else PE_LAUNCH((conv_mfma_kernel<WM, WN, MT, NT, KS, G, 128>), grid, dim3(256), smem, stream_, p);          \
+  } while (0)
   if (pc.gate) {
     switch (cfg) {
-      case CFG_A: PE_LAUNCH((conv_mfma_kernel<2, 2, 2, 2, 8, true>), grid, dim3(256), smem, stream_, p); break;
-      case CFG_B: PE_LAUNCH((conv_mfma_kernel<1, 4, 2, 1, 16, true>), grid, dim3(256), smem, stream_, p); break;
-      default:    PE_LAUNCH((conv_mfma_kernel<2, 2, 2, 1, 16, true>), grid, dim3(256), smem, stream_, p); break;
+      case CFG_A: PE_CONV_LAUNCH(2, 2, 2, 2, 8, true); break;
+      case CFG_B: PE_CONV_LAUNCH(1, 4, 2, 1, 16, true); break;
+      default:    PE_CONV_LAUNCH(2, 2, 2, 1, 16, true); break;
     }
-    kend(kh);
-    return;
+  } else {
+    switch (cfg) {
+      case CFG_A: PE_CONV_LAUNCH(2, 2, 2, 2, 8, false); break;
+      case CFG_B: PE_CONV_LAUNCH(1, 4, 2, 1, 16, false); break;
+      case CFG_C: PE_CONV_LAUNCH(1, 4, 1, 1, 16, false); break;
+      case CFG_S: PE_CONV_LAUNCH(2, 2, 1, 1, 16, false); break;
+      case CFG_C2: PE_CONV_LAUNCH(1, 4, 1, 2, 16, false); break;
+      case CFG_B2: PE_CONV_LAUNCH(1, 4, 2, 2, 8, false); break;
+      default:    PE_CONV_LAUNCH(2, 2, 2, 1, 16, false); break;
+    }
   }
-  switch (cfg) {
-    case CFG_A: PE_LAUNCH((conv_mfma_kernel<2, 2, 2, 2, 8, false>), grid, dim3(256), smem, stream_, p); break;
-    case CFG_B: PE_LAUNCH((conv_mfma_kernel<1, 4, 2, 1, 16, false>), grid, dim3(256), smem, stream_, p); break;
-    case CFG_C: PE_LAUNCH((conv_mfma_kernel<1, 4, 1, 1, 16, false>), grid, dim3(256), smem, stream_, p); break;
-    case CFG_S: PE_LAUNCH((conv_mfma_kernel<2, 2, 1, 1, 16, false>), grid, dim3(256), smem, stream_, p); break;
-    case CFG_C2: PE_LAUNCH((conv_mfma_kernel<1, 4, 1, 2, 16, false>), grid, dim3(256), smem, stream_, p); break;
-    case CFG_B2: PE_LAUNCH((conv_mfma_kernel<1, 4, 2, 2, 8, false>), grid, dim3(256), smem, stream_, p); break;
-    default:    PE_LAUNCH((conv_mfma_kernel<2, 2, 2, 1, 16, false>), grid, dim3(256), smem, stream_, p); break;
-  }
+#undef PE_CONV_LAUNCH
   kend(kh);
 }
 

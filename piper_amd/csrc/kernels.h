@@ -36,6 +36,8 @@ struct ConvP {
   int mode;                                     // ACCUM: 0 first,1 middle,2 last,3 only ; WNRS: 1 = first layer
   float alpha;                                  // ACCUM last/only: scale
   int tpb;                                      // conv_mfma_kernel: column tiles walked by one workgroup
+  int abl;                                      // timing ablation (tuning only, wrong results): 1 no weight reloads,
+                                                // 2 no x-slab reloads, 3 no epilogue, 4 no MFMAs
 };
 
 // ---- shared epilogue of the conv GEMM kernels: one accumulator element (row, col) of utterance b.
@@ -168,10 +170,13 @@ __device__ __forceinline__ void conv_store_gate(const ConvP& p, int b, int ch, i
 //     are prefetched into a second register set (ping-pong) while the current unit's MFMAs issue.
 // Covers every groups=1 Conv1d of attentions.py / modules.py / models.py and (EPI_CONVT) the polyphase
 // form of Generator.ups ConvTranspose1d (models.py:321-332) where k = 2*stride.
-template <int WM, int WN, int MT, int NT, int KS, bool GATE>
-__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
+// second launch-bound argument = waves per SIMD the register allocation must leave room for: latency here is
+// hidden across workgroups (profiles/r01_ablation.txt), so small wave tiles are held to 128 / 168 registers
+template <int WM, int WN, int MT, int NT, int KS, bool GATE, int HALO>
+__global__ __launch_bounds__(256, (MT * NT == 1 ? ((HALO == 128 && WN == 4) ? 3 : 4) : ((GATE && MT * NT == 2) ? 3 : 2)))
+void conv_mfma_kernel(ConvP p) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
-  constexpr int NCOL = (BN + 128 + 63) / 64;     // staging columns per lane (halo <= 128)
+  constexpr int NCOL = (BN + HALO + 63) / 64;    // staging columns per lane; (taps-1)*dilation <= HALO
   constexpr int NSUB = (KC / 2) / KS;             // A prefetch sets per (chunk, tap)
   static_assert(WM * WN == 4, "4 waves per block");
   static_assert(NSUB * KS == KC / 2, "KS must divide KC/2");
@@ -256,12 +261,14 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
     const int ut = u / NSUB, sub = u - ut * NSUB;
     const int c = ut / ntaps, tap = ut - c * ntaps;
     const int s = tl * nchunks + c;
-    if (tap == 0 && sub == 0 && s + 1 < nslabs) load_x(s + 1);
-    if (u + 1 < nunits) load_a(u + 1, nxt);
-    else if (tl + 1 < ntl) load_a(0, nxt);
-    mma(tap, sub, cur, xs + (s & 1) * KC * XS);
+    if (tap == 0 && sub == 0 && s + 1 < nslabs && p.abl != 2) load_x(s + 1);
+    if (p.abl != 1) {
+      if (u + 1 < nunits) load_a(u + 1, nxt);
+      else if (tl + 1 < ntl) load_a(0, nxt);
+    }
+    if (p.abl != 4) mma(tap, sub, cur, xs + (s & 1) * KC * XS);
     if (tap == ntaps - 1 && sub == NSUB - 1 && s + 1 < nslabs) {
-      store_x((s + 1) & 1);
+      if (p.abl != 2) store_x((s + 1) & 1);
       __syncthreads();
     }
   };
@@ -273,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
   __syncthreads();
   const EpiFlags ef = epi_flags(p);
   // wave tiles of <= 2 MFMA tiles fetch their epilogue operands before the MFMAs (32 registers at most)
-  constexpr bool PREF = !GATE && MT * NT <= 2;
+  constexpr bool PREF = false;   // measured: no gain, and the 32 extra registers cost a wave per SIMD
   float eadd[PREF ? MT : 1][PREF ? NT : 1][16], eold[PREF ? MT : 1][PREF ? NT : 1][16];
   for (int tl = 0; tl < ntl; ++tl) {
     const int n0 = (tile0 + tl) * BN;
@@ -301,6 +308,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvP p) {
         for (int i = 0; i < MT; ++i) aA[kk][i] = aB[kk][i];
     }
     // ---- epilogue of this tile
+    if (p.abl == 3) {
+      if (acc[0][0][0] == 123.456f) p.out[0] = 1.f;     // keep the accumulators live
+      continue;
+    }
     if constexpr (GATE) {
       const int q = mtile0 >> 1;
 #pragma unroll
