@@ -359,7 +359,7 @@ struct Carver {
 };
 
 void Engine::ensure_stage_a(int B, int Tmax) {
-  const int Ts = rup(Tmax, 64);
+  const int Ts = rup(Tmax, 128);    // row strides are multiples of 128 columns (conv epilogue relies on it)
   bool grow = false;
   if ((size_t)B > capA_B_) { capA_B_ = B; grow = true; }
   if ((size_t)Ts > capA_T_) { capA_T_ = Ts; grow = true; }
@@ -405,7 +405,7 @@ void Engine::ensure_stage_a(int B, int Tmax) {
 }
 
 void Engine::ensure_stage_b(int Fmax) {
-  const int Fs = rup(Fmax, 64);
+  const int Fs = rup(Fmax, 128);
   bool grow = false;
   if ((size_t)Fs > capB_F_) { capB_F_ = Fs; grow = true; }
   Fs_ = (int)capB_F_;
@@ -497,7 +497,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
   if (blocks < 192 || small_tiles_) {   // medium-small: smaller tiles, more workgroups
     if (cfg == CFG_A) cfg = pc.gate ? CFG_G : CFG_S;
     else if (cfg == CFG_B && !pc.gate) cfg = CFG_S;
-  } else if (!pc.gate && blocks >= wide_min_blocks_) {
+  } else if (!pc.gate && blocks >= wide_min_blocks_ && out.cs % 256 == 0) {
     // plenty of columns (late generator stages): twice the columns per wave halves the weight-fragment
     // loads and the per-workgroup prologue/epilogue overhead per MFMA
     if (cfg == CFG_C) cfg = CFG_C2;
