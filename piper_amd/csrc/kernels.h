@@ -65,93 +65,97 @@ __device__ __forceinline__ EpiFlags epi_flags(const ConvP& p) {
   }
   return f;
 }
-// Epilogue tensors as buffer descriptors (per utterance): loads outside the tensor return 0 and stores
-// outside are dropped by the hardware range check, so padded GEMM rows (row >= rows) need no predicate.
-// Columns between the valid length and the row stride are scratch (nothing ever reads them: every
-// consumer bounds its reads by the length), and the engine keeps row strides at multiples of 128 columns,
-// so a tile overhanging the valid length stays inside its own row and needs no column predicate either.
-struct EpiBufs {
-  pe_rowsrc out, out2, res, bias, bias2;
-};
-__device__ __forceinline__ EpiBufs epi_bufs(const ConvP& p, int b) {
-  EpiBufs e;
-  const int orow = (p.epi == EPI_GATE) ? p.split : (p.epi == EPI_WNRS ? p.split : (p.epi == EPI_CONVT ? p.rows / p.up : p.rows));
-  e.out = pe_make_row(p.out + (long)b * p.o_bs, orow * p.o_cs);
-  e.out2 = pe_make_row(p.out2 ? p.out2 + (long)b * p.o2_bs : p.out, p.out2 ? (p.rows - p.split) * p.o2_cs : 0);
-  e.res = pe_make_row(p.res ? p.res + (long)b * p.r_bs : p.out, p.res ? p.rows * p.r_cs : 0);
-  const int nb = (p.epi == EPI_GATE) ? 2 * p.split : (p.epi == EPI_CONVT ? p.rows / p.up : p.rows);
-  e.bias = pe_make_row(p.bias ? p.bias : p.wp, p.bias ? nb : 0);
-  e.bias2 = pe_make_row(p.bias2 ? p.bias2 + (long)b * p.bias2_bs : p.wp, p.bias2 ? nb : 0);
-  return e;
-}
-// one accumulator element (row, col)
-__device__ __forceinline__ void conv_store(const ConvP& p, const EpiFlags& f, const EpiBufs& e, int row, int col,
-                                           float v, int L) {
+__device__ __forceinline__ void conv_store(const ConvP& p, const EpiFlags& f, int b, int row, int col, float v, int L) {
   if (p.epi == EPI_CONVT) {
     const int co = row / p.up, ph = row - co * p.up;
     const int t = col * p.up + ph - p.padT;
-    const bool ok = row < p.rows && t >= 0 && t < L * p.up;
-    pe_row_store(e.out, ok ? co * p.o_cs + t : -1, v + pe_row_load(e.bias, co));
+    if (t >= 0 && t < L * p.up) p.out[(long)b * p.o_bs + (long)co * p.o_cs + t] = v + (p.bias ? p.bias[co] : 0.f);
     return;
   }
-  v += pe_row_load(e.bias, row) + pe_row_load(e.bias2, row);
-  float o = 0.f;
-  if (p.epi == EPI_WNRS && row >= p.split) {
-    const int off = (row - p.split) * p.o2_cs + col;
-    if (p.mode != 1) o = pe_row_load(e.out2, off);
-    pe_row_store(e.out2, off, v + o);
-    return;
-  }
-  const int off = row * p.o_cs + col;
-  if (f.use_old || p.epi == EPI_WNRS) o = pe_row_load(e.out, off);
-  if (f.use_res) o += pe_row_load(e.res, row * p.r_cs + col);
-  v = (v * f.sign + o) * f.alpha;
-  if (f.relu) v = v > 0.f ? v : 0.f;
-  pe_row_store(e.out, off, v);
-}
-// One 32x32 accumulator tile (16 values per lane): all operand loads first, then compute and store, so
-// the 16 read-modify-write chains overlap instead of serialising on memory latency.
-__device__ __forceinline__ void conv_store_tile(const ConvP& p, const EpiFlags& f, const EpiBufs& e, int row0, int col,
-                                                int lhi, int L, const f32x16& acc) {
-  if (p.epi == EPI_CONVT) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-      PE_OPAQUE(row);
-      conv_store(p, f, e, row, col, acc[r], L);
+  if (p.bias) v += p.bias[row];
+  if (p.bias2) v += p.bias2[(long)b * p.bias2_bs + row];
+  float* d = p.out + (long)b * p.o_bs + (long)row * p.o_cs + col;
+  bool use_old = f.use_old;
+  if (p.epi == EPI_WNRS) {
+    if (row < p.split) use_old = true;
+    else {
+      d = p.out2 + (long)b * p.o2_bs + (long)(row - p.split) * p.o2_cs + col;
+      use_old = p.mode != 1;
     }
-    return;
   }
-  float add[16], old[16];
+  v *= f.sign;
+  if (f.use_res) v += p.res[(long)b * p.r_bs + (long)row * p.r_cs + col];
+  if (use_old) v += *d;
+  v *= f.alpha;
+  if (f.relu) v = v > 0.f ? v : 0.f;
+  *d = v;
+}
+// One 32x32 accumulator tile (16 values per lane) goes through the epilogue in two phases: epi_fetch
+// reads every operand the epilogue needs (bias, residual, previous value) for all 16 elements, epi_finish
+// computes and stores. Splitting them (a) lets the 16 read-modify-write chains overlap instead of
+// serialising on memory latency (out/res may alias, which otherwise forces load-wait-store per element)
+// and (b) lets the kernel issue the fetch BEFORE the tile's MFMAs so the latency hides under them.
+__device__ __forceinline__ void epi_fetch(const ConvP& p, const EpiFlags& f, int b, int row0, int col, int lhi,
+                                          int ncols, float (&add)[16], float (&old)[16]) {
+  const bool colok = col < ncols;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
     PE_OPAQUE(row);
-    add[r] = pe_row_load(e.bias, row) + pe_row_load(e.bias2, row);
-    float o = 0.f;
-    if (p.epi == EPI_WNRS && row >= p.split) {
-      if (p.mode != 1) o = pe_row_load(e.out2, (row - p.split) * p.o2_cs + col);
-    } else {
-      if (f.use_old || p.epi == EPI_WNRS) o = pe_row_load(e.out, row * p.o_cs + col);
-      if (f.use_res) o += pe_row_load(e.res, row * p.r_cs + col);
+    float a = 0.f, o = 0.f;
+    if (p.epi == EPI_CONVT) {
+      if (p.bias && row < p.rows) a = p.bias[row / p.up];
+    } else if (colok && row < p.rows) {
+      if (p.bias) a = p.bias[row];
+      if (p.bias2) a += p.bias2[(long)b * p.bias2_bs + row];
+      const float* d = p.out + (long)b * p.o_bs + (long)row * p.o_cs + col;
+      bool use_old = f.use_old;
+      if (p.epi == EPI_WNRS) {
+        if (row < p.split) use_old = true;
+        else {
+          d = p.out2 + (long)b * p.o2_bs + (long)(row - p.split) * p.o2_cs + col;
+          use_old = p.mode != 1;
+        }
+      }
+      if (use_old) o = *d;
+      if (f.use_res) o += p.res[(long)b * p.r_bs + (long)row * p.r_cs + col];
     }
+    add[r] = a;
     old[r] = o;
   }
+}
+__device__ __forceinline__ void epi_finish(const ConvP& p, const EpiFlags& f, int b, int row0, int col, int lhi, int L,
+                                           int ncols, const f32x16& acc, const float (&add)[16],
+                                           const float (&old)[16]) {
+  const bool colok = col < ncols;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
     PE_OPAQUE(row);
+    if (!(colok && row < p.rows)) continue;
+    if (p.epi == EPI_CONVT) {
+      const int co = row / p.up, ph = row - co * p.up;
+      const int t = col * p.up + ph - p.padT;
+      if (t >= 0 && t < L * p.up) p.out[(long)b * p.o_bs + (long)co * p.o_cs + t] = acc[r] + add[r];
+      continue;
+    }
+    float* d = p.out + (long)b * p.o_bs + (long)row * p.o_cs + col;
+    if (p.epi == EPI_WNRS && row >= p.split) d = p.out2 + (long)b * p.o2_bs + (long)(row - p.split) * p.o2_cs + col;
     float v = ((acc[r] + add[r]) * f.sign + old[r]) * f.alpha;
     if (f.relu) v = v > 0.f ? v : 0.f;
-    if (p.epi == EPI_WNRS && row >= p.split) pe_row_store(e.out2, (row - p.split) * p.o2_cs + col, v);
-    else pe_row_store(e.out, row * p.o_cs + col, v);
+    *d = v;
   }
 }
 // commons.py:99-106 fused_add_tanh_sigmoid_multiply on a (tanh-tile, sigmoid-tile) accumulator pair
-__device__ __forceinline__ void conv_store_gate(const ConvP& p, const EpiBufs& e, int ch, int col, float ta, float sa) {
-  ta += pe_row_load(e.bias, ch) + pe_row_load(e.bias2, ch);
-  sa += pe_row_load(e.bias, p.split + ch) + pe_row_load(e.bias2, p.split + ch);
-  pe_row_store(e.out, ch < p.split ? ch * p.o_cs + col : -1, tanhf(ta) * (1.f / (1.f + expf(-sa))));
+__device__ __forceinline__ void conv_store_gate(const ConvP& p, int b, int ch, int col, float ta, float sa) {
+  ta += p.bias[ch];
+  sa += p.bias[p.split + ch];
+  if (p.bias2) {
+    const float* b2 = p.bias2 + (long)b * p.bias2_bs;
+    ta += b2[ch];
+    sa += b2[p.split + ch];
+  }
+  p.out[(long)b * p.o_bs + (long)ch * p.o_cs + col] = tanhf(ta) * (1.f / (1.f + expf(-sa)));
 }
 
 // Conv1d / ConvTranspose1d as an implicit GEMM on the f32 matrix cores.
@@ -275,7 +279,9 @@ void conv_mfma_kernel(ConvP p) {
   store_x(0);
   __syncthreads();
   const EpiFlags ef = epi_flags(p);
-  const EpiBufs eb = epi_bufs(p, b);
+  // wave tiles of <= 2 MFMA tiles fetch their epilogue operands before the MFMAs (32 registers at most)
+  constexpr bool PREF = false;   // measured: no gain, and the 32 extra registers cost a wave per SIMD
+  float eadd[PREF ? MT : 1][PREF ? NT : 1][16], eold[PREF ? MT : 1][PREF ? NT : 1][16];
   for (int tl = 0; tl < ntl; ++tl) {
     const int n0 = (tile0 + tl) * BN;
 #pragma unroll
@@ -284,6 +290,13 @@ void conv_mfma_kernel(ConvP p) {
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    if constexpr (PREF) {
+#pragma unroll
+      for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          epi_fetch(p, ef, b, (mtile0 + i) * 32, n0 + (wn * NT + j) * 32 + l31, lhi, ncols, eadd[i][j], eold[i][j]);
+    }
     for (int u = 0; u < nunits; u += 2) {
       step(tl, u, aA, aB);
       if (u + 1 < nunits) step(tl, u + 1, aB, aA);
@@ -308,15 +321,24 @@ void conv_mfma_kernel(ConvP p) {
         for (int r = 0; r < 16; ++r) {
           int ch = q * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
           PE_OPAQUE(ch);
-          conv_store_gate(p, eb, ch, col, acc[0][j][r], acc[MT - 1][j][r]);
+          if (ch < p.split && col < ncols) conv_store_gate(p, b, ch, col, acc[0][j][r], acc[MT - 1][j][r]);
         }
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < MT; ++i)
+      for (int i = 0; i < MT; ++i) {
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-          conv_store_tile(p, ef, eb, (mtile0 + i) * 32, n0 + (wn * NT + j) * 32 + l31, lhi, L, acc[i][j]);
+        for (int j = 0; j < NT; ++j) {
+          const int row0 = (mtile0 + i) * 32, col = n0 + (wn * NT + j) * 32 + l31;
+          if constexpr (PREF) {
+            epi_finish(p, ef, b, row0, col, lhi, L, ncols, acc[i][j], eadd[i][j], eold[i][j]);
+          } else {
+            float add[16], old[16];
+            epi_fetch(p, ef, b, row0, col, lhi, ncols, add, old);
+            epi_finish(p, ef, b, row0, col, lhi, L, ncols, acc[i][j], add, old);
+          }
+        }
+      }
     }
   }
 }
@@ -428,8 +450,6 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk_kernel(ConvP p) {
     for (int r = 0; r < 16; ++r) red[(wv * MT * 16 + i * 16 + r) * 64 + lane] = acc[i][r];
   __syncthreads();
   const int col = n0 + l31;
-  const EpiFlags ef = epi_flags(p);
-  const EpiBufs eb = epi_bufs(p, b);
   if constexpr (GATE) {
     for (int r = wv; r < 16; r += NW) {
       float ta = 0.f, sa = 0.f;
@@ -438,7 +458,7 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk_kernel(ConvP p) {
         sa += red[(w * MT * 16 + (MT - 1) * 16 + r) * 64 + lane];
       }
       const int ch = (mtile0 >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-      conv_store_gate(p, eb, ch, col, ta, sa);
+      if (ch < p.split && col < ncols) conv_store_gate(p, b, ch, col, ta, sa);
     }
     return;
   }
@@ -447,7 +467,7 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk_kernel(ConvP p) {
     for (int w = 0; w < NW; ++w) v += red[(w * MT * 16 + s) * 64 + lane];
     const int i = s >> 4, r = s & 15;
     const int row = (mtile0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-    conv_store(p, ef, eb, row, col, v, L);
+    if (row < p.rows && col < ncols) conv_store(p, epi_flags(p), b, row, col, v, L);
   }
 }
 

@@ -17,9 +17,6 @@
 struct pe_rowsrc { const float* p; int n; };
 inline pe_rowsrc pe_make_row(const float* row, int n) { return pe_rowsrc{row, n}; }
 inline float pe_row_load(const pe_rowsrc& r, int idx) { return (idx >= 0 && idx < r.n) ? r.p[idx] : 0.f; }
-inline void pe_row_store(const pe_rowsrc& r, int idx, float v) {
-  if (idx >= 0 && idx < r.n) const_cast<float*>(r.p)[idx] = v;
-}
 #else
 #include <hip/hip_runtime.h>
 #define PE_LAUNCH(kernel, grid, block, smem, stream, ...) \
@@ -48,10 +45,6 @@ __device__ __forceinline__ pe_rowsrc pe_make_row(const float* row, int n) {
 }
 __device__ __forceinline__ float pe_row_load(pe_rowsrc r, int idx) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, idx * 4, 0, 0));
-}
-// out-of-range stores are dropped by the same hardware check
-__device__ __forceinline__ void pe_row_store(pe_rowsrc r, int idx, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), r, idx * 4, 0, 0);
 }
 #endif
 
