@@ -167,6 +167,7 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
   if (H_ <= 0 || C_ <= 0 || nh_ <= 0 || H_ % nh_ || (C_ & 1)) throw std::runtime_error("bad architecture header");
   dk_ = H_ / nh_;
   if (dk_ > 128 || (dk_ & 1)) throw std::runtime_error("head dimension must be even and <= 128");
+  if (H_ % 32) throw std::runtime_error("hidden_channels must be a multiple of 32");
   hop_ = 1;
   for (int i = 0; i < arch_[A_NUPS]; ++i) hop_ *= arch_[A_UPR0 + i];
 

@@ -90,60 +90,62 @@ __device__ __forceinline__ void conv_store(const ConvP& p, const EpiFlags& f, in
   if (f.relu) v = v > 0.f ? v : 0.f;
   *d = v;
 }
-// One 32x32 accumulator tile (16 values per lane) goes through the epilogue in two phases: epi_fetch
-// reads every operand the epilogue needs (bias, residual, previous value) for all 16 elements, epi_finish
-// computes and stores. Splitting them (a) lets the 16 read-modify-write chains overlap instead of
-// serialising on memory latency (out/res may alias, which otherwise forces load-wait-store per element)
-// and (b) lets the kernel issue the fetch BEFORE the tile's MFMAs so the latency hides under them.
-__device__ __forceinline__ void epi_fetch(const ConvP& p, const EpiFlags& f, int b, int row0, int col, int lhi,
-                                          int ncols, float (&add)[16], float (&old)[16]) {
-  const bool colok = col < ncols;
+// One 32x32 accumulator tile (16 values per lane) through the epilogue. Two phases -- fetch every operand
+// (bias, residual, previous value) for all 16 elements, then compute and store -- so the 16
+// read-modify-write chains overlap instead of serialising on memory latency (out/res may alias, which
+// otherwise forces load-wait-store order per element). The column predicate is one exec-mask region for
+// the whole tile; full tiles (the common case) carry no row predicate; addresses are a uniform base
+// pointer plus a 32-bit lane offset plus a uniform k*stride, i.e. one VALU add per element.
+// WNRS relies on split % 32 == 0 (checked at load), so a tile lies entirely on one side of the split.
+__device__ __forceinline__ void conv_store_tile(const ConvP& p, const EpiFlags& f, int b, int row0, int col, int lhi,
+                                                int L, int ncols, const f32x16& acc) {
+  if (col >= ncols) return;
+  int rb = row0 + 4 * lhi;
+  PE_OPAQUE(rb);       // keeps the (tile-invariant) row addressing and bias loads from being hoisted out of the
+                       // tile loop into dozens of live registers
+  if (p.epi == EPI_CONVT) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = rb + (r & 3) + 8 * (r >> 2);
+      if (row >= p.rows) continue;
+      const int co = row / p.up, ph = row - co * p.up;
+      const int t = col * p.up + ph - p.padT;
+      if (t >= 0 && t < L * p.up)
+        p.out[(long)b * p.o_bs + (long)co * p.o_cs + t] = acc[r] + (p.bias ? p.bias[co] : 0.f);
+    }
+    return;
+  }
+  const bool full = row0 + 32 <= p.rows;
+  const bool to_skip = p.epi == EPI_WNRS && row0 >= p.split;        // uniform per tile
+  const bool rd_old = to_skip ? (p.mode != 1) : (f.use_old || p.epi == EPI_WNRS);
+  float* ob = to_skip ? p.out2 + (long)b * p.o2_bs : p.out + (long)b * p.o_bs;
+  const unsigned ocs = to_skip ? (unsigned)p.o2_cs : (unsigned)p.o_cs;
+  const unsigned ooff = (unsigned)(to_skip ? rb - p.split : rb) * ocs + (unsigned)col;
+  const float* rs = p.res + (long)b * p.r_bs;
+  const unsigned roff = (unsigned)rb * (unsigned)p.r_cs + (unsigned)col;
+  const float* b2 = p.bias2 ? p.bias2 + (long)b * p.bias2_bs : nullptr;
+  float add[16], old[16];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-    PE_OPAQUE(row);
+    const int kr = (r & 3) + 8 * (r >> 2);
     float a = 0.f, o = 0.f;
-    if (p.epi == EPI_CONVT) {
-      if (p.bias && row < p.rows) a = p.bias[row / p.up];
-    } else if (colok && row < p.rows) {
-      if (p.bias) a = p.bias[row];
-      if (p.bias2) a += p.bias2[(long)b * p.bias2_bs + row];
-      const float* d = p.out + (long)b * p.o_bs + (long)row * p.o_cs + col;
-      bool use_old = f.use_old;
-      if (p.epi == EPI_WNRS) {
-        if (row < p.split) use_old = true;
-        else {
-          d = p.out2 + (long)b * p.o2_bs + (long)(row - p.split) * p.o2_cs + col;
-          use_old = p.mode != 1;
-        }
-      }
-      if (use_old) o = *d;
-      if (f.use_res) o += p.res[(long)b * p.r_bs + (long)row * p.r_cs + col];
+    if (full || rb + kr < p.rows) {
+      if (p.bias) a = p.bias[rb + kr];
+      if (b2) a += b2[rb + kr];
+      if (rd_old) o = ob[ooff + (unsigned)kr * ocs];
+      if (f.use_res) o += rs[roff + (unsigned)kr * (unsigned)p.r_cs];
     }
     add[r] = a;
     old[r] = o;
   }
-}
-__device__ __forceinline__ void epi_finish(const ConvP& p, const EpiFlags& f, int b, int row0, int col, int lhi, int L,
-                                           int ncols, const f32x16& acc, const float (&add)[16],
-                                           const float (&old)[16]) {
-  const bool colok = col < ncols;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-    PE_OPAQUE(row);
-    if (!(colok && row < p.rows)) continue;
-    if (p.epi == EPI_CONVT) {
-      const int co = row / p.up, ph = row - co * p.up;
-      const int t = col * p.up + ph - p.padT;
-      if (t >= 0 && t < L * p.up) p.out[(long)b * p.o_bs + (long)co * p.o_cs + t] = acc[r] + add[r];
-      continue;
+    const int kr = (r & 3) + 8 * (r >> 2);
+    if (full || rb + kr < p.rows) {
+      float v = ((acc[r] + add[r]) * f.sign + old[r]) * f.alpha;
+      if (f.relu) v = v > 0.f ? v : 0.f;
+      ob[ooff + (unsigned)kr * ocs] = v;
     }
-    float* d = p.out + (long)b * p.o_bs + (long)row * p.o_cs + col;
-    if (p.epi == EPI_WNRS && row >= p.split) d = p.out2 + (long)b * p.o2_bs + (long)(row - p.split) * p.o2_cs + col;
-    float v = ((acc[r] + add[r]) * f.sign + old[r]) * f.alpha;
-    if (f.relu) v = v > 0.f ? v : 0.f;
-    *d = v;
   }
 }
 // commons.py:99-106 fused_add_tanh_sigmoid_multiply on a (tanh-tile, sigmoid-tile) accumulator pair
@@ -279,9 +281,6 @@ void conv_mfma_kernel(ConvP p) {
   store_x(0);
   __syncthreads();
   const EpiFlags ef = epi_flags(p);
-  // wave tiles of <= 2 MFMA tiles fetch their epilogue operands before the MFMAs (32 registers at most)
-  constexpr bool PREF = false;   // measured: no gain, and the 32 extra registers cost a wave per SIMD
-  float eadd[PREF ? MT : 1][PREF ? NT : 1][16], eold[PREF ? MT : 1][PREF ? NT : 1][16];
   for (int tl = 0; tl < ntl; ++tl) {
     const int n0 = (tile0 + tl) * BN;
 #pragma unroll
@@ -290,13 +289,6 @@ void conv_mfma_kernel(ConvP p) {
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    if constexpr (PREF) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-          epi_fetch(p, ef, b, (mtile0 + i) * 32, n0 + (wn * NT + j) * 32 + l31, lhi, ncols, eadd[i][j], eold[i][j]);
-    }
     for (int u = 0; u < nunits; u += 2) {
       step(tl, u, aA, aB);
       if (u + 1 < nunits) step(tl, u + 1, aB, aA);
@@ -326,19 +318,10 @@ void conv_mfma_kernel(ConvP p) {
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < MT; ++i) {
+      for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int row0 = (mtile0 + i) * 32, col = n0 + (wn * NT + j) * 32 + l31;
-          if constexpr (PREF) {
-            epi_finish(p, ef, b, row0, col, lhi, L, ncols, acc[i][j], eadd[i][j], eold[i][j]);
-          } else {
-            float add[16], old[16];
-            epi_fetch(p, ef, b, row0, col, lhi, ncols, add, old);
-            epi_finish(p, ef, b, row0, col, lhi, L, ncols, acc[i][j], add, old);
-          }
-        }
-      }
+        for (int j = 0; j < NT; ++j)
+          conv_store_tile(p, ef, b, (mtile0 + i) * 32, n0 + (wn * NT + j) * 32 + l31, lhi, L, ncols, acc[i][j]);
     }
   }
 }
