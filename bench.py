@@ -33,6 +33,8 @@ def main():
     ap.add_argument("--ids", type=int, default=128, help="phoneme ids per utterance")
     ap.add_argument("--batch", type=int, default=1, help="utterances per step (per GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stream-latency", action="store_true",
+                    help="BASELINE configs[4]: p50 time to the first chunk of a chunked (45-frame) decode, then exit")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -77,6 +79,10 @@ def main():
         torch.cuda.synchronize()
         t_bcast = time.perf_counter() - t0
     eng = Engine(blob=blob, device=dev_index)
+
+    if args.stream_latency:
+        stream_latency(eng, cfg, args, rank)
+        return
 
     # ---- synthetic input, resident in HBM before timing
     B, T = args.batch, args.ids
@@ -187,6 +193,38 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def stream_latency(eng, cfg, args, rank):
+    """Time from the request to the first 45-frame chunk of PCM (encoder + durations + flow + one
+    exact-halo vocoder window), like the "Latency" the reference's streaming script logs
+    (infer_onnx_streaming.py:118-121), over >= 100 requests; plus the whole-utterance streaming rate."""
+    from piper_amd import weights as W
+    ids = W.synthetic_phoneme_ids(args.ids, rank, id_max=min(cfg.n_vocab - 1, 129))
+    scales = (0.667, 1.0, 0.8)
+    first, total, samples = [], [], 0
+    n = max(100, args.steps)
+    for i in range(n + args.warmup):
+        t0 = time.perf_counter()
+        it = eng.stream(ids, scales, chunk_frames=45)
+        a, _ = next(it)
+        t1 = time.perf_counter()
+        cnt = a.size + sum(c[0].size for c in it)
+        t2 = time.perf_counter()
+        if i >= args.warmup:
+            first.append((t1 - t0) * 1e3)
+            total.append((t2 - t0) * 1e3)
+            samples = cnt
+    first.sort()
+    total.sort()
+    print(json.dumps({
+        "metric": "p50 first-chunk latency", "value": first[len(first) // 2], "unit": "ms", "higher_is_better": False,
+        "p95_ms": first[int(len(first) * 0.95)], "n_gpus": 1, "steps": n, "warmup": args.warmup, "dtype": "f32",
+        "data": "synthetic", "vs_baseline": None,
+        "config": {"workload": f"{args.preset} VITS voice, streaming decode, one {args.ids}-id utterance, 45-frame chunks, "
+                               f"halo {eng.stream_halo} frames, {eng.stream_frames} frames total"},
+        "utterance_ms_p50": total[len(total) // 2],
+        "streaming_samples_per_s": samples / (total[len(total) // 2] * 1e-3)}), flush=True)
 
 
 def cpu_baseline(cfg, wts, ids, scales, noise_w, budget_s):

@@ -76,6 +76,17 @@ int pe_upload(pe_engine* e, const int64_t* ids, const int64_t* offsets, int32_t 
 int pe_run(pe_engine* e);
 int pe_fetch(pe_engine* e, int want_audio, int want_pcm, pe_result* result);
 
+/* Streaming decode of one utterance (BASELINE.json configs[4]; reference behaviour:
+ * src/python/piper_train/infer_onnx_streaming.py:76-124 -- encoder once, then the decoder on chunks of
+ * frames). pe_stream_begin runs the text encoder, duration predictor and flow and reports the frame count;
+ * every pe_stream_next returns the samples of the next `chunk_frames` frames (reference default 45),
+ * decoded on a window padded by the generator's exact receptive half-width (`halo_frames`), so the chunks
+ * concatenate to exactly the unchunked waveform. `pcm` is peak-normalised per chunk, like the reference's
+ * streaming script. *n_samples == 0 means the utterance is finished. */
+int pe_stream_begin(pe_engine* e, const int64_t* ids, int64_t n_ids, const float scales[3], int64_t sid,
+                    const pe_noise* noise, int32_t* total_frames, int32_t* halo_frames);
+int pe_stream_next(pe_engine* e, int32_t chunk_frames, const float** audio, const int16_t** pcm, int64_t* n_samples);
+
 /* Integer per-id durations (ceil(w), reference models.py:703) of the last call, concatenated like ids. */
 int pe_get_durations(pe_engine* e, int32_t* out, int64_t capacity, int64_t* n);
 

@@ -13,7 +13,8 @@ LIB_PATH = os.path.join(_HERE, "libpiper_hip.so")
 
 SYMBOLS = [
     "pe_create", "pe_create_from_blob", "pe_onnx_to_blob", "pe_free", "pe_synthesize",
-    "pe_synthesize_batch", "pe_upload", "pe_run", "pe_fetch", "pe_get_durations", "pe_get_info",
+    "pe_synthesize_batch", "pe_upload", "pe_run", "pe_fetch", "pe_stream_begin", "pe_stream_next",
+    "pe_get_durations", "pe_get_info",
     "pe_set_seed", "pe_profile_enable", "pe_profile_reset", "pe_profile_rows", "pe_profile_get",
     "pe_stream", "pe_debug_tensor", "pe_last_error", "pe_destroy",
 ]
@@ -51,6 +52,8 @@ def bind(path: str) -> C.CDLL:
     lib.pe_upload.argtypes = [vp, i64p, i64p, C.c_int32, f32p, i64p, C.POINTER(PeNoise)]
     lib.pe_run.argtypes = [vp]
     lib.pe_fetch.argtypes = [vp, C.c_int, C.c_int, C.POINTER(PeResult)]
+    lib.pe_stream_begin.argtypes = [vp, i64p, C.c_int64, f32p, C.c_int64, C.POINTER(PeNoise), i32p, i32p]
+    lib.pe_stream_next.argtypes = [vp, C.c_int32, C.POINTER(f32p), C.POINTER(C.POINTER(C.c_int16)), i64p]
     lib.pe_get_durations.argtypes = [vp, i32p, C.c_int64, i64p]
     lib.pe_get_info.argtypes = [vp, i32p, i32p, i32p, i32p, i64p]
     lib.pe_set_seed.argtypes = [vp, C.c_uint64]

@@ -300,6 +300,27 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
     cond_bs_ = off;
   }
 
+  {
+    // receptive half-width of the generator in frames (SURVEY.md section 7 hard part F), walking back from
+    // the waveform: conv_post, then per stage the widest resblock and the transposed conv, then conv_pre
+    long r = 3;
+    const int nk = arch_[A_NRB], nd = arch_[A_NDIL];
+    for (int i = (int)ups_.size() - 1; i >= 0; --i) {
+      long widest = 0;
+      for (int j = 0; j < nk; ++j) {
+        const long hk = (arch_[A_RBK0 + j] - 1) / 2;
+        long w = 0;
+        for (int d = 0; d < nd; ++d) {
+          w += hk * arch_[A_RBDIL0 + j * MAX_DIL + d];
+          if (arch_[A_RESBLOCK] == 1) w += hk;
+        }
+        widest = std::max(widest, w);
+      }
+      r += widest;
+      r = (r + ups_[i].rate - 1) / ups_[i].rate + 1;
+    }
+    halo_frames_ = (int)(r + 3);
+  }
 #ifndef PE_EMU
   {
     // allow > 64 KiB of dynamic LDS (gfx950: 160 KiB per workgroup)
@@ -426,6 +447,8 @@ void Engine::ensure_stage_b(int Fmax) {
     fskip_ = c.take<float>(Bc * H_ * F);
     noise_z_ = c.take<float>(Bc * C_ * F);
     for (int i = 0; i < 5; ++i) hb_[i] = c.take<float>(Bc * hmax);
+    zwin_ = c.take<float>((size_t)C_ * F);
+    d_win_ = c.take<int>(4);
     audio_ = c.take<float>(Bc * (size_t)Ss_);
     pcm_ = c.take<int16_t>(Bc * (size_t)Ss_);
     return c.off + 256;
@@ -808,12 +831,11 @@ void Engine::issue_stage_a() {
 
 // Length regulator, prior sample, coupling flow, HiFiGAN, int16 conversion -- sized by the bucketed
 // maximum frame count Fg_.
-void Engine::issue_stage_b() {
+void Engine::issue_flow() {
   const int B = B_, Ts = Ts_, Fmax = Fg_, Fs = Fs_;
   const View none{nullptr, 0, 0};
   double fsum = 0;
   for (int b = 0; b < B; ++b) fsum += frames_h_[b];
-  const float* cb_dec = nspk_ > 1 ? cond_ + cond_off_dec_ : nullptr;
   double fl = 0;
 
   // ================= length regulator + prior noise + coupling flow (models.py:705-719)
@@ -860,12 +882,34 @@ void Engine::issue_stage_b() {
   }
   prof_end(2, fl);
 
+}
+
+void Engine::issue_stage_b() {
+  issue_flow();
+  double fsum = 0;
+  for (int b = 0; b < B_; ++b) fsum += frames_h_[b];
+  issue_decoder(zp_, d_frames_, Fg_, fsum);
+}
+
+// streaming: window of z -> window buffer -> generator (lens = window length, in device memory)
+void Engine::issue_window() {
+  PE_LAUNCH(window_copy_kernel, dim3((s_wg_ + 63) / 64, C_), dim3(64), 0, stream_, zp_, Fs_, d_win_, zwin_, Fs_, C_);
+  issue_decoder(zwin_, d_win_ + 1, s_wg_, (double)s_wg_);
+}
+
+// HiFiGAN generator + conv_post + int16 on z (already masked by its length semantics). `zsrc` is
+// [B][C][Fs_]; `lens` the per-utterance frame counts in device memory; Fmax the grid bound.
+void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double fsum) {
+  const int B = B_, Fs = Fs_;
+  const View none{nullptr, 0, 0};
+  const float* cb_dec = nspk_ > 1 ? cond_ + cond_off_dec_ : nullptr;
+  double fl = 0;
   // ================= HiFiGAN generator (models.py:348-368)
   prof_begin();
   fl = 0;
   {
     View cur{hb_[0], (long)U_ * Fs, Fs};
-    conv(dec_pre_, View{zp_, (long)C_ * Fs, Fs}, cur, d_frames_, 1, Fmax, EPI_STORE, 1.f, ACT_NONE, none, none, 0, 1.f,
+    conv(dec_pre_, View{const_cast<float*>(zsrc), (long)C_ * Fs, Fs}, cur, lens, 1, Fmax, EPI_STORE, 1.f, ACT_NONE, none, none, 0, 1.f,
          cb_dec, cond_bs_);
     fl += 2.0 * fsum * dec_pre_.macs_per_col;
     int mult = 1;
@@ -883,7 +927,7 @@ void Engine::issue_stage_b() {
       auto VS = [&](int bi) { return View{hb_[bi], (long)st.ch * Ls, (int)Ls}; };
       const View u = VS(ids[0]), ta = VS(ids[1]), tb = VS(ids[2]), tc = VS(ids[3]);
       // leaky_relu(0.1) -> ConvTranspose1d
-      conv(st.up, cur, u, d_frames_, Lin, Fmax * Lin, EPI_CONVT, 0.1f);
+      conv(st.up, cur, u, lens, Lin, Fmax * Lin, EPI_CONVT, 0.1f);
       fl += 2.0 * fsum * Lin * st.up.macs_per_col;
       // xs accumulates into the buffer that held the stage input (free once the up-conv is done)
       const View xs{hb_[cur_buf], (long)st.ch * Ls, (int)Ls};
@@ -896,13 +940,13 @@ void Engine::issue_stage_b() {
           View xin = u;
           const int np = (int)cv.size() / 2;
           for (int d = 0; d < np; ++d) {
-            conv(cv[2 * d], xin, tb, d_frames_, mult, Lmax, EPI_STORE, 0.1f);
+            conv(cv[2 * d], xin, tb, lens, mult, Lmax, EPI_STORE, 0.1f);
             if (d < np - 1) {
               const View nxt = (d & 1) ? tc : ta;
-              conv(cv[2 * d + 1], tb, nxt, d_frames_, mult, Lmax, EPI_RESADD, 0.1f, ACT_NONE, xin);
+              conv(cv[2 * d + 1], tb, nxt, lens, mult, Lmax, EPI_RESADD, 0.1f, ACT_NONE, xin);
               xin = nxt;
             } else {
-              conv(cv[2 * d + 1], tb, xs, d_frames_, mult, Lmax, EPI_ACCUM, 0.1f, ACT_NONE, xin, none, accmode, inv_nk);
+              conv(cv[2 * d + 1], tb, xs, lens, mult, Lmax, EPI_ACCUM, 0.1f, ACT_NONE, xin, none, accmode, inv_nk);
             }
             fl += 2.0 * fsum * mult * (cv[2 * d].macs_per_col + cv[2 * d + 1].macs_per_col);
           }
@@ -913,10 +957,10 @@ void Engine::issue_stage_b() {
           for (int d = 0; d < nc; ++d) {
             if (d < nc - 1) {
               const View nxt = (d & 1) ? tc : ta;
-              conv(cv[d], xin, nxt, d_frames_, mult, Lmax, EPI_RESADD, 0.1f, ACT_NONE, xin);
+              conv(cv[d], xin, nxt, lens, mult, Lmax, EPI_RESADD, 0.1f, ACT_NONE, xin);
               xin = nxt;
             } else {
-              conv(cv[d], xin, xs, d_frames_, mult, Lmax, EPI_ACCUM, 0.1f, ACT_NONE, xin, none, accmode, inv_nk);
+              conv(cv[d], xin, xs, lens, mult, Lmax, EPI_ACCUM, 0.1f, ACT_NONE, xin, none, accmode, inv_nk);
             }
             fl += 2.0 * fsum * mult * cv[d].macs_per_col;
           }
@@ -932,8 +976,8 @@ void Engine::issue_stage_b() {
     const int K = 7, Lmax = Fmax * hop_;
     const size_t smem = ((size_t)post_cin_ * K + (size_t)post_cin_ * (256 + K - 1)) * sizeof(float);
     PE_LAUNCH(conv_post_kernel, dim3((Lmax + 255) / 256, B), dim3(256), smem, stream_, cur.p, cur.bs, cur.cs, post_w_,
-              post_cin_, K, 0.01f, d_frames_, hop_, audio_, Ss_, absmax_);
-    PE_LAUNCH(pcm16_kernel, dim3((Lmax + 255) / 256, B), dim3(256), 0, stream_, audio_, Ss_, absmax_, d_frames_, hop_,
+              post_cin_, K, 0.01f, lens, hop_, audio_, Ss_, absmax_);
+    PE_LAUNCH(pcm16_kernel, dim3((Lmax + 255) / 256, B), dim3(256), 0, stream_, audio_, Ss_, absmax_, lens, hop_,
               pcm_, Ss_);
     prof_end(4, 2.0 * fsum * hop_ * post_cin_ * K);
   }
@@ -949,7 +993,7 @@ void Engine::run_stage(char which, const std::string& key) {
       hipGraph_t g = nullptr;
       PE_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
       try {
-        if (which == 'A') issue_stage_a(); else issue_stage_b();
+        dispatch_stage(which);
       } catch (...) {
         hipStreamEndCapture(stream_, &g);
         if (g) hipGraphDestroy(g);
@@ -967,7 +1011,16 @@ void Engine::run_stage(char which, const std::string& key) {
   }
 #endif
   (void)key;
-  if (which == 'A') issue_stage_a(); else issue_stage_b();
+  dispatch_stage(which);
+}
+
+void Engine::dispatch_stage(char which) {
+  switch (which) {
+    case 'A': issue_stage_a(); break;
+    case 'B': issue_stage_b(); break;
+    case 'F': issue_flow(); break;
+    default: issue_window(); break;
+  }
 }
 
 void Engine::drop_graphs() {
@@ -1026,6 +1079,75 @@ void Engine::download(bool want_audio, bool want_pcm) {
                             stream_));
   }
   PE_HIP(hipStreamSynchronize(stream_));
+}
+
+int Engine::stream_begin(const int64_t* ids, int64_t n, const float scales[3], int64_t sid, const NoiseIn* noise) {
+  const int64_t offs[2] = {0, n};
+  const int64_t sids[1] = {sid < 0 ? 0 : sid};
+  upload(ids, offs, 1, scales, sids, noise);
+  PE_HIP(hipSetDevice(device_));
+  Tg_ = std::min(rup(Tmax_, 32), Ts_);
+  char key[160];
+  snprintf(key, sizeof(key), "A|%d|%d|%d|%a|%a|%d", 1, Tg_, Ts_, scales_[1], scales_[2], (int)have_noise_w_);
+  run_stage('A', key);
+  PE_HIP(hipStreamSynchronize(stream_));
+  frames_h_.assign(h_frames_, h_frames_ + 1);
+  Fmax_ = std::max(1, frames_h_[0]);
+  ensure_stage_b(rup(Fmax_, 32));
+  Fg_ = std::min(rup(Fmax_, 32), Fs_);
+  if (have_noise_z_) {
+    issue_flow();
+  } else {
+    snprintf(key, sizeof(key), "F|%d|%d|%d|%d|%a", 1, Fg_, Fs_, Ts_, scales_[0]);
+    run_stage('F', key);
+  }
+  s_frames_ = Fmax_;
+  s_pos_ = 0;
+  s_active_ = true;
+  sample_off_.assign(2, 0);
+  return s_frames_;
+}
+
+bool Engine::stream_next(int chunk_frames, const float** audio, const int16_t** pcm, int64_t* nsamples) {
+  if (!s_active_ || s_pos_ >= s_frames_) {
+    s_active_ = false;
+    if (nsamples) *nsamples = 0;
+    return false;
+  }
+  if (chunk_frames < 1) throw std::runtime_error("chunk_frames must be >= 1");
+  PE_HIP(hipSetDevice(device_));
+  const int f0 = s_pos_, f1 = std::min(s_frames_, s_pos_ + chunk_frames);
+  const int a = std::max(0, f0 - halo_frames_), b = std::min(s_frames_, f1 + halo_frames_);
+  const int win[2] = {a, b - a};
+  PE_HIP(hipMemcpyAsync(d_win_, win, sizeof(win), hipMemcpyHostToDevice, stream_));
+  s_wg_ = std::min(rup(chunk_frames + 2 * halo_frames_, 32), Fs_);
+  if (s_wg_ < b - a) s_wg_ = std::min(rup(b - a, 32), Fs_);
+  char key[96];
+  snprintf(key, sizeof(key), "W|%d|%d", s_wg_, Fs_);
+  run_stage('W', key);
+  const size_t n = (size_t)(f1 - f0) * hop_;
+  if (n > h_audio_cap_) {
+    if (h_audio_) PE_HIP(hipHostFree(h_audio_));
+    h_audio_cap_ = n + n / 2;
+    PE_HIP(hipHostMalloc((void**)&h_audio_, h_audio_cap_ * sizeof(float)));
+  }
+  PE_HIP(hipMemcpyAsync(h_audio_, audio_ + (size_t)(f0 - a) * hop_, n * sizeof(float), hipMemcpyDeviceToHost, stream_));
+  PE_HIP(hipStreamSynchronize(stream_));
+  // per-chunk peak normalisation, as the reference's streaming script does (infer_onnx_streaming.py:122)
+  float peak = 0.01f;
+  for (size_t i = 0; i < n; ++i) peak = std::max(peak, std::fabs(h_audio_[i]));
+  const float sc = 32767.0f / peak;
+  s_pcm_.resize(n);
+  for (size_t i = 0; i < n; ++i) {
+    float v = h_audio_[i] * sc;
+    v = std::min(std::max(v, -32768.0f), 32767.0f);
+    s_pcm_[i] = (int16_t)v;
+  }
+  s_pos_ = f1;
+  if (audio) *audio = h_audio_;
+  if (pcm) *pcm = s_pcm_.data();
+  if (nsamples) *nsamples = (int64_t)n;
+  return true;
 }
 
 const std::vector<int32_t>& Engine::durations_host() {

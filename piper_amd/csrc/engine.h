@@ -57,6 +57,15 @@ class Engine {
   // Phase 3: results to host (pinned buffers owned by the engine, valid until the next upload()).
   void download(bool want_audio, bool want_pcm);
 
+  // Streaming decode of ONE utterance (BASELINE configs[4]; reference infer_onnx_streaming.py:76-124):
+  // stream_begin runs everything up to the latent z (encoder, durations, flow) and returns the frame
+  // count; every stream_next decodes the next `chunk_frames` frames through HiFiGAN on a window padded
+  // with the generator's exact receptive half-width, so the concatenated chunks equal the unchunked
+  // waveform (the reference pads by a heuristic 5-10 frames and does not). Returns false when done.
+  int stream_begin(const int64_t* ids, int64_t n, const float scales[3], int64_t sid, const NoiseIn* noise);
+  bool stream_next(int chunk_frames, const float** audio, const int16_t** pcm, int64_t* nsamples);
+  int decoder_halo_frames() const { return halo_frames_; }
+
   int batch() const { return B_; }
   const std::vector<int64_t>& sample_offsets() const { return sample_off_; }
   const float* audio_host() const { return h_audio_; }
@@ -103,7 +112,11 @@ class Engine {
   void dds(const DdsW& d, View x, View tmp1, View tmp2);
   void issue_stage_a();
   void issue_stage_b();
+  void issue_flow();
+  void issue_window();
+  void issue_decoder(const float* zsrc, const int* lens, int Fmax, double fsum);
   void run_stage(char which, const std::string& key);
+  void dispatch_stage(char which);
   void drop_graphs();
   void prof_begin();
   void prof_end(int row, double flops);
@@ -186,6 +199,11 @@ class Engine {
   int cond_off_dp_ = 0, cond_off_dec_ = 0;
   float *zp_ = nullptr, *fh_ = nullptr, *facts_ = nullptr, *fskip_ = nullptr, *noise_z_ = nullptr;
   float* hb_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  float* zwin_ = nullptr;          // streaming: current window of z, [C][Fs]
+  int* d_win_ = nullptr;           // streaming: {start, length} of the window in frames
+  int halo_frames_ = 0, s_frames_ = 0, s_pos_ = 0, s_wg_ = 0;
+  bool s_active_ = false;
+  std::vector<int16_t> s_pcm_;
   float* audio_ = nullptr;
   int16_t* pcm_ = nullptr;
   unsigned* absmax_ = nullptr;

@@ -959,6 +959,14 @@ __global__ void randn_kernel(float* out, long n, const unsigned long long* state
   for (int k = 0; k < 4 && i4 + k < n; ++k) out[i4 + k] = g[k];
 }
 
+// Streaming decode: copy frames [win[0], win[0]+win[1]) of z [C][zs] into the window buffer [C][ws]
+// (window bounds live in device memory so one captured graph serves every chunk).
+__global__ void window_copy_kernel(const float* z, int zs, const int* win, float* out, int ws, int C) {
+  const int c = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C && t < win[1]) out[(long)c * ws + t] = z[(long)c * zs + win[0] + t];
+}
+
 __global__ void scale_kernel(float* x, long n, float s) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] *= s;

@@ -152,6 +152,28 @@ int pe_synthesize(pe_engine* e, const int64_t* ids, int64_t n_ids, const float s
   return pe_synthesize_batch(e, ids, e->one_off.data(), 1, scales, sids, noise, result);
 }
 
+int pe_stream_begin(pe_engine* e, const int64_t* ids, int64_t n_ids, const float scales[3], int64_t sid,
+                    const pe_noise* noise, int32_t* total_frames, int32_t* halo_frames) {
+  return guard([&] {
+    if (!e || !ids || !scales) throw std::runtime_error("null argument");
+    pe::NoiseIn n;
+    if (noise) {
+      n.noise_w = noise->noise_w; n.w_stride = noise->w_stride;
+      n.noise_z = noise->noise_z; n.z_stride = noise->z_stride;
+    }
+    const int f = e->eng->stream_begin(ids, n_ids, scales, sid, noise ? &n : nullptr);
+    if (total_frames) *total_frames = f;
+    if (halo_frames) *halo_frames = e->eng->decoder_halo_frames();
+  });
+}
+
+int pe_stream_next(pe_engine* e, int32_t chunk_frames, const float** audio, const int16_t** pcm, int64_t* n_samples) {
+  return guard([&] {
+    if (!e || !n_samples) throw std::runtime_error("null argument");
+    e->eng->stream_next(chunk_frames, audio, pcm, n_samples);
+  });
+}
+
 int pe_get_durations(pe_engine* e, int32_t* out, int64_t capacity, int64_t* n) {
   return guard([&] {
     if (!e || !n) throw std::runtime_error("null argument");

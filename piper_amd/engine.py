@@ -148,6 +148,27 @@ class Engine:
         self._check(self._lib.pe_fetch(self._h, int(want_audio), int(want_pcm), C.byref(res)))
         return self._collect(res, want_audio, want_pcm)
 
+    def stream(self, ids, scales=(0.667, 1.0, 0.8), sid=None, chunk_frames: int = 45, noise_w=None, noise_z=None):
+        """Generator over (float_audio, int16_pcm) chunks of one utterance: encoder/flow once, then the
+        vocoder on exact-halo windows of `chunk_frames` frames (reference default 45). Concatenating
+        the float chunks gives exactly the unchunked waveform; pcm is peak-normalised per chunk."""
+        ids_np = np.ascontiguousarray(ids, np.int64)
+        sc = (C.c_float * 3)(*[float(s) for s in scales])
+        keep: list = []
+        nw = None if noise_w is None else np.asarray(noise_w, np.float32)[None]
+        nz = None if noise_z is None else np.asarray(noise_z, np.float32)[None]
+        nref = self._noise(nw, nz, keep)
+        frames, halo = C.c_int32(), C.c_int32()
+        self._check(self._lib.pe_stream_begin(self._h, ids_np.ctypes.data_as(C.POINTER(C.c_int64)), ids_np.size, sc,
+                                              -1 if sid is None else int(sid), nref, C.byref(frames), C.byref(halo)))
+        self.stream_frames, self.stream_halo = frames.value, halo.value
+        while True:
+            a, p, n = C.POINTER(C.c_float)(), C.POINTER(C.c_int16)(), C.c_int64()
+            self._check(self._lib.pe_stream_next(self._h, int(chunk_frames), C.byref(a), C.byref(p), C.byref(n)))
+            if n.value == 0:
+                return
+            yield (np.ctypeslib.as_array(a, (n.value,)).copy(), np.ctypeslib.as_array(p, (n.value,)).copy())
+
     def durations(self) -> np.ndarray:
         n = C.c_int64()
         self._check(self._lib.pe_get_durations(self._h, None, 0, C.byref(n)))
@@ -174,7 +195,7 @@ class Engine:
         return rows
 
     @property
-    def stream(self) -> int:
+    def hip_stream(self) -> int:
         return int(self._lib.pe_stream(self._h) or 0)
 
     def debug_tensor(self, name: str, b: int = 0, capacity: int = 1 << 24) -> np.ndarray:

@@ -78,3 +78,18 @@ def test_emulated_multi_tile_conv_pipeline(emu_lib, monkeypatch):
     assert outs[0].shape == outs[1].shape and np.array_equal(outs[0], outs[1])
     o = O.synthesize(w, cfg, ids, (0.0, 1.0, 0.0))
     assert np.max(np.abs(outs[1] - o["audio"])) < 1e-4
+
+
+def test_emulated_streaming_equals_unchunked(emu_lib):
+    """Exact-halo chunked vocoding (pe_stream_*): chunks concatenate to the unchunked waveform."""
+    cfg = W.preset("tiny")
+    w = W.synthetic_weights(cfg, 1234)
+    eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
+    ids = W.synthetic_phoneme_ids(14, 2, id_max=cfg.n_vocab - 1)
+    full = eng.synthesize(ids, (0.0, 1.0, 0.0)).audio[0]
+    chunks = list(eng.stream(ids, (0.0, 1.0, 0.0), chunk_frames=4))
+    assert eng.stream_halo >= 8 and len(chunks) == -(-eng.stream_frames // 4)
+    cat = np.concatenate([c[0] for c in chunks])
+    assert cat.shape == full.shape
+    assert np.max(np.abs(cat - full)) < 1e-5
+    assert all(c[1].dtype == np.int16 and np.max(np.abs(c[1].astype(np.int32))) <= 32767 for c in chunks)

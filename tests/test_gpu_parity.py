@@ -216,3 +216,21 @@ def test_cpp_piper_api_on_gpu(tmp_path):
                          capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr + out.stdout
     assert out.stdout.startswith("OK ") and os.path.getsize(wav) >= 10000
+
+
+@pytest.mark.parametrize("preset,T,chunk", [("medium", 96, 45), ("high", 40, 45), ("tiny", 50, 7)])
+def test_streaming_chunks_equal_unchunked(preset, T, chunk):
+    """BASELINE configs[4]: chunked HiFiGAN decode. With the exact receptive-field halo the concatenated
+    chunks are the unchunked waveform (same noise), which the reference's heuristic padding is not."""
+    cfg, w, eng = engine_for(preset)
+    ids = W.synthetic_phoneme_ids(T, 5, id_max=min(cfg.n_vocab - 1, 129))
+    nw, nz = noise_for(cfg, T, 13)
+    scales = (0.667, 1.0, 0.8)
+    full = eng.synthesize(ids, scales, noise_w=nw, noise_z=nz)
+    chunks = list(eng.stream(ids, scales, chunk_frames=chunk, noise_w=nw, noise_z=nz))
+    assert eng.stream_frames == int(full.frames[0])
+    assert len(chunks) == -(-eng.stream_frames // chunk)
+    cat = np.concatenate([c[0] for c in chunks])
+    assert cat.shape == full.audio[0].shape
+    assert np.max(np.abs(cat - full.audio[0])) < 2e-5
+    assert all(c[0].size == chunk * eng.hop for c in chunks[:-1])
