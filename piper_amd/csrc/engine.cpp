@@ -161,6 +161,12 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
   memcpy(arch_, ws.arch, sizeof(arch_));
   PE_HIP(hipSetDevice(device_));
   PE_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
+  ls_ = stream_;
+  for (int i = 0; i < 2; ++i) {
+    PE_HIP(hipStreamCreateWithFlags(&side_stream_[i], hipStreamNonBlocking));
+    PE_HIP(hipEventCreateWithFlags(&ev_join_[i], hipEventDisableTiming));
+  }
+  PE_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
   H_ = arch_[A_HIDDEN]; C_ = arch_[A_INTER]; FC_ = arch_[A_FILTER]; nh_ = arch_[A_NHEADS];
   nlayers_ = arch_[A_NLAYERS]; ksz_ = arch_[A_KSIZE]; window_ = arch_[A_WINDOW]; U_ = arch_[A_UPINIT];
   gin_ = arch_[A_GIN]; nspk_ = arch_[A_NSPK];
@@ -347,6 +353,7 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
   if (const char* t = getenv("PIPER_HIP_TPB")) tpb_override_ = atoi(t);     // tuning / test knob
   if (const char* t = getenv("PIPER_HIP_WIDE_MIN")) wide_min_blocks_ = atol(t);
   if (const char* t = getenv("PIPER_HIP_SMALL")) small_tiles_ = atoi(t) != 0;
+  if (const char* t = getenv("PIPER_HIP_PAR_MRF")) par_mrf_ = atoi(t) != 0;
   if (const char* t = getenv("PIPER_HIP_ABL")) abl_ = atoi(t);              // timing ablations, results invalid
 }
 
@@ -361,6 +368,13 @@ Engine::~Engine() {
   if (h_frames_) hipHostFree(h_frames_);
   if (ev0_) hipEventDestroy(ev0_);
   if (ev1_) hipEventDestroy(ev1_);
+  for (int i = 0; i < 2; ++i) {
+    if (side_stream_[i]) hipStreamSynchronize(side_stream_[i]);
+    if (ev_join_[i]) hipEventDestroy(ev_join_[i]);
+    if (side_stream_[i]) hipStreamDestroy(side_stream_[i]);
+  }
+  if (ev_fork_) hipEventDestroy(ev_fork_);
+  for (float* p : side_) if (p) hipFree(p);
   hipStreamDestroy(stream_);
 }
 
@@ -461,6 +475,16 @@ void Engine::ensure_stage_b(int Fmax) {
     PE_HIP(hipMalloc((void**)&wsB_, wsB_bytes_));
   }
   carve(wsB_);
+  // per-branch buffers of the parallel MRF schedule (only used while a stage is small): allocated here,
+  // outside any graph capture
+  const size_t want = std::min<size_t>(Bc * hmax, ((size_t)64 << 20) / sizeof(float));
+  if (par_mrf_ && side_floats_ < want) {
+    PE_HIP(hipStreamSynchronize(stream_));
+    drop_graphs();
+    for (float*& sp : side_) { if (sp) PE_HIP(hipFree(sp)); sp = nullptr; }
+    side_floats_ = want;
+    for (float*& sp : side_) PE_HIP(hipMalloc((void**)&sp, side_floats_ * sizeof(float)));
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -509,11 +533,11 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     const size_t smem = std::max<size_t>((size_t)NW * KC * (32 + p.xhalo), (size_t)NW * MT * 16 * 64) * sizeof(float);
     const int kh = kbegin(prof_level_ >= 2 ? krow("conv_splitk_kernel") : 0, kflops);
     if (pc.gate) {
-      if (NW == 8) PE_LAUNCH((conv_splitk_kernel<2, true, 8>), grid, dim3(512), smem, stream_, p);
-      else PE_LAUNCH((conv_splitk_kernel<2, true, 4>), grid, dim3(256), smem, stream_, p);
+      if (NW == 8) PE_LAUNCH((conv_splitk_kernel<2, true, 8>), grid, dim3(512), smem, ls_, p);
+      else PE_LAUNCH((conv_splitk_kernel<2, true, 4>), grid, dim3(256), smem, ls_, p);
     } else {
-      if (NW == 8) PE_LAUNCH((conv_splitk_kernel<1, false, 8>), grid, dim3(512), smem, stream_, p);
-      else PE_LAUNCH((conv_splitk_kernel<1, false, 4>), grid, dim3(256), smem, stream_, p);
+      if (NW == 8) PE_LAUNCH((conv_splitk_kernel<1, false, 8>), grid, dim3(512), smem, ls_, p);
+      else PE_LAUNCH((conv_splitk_kernel<1, false, 4>), grid, dim3(256), smem, ls_, p);
     }
     kend(kh);
     return;
@@ -548,8 +572,8 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
   const int kh = kbegin(prof_level_ >= 2 ? krow(knames[cfg]) : 0, kflops);
 #define PE_CONV_LAUNCH(WM, WN, MT, NT, KS, G)                                                                  \
   do {                                                                                                         \
-    if (HALO == 64) PE_LAUNCH((conv_mfma_kernel<WM, WN, MT, NT, KS, G, 64>), grid, dim3(256), smem, stream_, p); \
-    else PE_LAUNCH((conv_mfma_kernel<WM, WN, MT, NT, KS, G, 128>), grid, dim3(256), smem, stream_, p);          \
+    if (HALO == 64) PE_LAUNCH((conv_mfma_kernel<WM, WN, MT, NT, KS, G, 64>), grid, dim3(256), smem, ls_, p); \
+    else PE_LAUNCH((conv_mfma_kernel<WM, WN, MT, NT, KS, G, 128>), grid, dim3(256), smem, ls_, p);          \
   } while (0)
   if (pc.gate) {
     switch (cfg) {
@@ -622,12 +646,12 @@ int Engine::kbegin(int row, double flops) {
     PE_HIP(hipEventCreate(&a));
     PE_HIP(hipEventCreate(&b));
   }
-  PE_HIP(hipEventRecord(a, stream_));
+  PE_HIP(hipEventRecord(a, ls_));
   kev_.push_back(KEvent{row, flops, a, b});
   return (int)kev_.size() - 1;
 }
 void Engine::kend(int h) {
-  if (h >= 0) PE_HIP(hipEventRecord(kev_[h].b, stream_));
+  if (h >= 0) PE_HIP(hipEventRecord(kev_[h].b, ls_));
 }
 const std::vector<ProfileRow>& Engine::profile() {
   if (!kev_.empty()) {
@@ -932,38 +956,69 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
       // xs accumulates into the buffer that held the stage input (free once the up-conv is done)
       const View xs{hb_[cur_buf], (long)st.ch * Ls, (int)Ls};
       const int Lmax = Fmax * mult;
-      for (int j = 0; j < nk; ++j) {
-        const int accmode = nk == 1 ? 3 : (j == 0 ? 0 : (j == nk - 1 ? 2 : 1));
+      // One resblock chain. `t` = {c1 output, ping, pong}; the chain's result goes to `dst` either as a plain
+      // residual add (parallel schedule) or accumulated into xs with the MRF mode (sequential schedule).
+      auto chain = [&](int j, const View (&t)[3], View dst, bool accumulate, int accmode) {
         auto& cv = st.rb[j];
+        const int last_epi = accumulate ? EPI_ACCUM : EPI_RESADD;
+        View xin = u;
         if (arch_[A_RESBLOCK] == 1) {
-          // ResBlock1 (modules.py:301-314): x = x + c2(lrelu(c1(lrelu(x)))) three times
-          View xin = u;
+          // ResBlock1 (modules.py:301-314): x = x + c2(lrelu(c1(lrelu(x)))) per dilation
           const int np = (int)cv.size() / 2;
           for (int d = 0; d < np; ++d) {
-            conv(cv[2 * d], xin, tb, lens, mult, Lmax, EPI_STORE, 0.1f);
+            conv(cv[2 * d], xin, t[0], lens, mult, Lmax, EPI_STORE, 0.1f);
             if (d < np - 1) {
-              const View nxt = (d & 1) ? tc : ta;
-              conv(cv[2 * d + 1], tb, nxt, lens, mult, Lmax, EPI_RESADD, 0.1f, ACT_NONE, xin);
+              const View nxt = (d & 1) ? t[2] : t[1];
+              conv(cv[2 * d + 1], t[0], nxt, lens, mult, Lmax, EPI_RESADD, 0.1f, ACT_NONE, xin);
               xin = nxt;
             } else {
-              conv(cv[2 * d + 1], tb, xs, lens, mult, Lmax, EPI_ACCUM, 0.1f, ACT_NONE, xin, none, accmode, inv_nk);
+              conv(cv[2 * d + 1], t[0], dst, lens, mult, Lmax, last_epi, 0.1f, ACT_NONE, xin, none, accmode, inv_nk);
             }
             fl += 2.0 * fsum * mult * (cv[2 * d].macs_per_col + cv[2 * d + 1].macs_per_col);
           }
         } else {
-          // ResBlock2 (modules.py:355-364): x = x + c(lrelu(x)) for each dilation
-          View xin = u;
+          // ResBlock2 (modules.py:355-364): x = x + c(lrelu(x)) per dilation
           const int nc = (int)cv.size();
           for (int d = 0; d < nc; ++d) {
             if (d < nc - 1) {
-              const View nxt = (d & 1) ? tc : ta;
+              const View nxt = (d & 1) ? t[2] : t[1];
               conv(cv[d], xin, nxt, lens, mult, Lmax, EPI_RESADD, 0.1f, ACT_NONE, xin);
               xin = nxt;
             } else {
-              conv(cv[d], xin, xs, lens, mult, Lmax, EPI_ACCUM, 0.1f, ACT_NONE, xin, none, accmode, inv_nk);
+              conv(cv[d], xin, dst, lens, mult, Lmax, last_epi, 0.1f, ACT_NONE, xin, none, accmode, inv_nk);
             }
             fl += 2.0 * fsum * mult * cv[d].macs_per_col;
           }
+        }
+      };
+      // Small launches (one utterance, early stages) leave most CUs idle: run the resblocks of the MRF as
+      // parallel graph branches on side streams, each into its own buffer, and combine them in one pass.
+      const size_t need = (size_t)B * st.ch * Ls;
+      const long blocks64 = (long)((Lmax + 63) / 64) * ((st.ch + 63) / 64) * B;
+      const bool par = par_mrf_ && !prof_on_ && nk >= 2 && nk <= 3 && blocks64 < 700 && need <= side_floats_;
+      if (par) {
+        auto SV = [&](int k) { return View{side_[k], (long)st.ch * Ls, (int)Ls}; };
+        PE_HIP(hipEventRecord(ev_fork_, stream_));
+        for (int j = 1; j < nk; ++j) {
+          PE_HIP(hipStreamWaitEvent(side_stream_[j - 1], ev_fork_, 0));
+          ls_ = side_stream_[j - 1];
+          const View t[3] = {SV(4 * (j - 1)), SV(4 * (j - 1) + 1), SV(4 * (j - 1) + 2)};
+          chain(j, t, SV(4 * (j - 1) + 3), false, 0);
+          PE_HIP(hipEventRecord(ev_join_[j - 1], side_stream_[j - 1]));
+        }
+        ls_ = stream_;
+        {
+          const View t[3] = {tb, ta, tc};
+          chain(0, t, SV(8), false, 0);
+        }
+        for (int j = 1; j < nk; ++j) PE_HIP(hipStreamWaitEvent(stream_, ev_join_[j - 1], 0));
+        PE_LAUNCH(mrf_sum_kernel, dim3((Lmax + 255) / 256, st.ch, B), dim3(256), 0, stream_, side_[8], side_[3],
+                  nk == 3 ? side_[7] : (const float*)nullptr, xs.p, xs.bs, xs.cs, lens, mult, inv_nk);
+      } else {
+        for (int j = 0; j < nk; ++j) {
+          const int accmode = nk == 1 ? 3 : (j == 0 ? 0 : (j == nk - 1 ? 2 : 1));
+          const View t[3] = {tb, ta, tc};
+          chain(j, t, xs, true, accmode);
         }
       }
       cur = xs;      // same buffer index cur_buf, new shape

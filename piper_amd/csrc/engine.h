@@ -199,6 +199,13 @@ class Engine {
   int cond_off_dp_ = 0, cond_off_dec_ = 0;
   float *zp_ = nullptr, *fh_ = nullptr, *facts_ = nullptr, *fskip_ = nullptr, *noise_z_ = nullptr;
   float* hb_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+  // parallel MRF branches (small launches only): side streams, fork/join events, per-branch buffers
+  hipStream_t side_stream_[2] = {nullptr, nullptr};
+  hipStream_t ls_ = nullptr;       // stream conv()/layer launches go to (stream_ or a side stream)
+  hipEvent_t ev_fork_ = nullptr, ev_join_[2] = {nullptr, nullptr};
+  float* side_[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  size_t side_floats_ = 0;
+  bool par_mrf_ = true;
   float* zwin_ = nullptr;          // streaming: current window of z, [C][Fs]
   int* d_win_ = nullptr;           // streaming: {start, length} of the window in frames
   int halo_frames_ = 0, s_frames_ = 0, s_pos_ = 0, s_wg_ = 0;

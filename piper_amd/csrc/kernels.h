@@ -967,6 +967,18 @@ __global__ void window_copy_kernel(const float* z, int zs, const int* win, float
   if (c < C && t < win[1]) out[(long)c * ws + t] = z[(long)c * zs + win[0] + t];
 }
 
+// MRF combine for the parallel-branch schedule: out = ((r0 + r1) + r2) * scale  (models.py:356-363)
+__global__ void mrf_sum_kernel(const float* r0, const float* r1, const float* r2, float* out, long bs, int cs,
+                               const int* lens, int len_mul, float scale) {
+  const int b = blockIdx.z, c = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= lens[b] * len_mul) return;
+  const long i = (long)b * bs + (long)c * cs + t;
+  float v = r0[i] + r1[i];
+  if (r2) v += r2[i];
+  out[i] = v * scale;
+}
+
 __global__ void scale_kernel(float* x, long n, float s) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] *= s;

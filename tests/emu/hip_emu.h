@@ -153,6 +153,9 @@ inline double emu_now() {
   return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new emu_event{0}; return 0; }
+#define hipEventDisableTiming 2
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new emu_event{0}; return 0; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return 0; }
 inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = emu_now(); return 0; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
