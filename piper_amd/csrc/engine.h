@@ -205,7 +205,7 @@ class Engine {
   hipEvent_t ev_fork_ = nullptr, ev_join_[2] = {nullptr, nullptr};
   float* side_[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t side_floats_ = 0;
-  bool par_mrf_ = true;
+  bool par_mrf_ = false;            // measured no gain at B=1 (profiles/r01_notes.md); PIPER_HIP_PAR_MRF=1 enables
   float* zwin_ = nullptr;          // streaming: current window of z, [C][Fs]
   int* d_win_ = nullptr;           // streaming: {start, length} of the window in frames
   int halo_frames_ = 0, s_frames_ = 0, s_pos_ = 0, s_wg_ = 0;

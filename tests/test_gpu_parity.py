@@ -234,3 +234,32 @@ def test_streaming_chunks_equal_unchunked(preset, T, chunk):
     assert cat.shape == full.audio[0].shape
     assert np.max(np.abs(cat - full.audio[0])) < 2e-5
     assert all(c[0].size == chunk * eng.hop for c in chunks[:-1])
+
+
+@pytest.mark.parametrize("T", [1, 2, 700])
+def test_extreme_lengths_match_oracle(T):
+    """Shortest possible inputs and one far longer than any test sentence (attention score slab, many
+    column tiles)."""
+    from oracle import vits_oracle as O
+    cfg, w, eng = engine_for("tiny")
+    ids = W.synthetic_phoneme_ids(T, 6, id_max=cfg.n_vocab - 1) if T > 2 else np.array([1, 2][:T], np.int64)
+    nw, nz = noise_for(cfg, T, 17)
+    o = O.synthesize(w, cfg, ids, (0.667, 1.0, 0.8), nw, nz)
+    r = eng.synthesize(ids, (0.667, 1.0, 0.8), noise_w=nw, noise_z=nz)
+    assert np.array_equal(eng.durations(), o["durations"])
+    assert r.audio[0].shape == o["audio"].shape
+    assert np.max(np.abs(r.audio[0] - o["audio"])) < TIGHT_AUDIO_TOL
+    assert pcm_rms(r.pcm[0], o["pcm"]) <= RMS_TOL
+
+
+def test_all_zero_durations_give_one_frame():
+    """length_scale 0 -> every ceil(w) is 0 -> the reference clamps the frame count to 1 and the path matrix
+    is empty (models.py:702-716): z_p is then pure prior noise."""
+    from oracle import vits_oracle as O
+    cfg, w, eng = engine_for("tiny")
+    ids = W.synthetic_phoneme_ids(6, 0, id_max=cfg.n_vocab - 1)
+    nz = np.ones((cfg.inter, 8), np.float32)
+    o = O.synthesize(w, cfg, ids, (0.3, 0.0, 0.0), noise_z=nz)
+    r = eng.synthesize(ids, (0.3, 0.0, 0.0), noise_z=nz)
+    assert int(r.frames[0]) == 1 == o["frames"] and not eng.durations().any()
+    assert np.max(np.abs(r.audio[0] - o["audio"])) < TIGHT_AUDIO_TOL
