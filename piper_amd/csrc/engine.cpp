@@ -173,7 +173,7 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
   if (H_ <= 0 || C_ <= 0 || nh_ <= 0 || H_ % nh_ || (C_ & 1)) throw std::runtime_error("bad architecture header");
   dk_ = H_ / nh_;
   if (dk_ > 128 || (dk_ & 1)) throw std::runtime_error("head dimension must be even and <= 128");
-  if (H_ % 32) throw std::runtime_error("hidden_channels must be a multiple of 32");
+  if (H_ % 32 || H_ > 256) throw std::runtime_error("hidden_channels must be a multiple of 32 and <= 256");
   hop_ = 1;
   for (int i = 0; i < arch_[A_NUPS]; ++i) hop_ *= arch_[A_UPR0 + i];
 
@@ -341,6 +341,7 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
     const void* ks2[] = {(const void*)conv_splitk_kernel<2, true, 8>, (const void*)conv_splitk_kernel<2, true, 4>,
                          (const void*)conv_splitk_kernel<1, false, 8>, (const void*)conv_splitk_kernel<1, false, 4>};
     for (const void* k : ks2) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    PE_HIP(hipFuncSetAttribute((const void*)dds_layer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     PE_HIP(hipFuncSetAttribute((const void*)attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
   }
 #endif
@@ -615,14 +616,29 @@ void Engine::layer_norm(int mode, View in, View res, View out, const float* g, c
   kend(kh);
 }
 
-// DDSConv.forward (modules.py:117-129) in place on x; tmp1/tmp2 are [B][H][Ts] scratch.
-void Engine::dds(const DdsW& d, View x, View t1, View t2) {
+// DDSConv.forward (modules.py:117-129): one fused launch per layer (dds_layer_kernel), ping-ponging between
+// `out` and `tmp` so that the last layer lands in `out`; `in` must not alias the first layer's target.
+void Engine::dds(const DdsW& d, View in, View out, View tmp) {
   int dil = 1;
-  for (size_t i = 0; i < d.c1x1.size(); ++i) {
-    layer_norm(2, x, View{nullptr, 0, 0}, t1, d.g1[i], d.b1[i], d.dw_w[i], d.dw_b[i], ksz_, dil, H_, d_tlens_, Tg_);
-    conv(d.c1x1[i], t1, t2, d_tlens_, 1, Tg_, EPI_STORE);
-    layer_norm(1, t2, x, x, d.g2[i], d.b2[i], nullptr, nullptr, 0, 0, H_, d_tlens_, Tg_);
+  const int n = (int)d.c1x1.size();
+  View cur = in;
+  for (int i = 0; i < n; ++i) {
+    const View dst = ((n - 1 - i) & 1) ? tmp : out;
+    if (dst.p == cur.p) throw std::runtime_error("internal: DDSConv buffer aliasing");
+    DdsP p;
+    p.x = cur.p; p.x_bs = cur.bs; p.x_cs = cur.cs;
+    p.out = dst.p; p.o_bs = dst.bs; p.o_cs = dst.cs;
+    p.dw_w = d.dw_w[i]; p.dw_b = d.dw_b[i]; p.dw_k = ksz_; p.dw_dil = dil;
+    p.g1 = d.g1[i]; p.b1 = d.b1[i]; p.g2 = d.g2[i]; p.b2 = d.b2[i];
+    p.wp = d.c1x1[i].wp; p.bias = d.c1x1[i].bias;
+    p.nchunks = d.c1x1[i].nchunks;
+    p.lens = d_tlens_; p.H = H_;
+    const size_t smem = ((size_t)2 * p.nchunks * 32 * 32 + 8 * 32) * sizeof(float);
+    const int kh = kbegin(prof_level_ >= 2 ? krow("dds_layer_kernel") : 0, 2.0 * H_ * H_ * 0);
+    PE_LAUNCH(dds_layer_kernel, dim3((Tg_ + 31) / 32, B_), dim3(512), smem, stream_, p);
+    kend(kh);
     dil *= ksz_;
+    cur = dst;
   }
 }
 
@@ -814,8 +830,8 @@ void Engine::issue_stage_a() {
   // ================= stochastic duration predictor, reverse (models.py:63-71,108-117)
   prof_begin();
   fl = 0;
-  conv(dp_pre_, x, dh, d_tlens_, 1, T, EPI_STORE, 1.f, ACT_NONE, none, none, 0, 1.f, cb_dp, cond_bs_);
-  dds(dp_dds_, dh, dy, dy2);
+  conv(dp_pre_, x, dy, d_tlens_, 1, T, EPI_STORE, 1.f, ACT_NONE, none, none, 0, 1.f, cb_dp, cond_bs_);
+  dds(dp_dds_, dy, dh, dy2);
   conv(dp_proj_, dh, xg, d_tlens_, 1, T, EPI_STORE);
   fl += 2.0 * tsum * (2 + arch_[A_DDSLAYERS]) * dp_pre_.macs_per_col;
   // z = noise * noise_scale_w   [B][2][Ts]
@@ -836,8 +852,8 @@ void Engine::issue_stage_a() {
     const int c0 = (flips & 1) ? 1 : 0;     // physical channel holding logical x0
     const int c1 = 1 - c0;
     PE_LAUNCH(cf_pre_kernel, dim3((T + 63) / 64, H_, B), dim3(64), 0, stream_, z2_ + (long)c0 * Ts, (long)2 * Ts,
-              cf.pre_w, cf.pre_b, xg_, (long)H_ * Ts, Ts, dh_, (long)H_ * Ts, Ts, d_tlens_, H_);
-    dds(cf.dds, dh, dy, dy2);
+              cf.pre_w, cf.pre_b, xg_, (long)H_ * Ts, Ts, dy_, (long)H_ * Ts, Ts, d_tlens_, H_);
+    dds(cf.dds, dy, dh, dy2);
     conv(cf.proj, dh, hproj, d_tlens_, 1, T, EPI_STORE);
     PE_LAUNCH(spline_inverse_kernel, dim3((T + 63) / 64, B), dim3(64), 0, stream_, hproj_, (long)32 * Ts, Ts,
               z2_ + (long)c1 * Ts, (long)2 * Ts, d_tlens_, 1.0f / std::sqrt((float)H_));

@@ -109,7 +109,7 @@ class Engine {
             int bias2_bs = 0);
   void layer_norm(int mode, View in, View res, View out, const float* g, const float* b, const float* dw_w,
                   const float* dw_b, int dw_k, int dw_dil, int C, const int* lens, int Lmax);
-  void dds(const DdsW& d, View x, View tmp1, View tmp2);
+  void dds(const DdsW& d, View in, View out, View tmp);
   void issue_stage_a();
   void issue_stage_b();
   void issue_flow();

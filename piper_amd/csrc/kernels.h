@@ -707,6 +707,135 @@ __global__ __launch_bounds__(256) void ln_kernel(LnP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// One whole DDSConv layer (modules.py:119-128) per launch (out of place: neighbouring workgroups read each
+// other's halo columns of x, so the result goes to a second buffer):
+//     out = x + gelu(LN2(W1x1 . gelu(LN1(dwconv_dil(x) + b_dw)) + b_1x1))
+// A workgroup (8 waves) owns 32 time columns and all H <= 256 channels: the depthwise conv + LN1 + GELU run in
+// registers (thread = (column, channel lane), 16 channel lanes), the 1x1 conv is an [H x H] x [H x 32] GEMM on
+// the f32 MFMAs with the activations in LDS and the pre-packed weights read from L2, LN2 + GELU + residual
+// read the GEMM tile back from LDS. Replaces three launches (ln_kernel<2>, conv, ln_kernel<1>) and two
+// round trips of the [H x T] activations through memory.
+struct DdsP {
+  const float* x; long x_bs; int x_cs;
+  float* out; long o_bs; int o_cs;
+  const float* dw_w; const float* dw_b; int dw_k, dw_dil;
+  const float* g1; const float* b1; const float* g2; const float* b2;
+  const float* wp; const float* bias;      // packed 1x1 weights (conv_mfma layout, one tap), bias
+  int nchunks;                              // ceil(H / 32)
+  const int* lens;
+  int H;
+};
+static constexpr int DDS_NV = 16;           // channels per thread: H <= 16 * 16
+
+__global__ __launch_bounds__(512) void dds_layer_kernel(DdsP p) {
+  PE_DYN_SMEM(float, sm);                   // Y[Hp][32] | Z[Hp][32] | red[8][32]
+  const int b = blockIdx.y, L = p.lens[b];
+  const int t0 = blockIdx.x * 32;
+  if (t0 >= L) return;
+  const int H = p.H, Hp = p.nchunks * 32;
+  float* Y = sm;
+  float* Z = Y + Hp * 32;
+  float* red = Z + Hp * 32;
+  const int tid = threadIdx.x, col = tid & 31, rl = tid >> 5, wv = tid >> 6, lane = tid & 63;
+  const int t = t0 + col;
+  const bool ok = t < L;
+  const float* xb = p.x + (long)b * p.x_bs;
+  float* ob = p.out + (long)b * p.o_bs;
+  const int pad = (p.dw_k - 1) / 2 * p.dw_dil;
+
+  auto col_sum = [&](float v) -> float {     // sum over all channel lanes of this column
+    v += __shfl_xor(v, 32);
+    __syncthreads();
+    if (lane < 32) red[wv * 32 + col] = v;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) s += red[w * 32 + col];
+    return s;
+  };
+
+  // ---- phase 1: depthwise conv, LN1, GELU -> Y
+  float v[DDS_NV], xc[DDS_NV];
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < DDS_NV; ++k) {
+    const int c = rl + 16 * k;
+    float a = 0.f, center = 0.f;
+    if (ok && c < H) {
+      const float* xr = xb + (long)c * p.x_cs;
+      center = xr[t];
+      a = p.dw_b[c];
+      for (int kk = 0; kk < p.dw_k; ++kk) {
+        const int tt = t + kk * p.dw_dil - pad;
+        if (tt >= 0 && tt < L) a = fmaf(p.dw_w[c * p.dw_k + kk], tt == t ? center : xr[tt], a);
+      }
+    }
+    v[k] = a;
+    xc[k] = center;
+    s += a;
+  }
+  float mean = col_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < DDS_NV; ++k)
+    if (rl + 16 * k < H) { const float d = v[k] - mean; q = fmaf(d, d, q); }
+  float rstd = 1.f / sqrtf(col_sum(q) / (float)H + 1e-5f);
+#pragma unroll
+  for (int k = 0; k < DDS_NV; ++k) {
+    const int c = rl + 16 * k;
+    if (c < Hp) Y[c * 32 + col] = (c < H && ok) ? gelu_erf((v[k] - mean) * rstd * p.g1[c] + p.b1[c]) : 0.f;
+  }
+  __syncthreads();
+
+  // ---- phase 2: Z = W1x1 . Y + bias ; wave w owns row tiles w, w+8, ...
+  {
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const long wstride_mt = (long)p.nchunks * (KC / 2) * 64;
+    for (int mt = wv; mt < p.nchunks; mt += 8) {
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float* wt = p.wp + (long)mt * wstride_mt + lane;
+      for (int c = 0; c < p.nchunks; ++c) {
+        float a[KC / 2];
+#pragma unroll
+        for (int kk = 0; kk < KC / 2; ++kk) a[kk] = wt[((long)c * (KC / 2) + kk) * 64];
+#pragma unroll
+        for (int kk = 0; kk < KC / 2; ++kk)
+          acc = pe_mfma_32x32x2(a[kk], Y[(c * KC + 2 * kk + lhi) * 32 + l31], acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        Z[row * 32 + l31] = acc[r] + (row < H ? p.bias[row] : 0.f);
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 3: LN2, GELU, residual -> x
+  s = 0.f;
+#pragma unroll
+  for (int k = 0; k < DDS_NV; ++k) {
+    const int c = rl + 16 * k;
+    v[k] = (c < H) ? Z[c * 32 + col] : 0.f;
+    s += v[k];
+  }
+  mean = col_sum(s) / (float)H;
+  q = 0.f;
+#pragma unroll
+  for (int k = 0; k < DDS_NV; ++k)
+    if (rl + 16 * k < H) { const float d = v[k] - mean; q = fmaf(d, d, q); }
+  rstd = 1.f / sqrtf(col_sum(q) / (float)H + 1e-5f);
+  if (!ok) return;
+#pragma unroll
+  for (int k = 0; k < DDS_NV; ++k) {
+    const int c = rl + 16 * k;
+    if (c < H) ob[(long)c * p.o_cs + t] = xc[k] + gelu_erf((v[k] - mean) * rstd * p.g2[c] + p.b2[c]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // ConvFlow.pre (1 -> H channels, 1x1) fused with DDSConv's "x = x + g" (modules.py:504-505,118-119):
 //   h[c][t] = w[c] * z0[t] + b[c] + g[c][t]
 __global__ void cf_pre_kernel(const float* z0, long z_bs, const float* w, const float* bia,
