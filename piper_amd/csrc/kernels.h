@@ -514,9 +514,22 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
   const int nk2 = dk / 2;                             // MFMA k-steps over channels (dk even)
 
   // ---- 1. scores
-  for (int e = tid; e < dk * ATT_QB; e += 256) {
-    const int d = e >> 5, i = e & 31;
-    Qs[e] = (i0 + i < T) ? qb[(long)d * p.q_cs + i0 + i] * p.qscale : 0.f;
+  // all global reads go through buffer descriptors with index -1 for masked elements (hardware returns 0), so
+  // each staging step issues its loads back to back: one memory latency per step instead of one per element
+  const pe_rowsrc qd = pe_make_row(qb, dk * p.q_cs), kd = pe_make_row(kb, dk * p.q_cs), vd = pe_make_row(vb, dk * p.q_cs);
+  {
+    constexpr int NQ = ATT_MAXDK * ATT_QB / 256;     // 16 elements per thread at dk = 128
+    float qv[NQ];
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+      const int e = tid + 256 * u, d = e >> 5, i = e & 31;
+      qv[u] = pe_row_load(qd, (d < dk && i0 + i < T) ? d * p.q_cs + i0 + i : -1);
+    }
+#pragma unroll
+    for (int u = 0; u < NQ; ++u) {
+      const int e = tid + 256 * u;
+      if (e < dk * ATT_QB) Qs[e] = qv[u] * p.qscale;
+    }
   }
   __syncthreads();
   {
@@ -526,13 +539,13 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      for (int s0 = 0; s0 < nk2; s0 += 16) {           // 16 independent K-fragment loads in flight
-        float kf[16];
+      for (int s0 = 0; s0 < nk2; s0 += 32) {           // 32 independent K-fragment loads in flight
+        float kf[32];
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
-          kf[u] = (kok && s0 + u < nk2) ? kb[(long)(2 * (s0 + u) + lhi) * p.q_cs + j] : 0.f;
+        for (int u = 0; u < 32; ++u)
+          kf[u] = pe_row_load(kd, (kok && s0 + u < nk2) ? (2 * (s0 + u) + lhi) * p.q_cs + j : -1);
 #pragma unroll
-        for (int u = 0; u < 16; ++u)
+        for (int u = 0; u < 32; ++u)
           if (s0 + u < nk2) acc = pe_mfma_32x32x2(Qs[(2 * (s0 + u) + lhi) * ATT_QB + l31], kf[u], acc);
       }
 #pragma unroll
@@ -583,14 +596,21 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
         // thread -> (key jj = tid&63, channel group tid>>6): 8 independent row loads per pass
         const int jj = tid & 63;
         const bool jok = j0 + jj < T;
-        for (int d0 = (tid >> 6) * 8; d0 < dk; d0 += 32) {
-          float vv[8];
+        float vv[ATT_MAXDK / 32][8];                   // 32 loads in flight per thread
 #pragma unroll
-          for (int u = 0; u < 8; ++u) vv[u] = (jok && d0 + u < dk) ? vb[(long)(d0 + u) * p.q_cs + j0 + jj] : 0.f;
+        for (int g = 0; g < ATT_MAXDK / 32; ++g)
 #pragma unroll
-          for (int u = 0; u < 8; ++u)
-            if (d0 + u < dk) Vt[jj * VS + d0 + u] = vv[u];
-        }
+          for (int u = 0; u < 8; ++u) {
+            const int d = (tid >> 6) * 8 + 32 * g + u;
+            vv[g][u] = pe_row_load(vd, (jok && d < dk) ? d * p.q_cs + j0 + jj : -1);
+          }
+#pragma unroll
+        for (int g = 0; g < ATT_MAXDK / 32; ++g)
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int d = (tid >> 6) * 8 + 32 * g + u;
+            if (d < dk) Vt[jj * VS + d] = vv[g][u];
+          }
       }
       __syncthreads();
       if (dt < ndt) {
@@ -754,40 +774,65 @@ __global__ __launch_bounds__(512) void dds_layer_kernel(DdsP p) {
     return s;
   };
 
-  // ---- phase 1: depthwise conv, LN1, GELU -> Y
+  // ---- phase 1: depthwise conv, LN1, GELU -> Y.  Every operand is fetched first through buffer descriptors
+  // (invalid taps / padded channels get index -1 -> hardware returns 0), so the ~8 loads per channel are all
+  // in flight together instead of one dependent load per tap.
+  constexpr int MAXK = 3;
+  const pe_rowsrc xd = pe_make_row(xb, H * p.x_cs);
+  const pe_rowsrc wd = pe_make_row(p.dw_w, H * p.dw_k), bd = pe_make_row(p.dw_b, H);
+  const pe_rowsrc g1d = pe_make_row(p.g1, H), b1d = pe_make_row(p.b1, H);
   float v[DDS_NV], xc[DDS_NV];
+  {
+    float xv[DDS_NV][MAXK], ww[DDS_NV][MAXK], wb[DDS_NV];
+#pragma unroll
+    for (int k = 0; k < DDS_NV; ++k) {
+      const int c = rl + 16 * k;
+      const bool cv = ok && c < H;
+#pragma unroll
+      for (int kk = 0; kk < MAXK; ++kk) {
+        const int tt = t + kk * p.dw_dil - pad;
+        const bool tv = cv && kk < p.dw_k && tt >= 0 && tt < L;
+        xv[k][kk] = pe_row_load(xd, tv ? c * p.x_cs + tt : -1);
+        ww[k][kk] = pe_row_load(wd, tv ? c * p.dw_k + kk : -1);
+      }
+      wb[k] = pe_row_load(bd, cv ? c : -1);
+    }
+#pragma unroll
+    for (int k = 0; k < DDS_NV; ++k) {
+      float a = wb[k];
+#pragma unroll
+      for (int kk = 0; kk < MAXK; ++kk) a = fmaf(ww[k][kk], xv[k][kk], a);
+      v[k] = a;
+      xc[k] = xv[k][(MAXK - 1) / 2];     // centre tap = x[c][t] (odd kernel, "same" padding)
+    }
+  }
   float s = 0.f;
 #pragma unroll
-  for (int k = 0; k < DDS_NV; ++k) {
-    const int c = rl + 16 * k;
-    float a = 0.f, center = 0.f;
-    if (ok && c < H) {
-      const float* xr = xb + (long)c * p.x_cs;
-      center = xr[t];
-      a = p.dw_b[c];
-      for (int kk = 0; kk < p.dw_k; ++kk) {
-        const int tt = t + kk * p.dw_dil - pad;
-        if (tt >= 0 && tt < L) a = fmaf(p.dw_w[c * p.dw_k + kk], tt == t ? center : xr[tt], a);
-      }
-    }
-    v[k] = a;
-    xc[k] = center;
-    s += a;
-  }
+  for (int k = 0; k < DDS_NV; ++k) s += v[k];
   float mean = col_sum(s) / (float)H;
   float q = 0.f;
 #pragma unroll
   for (int k = 0; k < DDS_NV; ++k)
     if (rl + 16 * k < H) { const float d = v[k] - mean; q = fmaf(d, d, q); }
   float rstd = 1.f / sqrtf(col_sum(q) / (float)H + 1e-5f);
+  {
+    float gg[DDS_NV], bb[DDS_NV];
 #pragma unroll
-  for (int k = 0; k < DDS_NV; ++k) {
-    const int c = rl + 16 * k;
-    if (c < Hp) Y[c * 32 + col] = (c < H && ok) ? gelu_erf((v[k] - mean) * rstd * p.g1[c] + p.b1[c]) : 0.f;
+    for (int k = 0; k < DDS_NV; ++k) {
+      const int c = rl + 16 * k;
+      gg[k] = pe_row_load(g1d, c < H ? c : -1);
+      bb[k] = pe_row_load(b1d, c < H ? c : -1);
+    }
+#pragma unroll
+    for (int k = 0; k < DDS_NV; ++k) {
+      const int c = rl + 16 * k;
+      if (c < Hp) Y[c * 32 + col] = (c < H && ok) ? gelu_erf((v[k] - mean) * rstd * gg[k] + bb[k]) : 0.f;
+    }
   }
   __syncthreads();
 
-  // ---- phase 2: Z = W1x1 . Y + bias ; wave w owns row tiles w, w+8, ...
+  // ---- phase 2: Z = W1x1 . Y + bias ; wave w owns row tiles w, w+8, ...; the next chunk's 16 weight
+  // fragments are prefetched while the current chunk's MFMAs issue
   {
     const int l31 = lane & 31, lhi = lane >> 5;
     const long wstride_mt = (long)p.nchunks * (KC / 2) * 64;
@@ -796,13 +841,23 @@ __global__ __launch_bounds__(512) void dds_layer_kernel(DdsP p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
       const float* wt = p.wp + (long)mt * wstride_mt + lane;
-      for (int c = 0; c < p.nchunks; ++c) {
-        float a[KC / 2];
+      float aA[KC / 2], aB[KC / 2];
+      auto lda = [&](int c, float (&a)[KC / 2]) {
 #pragma unroll
         for (int kk = 0; kk < KC / 2; ++kk) a[kk] = wt[((long)c * (KC / 2) + kk) * 64];
+      };
+      auto mm = [&](int c, const float (&a)[KC / 2]) {
 #pragma unroll
-        for (int kk = 0; kk < KC / 2; ++kk)
-          acc = pe_mfma_32x32x2(a[kk], Y[(c * KC + 2 * kk + lhi) * 32 + l31], acc);
+        for (int kk = 0; kk < KC / 2; ++kk) acc = pe_mfma_32x32x2(a[kk], Y[(c * KC + 2 * kk + lhi) * 32 + l31], acc);
+      };
+      lda(0, aA);
+      for (int c = 0; c < p.nchunks; c += 2) {
+        if (c + 1 < p.nchunks) lda(c + 1, aB);
+        mm(c, aA);
+        if (c + 1 < p.nchunks) {
+          if (c + 2 < p.nchunks) lda(c + 2, aA);
+          mm(c + 1, aB);
+        }
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -813,7 +868,15 @@ __global__ __launch_bounds__(512) void dds_layer_kernel(DdsP p) {
   }
   __syncthreads();
 
-  // ---- phase 3: LN2, GELU, residual -> x
+  // ---- phase 3: LN2, GELU, residual -> out
+  const pe_rowsrc g2d = pe_make_row(p.g2, H), b2d = pe_make_row(p.b2, H);
+  float g2v[DDS_NV], b2v[DDS_NV];
+#pragma unroll
+  for (int k = 0; k < DDS_NV; ++k) {
+    const int c = rl + 16 * k;
+    g2v[k] = pe_row_load(g2d, c < H ? c : -1);
+    b2v[k] = pe_row_load(b2d, c < H ? c : -1);
+  }
   s = 0.f;
 #pragma unroll
   for (int k = 0; k < DDS_NV; ++k) {
@@ -831,7 +894,7 @@ __global__ __launch_bounds__(512) void dds_layer_kernel(DdsP p) {
 #pragma unroll
   for (int k = 0; k < DDS_NV; ++k) {
     const int c = rl + 16 * k;
-    if (c < H) ob[(long)c * p.o_cs + t] = xc[k] + gelu_erf((v[k] - mean) * rstd * p.g2[c] + p.b2[c]);
+    if (c < H) ob[(long)c * p.o_cs + t] = xc[k] + gelu_erf((v[k] - mean) * rstd * g2v[k] + b2v[k]);
   }
 }
 
