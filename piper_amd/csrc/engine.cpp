@@ -283,6 +283,7 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
         }
         st.rb.push_back(cv);
       }
+      build_mrf(st);
       ups_.push_back(st);
     }
     const HostTensor& pw = ws.get("dec.conv_post.weight");
@@ -344,6 +345,11 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
     for (const void* k : ks2) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     PE_HIP(hipFuncSetAttribute((const void*)dds_layer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     PE_HIP(hipFuncSetAttribute((const void*)attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    const void* ks3[] = {(const void*)mrf_fused_kernel<32, 4, 4, 256>, (const void*)mrf_fused_kernel<32, 4, 4, 320>,
+                         (const void*)mrf_fused_kernel<32, 4, 4, 384>, (const void*)mrf_fused_kernel<32, 4, 8, 256>,
+                         (const void*)mrf_fused_kernel<32, 4, 8, 320>, (const void*)mrf_fused_kernel<32, 4, 8, 384>,
+                         (const void*)mrf_fused_kernel<64, 4, 8, 256>};
+    for (const void* k : ks3) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
   }
 #endif
   static const char* rows[] = {"text_encoder", "duration_predictor", "regulate+flow", "hifigan", "post+pcm"};
@@ -357,6 +363,7 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
   if (const char* t = getenv("PIPER_HIP_SMALL")) small_tiles_ = atoi(t) != 0;
   if (const char* t = getenv("PIPER_HIP_PAR_MRF")) par_mrf_ = atoi(t) != 0;
   if (const char* t = getenv("PIPER_HIP_ABL")) abl_ = atoi(t);              // timing ablations, results invalid
+  if (const char* t = getenv("PIPER_HIP_FUSE_MRF")) fuse_mrf_ = atoi(t) != 0;   // A/B knob: 0 = conv-by-conv MRF stages
 }
 
 Engine::~Engine() {
@@ -595,6 +602,98 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     }
   }
 #undef PE_CONV_LAUNCH
+  kend(kh);
+}
+
+// Flattens one MRF stage (all resblocks of an upsampling stage) into the step table of mrf_fused_kernel.
+// ResBlock2 (modules.py:355-364): x <- x + c_d(lrelu(x));   ResBlock1 (:301-314): x <- x + c2_d(lrelu(c1_d(lrelu(x)))).
+// Buffer 0 holds the stage input for every resblock; 1 and 2 carry the chain. Stages whose window does not
+// fit the 160 KiB of LDS (or with > 64 channels) keep the conv-by-conv schedule.
+static constexpr int MRF_NT = 4;            // 128 output columns per workgroup
+void Engine::build_mrf(UpStage& st) {
+  const int ch = st.ch;
+  if (ch > 64 || st.rb.empty()) return;
+  const int CP = ch <= 32 ? 32 : 64;
+  const bool rb1 = arch_[A_RESBLOCK] == 1;
+  std::vector<MrfStep> steps;
+  int hx = 0, nbuf = 2;
+  double macs = 0;
+  for (auto& cv : st.rb) {
+    const int n = (int)cv.size();
+    if (n == 0 || (rb1 && (n & 1))) return;
+    std::vector<int> h(n);
+    for (int i = 0; i < n; ++i) {
+      const PackedConv& c = cv[i];
+      if (!(c.ntaps & 1) || c.Cin != ch || c.rows != ch || c.padl != c.dil * (c.ntaps - 1) / 2 ||
+          c.nchunks != CP / KC || c.mtiles < CP / 32 || c.gate)
+        return;
+      h[i] = c.padl;
+      macs += c.macs_per_col;
+    }
+    int e = 0;
+    for (int i = 0; i < n; ++i) e += h[i];
+    hx = std::max(hx, e);
+    int xcur = 0;                            // buffer holding the running x of this chain
+    for (int i = 0; i < n; ++i) {
+      e -= h[i];
+      MrfStep s;
+      s.wp = cv[i].wp; s.bias = cv[i].bias; s.ntaps = cv[i].ntaps; s.dil = cv[i].dil; s.e = e;
+      const bool last = i == n - 1;
+      if (rb1) {
+        if (!(i & 1)) { s.src = xcur; s.res = -1; s.dst = 1; }
+        else { s.src = 1; s.res = xcur; s.dst = last ? -1 : 2; xcur = 2; nbuf = std::max(nbuf, last ? 2 : 3); }
+      } else {
+        s.src = xcur; s.res = xcur; s.dst = last ? -1 : (xcur == 1 ? 2 : 1);
+        if (!last) { xcur = s.dst; nbuf = std::max(nbuf, xcur + 1); }
+      }
+      steps.push_back(s);
+    }
+  }
+  const int N = MRF_NT * 32;
+  const int ws = std::max(256, rup(N + 2 * hx + 32, 64));
+  if (ws < 256 || ws > 384 || (size_t)nbuf * CP * ws * sizeof(float) > 160u * 1024u) return;
+  if (CP == 64 && ws != 256) return;       // instantiated strides: 32 channels 256/320/384, 64 channels 256
+  void* d = nullptr;
+  PE_HIP(hipMalloc(&d, steps.size() * sizeof(MrfStep)));
+  PE_HIP(hipMemcpy(d, steps.data(), steps.size() * sizeof(MrfStep), hipMemcpyHostToDevice));
+  owned_.push_back(d);
+  st.mrf_steps = d;
+  st.mrf_nsteps = (int)steps.size();
+  st.mrf_hx = hx; st.mrf_ws = ws; st.mrf_cp = CP; st.mrf_nbuf = nbuf;
+  st.mrf_macs_per_col = macs;
+}
+
+void Engine::mrf(const UpStage& st, View x, View out, const int* lens, int len_mul, int Lmax) {
+  MrfP p;
+  p.x = x.p; p.x_bs = x.bs; p.x_cs = x.cs;
+  p.out = out.p; p.o_bs = out.bs; p.o_cs = out.cs;
+  p.lens = lens; p.len_mul = len_mul;
+  p.steps = static_cast<const MrfStep*>(st.mrf_steps); p.nsteps = st.mrf_nsteps;
+  p.C = st.ch; p.hx = st.mrf_hx;
+  p.slope = 0.1f;                            // modules.py LRELU_SLOPE
+  p.alpha = 1.0f / (float)st.rb.size();
+  double kflops = 0;
+  if (prof_level_ >= 2) {
+    double cols = 0;
+    for (int b = 0; b < B_; ++b) cols += (double)frames_h_[b] * len_mul;
+    kflops = 2.0 * st.mrf_macs_per_col * cols;
+  }
+  const size_t smem = (size_t)st.mrf_nbuf * st.mrf_cp * st.mrf_ws * sizeof(float);
+  dim3 grid((Lmax + MRF_NT * 32 - 1) / (MRF_NT * 32), 1, B_);
+  const int kh = kbegin(prof_level_ >= 2 ? krow("mrf_fused_kernel") : 0, kflops);
+  // 32-channel stages whose window allows two workgroups per CU run 4 waves each, otherwise 8 (either way
+  // two waves per SIMD)
+  const bool two = 2 * smem <= 160u * 1024u;
+#define PE_MRF32(WS_)                                                                                     \
+  do {                                                                                                    \
+    if (two) PE_LAUNCH((mrf_fused_kernel<32, MRF_NT, 4, WS_>), grid, dim3(256), smem, ls_, p);          \
+    else PE_LAUNCH((mrf_fused_kernel<32, MRF_NT, 8, WS_>), grid, dim3(512), smem, ls_, p);              \
+  } while (0)
+  if (st.mrf_cp == 64) PE_LAUNCH((mrf_fused_kernel<64, MRF_NT, 8, 256>), grid, dim3(512), smem, ls_, p);
+  else if (st.mrf_ws == 256) PE_MRF32(256);
+  else if (st.mrf_ws == 320) PE_MRF32(320);
+  else PE_MRF32(384);
+#undef PE_MRF32
   kend(kh);
 }
 
@@ -1013,7 +1112,11 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
       const size_t need = (size_t)B * st.ch * Ls;
       const long blocks64 = (long)((Lmax + 63) / 64) * ((st.ch + 63) / 64) * B;
       const bool par = par_mrf_ && !prof_on_ && nk >= 2 && nk <= 3 && blocks64 < 700 && need <= side_floats_;
-      if (par) {
+      if (fuse_mrf_ && st.mrf_steps) {
+        mrf(st, u, xs, lens, mult, Lmax);
+        for (auto& cv : st.rb)
+          for (auto& c : cv) fl += 2.0 * fsum * mult * c.macs_per_col;
+      } else if (par) {
         auto SV = [&](int k) { return View{side_[k], (long)st.ch * Ls, (int)Ls}; };
         PE_HIP(hipEventRecord(ev_fork_, stream_));
         for (int j = 1; j < nk; ++j) {

@@ -157,7 +157,14 @@ class Engine {
     PackedConv up;
     int rate, ch;
     std::vector<std::vector<PackedConv>> rb;   // [resblock][conv] (ResBlock1: c1_0,c2_0,c1_1,...)
+    // fused MRF stage (mrf_fused_kernel): device step table, or null when the stage runs conv by conv
+    void* mrf_steps = nullptr;
+    int mrf_nsteps = 0, mrf_hx = 0, mrf_ws = 0, mrf_cp = 0, mrf_nbuf = 0;
+    double mrf_macs_per_col = 0;
   };
+  void build_mrf(UpStage& st);
+  void mrf(const UpStage& st, View x, View out, const int* lens, int len_mul, int Lmax);
+  bool fuse_mrf_ = true;
   std::vector<UpStage> ups_;
   float* post_w_ = nullptr;
   int post_cin_ = 0;

@@ -1171,6 +1171,228 @@ __global__ void mrf_sum_kernel(const float* r0, const float* r1, const float* r2
   out[i] = v * scale;
 }
 
+// ------------------------------------------------------------------------------------------------
+// One whole MRF stage of the HiFiGAN generator in one launch (models.py:356-363: xs = sum_j resblock_j(x) / n;
+// modules.py:301-314 ResBlock1, :355-364 ResBlock2) for the stages with <= 64 channels, which are at the HBM
+// ridge when run conv by conv (x, residual and accumulator round trips per conv). A workgroup owns N = 32*NT
+// output columns of one utterance: the input window x[n0-hx, n0+N+hx) is staged once in LDS (hx = the widest
+// resblock's receptive half-width) and every resblock chain runs out of LDS on shrinking column windows
+// (halo recompute), intermediates ping-pong between LDS buffers, the residual is read from LDS in the
+// epilogue, and the MRF sum lives in the accumulator registers of the wave that owns the output tile.
+// HBM traffic per stage: one read of x (+halo) and one write, instead of ~3 accesses per conv.
+// The host flattens the stage into a list of conv steps (engine.cpp: build_mrf); the kernel is agnostic of
+// the resblock type. Every step is the same GEMM as conv_mfma_kernel (weights in the same packed fragment
+// order, f32 MFMA, k-ordered), so results match the unfused path up to the order of the final MRF adds.
+struct MrfStep {
+  const float* wp;      // packed conv weights (pack_matrix order)
+  const float* bias;
+  int ntaps, dil;
+  int e;                // columns of halo still needed after this conv (0 for the last conv of a resblock)
+  int src, dst, res;    // LDS buffer ids (0 = x, 1, 2); dst < 0: add into the output accumulators; res < 0: none
+};
+struct MrfP {
+  const float* x; long x_bs; int x_cs;
+  float* out; long o_bs; int o_cs;
+  const int* lens; int len_mul;
+  const MrfStep* steps; int nsteps;     // device table
+  int C;                                // real channels (<= CP)
+  int hx;                               // window halo (the kernel's WS template argument >= N + 2*hx + 32)
+  float slope, alpha;
+};
+
+template <int CP, int NT, int NW, int WS>
+__global__ __launch_bounds__(64 * NW, 2) void mrf_fused_kernel(MrfP p) {
+  constexpr int N = NT * 32, MTL = CP / 32, NCH = CP / KC;
+  constexpr int FU = (NT * MTL + NW - 1) / NW;     // output tiles owned by one wave
+  constexpr int RG = 4, NCC = WS / 64;             // staging: rows per register batch, 64-column groups per row
+  constexpr int KH = KC / 2;                       // MFMAs per (chunk, tap) step
+  static_assert(WS % 64 == 0, "row stride");
+  PE_DYN_SMEM(float, sm);                          // nbuf x [CP][WS]
+  const int b = blockIdx.z;
+  const int L = p.lens[b] * p.len_mul;
+  const int n0 = blockIdx.x * N;
+  if (n0 >= L) return;
+  const int tid = threadIdx.x, lane = tid & 63, wv = PE_UNIFORM(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int hx = p.hx;
+  constexpr int bufsz = CP * WS;
+  const float slope = p.slope;
+  const int nph = p.nsteps;
+  // table rows are wave-uniform; say so, or every descriptor built from them is loaded in a waterfall loop
+  auto get_step = [&](int ph) {
+    MrfStep s = p.steps[ph];
+    s.wp = pe_uniform_ptr(s.wp); s.bias = pe_uniform_ptr(s.bias);
+    s.ntaps = PE_UNIFORM(s.ntaps); s.dil = PE_UNIFORM(s.dil); s.e = PE_UNIFORM(s.e);
+    s.src = PE_UNIFORM(s.src); s.dst = PE_UNIFORM(s.dst); s.res = PE_UNIFORM(s.res);
+    return s;
+  };
+
+  // weights and bias are read through buffer descriptors: a uniform base + lane offset + immediate, vmcnt
+  // only (a flat load would also hold up every LDS wait), zero for rows beyond C
+  float aA[KH], aB[KH], bA[KH], bB[KH];
+  auto load_a = [&](const pe_rowsrc& w, int step, float (&a)[KH]) {
+    const int o = PE_UNIFORM(step * KH * 64);
+#pragma unroll
+    for (int kk = 0; kk < KH; ++kk) a[kk] = pe_row_load(w, o + kk * 64 + lane);
+  };
+  // unit u of a phase -> (m tile, column tile); waves take units round-robin, rotated per phase so the idle
+  // slots of the uneven phases move around the SIMDs
+  auto first_unit = [&](int ph, bool fin) { return fin ? wv : (wv + ph) % NW; };
+  auto unit_w = [&](const MrfStep& st, int u) {
+    const int per_mt = NCH * st.ntaps * KH * 64;
+    return pe_make_row(st.wp + (long)(u % MTL) * per_mt, per_mt);
+  };
+  auto phase_units = [&](const MrfStep& st) { return (st.dst < 0 ? NT : (N + 2 * st.e + 31) / 32) * MTL; };
+
+  // the first weight fragments travel while the window is staged
+  bool have = false;
+  {
+    const MrfStep s0 = get_step(0);
+    const int u0 = first_unit(0, s0.dst < 0);
+    if (u0 < phase_units(s0)) { load_a(unit_w(s0, u0), 0, aA); have = true; }
+  }
+  // ---- stage x[n0-hx, n0-hx+WS) of every channel: raw values (the residual needs them), zero outside [0, L)
+  {
+    const float* xb = p.x + (long)b * p.x_bs;
+    const int g0 = n0 - hx + lane;
+    for (int r0 = wv * RG; r0 < CP; r0 += NW * RG) {
+      float v[RG][NCC];
+#pragma unroll
+      for (int i = 0; i < RG; ++i) {
+        const int ci = r0 + i;
+        const pe_rowsrc row = pe_make_row(xb + (long)ci * p.x_cs, ci < p.C ? L : 0);
+#pragma unroll
+        for (int cc = 0; cc < NCC; ++cc) v[i][cc] = pe_row_load(row, g0 + 64 * cc);
+      }
+#pragma unroll
+      for (int i = 0; i < RG; ++i)
+#pragma unroll
+        for (int cc = 0; cc < NCC; ++cc) sm[(r0 + i) * WS + lane + 64 * cc] = v[i][cc];
+    }
+  }
+
+  f32x16 tot[FU];
+#pragma unroll
+  for (int i = 0; i < FU; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) tot[i][r] = 0.f;
+
+  for (int ph = 0; ph < nph; ++ph) {
+    const MrfStep st = get_step(ph);
+    const bool fin = st.dst < 0;
+    const int nunits = phase_units(st);
+    const int ntaps = st.ntaps, dil = st.dil;
+    const int hh = dil * (ntaps - 1) / 2;
+    const int nst = NCH * ntaps;
+    const float* src = sm + st.src * bufsz;
+    const float* rs = sm + (st.res < 0 ? 0 : st.res) * bufsz;
+    float* dp = sm + (fin ? 0 : st.dst) * bufsz;
+    const pe_rowsrc brow = pe_make_row(st.bias, st.bias ? p.C : 0);
+    // where this wave's weights come from after the unit at hand: its next unit of this phase, else its
+    // first unit of the next phase
+    const bool more = ph + 1 < nph;
+    MrfStep sn = st;
+    if (more) sn = get_step(ph + 1);
+    const int nfirst = first_unit(ph + 1, sn.dst < 0);
+    const bool nhas = more && nfirst < phase_units(sn);
+
+    __syncthreads();      // the previous phase's LDS writes (or the staging) are visible, its reads are done
+
+    // one 32x32 output tile: K loop over (chunk, tap) steps of 16 MFMAs; the A fragments (L2) and the B
+    // values (LDS) of the next step are in flight while this step's MFMAs issue
+    auto gemm = [&](int u, f32x16& acc, float (&bs)[16]) {
+      const int mt = u % MTL, j0 = hx - st.e + 32 * (u / MTL);
+      const pe_rowsrc wb = unit_w(st, u);
+      if (!have) load_a(wb, 0, aA);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) bs[r] = pe_row_load(brow, mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+      const float* xp0 = src + lhi * WS + j0 + l31 - hh;
+      auto load_b = [&](int c, int tap, float (&bv)[KH]) {
+        const float* xp = xp0 + c * KC * WS + tap * dil;
+#pragma unroll
+        for (int kk = 0; kk < KH; ++kk) bv[kk] = xp[2 * kk * WS];
+      };
+      auto mma = [&](const float (&a)[KH], const float (&bv)[KH]) {
+#pragma unroll
+        for (int kk = 0; kk < KH; ++kk) acc = pe_mfma_32x32x2(a[kk], pe_lrelu(bv[kk], slope), acc);
+      };
+      load_b(0, 0, bA);
+      int c = 0, tap = 0;            // (chunk, tap) of the step being prefetched
+      auto advance = [&]() { if (++tap == ntaps) { tap = 0; if (++c == NCH) c = 0; } };
+      // The prefetches are unconditional -- past the last step the descriptor returns zeros and the LDS
+      // position wraps to step 0 -- so that no branch sits between a load and its use: with one, the
+      // compiler's wait-count bookkeeping degrades to "drain everything" at every step.
+      for (int s = 0; s < nst; s += 2) {
+        advance(); load_a(wb, s + 1, aB); load_b(c, tap, bB);
+        PE_SCHED_FENCE();
+        mma(aA, bA);
+        PE_SCHED_FENCE();
+        if (s + 1 < nst) {
+          advance(); load_a(wb, s + 2, aA); load_b(c, tap, bA);
+          PE_SCHED_FENCE();
+          mma(aB, bB);
+          PE_SCHED_FENCE();
+        }
+      }
+      // next unit's first fragments: in flight during the epilogue (and the barrier)
+      have = false;
+      if (u + NW < nunits) { load_a(unit_w(st, u + NW), 0, aA); have = true; }
+      else if (nhas) { load_a(unit_w(sn, nfirst), 0, aA); have = true; }
+    };
+
+    if (fin) {
+#pragma unroll
+      for (int i = 0; i < FU; ++i) {
+        const int u = wv + NW * i;
+        if (u < nunits) {
+          f32x16 acc;
+          float bs[16];
+          gemm(u, acc, bs);
+          const float* rp = rs + ((u % MTL) * 32 + 4 * lhi) * WS + hx + 32 * (u / MTL) + l31;
+#pragma unroll
+          for (int r = 0; r < 16; ++r)     // conv_store_tile's ACCUM association
+            tot[i][r] = (acc[r] + bs[r]) + (tot[i][r] + rp[((r & 3) + 8 * (r >> 2)) * WS]);
+        }
+      }
+    } else {
+      for (int u = first_unit(ph, false); u < nunits; u += NW) {
+        f32x16 acc;
+        float bs[16];
+        gemm(u, acc, bs);
+        const int j = hx - st.e + 32 * (u / MTL) + l31;
+        const int g = n0 - hx + j;
+        const bool inside = g >= 0 && g < L;      // intermediates only exist on [0, L): zero padding
+        const int off0 = ((u % MTL) * 32 + 4 * lhi) * WS + j;
+        const bool has_res = st.res >= 0;
+        float rv[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[r] = has_res ? rs[off0 + ((r & 3) + 8 * (r >> 2)) * WS] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = (acc[r] + bs[r]) + rv[r];
+          dp[off0 + ((r & 3) + 8 * (r >> 2)) * WS] = inside ? v : 0.f;
+        }
+      }
+    }
+  }
+  // ---- MRF mean of the owned output tiles
+  float* ob = p.out + (long)b * p.o_bs;
+#pragma unroll
+  for (int i = 0; i < FU; ++i) {
+    const int u = wv + NW * i;
+    if (u >= NT * MTL) continue;
+    const int g = n0 + 32 * (u / MTL) + l31;
+    if (g >= L) continue;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = (u % MTL) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      if (row < p.C) ob[(long)row * p.o_cs + g] = tot[i][r] * p.alpha;
+    }
+  }
+}
+
 __global__ void scale_kernel(float* x, long n, float s) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] *= s;

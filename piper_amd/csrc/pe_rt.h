@@ -13,10 +13,13 @@
 #define PE_WAVE_SYNC() emu::wave_sync()
 #define PE_OPAQUE(x) ((void)0)
 #define PE_UNIFORM(x) (x)
+#define PE_SCHED_FENCE() ((void)0)
+template <class T> inline T* pe_uniform_ptr(T* p) { return p; }
 // bounds-checked row load: element idx of a row of n floats, 0 outside [0, n)
 struct pe_rowsrc { const float* p; int n; };
 inline pe_rowsrc pe_make_row(const float* row, int n) { return pe_rowsrc{row, n}; }
 inline float pe_row_load(const pe_rowsrc& r, int idx) { return (idx >= 0 && idx < r.n) ? r.p[idx] : 0.f; }
+inline float pe_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 #else
 #include <hip/hip_runtime.h>
 #define PE_LAUNCH(kernel, grid, block, smem, stream, ...) \
@@ -36,6 +39,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define PE_OPAQUE(x) asm volatile("" : "+v"(x))
 // makes a wave-uniform value provably uniform (SGPR) for the compiler
 #define PE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+// nothing is scheduled across this point: keeps a block of prefetch loads ahead of the MFMAs they overlap
+// with (the machine scheduler otherwise sinks each load next to its use to save registers)
+#define PE_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+template <class T> __device__ __forceinline__ T* pe_uniform_ptr(T* p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (T*)(((unsigned long long)hi << 32) | lo);
+}
 // Bounds-checked row load through a buffer descriptor: the hardware range check returns 0 for any
 // element outside [0, n) (negative indices wrap to huge unsigned offsets), so halo / tail / padded-channel
 // reads need no clamps, selects or branches. `row` and `n` must be wave-uniform.
@@ -45,6 +57,10 @@ __device__ __forceinline__ pe_rowsrc pe_make_row(const float* row, int n) {
 }
 __device__ __forceinline__ float pe_row_load(pe_rowsrc r, int idx) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, idx * 4, 0, 0));
+}
+// leaky-relu for 0 < slope < 1 in two VALU ops: median(v, v*slope, +inf) = max(v, v*slope)
+__device__ __forceinline__ float pe_lrelu(float v, float slope) {
+  return __builtin_amdgcn_fmed3f(v, v * slope, __builtin_inff());
 }
 #endif
 

@@ -93,3 +93,29 @@ def test_emulated_streaming_equals_unchunked(emu_lib):
     assert cat.shape == full.shape
     assert np.max(np.abs(cat - full)) < 1e-5
     assert all(c[1].dtype == np.int16 and np.max(np.abs(c[1].astype(np.int32))) <= 32767 for c in chunks)
+
+
+@pytest.mark.parametrize("preset", ["tiny", "tiny-high"])
+def test_emulated_fused_mrf_equals_conv_by_conv(emu_lib, monkeypatch, preset):
+    """mrf_fused_kernel (whole MRF stage out of LDS, halo recompute; ResBlock2 for 'tiny', ResBlock1 for
+    'tiny-high') must reproduce the conv-by-conv schedule: same GEMM order, same epilogue association."""
+    cfg = W.preset(preset)
+    w = W.synthetic_weights(cfg, 77)
+    ids = [W.synthetic_phoneme_ids(T, i, id_max=cfg.n_vocab - 1) for i, T in enumerate((9, 4))]
+    nw, nz = _noise(cfg, 2, 9, 11)
+    outs, used = [], []
+    for fuse in ("0", "1"):
+        monkeypatch.setenv("PIPER_HIP_FUSE_MRF", fuse)
+        eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
+        eng.profile_enable(2)
+        r = eng.synthesize_batch(ids, (0.667, 1.0, 0.8), noise_w=nw, noise_z=nz)
+        used.append(any(row["name"] == "mrf_fused_kernel" for row in eng.profile()))
+        outs.append(r.audio)
+        eng.close()
+    assert used == [False, True]
+    for a, b in zip(*outs):
+        assert a.shape == b.shape
+        # the small-launch split-K path of the unfused schedule sums K in a different order
+        assert np.max(np.abs(a - b)) < 2e-6
+    o = O.synthesize(w, cfg, ids[0], (0.667, 1.0, 0.8), nw[0], nz[0])
+    assert np.max(np.abs(outs[1][0] - o["audio"])) < 1e-4
