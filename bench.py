@@ -153,9 +153,22 @@ def main():
     kernels = {r["name"]: {"ms_per_step": r["ms"] / nprof, "launches_per_step": r["launches"] / nprof,
                            "avg_launch_us": r["ms"] / r["launches"] * 1e3,
                            "tflops": (r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0)} for r in krows}
-    convs = [r for r in krows if r["name"].startswith("conv_mfma_kernel")] or krows
+    # the MFMA-bound kernels are the tiled conv GEMM and the fused MRF stage (the HiFiGAN stage north_star
+    # prices); conv_splitk_kernel / attention / DDS launches are latency chains and are listed in `kernels`
+    convs = [r for r in krows if r["name"].startswith(("conv_mfma_kernel", "mrf_fused_kernel"))] or krows
     dom = max(convs, key=lambda r: r["ms"])
     achieved = kernels[dom["name"]]["tflops"]
+    traffic = pmc_traffic(args, B, T, dom["name"])
+    if traffic and dom["name"].startswith("mrf_fused_kernel<"):
+        # one read of the stage input + one write of the MRF mean, fp32
+        cp = int(dom["name"].split("<")[1].split(",")[0])
+        ch, mult, alg = cfg.up_initial, 1, 0
+        for rate in cfg.up_rates:
+            ch //= 2
+            mult *= rate
+            if (ch <= 32) == (cp == 32) and ch <= 64:
+                alg += 8 * ch * int(frames.sum()) * mult
+        traffic["algorithmic_bytes_per_launch"] = alg
 
     out = None
     if rank == 0:
@@ -180,7 +193,7 @@ def main():
                        "parallelism": f"utterance-parallel x{world}, RCCL weight broadcast"},
             "roofline": {"bound": "mfma", "kernel": dom["name"],
                          "achieved": achieved, "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": traffic,
                          "avg_launch_us": kernels[dom["name"]]["avg_launch_us"],
                          "launches_per_step": kernels[dom["name"]]["launches_per_step"],
                          "kernels": kernels, "stage_ms": stage_ms, "stage_tflops": stage_tf},
@@ -193,6 +206,27 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pmc_traffic(args, B, T, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command
+    (profiles/*_pmc_traffic.json, written by scripts/pmc_traffic.py from separate --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE runs; (2*FETCH_SIZE + WRITE_SIZE) KiB per the gfx950 note in MI355X_MICROARCH.md).
+    Counters cannot be read from inside the timed process, so this is null for a workload that has no
+    committed pass."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    key = f"{args.preset}/b{B}/t{T}"
+    for f in sorted(glob.glob(os.path.join(here, "profiles", "*_pmc_traffic.json")), reverse=True):
+        try:
+            d = json.load(open(f))
+            k = d.get(key, {}).get("kernels", {}).get(kernel.replace(" ", ""))
+            if k:
+                return {"hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "unit": "B",
+                        "algorithmic_bytes_per_launch": k.get("algorithmic_bytes_per_launch"), "source": os.path.basename(f)}
+        except (OSError, ValueError):
+            continue
+    return None
 
 
 def stream_latency(eng, cfg, args, rank):

@@ -33,8 +33,8 @@ float* Engine::dev_copy(const std::vector<float>& v) {
 float* Engine::dev_tensor(const WeightSet& ws, const std::string& name) { return dev_copy(ws.get(name).data); }
 
 // Packs a dense [rows][Cin][ntaps] matrix into the A-operand order of conv_mfma_kernel:
-//   [mtile][chunk][tap][kk = 0..15][lane = 0..63] with lane -> row = mtile*32 + (lane&31),
-//   ci = chunk*32 + 2*kk + (lane>>5). With gate=true the 32-row tiles alternate between the tanh
+//   [mtile][chunk][tap][q = 0..3][lane = 0..63][j = 0..3] with kk = 4q + j, lane -> row = mtile*32 + (lane&31),
+//   ci = chunk*32 + 2*kk + (lane>>5): the 16 fragments of a step are four 16-byte loads per lane. With gate=true the 32-row tiles alternate between the tanh
 //   half (rows [0,split)) and the sigmoid half (rows [split,2*split)) so that one wave owns both.
 PackedConv Engine::pack_matrix(const std::vector<float>& W, int rows, int Cin, int ntaps,
                                const std::vector<float>* bias, int dil, int padl, bool gate, int split) {
@@ -69,7 +69,8 @@ PackedConv Engine::pack_matrix(const std::vector<float>& W, int rows, int Cin, i
             int ci = c * KC + 2 * kk + (lane >> 5);
             float v = 0.f;
             if (row >= 0 && ci < Cin) v = W[((size_t)row * Cin + ci) * ntaps + tap];
-            P[((((size_t)mt * pc.nchunks + c) * ntaps + tap) * (KC / 2) + kk) * 64 + lane] = v;
+            // within a (tile, chunk, tap) step a lane's 16 values are four float4 (kk = 4q + j)
+            P[(((size_t)mt * pc.nchunks + c) * ntaps + tap) * (KC / 2) * 64 + (kk >> 2) * 256 + lane * 4 + (kk & 3)] = v;
           }
   pc.wp = dev_copy(P);
   pc.bias = bias ? dev_copy(*bias) : nullptr;
@@ -340,8 +341,8 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
                         PE_K2(2, 2, 2, 1, 16, true)};
 #undef PE_K2
     for (const void* k : ks) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    const void* ks2[] = {(const void*)conv_splitk_kernel<2, true, 8>, (const void*)conv_splitk_kernel<2, true, 4>,
-                         (const void*)conv_splitk_kernel<1, false, 8>, (const void*)conv_splitk_kernel<1, false, 4>};
+    const void* ks2[] = {(const void*)conv_splitk_kernel<2, true, 8, 3>, (const void*)conv_splitk_kernel<2, true, 4, 3>,
+                         (const void*)conv_splitk_kernel<1, false, 8, 4>, (const void*)conv_splitk_kernel<1, false, 4, 4>};
     for (const void* k : ks2) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     PE_HIP(hipFuncSetAttribute((const void*)dds_layer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     PE_HIP(hipFuncSetAttribute((const void*)attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
@@ -539,14 +540,14 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     const int MT = pc.gate ? 2 : 1;
     const int NW = pc.nchunks >= 5 ? 8 : 4;
     dim3 grid((ncols + 31) / 32, pc.mtiles / MT, B_);
-    const size_t smem = std::max<size_t>((size_t)NW * KC * (32 + p.xhalo), (size_t)NW * MT * 16 * 64) * sizeof(float);
+    const size_t smem = std::max<size_t>((size_t)NW * KC * 64, (size_t)NW * MT * 16 * 64) * sizeof(float);
     const int kh = kbegin(prof_level_ >= 2 ? krow("conv_splitk_kernel") : 0, kflops);
     if (pc.gate) {
-      if (NW == 8) PE_LAUNCH((conv_splitk_kernel<2, true, 8>), grid, dim3(512), smem, ls_, p);
-      else PE_LAUNCH((conv_splitk_kernel<2, true, 4>), grid, dim3(256), smem, ls_, p);
+      if (NW == 8) PE_LAUNCH((conv_splitk_kernel<2, true, 8, 3>), grid, dim3(512), smem, ls_, p);
+      else PE_LAUNCH((conv_splitk_kernel<2, true, 4, 3>), grid, dim3(256), smem, ls_, p);
     } else {
-      if (NW == 8) PE_LAUNCH((conv_splitk_kernel<1, false, 8>), grid, dim3(512), smem, ls_, p);
-      else PE_LAUNCH((conv_splitk_kernel<1, false, 4>), grid, dim3(256), smem, ls_, p);
+      if (NW == 8) PE_LAUNCH((conv_splitk_kernel<1, false, 8, 4>), grid, dim3(512), smem, ls_, p);
+      else PE_LAUNCH((conv_splitk_kernel<1, false, 4, 4>), grid, dim3(256), smem, ls_, p);
     }
     kend(kh);
     return;
@@ -680,10 +681,15 @@ void Engine::mrf(const UpStage& st, View x, View out, const int* lens, int len_m
   }
   const size_t smem = (size_t)st.mrf_nbuf * st.mrf_cp * st.mrf_ws * sizeof(float);
   dim3 grid((Lmax + MRF_NT * 32 - 1) / (MRF_NT * 32), 1, B_);
-  const int kh = kbegin(prof_level_ >= 2 ? krow("mrf_fused_kernel") : 0, kflops);
   // 32-channel stages whose window allows two workgroups per CU run 4 waves each, otherwise 8 (either way
   // two waves per SIMD)
   const bool two = 2 * smem <= 160u * 1024u;
+  const char* kname = st.mrf_cp == 64 ? "mrf_fused_kernel<64,4,8,256>"
+                      : two ? (st.mrf_ws == 256 ? "mrf_fused_kernel<32,4,4,256>"
+                               : st.mrf_ws == 320 ? "mrf_fused_kernel<32,4,4,320>" : "mrf_fused_kernel<32,4,4,384>")
+                            : (st.mrf_ws == 256 ? "mrf_fused_kernel<32,4,8,256>"
+                               : st.mrf_ws == 320 ? "mrf_fused_kernel<32,4,8,320>" : "mrf_fused_kernel<32,4,8,384>");
+  const int kh = kbegin(prof_level_ >= 2 ? krow(kname) : 0, kflops);
 #define PE_MRF32(WS_)                                                                                     \
   do {                                                                                                    \
     if (two) PE_LAUNCH((mrf_fused_kernel<32, MRF_NT, 4, WS_>), grid, dim3(256), smem, ls_, p);          \

@@ -12,6 +12,27 @@ namespace pe {
 
 static constexpr int KC = 32;           // input channels staged per K-chunk of the conv GEMM
 
+// A-operand fragments (engine.cpp: pack_matrix). One (m tile, chunk, tap) step is 1024 floats:
+// [q = 0..3][lane][j = 0..3] holds fragment kk = 4q + j of `lane`, so NK fragments are NK/4 float4 loads.
+template <int NK>
+__device__ __forceinline__ void load_frags(const float* step_base, int lane, int kk0, float (&a)[NK]) {
+#pragma unroll
+  for (int q = 0; q < NK / 4; ++q) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(step_base + (kk0 / 4 + q) * 256 + lane * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[4 * q + j] = t[j];
+  }
+}
+template <int NK>
+__device__ __forceinline__ void load_frags(const pe_rowsrc& w, int step_off, int lane, float (&a)[NK]) {
+#pragma unroll
+  for (int q = 0; q < NK / 4; ++q) {
+    const f32x4 t = pe_row_load4(w, step_off + q * 256 + lane * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[4 * q + j] = t[j];
+  }
+}
+
 enum Epi { EPI_STORE = 0, EPI_RESADD = 1, EPI_GATE = 2, EPI_WNRS = 3, EPI_SUBFROM = 4,
            EPI_ACCUM = 5, EPI_CONVT = 6 };
 enum Act { ACT_NONE = 0, ACT_RELU = 1 };
@@ -208,7 +229,7 @@ void conv_mfma_kernel(ConvP p) {
   const int nunits = nchunks * ntaps * NSUB;
   const int nslabs = ntl * nchunks;
   const long wstride_mt = (long)nchunks * ntaps * (KC / 2) * 64;
-  const float* wbase = p.wp + (long)mtile0 * wstride_mt + lane;
+  const float* wbase = p.wp + (long)mtile0 * wstride_mt;
 
   float xr[KC / 4][NCOL];
   // Branch-free staging: rows are read through buffer descriptors (hardware range check returns 0 for
@@ -238,11 +259,15 @@ void conv_mfma_kernel(ConvP p) {
       }
   };
   auto load_a = [&](int u, float (&a)[KS][MT]) {
-    const float* wt = wbase + (long)u * KS * 64;
+    const int ut = u / NSUB, sub = u - ut * NSUB;      // (chunk, tap) step and KS-fragment group inside it
+    const float* wt = wbase + (long)ut * (KC / 2) * 64;
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk)
+    for (int i = 0; i < MT; ++i) {
+      float t[KS];
+      load_frags<KS>(wt + i * wstride_mt, lane, sub * KS, t);
 #pragma unroll
-      for (int i = 0; i < MT; ++i) a[kk][i] = wt[i * wstride_mt + kk * 64];
+      for (int kk = 0; kk < KS; ++kk) a[kk][i] = t[kk];
+    }
   };
   auto mma = [&](int tap, int sub, const float (&a)[KS][MT], const float* xbuf) {
     const float* xp = xbuf + (lhi + 2 * KS * sub) * XS + tap * p.dil + wn * NT * 32 + l31;
@@ -327,24 +352,81 @@ void conv_mfma_kernel(ConvP p) {
 }
 
 // Same GEMM for launches that would otherwise fill only a few CUs (one utterance through the text
-// encoder / duration predictor / flow: 128..500 columns): one 32*MT x 32 output tile per workgroup
-// and the workgroup's NW (4 or 8) waves split the K-chunks between them (wave w takes chunks w, w+NW, ...),
-// each with a private x slab in LDS and the same A ping-pong; partial tiles are summed through LDS in
-// a fixed order (deterministic) and wave-striped through the shared epilogue.
-template <int MT, bool GATE, int NW>
+// encoder / duration predictor / flow / first generator stage: 128..3500 columns). These launches are pure
+// latency chains, so the kernel is organised around having every memory request in flight as early as
+// possible:
+//   * one 32*MT x 32 output tile per workgroup; its NW (4 or 8) waves split the K-chunks between them
+//     (wave w takes chunks w, w+NW, ...), each with a private x slab in LDS;
+//   * the epilogue operands (bias, residual, previous value) of the slots a wave will finish do not depend
+//     on the GEMM and are requested first;
+//   * weight fragments come through a buffer descriptor as float4 loads into a ring of D steps, issued
+//     unconditionally (past the end the descriptor returns zeros) so that the wait counts stay exact and a
+//     wave with <= D steps has its whole K range in flight at once;
+//   * partial tiles are summed through LDS in a fixed order (deterministic).
+template <int MT, bool GATE, int NW, int D>
 __global__ __launch_bounds__(64 * NW) void conv_splitk_kernel(ConvP p) {
-  constexpr int BN = 32;
-  constexpr int NCOL = 1;                         // private slab: 32 + halo <= 64 columns
-  PE_DYN_SMEM(float, sm);                         // max(NW x [KC][XW], NW x MT x 16 x 64)
+  constexpr int BN = 32, XW = 64, KH = KC / 2;
+  constexpr int NS = GATE ? (16 + NW - 1) / NW : (MT * 16 + NW - 1) / NW;    // epilogue slots per wave
+  PE_DYN_SMEM(float, sm);                         // NW x [KC][XW] slabs, then NW x [MT*16][64] partial tiles
   const int b = blockIdx.z;
   const int L = p.lens[b] * p.len_mul;
   const int ncols = (p.epi == EPI_CONVT) ? L + 1 : L;
   const int n0 = blockIdx.x * BN;
   if (n0 >= ncols) return;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int XW = BN + p.xhalo;
+  const int tid = threadIdx.x, lane = tid & 63, wv = PE_UNIFORM(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
   const int mtile0 = blockIdx.y * MT;
+  const int col = n0 + l31;
+  const int ntaps = p.ntaps, nchunks = p.nchunks;
+  const int wstride_mt = nchunks * ntaps * KH * 64;
+  const EpiFlags ef = epi_flags(p);
+
+  // ---- epilogue operands of this wave's slots: four independent loads per slot, combined only in the
+  // epilogue (adding them here would wait for each load in turn)
+  float e_b1[NS], e_b2[NS], e_o1[NS], e_o2[NS];
+  float* e_dst[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int s = wv + NW * i;
+    e_b1[i] = 0.f; e_b2[i] = 0.f; e_o1[i] = 0.f; e_o2[i] = 0.f; e_dst[i] = nullptr;
+    if constexpr (GATE) {
+      // commons.py:99-106: (b1, b2) = tanh-half bias + speaker bias, (o1, o2) = the sigmoid half's
+      const int ch = (mtile0 >> 1) * 32 + (s & 3) + 8 * (s >> 2) + 4 * lhi;
+      if (s < 16 && ch < p.split && col < ncols) {
+        e_b1[i] = p.bias[ch];
+        e_o1[i] = p.bias[p.split + ch];
+        if (p.bias2) {
+          const float* b2 = p.bias2 + (long)b * p.bias2_bs;
+          e_b2[i] = b2[ch];
+          e_o2[i] = b2[p.split + ch];
+        }
+        e_dst[i] = p.out + (long)b * p.o_bs + (long)ch * p.o_cs + col;
+      }
+    } else {
+      const int r = s & 15;
+      const int row = (mtile0 + (s >> 4)) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      if (s < MT * 16 && row < p.rows && col < ncols) {
+        if (p.epi == EPI_CONVT) {
+          const int co = row / p.up, ph = row - co * p.up;
+          const int t = col * p.up + ph - p.padT;
+          if (t >= 0 && t < L * p.up) {
+            if (p.bias) e_b1[i] = p.bias[co];
+            e_dst[i] = p.out + (long)b * p.o_bs + (long)co * p.o_cs + t;
+          }
+        } else {
+          if (p.bias) e_b1[i] = p.bias[row];
+          if (p.bias2) e_b2[i] = p.bias2[(long)b * p.bias2_bs + row];
+          const bool to_skip = p.epi == EPI_WNRS && row >= p.split;
+          const bool rd_old = to_skip ? (p.mode != 1) : (ef.use_old || p.epi == EPI_WNRS);
+          float* d = to_skip ? p.out2 + (long)b * p.o2_bs + (long)(row - p.split) * p.o2_cs + col
+                             : p.out + (long)b * p.o_bs + (long)row * p.o_cs + col;
+          if (rd_old) e_o1[i] = *d;
+          if (ef.use_res) e_o2[i] = p.res[(long)b * p.r_bs + (long)row * p.r_cs + col];
+          e_dst[i] = d;
+        }
+      }
+    }
+  }
 
   f32x16 acc[MT];
 #pragma unroll
@@ -353,78 +435,76 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk_kernel(ConvP p) {
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
   const float* xb = p.x + (long)b * p.x_bs;
-  const int tbase = n0 - p.padl;
+  const int tbase = n0 - p.padl + lane;
   const float slope = p.in_slope;
-  const int ntaps = p.ntaps, nchunks = p.nchunks;
-  const long wstride_mt = (long)nchunks * ntaps * (KC / 2) * 64;
-  const float* wbase = p.wp + (long)mtile0 * wstride_mt + lane;
-  float* xw = sm + wv * KC * XW;                  // this wave's slab
-  const int myc = (nchunks - wv + NW - 1) / NW;   // chunks wv, wv+NW, ...
-  const int nunits = myc * ntaps;
+  const pe_rowsrc wsrc = pe_make_row(p.wp + (long)mtile0 * wstride_mt, MT * wstride_mt);
+  float* xw = sm + wv * KC * XW;                  // this wave's slab: 32 channels x 64 columns
+  const int myc = wv < nchunks ? (nchunks - wv + NW - 1) / NW : 0;   // chunks wv, wv+NW, ...
+  const int nsteps = myc * ntaps;
 
-  float xr[KC][NCOL];
+  float xr[KC];
   auto load_x = [&](int c) {
-    c = PE_UNIFORM(c);
 #pragma unroll
     for (int r = 0; r < KC; ++r) {
       const int ci = c * KC + r;
       const pe_rowsrc row = pe_make_row(xb + (long)ci * p.x_cs, ci < p.Cin ? L : 0);
-#pragma unroll
-      for (int cc = 0; cc < NCOL; ++cc) xr[r][cc] = pe_row_load(row, tbase + lane + 64 * cc);
+      xr[r] = pe_row_load(row, tbase);
     }
   };
   auto store_x = [&]() {
 #pragma unroll
-    for (int r = 0; r < KC; ++r)
-#pragma unroll
-      for (int cc = 0; cc < NCOL; ++cc) {
-        const int col = lane + 64 * cc;
-        if (col < XW) {
-          float v = xr[r][cc];
-          v = v > 0.f ? v : v * slope;
-          xw[r * XW + col] = v;
-        }
-      }
+    for (int r = 0; r < KC; ++r) {
+      float v = xr[r];
+      v = v > 0.f ? v : v * slope;
+      xw[r * XW + lane] = v;
+    }
   };
-  auto load_a = [&](int u, float (&a)[KC / 2][MT]) {
-    const int k = u / ntaps, tap = u - k * ntaps;
-    const int c = wv + NW * k;
-    const float* wt = wbase + ((long)c * ntaps + tap) * (KC / 2) * 64;
+  // weight ring: slot d holds the fragments of step (s with s % D == d); the load cursor runs D steps ahead
+  float a[D][MT][KH];
+  int lk = 0, ltap = 0;
+  auto load_ring = [&](float (&dst)[MT][KH]) {
+    const int off = PE_UNIFORM(((wv + NW * lk) * ntaps + ltap) * (KH * 64));
 #pragma unroll
-    for (int kk = 0; kk < KC / 2; ++kk)
-#pragma unroll
-      for (int i = 0; i < MT; ++i) a[kk][i] = wt[i * wstride_mt + kk * 64];
+    for (int i = 0; i < MT; ++i) load_frags<KH>(wsrc, off + i * wstride_mt, lane, dst[i]);
+    if (++ltap == ntaps) { ltap = 0; ++lk; }
   };
-  auto mma = [&](int tap, const float (&a)[KC / 2][MT]) {
+  auto mma = [&](int tap, const float (&af)[MT][KH]) {
     const float* xp = xw + lhi * XW + tap * p.dil + l31;
+    float bv[KH];
 #pragma unroll
-    for (int kk = 0; kk < KC / 2; ++kk) {
-      const float bv = xp[2 * kk * XW];
+    for (int kk = 0; kk < KH; ++kk) bv[kk] = xp[2 * kk * XW];
 #pragma unroll
-      for (int i = 0; i < MT; ++i) acc[i] = pe_mfma_32x32x2(a[kk][i], bv, acc[i]);
-    }
+    for (int kk = 0; kk < KH; ++kk)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) acc[i] = pe_mfma_32x32x2(af[i][kk], bv[kk], acc[i]);
   };
-  auto step = [&](int u, float (&cur)[KC / 2][MT], float (&nxt)[KC / 2][MT]) {
-    const int k = u / ntaps, tap = u - k * ntaps;
-    if (tap == 0) {               // new chunk: its slab was prefetched during the previous chunk
-      PE_WAVE_SYNC();             // all lanes done reading the previous slab
-      store_x();
-      PE_WAVE_SYNC();
-      if (k + 1 < myc) load_x(wv + NW * (k + 1));
+
+  load_x(wv);                     // unconditional (zeros for a wave without chunks): keeps the wait counts exact
+#pragma unroll
+  for (int d = 0; d < D; ++d) load_ring(a[d]);
+  PE_SCHED_FENCE();
+  {
+    int k = 0, tap = 0;
+    for (int s0 = 0; s0 < nsteps; s0 += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        if (s0 + d < nsteps) {
+          if (tap == 0) {               // new chunk: its slab is in xr
+            PE_WAVE_SYNC();             // all lanes done reading the previous slab
+            store_x();
+            PE_WAVE_SYNC();
+            if (k + 1 < myc) load_x(wv + NW * (k + 1));
+          }
+          mma(tap, a[d]);
+          if (++tap == ntaps) { tap = 0; ++k; }
+        }
+        PE_SCHED_FENCE();
+        load_ring(a[d]);
+        PE_SCHED_FENCE();
+      }
     }
-    if (u + 1 < nunits) load_a(u + 1, nxt);
-    mma(tap, cur);
-  };
-  float aA[KC / 2][MT], aB[KC / 2][MT];
-  if (nunits > 0) {
-    load_x(wv);
-    load_a(0, aA);
   }
-  for (int u = 0; u < nunits; u += 2) {
-    step(u, aA, aB);
-    if (u + 1 < nunits) step(u + 1, aB, aA);
-  }
-  // ---- cross-wave reduction through LDS (fixed order w = 0..3)
+  // ---- cross-wave reduction through LDS (fixed order w = 0..NW-1)
   __syncthreads();
   float* red = sm;                                // [NW waves][MT*16 slots][64 lanes]
 #pragma unroll
@@ -432,25 +512,35 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk_kernel(ConvP p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[(wv * MT * 16 + i * 16 + r) * 64 + lane] = acc[i][r];
   __syncthreads();
-  const int col = n0 + l31;
-  if constexpr (GATE) {
-    for (int r = wv; r < 16; r += NW) {
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int s = wv + NW * i;
+    if constexpr (GATE) {
       float ta = 0.f, sa = 0.f;
-      for (int w = 0; w < NW; ++w) {
-        ta += red[(w * MT * 16 + r) * 64 + lane];
-        sa += red[(w * MT * 16 + (MT - 1) * 16 + r) * 64 + lane];
+      if (s < 16) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          ta += red[(w * MT * 16 + s) * 64 + lane];
+          sa += red[(w * MT * 16 + (MT - 1) * 16 + s) * 64 + lane];
+        }
       }
-      const int ch = (mtile0 >> 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-      if (ch < p.split && col < ncols) conv_store_gate(p, b, ch, col, ta, sa);
+      if (e_dst[i]) {
+        ta += e_b1[i] + e_b2[i];
+        sa += e_o1[i] + e_o2[i];
+        *e_dst[i] = tanhf(ta) * (1.f / (1.f + expf(-sa)));
+      }
+    } else {
+      float v = 0.f;
+      if (s < MT * 16) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[(w * MT * 16 + s) * 64 + lane];
+      }
+      if (e_dst[i]) {
+        v = ((v + (e_b1[i] + e_b2[i])) * ef.sign + (e_o1[i] + e_o2[i])) * ef.alpha;
+        if (ef.relu) v = v > 0.f ? v : 0.f;
+        *e_dst[i] = v;
+      }
     }
-    return;
-  }
-  for (int s = wv; s < MT * 16; s += NW) {
-    float v = 0.f;
-    for (int w = 0; w < NW; ++w) v += red[(w * MT * 16 + s) * 64 + lane];
-    const int i = s >> 4, r = s & 15;
-    const int row = (mtile0 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-    if (row < p.rows && col < ncols) conv_store(p, epi_flags(p), b, row, col, v, L);
   }
 }
 
@@ -840,12 +930,9 @@ __global__ __launch_bounds__(512) void dds_layer_kernel(DdsP p) {
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      const float* wt = p.wp + (long)mt * wstride_mt + lane;
+      const float* wt = p.wp + (long)mt * wstride_mt;
       float aA[KC / 2], aB[KC / 2];
-      auto lda = [&](int c, float (&a)[KC / 2]) {
-#pragma unroll
-        for (int kk = 0; kk < KC / 2; ++kk) a[kk] = wt[((long)c * (KC / 2) + kk) * 64];
-      };
+      auto lda = [&](int c, float (&a)[KC / 2]) { load_frags<KC / 2>(wt + (long)c * (KC / 2) * 64, lane, 0, a); };
       auto mm = [&](int c, const float (&a)[KC / 2]) {
 #pragma unroll
         for (int kk = 0; kk < KC / 2; ++kk) acc = pe_mfma_32x32x2(a[kk], Y[(c * KC + 2 * kk + lhi) * 32 + l31], acc);
@@ -1231,9 +1318,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mrf_fused_kernel(MrfP p) {
   // only (a flat load would also hold up every LDS wait), zero for rows beyond C
   float aA[KH], aB[KH], bA[KH], bB[KH];
   auto load_a = [&](const pe_rowsrc& w, int step, float (&a)[KH]) {
-    const int o = PE_UNIFORM(step * KH * 64);
-#pragma unroll
-    for (int kk = 0; kk < KH; ++kk) a[kk] = pe_row_load(w, o + kk * 64 + lane);
+    load_frags<KH>(w, PE_UNIFORM(step * KH * 64), lane, a);
   };
   // unit u of a phase -> (m tile, column tile); waves take units round-robin, rotated per phase so the idle
   // slots of the uneven phases move around the SIMDs

@@ -19,6 +19,11 @@ template <class T> inline T* pe_uniform_ptr(T* p) { return p; }
 struct pe_rowsrc { const float* p; int n; };
 inline pe_rowsrc pe_make_row(const float* row, int n) { return pe_rowsrc{row, n}; }
 inline float pe_row_load(const pe_rowsrc& r, int idx) { return (idx >= 0 && idx < r.n) ? r.p[idx] : 0.f; }
+inline f32x4 pe_row_load4(const pe_rowsrc& r, int idx) {
+  f32x4 v;
+  for (int j = 0; j < 4; ++j) v[j] = (idx + j >= 0 && idx + j < r.n) ? r.p[idx + j] : 0.f;
+  return v;
+}
 inline float pe_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 #else
 #include <hip/hip_runtime.h>
@@ -57,6 +62,10 @@ __device__ __forceinline__ pe_rowsrc pe_make_row(const float* row, int n) {
 }
 __device__ __forceinline__ float pe_row_load(pe_rowsrc r, int idx) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, idx * 4, 0, 0));
+}
+// four consecutive floats (16-byte aligned index) in one instruction
+__device__ __forceinline__ f32x4 pe_row_load4(pe_rowsrc r, int idx) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, idx * 4, 0, 0));
 }
 // leaky-relu for 0 < slope < 1 in two VALU ops: median(v, v*slope, +inf) = max(v, v*slope)
 __device__ __forceinline__ float pe_lrelu(float v, float slope) {
