@@ -363,7 +363,6 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
   if (const char* t = getenv("PIPER_HIP_WIDE_MIN")) wide_min_blocks_ = atol(t);
   if (const char* t = getenv("PIPER_HIP_SMALL")) small_tiles_ = atoi(t) != 0;
   if (const char* t = getenv("PIPER_HIP_PAR_MRF")) par_mrf_ = atoi(t) != 0;
-  if (const char* t = getenv("PIPER_HIP_ABL")) abl_ = atoi(t);              // timing ablations, results invalid
   if (const char* t = getenv("PIPER_HIP_FUSE_MRF")) fuse_mrf_ = atoi(t) != 0;   // A/B knob: 0 = conv-by-conv MRF stages
 }
 
@@ -519,9 +518,9 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
   p.epi = epi; p.act = act;
   p.split = (epi == EPI_GATE) ? pc.split : (epi == EPI_WNRS ? (pc.rows > H_ ? H_ : 0) : 0);
   p.up = pc.up; p.padT = pc.padT;
+  p.up_magic = pc.up ? (unsigned)((0x100000000ULL + pc.up - 1) / pc.up) : 0u;
   p.mode = mode; p.alpha = alpha;
   p.tpb = 1;
-  p.abl = abl_;
   if ((epi == EPI_GATE) != pc.gate) throw std::runtime_error("internal: gate epilogue/packing mismatch");
 
   const int ncols = (epi == EPI_CONVT) ? Lmax + 1 : Lmax;

@@ -178,7 +178,6 @@ class Engine {
   int B_ = 0, Tmax_ = 0, Ts_ = 0, Fmax_ = 0, Fs_ = 0, Tg_ = 0, Fg_ = 0;
   bool use_graphs_ = true;
   int tpb_override_ = 0;
-  int abl_ = 0;
   bool small_tiles_ = true;                 // 32x32 wave tiles everywhere: occupancy beats register reuse here (profiles/)
   long wide_min_blocks_ = 1L << 40;        // 256-column tiles measured slower than 128 (profiles/): off unless PIPER_HIP_WIDE_MIN is set
   std::map<std::string, void*> graphs_;       // hipGraphExec_t per (stage, shape bucket, scales)

@@ -24,10 +24,10 @@ __device__ __forceinline__ void load_frags(const float* step_base, int lane, int
   }
 }
 template <int NK>
-__device__ __forceinline__ void load_frags(const pe_rowsrc& w, int step_off, int lane, float (&a)[NK]) {
+__device__ __forceinline__ void load_frags(const pe_rowsrc& w, int step_off, int lane, float (&a)[NK], int kk0 = 0) {
 #pragma unroll
   for (int q = 0; q < NK / 4; ++q) {
-    const f32x4 t = pe_row_load4(w, step_off + q * 256 + lane * 4);
+    const f32x4 t = pe_row_load4(w, step_off + (kk0 / 4 + q) * 256 + lane * 4);
 #pragma unroll
     for (int j = 0; j < 4; ++j) a[4 * q + j] = t[j];
   }
@@ -54,11 +54,10 @@ struct ConvP {
   int epi, act;
   int split;                                    // GATE: H ; WNRS: rows < split go to h, rest to skip
   int up, padT;                                 // CONVT: stride and padding
+  unsigned up_magic;                            // CONVT: ceil(2^32 / up): row / up == (row * up_magic) >> 32 for row < 2^16
   int mode;                                     // ACCUM: 0 first,1 middle,2 last,3 only ; WNRS: 1 = first layer
   float alpha;                                  // ACCUM last/only: scale
   int tpb;                                      // conv_mfma_kernel: column tiles walked by one workgroup
-  int abl;                                      // timing ablation (tuning only, wrong results): 1 no weight reloads,
-                                                // 2 no x-slab reloads, 3 no epilogue, 4 no MFMAs
 };
 
 // ---- shared epilogue of the conv GEMM kernels: one accumulator element (row, col) of utterance b.
@@ -111,62 +110,72 @@ __device__ __forceinline__ void conv_store(const ConvP& p, const EpiFlags& f, in
   if (f.relu) v = v > 0.f ? v : 0.f;
   *d = v;
 }
-// One 32x32 accumulator tile (16 values per lane) through the epilogue. Two phases -- fetch every operand
-// (bias, residual, previous value) for all 16 elements, then compute and store -- so the 16
-// read-modify-write chains overlap instead of serialising on memory latency (out/res may alias, which
-// otherwise forces load-wait-store order per element). The column predicate is one exec-mask region for
-// the whole tile; full tiles (the common case) carry no row predicate; addresses are a uniform base
-// pointer plus a 32-bit lane offset plus a uniform k*stride, i.e. one VALU add per element.
-// WNRS relies on split % 32 == 0 (checked at load), so a tile lies entirely on one side of the split.
+// One 32x32 accumulator tile (16 values per lane) through the epilogue, branch-free: every operand stream
+// (bias, speaker bias, previous value, residual) is a buffer descriptor whose length is 0 when the stream
+// is not used and rows*stride otherwise, so unused operands and rows beyond the GEMM read as 0 and such
+// stores are dropped by the range check; invalid columns poison the lane offset. Addresses are one
+// per-lane offset (row base, column) shared by the 16 elements plus a wave-uniform k*stride that rides in
+// an SGPR: no per-element VALU address arithmetic. All loads are issued before the first store (out and
+// res may alias). WNRS relies on split % 32 == 0 (checked at load): a tile lies on one side of the split.
 __device__ __forceinline__ void conv_store_tile(const ConvP& p, const EpiFlags& f, int b, int row0, int col, int lhi,
                                                 int L, int ncols, const f32x16& acc) {
-  if (col >= ncols) return;
+  constexpr int OOB = 0x3fffffff;                // element index beyond any descriptor
   int rb = row0 + 4 * lhi;
-  PE_OPAQUE(rb);       // keeps the (tile-invariant) row addressing and bias loads from being hoisted out of the
-                       // tile loop into dozens of live registers
+  PE_OPAQUE(rb);       // keeps the (tile-invariant) row addressing from being hoisted out of the tile loop
   if (p.epi == EPI_CONVT) {
+    // row = co*up + phase; output sample t = col*up + phase - padT (models.py:321-332, polyphase form)
+    const pe_rowsrc od = pe_make_row_u(p.out + (long)b * p.o_bs, (p.rows / p.up) * p.o_cs);
+    const pe_rowsrc bd = pe_make_row_u(p.bias, p.bias ? p.rows / p.up : 0);
+    const int tmax = L * p.up;
+    float bv[16];
+    int off[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = rb + (r & 3) + 8 * (r >> 2);
-      if (row >= p.rows) continue;
-      const int co = row / p.up, ph = row - co * p.up;
-      const int t = col * p.up + ph - p.padT;
-      if (t >= 0 && t < L * p.up)
-        p.out[(long)b * p.o_bs + (long)co * p.o_cs + t] = acc[r] + (p.bias ? p.bias[co] : 0.f);
+      const int co = (int)(((unsigned long long)(unsigned)row * p.up_magic) >> 32);     // row / up
+      const int t = col * p.up + (row - co * p.up) - p.padT;
+      off[r] = (row < p.rows && col < ncols && t >= 0 && t < tmax) ? co * p.o_cs + t : OOB;
+      bv[r] = pe_row_load(bd, row < p.rows ? co : OOB);
     }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pe_row_store_so(od, off[r], 0, acc[r] + bv[r]);
     return;
   }
-  const bool full = row0 + 32 <= p.rows;
   const bool to_skip = p.epi == EPI_WNRS && row0 >= p.split;        // uniform per tile
   const bool rd_old = to_skip ? (p.mode != 1) : (f.use_old || p.epi == EPI_WNRS);
+  const int orow0 = to_skip ? p.split : 0;                           // first GEMM row of the destination tensor
+  const int orows = to_skip ? p.rows - p.split : (p.epi == EPI_WNRS ? p.split : p.rows);
+  const int ocs = to_skip ? p.o2_cs : p.o_cs;
   float* ob = to_skip ? p.out2 + (long)b * p.o2_bs : p.out + (long)b * p.o_bs;
-  const unsigned ocs = to_skip ? (unsigned)p.o2_cs : (unsigned)p.o_cs;
-  const unsigned ooff = (unsigned)(to_skip ? rb - p.split : rb) * ocs + (unsigned)col;
-  const float* rs = p.res + (long)b * p.r_bs;
-  const unsigned roff = (unsigned)rb * (unsigned)p.r_cs + (unsigned)col;
-  const float* b2 = p.bias2 ? p.bias2 + (long)b * p.bias2_bs : nullptr;
-  float add[16], old[16];
+  const pe_rowsrc od = pe_make_row_u(ob, orows * ocs);
+  const pe_rowsrc old = pe_make_row_u(ob, rd_old ? orows * ocs : 0);
+  const pe_rowsrc rd = pe_make_row_u(p.res + (long)b * p.r_bs, f.use_res ? p.rows * p.r_cs : 0);
+  const pe_rowsrc bd = pe_make_row_u(p.bias, p.bias ? p.rows : 0);
+  const pe_rowsrc b2d = pe_make_row_u(p.bias2 + (long)b * p.bias2_bs, p.bias2 ? p.rows : 0);
+  const bool cok = col < ncols;
+  const int ooff = cok ? (rb - orow0) * ocs + col : OOB;
+  const int roff = cok ? rb * p.r_cs + col : OOB;
+  // two groups of eight elements (register budget of the 4-waves-per-SIMD instantiations); an element only
+  // ever reads its own location, so a group's stores cannot disturb the next group's loads
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int kr = (r & 3) + 8 * (r >> 2);
-    float a = 0.f, o = 0.f;
-    if (full || rb + kr < p.rows) {
-      if (p.bias) a = p.bias[rb + kr];
-      if (b2) a += b2[rb + kr];
-      if (rd_old) o = ob[ooff + (unsigned)kr * ocs];
-      if (f.use_res) o += rs[roff + (unsigned)kr * (unsigned)p.r_cs];
+  for (int g = 0; g < 2; ++g) {
+    float b1[8], b2[8], o1[8], o2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int r = 8 * g + e, kr = (r & 3) + 8 * (r >> 2);
+      b1[e] = pe_row_load(bd, rb + kr);
+      b2[e] = pe_row_load(b2d, rb + kr);
+      o1[e] = pe_row_load_so(old, ooff, kr * ocs);
+      o2[e] = pe_row_load_so(rd, roff, kr * p.r_cs);
     }
-    add[r] = a;
-    old[r] = o;
-  }
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int kr = (r & 3) + 8 * (r >> 2);
-    if (full || rb + kr < p.rows) {
-      float v = ((acc[r] + add[r]) * f.sign + old[r]) * f.alpha;
+    for (int e = 0; e < 8; ++e) {
+      const int r = 8 * g + e, kr = (r & 3) + 8 * (r >> 2);
+      float v = ((acc[r] + (b1[e] + b2[e])) * f.sign + (o1[e] + o2[e])) * f.alpha;
       if (f.relu) v = v > 0.f ? v : 0.f;
-      ob[ooff + (unsigned)kr * ocs] = v;
+      pe_row_store_so(od, ooff, kr * ocs, v);
     }
+    PE_SCHED_FENCE();
   }
 }
 // commons.py:99-106 fused_add_tanh_sigmoid_multiply on a (tanh-tile, sigmoid-tile) accumulator pair
@@ -188,9 +197,13 @@ __device__ __forceinline__ void conv_store_gate(const ConvP& p, int b, int ch, i
 //   * B operand (activations): one [KC x (BN+halo)] slab per K-chunk in LDS, double-buffered; the next
 //     chunk is fetched into registers while the current one feeds the MFMAs, so a dilated tap is just
 //     a shifted LDS read and the pre-activation (leaky-relu) is applied once per element.
-//   * A operand (weights): pre-packed at load time in fragment order, so a wave reads its 32x2 slice
-//     as ONE coalesced dword per lane straight from L2; the 16 fragments of the next (chunk,tap) unit
-//     are prefetched into a second register set (ping-pong) while the current unit's MFMAs issue.
+//   * A operand (weights): pre-packed at load time in fragment order and read through a buffer
+//     descriptor as float4 per lane; the fragments of the next unit are prefetched into a second register
+//     set (ping-pong) while the current unit's MFMAs issue.
+//   * Every global load sits at an unconditional position of the loop nest (a slab or a unit that does not
+//     exist is read through a zero-length descriptor / wraps to unit 0) and scheduling fences keep the
+//     prefetch block ahead of the MFMAs: with a branch between a load and its use the compiler's wait-count
+//     bookkeeping collapses to "drain everything" in every unit.
 // Covers every groups=1 Conv1d of attentions.py / modules.py / models.py and (EPI_CONVT) the polyphase
 // form of Generator.ups ConvTranspose1d (models.py:321-332) where k = 2*stride.
 // second launch-bound argument = waves per SIMD the register allocation must leave room for: latency here is
@@ -200,24 +213,23 @@ __global__ __launch_bounds__(256, (MT * NT == 1 ? ((HALO == 128 && WN == 4) ? 3 
 void conv_mfma_kernel(ConvP p) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
   constexpr int NCOL = (BN + HALO + 63) / 64;    // staging columns per lane; (taps-1)*dilation <= HALO
-  constexpr int NSUB = (KC / 2) / KS;             // A prefetch sets per (chunk, tap)
+  constexpr int KH = KC / 2;
+  constexpr int NSUB = KH / KS;                   // A prefetch sets per (chunk, tap)
   static_assert(WM * WN == 4, "4 waves per block");
-  static_assert(NSUB * KS == KC / 2, "KS must divide KC/2");
+  static_assert(NSUB * KS == KH && KS % 4 == 0, "KS must divide KC/2 in float4 groups");
   static_assert(!GATE || MT == 2, "gate epilogue pairs two M tiles");
   constexpr int XS = NCOL * 64;                   // LDS row stride (compile time: taps become immediates)
   PE_DYN_SMEM(float, xs);                         // 2 x [KC][XS]
   const int b = blockIdx.z;
   const int L = p.lens[b] * p.len_mul;
   const int ncols = (p.epi == EPI_CONVT) ? L + 1 : L;
-  // a workgroup walks p.tpb consecutive column tiles: the x slab of the next (tile, chunk) and the A
-  // fragments of the next unit are in flight while the current unit's MFMAs issue, and the previous
-  // tile's epilogue stores drain under the next tile's MFMAs
+  // a workgroup walks p.tpb consecutive column tiles (1 by default, profiles/r01_tpb_sweep.txt)
   const int tile0 = blockIdx.x * p.tpb;
   const int ntile_all = (ncols + BN - 1) / BN;
   if (tile0 >= ntile_all) return;
   const int ntl = (ntile_all - tile0) < p.tpb ? (ntile_all - tile0) : p.tpb;
   const int m0 = blockIdx.y * BM;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = PE_UNIFORM(tid >> 6);
   const int wm = wv / WN, wn = wv % WN;
   const int l31 = lane & 31, lhi = lane >> 5;
 
@@ -226,23 +238,23 @@ void conv_mfma_kernel(ConvP p) {
   const int mtile0 = m0 / 32 + wm * MT;
   const float slope = p.in_slope;
   const int ntaps = p.ntaps, nchunks = p.nchunks;
-  const int nunits = nchunks * ntaps * NSUB;
+  const int upc = ntaps * NSUB;                   // units per chunk
+  const int nunits = nchunks * upc;
   const int nslabs = ntl * nchunks;
-  const long wstride_mt = (long)nchunks * ntaps * (KC / 2) * 64;
-  const float* wbase = p.wp + (long)mtile0 * wstride_mt;
+  const int wstride_mt = nchunks * ntaps * KH * 64;
+  const pe_rowsrc wsrc = pe_make_row(p.wp + (long)mtile0 * wstride_mt, MT * wstride_mt);
 
   float xr[KC / 4][NCOL];
   // Branch-free staging: rows are read through buffer descriptors (hardware range check returns 0 for
   // the halo, the tail and padded channels) and the LDS rows are NCOL*64 wide so every lane stores
-  // unconditionally.
-  const int wvu = PE_UNIFORM(wv);
-  auto load_x = [&](int s) {
+  // unconditionally. A slab that does not exist (`live` false) reads through zero-length descriptors.
+  auto load_x = [&](int s, bool live) {
     const int tl = s / nchunks, c = s - tl * nchunks;
     const int tbase = (tile0 + tl) * BN - p.padl + lane;
 #pragma unroll
     for (int rr = 0; rr < KC / 4; ++rr) {
-      const int ci = c * KC + wvu + 4 * rr;
-      const pe_rowsrc row = pe_make_row(xb + (long)ci * p.x_cs, ci < p.Cin ? L : 0);
+      const int ci = c * KC + wv + 4 * rr;
+      const pe_rowsrc row = pe_make_row(xb + (long)ci * p.x_cs, (live && ci < p.Cin) ? L : 0);
 #pragma unroll
       for (int cc = 0; cc < NCOL; ++cc) xr[rr][cc] = pe_row_load(row, tbase + 64 * cc);
     }
@@ -258,50 +270,31 @@ void conv_mfma_kernel(ConvP p) {
         dst[4 * rr * XS + 64 * cc] = v;
       }
   };
-  auto load_a = [&](int u, float (&a)[KS][MT]) {
-    const int ut = u / NSUB, sub = u - ut * NSUB;      // (chunk, tap) step and KS-fragment group inside it
-    const float* wt = wbase + (long)ut * (KC / 2) * 64;
+  // unit u of a tile = (chunk, tap, sub): KS fragments per M tile
+  auto load_a = [&](int u, float (&a)[MT][KS]) {
+    const int ut = u / NSUB, sub = u - ut * NSUB;
+    const int off = PE_UNIFORM(ut * (KH * 64));
 #pragma unroll
-    for (int i = 0; i < MT; ++i) {
-      float t[KS];
-      load_frags<KS>(wt + i * wstride_mt, lane, sub * KS, t);
-#pragma unroll
-      for (int kk = 0; kk < KS; ++kk) a[kk][i] = t[kk];
-    }
+    for (int i = 0; i < MT; ++i) load_frags<KS>(wsrc, off + i * wstride_mt, lane, a[i], sub * KS);
   };
-  auto mma = [&](int tap, int sub, const float (&a)[KS][MT], const float* xbuf) {
+  auto read_b = [&](int tap, int sub, const float* xbuf, float (&bv)[KS][NT]) {
     const float* xp = xbuf + (lhi + 2 * KS * sub) * XS + tap * p.dil + wn * NT * 32 + l31;
 #pragma unroll
-    for (int kk = 0; kk < KS; ++kk) {
-      float bv[NT];
+    for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
-      for (int j = 0; j < NT; ++j) bv[j] = xp[2 * kk * XS + j * 32];
+      for (int j = 0; j < NT; ++j) bv[kk][j] = xp[2 * kk * XS + j * 32];
+  };
+  auto mma = [&](const float (&a)[MT][KS], const float (&bv)[KS][NT]) {
+#pragma unroll
+    for (int kk = 0; kk < KS; ++kk)
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = pe_mfma_32x32x2(a[kk][i], bv[j], acc[i][j]);
-    }
-  };
-  // one (chunk, tap, sub) unit of tile tl: prefetch the next unit's A set (wrapping to the next tile),
-  // run this unit's MFMAs, and at chunk boundaries move the prefetched x slab into the other LDS buffer
-  auto step = [&](int tl, int u, float (&cur)[KS][MT], float (&nxt)[KS][MT]) {
-    const int ut = u / NSUB, sub = u - ut * NSUB;
-    const int c = ut / ntaps, tap = ut - c * ntaps;
-    const int s = tl * nchunks + c;
-    if (tap == 0 && sub == 0 && s + 1 < nslabs && p.abl != 2) load_x(s + 1);
-    if (p.abl != 1) {
-      if (u + 1 < nunits) load_a(u + 1, nxt);
-      else if (tl + 1 < ntl) load_a(0, nxt);
-    }
-    if (p.abl != 4) mma(tap, sub, cur, xs + (s & 1) * KC * XS);
-    if (tap == ntaps - 1 && sub == NSUB - 1 && s + 1 < nslabs) {
-      if (p.abl != 2) store_x((s + 1) & 1);
-      __syncthreads();
-    }
+        for (int j = 0; j < NT; ++j) acc[i][j] = pe_mfma_32x32x2(a[i][kk], bv[kk][j], acc[i][j]);
   };
 
-  float aA[KS][MT], aB[KS][MT];
-  load_x(0);
+  float aA[MT][KS], aB[MT][KS];
+  load_x(0, true);
   load_a(0, aA);
   store_x(0);
   __syncthreads();
@@ -314,21 +307,42 @@ void conv_mfma_kernel(ConvP p) {
       for (int j = 0; j < NT; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    for (int u = 0; u < nunits; u += 2) {
-      step(tl, u, aA, aB);
-      if (u + 1 < nunits) step(tl, u + 1, aB, aA);
-    }
-    if (nunits & 1) {     // odd unit count: the next tile's first A set was prefetched into aB
+    int u = 0;                                    // unit index inside the tile
+    for (int c = 0; c < nchunks; ++c) {
+      const int s = tl * nchunks + c;
+      const float* xbuf = xs + (s & 1) * KC * XS;
+      load_x(s + 1, s + 1 < nslabs);              // next slab: in flight for the whole chunk
+      int tap = 0, sub = 0;
+      auto next_unit = [&]() { ++u; if (++sub == NSUB) { sub = 0; ++tap; } };
+      for (int j = 0; j < upc; j += 2) {
+        float bv[KS][NT];
+        load_a(u + 1 == nunits ? 0 : u + 1, aB);  // wraps to the next tile's first unit
+        read_b(tap, sub, xbuf, bv);
+        PE_SCHED_FENCE();
+        mma(aA, bv);
+        PE_SCHED_FENCE();
+        next_unit();
+        if (j + 1 < upc) {
+          load_a(u + 1 == nunits ? 0 : u + 1, aA);
+          read_b(tap, sub, xbuf, bv);
+          PE_SCHED_FENCE();
+          mma(aB, bv);
+          PE_SCHED_FENCE();
+          next_unit();
+        }
+      }
+      if (upc & 1) {        // odd unit count: the next unit's fragments were prefetched into aB
 #pragma unroll
-      for (int kk = 0; kk < KS; ++kk)
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int i = 0; i < MT; ++i) aA[kk][i] = aB[kk][i];
+          for (int kk = 0; kk < KS; ++kk) aA[i][kk] = aB[i][kk];
+      }
+      if (s + 1 < nslabs) {
+        store_x((s + 1) & 1);
+        __syncthreads();
+      }
     }
     // ---- epilogue of this tile
-    if (p.abl == 3) {
-      if (acc[0][0][0] == 123.456f) p.out[0] = 1.f;     // keep the accumulators live
-      continue;
-    }
     if constexpr (GATE) {
       const int q = mtile0 >> 1;
 #pragma unroll

@@ -19,6 +19,13 @@ template <class T> inline T* pe_uniform_ptr(T* p) { return p; }
 struct pe_rowsrc { const float* p; int n; };
 inline pe_rowsrc pe_make_row(const float* row, int n) { return pe_rowsrc{row, n}; }
 inline float pe_row_load(const pe_rowsrc& r, int idx) { return (idx >= 0 && idx < r.n) ? r.p[idx] : 0.f; }
+inline pe_rowsrc pe_make_row_u(const float* row, int n) { return pe_rowsrc{row, n}; }
+// element (vidx + sidx): vidx per lane, sidx wave-uniform (an SGPR offset on the GPU)
+inline float pe_row_load_so(const pe_rowsrc& r, int vidx, int sidx) { return pe_row_load(r, vidx + sidx); }
+inline void pe_row_store_so(const pe_rowsrc& r, int vidx, int sidx, float v) {
+  const long i = (long)vidx + sidx;
+  if (i >= 0 && i < r.n) const_cast<float*>(r.p)[i] = v;
+}
 inline f32x4 pe_row_load4(const pe_rowsrc& r, int idx) {
   f32x4 v;
   for (int j = 0; j < 4; ++j) v[j] = (idx + j >= 0 && idx + j < r.n) ? r.p[idx + j] : 0.f;
@@ -60,8 +67,20 @@ typedef __amdgpu_buffer_rsrc_t pe_rowsrc;
 __device__ __forceinline__ pe_rowsrc pe_make_row(const float* row, int n) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(row), 0, n * 4, 0x00020000);
 }
+// same, for a base/length the compiler cannot prove wave-uniform although they are (values that depend on
+// the wave index or live in vector registers): without this every access runs in a waterfall loop
+__device__ __forceinline__ pe_rowsrc pe_make_row_u(const float* row, int n) {
+  return pe_make_row(pe_uniform_ptr(row), __builtin_amdgcn_readfirstlane(n));
+}
 __device__ __forceinline__ float pe_row_load(pe_rowsrc r, int idx) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, idx * 4, 0, 0));
+}
+// element (vidx + sidx): vidx per lane, sidx wave-uniform -> the uniform part rides in an SGPR, no VALU add
+__device__ __forceinline__ float pe_row_load_so(pe_rowsrc r, int vidx, int sidx) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, vidx * 4, sidx * 4, 0));
+}
+__device__ __forceinline__ void pe_row_store_so(pe_rowsrc r, int vidx, int sidx, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, vidx * 4, sidx * 4, 0);
 }
 // four consecutive floats (16-byte aligned index) in one instruction
 __device__ __forceinline__ f32x4 pe_row_load4(pe_rowsrc r, int idx) {
