@@ -164,7 +164,11 @@ class Engine {
   };
   void build_mrf(UpStage& st);
   void mrf(const UpStage& st, View x, View out, const int* lens, int len_mul, int Lmax);
-  bool fuse_mrf_ = true;
+  // The fused MRF stage kernel moves ~3x fewer HBM bytes but is LDS-capacity bound to 2 waves per SIMD; since the
+  // conv GEMM kernel's prefetch/epilogue rework the conv-by-conv schedule is faster at every batch size measured
+  // (profiles/r01_mrf_ab.txt), so it is opt-in (PIPER_HIP_FUSE_MRF=1).
+  bool fuse_mrf_ = false;
+  long splitk_max_blocks_ = 96;             // launches with fewer tile-kernel workgroups use conv_splitk_kernel
   std::vector<UpStage> ups_;
   float* post_w_ = nullptr;
   int post_cin_ = 0;

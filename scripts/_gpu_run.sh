@@ -1,15 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -8 > gpurun_out/t1.log
-for v in old new; do
-  cp scripts/ab/lib_$v.so piper_amd/libpiper_hip.so
-  python bench.py --no-cpu-baseline > gpurun_out/ab_${v}_b1.json 2> gpurun_out/ab_${v}.err
-  python bench.py --no-cpu-baseline --batch 16 --steps 20 > gpurun_out/ab_${v}_b16.json 2>> gpurun_out/ab_${v}.err
-  python bench.py --no-cpu-baseline --preset high --batch 8 --steps 10 > gpurun_out/ab_${v}_h8.json 2>> gpurun_out/ab_${v}.err
+for m in 160 96 48 0; do
+  PIPER_HIP_SPLITK_MAX=$m python bench.py --no-cpu-baseline > gpurun_out/sk${m}_b1.json 2> gpurun_out/f.err
+  PIPER_HIP_SPLITK_MAX=$m python bench.py --no-cpu-baseline --batch 4 > gpurun_out/sk${m}_b4.json 2>> gpurun_out/f.err
 done
-cp scripts/ab/lib_new.so piper_amd/libpiper_hip.so
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/st_b16 -- python bench.py --no-cpu-baseline --batch 16 --steps 20 > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/st_h8 -- python bench.py --no-cpu-baseline --preset high --batch 8 --steps 10 > /dev/null 2>&1
-find gpurun_out -name "*kernel_trace.csv" -delete
-cat gpurun_out/t1.log
