@@ -128,3 +128,29 @@ def test_cpp_piper_api_on_emulator(tmp_path):
     with wave.open(wav, "rb") as wf:
         assert (wf.getframerate(), wf.getsampwidth(), wf.getnchannels()) == (16000, 2, 1)
         assert wf.getnframes() * 2 + 44 == os.path.getsize(wav) >= 10000
+
+
+def test_jsonl_drivers_on_emulator(tmp_path):
+    """piper_amd.infer / piper_amd.benchmark mirror the reference's infer_onnx.py / benchmark_onnx.py command
+    lines (JSONL of phoneme ids on stdin); run here against the emulator build of the engine."""
+    import io
+    import wave
+    from piper_amd import _lib as L, benchmark, infer
+    emu = os.path.join(ROOT, "tests", "emu", "libpiper_hip_emu.so")
+    if not os.path.exists(emu):
+        subprocess.check_call(["make", "-C", ROOT, "emu"])
+    elib = L.bind(emu)
+    model = os.path.join(GOLD, "tinyhms_voice.onnx")
+    lines = ['{"phoneme_ids": [1, 5, 2], "speaker_id": 1}', "", '{"phoneme_ids": [1, 9]}']
+    out = tmp_path / "wavs"
+    assert infer.main(["--model", model, "--output-dir", str(out), "--sample-rate", "16000", "--batch", "2",
+                       "--seed", "3"], stdin=io.StringIO("\n".join(lines)), lib=elib) == 0
+    assert sorted(p.name for p in out.iterdir()) == ["0.wav", "2.wav"]       # blank line keeps its index
+    with wave.open(str(out / "0.wav"), "rb") as w:
+        assert (w.getframerate(), w.getnchannels(), w.getsampwidth()) == (16000, 1, 2)
+        assert w.getnframes() > 0 and w.getnframes() % 256 == 0
+    buf = io.StringIO()
+    assert benchmark.main(["-m", model], stdin=io.StringIO("\n".join(lines)), stdout=buf, lib=elib) == 0
+    rep = json.loads(buf.getvalue())
+    assert set(rep) == {"load_sec", "rtf_mean", "rtf_stdev", "rtfs"} and len(rep["rtfs"]) == 2
+    assert all(r > 0 for r in rep["rtfs"]) and rep["load_sec"] > 0
