@@ -47,7 +47,9 @@ typedef struct pe_result {
 
 /* Replaces Ort::Env + SessionOptions + Ort::Session(model path) in loadModel()
  * (piper.cpp:262-306): parses the voice .onnx (export_onnx.py graph), packs the weights for the
- * MFMA kernels and uploads them to GPU `device`. */
+ * MFMA kernels and uploads them to GPU `device`. `onnx_path` may also name the output of the reference's
+ * streaming export (export_onnx_streaming.py: a directory with encoder.onnx + decoder.onnx, or either of
+ * the two files): both graphs are read and the voice behaves like the single-file one. */
 int pe_create(const char* onnx_path, int device, pe_engine** out);
 
 /* Same from an in-memory weight blob (PEBLOB01, see piper_amd/weights.py). This is also what the

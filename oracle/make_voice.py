@@ -21,7 +21,9 @@ from oracle import ref_harness as R  # noqa: E402
 from piper_amd import weights as W  # noqa: E402
 
 
-def export(preset: str, out_prefix: str, seed: int = 1234):
+def build_model(preset: str, seed: int):
+    """Reference SynthesizerTrn with the seeded canonical weights, dec weight norm removed (export_onnx.py:51-52,
+    export_onnx_streaming.py:101-102), the flow still weight-normed as in real voices."""
     cfg = W.preset(preset)
     w = W.synthetic_weights(cfg, seed)
     SynthesizerTrn = R.import_reference()
@@ -35,7 +37,7 @@ def export(preset: str, out_prefix: str, seed: int = 1234):
             upsample_rates=cfg.up_rates, upsample_initial_channel=cfg.up_initial,
             upsample_kernel_sizes=cfg.up_kernel_sizes, n_speakers=cfg.n_speakers, gin_channels=cfg.gin,
             use_sdp=True).eval()
-        m.dec.remove_weight_norm()                       # export_onnx.py:51-52
+        m.dec.remove_weight_norm()
     sd = m.state_dict()
     for k, v in w.items():
         t = torch.as_tensor(v)
@@ -47,16 +49,73 @@ def export(preset: str, out_prefix: str, seed: int = 1234):
         else:
             raise KeyError(k)
     m.load_state_dict(sd)
+    # the legacy exporter's onnxscript post-pass needs the `onnx` package (absent here); it is a no-op
+    # for graphs made of stock ops (SURVEY.md section 8c)
+    import torch.onnx._internal.torchscript_exporter.onnx_proto_utils as opu
+    opu._add_onnxscript_fn = lambda model_bytes, custom_opsets: model_bytes
+    return cfg, m
+
+
+def write_config(cfg, preset, seed, path):
+    # voice config with the schema of etc/test_voice.onnx.json; a `text` voice over printable ASCII
+    pool = " abcdefghijklmnopqrstuvwxyz.,!?'-;:" + "".join(chr(c) for c in range(48, 91))
+    chars = list(dict.fromkeys(pool))[: cfg.n_vocab - 3]
+    id_map = {"_": [0], "^": [1], "$": [2]}
+    id_map.update({ch: [3 + i] for i, ch in enumerate(chars)})
+    conf = {"audio": {"sample_rate": cfg.sample_rate}, "espeak": {"voice": "en-us"}, "phoneme_type": "text",
+            "inference": {"noise_scale": 0.667, "length_scale": 1, "noise_w": 0.8},
+            "phoneme_map": {}, "phoneme_id_map": id_map, "num_symbols": cfg.n_vocab,
+            "num_speakers": cfg.n_speakers,
+            "speaker_id_map": {f"spk{i}": i for i in range(cfg.n_speakers)} if cfg.n_speakers > 1 else {},
+            "synthetic": {"preset": preset, "weight_seed": seed}}
+    with open(path, "w", encoding="utf-8") as f:
+        json.dump(conf, f, indent=1)
+
+
+def export_streaming(preset: str, out_dir: str, seed: int = 1234):
+    """encoder.onnx + decoder.onnx exactly as the reference's export_onnx_streaming.py:111-190 writes them:
+    its own VitsEncoder / VitsDecoder wrapper modules, dummy inputs, names, dynamic axes and opset are used
+    (imported from the reference; only the checkpoint loader, which needs pytorch_lightning, is stubbed)."""
+    import argparse
+    import types
+    from pathlib import Path
+    cfg, m = build_model(preset, seed)
+    name = "piper_train.vits.lightning"
+    if name not in sys.modules:
+        stub = types.ModuleType(name)
+        stub.VitsModel = None
+        sys.modules[name] = stub
+    from piper_train import export_onnx_streaming as S
+    os.makedirs(out_dir, exist_ok=True)
+    args = argparse.Namespace(output_dir=Path(out_dir))
+    orig_export = torch.onnx.export
+
+    def legacy_export(*a, **kw):
+        kw.setdefault("dynamo", False)
+        return orig_export(*a, **kw)
+
+    torch.onnx.export = legacy_export
+    try:
+        torch.manual_seed(1234)                          # export_onnx_streaming.py:73
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            dec_in = S.export_encoder(args, m)
+            S.export_decoder(args, m, dec_in)
+    finally:
+        torch.onnx.export = orig_export
+    write_config(cfg, preset, seed, os.path.join(out_dir, "config.json"))
+    for f in ("encoder.onnx", "decoder.onnx"):
+        print(f"{out_dir}/{f}: {os.path.getsize(os.path.join(out_dir, f))} bytes")
+
+
+def export(preset: str, out_prefix: str, seed: int = 1234):
+    cfg, m = build_model(preset, seed)
 
     def infer_forward(text, text_lengths, scales, sid=None):            # export_onnx.py:56-69
         return m.infer(text, text_lengths, noise_scale=scales[0], length_scale=scales[1],
                        noise_scale_w=scales[2], sid=sid)[0].unsqueeze(1)
 
     m.forward = infer_forward
-    # the legacy exporter's onnxscript post-pass needs the `onnx` package (absent here); it is a no-op
-    # for graphs made of stock ops (SURVEY.md section 8c)
-    import torch.onnx._internal.torchscript_exporter.onnx_proto_utils as opu
-    opu._add_onnxscript_fn = lambda model_bytes, custom_opsets: model_bytes
     torch.manual_seed(1234)
     seq = torch.randint(low=0, high=cfg.n_vocab, size=(1, 50), dtype=torch.long)
     lens = torch.LongTensor([50])
@@ -70,21 +129,12 @@ def export(preset: str, out_prefix: str, seed: int = 1234):
                           dynamic_axes={"input": {0: "batch_size", 1: "phonemes"},
                                         "input_lengths": {0: "batch_size"},
                                         "output": {0: "batch_size", 1: "time"}})
-    # voice config with the schema of etc/test_voice.onnx.json; a `text` voice over printable ASCII
-    pool = " abcdefghijklmnopqrstuvwxyz.,!?'-;:" + "".join(chr(c) for c in range(48, 91))
-    chars = list(dict.fromkeys(pool))[: cfg.n_vocab - 3]
-    id_map = {"_": [0], "^": [1], "$": [2]}
-    id_map.update({ch: [3 + i] for i, ch in enumerate(chars)})
-    conf = {"audio": {"sample_rate": cfg.sample_rate}, "espeak": {"voice": "en-us"}, "phoneme_type": "text",
-            "inference": {"noise_scale": 0.667, "length_scale": 1, "noise_w": 0.8},
-            "phoneme_map": {}, "phoneme_id_map": id_map, "num_symbols": cfg.n_vocab,
-            "num_speakers": cfg.n_speakers,
-            "speaker_id_map": {f"spk{i}": i for i in range(cfg.n_speakers)} if cfg.n_speakers > 1 else {},
-            "synthetic": {"preset": preset, "weight_seed": seed}}
-    with open(out_prefix + ".onnx.json", "w", encoding="utf-8") as f:
-        json.dump(conf, f, indent=1)
+    write_config(cfg, preset, seed, out_prefix + ".onnx.json")
     print(f"{out_prefix}.onnx: {os.path.getsize(out_prefix + '.onnx')} bytes")
 
 
 if __name__ == "__main__":
-    export(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 1234)
+    if sys.argv[1] == "--streaming":     # python oracle/make_voice.py --streaming tiny tests/golden/tiny_stream
+        export_streaming(sys.argv[2], sys.argv[3], int(sys.argv[4]) if len(sys.argv) > 4 else 1234)
+    else:
+        export(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 1234)

@@ -170,7 +170,9 @@ static ONode parse_node(Span s, Graph& g) {
   return n;
 }
 
-static Graph parse_model(Span file) {
+// Appends the graph of one model file to `g`. A non-empty `prefix` renames every value and initialiser of this
+// file (two separately exported graphs reuse the exporter's anonymous names).
+static void parse_into(Graph& g, Span file, const std::string& prefix) {
   Span graph{nullptr, 0};
   {
     Reader r(file);
@@ -183,26 +185,52 @@ static Graph parse_model(Span file) {
     }
   }
   if (!graph.p) throw std::runtime_error("onnx: no graph in model file");
-  Graph g;
+  const size_t n0 = g.nodes.size(), t0 = g.tensors.size();
   Reader r(graph);
   int wt;
   uint64_t v;
   Span x;
   while (r.more()) {
     int f = r.next(wt, v, x);
-    if (f == 1 && wt == 2) g.nodes.push_back(parse_node(x, g));
-    else if (f == 5 && wt == 2) {
+    if (f == 1 && wt == 2) {
+      ONode n = parse_node(x, g);       // may append Constant tensors to g.tensors
+      g.nodes.push_back(std::move(n));
+    } else if (f == 5 && wt == 2) {
       g.tensors.push_back(parse_tensor(x));
-      g.tensor_by_name[g.tensors.back().name] = (int)g.tensors.size() - 1;
     }
   }
+  if (!prefix.empty()) {
+    for (size_t i = t0; i < g.tensors.size(); ++i)
+      if (!g.tensors[i].name.empty()) g.tensors[i].name = prefix + g.tensors[i].name;
+    for (size_t i = n0; i < g.nodes.size(); ++i) {
+      for (auto& s : g.nodes[i].in) if (!s.empty()) s = prefix + s;
+      for (auto& s : g.nodes[i].out) if (!s.empty()) s = prefix + s;
+    }
+  }
+}
+
+static void index_graph(Graph& g) {
+  g.tensor_by_name.clear(); g.producer.clear(); g.consumers.clear();
+  std::set<int> const_attr;
+  for (auto& n : g.nodes) if (n.tensor_attr >= 0) const_attr.insert(n.tensor_attr);
+  for (size_t i = 0; i < g.tensors.size(); ++i)
+    if (!const_attr.count((int)i)) g.tensor_by_name[g.tensors[i].name] = (int)i;     // initialisers
   for (size_t i = 0; i < g.nodes.size(); ++i) {
     ONode& n = g.nodes[i];
     if (n.op == "Constant" && n.tensor_attr >= 0 && !n.out.empty()) g.tensor_by_name[n.out[0]] = n.tensor_attr;
     for (auto& o : n.out) g.producer[o] = (int)i;
     for (auto& in : n.in) g.consumers.insert({in, (int)i});
   }
-  return g;
+}
+
+static std::vector<uint8_t> read_file(const std::string& path) {
+  std::ifstream f(path, std::ios::binary | std::ios::ate);
+  if (!f) throw std::runtime_error("cannot open voice model " + path);
+  const std::streamsize sz = f.tellg();
+  f.seekg(0);
+  std::vector<uint8_t> buf((size_t)sz);
+  if (sz > 0 && !f.read((char*)buf.data(), sz)) throw std::runtime_error("cannot read voice model " + path);
+  return buf;
 }
 
 struct ConvRec {
@@ -225,14 +253,38 @@ static int64_t attr1(const ONode& n, const char* name, int64_t def) {
 
 }  // namespace
 
+// `path` is a voice .onnx (export_onnx.py) or the output of the reference's streaming export
+// (export_onnx_streaming.py:111-190): a directory holding encoder.onnx + decoder.onnx, or the path of either
+// file. The two streaming graphs are the same infer() graph cut after the prior sample (encoder: enc_p, emb_g,
+// dp, path expansion; decoder: flow, dec), so appending the decoder's nodes to the encoder's reproduces the
+// execution order the structural recovery below walks.
 WeightSet load_onnx(const std::string& path) {
-  std::ifstream f(path, std::ios::binary | std::ios::ate);
-  if (!f) throw std::runtime_error("cannot open voice model " + path);
-  const std::streamsize sz = f.tellg();
-  f.seekg(0);
-  std::vector<uint8_t> buf((size_t)sz);
-  if (sz > 0 && !f.read((char*)buf.data(), sz)) throw std::runtime_error("cannot read voice model " + path);
-  Graph g = parse_model(Span{buf.data(), buf.size()});
+  std::string enc_path, dec_path;
+  {
+    auto ends_with = [](const std::string& s, const std::string& e) {
+      return s.size() >= e.size() && s.compare(s.size() - e.size(), e.size(), e) == 0;
+    };
+    std::string dir;
+    if (ends_with(path, "/encoder.onnx") || ends_with(path, "/decoder.onnx")) dir = path.substr(0, path.size() - 13);
+    else if (path == "encoder.onnx" || path == "decoder.onnx") dir = ".";
+    else if (!ends_with(path, ".onnx")) {
+      std::ifstream probe(path + "/encoder.onnx", std::ios::binary);
+      if (probe) dir = path;
+    }
+    if (!dir.empty()) { enc_path = dir + "/encoder.onnx"; dec_path = dir + "/decoder.onnx"; }
+  }
+  std::vector<uint8_t> buf, buf2;
+  Graph g;
+  if (enc_path.empty()) {
+    buf = read_file(path);
+    parse_into(g, Span{buf.data(), buf.size()}, "");
+  } else {
+    buf = read_file(enc_path);
+    buf2 = read_file(dec_path);
+    parse_into(g, Span{buf.data(), buf.size()}, "");
+    parse_into(g, Span{buf2.data(), buf2.size()}, "decoder::");
+  }
+  index_graph(g);
 
   // ---- Conv / ConvTranspose nodes in graph order
   std::vector<ConvRec> convs;

@@ -60,6 +60,24 @@ def test_onnx_loader_recovers_canonical_weights(lib, stem, preset):
         assert np.max(np.abs(w2[k] - w[k])) <= 1e-6, k      # weight_norm fold g*v/|v| rounding only
 
 
+@pytest.mark.parametrize("stem,preset", [("tiny_stream", "tiny"), ("tinyhms_stream", "tiny-high-ms")])
+def test_onnx_loader_reads_streaming_export(lib, stem, preset):
+    """encoder.onnx + decoder.onnx written by the reference's export_onnx_streaming.py (fixtures made by
+    oracle/make_voice.py --streaming through the reference's own VitsEncoder / VitsDecoder wrappers) load as one
+    voice: by directory or by either file's path."""
+    cfg = W.preset(preset)
+    w = W.synthetic_weights(cfg, 1234)
+    d = os.path.join(GOLD, stem)
+    for path in (d, os.path.join(d, "encoder.onnx"), os.path.join(d, "decoder.onnx")):
+        blob, n = C.c_void_p(), C.c_size_t()
+        assert lib.pe_onnx_to_blob(path.encode(), C.byref(blob), C.byref(n)) == 0, lib.pe_last_error()
+        arch, tensors = W.unpack_blob(C.string_at(blob, n.value))
+        lib.pe_free(blob)
+        assert set(tensors) == set(w)
+        for k, v in w.items():
+            assert tensors[k].shape == v.shape and np.max(np.abs(tensors[k] - v)) < 1e-6, k
+
+
 def test_onnx_loader_errors(lib, tmp_path):
     with pytest.raises(RuntimeError, match="cannot open"):
         _onnx_to_blob(lib, str(tmp_path / "missing.onnx"))
