@@ -290,7 +290,8 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
     const HostTensor& pw = ws.get("dec.conv_post.weight");
     post_w_ = dev_copy(pw.data);
     post_cin_ = (int)pw.dims[1];
-    if ((int)pw.dims[0] != 1 || post_cin_ != ch) throw std::runtime_error("dec.conv_post shape mismatch");
+    if ((int)pw.dims[0] != 1 || post_cin_ != ch || (int)pw.dims[2] != POST_K)
+      throw std::runtime_error("dec.conv_post shape mismatch");
   }
 
   // ---- speaker conditioning
@@ -1155,9 +1156,8 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
     prof_begin();
     PE_HIP(hipMemsetAsync(absmax_, 0, B * sizeof(unsigned), stream_));
     const int K = 7, Lmax = Fmax * hop_;
-    const size_t smem = ((size_t)post_cin_ * K + (size_t)post_cin_ * (256 + K - 1)) * sizeof(float);
-    PE_LAUNCH(conv_post_kernel, dim3((Lmax + 255) / 256, B), dim3(256), smem, stream_, cur.p, cur.bs, cur.cs, post_w_,
-              post_cin_, K, 0.01f, lens, hop_, audio_, Ss_, absmax_);
+    PE_LAUNCH(conv_post_kernel, dim3((Lmax + 256 * POST_OPT - 1) / (256 * POST_OPT), B), dim3(256), 0, stream_, cur.p,
+              cur.bs, cur.cs, post_w_, post_cin_, 0.01f, lens, hop_, audio_, Ss_, absmax_);
     PE_LAUNCH(pcm16_kernel, dim3((Lmax + 255) / 256, B), dim3(256), 0, stream_, audio_, Ss_, absmax_, lens, hop_,
               pcm_, Ss_);
     prof_end(4, 2.0 * fsum * hop_ * post_cin_ * K);

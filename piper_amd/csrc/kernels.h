@@ -1158,51 +1158,55 @@ __global__ void regulate_kernel(RegP p) {
 // ------------------------------------------------------------------------------------------------
 // Generator tail (models.py:364-366): leaky_relu(0.01) -> conv_post (k=7, no bias, 1 output channel)
 // -> tanh, fused with the per-utterance max|x| that the int16 conversion needs (piper.cpp:410-418).
-__global__ __launch_bounds__(256) void conv_post_kernel(const float* x, long x_bs, int x_cs, const float* w,
-                                                        int Cin, int K, float slope, const int* lens,
+// HBM-bound (4*Cin bytes in, 4 out per sample): a thread owns POST_OPT consecutive samples and, per input
+// channel, reads its POST_OPT+6 inputs through a row descriptor (zero padding = range check; neighbouring
+// threads' overlap is served by L1) four channels at a time; the weights are wave-uniform and stay in
+// scalar registers. No LDS, no barrier.
+static constexpr int POST_K = 7, POST_OPT = 4, POST_CU = 4;
+__global__ __launch_bounds__(256) void conv_post_kernel(const float* x, long x_bs, int x_cs, const float* __restrict__ w,
+                                                        int Cin, float slope, const int* lens,
                                                         int len_mul, float* audio, long a_bs,
                                                         unsigned* absmax) {
-  PE_DYN_SMEM(float, sm);                    // w[Cin*K] then tile[Cin][256+K-1]
+  constexpr int NIN = POST_OPT + POST_K - 1;
   const int b = blockIdx.y, L = lens[b] * len_mul;
-  const int t0 = blockIdx.x * 256;
-  if (t0 >= L) return;
-  float* ws = sm;
-  float* tile = sm + Cin * K;
-  const int W = 256 + K - 1, pad = (K - 1) / 2, tid = threadIdx.x;
-  for (int e = tid; e < Cin * K; e += 256) ws[e] = w[e];
-  {
-    // rows handled 8 at a time so 8 (x2 with the halo column) independent loads are in flight per thread
-    const float* xb = x + (long)b * x_bs;
-    for (int c0 = 0; c0 < Cin; c0 += 8) {
-      float v0[8], v1[8];
-      const int ta = t0 + tid - pad, tb = ta + 256;
+  const int t0 = (blockIdx.x * 256 + threadIdx.x) * POST_OPT;
+  if (blockIdx.x * 256 * POST_OPT >= L) return;
+  const float* xb = x + (long)b * x_bs;
+  float acc[POST_OPT];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const bool cok = c0 + k < Cin;
-        v0[k] = (cok && ta >= 0 && ta < L) ? xb[(long)(c0 + k) * x_cs + ta] : 0.f;
-        v1[k] = (cok && tid + 256 < W && tb >= 0 && tb < L) ? xb[(long)(c0 + k) * x_cs + tb] : 0.f;
+  for (int o = 0; o < POST_OPT; ++o) acc[o] = 0.f;
+  for (int c0 = 0; c0 < Cin; c0 += POST_CU) {
+    float v[POST_CU][NIN];
+#pragma unroll
+    for (int cc = 0; cc < POST_CU; ++cc) {
+      const pe_rowsrc row = pe_make_row(xb + (long)(c0 + cc) * x_cs, c0 + cc < Cin ? L : 0);
+#pragma unroll
+      for (int j = 0; j < NIN; ++j) v[cc][j] = pe_row_load(row, t0 - (POST_K - 1) / 2 + j);
+    }
+#pragma unroll
+    for (int cc = 0; cc < POST_CU; ++cc) {
+      const float* wc = w + (c0 + cc < Cin ? c0 + cc : 0) * POST_K;     // wave-uniform
+#pragma unroll
+      for (int j = 0; j < NIN; ++j) v[cc][j] = pe_lrelu(v[cc][j], slope);
+#pragma unroll
+      for (int k = 0; k < POST_K; ++k) {
+        const float wk = wc[k];
+#pragma unroll
+        for (int o = 0; o < POST_OPT; ++o) acc[o] = fmaf(wk, v[cc][o + k], acc[o]);   // channel-major, tap-minor
       }
-#pragma unroll
-      for (int k = 0; k < 8; ++k)
-        if (c0 + k < Cin) {
-          tile[(c0 + k) * W + tid] = v0[k] > 0.f ? v0[k] : v0[k] * slope;
-          if (tid + 256 < W) tile[(c0 + k) * W + tid + 256] = v1[k] > 0.f ? v1[k] : v1[k] * slope;
-        }
     }
   }
-  __syncthreads();
-  const int t = t0 + tid;
-  float v = 0.f;
-  if (t < L) {
-    float s = 0.f;
-    for (int c = 0; c < Cin; ++c)
-      for (int k = 0; k < K; ++k) s = fmaf(ws[c * K + k], tile[c * W + tid + k], s);
-    v = tanhf(s);
-    audio[(long)b * a_bs + t] = v;
+  float m = 0.f;
+#pragma unroll
+  for (int o = 0; o < POST_OPT; ++o) {
+    const float y = tanhf(acc[o]);
+    if (t0 + o < L) {
+      audio[(long)b * a_bs + t0 + o] = y;
+      m = fmaxf(m, fabsf(y));
+    }
   }
-  float m = fabsf(v);
   for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((tid & 63) == 0) atomicMax(absmax + b, __float_as_uint(m));
+  if ((threadIdx.x & 63) == 0) atomicMax(absmax + b, __float_as_uint(m));
 }
 
 // float -> int16 exactly as piper.cpp:420-431 (scale 32767/max(0.01,peak), clamp, truncate)

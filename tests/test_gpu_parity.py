@@ -289,3 +289,22 @@ def test_optional_fused_mrf_stage_kernel_matches(monkeypatch, preset, T):
     o = O.synthesize(w, cfg, ids[0], scales, nw[0], nz[0])
     assert np.max(np.abs(fused.audio[0] - o["audio"])) < TIGHT_AUDIO_TOL
     assert pcm_rms(fused.pcm[0], O.audio_float_to_int16(o["audio"])) <= RMS_TOL
+
+
+def test_streaming_export_directory_is_the_same_voice():
+    """encoder.onnx + decoder.onnx (reference export_onnx_streaming.py) loaded as a directory give the waveform
+    of the single-file export of the same weights, also through the chunked streaming API."""
+    from piper_amd.engine import Engine
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    cfg = W.preset("tiny-high-ms")
+    ids = W.synthetic_phoneme_ids(14, 2, id_max=cfg.n_vocab - 1)
+    nw, nz = noise_for(cfg, 14, seed=5)
+    one = Engine(onnx_path=os.path.join(gold, "tinyhms_voice.onnx"), device=0)
+    two = Engine(onnx_path=os.path.join(gold, "tinyhms_stream"), device=0)
+    a = one.synthesize(ids, (0.5, 1.1, 0.7), sid=2, noise_w=nw, noise_z=nz)
+    b = two.synthesize(ids, (0.5, 1.1, 0.7), sid=2, noise_w=nw, noise_z=nz)
+    assert np.array_equal(a.audio[0], b.audio[0]) and np.array_equal(a.pcm[0], b.pcm[0])
+    chunks = [c[0] for c in two.stream(ids, (0.5, 1.1, 0.7), sid=2, noise_w=nw, noise_z=nz, chunk_frames=9)]
+    assert np.max(np.abs(np.concatenate(chunks) - a.audio[0])) < 1e-6
+    one.close()
+    two.close()
