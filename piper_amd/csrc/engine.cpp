@@ -174,6 +174,7 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
   if (H_ <= 0 || C_ <= 0 || nh_ <= 0 || H_ % nh_ || (C_ & 1)) throw std::runtime_error("bad architecture header");
   dk_ = H_ / nh_;
   if (dk_ > 128 || (dk_ & 1)) throw std::runtime_error("head dimension must be even and <= 128");
+  if ((2 * window_ + 1) * dk_ > 1280) throw std::runtime_error("relative-attention window too wide (window * head dim)");
   if (H_ % 32 || H_ > 256) throw std::runtime_error("hidden_channels must be a multiple of 32 and <= 256");
   if (ksz_ > 3 || !(ksz_ & 1)) throw std::runtime_error("kernel_size must be 1 or 3");
   hop_ = 1;
@@ -915,7 +916,8 @@ void Engine::issue_stage_a() {
     ap.SP = rup(T, 64) + 1;
     ap.qscale = 1.0f / std::sqrt((float)dk_);
     const int VS = dk_ + 1 + (dk_ & 1);
-    const size_t smem = ((size_t)ATT_QB * ap.SP + (size_t)ATT_KCH * VS + (size_t)dk_ * ATT_QB) * sizeof(float);
+    const size_t smem = ((size_t)ATT_QB * ap.SP + (size_t)ATT_KCH * VS + (size_t)dk_ * ATT_QB +
+                         (size_t)2 * (2 * window_ + 1) * dk_) * sizeof(float);
     if (smem > 160 * 1024) throw std::runtime_error("utterance too long for the attention score tile");
     double afl = 0;
     for (int b = 0; b < B; ++b) afl += 4.0 * (double)tlens_h_[b] * tlens_h_[b] * H_;

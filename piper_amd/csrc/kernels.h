@@ -611,6 +611,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
   float* S = sm;                                      // [32][SP]
   float* Vt = S + ATT_QB * SP;                        // [KCH][VS]
   float* Qs = Vt + ATT_KCH * VS;                      // [dk][32], scaled by 1/sqrt(dk)
+  const int nrel = 2 * p.window + 1;
+  float* RK = Qs + dk * ATT_QB;                       // [nrel][dk] relative-key embeddings
+  float* RV = RK + nrel * dk;                         // [nrel][dk] relative-value embeddings
   const float* qb = p.qkv + (long)b * p.q_bs + (long)(h * dk) * p.q_cs;
   const float* kb = qb + (long)p.H * p.q_cs;
   const float* vb = kb + (long)p.H * p.q_cs;
@@ -629,10 +632,24 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
       const int e = tid + 256 * u, d = e >> 5, i = e & 31;
       qv[u] = pe_row_load(qd, (d < dk && i0 + i < T) ? d * p.q_cs + i0 + i : -1);
     }
+    // the two small relative-position tables ride along: the band loops below then never touch global memory
+    constexpr int NR = 5;                              // (2*4+1) * 128 / 256 rounded up
+    const pe_rowsrc rkd = pe_make_row(p.relk, nrel * dk), rvd = pe_make_row(p.relv, nrel * dk);
+    float rk[NR], rv[NR];
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+      rk[u] = pe_row_load(rkd, tid + 256 * u);
+      rv[u] = pe_row_load(rvd, tid + 256 * u);
+    }
 #pragma unroll
     for (int u = 0; u < NQ; ++u) {
       const int e = tid + 256 * u;
       if (e < dk * ATT_QB) Qs[e] = qv[u] * p.qscale;
+    }
+#pragma unroll
+    for (int u = 0; u < NR; ++u) {
+      const int e = tid + 256 * u;
+      if (e < nrel * dk) { RK[e] = rk[u]; RV[e] = rv[u]; }
     }
   }
   __syncthreads();
@@ -658,16 +675,39 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
   }
   __syncthreads();
   // ---- 2a. relative-key band: S[i][i+r-w] += (q_i/sqrt(dk)) . rel_k[r]
-  const int nrel = 2 * p.window + 1;
   for (int e = tid; e < ATT_QB * nrel; e += 256) {
     const int i = e % ATT_QB, r = e / ATT_QB;
     const int j = i0 + i + r - p.window;
     if (i0 + i < T && j >= 0 && j < T) {
       float s = 0.f;
-      for (int d = 0; d < dk; ++d) s = fmaf(Qs[d * ATT_QB + i], p.relk[r * dk + d], s);
+      for (int d = 0; d < dk; ++d) s = fmaf(Qs[d * ATT_QB + i], RK[r * dk + d], s);
       S[i * SP + j] += s;
     }
   }
+  // the first V chunk travels while the softmax runs (thread -> key jj = tid&63, channel group tid>>6)
+  float vv[ATT_MAXDK / 32][8];
+  auto load_v = [&](int j0) {
+    const int jj = tid & 63;
+    const bool jok = j0 + jj < T;
+#pragma unroll
+    for (int g = 0; g < ATT_MAXDK / 32; ++g)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int d = (tid >> 6) * 8 + 32 * g + u;
+        vv[g][u] = pe_row_load(vd, (jok && d < dk) ? d * p.q_cs + j0 + jj : -1);
+      }
+  };
+  auto store_v = [&]() {
+    const int jj = tid & 63;
+#pragma unroll
+    for (int g = 0; g < ATT_MAXDK / 32; ++g)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int d = (tid >> 6) * 8 + 32 * g + u;
+        if (d < dk) Vt[jj * VS + d] = vv[g][u];
+      }
+  };
+  load_v(0);
   __syncthreads();
   // ---- 2b. softmax over valid keys: row = tid/8, 8 adjacent lanes per row
   {
@@ -696,26 +736,10 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
     for (int r = 0; r < 16; ++r) oacc[r] = 0.f;
     for (int j0 = 0; j0 < T; j0 += ATT_KCH) {
       __syncthreads();                                // previous chunk consumed / softmax finished
-      {
-        // thread -> (key jj = tid&63, channel group tid>>6): 8 independent row loads per pass
-        const int jj = tid & 63;
-        const bool jok = j0 + jj < T;
-        float vv[ATT_MAXDK / 32][8];                   // 32 loads in flight per thread
-#pragma unroll
-        for (int g = 0; g < ATT_MAXDK / 32; ++g)
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int d = (tid >> 6) * 8 + 32 * g + u;
-            vv[g][u] = pe_row_load(vd, (jok && d < dk) ? d * p.q_cs + j0 + jj : -1);
-          }
-#pragma unroll
-        for (int g = 0; g < ATT_MAXDK / 32; ++g)
-#pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int d = (tid >> 6) * 8 + 32 * g + u;
-            if (d < dk) Vt[jj * VS + d] = vv[g][u];
-          }
-      }
+      store_v();
+      // next chunk (of this pass, or the first one of the next channel pass) in flight under the MFMAs
+      if (j0 + ATT_KCH < T) load_v(j0 + ATT_KCH);
+      else if (dt0 + 4 < ndt) load_v(0);
       __syncthreads();
       if (dt < ndt) {
         const int d = dt * 32 + l31;
@@ -737,7 +761,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
           float acc = oacc[r];
           for (int rr = 0; rr < nrel; ++rr) {         // relative-value band
             const int j = q + rr - p.window;
-            if (j >= 0 && j < T) acc = fmaf(S[l31 * SP + j], p.relv[rr * dk + d], acc);
+            if (j >= 0 && j < T) acc = fmaf(S[l31 * SP + j], RV[rr * dk + d], acc);
           }
           p.out[(long)b * p.o_bs + (long)(h * dk + d) * p.o_cs + q] = acc;
         }
