@@ -152,13 +152,17 @@ def main():
     eng.profile_enable(0)
     kernels = {r["name"]: {"ms_per_step": r["ms"] / nprof, "launches_per_step": r["launches"] / nprof,
                            "avg_launch_us": r["ms"] / r["launches"] * 1e3,
-                           "tflops": (r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0)} for r in krows}
+                           "tflops": (r["flops"] / (r["ms"] * 1e-3) / 1e12 if r["ms"] > 0 else 0.0),
+                           "algorithmic_bytes_per_launch": (r["bytes"] / r["launches"] if r.get("bytes") else None)}
+               for r in krows}
     # the MFMA-bound kernels are the tiled conv GEMM and the fused MRF stage (the HiFiGAN stage north_star
     # prices); conv_splitk_kernel / attention / DDS launches are latency chains and are listed in `kernels`
     convs = [r for r in krows if r["name"].startswith(("conv_mfma_kernel", "mrf_fused_kernel"))] or krows
     dom = max(convs, key=lambda r: r["ms"])
     achieved = kernels[dom["name"]]["tflops"]
     traffic = pmc_traffic(args, B, T, dom["name"])
+    if traffic:
+        traffic["algorithmic_bytes_per_launch"] = kernels[dom["name"]]["algorithmic_bytes_per_launch"]
     if traffic and dom["name"].startswith("mrf_fused_kernel<"):
         # one read of the stage input + one write of the MRF mean, fp32
         cp = int(dom["name"].split("<")[1].split(",")[0])

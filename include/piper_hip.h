@@ -106,6 +106,9 @@ int pe_profile_enable(pe_engine* e, int level);
 int pe_profile_reset(pe_engine* e);
 int pe_profile_rows(pe_engine* e);
 int pe_profile_get(pe_engine* e, int row, const char** name, double* ms, double* flops, int64_t* launches);
+/* level 2 rows of the conv kernels also carry the launches' algorithmic HBM bytes (inputs + outputs + residual
+ * operands + weights once), the denominator for comparing PMC-measured traffic against */
+int pe_profile_bytes(pe_engine* e, int row, double* bytes);
 
 /* The HIP stream (hipStream_t) the engine launches on, for callers that bracket it with their own events. */
 void* pe_stream(pe_engine* e);

@@ -15,7 +15,7 @@ SYMBOLS = [
     "pe_create", "pe_create_from_blob", "pe_onnx_to_blob", "pe_free", "pe_synthesize",
     "pe_synthesize_batch", "pe_upload", "pe_run", "pe_fetch", "pe_stream_begin", "pe_stream_next",
     "pe_get_durations", "pe_get_info",
-    "pe_set_seed", "pe_profile_enable", "pe_profile_reset", "pe_profile_rows", "pe_profile_get",
+    "pe_set_seed", "pe_profile_enable", "pe_profile_reset", "pe_profile_rows", "pe_profile_get", "pe_profile_bytes",
     "pe_stream", "pe_debug_tensor", "pe_last_error", "pe_destroy",
 ]
 
@@ -63,6 +63,7 @@ def bind(path: str) -> C.CDLL:
     lib.pe_profile_rows.argtypes = [vp]
     lib.pe_profile_get.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double),
                                    C.POINTER(C.c_double), i64p]
+    lib.pe_profile_bytes.argtypes = [vp, C.c_int, C.POINTER(C.c_double)]
     lib.pe_stream.argtypes = [vp]
     lib.pe_stream.restype = vp
     lib.pe_debug_tensor.argtypes = [vp, C.c_char_p, C.c_int32, f32p, C.c_int64, i32p, i32p]

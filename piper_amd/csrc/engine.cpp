@@ -528,13 +528,20 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
 
   const int ncols = (epi == EPI_CONVT) ? Lmax + 1 : Lmax;
   int cfg = pc.cfg;
-  double kflops = 0;
+  double kflops = 0, kbytes = 0;
   if (prof_level_ >= 2) {
     // algorithmic FLOPs of this launch: 2 * MACs per output column * valid columns over the batch
     const std::vector<int32_t>& lh = (lens == d_tlens_) ? tlens_h_ : frames_h_;
     double cols = 0;
     for (int b = 0; b < B_; ++b) cols += (double)lh[b] * len_mul;
     kflops = 2.0 * pc.macs_per_col * cols;
+    // algorithmic bytes: every input channel and every output row once per column, residual / read-modify-write
+    // operands once more each, the weights once per launch
+    const bool rd_res = epi == EPI_RESADD || epi == EPI_ACCUM;
+    const bool rd_old = epi == EPI_SUBFROM || epi == EPI_WNRS || (epi == EPI_ACCUM && (mode == 1 || mode == 2));
+    const double out_rows = epi == EPI_GATE ? pc.split : pc.rows;
+    kbytes = 4.0 * (cols * (pc.Cin + out_rows * (1 + (rd_res ? 1 : 0) + (rd_old ? 1 : 0))) +
+                    (double)pc.rows * pc.Cin * pc.ntaps);
   }
   const long blocks = (long)((ncols + CFG_BN[cfg] - 1) / CFG_BN[cfg]) * (pc.mtiles * 32 / CFG_BM[cfg]) * B_;
   if (blocks < splitk_max_blocks_ && p.xhalo <= 32) {
@@ -543,7 +550,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     const int NW = pc.nchunks >= 5 ? 8 : 4;
     dim3 grid((ncols + 31) / 32, pc.mtiles / MT, B_);
     const size_t smem = std::max<size_t>((size_t)NW * KC * 64, (size_t)NW * MT * 16 * 64) * sizeof(float);
-    const int kh = kbegin(prof_level_ >= 2 ? krow("conv_splitk_kernel") : 0, kflops);
+    const int kh = kbegin(prof_level_ >= 2 ? krow("conv_splitk_kernel") : 0, kflops, kbytes);
     if (pc.gate) {
       if (NW == 8) PE_LAUNCH((conv_splitk_kernel<2, true, 8, 3>), grid, dim3(512), smem, ls_, p);
       else PE_LAUNCH((conv_splitk_kernel<2, true, 4, 3>), grid, dim3(256), smem, ls_, p);
@@ -581,7 +588,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
   static const char* knames[] = {"conv_mfma_kernel<2,2,2,2>", "conv_mfma_kernel<1,4,2,1>", "conv_mfma_kernel<1,4,1,1>",
                                  "conv_mfma_kernel<2,2,1,1>", "conv_mfma_kernel<2,2,2,1>", "conv_mfma_kernel<1,4,1,2>",
                                  "conv_mfma_kernel<1,4,2,2>"};
-  const int kh = kbegin(prof_level_ >= 2 ? krow(knames[cfg]) : 0, kflops);
+  const int kh = kbegin(prof_level_ >= 2 ? krow(knames[cfg]) : 0, kflops, kbytes);
 #define PE_CONV_LAUNCH(WM, WN, MT, NT, KS, G)                                                                  \
   do {                                                                                                         \
     if (HALO == 64) PE_LAUNCH((conv_mfma_kernel<WM, WN, MT, NT, KS, G, 64>), grid, dim3(256), smem, ls_, p); \
@@ -760,7 +767,7 @@ int Engine::krow(const char* name) {
   prof_.push_back(ProfileRow{name});
   return (int)prof_.size() - 1;
 }
-int Engine::kbegin(int row, double flops) {
+int Engine::kbegin(int row, double flops, double bytes) {
   if (prof_level_ < 2) return -1;
   hipEvent_t a, b;
   if (ev_pool_.size() >= 2) {
@@ -771,7 +778,7 @@ int Engine::kbegin(int row, double flops) {
     PE_HIP(hipEventCreate(&b));
   }
   PE_HIP(hipEventRecord(a, ls_));
-  kev_.push_back(KEvent{row, flops, a, b});
+  kev_.push_back(KEvent{row, flops, bytes, a, b});
   return (int)kev_.size() - 1;
 }
 void Engine::kend(int h) {
@@ -785,6 +792,7 @@ const std::vector<ProfileRow>& Engine::profile() {
       PE_HIP(hipEventElapsedTime(&ms, k.a, k.b));
       prof_[k.row].ms += ms;
       prof_[k.row].flops += k.flops;
+      prof_[k.row].bytes += k.bytes;
       prof_[k.row].launches += 1;
       ev_pool_.push_back(k.a);
       ev_pool_.push_back(k.b);
@@ -795,7 +803,7 @@ const std::vector<ProfileRow>& Engine::profile() {
 }
 void Engine::reset_profile() {
   profile();
-  for (auto& r : prof_) { r.ms = 0; r.flops = 0; r.launches = 0; }
+  for (auto& r : prof_) { r.ms = 0; r.flops = 0; r.launches = 0; r.bytes = 0; }
 }
 void Engine::prof_begin() {
   if (prof_on_) PE_HIP(hipEventRecord(ev0_, stream_));

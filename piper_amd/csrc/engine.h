@@ -35,6 +35,7 @@ struct ProfileRow {
   double ms = 0;
   double flops = 0;
   long launches = 0;
+  double bytes = 0;         // algorithmic HBM bytes (activations in + out + residual operands + weights), level 2 rows
 };
 
 struct NoiseIn {            // optional injected N(0,1) draws (parity tests); host pointers
@@ -236,10 +237,10 @@ class Engine {
   std::vector<ProfileRow> prof_;
   hipEvent_t ev0_ = nullptr, ev1_ = nullptr;
   // level-2 per-launch timing: event pairs recorded without host syncs, resolved in profile()
-  struct KEvent { int row; double flops; hipEvent_t a, b; };
+  struct KEvent { int row; double flops; double bytes; hipEvent_t a, b; };
   std::vector<KEvent> kev_;
   std::vector<hipEvent_t> ev_pool_;
-  int kbegin(int row, double flops);
+  int kbegin(int row, double flops, double bytes = 0);
   void kend(int h);
   int krow(const char* name);
 };

@@ -220,6 +220,14 @@ int pe_profile_get(pe_engine* e, int row, const char** name, double* ms, double*
   });
 }
 
+int pe_profile_bytes(pe_engine* e, int row, double* bytes) {
+  return guard([&] {
+    const auto& p = e->eng->profile();
+    if (row < 0 || row >= (int)p.size() || !bytes) throw std::runtime_error("profile row out of range");
+    *bytes = p[row].bytes;
+  });
+}
+
 void* pe_stream(pe_engine* e) { return e ? (void*)e->eng->stream() : nullptr; }
 
 int pe_debug_tensor(pe_engine* e, const char* name, int32_t b, float* out, int64_t capacity, int32_t* rows,

@@ -191,7 +191,10 @@ class Engine:
         for i in range(self._lib.pe_profile_rows(self._h)):
             name, ms, fl, n = C.c_char_p(), C.c_double(), C.c_double(), C.c_int64()
             self._check(self._lib.pe_profile_get(self._h, i, C.byref(name), C.byref(ms), C.byref(fl), C.byref(n)))
-            rows.append({"name": name.value.decode(), "ms": ms.value, "flops": fl.value, "launches": n.value})
+            by = C.c_double()
+            self._check(self._lib.pe_profile_bytes(self._h, i, C.byref(by)))
+            rows.append({"name": name.value.decode(), "ms": ms.value, "flops": fl.value, "launches": n.value,
+                         "bytes": by.value})
         return rows
 
     @property
