@@ -174,7 +174,8 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
   if (H_ <= 0 || C_ <= 0 || nh_ <= 0 || H_ % nh_ || (C_ & 1)) throw std::runtime_error("bad architecture header");
   dk_ = H_ / nh_;
   if (dk_ > 128 || (dk_ & 1)) throw std::runtime_error("head dimension must be even and <= 128");
-  if ((2 * window_ + 1) * dk_ > 1280) throw std::runtime_error("relative-attention window too wide (window * head dim)");
+  if ((2 * window_ + 1) * dk_ > 1280 || window_ > 4)
+    throw std::runtime_error("relative-attention window too wide (window <= 4, (2*window+1) * head dim <= 1280)");
   if (H_ % 32 || H_ > 256) throw std::runtime_error("hidden_channels must be a multiple of 32 and <= 256");
   if (ksz_ > 3 || !(ksz_ & 1)) throw std::runtime_error("kernel_size must be 1 or 3");
   hop_ = 1;

@@ -660,14 +660,24 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      for (int s0 = 0; s0 < nk2; s0 += 32) {           // 32 independent K-fragment loads in flight
-        float kf[32];
+      // all K fragments of this key tile are requested at once (<= 64 loads), then each batch of 32 steps reads
+      // its Q operands from LDS in one go and issues its MFMAs back to back
+      constexpr int NKF = ATT_MAXDK / 2;
+      float kf[NKF];
 #pragma unroll
-        for (int u = 0; u < 32; ++u)
-          kf[u] = pe_row_load(kd, (kok && s0 + u < nk2) ? (2 * (s0 + u) + lhi) * p.q_cs + j : -1);
+      for (int u = 0; u < NKF; ++u) kf[u] = pe_row_load(kd, (kok && u < nk2) ? (2 * u + lhi) * p.q_cs + j : -1);
 #pragma unroll
-        for (int u = 0; u < 32; ++u)
-          if (s0 + u < nk2) acc = pe_mfma_32x32x2(Qs[(2 * (s0 + u) + lhi) * ATT_QB + l31], kf[u], acc);
+      for (int s0 = 0; s0 < NKF; s0 += 32) {
+        if (s0 < nk2) {
+          float qf[32];
+#pragma unroll
+          for (int u = 0; u < 32; ++u) qf[u] = (s0 + u < nk2) ? Qs[(2 * (s0 + u) + lhi) * ATT_QB + l31] : 0.f;
+          PE_SCHED_FENCE();
+#pragma unroll
+          for (int u = 0; u < 32; ++u)
+            if (s0 + u < nk2) acc = pe_mfma_32x32x2(qf[u], kf[s0 + u], acc);
+          PE_SCHED_FENCE();
+        }
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) S[((r & 3) + 8 * (r >> 2) + 4 * lhi) * SP + kt * 32 + l31] = acc[r];
@@ -743,26 +753,37 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
       __syncthreads();
       if (dt < ndt) {
         const int d = dt * 32 + l31;
-#pragma unroll 8
+        float af[ATT_KCH / 2], pf[ATT_KCH / 2];
+#pragma unroll
         for (int s2 = 0; s2 < ATT_KCH / 2; ++s2) {
           const int key = 2 * s2 + lhi;
-          const float a = d < dk ? Vt[key * VS + d] : 0.f;
-          const float pb = S[l31 * SP + j0 + key];
-          oacc = pe_mfma_32x32x2(a, pb, oacc);
+          af[s2] = d < dk ? Vt[key * VS + d] : 0.f;
+          pf[s2] = S[l31 * SP + j0 + key];
         }
+        PE_SCHED_FENCE();
+#pragma unroll
+        for (int s2 = 0; s2 < ATT_KCH / 2; ++s2) oacc = pe_mfma_32x32x2(af[s2], pf[s2], oacc);
+        PE_SCHED_FENCE();
       }
     }
     if (dt < ndt) {
       const int q = i0 + l31;
+      // relative-value band: the (at most 2w+1) probabilities of this lane's query are read once
+      constexpr int MAXREL = 9;
+      float pr[MAXREL];
+#pragma unroll
+      for (int rr = 0; rr < MAXREL; ++rr) {
+        const int j = q + rr - p.window;
+        pr[rr] = (rr < nrel && q < T && j >= 0 && j < T) ? S[l31 * SP + j] : 0.f;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
         if (d < dk && q < T) {
           float acc = oacc[r];
-          for (int rr = 0; rr < nrel; ++rr) {         // relative-value band
-            const int j = q + rr - p.window;
-            if (j >= 0 && j < T) acc = fmaf(S[l31 * SP + j], RV[rr * dk + d], acc);
-          }
+#pragma unroll
+          for (int rr = 0; rr < MAXREL; ++rr)
+            if (rr < nrel) acc = fmaf(pr[rr], RV[rr * dk + d], acc);
           p.out[(long)b * p.o_bs + (long)(h * dk + d) * p.o_cs + q] = acc;
         }
       }

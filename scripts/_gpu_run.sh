@@ -1,24 +1,12 @@
-# final round-1 collection: bench lines, rocprof kernel stats of the same commands, PMC traffic passes
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/final
+mkdir -p gpurun_out
 export TMPDIR=/tmp
-O=gpurun_out/final
-python bench.py > $O/bench_b1.json 2> $O/bench_b1.err
-python bench.py --no-cpu-baseline --batch 16 --steps 20 > $O/bench_b16.json 2>> $O/err.log
-python bench.py --no-cpu-baseline --batch 64 --steps 10 > $O/bench_b64.json 2>> $O/err.log
-python bench.py --no-cpu-baseline --preset high --batch 8 --steps 10 > $O/bench_high_b8.json 2>> $O/err.log
-python bench.py --no-cpu-baseline --preset high > $O/bench_high_b1.json 2>> $O/err.log
-python bench.py --no-cpu-baseline --preset high --batch 64 --steps 3 --warmup 1 > $O/bench_high_b64.json 2>> $O/err.log
-python bench.py --stream-latency > $O/stream_medium.json 2>> $O/err.log
-python bench.py --stream-latency --preset high > $O/stream_high.json 2>> $O/err.log
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/st_b1 -- python bench.py --no-cpu-baseline > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/st_b16 -- python bench.py --no-cpu-baseline --batch 16 --steps 20 > /dev/null 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/st_high -- python bench.py --no-cpu-baseline --preset high --batch 8 --steps 10 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch_b1 -- python bench.py --no-cpu-baseline --steps 5 --warmup 1 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write_b1 -- python bench.py --no-cpu-baseline --steps 5 --warmup 1 > /dev/null 2>&1
-SQ="SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_INSTS_VALU_MFMA_MOPS_F32"
-rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/pmc_sq_b16 -- python bench.py --no-cpu-baseline --batch 16 --steps 3 --warmup 1 > /dev/null 2>&1
-rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $O/pmc_sq_h8 -- python bench.py --no-cpu-baseline --preset high --batch 8 --steps 2 --warmup 1 > /dev/null 2>&1
-find $O -name "*kernel_trace.csv" -delete
-PIPER_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29611 bench.py --gpus 2 --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_2rank_gloo_1gpu.json 2>> $O/err.log
-tail -2 $O/err.log
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -8 > gpurun_out/t1.log
+for v in old new old new; do
+  cp scripts/ab/lib_$v.so piper_amd/libpiper_hip.so
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/at_${v} -- python bench.py --no-cpu-baseline > gpurun_out/at_${v}.json 2> gpurun_out/at.err
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/at16_${v} -- python bench.py --no-cpu-baseline --batch 16 --steps 20 > gpurun_out/at16_${v}.json 2> gpurun_out/at.err
+done
+cp scripts/ab/lib_new.so piper_amd/libpiper_hip.so
+find gpurun_out -name "*kernel_trace.csv" -delete
+cat gpurun_out/t1.log
