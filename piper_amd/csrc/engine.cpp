@@ -466,6 +466,9 @@ void Engine::ensure_stage_b(int Fmax) {
     for (auto& st : ups_) { L *= st.rate; hmax = std::max(hmax, (size_t)st.ch * L); }
   }
   Ss_ = (long)F * hop_;
+  // per-utterance activations are addressed with 32-bit byte offsets (buffer descriptors)
+  if (hmax * sizeof(float) >= (size_t)1 << 31 || (size_t)3 * H_ * F * sizeof(float) >= (size_t)1 << 31)
+    throw std::runtime_error("utterance too long: a per-utterance activation would exceed 2 GiB");
   auto carve = [&](char* base) -> size_t {
     Carver c(base);
     zp_ = c.take<float>(Bc * C_ * F);

@@ -73,14 +73,14 @@ __device__ __forceinline__ pe_rowsrc pe_make_row_u(const float* row, int n) {
   return pe_make_row(pe_uniform_ptr(row), __builtin_amdgcn_readfirstlane(n));
 }
 __device__ __forceinline__ float pe_row_load(pe_rowsrc r, int idx) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, idx * 4, 0, 0));
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)((unsigned)idx * 4u), 0, 0));
 }
 // element (vidx + sidx): vidx per lane, sidx wave-uniform -> the uniform part rides in an SGPR, no VALU add
 __device__ __forceinline__ float pe_row_load_so(pe_rowsrc r, int vidx, int sidx) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, vidx * 4, sidx * 4, 0));
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)((unsigned)vidx * 4u), sidx * 4, 0));
 }
 __device__ __forceinline__ void pe_row_store_so(pe_rowsrc r, int vidx, int sidx, float v) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, vidx * 4, sidx * 4, 0);
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)((unsigned)vidx * 4u), sidx * 4, 0);
 }
 // four consecutive floats (16-byte aligned index) in one instruction
 __device__ __forceinline__ f32x4 pe_row_load4(pe_rowsrc r, int idx) {
