@@ -1,12 +1,9 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -8 > gpurun_out/t1.log
-for v in old new old new; do
-  cp scripts/ab/lib_$v.so piper_amd/libpiper_hip.so
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/at_${v} -- python bench.py --no-cpu-baseline > gpurun_out/at_${v}.json 2> gpurun_out/at.err
-  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/at16_${v} -- python bench.py --no-cpu-baseline --batch 16 --steps 20 > gpurun_out/at16_${v}.json 2> gpurun_out/at.err
+for r in 0 1 0 1; do
+  PIPER_HIP_RES_X=$r python bench.py --no-cpu-baseline > gpurun_out/rx${r}_b1.json 2> gpurun_out/f.err
+  PIPER_HIP_RES_X=$r python bench.py --no-cpu-baseline --batch 16 --steps 20 > gpurun_out/rx${r}_b16.json 2>> gpurun_out/f.err
+  PIPER_HIP_RES_X=$r python bench.py --no-cpu-baseline --batch 64 --steps 10 > gpurun_out/rx${r}_b64.json 2>> gpurun_out/f.err
 done
-cp scripts/ab/lib_new.so piper_amd/libpiper_hip.so
-find gpurun_out -name "*kernel_trace.csv" -delete
 cat gpurun_out/t1.log
