@@ -161,6 +161,14 @@ def main():
     dom = max(convs, key=lambda r: r["ms"])
     achieved = kernels[dom["name"]]["tflops"]
     traffic = pmc_traffic(args, B, T, dom["name"])
+    # for transparency: the kernel with the largest share of device time whatever its bound (at B=1 that is the
+    # split-K conv kernel, a latency chain: tiny GEMMs, one 32x32 tile per workgroup)
+    top = max(krows, key=lambda r: r["ms"])
+    ksum = sum(r["ms"] for r in krows)
+    by_time = {"kernel": top["name"], "share_of_profiled_kernel_time": top["ms"] / ksum if ksum else 0.0,
+               "tflops": kernels[top["name"]]["tflops"],
+               "frac_of_mfma_peak": kernels[top["name"]]["tflops"] / FP32_MATRIX_PEAK_TFLOPS,
+               "avg_launch_us": kernels[top["name"]]["avg_launch_us"]}
     if traffic:
         traffic["algorithmic_bytes_per_launch"] = kernels[dom["name"]]["algorithmic_bytes_per_launch"]
     if traffic and dom["name"].startswith("mrf_fused_kernel<"):
@@ -200,6 +208,7 @@ def main():
                          "frac": achieved / FP32_MATRIX_PEAK_TFLOPS, "traffic": traffic,
                          "avg_launch_us": kernels[dom["name"]]["avg_launch_us"],
                          "launches_per_step": kernels[dom["name"]]["launches_per_step"],
+                         "largest_by_time": by_time,
                          "kernels": kernels, "stage_ms": stage_ms, "stage_tflops": stage_tf},
             "host_api_samples_per_s": api_rate,
             "weight_broadcast_s": t_bcast,
