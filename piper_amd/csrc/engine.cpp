@@ -347,7 +347,9 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
     const void* ks2[] = {(const void*)conv_splitk_kernel<2, true, 8, 3>, (const void*)conv_splitk_kernel<2, true, 4, 3>,
                          (const void*)conv_splitk_kernel<1, false, 8, 4>, (const void*)conv_splitk_kernel<1, false, 4, 4>};
     for (const void* k : ks2) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    PE_HIP(hipFuncSetAttribute((const void*)dds_layer_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    PE_HIP(hipFuncSetAttribute((const void*)dds_layer_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    PE_HIP(hipFuncSetAttribute((const void*)dds_layer_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    PE_HIP(hipFuncSetAttribute((const void*)dds_layer_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     PE_HIP(hipFuncSetAttribute((const void*)attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     const void* ks3[] = {(const void*)mrf_fused_kernel<32, 4, 4, 256>, (const void*)mrf_fused_kernel<32, 4, 4, 320>,
                          (const void*)mrf_fused_kernel<32, 4, 4, 384>, (const void*)mrf_fused_kernel<32, 4, 8, 256>,
@@ -754,7 +756,10 @@ void Engine::dds(const DdsW& d, View in, View out, View tmp) {
     p.lens = d_tlens_; p.H = H_;
     const size_t smem = ((size_t)2 * p.nchunks * 32 * 32 + 8 * 32) * sizeof(float);
     const int kh = kbegin(prof_level_ >= 2 ? krow("dds_layer_kernel") : 0, 2.0 * H_ * H_ * 0);
-    PE_LAUNCH(dds_layer_kernel, dim3((Tg_ + 31) / 32, B_), dim3(512), smem, stream_, p);
+    const dim3 grid((Tg_ + 31) / 32, B_);
+    if (p.nchunks * 32 <= 96) PE_LAUNCH(dds_layer_kernel<6>, grid, dim3(512), smem, stream_, p);
+    else if (p.nchunks * 32 <= 192) PE_LAUNCH(dds_layer_kernel<12>, grid, dim3(512), smem, stream_, p);
+    else PE_LAUNCH(dds_layer_kernel<16>, grid, dim3(512), smem, stream_, p);
     kend(kh);
     dil *= ksz_;
     cur = dst;

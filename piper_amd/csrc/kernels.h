@@ -894,8 +894,10 @@ struct DdsP {
   const int* lens;
   int H;
 };
-static constexpr int DDS_NV = 16;           // channels per thread: H <= 16 * 16
+static constexpr int DDS_MAXNV = 16;        // channel slots per thread (16 row groups): H <= 16 * 16
 
+// DDS_NV = channel slots per thread actually instantiated (ceil(Hp / 16)): 6 for H <= 96, 12 for H <= 192, 16 otherwise
+template <int DDS_NV>
 __global__ __launch_bounds__(512) void dds_layer_kernel(DdsP p) {
   PE_DYN_SMEM(float, sm);                   // Y[Hp][32] | Z[Hp][32] | red[8][32]
   const int b = blockIdx.y, L = p.lens[b];
@@ -989,19 +991,26 @@ __global__ __launch_bounds__(512) void dds_layer_kernel(DdsP p) {
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      const float* wt = p.wp + (long)mt * wstride_mt;
+      // weights through a descriptor, prefetched unconditionally (zeros past the last chunk) so the wait
+      // counts stay exact; the 16 activations of a chunk are read from LDS in one batch
+      const pe_rowsrc wsrc = pe_make_row_u(p.wp + (long)mt * wstride_mt, (int)wstride_mt);
       float aA[KC / 2], aB[KC / 2];
-      auto lda = [&](int c, float (&a)[KC / 2]) { load_frags<KC / 2>(wt + (long)c * (KC / 2) * 64, lane, 0, a); };
+      auto lda = [&](int c, float (&a)[KC / 2]) { load_frags<KC / 2>(wsrc, c * (KC / 2) * 64, lane, a); };
       auto mm = [&](int c, const float (&a)[KC / 2]) {
+        float yv[KC / 2];
 #pragma unroll
-        for (int kk = 0; kk < KC / 2; ++kk) acc = pe_mfma_32x32x2(a[kk], Y[(c * KC + 2 * kk + lhi) * 32 + l31], acc);
+        for (int kk = 0; kk < KC / 2; ++kk) yv[kk] = Y[(c * KC + 2 * kk + lhi) * 32 + l31];
+        PE_SCHED_FENCE();
+#pragma unroll
+        for (int kk = 0; kk < KC / 2; ++kk) acc = pe_mfma_32x32x2(a[kk], yv[kk], acc);
+        PE_SCHED_FENCE();
       };
       lda(0, aA);
       for (int c = 0; c < p.nchunks; c += 2) {
-        if (c + 1 < p.nchunks) lda(c + 1, aB);
+        lda(c + 1, aB);
         mm(c, aA);
         if (c + 1 < p.nchunks) {
-          if (c + 2 < p.nchunks) lda(c + 2, aA);
+          lda(c + 2, aA);
           mm(c + 1, aB);
         }
       }

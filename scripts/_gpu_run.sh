@@ -1,7 +1,11 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-for m in 96 200 400 800; do
-  for b in 4 8 16 32; do
-    PIPER_HIP_SPLITK_MAX=$m python bench.py --no-cpu-baseline --batch $b --steps 20 > gpurun_out/skm${m}_b$b.json 2> gpurun_out/f.err
-  done
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -8 > gpurun_out/t1.log
+for v in old new old new; do
+  cp scripts/ab/lib_$v.so piper_amd/libpiper_hip.so
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/dd_${v} -- python bench.py --no-cpu-baseline > gpurun_out/dd_${v}.json 2> gpurun_out/at.err
 done
+cp scripts/ab/lib_new.so piper_amd/libpiper_hip.so
+find gpurun_out -name "*kernel_trace.csv" -delete
+cat gpurun_out/t1.log
