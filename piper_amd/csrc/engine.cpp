@@ -965,10 +965,9 @@ void Engine::issue_stage_a() {
     const long n = (long)B * 2 * Ts;
     PE_LAUNCH(randn_kernel, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, stream_, noise_w_, n, d_rng_, 0);
   }
-  PE_HIP(hipMemcpyAsync(z2_, noise_w_, (size_t)B * 2 * Ts * sizeof(float), hipMemcpyDeviceToDevice, stream_));
   {
     const long n = (long)B * 2 * Ts;
-    PE_LAUNCH(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream_, z2_, n, scales_[2]);
+    PE_LAUNCH(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream_, noise_w_, z2_, n, scales_[2]);
   }
   // Flip is folded into which physical channel is x0 (conditioning) and which is x1 (transformed):
   // logical = physical when an even number of flips has been applied.

@@ -1078,14 +1078,19 @@ __global__ void spline_inverse_kernel(const float* hproj, long h_bs, int h_cs, f
   if (t >= lens[b]) return;
   constexpr int NB = 10;
   constexpr float TB = 5.0f, MINB = 1e-3f, MIND = 1e-3f;
+  // all 3*NB-1 spline parameters of this element are requested together with x (one memory round trip)
+  const float* hp = hproj + (long)b * h_bs + t;
+  float raw[3 * NB - 1];
+#pragma unroll
+  for (int i = 0; i < 3 * NB - 1; ++i) raw[i] = hp[(long)i * h_cs];
   const float x = z1[(long)b * z_bs + t];
   if (!(x >= -TB && x <= TB)) return;            // identity outside the interval
-  const float* hp = hproj + (long)b * h_bs + t;
   float uw[NB], uh[NB], dv[NB + 1];
   float mw = -3.0e38f, mh = -3.0e38f;
+#pragma unroll
   for (int i = 0; i < NB; ++i) {
-    uw[i] = hp[(long)i * h_cs] * inv_sqrt_h;
-    uh[i] = hp[(long)(NB + i) * h_cs] * inv_sqrt_h;
+    uw[i] = raw[i] * inv_sqrt_h;
+    uh[i] = raw[NB + i] * inv_sqrt_h;
     mw = fmaxf(mw, uw[i]);
     mh = fmaxf(mh, uh[i]);
   }
@@ -1097,7 +1102,7 @@ __global__ void spline_inverse_kernel(const float* hproj, long h_bs, int h_cs, f
   // derivatives: min + softplus(u), boundary u = log(exp(1-min)-1) -> derivative exactly ~1
   const float ucst = logf(expf(1.f - MIND) - 1.f);
   for (int i = 0; i <= NB; ++i) {
-    const float u = (i == 0 || i == NB) ? ucst : hp[(long)(2 * NB + i - 1) * h_cs];
+    const float u = (i == 0 || i == NB) ? ucst : raw[2 * NB + i - 1];
     dv[i] = MIND + (u > 20.f ? u : log1pf(expf(u)));
   }
   // cumulative widths / heights scaled to [-TB, TB], end knots pinned
@@ -1550,9 +1555,9 @@ __global__ __launch_bounds__(64 * NW, 2) void mrf_fused_kernel(MrfP p) {
   }
 }
 
-__global__ void scale_kernel(float* x, long n, float s) {
+__global__ void scale_kernel(const float* in, float* out, long n, float s) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) x[i] *= s;
+  if (i < n) out[i] = in[i] * s;
 }
 
 // Speaker conditioning (models.py:692-696 emb_g; :66-68 dp.cond; modules.py:188-199 WN.cond_layer;
