@@ -345,7 +345,8 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
 #undef PE_K2
     for (const void* k : ks) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     const void* ks2[] = {(const void*)conv_splitk_kernel<2, true, 8, 3>, (const void*)conv_splitk_kernel<2, true, 4, 3>,
-                         (const void*)conv_splitk_kernel<1, false, 8, 4>, (const void*)conv_splitk_kernel<1, false, 4, 4>};
+                         (const void*)conv_splitk_kernel<1, false, 8, 4>, (const void*)conv_splitk_kernel<1, false, 4, 4>,
+                         (const void*)conv_splitk_kernel<2, true, 12, 2>, (const void*)conv_splitk_kernel<1, false, 12, 4>};
     for (const void* k : ks2) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     PE_HIP(hipFuncSetAttribute((const void*)dds_layer_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     PE_HIP(hipFuncSetAttribute((const void*)dds_layer_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
@@ -370,6 +371,7 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
   if (const char* t = getenv("PIPER_HIP_PAR_MRF")) par_mrf_ = atoi(t) != 0;
   if (const char* t = getenv("PIPER_HIP_FUSE_MRF")) fuse_mrf_ = atoi(t) != 0;   // A/B knob: 1 = fused MRF stage kernel
   if (const char* t = getenv("PIPER_HIP_SPLITK_MAX")) splitk_max_blocks_ = atol(t);   // tuning knob
+  if (const char* t = getenv("PIPER_HIP_WIDE_SPLITK")) wide_splitk_ = atoi(t);        // 0 off, 1 auto, 2 always (tests)
 }
 
 Engine::~Engine() {
@@ -530,6 +532,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
   p.up_magic = pc.up ? (unsigned)((0x100000000ULL + pc.up - 1) / pc.up) : 0u;
   p.mode = mode; p.alpha = alpha;
   p.tpb = 1;
+  p.tgroups = 1;
   if ((epi == EPI_GATE) != pc.gate) throw std::runtime_error("internal: gate epilogue/packing mismatch");
 
   const int ncols = (epi == EPI_CONVT) ? Lmax + 1 : Lmax;
@@ -553,15 +556,27 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
   if (blocks < splitk_max_blocks_ && p.xhalo <= 32) {
     // few columns (one utterance through encoder / duration predictor / flow): split K across the waves
     const int MT = pc.gate ? 2 : 1;
-    const int NW = pc.nchunks >= 5 ? 8 : 4;
+    // waves per workgroup: 4 / 8 take whole chunks; the WN gate conv (6 chunks x 5 taps, two M tiles per wave)
+    // goes to 12 waves whose two halves split the taps: 15.8 -> 14.2 us per launch at B=1. Measured and not used:
+    // the same 12 waves for conv_pre (6 x 7) and FFN conv_2 (24 chunks) are slower than 8.
+    const int units = pc.nchunks * pc.ntaps;
+    int NW = pc.nchunks >= 5 ? 8 : 4;
+    p.tgroups = 1;
+    if ((wide_splitk_ == 1 && pc.gate && units >= 24 && pc.nchunks <= 6 && pc.ntaps >= 4) ||
+        wide_splitk_ == 2) {          // 2 = always (tests)
+      NW = 12;
+      p.tgroups = pc.nchunks <= 6 ? 2 : 1;
+    }
     dim3 grid((ncols + 31) / 32, pc.mtiles / MT, B_);
     const size_t smem = std::max<size_t>((size_t)NW * KC * 64, (size_t)NW * MT * 16 * 64) * sizeof(float);
     const int kh = kbegin(prof_level_ >= 2 ? krow("conv_splitk_kernel") : 0, kflops, kbytes);
     if (pc.gate) {
-      if (NW == 8) PE_LAUNCH((conv_splitk_kernel<2, true, 8, 3>), grid, dim3(512), smem, ls_, p);
+      if (NW == 12) PE_LAUNCH((conv_splitk_kernel<2, true, 12, 2>), grid, dim3(768), smem, ls_, p);
+      else if (NW == 8) PE_LAUNCH((conv_splitk_kernel<2, true, 8, 3>), grid, dim3(512), smem, ls_, p);
       else PE_LAUNCH((conv_splitk_kernel<2, true, 4, 3>), grid, dim3(256), smem, ls_, p);
     } else {
-      if (NW == 8) PE_LAUNCH((conv_splitk_kernel<1, false, 8, 4>), grid, dim3(512), smem, ls_, p);
+      if (NW == 12) PE_LAUNCH((conv_splitk_kernel<1, false, 12, 4>), grid, dim3(768), smem, ls_, p);
+      else if (NW == 8) PE_LAUNCH((conv_splitk_kernel<1, false, 8, 4>), grid, dim3(512), smem, ls_, p);
       else PE_LAUNCH((conv_splitk_kernel<1, false, 4, 4>), grid, dim3(256), smem, ls_, p);
     }
     kend(kh);

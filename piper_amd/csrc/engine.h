@@ -169,6 +169,7 @@ class Engine {
   // conv GEMM kernel's prefetch/epilogue rework the conv-by-conv schedule is faster at every batch size measured
   // (profiles/r01_mrf_ab.txt), so it is opt-in (PIPER_HIP_FUSE_MRF=1).
   bool fuse_mrf_ = false;
+  int wide_splitk_ = 1;                     // 12-wave split-K workgroups for long-K launches
   long splitk_max_blocks_ = 96;             // launches with fewer tile-kernel workgroups use conv_splitk_kernel
   std::vector<UpStage> ups_;
   float* post_w_ = nullptr;

@@ -58,6 +58,7 @@ struct ConvP {
   int mode;                                     // ACCUM: 0 first,1 middle,2 last,3 only ; WNRS: 1 = first layer
   float alpha;                                  // ACCUM last/only: scale
   int tpb;                                      // conv_mfma_kernel: column tiles walked by one workgroup
+  int tgroups;                                  // conv_splitk_kernel: 1, or 2 = two halves of the waves split the taps
 };
 
 // ---- shared epilogue of the conv GEMM kernels: one accumulator element (row, col) of utterance b.
@@ -453,8 +454,16 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk_kernel(ConvP p) {
   const float slope = p.in_slope;
   const pe_rowsrc wsrc = pe_make_row(p.wp + (long)mtile0 * wstride_mt, MT * wstride_mt);
   float* xw = sm + wv * KC * XW;                  // this wave's slab: 32 channels x 64 columns
-  const int myc = wv < nchunks ? (nchunks - wv + NW - 1) / NW : 0;   // chunks wv, wv+NW, ...
-  const int nsteps = myc * ntaps;
+  // K is dealt to the waves as (chunk lane, tap group): with p.tgroups == 1 wave w takes chunks w, w+NW, ...
+  // and every tap; with 2 groups the waves form two halves that share the chunks and split the taps (a 5-tap
+  // conv with 6 chunks then keeps 12 waves busy with 3 / 2 steps each instead of 6 waves with 5)
+  const int CL = NW / p.tgroups;                  // chunk lanes
+  const int wi = wv % CL, wg = wv / CL;
+  const int tpg = (ntaps + p.tgroups - 1) / p.tgroups;
+  const int tap_lo = wg * tpg, tap_hi = (tap_lo + tpg < ntaps) ? tap_lo + tpg : ntaps;
+  const int mytaps = tap_hi > tap_lo ? tap_hi - tap_lo : 0;
+  const int myc = (wi < nchunks && mytaps > 0) ? (nchunks - wi + CL - 1) / CL : 0;   // chunks wi, wi+CL, ...
+  const int nsteps = myc * mytaps;
 
   float xr[KC];
   auto load_x = [&](int c) {
@@ -475,12 +484,12 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk_kernel(ConvP p) {
   };
   // weight ring: slot d holds the fragments of step (s with s % D == d); the load cursor runs D steps ahead
   float a[D][MT][KH];
-  int lk = 0, ltap = 0;
+  int lk = 0, ltap = tap_lo;
   auto load_ring = [&](float (&dst)[MT][KH]) {
-    const int off = PE_UNIFORM(((wv + NW * lk) * ntaps + ltap) * (KH * 64));
+    const int off = PE_UNIFORM(((wi + CL * lk) * ntaps + ltap) * (KH * 64));
 #pragma unroll
     for (int i = 0; i < MT; ++i) load_frags<KH>(wsrc, off + i * wstride_mt, lane, dst[i]);
-    if (++ltap == ntaps) { ltap = 0; ++lk; }
+    if (++ltap >= tap_hi) { ltap = tap_lo; ++lk; }
   };
   auto mma = [&](int tap, const float (&af)[MT][KH]) {
     const float* xp = xw + lhi * XW + tap * p.dil + l31;
@@ -493,24 +502,24 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk_kernel(ConvP p) {
       for (int i = 0; i < MT; ++i) acc[i] = pe_mfma_32x32x2(af[i][kk], bv[kk], acc[i]);
   };
 
-  load_x(wv);                     // unconditional (zeros for a wave without chunks): keeps the wait counts exact
+  load_x(myc > 0 ? wi : nchunks);   // unconditional (zeros for a wave without work): keeps the wait counts exact
 #pragma unroll
   for (int d = 0; d < D; ++d) load_ring(a[d]);
   PE_SCHED_FENCE();
   {
-    int k = 0, tap = 0;
+    int k = 0, tap = tap_lo;
     for (int s0 = 0; s0 < nsteps; s0 += D) {
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         if (s0 + d < nsteps) {
-          if (tap == 0) {               // new chunk: its slab is in xr
+          if (tap == tap_lo) {          // new chunk: its slab is in xr
             PE_WAVE_SYNC();             // all lanes done reading the previous slab
             store_x();
             PE_WAVE_SYNC();
-            if (k + 1 < myc) load_x(wv + NW * (k + 1));
+            if (k + 1 < myc) load_x(wi + CL * (k + 1));
           }
           mma(tap, a[d]);
-          if (++tap == ntaps) { tap = 0; ++k; }
+          if (++tap >= tap_hi) { tap = tap_lo; ++k; }
         }
         PE_SCHED_FENCE();
         load_ring(a[d]);

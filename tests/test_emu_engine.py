@@ -119,3 +119,23 @@ def test_emulated_fused_mrf_equals_conv_by_conv(emu_lib, monkeypatch, preset):
         assert np.max(np.abs(a - b)) < 2e-6
     o = O.synthesize(w, cfg, ids[0], (0.667, 1.0, 0.8), nw[0], nz[0])
     assert np.max(np.abs(outs[1][0] - o["audio"])) < 1e-4
+
+
+def test_emulated_wide_splitk_matches(emu_lib, monkeypatch):
+    """12-wave split-K workgroups (chunk lanes x tap groups; chosen automatically for long-K launches of the
+    full-size voices) forced on for every small launch of a tiny voice: same waveform as the 4/8-wave form up to
+    the K summation order."""
+    cfg = W.preset("tiny-ms")
+    w = W.synthetic_weights(cfg, 5)
+    ids = [W.synthetic_phoneme_ids(T, i, id_max=cfg.n_vocab - 1) for i, T in enumerate((8, 3))]
+    nw, nz = _noise(cfg, 2, 8, 13)
+    outs = []
+    for mode in ("0", "2"):
+        monkeypatch.setenv("PIPER_HIP_WIDE_SPLITK", mode)
+        eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
+        outs.append(eng.synthesize_batch(ids, (0.5, 1.0, 0.6), sids=[1, 3], noise_w=nw, noise_z=nz).audio)
+        eng.close()
+    for a, b in zip(*outs):
+        assert a.shape == b.shape and np.max(np.abs(a - b)) < 2e-6
+    o = O.synthesize(w, cfg, ids[0], (0.5, 1.0, 0.6), nw[0], nz[0], sid=1)
+    assert np.max(np.abs(outs[1][0] - o["audio"])) < 1e-4
