@@ -949,7 +949,7 @@ void Engine::issue_stage_a() {
     ap.qscale = 1.0f / std::sqrt((float)dk_);
     const int VS = dk_ + 1 + (dk_ & 1);
     const size_t smem = ((size_t)ATT_QB * ap.SP + (size_t)ATT_KCH * VS + (size_t)dk_ * ATT_QB +
-                         (size_t)2 * (2 * window_ + 1) * dk_) * sizeof(float);
+                         (size_t)2 * (2 * window_ + 1) * dk_ + 4 * ATT_QB * 16) * sizeof(float);
     if (smem > 160 * 1024) throw std::runtime_error("utterance too long for the attention score tile");
     double afl = 0;
     for (int b = 0; b < B; ++b) afl += 4.0 * (double)tlens_h_[b] * tlens_h_[b] * H_;

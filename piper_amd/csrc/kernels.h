@@ -633,6 +633,16 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
   // all global reads go through buffer descriptors with index -1 for masked elements (hardware returns 0), so
   // each staging step issues its loads back to back: one memory latency per step instead of one per element
   const pe_rowsrc qd = pe_make_row(qb, dk * p.q_cs), kd = pe_make_row(kb, dk * p.q_cs), vd = pe_make_row(vb, dk * p.q_cs);
+  constexpr int NKF = ATT_MAXDK / 2;
+  float kf[NKF];
+  auto load_k = [&](int kt) {
+    // one per-lane base (channel parity, key) + a wave-uniform 2*u*stride in an SGPR: no VALU per load; rows
+    // beyond dk fall outside the descriptor and read 0
+    const int j = kt * 32 + l31;
+    const int base = (kt < nkt && j < T) ? lhi * p.q_cs + j : 0x3fffffff;
+#pragma unroll
+    for (int u = 0; u < NKF; ++u) kf[u] = pe_row_load_so(kd, base, 2 * u * p.q_cs);
+  };
   {
     constexpr int NQ = ATT_MAXDK * ATT_QB / 256;     // 16 elements per thread at dk = 128
     float qv[NQ];
@@ -664,17 +674,12 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
   __syncthreads();
   {
     for (int kt = wv; kt < nkt; kt += 4) {
-      const int j = kt * 32 + l31;
-      const bool kok = j < T;
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      // all K fragments of this key tile are requested at once (<= 64 loads), then each batch of 32 steps reads
-      // its Q operands from LDS in one go and issues its MFMAs back to back
-      constexpr int NKF = ATT_MAXDK / 2;
-      float kf[NKF];
-#pragma unroll
-      for (int u = 0; u < NKF; ++u) kf[u] = pe_row_load(kd, (kok && u < nk2) ? (2 * u + lhi) * p.q_cs + j : -1);
+      // all K fragments of a key tile are requested at once (<= 64 loads), then each batch of 32 steps reads its
+      // Q operands from LDS in one go and issues its MFMAs back to back
+      load_k(kt);
 #pragma unroll
       for (int s0 = 0; s0 < NKF; s0 += 32) {
         if (s0 < nk2) {
@@ -693,28 +698,39 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
     }
   }
   __syncthreads();
-  // ---- 2a. relative-key band: S[i][i+r-w] += (q_i/sqrt(dk)) . rel_k[r]
-  for (int e = tid; e < ATT_QB * nrel; e += 256) {
-    const int i = e % ATT_QB, r = e / ATT_QB;
-    const int j = i0 + i + r - p.window;
-    if (i0 + i < T && j >= 0 && j < T) {
-      float s = 0.f;
-      for (int d = 0; d < dk; ++d) s = fmaf(Qs[d * ATT_QB + i], RK[r * dk + d], s);
-      S[i * SP + j] += s;
+  // ---- 2a. relative-key band: S[i][i+r-w] += (q_i/sqrt(dk)) . rel_k[r].  R[q][r] = Q . rel_k^T is a 32 x (2w+1)
+  // GEMM over dk: each wave takes a quarter of the channel steps on the MFMA, the four partial tiles meet in LDS
+  // and are scattered onto the band.
+  {
+    float* part = RV + nrel * dk;                      // [4 waves][32 queries][16 offsets]
+    f32x16 racc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) racc[r] = 0.f;
+    for (int s2 = wv; s2 < nk2; s2 += 4) {
+      const int d = 2 * s2 + lhi;
+      racc = pe_mfma_32x32x2(Qs[d * ATT_QB + l31], l31 < nrel ? RK[l31 * dk + d] : 0.f, racc);
+    }
+    if (l31 < 16) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[(wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * 16 + l31] = racc[r];
+    }
+    __syncthreads();
+    for (int e = tid; e < ATT_QB * nrel; e += 256) {
+      const int i = e % ATT_QB, r = e / ATT_QB;
+      const int j = i0 + i + r - p.window;
+      if (i0 + i < T && j >= 0 && j < T)
+        S[i * SP + j] += (part[i * 16 + r] + part[(32 + i) * 16 + r]) + (part[(64 + i) * 16 + r] + part[(96 + i) * 16 + r]);
     }
   }
   // the first V chunk travels while the softmax runs (thread -> key jj = tid&63, channel group tid>>6)
   float vv[ATT_MAXDK / 32][8];
   auto load_v = [&](int j0) {
     const int jj = tid & 63;
-    const bool jok = j0 + jj < T;
+    const int base = (j0 + jj < T) ? (tid >> 6) * 8 * p.q_cs + j0 + jj : 0x3fffffff;   // rows >= dk read 0
 #pragma unroll
     for (int g = 0; g < ATT_MAXDK / 32; ++g)
 #pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int d = (tid >> 6) * 8 + 32 * g + u;
-        vv[g][u] = pe_row_load(vd, (jok && d < dk) ? d * p.q_cs + j0 + jj : -1);
-      }
+      for (int u = 0; u < 8; ++u) vv[g][u] = pe_row_load_so(vd, base, (32 * g + u) * p.q_cs);
   };
   auto store_v = [&]() {
     const int jj = tid & 63;
@@ -728,24 +744,52 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
   };
   load_v(0);
   __syncthreads();
-  // ---- 2b. softmax over valid keys: row = tid/8, 8 adjacent lanes per row
+  // ---- 2b. softmax over valid keys: row = tid/8, 8 adjacent lanes per row (values stay in registers for the
+  // common T <= 128)
   {
     const int i = tid >> 3, sj = tid & 7;
     float* Sr = S + i * SP;
-    float mx = -3.0e38f;
-    for (int j = sj; j < T; j += 8) mx = fmaxf(mx, Sr[j]);
-    for (int m = 4; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m));
-    float sum = 0.f;
-    for (int j = sj; j < T; j += 8) {
-      const float e = expf(Sr[j] - mx);
-      Sr[j] = e;
-      sum += e;
-    }
-    for (int m = 4; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
-    const float inv = 1.f / sum;
     const int Tpad = (T + ATT_KCH - 1) / ATT_KCH * ATT_KCH;
-    for (int j = sj; j < Tpad; j += 8) Sr[j] = (j < T) ? Sr[j] * inv : 0.f;
+    if (T <= 128) {
+      float ev[16];
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int j = sj + 8 * k;
+        ev[k] = j < T ? Sr[j] : -3.0e38f;
+        mx = fmaxf(mx, ev[k]);
+      }
+      for (int m = 4; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m));
+      float sum = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int j = sj + 8 * k;
+        ev[k] = j < T ? expf(ev[k] - mx) : 0.f;
+        sum += ev[k];
+      }
+      for (int m = 4; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
+      const float inv = 1.f / sum;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const int j = sj + 8 * k;
+        if (j < Tpad) Sr[j] = ev[k] * inv;
+      }
+    } else {
+      float mx = -3.0e38f;
+      for (int j = sj; j < T; j += 8) mx = fmaxf(mx, Sr[j]);
+      for (int m = 4; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m));
+      float sum = 0.f;
+      for (int j = sj; j < T; j += 8) {
+        const float e = expf(Sr[j] - mx);
+        Sr[j] = e;
+        sum += e;
+      }
+      for (int m = 4; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
+      const float inv = 1.f / sum;
+      for (int j = sj; j < Tpad; j += 8) Sr[j] = (j < T) ? Sr[j] * inv : 0.f;
+    }
   }
+  __syncthreads();
   // ---- 3. O^T[d][q] = sum_key V[d][key] P[q][key]
   const int ndt = (dk + 31) / 32;
   f32x16 oacc;                                        // this wave's channel tile (wv < ndt), one tile per wave pass
@@ -776,25 +820,23 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
       }
     }
     if (dt < ndt) {
+      // relative-value band as five more k-steps of the same accumulation: key index -> relative offset rr,
+      // A = rel_v[rr][d], B = p[q][q + rr - w] (zero outside the band / the utterance)
       const int q = i0 + l31;
-      // relative-value band: the (at most 2w+1) probabilities of this lane's query are read once
+      const int d0 = dt * 32 + l31;
       constexpr int MAXREL = 9;
-      float pr[MAXREL];
 #pragma unroll
-      for (int rr = 0; rr < MAXREL; ++rr) {
+      for (int s2 = 0; s2 < (MAXREL + 1) / 2; ++s2) {
+        const int rr = 2 * s2 + lhi;
         const int j = q + rr - p.window;
-        pr[rr] = (rr < nrel && q < T && j >= 0 && j < T) ? S[l31 * SP + j] : 0.f;
+        const float av = (rr < nrel && d0 < dk) ? RV[rr * dk + d0] : 0.f;
+        const float bvv = (rr < nrel && q < T && j >= 0 && j < T) ? S[l31 * SP + j] : 0.f;
+        oacc = pe_mfma_32x32x2(av, bvv, oacc);
       }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int d = dt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        if (d < dk && q < T) {
-          float acc = oacc[r];
-#pragma unroll
-          for (int rr = 0; rr < MAXREL; ++rr)
-            if (rr < nrel) acc = fmaf(pr[rr], RV[rr * dk + d], acc);
-          p.out[(long)b * p.o_bs + (long)(h * dk + d) * p.o_cs + q] = acc;
-        }
+        if (d < dk && q < T) p.out[(long)b * p.o_bs + (long)(h * dk + d) * p.o_cs + q] = oacc[r];
       }
     }
   }
