@@ -384,16 +384,77 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk_kernel(ConvP p) {
   constexpr int NS = GATE ? (16 + NW - 1) / NW : (MT * 16 + NW - 1) / NW;    // epilogue slots per wave
   PE_DYN_SMEM(float, sm);                         // NW x [KC][XW] slabs, then NW x [MT*16][64] partial tiles
   const int b = blockIdx.z;
+  // The utterance length lives in device memory (one graph per shape bucket). Nothing below touches it until the
+  // x slab and the first weight fragments are requested, so its latency overlaps theirs instead of preceding them.
   const int L = p.lens[b] * p.len_mul;
-  const int ncols = (p.epi == EPI_CONVT) ? L + 1 : L;
   const int n0 = blockIdx.x * BN;
-  if (n0 >= ncols) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = PE_UNIFORM(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
   const int mtile0 = blockIdx.y * MT;
   const int col = n0 + l31;
   const int ntaps = p.ntaps, nchunks = p.nchunks;
   const int wstride_mt = nchunks * ntaps * KH * 64;
+  const float* xb = p.x + (long)b * p.x_bs;
+  const float slope = p.in_slope;
+  const pe_rowsrc wsrc = pe_make_row(p.wp + (long)mtile0 * wstride_mt, MT * wstride_mt);
+  float* xw = sm + wv * KC * XW;                  // this wave's slab: 32 channels x 64 columns
+  // K is dealt to the waves as (chunk lane, tap group): with p.tgroups == 1 wave w takes chunks w, w+NW, ...
+  // and every tap; with 2 groups the waves form two halves that share the chunks and split the taps (a 5-tap
+  // conv with 6 chunks then keeps 12 waves busy with 3 / 2 steps each instead of 6 waves with 5)
+  const int CL = NW / p.tgroups;                  // chunk lanes
+  const int wi = wv % CL, wg = wv / CL;
+  const int tpg = (ntaps + p.tgroups - 1) / p.tgroups;
+  const int tap_lo = wg * tpg, tap_hi = (tap_lo + tpg < ntaps) ? tap_lo + tpg : ntaps;
+  const int mytaps = tap_hi > tap_lo ? tap_hi - tap_lo : 0;
+  const int myc = (wi < nchunks && mytaps > 0) ? (nchunks - wi + CL - 1) / CL : 0;   // chunks wi, wi+CL, ...
+  const int nsteps = myc * mytaps;
+
+  // x slab: one descriptor over the utterance's [Cin][stride] tensor, a per-lane column offset (poisoned outside
+  // the row) and a wave-uniform row offset -- independent of L; columns >= L are zeroed when the slab is stored
+  float xr[KC];
+  const pe_rowsrc xd = pe_make_row(xb, p.Cin * p.x_cs);
+  const int xcol = n0 - p.padl + lane;
+  const int xoff = (xcol >= 0 && xcol < p.x_cs) ? xcol : 0x3fffffff;
+  auto load_x = [&](int c) {
+#pragma unroll
+    for (int r = 0; r < KC; ++r) xr[r] = pe_row_load_so(xd, xoff, (c * KC + r) * p.x_cs);
+  };
+  auto store_x = [&]() {
+    const bool live = xcol < L;
+#pragma unroll
+    for (int r = 0; r < KC; ++r) {
+      float v = live ? xr[r] : 0.f;
+      v = v > 0.f ? v : v * slope;
+      xw[r * XW + lane] = v;
+    }
+  };
+  // weight ring: slot d holds the fragments of step (s with s % D == d); the load cursor runs D steps ahead
+  float a[D][MT][KH];
+  int lk = 0, ltap = tap_lo;
+  auto load_ring = [&](float (&dst)[MT][KH]) {
+    const int off = PE_UNIFORM(((wi + CL * lk) * ntaps + ltap) * (KH * 64));
+#pragma unroll
+    for (int i = 0; i < MT; ++i) load_frags<KH>(wsrc, off + i * wstride_mt, lane, dst[i]);
+    if (++ltap >= tap_hi) { ltap = tap_lo; ++lk; }
+  };
+  f32x16 acc[MT];
+  auto mma = [&](int tap, const float (&af)[MT][KH]) {
+    const float* xp = xw + lhi * XW + tap * p.dil + l31;
+    float bv[KH];
+#pragma unroll
+    for (int kk = 0; kk < KH; ++kk) bv[kk] = xp[2 * kk * XW];
+#pragma unroll
+    for (int kk = 0; kk < KH; ++kk)
+#pragma unroll
+      for (int i = 0; i < MT; ++i) acc[i] = pe_mfma_32x32x2(af[i][kk], bv[kk], acc[i]);
+  };
+
+  load_x(myc > 0 ? wi : nchunks);   // unconditional (zeros for a wave without work): keeps the wait counts exact
+#pragma unroll
+  for (int d = 0; d < D; ++d) load_ring(a[d]);
+  PE_SCHED_FENCE();
+  const int ncols = (p.epi == EPI_CONVT) ? L + 1 : L;
+  if (n0 >= ncols) return;
   const EpiFlags ef = epi_flags(p);
 
   // ---- epilogue operands of this wave's slots: four independent loads per slot, combined only in the
@@ -443,69 +504,11 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk_kernel(ConvP p) {
     }
   }
 
-  f32x16 acc[MT];
 #pragma unroll
   for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-  const float* xb = p.x + (long)b * p.x_bs;
-  const int tbase = n0 - p.padl + lane;
-  const float slope = p.in_slope;
-  const pe_rowsrc wsrc = pe_make_row(p.wp + (long)mtile0 * wstride_mt, MT * wstride_mt);
-  float* xw = sm + wv * KC * XW;                  // this wave's slab: 32 channels x 64 columns
-  // K is dealt to the waves as (chunk lane, tap group): with p.tgroups == 1 wave w takes chunks w, w+NW, ...
-  // and every tap; with 2 groups the waves form two halves that share the chunks and split the taps (a 5-tap
-  // conv with 6 chunks then keeps 12 waves busy with 3 / 2 steps each instead of 6 waves with 5)
-  const int CL = NW / p.tgroups;                  // chunk lanes
-  const int wi = wv % CL, wg = wv / CL;
-  const int tpg = (ntaps + p.tgroups - 1) / p.tgroups;
-  const int tap_lo = wg * tpg, tap_hi = (tap_lo + tpg < ntaps) ? tap_lo + tpg : ntaps;
-  const int mytaps = tap_hi > tap_lo ? tap_hi - tap_lo : 0;
-  const int myc = (wi < nchunks && mytaps > 0) ? (nchunks - wi + CL - 1) / CL : 0;   // chunks wi, wi+CL, ...
-  const int nsteps = myc * mytaps;
-
-  float xr[KC];
-  auto load_x = [&](int c) {
-#pragma unroll
-    for (int r = 0; r < KC; ++r) {
-      const int ci = c * KC + r;
-      const pe_rowsrc row = pe_make_row(xb + (long)ci * p.x_cs, ci < p.Cin ? L : 0);
-      xr[r] = pe_row_load(row, tbase);
-    }
-  };
-  auto store_x = [&]() {
-#pragma unroll
-    for (int r = 0; r < KC; ++r) {
-      float v = xr[r];
-      v = v > 0.f ? v : v * slope;
-      xw[r * XW + lane] = v;
-    }
-  };
-  // weight ring: slot d holds the fragments of step (s with s % D == d); the load cursor runs D steps ahead
-  float a[D][MT][KH];
-  int lk = 0, ltap = tap_lo;
-  auto load_ring = [&](float (&dst)[MT][KH]) {
-    const int off = PE_UNIFORM(((wi + CL * lk) * ntaps + ltap) * (KH * 64));
-#pragma unroll
-    for (int i = 0; i < MT; ++i) load_frags<KH>(wsrc, off + i * wstride_mt, lane, dst[i]);
-    if (++ltap >= tap_hi) { ltap = tap_lo; ++lk; }
-  };
-  auto mma = [&](int tap, const float (&af)[MT][KH]) {
-    const float* xp = xw + lhi * XW + tap * p.dil + l31;
-    float bv[KH];
-#pragma unroll
-    for (int kk = 0; kk < KH; ++kk) bv[kk] = xp[2 * kk * XW];
-#pragma unroll
-    for (int kk = 0; kk < KH; ++kk)
-#pragma unroll
-      for (int i = 0; i < MT; ++i) acc[i] = pe_mfma_32x32x2(af[i][kk], bv[kk], acc[i]);
-  };
-
-  load_x(myc > 0 ? wi : nchunks);   // unconditional (zeros for a wave without work): keeps the wait counts exact
-#pragma unroll
-  for (int d = 0; d < D; ++d) load_ring(a[d]);
-  PE_SCHED_FENCE();
   {
     int k = 0, tap = tap_lo;
     for (int s0 = 0; s0 < nsteps; s0 += D) {
