@@ -150,6 +150,21 @@ DdsW Engine::load_dds(const WeightSet& ws, const std::string& p) {
     d.dw_b.push_back(dev_tensor(ws, p + ".convs_sep." + s + ".bias"));
     d.c1x1.push_back(pack_conv(ws, p + ".convs_1x1." + s + ".weight", p + ".convs_1x1." + s + ".bias", 1, -1,
                                false, 0, 0));
+    {
+      // the same matrix for dds_layer16_kernel: [16-row tile][q][lane][4], lane -> (row = lane & 15, k = lane >> 4),
+      // float4 element j of group q is k-step s = 4q + j, i.e. input channel 4s + k
+      const HostTensor& w1 = ws.get(p + ".convs_1x1." + s + ".weight");
+      const int Hh = (int)w1.dims[0], Hp = rup(Hh, 32), nq = Hp / 16;
+      std::vector<float> P((size_t)(Hp / 16) * nq * 256, 0.f);
+      for (int mt = 0; mt < Hp / 16; ++mt)
+        for (int q = 0; q < nq; ++q)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int jj = 0; jj < 4; ++jj) {
+              const int row = mt * 16 + (lane & 15), ci = 4 * (4 * q + jj) + (lane >> 4);
+              if (row < Hh && ci < Hh) P[(((size_t)mt * nq + q) * 64 + lane) * 4 + jj] = w1.data[(size_t)row * Hh + ci];
+            }
+      d.w16.push_back(dev_copy(P));
+    }
     d.g1.push_back(dev_tensor(ws, p + ".norms_1." + s + ".gamma"));
     d.b1.push_back(dev_tensor(ws, p + ".norms_1." + s + ".beta"));
     d.g2.push_back(dev_tensor(ws, p + ".norms_2." + s + ".gamma"));
@@ -348,9 +363,6 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
                          (const void*)conv_splitk_kernel<1, false, 8, 4>, (const void*)conv_splitk_kernel<1, false, 4, 4>,
                          (const void*)conv_splitk_kernel<2, true, 12, 2>, (const void*)conv_splitk_kernel<1, false, 12, 4>};
     for (const void* k : ks2) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    PE_HIP(hipFuncSetAttribute((const void*)dds_layer_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    PE_HIP(hipFuncSetAttribute((const void*)dds_layer_kernel<12>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    PE_HIP(hipFuncSetAttribute((const void*)dds_layer_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     PE_HIP(hipFuncSetAttribute((const void*)attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     const void* ks3[] = {(const void*)mrf_fused_kernel<32, 4, 4, 256>, (const void*)mrf_fused_kernel<32, 4, 4, 320>,
                          (const void*)mrf_fused_kernel<32, 4, 4, 384>, (const void*)mrf_fused_kernel<32, 4, 8, 256>,
@@ -752,7 +764,7 @@ void Engine::layer_norm(int mode, View in, View res, View out, const float* g, c
   kend(kh);
 }
 
-// DDSConv.forward (modules.py:117-129): one fused launch per layer (dds_layer_kernel), ping-ponging between
+// DDSConv.forward (modules.py:117-129): one fused launch per layer (dds_layer16_kernel), ping-ponging between
 // `out` and `tmp` so that the last layer lands in `out`; `in` must not alias the first layer's target.
 void Engine::dds(const DdsW& d, View in, View out, View tmp) {
   int dil = 1;
@@ -766,15 +778,16 @@ void Engine::dds(const DdsW& d, View in, View out, View tmp) {
     p.out = dst.p; p.o_bs = dst.bs; p.o_cs = dst.cs;
     p.dw_w = d.dw_w[i]; p.dw_b = d.dw_b[i]; p.dw_k = ksz_; p.dw_dil = dil;
     p.g1 = d.g1[i]; p.b1 = d.b1[i]; p.g2 = d.g2[i]; p.b2 = d.b2[i];
-    p.wp = d.c1x1[i].wp; p.bias = d.c1x1[i].bias;
+    p.bias = d.c1x1[i].bias;
+    p.wp16 = d.w16[i];
     p.nchunks = d.c1x1[i].nchunks;
     p.lens = d_tlens_; p.H = H_;
-    const size_t smem = ((size_t)2 * p.nchunks * 32 * 32 + 8 * 32) * sizeof(float);
-    const int kh = kbegin(prof_level_ >= 2 ? krow("dds_layer_kernel") : 0, 2.0 * H_ * H_ * 0);
-    const dim3 grid((Tg_ + 31) / 32, B_);
-    if (p.nchunks * 32 <= 96) PE_LAUNCH(dds_layer_kernel<6>, grid, dim3(512), smem, stream_, p);
-    else if (p.nchunks * 32 <= 192) PE_LAUNCH(dds_layer_kernel<12>, grid, dim3(512), smem, stream_, p);
-    else PE_LAUNCH(dds_layer_kernel<16>, grid, dim3(512), smem, stream_, p);
+    const int kh = kbegin(prof_level_ >= 2 ? krow("dds_layer16_kernel") : 0, 0.0);
+    const dim3 grid16((Tg_ + 15) / 16, B_);
+    const size_t smem16 = ((size_t)2 * p.nchunks * 32 * 16 + 8 * 16) * sizeof(float);
+    if (p.nchunks <= 3) PE_LAUNCH(dds_layer16_kernel<3>, grid16, dim3(512), smem16, stream_, p);
+    else if (p.nchunks <= 6) PE_LAUNCH(dds_layer16_kernel<6>, grid16, dim3(512), smem16, stream_, p);
+    else PE_LAUNCH(dds_layer16_kernel<8>, grid16, dim3(512), smem16, stream_, p);
     kend(kh);
     dil *= ksz_;
     cur = dst;

@@ -28,6 +28,7 @@ struct PackedConv {
 struct DdsW {               // one DDSConv (modules.py:81-129)
   std::vector<float*> dw_w, dw_b, g1, b1, g2, b2;
   std::vector<PackedConv> c1x1;
+  std::vector<float*> w16;           // 1x1 weights in the 16x16x4 fragment order (dds_layer16_kernel)
 };
 
 struct ProfileRow {

@@ -943,55 +943,59 @@ struct DdsP {
   float* out; long o_bs; int o_cs;
   const float* dw_w; const float* dw_b; int dw_k, dw_dil;
   const float* g1; const float* b1; const float* g2; const float* b2;
-  const float* wp; const float* bias;      // packed 1x1 weights (conv_mfma layout, one tap), bias
+  const float* bias;                        // 1x1 conv bias
+  const float* wp16;                        // 1x1 conv weights in the 16x16x4 fragment order (engine.cpp)
   int nchunks;                              // ceil(H / 32)
   const int* lens;
   int H;
 };
-static constexpr int DDS_MAXNV = 16;        // channel slots per thread (16 row groups): H <= 16 * 16
-
-// DDS_NV = channel slots per thread actually instantiated (ceil(Hp / 16)): 6 for H <= 96, 12 for H <= 192, 16 otherwise
-template <int DDS_NV>
-__global__ __launch_bounds__(512) void dds_layer_kernel(DdsP p) {
-  PE_DYN_SMEM(float, sm);                   // Y[Hp][32] | Z[Hp][32] | red[8][32]
+// One workgroup = 16 time columns x all channels, 512 threads; the 1x1 conv runs on the 16x16x4 f32 MFMA: the GEMM's
+// N matches the column count, its 16-row tiles (Hp/16 = 12 for H = 192) spread evenly over the four SIMDs of the 8
+// waves (three each), and a 128-id utterance still gives 8 workgroups. (A first version used 32 columns and the
+// 32x32x2 MFMA: six row tiles on eight waves put two tiles on two of the SIMDs; 17.3 vs 11.0 us per launch.) k runs
+// over the input channels in ascending order inside and across the instructions: the same fmaf chain. Weights: packed by engine.cpp pack_dds16 as
+// [16-row tile][q][lane][4] with lane -> (row = lane & 15, k = lane >> 4) and step s = 4q + j covering ci = 4s + k.
+template <int NVT>                              // channel slots per thread: ceil(Hp / 32)
+__global__ __launch_bounds__(512) void dds_layer16_kernel(DdsP p) {
+  constexpr int NC = 16;
+  PE_DYN_SMEM(float, sm);                       // Y[Hp][16] | Z[Hp][16] | red[8][16]
   const int b = blockIdx.y, L = p.lens[b];
-  const int t0 = blockIdx.x * 32;
+  const int t0 = blockIdx.x * NC;
   if (t0 >= L) return;
   const int H = p.H, Hp = p.nchunks * 32;
   float* Y = sm;
-  float* Z = Y + Hp * 32;
-  float* red = Z + Hp * 32;
-  const int tid = threadIdx.x, col = tid & 31, rl = tid >> 5, wv = tid >> 6, lane = tid & 63;
+  float* Z = Y + Hp * NC;
+  float* red = Z + Hp * NC;
+  const int tid = threadIdx.x, col = tid & 15, rl = tid >> 4, wv = PE_UNIFORM(tid >> 6), lane = tid & 63;
   const int t = t0 + col;
   const bool ok = t < L;
   const float* xb = p.x + (long)b * p.x_bs;
   float* ob = p.out + (long)b * p.o_bs;
   const int pad = (p.dw_k - 1) / 2 * p.dw_dil;
 
-  auto col_sum = [&](float v) -> float {     // sum over all channel lanes of this column
+  auto col_sum = [&](float v) -> float {       // sum over all channel lanes of this column
+    v += __shfl_xor(v, 16);
     v += __shfl_xor(v, 32);
     __syncthreads();
-    if (lane < 32) red[wv * 32 + col] = v;
+    if (lane < NC) red[wv * NC + col] = v;
     __syncthreads();
     float s = 0.f;
 #pragma unroll
-    for (int w = 0; w < 8; ++w) s += red[w * 32 + col];
+    for (int w = 0; w < 8; ++w) s += red[w * NC + col];
     return s;
   };
 
-  // ---- phase 1: depthwise conv, LN1, GELU -> Y.  Every operand is fetched first through buffer descriptors
-  // (invalid taps / padded channels get index -1 -> hardware returns 0), so the ~8 loads per channel are all
-  // in flight together instead of one dependent load per tap.
+  // ---- phase 1: depthwise conv, LN1, GELU -> Y (all operands requested up front through descriptors)
   constexpr int MAXK = 3;
   const pe_rowsrc xd = pe_make_row(xb, H * p.x_cs);
   const pe_rowsrc wd = pe_make_row(p.dw_w, H * p.dw_k), bd = pe_make_row(p.dw_b, H);
   const pe_rowsrc g1d = pe_make_row(p.g1, H), b1d = pe_make_row(p.b1, H);
-  float v[DDS_NV], xc[DDS_NV];
+  float v[NVT], xc[NVT], gg[NVT], bb[NVT];
   {
-    float xv[DDS_NV][MAXK], ww[DDS_NV][MAXK], wb[DDS_NV];
+    float xv[NVT][MAXK], ww[NVT][MAXK], wb[NVT];
 #pragma unroll
-    for (int k = 0; k < DDS_NV; ++k) {
-      const int c = rl + 16 * k;
+    for (int k = 0; k < NVT; ++k) {
+      const int c = rl + 32 * k;
       const bool cv = ok && c < H;
 #pragma unroll
       for (int kk = 0; kk < MAXK; ++kk) {
@@ -1001,9 +1005,11 @@ __global__ __launch_bounds__(512) void dds_layer_kernel(DdsP p) {
         ww[k][kk] = pe_row_load(wd, tv ? c * p.dw_k + kk : -1);
       }
       wb[k] = pe_row_load(bd, cv ? c : -1);
+      gg[k] = pe_row_load(g1d, c < H ? c : -1);
+      bb[k] = pe_row_load(b1d, c < H ? c : -1);
     }
 #pragma unroll
-    for (int k = 0; k < DDS_NV; ++k) {
+    for (int k = 0; k < NVT; ++k) {
       float a = wb[k];
 #pragma unroll
       for (int kk = 0; kk < MAXK; ++kk) a = fmaf(ww[k][kk], xv[k][kk], a);
@@ -1013,97 +1019,83 @@ __global__ __launch_bounds__(512) void dds_layer_kernel(DdsP p) {
   }
   float s = 0.f;
 #pragma unroll
-  for (int k = 0; k < DDS_NV; ++k) s += v[k];
+  for (int k = 0; k < NVT; ++k) s += v[k];
   float mean = col_sum(s) / (float)H;
   float q = 0.f;
 #pragma unroll
-  for (int k = 0; k < DDS_NV; ++k)
-    if (rl + 16 * k < H) { const float d = v[k] - mean; q = fmaf(d, d, q); }
+  for (int k = 0; k < NVT; ++k)
+    if (rl + 32 * k < H) { const float d = v[k] - mean; q = fmaf(d, d, q); }
   float rstd = 1.f / sqrtf(col_sum(q) / (float)H + 1e-5f);
-  {
-    float gg[DDS_NV], bb[DDS_NV];
 #pragma unroll
-    for (int k = 0; k < DDS_NV; ++k) {
-      const int c = rl + 16 * k;
-      gg[k] = pe_row_load(g1d, c < H ? c : -1);
-      bb[k] = pe_row_load(b1d, c < H ? c : -1);
-    }
+  for (int k = 0; k < NVT; ++k) {
+    const int c = rl + 32 * k;
+    if (c < Hp) Y[c * NC + col] = (c < H && ok) ? gelu_erf((v[k] - mean) * rstd * gg[k] + bb[k]) : 0.f;
+  }
+  // LN2 gains: needed in phase 3, in flight during the GEMM
+  const pe_rowsrc g2d = pe_make_row(p.g2, H), b2d = pe_make_row(p.b2, H);
 #pragma unroll
-    for (int k = 0; k < DDS_NV; ++k) {
-      const int c = rl + 16 * k;
-      if (c < Hp) Y[c * 32 + col] = (c < H && ok) ? gelu_erf((v[k] - mean) * rstd * gg[k] + bb[k]) : 0.f;
-    }
+  for (int k = 0; k < NVT; ++k) {
+    const int c = rl + 32 * k;
+    gg[k] = pe_row_load(g2d, c < H ? c : -1);
+    bb[k] = pe_row_load(b2d, c < H ? c : -1);
   }
   __syncthreads();
 
-  // ---- phase 2: Z = W1x1 . Y + bias ; wave w owns row tiles w, w+8, ...; the next chunk's 16 weight
-  // fragments are prefetched while the current chunk's MFMAs issue
+  // ---- phase 2: Z = W1x1 . Y + bias on 16x16x4 MFMAs; wave w owns the 16-row tiles w, w+8, ...
   {
-    const int l31 = lane & 31, lhi = lane >> 5;
-    const long wstride_mt = (long)p.nchunks * (KC / 2) * 64;
-    for (int mt = wv; mt < p.nchunks; mt += 8) {
-      f32x16 acc;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int ntile = Hp / 16, nq = Hp / 16;           // k steps = Hp/4, float4 groups per lane = Hp/16
+    const int tile_floats = nq * 256;
+    const pe_rowsrc biasd = pe_make_row(p.bias, H);
+    for (int mt = wv; mt < ntile; mt += 8) {
+      const pe_rowsrc wsrc = pe_make_row_u(p.wp16 + (long)mt * tile_floats, tile_floats);
+      f32x4 acc;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      // weights through a descriptor, prefetched unconditionally (zeros past the last chunk) so the wait
-      // counts stay exact; the 16 activations of a chunk are read from LDS in one batch
-      const pe_rowsrc wsrc = pe_make_row_u(p.wp + (long)mt * wstride_mt, (int)wstride_mt);
-      float aA[KC / 2], aB[KC / 2];
-      auto lda = [&](int c, float (&a)[KC / 2]) { load_frags<KC / 2>(wsrc, c * (KC / 2) * 64, lane, a); };
-      auto mm = [&](int c, const float (&a)[KC / 2]) {
-        float yv[KC / 2];
+      for (int r = 0; r < 4; ++r) acc[r] = 0.f;
+      float bz[4];
 #pragma unroll
-        for (int kk = 0; kk < KC / 2; ++kk) yv[kk] = Y[(c * KC + 2 * kk + lhi) * 32 + l31];
-        PE_SCHED_FENCE();
+      for (int r = 0; r < 4; ++r) bz[r] = pe_row_load(biasd, mt * 16 + 4 * lq + r);
+      // 16 k-steps (64 input channels) per batch: four float4 weight loads, sixteen LDS reads, sixteen MFMAs
+      for (int q0 = 0; q0 < nq; q0 += 4) {
+        float a[16], yv[16];
 #pragma unroll
-        for (int kk = 0; kk < KC / 2; ++kk) acc = pe_mfma_32x32x2(a[kk], yv[kk], acc);
-        PE_SCHED_FENCE();
-      };
-      lda(0, aA);
-      for (int c = 0; c < p.nchunks; c += 2) {
-        lda(c + 1, aB);
-        mm(c, aA);
-        if (c + 1 < p.nchunks) {
-          lda(c + 2, aA);
-          mm(c + 1, aB);
+        for (int qq = 0; qq < 4; ++qq) {
+          const f32x4 w4 = pe_row_load4(wsrc, (q0 + qq) * 256 + lane * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a[4 * qq + j] = w4[j];
         }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) yv[u] = (4 * q0 + u < Hp / 4) ? Y[(4 * (4 * q0 + u) + lq) * NC + l15] : 0.f;
+        PE_SCHED_FENCE();
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = pe_mfma_16x16x4(a[u], yv[u], acc);
+        PE_SCHED_FENCE();
       }
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        Z[row * 32 + l31] = acc[r] + (row < H ? p.bias[row] : 0.f);
-      }
+      for (int r = 0; r < 4; ++r) Z[(mt * 16 + 4 * lq + r) * NC + l15] = acc[r] + bz[r];
     }
   }
   __syncthreads();
 
   // ---- phase 3: LN2, GELU, residual -> out
-  const pe_rowsrc g2d = pe_make_row(p.g2, H), b2d = pe_make_row(p.b2, H);
-  float g2v[DDS_NV], b2v[DDS_NV];
-#pragma unroll
-  for (int k = 0; k < DDS_NV; ++k) {
-    const int c = rl + 16 * k;
-    g2v[k] = pe_row_load(g2d, c < H ? c : -1);
-    b2v[k] = pe_row_load(b2d, c < H ? c : -1);
-  }
   s = 0.f;
 #pragma unroll
-  for (int k = 0; k < DDS_NV; ++k) {
-    const int c = rl + 16 * k;
-    v[k] = (c < H) ? Z[c * 32 + col] : 0.f;
+  for (int k = 0; k < NVT; ++k) {
+    const int c = rl + 32 * k;
+    v[k] = (c < H) ? Z[c * NC + col] : 0.f;
     s += v[k];
   }
   mean = col_sum(s) / (float)H;
   q = 0.f;
 #pragma unroll
-  for (int k = 0; k < DDS_NV; ++k)
-    if (rl + 16 * k < H) { const float d = v[k] - mean; q = fmaf(d, d, q); }
+  for (int k = 0; k < NVT; ++k)
+    if (rl + 32 * k < H) { const float d = v[k] - mean; q = fmaf(d, d, q); }
   rstd = 1.f / sqrtf(col_sum(q) / (float)H + 1e-5f);
   if (!ok) return;
 #pragma unroll
-  for (int k = 0; k < DDS_NV; ++k) {
-    const int c = rl + 16 * k;
-    if (c < H) ob[(long)c * p.o_cs + t] = xc[k] + gelu_erf((v[k] - mean) * rstd * g2v[k] + b2v[k]);
+  for (int k = 0; k < NVT; ++k) {
+    const int c = rl + 32 * k;
+    if (c < H) ob[(long)c * p.o_cs + t] = xc[k] + gelu_erf((v[k] - mean) * rstd * gg[k] + bb[k]);
   }
 }
 
