@@ -73,6 +73,33 @@ PackedConv Engine::pack_matrix(const std::vector<float>& W, int rows, int Cin, i
             P[(((size_t)mt * pc.nchunks + c) * ntaps + tap) * (KC / 2) * 64 + (kk >> 2) * 256 + lane * 4 + (kk & 3)] = v;
           }
   pc.wp = dev_copy(P);
+  const char* f16 = getenv("PIPER_HIP_SPLITK16");          // 3 = every conv (tests)
+  if (pc.nchunks * ntaps >= 24 || (f16 && atoi(f16) >= 3)) {
+    // long-K convs may run through conv_splitk16_kernel: [16-row sub-tile][chunk][tap][q][lane][4], lane ->
+    // (row = lane & 15, k = lane >> 4), float4 element j of group q = k-step 4q + j = input channel chunk*32 + 4s + k
+    std::vector<float> Q((size_t)pc.mtiles * 2 * pc.nchunks * ntaps * (KC / 4) * 64, 0.f);
+    for (int st = 0; st < pc.mtiles * 2; ++st)
+      for (int c = 0; c < pc.nchunks; ++c)
+        for (int tap = 0; tap < ntaps; ++tap)
+          for (int q = 0; q < KC / 16; ++q)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int j = 0; j < 4; ++j) {
+                const int mt = st >> 1, r = (st & 1) * 16 + (lane & 15);
+                int row;
+                if (gate) {
+                  const int ch = (mt >> 1) * 32 + r;
+                  row = (ch < split) ? ((mt & 1) ? split + ch : ch) : -1;
+                } else {
+                  row = mt * 32 + r;
+                  if (row >= rows) row = -1;
+                }
+                const int ci = c * KC + 4 * (4 * q + j) + (lane >> 4);
+                if (row >= 0 && ci < Cin)
+                  Q[((((size_t)st * pc.nchunks + c) * ntaps + tap) * (KC / 16) + q) * 256 + lane * 4 + j] =
+                      W[((size_t)row * Cin + ci) * ntaps + tap];
+              }
+    pc.wp16 = dev_copy(Q);
+  }
   pc.bias = bias ? dev_copy(*bias) : nullptr;
   pc.macs_per_col = (double)rows * Cin * ntaps;
   return pc;
@@ -361,7 +388,8 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
     for (const void* k : ks) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     const void* ks2[] = {(const void*)conv_splitk_kernel<2, true, 8, 3>, (const void*)conv_splitk_kernel<2, true, 4, 3>,
                          (const void*)conv_splitk_kernel<1, false, 8, 4>, (const void*)conv_splitk_kernel<1, false, 4, 4>,
-                         (const void*)conv_splitk_kernel<2, true, 12, 2>, (const void*)conv_splitk_kernel<1, false, 12, 4>};
+                         (const void*)conv_splitk_kernel<2, true, 12, 2>, (const void*)conv_splitk_kernel<1, false, 12, 4>,
+                         (const void*)conv_splitk16_kernel<true, 12, 2>, (const void*)conv_splitk16_kernel<false, 8, 4>};
     for (const void* k : ks2) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     PE_HIP(hipFuncSetAttribute((const void*)attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     const void* ks3[] = {(const void*)mrf_fused_kernel<32, 4, 4, 256>, (const void*)mrf_fused_kernel<32, 4, 4, 320>,
@@ -383,6 +411,7 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
   if (const char* t = getenv("PIPER_HIP_PAR_MRF")) par_mrf_ = atoi(t) != 0;
   if (const char* t = getenv("PIPER_HIP_FUSE_MRF")) fuse_mrf_ = atoi(t) != 0;   // A/B knob: 1 = fused MRF stage kernel
   if (const char* t = getenv("PIPER_HIP_SPLITK_MAX")) splitk_max_blocks_ = atol(t);   // tuning knob
+  if (const char* t = getenv("PIPER_HIP_SPLITK16")) splitk16_ = atoi(t);              // A/B knob
   if (const char* t = getenv("PIPER_HIP_WIDE_SPLITK")) wide_splitk_ = atoi(t);        // 0 off, 1 auto, 2 always (tests)
 }
 
@@ -528,7 +557,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
                   int bias2_bs) {
   ConvP p;
   p.x = x.p; p.x_bs = x.bs; p.x_cs = x.cs;
-  p.wp = pc.wp; p.bias = pc.bias;
+  p.wp = pc.wp; p.wp16 = pc.wp16; p.bias = pc.bias;
   p.bias2 = bias2; p.bias2_bs = bias2_bs;
   p.out = out.p; p.o_bs = out.bs; p.o_cs = out.cs;
   p.res = res.p; p.r_bs = res.bs; p.r_cs = res.cs;
@@ -582,6 +611,22 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     dim3 grid((ncols + 31) / 32, pc.mtiles / MT, B_);
     const size_t smem = std::max<size_t>((size_t)NW * KC * 64, (size_t)NW * MT * 16 * 64) * sizeof(float);
     const int kh = kbegin(prof_level_ >= 2 ? krow("conv_splitk_kernel") : 0, kflops, kbytes);
+    // MFMA-pipe bound inside the workgroup (>= 24 chunk-tap units) although most CUs idle: 16 output columns
+    if (pc.wp16 && epi != EPI_CONVT && ((pc.gate && splitk16_ >= 1) || (!pc.gate && splitk16_ >= 2)) &&
+        (units >= 24 || splitk16_ >= 3)) {
+      dim3 grid16((ncols + 15) / 16, pc.mtiles / MT, B_);
+      if (pc.gate) {
+        const int nw = 12;
+        p.tgroups = pc.nchunks <= 6 ? 2 : 1;
+        PE_LAUNCH((conv_splitk16_kernel<true, 12, 2>), grid16, dim3(64 * nw), (size_t)nw * KC * 64 * sizeof(float), ls_, p);
+      } else {
+        const int nw = 8;
+        p.tgroups = 1;
+        PE_LAUNCH((conv_splitk16_kernel<false, 8, 4>), grid16, dim3(64 * nw), (size_t)nw * KC * 64 * sizeof(float), ls_, p);
+      }
+      kend(kh);
+      return;
+    }
     if (pc.gate) {
       if (NW == 12) PE_LAUNCH((conv_splitk_kernel<2, true, 12, 2>), grid, dim3(768), smem, ls_, p);
       else if (NW == 8) PE_LAUNCH((conv_splitk_kernel<2, true, 8, 3>), grid, dim3(512), smem, ls_, p);

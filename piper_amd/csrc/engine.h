@@ -14,6 +14,7 @@ namespace pe {
 
 struct PackedConv {
   float* wp = nullptr;      // device, packed for conv_mfma_kernel
+  float* wp16 = nullptr;    // device, the same in 16x16x4 fragment order (conv_splitk16_kernel), long-K convs only
   float* bias = nullptr;    // device or null
   int rows = 0;             // GEMM rows (real)
   int mtiles = 0;           // packed 32-row tiles (padded to the block tile)
@@ -170,6 +171,7 @@ class Engine {
   // conv GEMM kernel's prefetch/epilogue rework the conv-by-conv schedule is faster at every batch size measured
   // (profiles/r01_mrf_ab.txt), so it is opt-in (PIPER_HIP_FUSE_MRF=1).
   bool fuse_mrf_ = false;
+  int splitk16_ = 2;                        // 16-column split-K: 0 off, 1 WN gate conv, 2 also long-K plain convs, 3 all (tests)
   int wide_splitk_ = 1;                     // 12-wave split-K workgroups for long-K launches
   long splitk_max_blocks_ = 96;             // launches with fewer tile-kernel workgroups use conv_splitk_kernel
   std::vector<UpStage> ups_;

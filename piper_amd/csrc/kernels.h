@@ -40,6 +40,7 @@ enum Act { ACT_NONE = 0, ACT_RELU = 1 };
 struct ConvP {
   const float* x; long x_bs; int x_cs;          // input  x[b][ci][t]
   const float* wp;                              // packed weights (engine.cpp: pack_conv)
+  const float* wp16;                            // conv_splitk16_kernel: the same in 16x16x4 fragment order, or null
   const float* bias;                            // per output channel or null
   const float* bias2; int bias2_bs;             // per-utterance extra bias (speaker cond) or null
   float* out; long o_bs; int o_cs;
@@ -560,6 +561,191 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk_kernel(ConvP p) {
       if (s < MT * 16) {
 #pragma unroll
         for (int w = 0; w < NW; ++w) v += red[(w * MT * 16 + s) * 64 + lane];
+      }
+      if (e_dst[i]) {
+        v = ((v + (e_b1[i] + e_b2[i])) * ef.sign + (e_o1[i] + e_o2[i])) * ef.alpha;
+        if (ef.relu) v = v > 0.f ? v : 0.f;
+        *e_dst[i] = v;
+      }
+    }
+  }
+}
+
+// The split-K kernel on 16 output columns with the 16x16x4 f32 MFMA, for launches that are MFMA-pipe bound inside a
+// workgroup although most CUs idle (one utterance through the WN gate conv: 84 workgroups of 960 MFMAs): half the
+// columns per workgroup = half the matrix time per CU and twice the workgroups. One workgroup = MT16 sixteen-row
+// sub-tiles (4 for the gate: tanh a, tanh b, sigmoid a, sigmoid b of one 32-channel group; 2 otherwise) x 16 columns;
+// K is dealt to the waves exactly as in conv_splitk_kernel. Weights: engine.cpp pack16 --
+// [16-row sub-tile][chunk][tap][q = 0..1][lane][4] with lane -> (row = lane & 15, k = lane >> 4), float4 element j of
+// group q = k-step s = 4q + j, input channel chunk*32 + 4s + k; ascending k inside and across instructions, i.e. the
+// same fmaf chain as the 32x32x2 form.
+template <bool GATE, int NW, int D>
+__global__ __launch_bounds__(64 * NW) void conv_splitk16_kernel(ConvP p) {
+  constexpr int BN = 16, XW = 64, KS8 = KC / 4, MT16 = GATE ? 4 : 2;
+  constexpr int NSLOT = GATE ? 8 : MT16 * 4;                  // result slots per lane position (gate: tanh/sigmoid pairs)
+  constexpr int NS = (NSLOT + NW - 1) / NW;                   // epilogue slots per wave
+  PE_DYN_SMEM(float, sm);                         // NW x [KC][XW] slabs, then NW x [MT16*4][64] partial tiles
+  const int b = blockIdx.z;
+  const int L = p.lens[b] * p.len_mul;            // first used after the loads below are in flight
+  const int n0 = blockIdx.x * BN;
+  const int tid = threadIdx.x, lane = tid & 63, wv = PE_UNIFORM(tid >> 6);
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int st0 = blockIdx.y * MT16;              // first 16-row sub-tile of this workgroup
+  const int col = n0 + l15;
+  const int ntaps = p.ntaps, nchunks = p.nchunks;
+  const int sub_stride = nchunks * ntaps * KS8 * 64;          // floats per 16-row sub-tile
+  const float* xb = p.x + (long)b * p.x_bs;
+  const float slope = p.in_slope;
+  const pe_rowsrc wsrc = pe_make_row(p.wp16 + (long)st0 * sub_stride, MT16 * sub_stride);
+  float* xw = sm + wv * KC * XW;
+  const int CL = NW / p.tgroups;
+  const int wi = wv % CL, wg = wv / CL;
+  const int tpg = (ntaps + p.tgroups - 1) / p.tgroups;
+  const int tap_lo = wg * tpg, tap_hi = (tap_lo + tpg < ntaps) ? tap_lo + tpg : ntaps;
+  const int mytaps = tap_hi > tap_lo ? tap_hi - tap_lo : 0;
+  const int myc = (wi < nchunks && mytaps > 0) ? (nchunks - wi + CL - 1) / CL : 0;
+  const int nsteps = myc * mytaps;
+
+  float xr[KC];
+  const pe_rowsrc xd = pe_make_row(xb, p.Cin * p.x_cs);
+  const int xcol = n0 - p.padl + lane;
+  const int xoff = (xcol >= 0 && xcol < p.x_cs) ? xcol : 0x3fffffff;
+  auto load_x = [&](int c) {
+#pragma unroll
+    for (int r = 0; r < KC; ++r) xr[r] = pe_row_load_so(xd, xoff, (c * KC + r) * p.x_cs);
+  };
+  auto store_x = [&]() {
+    const bool live = xcol < L;
+#pragma unroll
+    for (int r = 0; r < KC; ++r) {
+      float v = live ? xr[r] : 0.f;
+      v = v > 0.f ? v : v * slope;
+      xw[r * XW + lane] = v;
+    }
+  };
+  float a[D][MT16][KS8];
+  int lk = 0, ltap = tap_lo;
+  auto load_ring = [&](float (&dst)[MT16][KS8]) {
+    const int off = PE_UNIFORM(((wi + CL * lk) * ntaps + ltap) * (KS8 * 64));
+#pragma unroll
+    for (int i = 0; i < MT16; ++i)
+#pragma unroll
+      for (int q = 0; q < KS8 / 4; ++q) {
+        const f32x4 t = pe_row_load4(wsrc, off + i * sub_stride + q * 256 + lane * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dst[i][4 * q + j] = t[j];
+      }
+    if (++ltap >= tap_hi) { ltap = tap_lo; ++lk; }
+  };
+  f32x4 acc[MT16];
+  auto mma = [&](int tap, const float (&af)[MT16][KS8]) {
+    const float* xp = xw + lq * XW + tap * p.dil + l15;
+    float bv[KS8];
+#pragma unroll
+    for (int s8 = 0; s8 < KS8; ++s8) bv[s8] = xp[4 * s8 * XW];
+#pragma unroll
+    for (int s8 = 0; s8 < KS8; ++s8)
+#pragma unroll
+      for (int i = 0; i < MT16; ++i) acc[i] = pe_mfma_16x16x4(af[i][s8], bv[s8], acc[i]);
+  };
+
+  load_x(myc > 0 ? wi : nchunks);
+#pragma unroll
+  for (int d = 0; d < D; ++d) load_ring(a[d]);
+  PE_SCHED_FENCE();
+  const int ncols = L;
+  if (n0 >= ncols) return;
+  const EpiFlags ef = epi_flags(p);
+
+  // ---- epilogue operands of this wave's slots (slot s -> sub-tile s >> 2, register s & 3; the lane adds row 4*lq)
+  float e_b1[NS], e_b2[NS], e_o1[NS], e_o2[NS];
+  float* e_dst[NS];
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int s = wv + NW * i;
+    e_b1[i] = 0.f; e_b2[i] = 0.f; e_o1[i] = 0.f; e_o2[i] = 0.f; e_dst[i] = nullptr;
+    if constexpr (GATE) {
+      const int ch = blockIdx.y * 32 + (s >> 2) * 16 + 4 * lq + (s & 3);
+      if (s < NSLOT && ch < p.split && col < ncols) {
+        e_b1[i] = p.bias[ch];
+        e_o1[i] = p.bias[p.split + ch];
+        if (p.bias2) {
+          const float* b2 = p.bias2 + (long)b * p.bias2_bs;
+          e_b2[i] = b2[ch];
+          e_o2[i] = b2[p.split + ch];
+        }
+        e_dst[i] = p.out + (long)b * p.o_bs + (long)ch * p.o_cs + col;
+      }
+    } else {
+      const int row = (st0 + (s >> 2)) * 16 + 4 * lq + (s & 3);
+      if (s < NSLOT && row < p.rows && col < ncols) {
+        if (p.bias) e_b1[i] = p.bias[row];
+        if (p.bias2) e_b2[i] = p.bias2[(long)b * p.bias2_bs + row];
+        const bool to_skip = p.epi == EPI_WNRS && row >= p.split;
+        const bool rd_old = to_skip ? (p.mode != 1) : (ef.use_old || p.epi == EPI_WNRS);
+        float* d = to_skip ? p.out2 + (long)b * p.o2_bs + (long)(row - p.split) * p.o2_cs + col
+                           : p.out + (long)b * p.o_bs + (long)row * p.o_cs + col;
+        if (rd_old) e_o1[i] = *d;
+        if (ef.use_res) e_o2[i] = p.res[(long)b * p.r_bs + (long)row * p.r_cs + col];
+        e_dst[i] = d;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < MT16; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+  {
+    int k = 0, tap = tap_lo;
+    for (int s0 = 0; s0 < nsteps; s0 += D) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        if (s0 + d < nsteps) {
+          if (tap == tap_lo) {
+            PE_WAVE_SYNC();
+            store_x();
+            PE_WAVE_SYNC();
+            if (k + 1 < myc) load_x(wi + CL * (k + 1));
+          }
+          mma(tap, a[d]);
+          if (++tap >= tap_hi) { tap = tap_lo; ++k; }
+        }
+        PE_SCHED_FENCE();
+        load_ring(a[d]);
+        PE_SCHED_FENCE();
+      }
+    }
+  }
+  // ---- cross-wave reduction through LDS (fixed order w = 0..NW-1)
+  __syncthreads();
+  float* red = sm;                                // [NW waves][MT16*4 slots][64 lanes]
+#pragma unroll
+  for (int i = 0; i < MT16; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) red[(wv * MT16 * 4 + i * 4 + r) * 64 + lane] = acc[i][r];
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int s = wv + NW * i;
+    if constexpr (GATE) {
+      float ta = 0.f, sa = 0.f;
+      if (s < NSLOT) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+          ta += red[(w * MT16 * 4 + s) * 64 + lane];
+          sa += red[(w * MT16 * 4 + 8 + s) * 64 + lane];
+        }
+      }
+      if (e_dst[i]) {
+        ta += e_b1[i] + e_b2[i];
+        sa += e_o1[i] + e_o2[i];
+        *e_dst[i] = tanhf(ta) * (1.f / (1.f + expf(-sa)));
+      }
+    } else {
+      float v = 0.f;
+      if (s < NSLOT) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[(w * MT16 * 4 + s) * 64 + lane];
       }
       if (e_dst[i]) {
         v = ((v + (e_b1[i] + e_b2[i])) * ef.sign + (e_o1[i] + e_o2[i])) * ef.alpha;

@@ -139,3 +139,22 @@ def test_emulated_wide_splitk_matches(emu_lib, monkeypatch):
         assert a.shape == b.shape and np.max(np.abs(a - b)) < 2e-6
     o = O.synthesize(w, cfg, ids[0], (0.5, 1.0, 0.6), nw[0], nz[0], sid=1)
     assert np.max(np.abs(outs[1][0] - o["audio"])) < 1e-4
+
+
+def test_emulated_splitk16_matches(emu_lib, monkeypatch):
+    """conv_splitk16_kernel (16 output columns, 16x16x4 MFMA; used for the WN gate conv of full-size voices) forced on
+    for every small launch of a tiny multi-speaker voice: gate and plain epilogues, ragged batch."""
+    cfg = W.preset("tiny-ms")
+    w = W.synthetic_weights(cfg, 6)
+    ids = [W.synthetic_phoneme_ids(T, i, id_max=cfg.n_vocab - 1) for i, T in enumerate((7, 2))]
+    nw, nz = _noise(cfg, 2, 7, 17)
+    outs = []
+    for mode in ("0", "3"):
+        monkeypatch.setenv("PIPER_HIP_SPLITK16", mode)
+        eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
+        outs.append(eng.synthesize_batch(ids, (0.4, 1.0, 0.7), sids=[2, 0], noise_w=nw, noise_z=nz).audio)
+        eng.close()
+    for a, b in zip(*outs):
+        assert a.shape == b.shape and np.max(np.abs(a - b)) < 2e-6
+    o = O.synthesize(w, cfg, ids[0], (0.4, 1.0, 0.7), nw[0], nz[0], sid=2)
+    assert np.max(np.abs(outs[1][0] - o["audio"])) < 1e-4
