@@ -1,4 +1,7 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 1200 python scripts/stress_parity.py 24 > gpurun_out/stress.log 2>&1
-tail -3 gpurun_out/stress.log
+for m in 0 512 4096; do
+  PIPER_HIP_S2_MIN=$m python bench.py --no-cpu-baseline --batch 16 --steps 20 > gpurun_out/s2_${m}_b16.json 2> gpurun_out/f.err
+  PIPER_HIP_S2_MIN=$m python bench.py --no-cpu-baseline --batch 64 --steps 10 > gpurun_out/s2_${m}_b64.json 2>> gpurun_out/f.err
+  PIPER_HIP_S2_MIN=$m python bench.py --no-cpu-baseline --preset high --batch 8 --steps 10 > gpurun_out/s2_${m}_h8.json 2>> gpurun_out/f.err
+done
