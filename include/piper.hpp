@@ -128,6 +128,13 @@ void loadVoice(PiperConfig &config, std::string modelPath, std::string modelConf
 void synthesize(std::vector<PhonemeId> &phonemeIds, SynthesisConfig &synthesisConfig, ModelSession &session,
                 std::vector<int16_t> &audioBuffer, SynthesisResult &result);
 
+// Extension (not in the reference): several id sequences in ONE device call (pe_synthesize_batch). Every sequence
+// is computed, and peak-normalised to int16, exactly as its own synthesize() call would; audioBuffers[i] receives
+// sequence i. textToAudio uses it for the phrases of a sentence.
+void synthesizeBatch(std::vector<std::vector<PhonemeId>> &phonemeIdLists, SynthesisConfig &synthesisConfig,
+                     ModelSession &session, std::vector<std::vector<int16_t>> &audioBuffers,
+                     SynthesisResult &result);
+
 // Phonemes -> ids with the piper-phonemize rule used at piper.cpp:555 (BOS, PAD, (id.., PAD)*, EOS)
 void phonemes_to_ids(const std::vector<Phoneme> &phonemes, const PhonemizeConfig &config,
                      std::vector<PhonemeId> &phonemeIds, std::map<Phoneme, std::size_t> &missingPhonemes);

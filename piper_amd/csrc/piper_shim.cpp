@@ -298,6 +298,32 @@ void synthesize(std::vector<PhonemeId>& phonemeIds, SynthesisConfig& synthesisCo
   audioBuffer.insert(audioBuffer.end(), r.pcm, r.pcm + n);
 }
 
+void synthesizeBatch(std::vector<std::vector<PhonemeId>>& phonemeIdLists, SynthesisConfig& synthesisConfig,
+                     ModelSession& session, std::vector<std::vector<int16_t>>& audioBuffers,
+                     SynthesisResult& result) {
+  if (!session.engine) throw std::runtime_error("voice model is not loaded");
+  const int32_t nb = (int32_t)phonemeIdLists.size();
+  audioBuffers.assign(nb, {});
+  if (nb == 0) return;
+  const float scales[3] = {synthesisConfig.noiseScale, synthesisConfig.lengthScale, synthesisConfig.noiseW};
+  std::vector<PhonemeId> flat;
+  std::vector<int64_t> offsets(1, 0), sids(nb, synthesisConfig.speakerId.value_or(0));
+  for (auto& ids : phonemeIdLists) {
+    flat.insert(flat.end(), ids.begin(), ids.end());
+    offsets.push_back((int64_t)flat.size());
+  }
+  check(pe_upload(session.engine, flat.data(), offsets.data(), nb, scales, sids.data(), nullptr));
+  const auto t0 = std::chrono::steady_clock::now();
+  check(pe_run(session.engine));
+  pe_result r;
+  check(pe_fetch(session.engine, 0, 1, &r));
+  result.inferSeconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  for (int32_t i = 0; i < nb; ++i)
+    audioBuffers[i].assign(r.pcm + r.sample_offsets[i], r.pcm + r.sample_offsets[i + 1]);
+  result.audioSeconds = (double)r.sample_offsets[nb] / (double)synthesisConfig.sampleRate;
+  result.realTimeFactor = result.audioSeconds > 0 ? result.inferSeconds / result.audioSeconds : 0.0;
+}
+
 void phonemes_to_ids(const std::vector<Phoneme>& phonemes, const PhonemizeConfig& config,
                      std::vector<PhonemeId>& phonemeIds, std::map<Phoneme, std::size_t>& missingPhonemes) {
   phonemeIds.push_back(config.idBos);
@@ -361,15 +387,33 @@ void textToAudio(PiperConfig& config, Voice& voice, std::string text, std::vecto
       phrases.push_back(sentence);
     }
     phraseSilence.resize(phrases.size(), 0);
+    // The reference runs one session.Run() per phrase (piper.cpp:548-575); the phrases of a sentence are
+    // independent, so here they go through the engine as one batch and are appended in order.
+    std::vector<std::vector<PhonemeId>> idLists;
+    std::vector<std::size_t> owner;
     for (std::size_t i = 0; i < phrases.size(); ++i) {
       if (phrases[i].empty()) continue;
       phonemes_to_ids(phrases[i], voice.phonemizeConfig, phonemeIds, missingPhonemes);
+      idLists.push_back(phonemeIds);
+      owner.push_back(i);
+      phonemeIds.clear();
+    }
+    if (idLists.size() == 1) {
       SynthesisResult pr;
-      synthesize(phonemeIds, voice.synthesisConfig, voice.session, audioBuffer, pr);
-      audioBuffer.insert(audioBuffer.end(), phraseSilence[i], (int16_t)0);
+      synthesize(idLists[0], voice.synthesisConfig, voice.session, audioBuffer, pr);
+      audioBuffer.insert(audioBuffer.end(), phraseSilence[owner[0]], (int16_t)0);
       result.audioSeconds += pr.audioSeconds;
       result.inferSeconds += pr.inferSeconds;
-      phonemeIds.clear();
+    } else if (!idLists.empty()) {
+      SynthesisResult pr;
+      std::vector<std::vector<int16_t>> parts;
+      synthesizeBatch(idLists, voice.synthesisConfig, voice.session, parts, pr);
+      for (std::size_t k = 0; k < parts.size(); ++k) {
+        audioBuffer.insert(audioBuffer.end(), parts[k].begin(), parts[k].end());
+        audioBuffer.insert(audioBuffer.end(), phraseSilence[owner[k]], (int16_t)0);
+      }
+      result.audioSeconds += pr.audioSeconds;
+      result.inferSeconds += pr.inferSeconds;
     }
     if (sentenceSilenceSamples > 0) audioBuffer.insert(audioBuffer.end(), sentenceSilenceSamples, (int16_t)0);
     if (audioCallback) {

@@ -3,6 +3,7 @@
 // the direct phoneme-id path and the config values, printed for the pytest wrapper to check.
 //   usage: test_piper <voice.onnx> <out.wav>
 #include <cstdio>
+#include <cstdlib>
 #include <fstream>
 #include <iostream>
 #include <sstream>
@@ -48,6 +49,39 @@ int main(int argc, char** argv) {
     std::printf("OK wav_bytes=%ld rate=%d speakers=%d ids_samples=%zu rtf=%.5f pid=%zu missing=%zu sum=%ld\n", size,
                 voice.synthesisConfig.sampleRate, voice.modelConfig.numSpeakers, audio.size() - 7, r2.realTimeFactor,
                 pid.size(), missing.size(), [&] { long s = 0; for (size_t i = 7; i < audio.size(); ++i) s += audio[i]; return s; }());
+    // phrases of a sentence (phoneme_silence) go through the engine as one batch: with the noise switched off the
+    // result must be the per-phrase synthesize() outputs joined by the configured silences (piper.cpp:548-575)
+    {
+      voice.synthesisConfig.phonemeSilenceSeconds.emplace();
+      (*voice.synthesisConfig.phonemeSilenceSeconds)[U','] = 0.01f;
+      std::vector<int16_t> joined;
+      piper::SynthesisResult r3;
+      piper::textToAudio(config, voice, "abc, de, f", joined, r3, nullptr);
+      std::vector<int16_t> expect;
+      const std::size_t sil = (std::size_t)(0.01f * voice.synthesisConfig.sampleRate * voice.synthesisConfig.channels);
+      for (const std::u32string phrase : {U"abc,", U" de,", U" f"}) {
+        std::vector<piper::PhonemeId> ids3;
+        std::map<piper::Phoneme, std::size_t> miss3;
+        piper::phonemes_to_ids(std::vector<piper::Phoneme>(phrase.begin(), phrase.end()), voice.phonemizeConfig, ids3, miss3);
+        piper::SynthesisResult r4;
+        piper::synthesize(ids3, voice.synthesisConfig, voice.session, expect, r4);
+        if (phrase.back() == U',') expect.insert(expect.end(), sil, (int16_t)0);
+      }
+      if (voice.synthesisConfig.sentenceSilenceSeconds > 0)
+        expect.insert(expect.end(), (std::size_t)(voice.synthesisConfig.sentenceSilenceSeconds * voice.synthesisConfig.sampleRate *
+                                                  voice.synthesisConfig.channels), (int16_t)0);
+      long maxd = joined.size() == expect.size() ? 0 : 1 << 20;
+      for (std::size_t i = 0; i < joined.size() && i < expect.size(); ++i) {
+        const long d = std::labs((long)joined[i] - (long)expect[i]);
+        if (d > maxd) maxd = d;
+      }
+      if (maxd > 2 || r3.audioSeconds <= 0) {
+        std::cerr << "ERROR: batched phrases differ from per-phrase synthesis (max |d| = " << maxd << ", sizes "
+                  << joined.size() << " vs " << expect.size() << ")\n";
+        return 1;
+      }
+      voice.synthesisConfig.phonemeSilenceSeconds.reset();
+    }
     piper::terminate(config);
     // errors surface as std::runtime_error, like the reference
     try {
