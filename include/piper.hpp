@@ -7,10 +7,12 @@
 //   * the vendored nlohmann json / utf8 / piper-phonemize headers are not needed by this header
 //     (config parsing uses a small built-in JSON reader; Phoneme/PhonemeId are defined here with the
 //     reference's types: char32_t / int64_t);
-//   * `useCuda` selects the GPU path; false is rejected (this library has no CPU path);
+//   * `useCuda` is accepted with either value (the reference's own test.cpp / main.cpp default pass false): this
+//     library has exactly one execution path, the GPU selected by ModelSession::device;
 //   * espeak-ng / libtashkeel phonemisation stays host-side and is not linked: voices with
-//     "phoneme_type": "text" are phonemised natively (code points), eSpeak voices need ids from the
-//     caller (synthesize()) or a build with the reference's piper-phonemize.
+//     "phoneme_type": "text" are phonemised natively (casefold + NFD code points, like piper-phonemize's
+//     phonemize_codepoints); eSpeak voices are phonemised through PiperConfig::phonemizer -- the slot a host that
+//     links piper-phonemize fills with phonemize_eSpeak -- or synthesised from ids (synthesize()).
 #ifndef PIPER_H_
 #define PIPER_H_
 
@@ -27,19 +29,30 @@ struct pe_engine;
 
 namespace piper {
 
+struct eSpeakConfig {
+  std::string voice = "en-us";
+};
+
 typedef char32_t Phoneme;      // piper-phonemize/phoneme_ids.hpp
 typedef int64_t PhonemeId;
 typedef int64_t SpeakerId;
 
-struct eSpeakConfig {
-  std::string voice = "en-us";
-};
+// text + espeak voice name -> phonemes of each sentence: the signature of piper-phonemize's phonemize_eSpeak as
+// piper.cpp:470-479 calls it (text, eSpeakPhonemeConfig{voice}, phonemes)
+typedef std::function<void(const std::string &text, const std::string &espeakVoice,
+                           std::vector<std::vector<Phoneme>> &sentencePhonemes)> PhonemizeFn;
+// where missing-phoneme warnings go (the reference logs them with spdlog::warn, piper.cpp:600-610); default: stderr
+typedef std::function<void(const std::string &message)> WarnFn;
 
 struct PiperConfig {
   std::string eSpeakDataPath;
   bool useESpeak = true;
   bool useTashkeel = false;
   std::optional<std::string> tashkeelModelPath;
+  // Host-side phonemizer for eSpeak voices (espeak-ng stays on the host: BASELINE.json north_star). Unset: textToAudio
+  // throws for eSpeak voices, exactly where the reference would call phonemize_eSpeak.
+  PhonemizeFn phonemizer;
+  WarnFn warn;
 };
 
 enum PhonemeType { eSpeakPhonemes, TextPhonemes };
@@ -134,6 +147,10 @@ void synthesize(std::vector<PhonemeId> &phonemeIds, SynthesisConfig &synthesisCo
 void synthesizeBatch(std::vector<std::vector<PhonemeId>> &phonemeIdLists, SynthesisConfig &synthesisConfig,
                      ModelSession &session, std::vector<std::vector<int16_t>> &audioBuffers,
                      SynthesisResult &result);
+
+// piper-phonemize's phonemize_codepoints with its default config (casing = fold, no phoneme map), as piper.cpp:480-484
+// calls it: Unicode full case folding, then NFD; one "sentence" holding every code point.
+void phonemize_codepoints(const std::string &text, std::vector<std::vector<Phoneme>> &sentencePhonemes);
 
 // Phonemes -> ids with the piper-phonemize rule used at piper.cpp:555 (BOS, PAD, (id.., PAD)*, EOS)
 void phonemes_to_ids(const std::vector<Phoneme> &phonemes, const PhonemizeConfig &config,

@@ -113,9 +113,20 @@ int pe_profile_bytes(pe_engine* e, int row, double* bytes);
 /* The HIP stream (hipStream_t) the engine launches on, for callers that bracket it with their own events. */
 void* pe_stream(pe_engine* e);
 
-/* Test hook: copy an internal per-stage tensor of utterance b (x_enc, stats, xg, logw, z, audio). */
+/* Test hook: copy an internal per-stage tensor of utterance b: x_enc, stats (rows m_p then logs_p, models.py:208),
+ * xg, logw, z_p (only with PIPER_HIP_DEBUG_KEEP=1 in the environment at pe_create), z, noise_w, noise_z, audio. */
 int pe_debug_tensor(pe_engine* e, const char* name, int32_t b, float* out, int64_t capacity, int32_t* rows,
                     int32_t* cols);
+
+/* Test hooks for the N(0,1) generator behind the graph's two RandomNormalLike sites (models.py:111, :718) when no
+ * noise is injected: pe_debug_randn fills out[n] with what site 0/1 draws at run counter `call` under the current
+ * seed; pe_rng_calls is the number of pipeline runs so far (the counter the next run will use is that + 1). */
+int pe_debug_randn(pe_engine* e, int32_t site, uint64_t call, int64_t n, float* out);
+uint64_t pe_rng_calls(pe_engine* e);
+
+/* Kernel launches (hipGraph kernel nodes) the last pe_run / pe_synthesize* issued: the length of the dependent
+ * launch chain one utterance costs (the latency figure of merit at batch 1). */
+int64_t pe_run_launches(pe_engine* e);
 
 const char* pe_last_error(void);
 void pe_destroy(pe_engine* e);

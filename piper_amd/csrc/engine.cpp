@@ -9,6 +9,8 @@
 
 namespace pe {
 
+long g_launches = 0;
+
 static inline int rup(int v, int m) { return (v + m - 1) / m * m; }
 
 // tile configurations of conv_mfma_kernel: {WM, WN, MT, NT}
@@ -201,6 +203,16 @@ DdsW Engine::load_dds(const WeightSet& ws, const std::string& p) {
 }
 
 Engine::Engine(const WeightSet& ws, int device) : device_(device) {
+  // a constructor that throws does not run the destructor: release what was acquired so far
+  try {
+    init(ws);
+  } catch (...) {
+    free_all();
+    throw;
+  }
+}
+
+void Engine::init(const WeightSet& ws) {
   memcpy(arch_, ws.arch, sizeof(arch_));
   PE_HIP(hipSetDevice(device_));
   PE_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
@@ -413,12 +425,16 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
   if (const char* t = getenv("PIPER_HIP_SPLITK_MAX")) splitk_max_blocks_ = atol(t);   // tuning knob
   if (const char* t = getenv("PIPER_HIP_SPLITK16")) splitk16_ = atoi(t);              // A/B knob
   if (const char* t = getenv("PIPER_HIP_WIDE_SPLITK")) wide_splitk_ = atoi(t);        // 0 off, 1 auto, 2 always (tests)
+  if (const char* t = getenv("PIPER_HIP_DEBUG_KEEP")) debug_keep_ = atoi(t) != 0;     // tests: keep z_p for debug_tensor
 }
 
-Engine::~Engine() {
-  hipStreamSynchronize(stream_);
+Engine::~Engine() { free_all(); }
+
+void Engine::free_all() {
+  if (stream_) hipStreamSynchronize(stream_);
   drop_graphs();
   for (void* p : owned_) hipFree(p);
+  owned_.clear();
   if (wsA_) hipFree(wsA_);
   if (wsB_) hipFree(wsB_);
   if (h_audio_) hipHostFree(h_audio_);
@@ -426,14 +442,21 @@ Engine::~Engine() {
   if (h_frames_) hipHostFree(h_frames_);
   if (ev0_) hipEventDestroy(ev0_);
   if (ev1_) hipEventDestroy(ev1_);
+  for (auto& k : kev_) { hipEventDestroy(k.a); hipEventDestroy(k.b); }
+  kev_.clear();
+  for (hipEvent_t e : ev_pool_) hipEventDestroy(e);
+  ev_pool_.clear();
   for (int i = 0; i < 2; ++i) {
     if (side_stream_[i]) hipStreamSynchronize(side_stream_[i]);
     if (ev_join_[i]) hipEventDestroy(ev_join_[i]);
     if (side_stream_[i]) hipStreamDestroy(side_stream_[i]);
+    ev_join_[i] = nullptr; side_stream_[i] = nullptr;
   }
   if (ev_fork_) hipEventDestroy(ev_fork_);
-  for (float* p : side_) if (p) hipFree(p);
-  hipStreamDestroy(stream_);
+  for (float*& p : side_) { if (p) hipFree(p); p = nullptr; }
+  if (stream_) hipStreamDestroy(stream_);
+  wsA_ = wsB_ = nullptr; h_audio_ = nullptr; h_pcm_ = nullptr; h_frames_ = nullptr;
+  ev0_ = ev1_ = ev_fork_ = nullptr; stream_ = nullptr;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -523,6 +546,7 @@ void Engine::ensure_stage_b(int Fmax) {
     noise_z_ = c.take<float>(Bc * C_ * F);
     for (int i = 0; i < 5; ++i) hb_[i] = c.take<float>(Bc * hmax);
     zwin_ = c.take<float>((size_t)C_ * F);
+    zp_keep_ = debug_keep_ ? c.take<float>(Bc * C_ * F) : nullptr;
     d_win_ = c.take<int>(4);
     audio_ = c.take<float>(Bc * (size_t)Ss_);
     pcm_ = c.take<int16_t>(Bc * (size_t)Ss_);
@@ -610,10 +634,19 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     }
     dim3 grid((ncols + 31) / 32, pc.mtiles / MT, B_);
     const size_t smem = std::max<size_t>((size_t)NW * KC * 64, (size_t)NW * MT * 16 * 64) * sizeof(float);
-    const int kh = kbegin(prof_level_ >= 2 ? krow("conv_splitk_kernel") : 0, kflops, kbytes);
+    const bool k16 = pc.wp16 && epi != EPI_CONVT && ((pc.gate && splitk16_ >= 1) || (!pc.gate && splitk16_ >= 2)) &&
+                     (units >= 24 || splitk16_ >= 3);
+    // profile rows carry the instantiation exactly as rocprofv3 prints it (minus spaces)
+    int kh = -1;
+    if (prof_level_ >= 2) {
+      char nm[96];
+      if (k16) snprintf(nm, sizeof(nm), "conv_splitk16_kernel<%s>", pc.gate ? "true,12,2" : "false,8,4");
+      else snprintf(nm, sizeof(nm), "conv_splitk_kernel<%d,%s,%d,%d>", MT, pc.gate ? "true" : "false", NW,
+                    pc.gate ? (NW == 12 ? 2 : 3) : 4);
+      kh = kbegin(krow(std::string(nm)), kflops, kbytes);
+    }
     // MFMA-pipe bound inside the workgroup (>= 24 chunk-tap units) although most CUs idle: 16 output columns
-    if (pc.wp16 && epi != EPI_CONVT && ((pc.gate && splitk16_ >= 1) || (!pc.gate && splitk16_ >= 2)) &&
-        (units >= 24 || splitk16_ >= 3)) {
+    if (k16) {
       dim3 grid16((ncols + 15) / 16, pc.mtiles / MT, B_);
       if (pc.gate) {
         const int nw = 12;
@@ -663,10 +696,13 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
   const int nbuf = (tpb == 1 && pc.nchunks == 1) ? 1 : 2;
   const int HALO = p.xhalo <= 64 ? 64 : 128;
   const size_t smem = (size_t)nbuf * KC * ((BN + HALO + 63) / 64 * 64) * sizeof(float);
-  static const char* knames[] = {"conv_mfma_kernel<2,2,2,2>", "conv_mfma_kernel<1,4,2,1>", "conv_mfma_kernel<1,4,1,1>",
-                                 "conv_mfma_kernel<2,2,1,1>", "conv_mfma_kernel<2,2,2,1>", "conv_mfma_kernel<1,4,1,2>",
-                                 "conv_mfma_kernel<1,4,2,2>"};
-  const int kh = kbegin(prof_level_ >= 2 ? krow(knames[cfg]) : 0, kflops, kbytes);
+  static const char* knames[] = {"2,2,2,2,8", "1,4,2,1,16", "1,4,1,1,16", "2,2,1,1,16", "2,2,2,1,16", "1,4,1,2,16", "1,4,2,2,8"};
+  int kh = -1;
+  if (prof_level_ >= 2) {
+    char nm[96];
+    snprintf(nm, sizeof(nm), "conv_mfma_kernel<%s,%s,%d>", knames[cfg], pc.gate ? "true" : "false", HALO);
+    kh = kbegin(krow(std::string(nm)), kflops, kbytes);
+  }
 #define PE_CONV_LAUNCH(WM, WN, MT, NT, KS, G)                                                                  \
   do {                                                                                                         \
     if (HALO == 64) PE_LAUNCH((conv_mfma_kernel<WM, WN, MT, NT, KS, G, 64>), grid, dim3(256), smem, ls_, p); \
@@ -802,7 +838,7 @@ void Engine::layer_norm(int mode, View in, View res, View out, const float* g, c
   p.lens = lens; p.C = C;
   if (C > LN_COLS * 32) throw std::runtime_error("LayerNorm over more than 256 channels is not supported");
   dim3 grid((Lmax + LN_COLS - 1) / LN_COLS, B_);
-  const int kh = kbegin(prof_level_ >= 2 ? krow("ln_kernel") : 0, 0.0);
+  const int kh = kbegin(prof_level_ >= 2 ? krow(mode == 0 ? "ln_kernel<0>" : mode == 1 ? "ln_kernel<1>" : "ln_kernel<2>") : 0, 0.0);
   if (mode == 0) PE_LAUNCH(ln_kernel<0>, grid, dim3(256), 0, stream_, p);
   else if (mode == 1) PE_LAUNCH(ln_kernel<1>, grid, dim3(256), 0, stream_, p);
   else PE_LAUNCH(ln_kernel<2>, grid, dim3(256), 0, stream_, p);
@@ -827,7 +863,8 @@ void Engine::dds(const DdsW& d, View in, View out, View tmp) {
     p.wp16 = d.w16[i];
     p.nchunks = d.c1x1[i].nchunks;
     p.lens = d_tlens_; p.H = H_;
-    const int kh = kbegin(prof_level_ >= 2 ? krow("dds_layer16_kernel") : 0, 0.0);
+    const int kh = kbegin(prof_level_ >= 2 ? krow(p.nchunks <= 3 ? "dds_layer16_kernel<3>" : p.nchunks <= 6 ? "dds_layer16_kernel<6>"
+                                                                                       : "dds_layer16_kernel<8>") : 0, 0.0);
     const dim3 grid16((Tg_ + 15) / 16, B_);
     const size_t smem16 = ((size_t)2 * p.nchunks * 32 * 16 + 8 * 16) * sizeof(float);
     if (p.nchunks <= 3) PE_LAUNCH(dds_layer16_kernel<3>, grid16, dim3(512), smem16, stream_, p);
@@ -847,6 +884,13 @@ int Engine::krow(const char* name) {
   for (size_t i = 5; i < prof_.size(); ++i)
     if (!strcmp(prof_[i].name, name)) return (int)i;
   prof_.push_back(ProfileRow{name});
+  return (int)prof_.size() - 1;
+}
+int Engine::krow(const std::string& name) {
+  for (size_t i = 5; i < prof_.size(); ++i)
+    if (name == prof_[i].name) return (int)i;
+  names_.push_back(name);
+  prof_.push_back(ProfileRow{names_.back().c_str()});
   return (int)prof_.size() - 1;
 }
 int Engine::kbegin(int row, double flops, double bytes) {
@@ -955,8 +999,8 @@ void Engine::upload(const int64_t* ids, const int64_t* offsets, int B, const flo
                tlens_h_[b] * sizeof(float));
     PE_HIP(hipMemcpyAsync(noise_w_, nb.data(), nb.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
   }
-  ++call_;
   {
+    // {seed, runs so far}: the first kernel of every run() advances the counter on the device (embed_kernel)
     const unsigned long long st[2] = {seed_, call_};
     PE_HIP(hipMemcpyAsync(d_rng_, st, sizeof(st), hipMemcpyHostToDevice, stream_));
   }
@@ -995,7 +1039,7 @@ void Engine::issue_stage_a() {
   prof_begin();
   double fl = 0;
   PE_LAUNCH(embed_kernel, dim3((T + 63) / 64, (H_ + 15) / 16, B), dim3(64), 0, stream_, d_ids_, Ts, d_tlens_, emb_, H_,
-            std::sqrt((float)H_), x_, (long)H_ * Ts, Ts);
+            std::sqrt((float)H_), x_, (long)H_ * Ts, Ts, d_rng_);
   for (auto& e : enc_) {
     conv(e.qkv, x, qkv, d_tlens_, 1, T, EPI_STORE);
     AttnP ap;
@@ -1098,6 +1142,8 @@ void Engine::issue_flow() {
     rp.noise_scale = scales_[0];
     rp.out = zp_; rp.o_bs = (long)C_ * Fs; rp.o_cs = Fs; rp.C = C_;
     PE_LAUNCH(regulate_kernel, dim3((Fmax + 63) / 64, (C_ + 15) / 16, B), dim3(64), 0, stream_, rp);
+    if (zp_keep_)     // tests: z_p, the flow's input (the flow transforms zp_ in place)
+      PE_HIP(hipMemcpyAsync(zp_keep_, zp_, (size_t)B * C_ * Fs * sizeof(float), hipMemcpyDeviceToDevice, stream_));
   }
   auto VF = [&](float* p, int ch) { return View{p, (long)ch * Fs, Fs}; };
   const View fh = VF(fh_, H_), facts = VF(facts_, H_), fskip = VF(fskip_, H_);
@@ -1258,6 +1304,7 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
 // hipGraph cache: the kernel sequence of a stage is captured once per shape bucket and replayed;
 // one utterance is ~160 short launches, which would otherwise be bound by host launch rate.
 void Engine::run_stage(char which, const std::string& key) {
+  const long l0 = g_launches;
 #ifndef PE_EMU
   if (use_graphs_ && !prof_on_) {
     auto it = graphs_.find(key);
@@ -1277,13 +1324,16 @@ void Engine::run_stage(char which, const std::string& key) {
       PE_HIP(hipGraphDestroy(g));
       if (graphs_.size() > 64) drop_graphs();
       it = graphs_.emplace(key, ex).first;
+      graph_launches_[key] = g_launches - l0;
     }
     PE_HIP(hipGraphLaunch((hipGraphExec_t)it->second, stream_));
+    run_launches_ += graph_launches_[key];
     return;
   }
 #endif
   (void)key;
   dispatch_stage(which);
+  run_launches_ += g_launches - l0;
 }
 
 void Engine::dispatch_stage(char which) {
@@ -1300,24 +1350,36 @@ void Engine::drop_graphs() {
   for (auto& kv : graphs_) hipGraphExecDestroy((hipGraphExec_t)kv.second);
 #endif
   graphs_.clear();
+  graph_launches_.clear();
 }
 
 void Engine::run() {
   PE_HIP(hipSetDevice(device_));
   const int B = B_;
   Tg_ = std::min(rup(Tmax_, 32), Ts_);
+  run_launches_ = 0;
   char key[160];
   snprintf(key, sizeof(key), "A|%d|%d|%d|%a|%a|%d", B, Tg_, Ts_, scales_[1], scales_[2], (int)have_noise_w_);
   run_stage('A', key);
+  ++call_;                                    // mirrors the device-side counter bump of this run
   PE_HIP(hipStreamSynchronize(stream_));      // the only data-dependent shape: F
+#ifdef PE_EMU
+  if (const char* pf = getenv("EMU_PLAN_FRAMES"))      // emulator plan-only mode (tests/emu): frames are not computed
+    for (int b = 0; b < B; ++b) h_frames_[b] = atoi(pf);
+#endif
   frames_h_.assign(h_frames_, h_frames_ + B);
   int Fmax = 1;
   for (int b = 0; b < B; ++b) Fmax = std::max(Fmax, frames_h_[b]);
+  if (Fmax > MAX_FRAMES)
+    throw std::runtime_error("utterance too long: more than " + std::to_string(MAX_FRAMES) + " spectrogram frames "
+                             "(check length_scale)");
   Fmax_ = Fmax;
   ensure_stage_b(rup(Fmax, 32));
   Fg_ = std::min(rup(Fmax, 32), Fs_);
   if (have_noise_z_) {
+    const long l0 = g_launches;
     issue_stage_b();                           // host-injected noise (tests): not graph-captured
+    run_launches_ += g_launches - l0;
   } else {
     snprintf(key, sizeof(key), "B|%d|%d|%d|%d|%a", B, Fg_, Fs_, Ts_, scales_[0]);
     run_stage('B', key);
@@ -1362,9 +1424,11 @@ int Engine::stream_begin(const int64_t* ids, int64_t n, const float scales[3], i
   char key[160];
   snprintf(key, sizeof(key), "A|%d|%d|%d|%a|%a|%d", 1, Tg_, Ts_, scales_[1], scales_[2], (int)have_noise_w_);
   run_stage('A', key);
+  ++call_;
   PE_HIP(hipStreamSynchronize(stream_));
   frames_h_.assign(h_frames_, h_frames_ + 1);
   Fmax_ = std::max(1, frames_h_[0]);
+  if (Fmax_ > MAX_FRAMES) throw std::runtime_error("utterance too long: more than " + std::to_string(MAX_FRAMES) + " frames");
   ensure_stage_b(rup(Fmax_, 32));
   Fg_ = std::min(rup(Fmax_, 32), Fs_);
   if (have_noise_z_) {
@@ -1431,7 +1495,26 @@ const std::vector<int32_t>& Engine::durations_host() {
   return dur_h_;
 }
 
-// Per-stage tensors for parity debugging (tests only): name in {x_enc, stats, logw, z_p, audio}.
+// Test hook: what randn_kernel draws for (seed_, call, site) -- the generator of the product path when the caller
+// injects no noise.
+void Engine::debug_randn(int site, uint64_t call, int64_t n, float* out) {
+  if (n <= 0 || !out || site < 0 || site > 1) throw std::runtime_error("debug_randn: bad arguments");
+  PE_HIP(hipSetDevice(device_));
+  float* d = nullptr;
+  unsigned long long* st = nullptr;
+  PE_HIP(hipMalloc((void**)&d, (size_t)n * sizeof(float)));
+  if (hipMalloc((void**)&st, 16) != hipSuccess) { hipFree(d); throw std::runtime_error("debug_randn: out of memory"); }
+  const unsigned long long hst[2] = {seed_, call};
+  hipMemcpy(st, hst, sizeof(hst), hipMemcpyHostToDevice);
+  PE_LAUNCH(randn_kernel, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, stream_, d, (long)n, st, site);
+  hipStreamSynchronize(stream_);
+  hipMemcpy(out, d, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
+  hipFree(d);
+  hipFree(st);
+}
+
+// Per-stage tensors for parity debugging (tests only): name in {x_enc, stats (m_p | logs_p), xg, logw, z_p, z, noise_w,
+// noise_z, audio}.
 void Engine::debug_tensor(const std::string& name, int b, std::vector<float>& out, int* rows, int* cols) {
   PE_HIP(hipStreamSynchronize(stream_));
   const float* src = nullptr;
@@ -1442,6 +1525,12 @@ void Engine::debug_tensor(const std::string& name, int b, std::vector<float>& ou
   else if (name == "xg") { src = xg_ + (size_t)b * H_ * Ts_; R = H_; Cn = tlens_h_[b]; stride = Ts_; }
   else if (name == "logw") { src = logw_ + (size_t)b * Ts_; R = 1; Cn = tlens_h_[b]; stride = Ts_; }
   else if (name == "z") { src = zp_ + (size_t)b * C_ * Fs_; R = C_; Cn = frames_h_[b]; stride = Fs_; }
+  else if (name == "z_p") {
+    if (!zp_keep_) throw std::runtime_error("z_p is only kept with PIPER_HIP_DEBUG_KEEP=1");
+    src = zp_keep_ + (size_t)b * C_ * Fs_; R = C_; Cn = frames_h_[b]; stride = Fs_;
+  }
+  else if (name == "noise_w") { src = noise_w_ + (size_t)b * 2 * Ts_; R = 2; Cn = tlens_h_[b]; stride = Ts_; }
+  else if (name == "noise_z") { src = noise_z_ + (size_t)b * C_ * Fs_; R = C_; Cn = frames_h_[b]; stride = Fs_; }
   else if (name == "audio") { src = audio_ + (size_t)b * Ss_; R = 1; Cn = frames_h_[b] * hop_; stride = Ss_; }
   else throw std::runtime_error("unknown debug tensor " + name);
   out.resize((size_t)R * Cn);

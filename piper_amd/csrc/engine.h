@@ -3,6 +3,7 @@
 // (reference src/cpp/piper.cpp:386-388).
 #pragma once
 #include <cstdint>
+#include <deque>
 #include <map>
 #include <string>
 #include <vector>
@@ -76,6 +77,11 @@ class Engine {
   const std::vector<int32_t>& durations_host();   // concatenated per id, same offsets as ids
   const std::vector<int32_t>& frames_host() const { return frames_h_; }
   void debug_tensor(const std::string& name, int b, std::vector<float>& out, int* rows, int* cols);
+  // test hook: n draws of the engine's N(0,1) generator (randn_kernel) at sampling site 0/1 with the engine's
+  // seed and the given call counter, exactly what run() would draw at that counter
+  void debug_randn(int site, uint64_t call, int64_t n, float* out);
+  uint64_t rng_call() const { return call_; }
+  long run_launches() const { return run_launches_; }   // kernel launches (graph nodes) of the last run()
 
   void set_seed(uint64_t s) { seed_ = s; }
   void set_use_graphs(bool on) { use_graphs_ = on; }
@@ -92,6 +98,7 @@ class Engine {
 
  private:
   // ---- setup
+  void init(const WeightSet& ws);
   float* dev_copy(const std::vector<float>& v);
   float* dev_tensor(const WeightSet& ws, const std::string& name);
   PackedConv pack_conv(const WeightSet& ws, const std::string& wname, const std::string& bname, int dil,
@@ -190,6 +197,8 @@ class Engine {
   bool small_tiles_ = true;                 // 32x32 wave tiles everywhere: occupancy beats register reuse here (profiles/)
   long wide_min_blocks_ = 1L << 40;        // 256-column tiles measured slower than 128 (profiles/): off unless PIPER_HIP_WIDE_MIN is set
   std::map<std::string, void*> graphs_;       // hipGraphExec_t per (stage, shape bucket, scales)
+  std::map<std::string, long> graph_launches_;
+  long run_launches_ = 0;
   unsigned long long* d_rng_ = nullptr;       // {seed, call counter} read by randn_kernel
   float scales_[3] = {0.667f, 1.0f, 0.8f};
   bool have_noise_w_ = false, have_noise_z_ = false;
@@ -247,6 +256,11 @@ class Engine {
   int kbegin(int row, double flops, double bytes = 0);
   void kend(int h);
   int krow(const char* name);
+  int krow(const std::string& name);
+  std::deque<std::string> names_;            // storage of generated profile row names (stable pointers)
+  bool debug_keep_ = false;                   // PIPER_HIP_DEBUG_KEEP=1: keep z_p (the flow's input) for debug_tensor
+  float* zp_keep_ = nullptr;
+  void free_all();
 };
 
 }  // namespace pe

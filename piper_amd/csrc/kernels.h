@@ -758,8 +758,11 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk16_kernel(ConvP p) {
 
 // ------------------------------------------------------------------------------------------------
 // Text-encoder embedding: x[b][h][t] = emb[id][h] * sqrt(H)  (models.py:199-200)
+// The first kernel of every pipeline run also advances the RNG call counter (state[1]) that both randn sites of
+// the run read afterwards, so a replayed graph draws fresh noise on every run without a host copy.
 __global__ void embed_kernel(const int* ids, int ids_bs, const int* lens, const float* emb, int H,
-                             float scale, float* out, long o_bs, int o_cs) {
+                             float scale, float* out, long o_bs, int o_cs, unsigned long long* rng_state) {
+  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) rng_state[1] += 1ull;
   const int b = blockIdx.z;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= lens[b]) return;
@@ -1377,14 +1380,17 @@ __global__ void spline_inverse_kernel(const float* hproj, long h_bs, int h_cs, f
 // ElementwiseAffine reverse + durations (modules.py:407-409; models.py:702-704):
 //   logw = (z0 - m0) * exp(-logs0); w = exp(logw) * length_scale; d = ceil(w);
 //   cum = inclusive prefix sum; frames = max(sum d, 1).   One block per utterance.
+// Sums run in 64 bits and are clamped to MAX_FRAMES + 1 (a single duration to 1e6): an absurd length_scale cannot
+// overflow `cum`, and the host rejects frames > MAX_FRAMES before sizing stage B from it.
+static constexpr int MAX_FRAMES = 60000;      // per-utterance activations stay below the 2 GiB descriptor range
 __global__ __launch_bounds__(256) void duration_kernel(const float* z0, long z_bs, float m0, float es0,
                                                        float length_scale, const int* lens, int* dur,
                                                        int* cum, int d_bs, int* frames, float* logw_out) {
-  __shared__ int part[256];
+  __shared__ long long part[256];
   const int b = blockIdx.x, T = lens[b], tid = threadIdx.x;
   const int per = (T + 255) / 256;
   const int lo = tid * per, hi = (lo + per < T) ? lo + per : T;
-  int s = 0;
+  long long s = 0;
   for (int t = lo; t < hi; ++t) {
     const float logw = (z0[(long)b * z_bs + t] - m0) * es0;
     const float w = expf(logw) * length_scale;
@@ -1398,15 +1404,15 @@ __global__ __launch_bounds__(256) void duration_kernel(const float* z0, long z_b
   part[tid] = s;
   __syncthreads();
   if (tid == 0) {
-    int run = 0;
-    for (int i = 0; i < 256; ++i) { const int v = part[i]; part[i] = run; run += v; }
-    frames[b] = run < 1 ? 1 : run;
+    long long run = 0;
+    for (int i = 0; i < 256; ++i) { const long long v = part[i]; part[i] = run; run += v; }
+    frames[b] = run < 1 ? 1 : (run > MAX_FRAMES ? MAX_FRAMES + 1 : (int)run);
   }
   __syncthreads();
-  int run = part[tid];
+  long long run = part[tid];
   for (int t = lo; t < hi; ++t) {
     run += dur[b * d_bs + t];
-    cum[b * d_bs + t] = run;
+    cum[b * d_bs + t] = run > MAX_FRAMES ? MAX_FRAMES + 1 : (int)run;
   }
 }
 

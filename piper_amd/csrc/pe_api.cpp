@@ -203,14 +203,21 @@ void pe_set_seed(pe_engine* e, uint64_t seed) {
 }
 
 int pe_profile_enable(pe_engine* e, int on) {
-  return guard([&] { e->eng->set_profile(on); });
+  return guard([&] {
+    if (!e) throw std::runtime_error("null engine");
+    e->eng->set_profile(on);
+  });
 }
 int pe_profile_reset(pe_engine* e) {
-  return guard([&] { e->eng->reset_profile(); });
+  return guard([&] {
+    if (!e) throw std::runtime_error("null engine");
+    e->eng->reset_profile();
+  });
 }
 int pe_profile_rows(pe_engine* e) { return e ? (int)e->eng->profile().size() : 0; }
 int pe_profile_get(pe_engine* e, int row, const char** name, double* ms, double* flops, int64_t* launches) {
   return guard([&] {
+    if (!e) throw std::runtime_error("null engine");
     const auto& p = e->eng->profile();
     if (row < 0 || row >= (int)p.size()) throw std::runtime_error("profile row out of range");
     if (name) *name = p[row].name;
@@ -222,6 +229,7 @@ int pe_profile_get(pe_engine* e, int row, const char** name, double* ms, double*
 
 int pe_profile_bytes(pe_engine* e, int row, double* bytes) {
   return guard([&] {
+    if (!e) throw std::runtime_error("null engine");
     const auto& p = e->eng->profile();
     if (row < 0 || row >= (int)p.size() || !bytes) throw std::runtime_error("profile row out of range");
     *bytes = p[row].bytes;
@@ -233,6 +241,7 @@ void* pe_stream(pe_engine* e) { return e ? (void*)e->eng->stream() : nullptr; }
 int pe_debug_tensor(pe_engine* e, const char* name, int32_t b, float* out, int64_t capacity, int32_t* rows,
                     int32_t* cols) {
   return guard([&] {
+    if (!e || !name || !out || !rows || !cols) throw std::runtime_error("null argument");
     std::vector<float> v;
     int r = 0, c = 0;
     e->eng->debug_tensor(name, b, v, &r, &c);
@@ -242,5 +251,16 @@ int pe_debug_tensor(pe_engine* e, const char* name, int32_t b, float* out, int64
     *cols = c;
   });
 }
+
+int pe_debug_randn(pe_engine* e, int32_t site, uint64_t call, int64_t n, float* out) {
+  return guard([&] {
+    if (!e || !out) throw std::runtime_error("null argument");
+    e->eng->debug_randn(site, call, n, out);
+  });
+}
+
+uint64_t pe_rng_calls(pe_engine* e) { return e ? e->eng->rng_call() : 0; }
+
+int64_t pe_run_launches(pe_engine* e) { return e ? (int64_t)e->eng->run_launches() : 0; }
 
 }  // extern "C"

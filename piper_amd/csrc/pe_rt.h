@@ -3,10 +3,11 @@
 // library is never built that way.)
 #pragma once
 
+namespace pe { extern long g_launches; }   // kernel launches issued by this library (captured launches count once)
 #ifdef PE_EMU
 #include "hip_emu.h"
 #define PE_LAUNCH(kernel, grid, block, smem, stream, ...) \
-  emu::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })
+  (++pe::g_launches, emu::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); }))
 #define PE_DYN_SMEM(type, name) type* name = reinterpret_cast<type*>(emu::dyn_smem)
 #define pe_mfma_32x32x2(a, b, c) emu_mfma_32x32x2((a), (b), (c))
 #define pe_mfma_16x16x4(a, b, c) emu_mfma_16x16x4((a), (b), (c))
@@ -35,7 +36,7 @@ inline float pe_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 #else
 #include <hip/hip_runtime.h>
 #define PE_LAUNCH(kernel, grid, block, smem, stream, ...) \
-  hipLaunchKernelGGL(kernel, (grid), (block), (smem), (stream), __VA_ARGS__)
+  do { ++pe::g_launches; hipLaunchKernelGGL(kernel, (grid), (block), (smem), (stream), __VA_ARGS__); } while (0)
 #define PE_DYN_SMEM(type, name) \
   extern __shared__ __attribute__((aligned(16))) unsigned char pe_dyn_smem_raw[]; \
   type* name = reinterpret_cast<type*>(pe_dyn_smem_raw)

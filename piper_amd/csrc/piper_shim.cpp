@@ -12,7 +12,11 @@
 #include <sstream>
 #include <stdexcept>
 
+#include <algorithm>
+#include <cstdio>
+
 #include "../../include/piper_hip.h"
+#include "unicode_tables.h"
 
 namespace piper {
 
@@ -177,6 +181,61 @@ static std::vector<Phoneme> decode_utf8(const std::string& s) {
   return out;
 }
 
+// ---- Unicode: full case folding and NFD (tables generated from unicodedata, scripts/gen_unicode_tables.py)
+static const UniMapEntry* uni_find(const UniMapEntry* idx, int n, char32_t cp) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (idx[mid].cp < cp) lo = mid + 1; else hi = mid;
+  }
+  return (lo < n && idx[lo].cp == cp) ? &idx[lo] : nullptr;
+}
+static int uni_combining(char32_t cp) {
+  int lo = 0, hi = uni_ccc_count;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (uni_ccc[mid].cp < cp) lo = mid + 1; else hi = mid;
+  }
+  return (lo < uni_ccc_count && uni_ccc[lo].cp == cp) ? uni_ccc[lo].ccc : 0;
+}
+static std::vector<Phoneme> casefold(const std::vector<Phoneme>& in) {
+  std::vector<Phoneme> out;
+  out.reserve(in.size());
+  for (Phoneme c : in) {
+    if (const UniMapEntry* e = uni_find(uni_fold_index, uni_fold_count, c))
+      out.insert(out.end(), uni_fold_pool + e->off, uni_fold_pool + e->off + e->n);
+    else out.push_back(c);
+  }
+  return out;
+}
+static std::vector<Phoneme> nfd(const std::vector<Phoneme>& in) {
+  std::vector<Phoneme> out;
+  out.reserve(in.size() + 8);
+  for (Phoneme c : in) {
+    if (c >= 0xAC00 && c <= 0xD7A3) {                       // Hangul syllable: algorithmic L V (T)
+      const uint32_t s = c - 0xAC00;
+      out.push_back(0x1100 + s / 588);
+      out.push_back(0x1161 + (s % 588) / 28);
+      if (s % 28) out.push_back(0x11A7 + s % 28);
+    } else if (const UniMapEntry* e = uni_find(uni_nfd_index, uni_nfd_count, c)) {
+      out.insert(out.end(), uni_nfd_pool + e->off, uni_nfd_pool + e->off + e->n);
+    } else {
+      out.push_back(c);
+    }
+  }
+  // canonical ordering: stable sort of every run of non-starters by combining class
+  size_t i = 0;
+  while (i < out.size()) {
+    if (uni_combining(out[i]) == 0) { ++i; continue; }
+    size_t j = i;
+    while (j < out.size() && uni_combining(out[j]) != 0) ++j;
+    std::stable_sort(out.begin() + i, out.begin() + j,
+                     [](Phoneme a, Phoneme b) { return uni_combining(a) < uni_combining(b); });
+    i = j;
+  }
+  return out;
+}
+
 static void check(int rc) {
   if (rc != 0) throw std::runtime_error(pe_last_error());
 }
@@ -273,7 +332,10 @@ void loadVoice(PiperConfig& config, std::string modelPath, std::string modelConf
   if (root.kind != JVal::Obj) throw std::runtime_error("voice config: top level is not an object");
   parseConfigs(root, voice);
   if (voice.modelConfig.numSpeakers > 1) voice.synthesisConfig.speakerId = speakerId ? speakerId : std::optional<SpeakerId>(0);
-  if (!useCuda) throw std::runtime_error("piper-hip runs on the GPU only: pass useCuda = true (--use-cuda)");
+  // The reference's flag picks the ORT execution provider (piper.cpp:266-274). There is one execution path here,
+  // the GPU voice.session.device, so both values load the same engine (the reference's test.cpp and main.cpp default
+  // pass false and must keep working against this header).
+  (void)useCuda;
   if (voice.session.engine) { pe_destroy(voice.session.engine); voice.session.engine = nullptr; }
   check(pe_create(modelPath.c_str(), voice.session.device, &voice.session.engine));
 }
@@ -283,11 +345,14 @@ void synthesize(std::vector<PhonemeId>& phonemeIds, SynthesisConfig& synthesisCo
   if (!session.engine) throw std::runtime_error("voice model is not loaded");
   const float scales[3] = {synthesisConfig.noiseScale, synthesisConfig.lengthScale, synthesisConfig.noiseW};
   const int64_t offsets[2] = {0, (int64_t)phonemeIds.size()};
+  // "sid" is only fed for multi-speaker voices (piper.cpp:367-377); single-speaker graphs have no such input
   const int64_t sid = synthesisConfig.speakerId.value_or(0);
-  // only the inference call is timed (piper.cpp:385-395): upload + device pipeline; the int16 conversion
-  // (done on the GPU here) and the copy to the caller's vector are outside, like the reference's loops
-  check(pe_upload(session.engine, phonemeIds.data(), offsets, 1, scales, &sid, nullptr));
+  const int64_t* sids = synthesisConfig.speakerId ? &sid : nullptr;
+  // inferSeconds spans what session.Run() spans in the reference (piper.cpp:385-395): inputs handed over in host
+  // memory, result available in host memory = upload + device pipeline + fetch. The copy into the caller's vector
+  // is outside, like the reference's conversion loops (:410-431; the int16 conversion itself runs on the GPU).
   const auto t0 = std::chrono::steady_clock::now();
+  check(pe_upload(session.engine, phonemeIds.data(), offsets, 1, scales, sids, nullptr));
   check(pe_run(session.engine));
   pe_result r;
   check(pe_fetch(session.engine, 0, 1, &r));
@@ -312,8 +377,9 @@ void synthesizeBatch(std::vector<std::vector<PhonemeId>>& phonemeIdLists, Synthe
     flat.insert(flat.end(), ids.begin(), ids.end());
     offsets.push_back((int64_t)flat.size());
   }
-  check(pe_upload(session.engine, flat.data(), offsets.data(), nb, scales, sids.data(), nullptr));
-  const auto t0 = std::chrono::steady_clock::now();
+  const auto t0 = std::chrono::steady_clock::now();     // same span as synthesize(): upload + pipeline + fetch
+  check(pe_upload(session.engine, flat.data(), offsets.data(), nb, scales,
+                  synthesisConfig.speakerId ? sids.data() : nullptr, nullptr));
   check(pe_run(session.engine));
   pe_result r;
   check(pe_fetch(session.engine, 0, 1, &r));
@@ -322,6 +388,10 @@ void synthesizeBatch(std::vector<std::vector<PhonemeId>>& phonemeIdLists, Synthe
     audioBuffers[i].assign(r.pcm + r.sample_offsets[i], r.pcm + r.sample_offsets[i + 1]);
   result.audioSeconds = (double)r.sample_offsets[nb] / (double)synthesisConfig.sampleRate;
   result.realTimeFactor = result.audioSeconds > 0 ? result.inferSeconds / result.audioSeconds : 0.0;
+}
+
+void phonemize_codepoints(const std::string& text, std::vector<std::vector<Phoneme>>& sentencePhonemes) {
+  sentencePhonemes.push_back(nfd(casefold(decode_utf8(text))));
 }
 
 void phonemes_to_ids(const std::vector<Phoneme>& phonemes, const PhonemizeConfig& config,
@@ -344,28 +414,23 @@ void phonemes_to_ids(const std::vector<Phoneme>& phonemes, const PhonemizeConfig
 
 void textToAudio(PiperConfig& config, Voice& voice, std::string text, std::vector<int16_t>& audioBuffer,
                  SynthesisResult& result, const std::function<void()>& audioCallback) {
-  (void)config;
   const SynthesisConfig& sc = voice.synthesisConfig;
   std::size_t sentenceSilenceSamples = 0;
   if (sc.sentenceSilenceSeconds > 0)
     sentenceSilenceSamples = (std::size_t)(sc.sentenceSilenceSeconds * sc.sampleRate * sc.channels);
 
   std::vector<std::vector<Phoneme>> sentences;
-  if (voice.phonemizeConfig.phonemeType == TextPhonemes) {
-    std::vector<Phoneme> cps = decode_utf8(text);
-    if (voice.phonemizeConfig.phonemeMap) {
-      std::vector<Phoneme> mapped;
-      for (Phoneme p : cps) {
-        auto it = voice.phonemizeConfig.phonemeMap->find(p);
-        if (it == voice.phonemizeConfig.phonemeMap->end()) mapped.push_back(p);
-        else mapped.insert(mapped.end(), it->second.begin(), it->second.end());
-      }
-      cps.swap(mapped);
-    }
-    sentences.push_back(std::move(cps));
+  if (voice.phonemizeConfig.phonemeType == eSpeakPhonemes) {
+    // piper.cpp:470-479: phonemize_eSpeak(text, {voice}, phonemes) -- espeak-ng lives on the host, behind the slot
+    if (!config.phonemizer)
+      throw std::runtime_error(
+          "this voice uses eSpeak phonemes: set PiperConfig::phonemizer (e.g. to piper-phonemize's phonemize_eSpeak) "
+          "or pass phoneme ids to piper::synthesize()");
+    config.phonemizer(text, voice.phonemizeConfig.eSpeak.voice, sentences);
   } else {
-    throw std::runtime_error(
-        "eSpeak phonemisation is host-side and not linked into piper-hip: pass phoneme ids to piper::synthesize()");
+    // piper.cpp:480-484: UTF-8 code points as phonemes, default CodepointsPhonemeConfig (case folding + NFD; the
+    // voice's phoneme_map is NOT applied on this path in the reference)
+    phonemize_codepoints(text, sentences);
   }
 
   std::vector<PhonemeId> phonemeIds;
@@ -419,6 +484,20 @@ void textToAudio(PiperConfig& config, Voice& voice, std::string text, std::vecto
     if (audioCallback) {
       audioCallback();      // the callback must copy: the buffer is cleared afterwards (piper.cpp:591-595)
       audioBuffer.clear();
+    }
+  }
+  if (!missingPhonemes.empty()) {     // piper.cpp:600-610
+    auto warn = [&](const std::string& m) {
+      if (config.warn) config.warn(m);
+      else fprintf(stderr, "[piper] warning: %s\n", m.c_str());
+    };
+    warn("Missing " + std::to_string(missingPhonemes.size()) + " phoneme(s) from phoneme/id map!");
+    for (auto& pc : missingPhonemes) {
+      std::string ph;
+      append_utf8((uint32_t)pc.first, ph);
+      char buf[64];
+      snprintf(buf, sizeof(buf), "\" (\\u%04X): %zu time(s)", (unsigned)pc.first, pc.second);
+      warn("Missing \"" + ph + buf);
     }
   }
   if (result.audioSeconds > 0) result.realTimeFactor = result.inferSeconds / result.audioSeconds;

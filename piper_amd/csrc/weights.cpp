@@ -41,7 +41,8 @@ WeightSet parse_blob(const void* data, size_t nbytes) {
     memcpy(&off, r + NAME_BYTES + 24, 8);
     memcpy(&numel, r + NAME_BYTES + 32, 8);
     if (ndim < 0 || ndim > 4) throw std::runtime_error("bad tensor rank in blob");
-    if (off + numel * 4 > nbytes) throw std::runtime_error("truncated weight blob (data)");
+    // overflow-safe: a corrupt blob (also one received over the weight broadcast) must not wrap the bound
+    if (off > nbytes || numel > (nbytes - off) / 4) throw std::runtime_error("truncated weight blob (data)");
     HostTensor ht;
     uint64_t chk = 1;
     for (int d = 0; d < ndim; ++d) {

@@ -197,6 +197,22 @@ class Engine:
                          "bytes": by.value})
         return rows
 
+    def debug_randn(self, site: int, call: int, n: int) -> np.ndarray:
+        """Test hook: n draws of the engine's own N(0,1) generator at sampling site 0/1, run counter `call`."""
+        out = np.zeros(int(n), np.float32)
+        self._check(self._lib.pe_debug_randn(self._h, int(site), int(call), int(n),
+                                             out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
+    @property
+    def run_launches(self) -> int:
+        """Kernel launches (graph nodes) of the last run: the dependent launch chain of one step."""
+        return int(self._lib.pe_run_launches(self._h))
+
+    @property
+    def rng_calls(self) -> int:
+        return int(self._lib.pe_rng_calls(self._h))
+
     @property
     def hip_stream(self) -> int:
         return int(self._lib.pe_stream(self._h) or 0)

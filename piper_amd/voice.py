@@ -12,6 +12,7 @@ package for espeak voices."""
 from __future__ import annotations
 
 import json
+import logging
 import unicodedata
 import wave
 from dataclasses import dataclass
@@ -44,6 +45,9 @@ def phonemes_to_ids_cpp(phonemes, id_map, intersperse_pad: bool = True) -> List[
     return ids
 
 
+_LOGGER = logging.getLogger(__name__)
+
+
 @dataclass
 class PiperVoice:
     session: Engine
@@ -64,7 +68,8 @@ class PiperVoice:
     def phonemize(self, text: str) -> List[List[str]]:
         """Text to phonemes grouped by sentence."""
         if self.config.phoneme_type == PhonemeType.TEXT:
-            return [list(unicodedata.normalize("NFD", text))]
+            # piper_phonemize.phonemize_codepoints with its default casing: full case folding, then NFD; one sentence
+            return [list(unicodedata.normalize("NFD", text.casefold()))]
         if self.config.phoneme_type == PhonemeType.ESPEAK:
             try:
                 from piper_phonemize import phonemize_espeak, tashkeel_run  # type: ignore
@@ -83,6 +88,7 @@ class PiperVoice:
         ids: List[int] = list(id_map[BOS])
         for phoneme in phonemes:
             if phoneme not in id_map:
+                _LOGGER.warning("Missing phoneme from id map: %s", phoneme)
                 continue
             ids.extend(id_map[phoneme])
             ids.extend(id_map[PAD])

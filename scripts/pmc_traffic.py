@@ -11,9 +11,8 @@ import collections, csv, glob, json, os, re, sys
 
 
 def norm(name):
-    n = re.sub(r"\(.*", "", name).replace("void ", "").replace("pe::", "").replace(" ", "")
-    m = re.match(r"(conv_mfma_kernel<\d+,\d+,\d+,\d+)", n)      # bench rows drop KS / GATE / HALO
-    return m.group(1) + ">" if m else n
+    # the engine's level-2 profile rows carry the same spelling (full template arguments, no spaces)
+    return re.sub(r"\(.*", "", name).replace("void ", "").replace("pe::", "").replace(" ", "")
 
 
 def collect(d, counter):

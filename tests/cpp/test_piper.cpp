@@ -19,7 +19,8 @@ int main(int argc, char** argv) {
     piper::PiperConfig config;
     piper::Voice voice;
     std::optional<piper::SpeakerId> speaker;
-    piper::loadVoice(config, argv[1], std::string(argv[1]) + ".json", voice, speaker, true);
+    // useCuda = false is what the reference's own test.cpp:41-42 and main.cpp's default pass: it must load too
+    piper::loadVoice(config, argv[1], std::string(argv[1]) + ".json", voice, speaker, false);
     piper::initialize(config);
 
     std::ofstream wav(argv[2], std::ios::binary);
@@ -81,6 +82,90 @@ int main(int argc, char** argv) {
         return 1;
       }
       voice.synthesisConfig.phonemeSilenceSeconds.reset();
+    }
+    // ---- text front end == piper-phonemize's phonemize_codepoints: full case folding, then NFD
+    {
+      std::vector<std::vector<piper::Phoneme>> a, b, c;
+      piper::phonemize_codepoints("This IS a T\xC3\x89ST \xC3\x85 \xC3\x9F \xEA\xB0\x81", a);   // É, Å, ß (folds to ss), Hangul U+AC01
+      piper::phonemize_codepoints("this is a te\xCC\x81st a\xCC\x8A ss \xEA\xB0\x81", b);
+      const std::u32string want = U"this is a te\u0301st a\u030A ss \u1100\u1161\u11A8";
+      if (a.size() != 1 || a[0] != std::vector<piper::Phoneme>(want.begin(), want.end()) || a[0] != b[0]) {
+        std::cerr << "ERROR: phonemize_codepoints is not casefold + NFD\n";
+        return 1;
+      }
+      // canonical ordering of combining marks: dot below (ccc 220) sorts before acute (ccc 230)
+      piper::phonemize_codepoints("a\xCC\x81\xCC\xA3", c);
+      const std::u32string want2 = U"a\u0323\u0301";
+      if (c[0] != std::vector<piper::Phoneme>(want2.begin(), want2.end())) {
+        std::cerr << "ERROR: NFD canonical ordering\n";
+        return 1;
+      }
+      // upper-case / precomposed input synthesises exactly what its folded + decomposed spelling does
+      voice.synthesisConfig.noiseScale = 0.0f;
+      voice.synthesisConfig.noiseW = 0.0f;
+      std::vector<int16_t> u, l;
+      piper::SynthesisResult ru, rl;
+      std::vector<std::string> warned;
+      config.warn = [&](const std::string& m) { warned.push_back(m); };
+      piper::textToAudio(config, voice, "HELLO THERE", u, ru, nullptr);
+      piper::textToAudio(config, voice, "hello there", l, rl, nullptr);
+      if (u != l || u.empty() || !warned.empty()) {
+        std::cerr << "ERROR: upper-case text differs from its case-folded form (" << u.size() << " vs " << l.size() << ")\n";
+        return 1;
+      }
+      // a phoneme without an id is dropped AND reported (piper.cpp:600-610)
+      std::vector<int16_t> m;
+      piper::textToAudio(config, voice, "ab\xE2\x98\x83\xE2\x98\x83", m, rl, nullptr);
+      if (warned.size() != 2 || warned[0].find("Missing 1 phoneme") == std::string::npos ||
+          warned[1].find("2 time(s)") == std::string::npos || warned[1].find("2603") == std::string::npos) {
+        std::cerr << "ERROR: missing phonemes not reported (" << warned.size() << " message(s))\n";
+        return 1;
+      }
+      config.warn = nullptr;
+    }
+    // ---- eSpeak voices: the host's phonemizer slot (espeak-ng stays on the host)
+    {
+      const std::string cfgPath = std::string(argv[2]) + ".espeak.json";
+      {
+        std::ifstream in(std::string(argv[1]) + ".json");
+        std::stringstream ss;
+        ss << in.rdbuf();
+        std::string js = ss.str();
+        const std::string key = "\"phoneme_type\": \"text\"";
+        const size_t at = js.find(key);
+        if (at == std::string::npos) { std::cerr << "ERROR: fixture config has no phoneme_type text\n"; return 1; }
+        js.replace(at, key.size(), "\"phoneme_type\": \"espeak\"");
+        std::ofstream(cfgPath) << js;
+      }
+      piper::PiperConfig ec;
+      piper::Voice ev;
+      std::optional<piper::SpeakerId> none;
+      piper::loadVoice(ec, argv[1], cfgPath, ev, none, true);
+      ev.synthesisConfig.noiseScale = 0.0f;
+      ev.synthesisConfig.noiseW = 0.0f;
+      std::vector<int16_t> got, want;
+      piper::SynthesisResult r5;
+      bool threw = false;
+      try { piper::textToAudio(ec, ev, "two. sentences", got, r5, nullptr); } catch (const std::runtime_error&) { threw = true; }
+      if (!threw) { std::cerr << "ERROR: eSpeak voice without a phonemizer must throw\n"; return 1; }
+      std::string seenVoice;
+      ec.phonemizer = [&](const std::string& text, const std::string& v, std::vector<std::vector<piper::Phoneme>>& out) {
+        seenVoice = v;                       // a stand-in for phonemize_eSpeak: one "sentence" per '.'-separated part
+        out.emplace_back();
+        for (char ch : text) {
+          if (ch == '.') { out.emplace_back(); continue; }
+          out.back().push_back((piper::Phoneme)(unsigned char)ch);
+        }
+      };
+      int callbacks = 0;
+      std::vector<int16_t> all;
+      piper::textToAudio(ec, ev, "two. sentences", got, r5, [&] { ++callbacks; all.insert(all.end(), got.begin(), got.end()); });
+      if (callbacks != 2 || !got.empty() || all.empty() || seenVoice.empty() || r5.inferSeconds <= 0 || r5.audioSeconds <= 0) {
+        std::cerr << "ERROR: phonemizer slot / per-sentence callback contract (" << callbacks << " callbacks)\n";
+        return 1;
+      }
+      // single-speaker voice: no speaker id is fed (reference omits the "sid" input)
+      if (ev.synthesisConfig.speakerId) { std::cerr << "ERROR: speakerId set on a single-speaker voice\n"; return 1; }
     }
     piper::terminate(config);
     // errors surface as std::runtime_error, like the reference

@@ -140,6 +140,10 @@ static void run_block(unsigned nthreads) {
 }
 
 void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body) {
+  // EMU_PLAN_ONLY=1: record-only mode for checking the host's launch decisions (which instantiation, which grid) on
+  // full-size shapes that would take hours to emulate; nothing is executed
+  static const bool plan_only = getenv("EMU_PLAN_ONLY") && atoi(getenv("EMU_PLAN_ONLY")) != 0;
+  if (plan_only) return;
   unsigned nthreads = block.x * block.y * block.z;
   if (nthreads == 0 || nthreads > MAXT) {
     fprintf(stderr, "hip_emu: bad block size %u\n", nthreads);

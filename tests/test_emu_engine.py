@@ -158,3 +158,79 @@ def test_emulated_splitk16_matches(emu_lib, monkeypatch):
         assert a.shape == b.shape and np.max(np.abs(a - b)) < 2e-6
     o = O.synthesize(w, cfg, ids[0], (0.4, 1.0, 0.7), nw[0], nz[0], sid=2)
     assert np.max(np.abs(outs[1][0] - o["audio"])) < 1e-4
+
+
+def test_absurd_length_scale_is_a_clean_error(emu_lib):
+    """durations are summed in 64 bits and clamped; a frame count beyond the supported maximum is an
+    error message, not an overflowed cumulative sum / a huge allocation."""
+    cfg = W.preset("tiny")
+    eng = Engine(blob=W.pack_blob(cfg, W.synthetic_weights(cfg, 1234)), lib=emu_lib)
+    ids = W.synthetic_phoneme_ids(200, 1, id_max=cfg.n_vocab - 1)
+    with pytest.raises(EngineError, match="too long"):
+        eng.synthesize(ids, (0.0, 1.0e9, 0.0))
+    r = eng.synthesize(ids[:8], (0.0, 1.0, 0.0))          # still usable
+    assert r.pcm[0].size == int(r.frames[0]) * eng.hop
+
+
+def test_rng_counter_advances_per_run_on_emulator(emu_lib):
+    """Every run() draws fresh noise (the first kernel of the pipeline bumps the device-side counter), also when the
+    inputs were uploaded once and run() is repeated -- what bench.py's timed loop does."""
+    cfg = W.preset("tiny")
+    eng = Engine(blob=W.pack_blob(cfg, W.synthetic_weights(cfg, 1234)), lib=emu_lib)
+    eng.set_seed(11)
+    ids = [W.synthetic_phoneme_ids(12, 1, id_max=cfg.n_vocab - 1)]
+    eng.upload(ids, (0.667, 1.0, 0.8))
+    outs = []
+    for run in (1, 2):
+        eng.run()
+        res = eng.fetch(True, False)
+        assert eng.rng_calls == run
+        nz = eng.debug_tensor("noise_z", 0)
+        Fs = 128
+        ref = eng.debug_randn(1, run, cfg.inter * Fs).reshape(cfg.inter, Fs)[:, :nz.shape[1]]
+        assert np.array_equal(nz, ref)
+        outs.append(res.audio[0])
+    assert outs[0].shape != outs[1].shape or not np.array_equal(outs[0], outs[1])
+    x = eng.debug_randn(0, 1, 1 << 14).astype(np.float64)
+    assert abs(x.mean()) < 0.05 and abs(x.var() - 1) < 0.05
+
+
+def test_launch_plan_of_the_baseline_configs():
+    """Host launch logic on the FULL-SIZE BASELINE shapes without executing kernels (emulator plan-only mode): which
+    kernel family each configuration is routed to, and how many launches one utterance costs (the latency figure of
+    merit at batch 1). Runs in a subprocess because the mode is read once per process."""
+    import json
+    import subprocess
+    import sys
+    code = r'''
+import json, os, sys
+sys.path.insert(0, %r)
+import numpy as np
+from piper_amd import _lib as L, weights as W
+from piper_amd.engine import Engine
+lib = L.bind(%r)
+out = {}
+for preset, B in (("medium", 1), ("medium", 64), ("high", 64)):
+    cfg = W.preset(preset)
+    eng = Engine(blob=W.pack_blob(cfg, W.synthetic_weights(cfg, 1234)), lib=lib)
+    ids = [W.synthetic_phoneme_ids(128, i, id_max=129) for i in range(B)]
+    eng.profile_enable(2)
+    eng.upload(ids, (0.667, 1.0, 0.8), noise_w=np.zeros((B, 2, 128), np.float32))
+    eng.run()
+    out["%%s/%%d" %% (preset, B)] = {"launches": eng.run_launches,
+                                  "names": sorted(r["name"] for r in eng.profile()[5:] if r["launches"])}
+    eng.close()
+print(json.dumps(out))
+''' % (ROOT, EMU)
+    env = dict(os.environ, EMU_PLAN_ONLY="1", EMU_PLAN_FRAMES="417")
+    for k in list(env):
+        if k.startswith("PIPER_HIP_"):
+            del env[k]
+    if not os.path.exists(EMU):
+        subprocess.check_call(["make", "-C", ROOT, "emu"])
+    res = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr
+    plan = json.loads(res.stdout.strip().splitlines()[-1])
+    assert plan["medium/1"]["launches"] <= 140
+    assert any(n.startswith("conv_mfma_kernel<2,2,2,1,16,true,") for n in plan["medium/64"]["names"])
+    assert any(n.startswith("conv_mfma_kernel<2,2,2,1,16,true,") for n in plan["high/64"]["names"])

@@ -1,0 +1,341 @@
+"""GPU parity tests of the BATCHED / TILED kernel family (run with -m gpu on an MI355X).
+
+tests/test_gpu_parity.py runs one utterance (or a few tiny ones) per call, which the launcher routes to the
+split-K kernels; the throughput configurations of BASELINE.json (configs[2]: high, 64 x 128 ids; configs[3]: medium,
+64 utterances per GPU) run through the tiled conv_mfma_kernel instantiations instead. Every test here
+
+  * compares the HIP path (through the C ABI) with the CPU oracle on sampled utterances of the batch:
+    integer durations exact, float waveform max |d| < 2e-4, int16 PCM RMS <= 1e-3 (north_star tolerance);
+  * records which kernel instantiations the engine launched (level-2 profile rows carry the instantiation name as
+    rocprofv3 prints it) so that the last test can assert that every instantiation listed in the committed
+    profiles/*kernel_stats.csv has been compared with the oracle in this session.
+"""
+import csv
+import glob
+import json
+import os
+
+import numpy as np
+import pytest
+
+from piper_amd import weights as W
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+RMS_TOL = 1e-3
+TIGHT_AUDIO_TOL = 2e-4
+SCALES = (0.667, 1.0, 0.8)
+
+SEEN = set()          # kernel instantiations whose output has been compared with the oracle in this session
+_weights = {}
+
+
+def voice(preset, seed=1234, **over):
+    key = (preset, seed, tuple(sorted(over.items())))
+    if key not in _weights:
+        cfg = W.preset(preset, **over)
+        _weights[key] = (cfg, W.synthetic_weights(cfg, seed))
+    return _weights[key]
+
+
+def make_engine(monkeypatch, cfg, w, env=None):
+    from piper_amd.engine import Engine
+    for k in ("PIPER_HIP_SPLITK_MAX", "PIPER_HIP_SMALL", "PIPER_HIP_WIDE_MIN", "PIPER_HIP_TPB", "PIPER_HIP_SPLITK16",
+              "PIPER_HIP_WIDE_SPLITK", "PIPER_HIP_FUSE_MRF", "PIPER_HIP_DEBUG_KEEP", "PIPER_HIP_PAR_MRF",
+              "PIPER_HIP_FUSED"):
+        monkeypatch.delenv(k, raising=False)
+    for k, v in (env or {}).items():
+        monkeypatch.setenv(k, str(v))
+    return Engine(blob=W.pack_blob(cfg, w), device=0)     # the knobs are read once, at engine creation
+
+
+def batch_inputs(cfg, lens, seed, zcols=None):
+    id_max = min(cfg.n_vocab - 1, 129)
+    ids = [W.synthetic_phoneme_ids(T, 100 * seed + i, id_max=id_max) if T > 2 else np.array([1, 2][:T], np.int64)
+           for i, T in enumerate(lens)]
+    Tm = max(lens)
+    rng = np.random.default_rng(seed)
+    nw = rng.standard_normal((len(lens), 2, Tm)).astype(np.float32)
+    nz = rng.standard_normal((len(lens), cfg.inter, zcols or (6 * Tm + 64))).astype(np.float32)
+    return ids, nw, nz
+
+
+def pcm_rms(a, b):
+    d = (a.astype(np.float64) - b.astype(np.float64)) / 32767.0
+    return float(np.sqrt(np.mean(d * d))) if d.size else 0.0
+
+
+def run_and_check(eng, cfg, w, ids, nw, nz, sample, scales=SCALES, sids=None):
+    """One profiled batched call; utterances `sample` are compared with the oracle, all of them with the
+    size-independent properties (sample count = frames * hop = sum of durations * hop, peak-normalised PCM)."""
+    from oracle import vits_oracle as O
+    eng.profile_enable(2)
+    eng.profile_reset()
+    r = eng.synthesize_batch(ids, scales, sids=sids, noise_w=nw, noise_z=nz)
+    names = {row["name"] for row in eng.profile()[5:] if row["launches"]}
+    eng.profile_enable(0)
+    durs = eng.durations()
+    off = np.concatenate([[0], np.cumsum([len(x) for x in ids])])
+    wt = O.to_torch(w)
+    for i in range(len(ids)):
+        d = durs[off[i]:off[i + 1]]
+        assert int(r.frames[i]) == max(int(d.sum()), 1)
+        assert r.pcm[i].size == int(r.frames[i]) * eng.hop == r.audio[i].size
+        assert np.max(np.abs(r.pcm[i].astype(np.int32))) == 32767 or np.max(np.abs(r.audio[i])) < 0.01
+    worst = 0.0
+    for i in sample:
+        o = O.synthesize(wt, cfg, ids[i], scales, nw[i], nz[i], sid=None if sids is None else sids[i])
+        assert np.array_equal(durs[off[i]:off[i + 1]], o["durations"]), f"utterance {i}: durations differ"
+        assert r.audio[i].shape == o["audio"].shape
+        d = float(np.max(np.abs(r.audio[i] - o["audio"])))
+        worst = max(worst, d)
+        assert d < TIGHT_AUDIO_TOL, f"utterance {i}: max |d audio| = {d}"
+        assert pcm_rms(r.pcm[i], o["pcm"]) <= RMS_TOL
+    SEEN.update(names)
+    return names, worst
+
+
+def test_high_b64_t128_matches_oracle(monkeypatch):
+    """BASELINE.json configs[2]: en_US-lessac-high architecture, batch of 64 fixed 128-id utterances."""
+    cfg, w = voice("high")
+    eng = make_engine(monkeypatch, cfg, w)
+    ids, nw, nz = batch_inputs(cfg, [128] * 64, seed=31)
+    names, worst = run_and_check(eng, cfg, w, ids, nw, nz, sample=[0, 9, 18, 27, 36, 45, 54, 63])
+    eng.close()
+    assert any(n.startswith("conv_mfma_kernel<") and ",true," in n for n in names), names    # tiled WN gate conv
+    assert any(n.startswith("conv_mfma_kernel<2,2,1,1,16,false,") for n in names), names
+    print("high B=64 kernels:", sorted(names), "worst |d audio| %.2e" % worst)
+
+
+def test_medium_b64_t128_matches_oracle(monkeypatch):
+    """BASELINE.json configs[3], one GPU's share: en_US-lessac-medium architecture, 64 utterances x 128 ids."""
+    cfg, w = voice("medium")
+    eng = make_engine(monkeypatch, cfg, w)
+    ids, nw, nz = batch_inputs(cfg, [128] * 64, seed=32)
+    names, worst = run_and_check(eng, cfg, w, ids, nw, nz, sample=[0, 7, 15, 23, 31, 42, 53, 63])
+    eng.close()
+    assert "conv_mfma_kernel<2,2,2,1,16,true,64>" in names, names
+    assert {"conv_mfma_kernel<2,2,1,1,16,false,64>", "conv_mfma_kernel<2,2,1,1,16,false,128>",
+            "conv_mfma_kernel<1,4,1,1,16,false,64>", "conv_mfma_kernel<1,4,1,1,16,false,128>"} <= names, names
+    print("medium B=64 kernels:", sorted(names), "worst |d audio| %.2e" % worst)
+
+
+def test_medium_b16_ragged_matches_oracle(monkeypatch):
+    """The profiled B=16 configuration with ragged lengths (masking of every utterance inside shared tiles)."""
+    cfg, w = voice("medium")
+    eng = make_engine(monkeypatch, cfg, w)
+    lens = [128, 3, 77, 128, 1, 50, 128, 19, 101, 64, 128, 33, 90, 2, 128, 111]
+    ids, nw, nz = batch_inputs(cfg, lens, seed=33)
+    names, worst = run_and_check(eng, cfg, w, ids, nw, nz, sample=[1, 2, 4, 7, 13, 15], scales=(0.5, 1.2, 0.9))
+    eng.close()
+    print("medium ragged B=16 kernels:", sorted(names), "worst |d audio| %.2e" % worst)
+
+
+# Launcher knobs (read at engine creation) that force each tile configuration of conv_mfma_kernel / each split-K
+# variant on shapes where the default heuristics would pick another one. `expect`: instantiations that must run.
+FORCED = [
+    # every conv of a single utterance through the TILED kernels (gate epilogue, 32-row and 64-row tiles, both halos)
+    ("medium", [128], {"PIPER_HIP_SPLITK_MAX": 0},
+     {"conv_mfma_kernel<2,2,2,1,16,true,64>", "conv_mfma_kernel<2,2,1,1,16,false,64>",
+      "conv_mfma_kernel<1,4,1,1,16,false,64>", "conv_mfma_kernel<2,2,1,1,16,false,128>",
+      "conv_mfma_kernel<1,4,1,1,16,false,128>"}),
+    # large tiles (CFG_A 128x128 incl. its gate form, CFG_B 64x128) -- chosen only when PIPER_HIP_SMALL=0
+    ("medium", [128] * 16, {"PIPER_HIP_SMALL": 0},
+     {"conv_mfma_kernel<2,2,2,2,8,true,64>", "conv_mfma_kernel<2,2,2,2,8,false,64>", "conv_mfma_kernel<1,4,2,1,16,false,64>"}),
+    ("x-low", [64] * 32, {"PIPER_HIP_SMALL": 0}, {"conv_mfma_kernel<1,4,2,1,16,true,64>"}),
+    # 256-column tiles (CFG_C2 / CFG_B2)
+    ("medium", [128] * 16, {"PIPER_HIP_SMALL": 0, "PIPER_HIP_WIDE_MIN": 1},
+     {"conv_mfma_kernel<1,4,1,2,16,false,64>", "conv_mfma_kernel<1,4,2,2,8,false,64>"}),
+    # several column tiles per workgroup (in-kernel slab pipeline across tiles)
+    ("medium", [128, 40], {"PIPER_HIP_SPLITK_MAX": 0, "PIPER_HIP_TPB": 3}, set()),
+    # split-K variants: 4/8-wave only (no 16-column form), 12-wave everywhere, 16-column form everywhere
+    ("medium", [128], {"PIPER_HIP_SPLITK16": 0, "PIPER_HIP_WIDE_SPLITK": 0},
+     {"conv_splitk_kernel<2,true,8,3>", "conv_splitk_kernel<1,false,8,4>", "conv_splitk_kernel<1,false,4,4>"}),
+    ("medium", [96], {"PIPER_HIP_SPLITK16": 0, "PIPER_HIP_WIDE_SPLITK": 2},
+     {"conv_splitk_kernel<2,true,12,2>", "conv_splitk_kernel<1,false,12,4>"}),
+    ("x-low", [64], {"PIPER_HIP_SPLITK16": 0, "PIPER_HIP_WIDE_SPLITK": 0}, {"conv_splitk_kernel<2,true,4,3>"}),
+    ("medium", [128, 17], {"PIPER_HIP_SPLITK16": 3},
+     {"conv_splitk16_kernel<true,12,2>", "conv_splitk16_kernel<false,8,4>"}),
+    ("high", [48], {"PIPER_HIP_SPLITK_MAX": 0}, {"conv_mfma_kernel<2,2,2,1,16,true,64>"}),
+]
+
+
+@pytest.mark.parametrize("preset,lens,env,expect", FORCED,
+                         ids=[f"{p}-B{len(l)}-" + "-".join(f"{k[10:]}{v}" for k, v in e.items()) for p, l, e, _ in FORCED])
+def test_forced_kernel_variants_match_oracle(monkeypatch, preset, lens, env, expect):
+    cfg, w = voice(preset)
+    eng = make_engine(monkeypatch, cfg, w, env)
+    ids, nw, nz = batch_inputs(cfg, lens, seed=41 + len(lens))
+    sample = sorted({0, len(lens) // 2, len(lens) - 1})
+    names, worst = run_and_check(eng, cfg, w, ids, nw, nz, sample=sample)
+    eng.close()
+    assert expect <= names, f"missing {sorted(expect - names)}; launched {sorted(names)}"
+    print(preset, env, "kernels:", sorted(names), "worst |d audio| %.2e" % worst)
+
+
+@pytest.mark.parametrize("preset,T", [("medium", 128), ("high", 96), ("x-low", 64)])
+def test_intermediate_tensors_match_oracle(monkeypatch, preset, T):
+    """Every stage boundary of SynthesizerTrn.infer (models.py:681-722) against the oracle, not only the audio:
+    x (encoder output), m_p / logs_p, logw (the SDP output BEFORE ceil, which the duration compare hides), z_p (length
+    regulator + prior sample), z (flow output)."""
+    from oracle import vits_oracle as O
+    cfg, w = voice(preset)
+    eng = make_engine(monkeypatch, cfg, w, {"PIPER_HIP_DEBUG_KEEP": 1})
+    ids, nw, nz = batch_inputs(cfg, [T, T // 2 + 1], seed=51)
+    r = eng.synthesize_batch(ids, SCALES, noise_w=nw, noise_z=nz)
+    for b in range(2):
+        o = O.synthesize(w, cfg, ids[b], SCALES, nw[b], nz[b], keep=True)
+        stats = eng.debug_tensor("stats", b)
+        C = cfg.inter
+        got = {"x_enc": eng.debug_tensor("x_enc", b), "m_p": stats[:C], "logs_p": stats[C:],
+               "logw": eng.debug_tensor("logw", b)[0], "z_p": eng.debug_tensor("z_p", b), "z": eng.debug_tensor("z", b)}
+        for name, g in got.items():
+            ref = o[name]
+            assert g.shape == ref.shape, (name, g.shape, ref.shape)
+            tol = 1e-4 * max(1.0, float(np.abs(ref).max()))
+            err = float(np.max(np.abs(g - ref)))
+            assert err < tol, f"{preset} utt {b} {name}: max |d| {err} (tol {tol})"
+        assert np.max(np.abs(r.audio[b] - o["audio"])) < TIGHT_AUDIO_TOL
+    eng.close()
+
+
+def test_randn_moments_both_sites(monkeypatch):
+    """The engine's own N(0,1) generator (Philox-4x32-10 + Box-Muller, randn_kernel) -- what the product path and
+    bench.py draw from when no noise is injected: 2^20 draws per site, mean / variance / skew / kurtosis / tails,
+    independence of the two sites and of consecutive runs."""
+    cfg, w = voice("tiny")
+    eng = make_engine(monkeypatch, cfg, w)
+    eng.set_seed(2026)
+    n = 1 << 20
+    a = eng.debug_randn(0, 1, n).astype(np.float64)
+    b = eng.debug_randn(1, 1, n).astype(np.float64)
+    c = eng.debug_randn(0, 2, n).astype(np.float64)
+    for x in (a, b, c):
+        assert np.all(np.isfinite(x))
+        assert abs(x.mean()) < 5e-3
+        assert abs(x.var() - 1.0) < 1e-2
+        assert abs(np.mean(x ** 3)) < 2e-2                    # skewness
+        assert abs(np.mean(x ** 4) - 3.0) < 5e-2              # kurtosis
+        assert abs(np.mean(np.abs(x) > 1.959964) - 0.05) < 2e-3
+        assert abs(np.mean(np.abs(x) > 3.0) - 0.0026998) < 4e-4
+        assert 4.0 < np.abs(x).max() < 7.0
+        assert abs(np.corrcoef(x[:-1], x[1:])[0, 1]) < 5e-3   # neighbouring draws (Box-Muller pairs included)
+    assert abs(np.corrcoef(a, b)[0, 1]) < 5e-3 and abs(np.corrcoef(a, c)[0, 1]) < 5e-3
+    assert not np.array_equal(a, c)
+    eng.close()
+
+
+def test_product_path_draws_from_the_tested_generator(monkeypatch):
+    """Without injected noise the pipeline's two sampling sites hold exactly what pe_debug_randn reports for the
+    run counter, and the counter advances on every run (a replayed hipGraph draws fresh noise)."""
+    cfg, w = voice("tiny")
+    eng = make_engine(monkeypatch, cfg, w)
+    eng.set_seed(77)
+    ids = [W.synthetic_phoneme_ids(40, 3, id_max=cfg.n_vocab - 1), W.synthetic_phoneme_ids(25, 4, id_max=cfg.n_vocab - 1)]
+    eng.upload(ids, SCALES)
+    audio = []
+    for run in (1, 2, 3):
+        eng.run()
+        res = eng.fetch(True, False)
+        assert eng.rng_calls == run
+        Ts = 128                                   # row strides are multiples of 128 columns
+        Fs = -(-int(res.frames.max()) // 128) * 128
+        ref_w = eng.debug_randn(0, run, 2 * 2 * Ts).reshape(2, 2, Ts)
+        ref_z = eng.debug_randn(1, run, 2 * cfg.inter * Fs).reshape(2, cfg.inter, Fs)
+        for b in range(2):
+            nw = eng.debug_tensor("noise_w", b)
+            nz = eng.debug_tensor("noise_z", b)
+            assert np.array_equal(nw, ref_w[b][:, :nw.shape[1]])
+            assert np.array_equal(nz, ref_z[b][:, :nz.shape[1]])
+        audio.append(res.audio[0])
+    assert audio[0].shape != audio[1].shape or not np.array_equal(audio[0], audio[1])
+    eng.close()
+
+
+def test_reference_test_sentences_medium(monkeypatch):
+    """the 7 rows of the reference's etc/test_sentences/test_en-us.jsonl (their
+    phoneme_ids as produced by piper-phonemize, 113..381 ids; fixture tests/golden/phoneme_ids_en-us.json) on the
+    medium architecture, each as its own B=1 call like piper.cpp, and all 7 as one ragged batch."""
+    from oracle import vits_oracle as O
+    rows = json.load(open(os.path.join(ROOT, "tests", "golden", "phoneme_ids_en-us.json"), encoding="utf-8"))["rows"]
+    id_lists = [np.asarray(r["phoneme_ids"], np.int64) for r in rows]
+    assert len(id_lists) == 7 and min(map(len, id_lists)) >= 100
+    cfg, w = voice("medium")
+    eng = make_engine(monkeypatch, cfg, w)
+    Tm = max(map(len, id_lists))
+    rng = np.random.default_rng(61)
+    nw = rng.standard_normal((7, 2, Tm)).astype(np.float32)
+    nz = rng.standard_normal((7, cfg.inter, 6 * Tm)).astype(np.float32)
+    wt = O.to_torch(w)
+    singles = []
+    for i, ids in enumerate(id_lists):
+        o = O.synthesize(wt, cfg, ids, SCALES, nw[i], nz[i])
+        eng.profile_enable(2)
+        r = eng.synthesize(ids, SCALES, noise_w=nw[i], noise_z=nz[i])
+        SEEN.update(row["name"] for row in eng.profile()[5:] if row["launches"])
+        eng.profile_enable(0)
+        assert np.array_equal(eng.durations(), o["durations"])
+        assert np.max(np.abs(r.audio[0] - o["audio"])) < TIGHT_AUDIO_TOL
+        assert pcm_rms(r.pcm[0], o["pcm"]) <= RMS_TOL
+        singles.append(r.pcm[0])
+    rb = eng.synthesize_batch(id_lists, SCALES, noise_w=nw, noise_z=nz)
+    for i in range(7):
+        assert rb.pcm[i].shape == singles[i].shape
+        assert np.max(np.abs(rb.pcm[i].astype(np.int32) - singles[i].astype(np.int32))) <= 2
+    eng.close()
+
+
+def test_full_size_multi_speaker_matches_oracle(monkeypatch):
+    """Speaker conditioning at the catalogue's real dimensions (gin_channels 512, e.g. en_US-libritts-high's graph
+    shape on the medium vocoder): emb_g -> dp.cond / WN.cond_layer / dec.cond (models.py:692-696)."""
+    cfg, w = voice("medium", n_speakers=12, gin=512)
+    eng = make_engine(monkeypatch, cfg, w)
+    ids, nw, nz = batch_inputs(cfg, [90, 128, 31], seed=71)
+    sids = [11, 0, 5]
+    run_and_check(eng, cfg, w, ids, nw, nz, sample=[0, 1, 2], sids=sids)
+    # a different speaker changes the audio; the same speaker alone reproduces its batched result
+    r1 = eng.synthesize(ids[0], SCALES, sid=11, noise_w=nw[0], noise_z=nz[0])
+    r2 = eng.synthesize(ids[0], SCALES, sid=3, noise_w=nw[0], noise_z=nz[0])
+    rb = eng.synthesize_batch(ids, SCALES, sids=sids, noise_w=nw, noise_z=nz)
+    assert np.max(np.abs(r1.pcm[0].astype(np.int32) - rb.pcm[0].astype(np.int32))) <= 2
+    assert r1.audio[0].shape != r2.audio[0].shape or np.max(np.abs(r1.audio[0] - r2.audio[0])) > 1e-3
+    eng.close()
+
+
+def test_randomised_stress_sweep(monkeypatch):
+    """Seeded random lengths / batch sizes / scales / speakers over the medium, high, x-low and multi-speaker
+    architectures (was scripts/stress_parity.py, builder-run only)."""
+    rng = np.random.default_rng(2026)
+    worst = 0.0
+    for preset, tmax, cases in (("medium", 220, 10), ("high", 90, 4), ("tiny-high-ms", 60, 6), ("x-low", 120, 4)):
+        cfg, w = voice(preset, seed=99)
+        eng = make_engine(monkeypatch, cfg, w)
+        for c in range(cases):
+            B = int(rng.integers(1, 7))
+            lens = [int(rng.integers(1, tmax)) for _ in range(B)]
+            ids, nw, nz = batch_inputs(cfg, lens, seed=1000 + 17 * c, zcols=8 * max(lens) + 64)
+            scales = (float(rng.uniform(0, 1)), float(rng.uniform(0.6, 1.5)), float(rng.uniform(0, 1)))
+            sids = [int(rng.integers(0, cfg.n_speakers)) for _ in range(B)] if cfg.n_speakers > 1 else None
+            _, d = run_and_check(eng, cfg, w, ids, nw, nz, sample=range(B), scales=scales, sids=sids)
+            worst = max(worst, d)
+        eng.close()
+    print("stress sweep worst |d audio| = %.2e" % worst)
+
+
+def test_every_profiled_instantiation_is_parity_tested():
+    """Closes the loop with profiles/: every templated pe:: kernel instantiation that appears in a committed
+    rocprofv3 kernel-stats summary must have run inside one of the oracle comparisons above."""
+    if not SEEN:
+        pytest.skip("run the whole module: this test checks the union of the instantiations the others launched")
+    profiled = set()
+    for path in glob.glob(os.path.join(ROOT, "profiles", "*kernel_stats.csv")):
+        with open(path, newline="") as f:
+            for row in csv.DictReader(f):
+                n = row.get("Name", "")
+                if "pe::" in n and "<" in n:
+                    n = n.replace("void ", "").replace("pe::", "")
+                    profiled.add(n[:n.index("(")].replace(" ", ""))
+    assert profiled, "no committed kernel-stats summaries found"
+    missing = sorted(profiled - SEEN)
+    assert not missing, f"profiled but never compared with the oracle: {missing}; seen: {sorted(SEEN)}"

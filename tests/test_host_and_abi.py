@@ -172,3 +172,46 @@ def test_jsonl_drivers_on_emulator(tmp_path):
     rep = json.loads(buf.getvalue())
     assert set(rep) == {"load_sec", "rtf_mean", "rtf_stdev", "rtfs"} and len(rep["rtfs"]) == 2
     assert all(r > 0 for r in rep["rtfs"]) and rep["load_sec"] > 0
+
+
+def test_blob_parser_survives_hostile_offsets(lib):
+    """a record whose offset + 4*numel wraps uint64 must be rejected, not memcpy'd."""
+    cfg = W.preset("tiny")
+    blob = bytearray(W.pack_blob(cfg, W.synthetic_weights(cfg, 1)))
+    head = 8 + 4 * W.ARCH_INTS + 8
+    rec = head                                    # first record: name[96] ndim dims[4] pad offset numel
+    import struct
+    for off, numel in ((2 ** 64 - 64, 32), (len(blob) - 8, 2 ** 62), (2 ** 63, 2 ** 62)):
+        bad = bytearray(blob)
+        struct.pack_into("<QQ", bad, rec + W.NAME_BYTES + 24, off, numel)
+        h = C.c_void_p()
+        assert lib.pe_create_from_blob(bytes(bad), len(bad), 0, C.byref(h)) != 0
+        assert b"truncated" in lib.pe_last_error() or b"mismatch" in lib.pe_last_error()
+
+
+def test_null_handles_are_errors_not_crashes(lib):
+    name, ms, fl, n, by = C.c_char_p(), C.c_double(), C.c_double(), C.c_int64(), C.c_double()
+    assert lib.pe_profile_enable(None, 1) != 0
+    assert lib.pe_profile_reset(None) != 0
+    assert lib.pe_profile_rows(None) == 0
+    assert lib.pe_profile_get(None, 0, C.byref(name), C.byref(ms), C.byref(fl), C.byref(n)) != 0
+    assert lib.pe_profile_bytes(None, 0, C.byref(by)) != 0
+    r, c = C.c_int32(), C.c_int32()
+    buf = (C.c_float * 4)()
+    assert lib.pe_debug_tensor(None, b"z", 0, buf, 4, C.byref(r), C.byref(c)) != 0
+    assert lib.pe_debug_randn(None, 0, 1, 4, buf) != 0
+    assert lib.pe_rng_calls(None) == 0 and lib.pe_run_launches(None) == 0
+    lib.pe_destroy(None)
+
+
+def test_text_front_end_casefold_nfd_matches_cpp():
+    """phoneme_type "text": piper-phonemize's phonemize_codepoints = full case folding, then NFD. The
+    Python mirror must agree with the C++ shim (tests/cpp/test_piper.cpp checks the same strings there)."""
+    g = json.load(open(os.path.join(GOLD, "tiny_voice.onnx.json"), encoding="utf-8"))
+    v = PiperVoice(session=None, config=PiperConfig.from_dict(g))
+    assert v.phonemize("This IS a TÉST Å ß 각") == [list("this is a tést å ss 각")]
+    assert v.phonemize("ạ́") == [list("ạ́")]
+    assert v.phonemes_to_ids(v.phonemize("HELLO")[0]) == v.phonemes_to_ids(v.phonemize("hello")[0])
+    # the generated C++ tables are exactly unicodedata's
+    hdr = open(os.path.join(ROOT, "piper_amd", "csrc", "unicode_tables.h")).read()
+    assert f"uni_fold_count = {sum(1 for c in map(chr, range(0x110000)) if not 0xD800 <= ord(c) <= 0xDFFF and c.casefold() != c)};" in hdr
