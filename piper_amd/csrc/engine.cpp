@@ -1,5 +1,6 @@
 #include "engine.h"
 #include "kernels.h"
+#include "mrf2.h"
 
 #include <algorithm>
 #include <cmath>
@@ -213,6 +214,7 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
 }
 
 void Engine::init(const WeightSet& ws) {
+  if (const char* t = getenv("PIPER_HIP_MRF2")) mrf2_mode_ = atoi(t);     // A/B knob: 0 = conv-by-conv MRF stages
   memcpy(arch_, ws.arch, sizeof(arch_));
   PE_HIP(hipSetDevice(device_));
   PE_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
@@ -325,22 +327,31 @@ void Engine::init(const WeightSet& ws) {
       for (int j = 0; j < nk; ++j) {
         const std::string rb = "dec.resblocks." + std::to_string(i * nk + j);
         std::vector<PackedConv> cv;
+        std::vector<UpStage::HostConv> hv;
+        auto add = [&](const std::string& wn, const std::string& bn, int dil) {
+          cv.push_back(pack_conv(ws, wn, bn, dil, -1, false, 0, 0));
+          const HostTensor& w = ws.get(wn);
+          UpStage::HostConv h;
+          h.w = w.data; h.co = (int)w.dims[0]; h.ci = (int)w.dims[1]; h.k = (int)w.dims[2]; h.dil = dil;
+          h.bias = cv.back().bias;
+          hv.push_back(std::move(h));
+        };
         for (int d = 0; d < nd; ++d) {
           const int dil = arch_[A_RBDIL0 + j * MAX_DIL + d];
           const std::string s = std::to_string(d);
           if (arch_[A_RESBLOCK] == 1) {
-            cv.push_back(pack_conv(ws, rb + ".convs1." + s + ".weight", rb + ".convs1." + s + ".bias", dil, -1,
-                                   false, 0, 0));
-            cv.push_back(pack_conv(ws, rb + ".convs2." + s + ".weight", rb + ".convs2." + s + ".bias", 1, -1,
-                                   false, 0, 0));
+            add(rb + ".convs1." + s + ".weight", rb + ".convs1." + s + ".bias", dil);
+            add(rb + ".convs2." + s + ".weight", rb + ".convs2." + s + ".bias", 1);
           } else {
-            cv.push_back(pack_conv(ws, rb + ".convs." + s + ".weight", rb + ".convs." + s + ".bias", dil, -1,
-                                   false, 0, 0));
+            add(rb + ".convs." + s + ".weight", rb + ".convs." + s + ".bias", dil);
           }
         }
         st.rb.push_back(cv);
+        st.rb_host.push_back(std::move(hv));
       }
       build_mrf(st);
+      build_mrf2(st);
+      st.rb_host.clear();
       ups_.push_back(st);
     }
     const HostTensor& pw = ws.get("dec.conv_post.weight");
@@ -409,6 +420,9 @@ void Engine::init(const WeightSet& ws) {
                          (const void*)mrf_fused_kernel<32, 4, 8, 320>, (const void*)mrf_fused_kernel<32, 4, 8, 384>,
                          (const void*)mrf_fused_kernel<64, 4, 8, 256>};
     for (const void* k : ks3) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    const void* ks4[] = {(const void*)mrf2_kernel<32, 16, 1, 2, 1, 368>, (const void*)mrf2_kernel<32, 16, 1, 2, 1, 400>,
+                         (const void*)mrf2_kernel<64, 16, 2, 1, 1, 240>};
+    for (const void* k : ks4) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
   }
 #endif
   static const char* rows[] = {"text_encoder", "duration_predictor", "regulate+flow", "hifigan", "post+pcm"};
@@ -823,6 +837,160 @@ void Engine::mrf(const UpStage& st, View x, View out, const int* lens, int len_m
   else if (st.mrf_ws == 320) PE_MRF32(320);
   else PE_MRF32(384);
 #undef PE_MRF32
+  kend(kh);
+}
+
+
+// Second-generation fused MRF stage (mrf2.h): flattens the resblocks of a <= 64-channel stage into phases (one per
+// conv), cuts every conv's (chunk, tap) steps into weight segments of at most one ring half, and writes the weights as
+// one stream in execution order. ResBlock2 (modules.py:355-364): x <- x + c_d(lrelu(x)); ResBlock1 (:301-314):
+// x <- x + c2_d(lrelu(c1_d(lrelu(x)))).
+void Engine::build_mrf2(UpStage& st) {
+  const int ch = st.ch;
+  if (!mrf2_mode_ || ch > 64 || st.rb_host.empty()) return;
+  // 32-channel stages: a wave owns one 16-row tile of 8 column groups; 64-channel stages: two row tiles (one B
+  // operand feeds two MFMAs) of 8 column groups
+  const int CP = ch <= 32 ? 32 : 64, MS = CP / 16, NCH = CP / KC, NW = 16, MSW = CP == 32 ? 1 : 2, NCG = NW / (MS / MSW);
+  const int STEPF = MS * 512, RINGF = 4 * 64 * NW, SEGSTEPS = RINGF / STEPF;
+  const bool rb1 = arch_[A_RESBLOCK] == 1;
+  std::vector<Mrf2Phase> phases;
+  std::vector<Mrf2Seg> segs;
+  std::vector<float> wstream;
+  int hx = 0;
+  for (size_t j = 0; j < st.rb_host.size(); ++j) {
+    auto& hv = st.rb_host[j];
+    const int n = (int)hv.size();
+    if (n == 0 || (rb1 && (n & 1))) return;
+    int e = 0;
+    for (auto& h : hv) {
+      if (!(h.k & 1) || h.ci != ch || h.co != ch) return;
+      e += h.dil * (h.k - 1) / 2;
+    }
+    hx = std::max(hx, e);
+    for (int i = 0; i < n; ++i) {
+      const auto& h = hv[i];
+      e -= h.dil * (h.k - 1) / 2;
+      Mrf2Phase P{};
+      P.bias = h.bias; P.ntaps = h.k; P.dil = h.dil; P.e = e;
+      const bool last = i == n - 1;
+      if (rb1) {
+        if (!(i & 1)) { P.src = 0; P.dst = 1; P.flags = 0; }
+        else { P.src = 1; P.dst = last ? -1 : 0; P.flags = MRF2_RES | MRF2_KEEP; }
+      } else {
+        P.src = i == 0 ? 0 : 1; P.dst = last ? -1 : 1; P.flags = MRF2_RES | MRF2_KEEP;
+        if (n > 2) return;             // a longer ResBlock2 chain would need ping-pong chain buffers
+      }
+      if (last) P.flags |= MRF2_FINAL;
+      if (i == 0) P.flags |= MRF2_INIT | ((rb1 && j > 0) ? MRF2_RESTAGE : 0);
+      // weight segments: steps = (chunk, tap), chunk-major; one step = [16-row tile][q][lane][4] with lane ->
+      // (row = lane & 15, k = lane >> 4), float4 element jj of group q = k-step 4q + jj = input channel chunk*32 + 4s + k
+      P.seg0 = (int)segs.size();
+      const int nsteps = NCH * h.k;
+      for (int s0 = 0; s0 < nsteps; s0 += SEGSTEPS) {
+        Mrf2Seg sg{};
+        sg.step0 = s0; sg.nsteps = std::min(SEGSTEPS, nsteps - s0); sg.woff = (int)wstream.size();
+        wstream.resize(wstream.size() + (size_t)sg.nsteps * STEPF, 0.f);
+        for (int st_i = 0; st_i < sg.nsteps; ++st_i) {
+          const int step = s0 + st_i, c = step / h.k, tap = step % h.k;
+          for (int ms = 0; ms < MS; ++ms)
+            for (int q = 0; q < 2; ++q)
+              for (int lane = 0; lane < 64; ++lane)
+                for (int jj = 0; jj < 4; ++jj) {
+                  const int row = ms * 16 + (lane & 15), ci = c * KC + 4 * (4 * q + jj) + (lane >> 4);
+                  if (row < ch && ci < ch)
+                    wstream[sg.woff + ((size_t)(st_i * MS + ms) * 2 + q) * 256 + lane * 4 + jj] =
+                        h.w[((size_t)row * ch + ci) * h.k + tap];
+                }
+        }
+        segs.push_back(sg);
+      }
+      P.nseg = (int)segs.size() - P.seg0;
+      phases.push_back(P);
+    }
+  }
+  // geometry: output columns per workgroup, window, units per wave -- the largest N whose LDS fits
+  const int hxa = rup(hx, 16);
+  int N = 0, WS = 0;
+  for (int n : {256, 128, 64}) {
+    int ws = hxa + n + hx;
+    ws = rup(ws, 32) + 16;
+    if (ws - 32 >= hxa + n + hx) ws -= 32;         // smallest value == 16 (mod 32) that covers the window
+    const size_t bytes = ((size_t)2 * RINGF + (size_t)2 * CP * ws + 128) * sizeof(float);
+    if (bytes <= 160u * 1024u) { N = n; WS = ws; break; }
+  }
+  if (!N) return;
+  const int cu_lo = (hxa - hx) / 16, cu_hi = (hxa + N + hx + 15) / 16;
+  const int nleft = hxa / 16 - cu_lo, nhalo = cu_hi - cu_lo - N / 16;
+  const int ou = N / 16 / NCG, hu = (nhalo + NCG - 1) / NCG;       // output / halo units per wave
+  if (N % (16 * NCG) || ou < 1 || ou > 2 || hu > 2 || (ou == 2 && hu == 2)) return;
+  {
+    const int key = CP * 1000000 + ou * 100000 + hu * 10000 + WS;       // the instantiated geometries (mrf2())
+    if (key != 32210368 && key != 32210400 && key != 64110240) return;
+  }
+  {
+    // MFMA work relative to the unfused convs (halo recompute in 16-column units): fuse only when it stays moderate
+    double done = 0, need = 0;
+    for (auto& P : phases) {
+      const int lo = (hxa - P.e) / 16, hi = (hxa + N + P.e + 15) / 16;
+      done += (double)(hi - lo) * 16 * P.ntaps;
+      need += (double)N * P.ntaps;
+    }
+    st.m2_recompute = done / need;
+    if (mrf2_mode_ == 1 && st.m2_recompute > 1.6) return;          // PIPER_HIP_MRF2=2 forces it (tests)
+  }
+  auto up = [&](const void* src, size_t bytes) {
+    void* d = nullptr;
+    PE_HIP(hipMalloc(&d, bytes));
+    PE_HIP(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+    owned_.push_back(d);
+    return d;
+  };
+  st.m2_phases = up(phases.data(), phases.size() * sizeof(Mrf2Phase));
+  st.m2_segs = up(segs.data(), segs.size() * sizeof(Mrf2Seg));
+  st.m2_w = (float*)up(wstream.data(), wstream.size() * sizeof(float));
+  weight_bytes_ += wstream.size() * sizeof(float);
+  st.m2_nphases = (int)phases.size(); st.m2_nsegs = (int)segs.size(); st.m2_wfloats = (int)wstream.size();
+  st.m2_cp = CP; st.m2_n = N; st.m2_ws = WS; st.m2_hxa = hxa; st.m2_cu_lo = cu_lo; st.m2_cu_hi = cu_hi;
+  st.m2_ou = ou; st.m2_hu = std::max(hu, 1); st.m2_nleft = nleft; st.m2_nhalo = nhalo;
+}
+
+void Engine::mrf2(const UpStage& st, View x, View out, const int* lens, int len_mul, int Lmax) {
+  Mrf2P p;
+  p.x = x.p; p.x_bs = x.bs; p.x_cs = x.cs;
+  p.out = out.p; p.o_bs = out.bs; p.o_cs = out.cs;
+  p.lens = lens; p.len_mul = len_mul;
+  p.phases = static_cast<const Mrf2Phase*>(st.m2_phases); p.nphases = st.m2_nphases;
+  p.segs = static_cast<const Mrf2Seg*>(st.m2_segs); p.nsegs = st.m2_nsegs;
+  p.wstream = st.m2_w; p.wfloats = st.m2_wfloats;
+  p.C = st.ch; p.N = st.m2_n; p.WS = st.m2_ws; p.hxa = st.m2_hxa; p.cu_lo = st.m2_cu_lo; p.cu_hi = st.m2_cu_hi;
+  p.nleft = st.m2_nleft; p.nhalo = st.m2_nhalo;
+  p.slope = 0.1f;                            // modules.py LRELU_SLOPE
+  p.alpha = 1.0f / (float)st.rb.size();
+  double kflops = 0, kbytes = 0;
+  if (prof_level_ >= 2) {
+    double cols = 0;
+    for (int b = 0; b < B_; ++b) cols += (double)frames_h_[b] * len_mul;
+    double macs = 0;
+    for (auto& cv : st.rb)
+      for (auto& c : cv) macs += c.macs_per_col;
+    kflops = 2.0 * macs * cols;
+    kbytes = 8.0 * st.ch * cols + 4.0 * st.m2_wfloats;      // one read of x, one write of the mean, the weights once
+  }
+  const int NW = 16;
+  const size_t smem = ((size_t)2 * 4 * 64 * NW + (size_t)2 * st.m2_cp * st.m2_ws + 128) * sizeof(float);
+  dim3 grid((Lmax + st.m2_n - 1) / st.m2_n, B_);
+  char nm[64];
+  snprintf(nm, sizeof(nm), "mrf2_kernel<%d,%d,%d,%d,%d,%d>", st.m2_cp, NW, st.m2_cp == 32 ? 1 : 2, st.m2_ou, st.m2_hu,
+           st.m2_ws);
+  const int kh = prof_level_ >= 2 ? kbegin(krow(std::string(nm)), kflops, kbytes) : -1;
+#define PE_MRF2(CP_, OU_, HU_, WS_) \
+  PE_LAUNCH((mrf2_kernel<CP_, 16, (CP_ == 32 ? 1 : 2), OU_, HU_, WS_>), grid, dim3(64 * NW), smem, ls_, p)
+  // instantiated geometries: medium / x-low (ResBlock2 3,5,7: halo 45) and high (ResBlock1 3,7,11: halo 60) stages
+  if (st.m2_cp == 32 && st.m2_ou == 2 && st.m2_hu == 1 && st.m2_ws == 368) PE_MRF2(32, 2, 1, 368);
+  else if (st.m2_cp == 32 && st.m2_ou == 2 && st.m2_hu == 1 && st.m2_ws == 400) PE_MRF2(32, 2, 1, 400);
+  else if (st.m2_cp == 64 && st.m2_ou == 1 && st.m2_hu == 1 && st.m2_ws == 240) PE_MRF2(64, 1, 1, 240);
+  else throw std::runtime_error("internal: no mrf2_kernel instantiation for this stage geometry");
+#undef PE_MRF2
   kend(kh);
 }
 
@@ -1256,7 +1424,11 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
       const size_t need = (size_t)B * st.ch * Ls;
       const long blocks64 = (long)((Lmax + 63) / 64) * ((st.ch + 63) / 64) * B;
       const bool par = par_mrf_ && !prof_on_ && nk >= 2 && nk <= 3 && blocks64 < 700 && need <= side_floats_;
-      if (fuse_mrf_ && st.mrf_steps) {
+      if (mrf2_mode_ && st.m2_phases && !fuse_mrf_) {
+        mrf2(st, u, xs, lens, mult, Lmax);
+        for (auto& cv : st.rb)
+          for (auto& c : cv) fl += 2.0 * fsum * mult * c.macs_per_col;
+      } else if (fuse_mrf_ && st.mrf_steps) {
         mrf(st, u, xs, lens, mult, Lmax);
         for (auto& cv : st.rb)
           for (auto& c : cv) fl += 2.0 * fsum * mult * c.macs_per_col;

@@ -171,7 +171,17 @@ class Engine {
     void* mrf_steps = nullptr;
     int mrf_nsteps = 0, mrf_hx = 0, mrf_ws = 0, mrf_cp = 0, mrf_nbuf = 0;
     double mrf_macs_per_col = 0;
+    // second-generation fused MRF stage (mrf2_kernel, mrf2.h): device tables, or null
+    struct HostConv { std::vector<float> w; int co = 0, ci = 0, k = 0, dil = 1; const float* bias = nullptr; };
+    std::vector<std::vector<HostConv>> rb_host;   // host copies of the resblock convs, dropped after build_mrf2
+    void* m2_phases = nullptr; void* m2_segs = nullptr; float* m2_w = nullptr;
+    int m2_nphases = 0, m2_nsegs = 0, m2_wfloats = 0, m2_cp = 0, m2_n = 0, m2_ws = 0, m2_hxa = 0, m2_cu_lo = 0,
+        m2_cu_hi = 0, m2_ou = 0, m2_hu = 0, m2_nleft = 0, m2_nhalo = 0;
+    double m2_recompute = 0;
   };
+  void build_mrf2(UpStage& st);
+  void mrf2(const UpStage& st, View x, View out, const int* lens, int len_mul, int Lmax);
+  int mrf2_mode_ = 1;                       // PIPER_HIP_MRF2: 0 off (conv by conv), 1 fused stage kernel where it applies
   void build_mrf(UpStage& st);
   void mrf(const UpStage& st, View x, View out, const int* lens, int len_mul, int Lmax);
   // The fused MRF stage kernel moves ~3x fewer HBM bytes but is LDS-capacity bound to 2 waves per SIMD; since the

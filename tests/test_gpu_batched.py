@@ -43,7 +43,7 @@ def make_engine(monkeypatch, cfg, w, env=None):
     from piper_amd.engine import Engine
     for k in ("PIPER_HIP_SPLITK_MAX", "PIPER_HIP_SMALL", "PIPER_HIP_WIDE_MIN", "PIPER_HIP_TPB", "PIPER_HIP_SPLITK16",
               "PIPER_HIP_WIDE_SPLITK", "PIPER_HIP_FUSE_MRF", "PIPER_HIP_DEBUG_KEEP", "PIPER_HIP_PAR_MRF",
-              "PIPER_HIP_FUSED"):
+              "PIPER_HIP_FUSED", "PIPER_HIP_MRF2"):
         monkeypatch.delenv(k, raising=False)
     for k, v in (env or {}).items():
         monkeypatch.setenv(k, str(v))
@@ -325,13 +325,38 @@ def test_randomised_stress_sweep(monkeypatch):
     print("stress sweep worst |d audio| = %.2e" % worst)
 
 
+@pytest.mark.parametrize("preset,lens", [("medium", [128, 37]), ("medium", [100] * 12), ("high", [64, 9]), ("x-low", [64])])
+def test_fused_mrf2_stage_kernel_matches_unfused_and_oracle(monkeypatch, preset, lens):
+    """mrf2_kernel (one launch per <= 64-channel MRF stage: every resblock conv out of LDS, activated tensors, residuals
+    and the MRF sum in registers) against the conv-by-conv schedule (PIPER_HIP_MRF2=0) and the oracle."""
+    cfg, w = voice(preset)
+    ids, nw, nz = batch_inputs(cfg, lens, seed=81)
+    fused = make_engine(monkeypatch, cfg, w)
+    names, worst = run_and_check(fused, cfg, w, ids, nw, nz, sample=sorted({0, len(lens) - 1}))
+    assert any(n.startswith("mrf2_kernel<") for n in names), names
+    a = fused.synthesize_batch(ids, SCALES, noise_w=nw, noise_z=nz)
+    fused.close()
+    plain = make_engine(monkeypatch, cfg, w, {"PIPER_HIP_MRF2": 0})
+    names0, _ = run_and_check(plain, cfg, w, ids, nw, nz, sample=[0])
+    assert not any(n.startswith("mrf2_kernel<") for n in names0)
+    b = plain.synthesize_batch(ids, SCALES, noise_w=nw, noise_z=nz)
+    plain.close()
+    for i in range(len(lens)):
+        assert a.audio[i].shape == b.audio[i].shape
+        assert np.max(np.abs(a.audio[i] - b.audio[i])) < 2e-5
+    print(preset, "mrf2 kernels:", sorted(n for n in names if n.startswith("mrf2")), "worst |d audio| %.2e" % worst)
+
+
 def test_every_profiled_instantiation_is_parity_tested():
     """Closes the loop with profiles/: every templated pe:: kernel instantiation that appears in a committed
     rocprofv3 kernel-stats summary must have run inside one of the oracle comparisons above."""
     if not SEEN:
         pytest.skip("run the whole module: this test checks the union of the instantiations the others launched")
     profiled = set()
-    for path in glob.glob(os.path.join(ROOT, "profiles", "*kernel_stats.csv")):
+    # r01_v2 / r01_v3 / r01_kernel_stats_v1 are history (kernel generations that no longer exist in the source)
+    paths = [q for q in glob.glob(os.path.join(ROOT, "profiles", "*kernel_stats.csv"))
+             if not os.path.basename(q).startswith(("r01_v", "r01_kernel_stats_v"))]
+    for path in paths:
         with open(path, newline="") as f:
             for row in csv.DictReader(f):
                 n = row.get("Name", "")
@@ -341,3 +366,4 @@ def test_every_profiled_instantiation_is_parity_tested():
     assert profiled, "no committed kernel-stats summaries found"
     missing = sorted(profiled - SEEN)
     assert not missing, f"profiled but never compared with the oracle: {missing}; seen: {sorted(SEEN)}"
+
