@@ -172,6 +172,22 @@ PackedConv Engine::pack_convT(const WeightSet& ws, const std::string& prefix, in
   return pc;
 }
 
+// A dense [rows][K] matrix in the A-operand order of the 16x16x4 MFMA used by dds_layer16_kernel:
+// [16-row tile][q][lane][4], lane -> (row = lane & 15, k = lane >> 4), float4 element j of group q = k-step 4q + j, i.e.
+// input channel 4 * (4q + j) + k. K is padded to a multiple of 32 (the kernel's Hp).
+float* Engine::pack16(const std::vector<float>& W, int rows, int K) {
+  const int Kp = rup(K, 32), nq = Kp / 16, ntile = (rows + 15) / 16;
+  std::vector<float> P((size_t)ntile * nq * 256, 0.f);
+  for (int mt = 0; mt < ntile; ++mt)
+    for (int q = 0; q < nq; ++q)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int jj = 0; jj < 4; ++jj) {
+          const int row = mt * 16 + (lane & 15), ci = 4 * (4 * q + jj) + (lane >> 4);
+          if (row < rows && ci < K) P[(((size_t)mt * nq + q) * 64 + lane) * 4 + jj] = W[(size_t)row * K + ci];
+        }
+  return dev_copy(P);
+}
+
 DdsW Engine::load_dds(const WeightSet& ws, const std::string& p) {
   DdsW d;
   for (int i = 0; i < arch_[A_DDSLAYERS]; ++i) {
@@ -262,6 +278,10 @@ void Engine::init(const WeightSet& ws) {
   dp_pre_ = pack_conv(ws, "dp.pre.weight", "dp.pre.bias", 1, -1, false, 0, 0);
   dp_dds_ = load_dds(ws, "dp.convs");
   dp_proj_ = pack_conv(ws, "dp.proj.weight", "dp.proj.bias", 1, -1, false, 0, 0);
+  {
+    const HostTensor& w = ws.get("dp.proj.weight");
+    dp_proj16_ = pack16(w.data, (int)w.dims[0], (int)w.dims[1]);
+  }
   for (int i = arch_[A_DPFLOWS] - 1; i >= 1; --i) {     // dp.flows.{7,5,3} (models.py:108-110)
     const std::string p = "dp.flows." + std::to_string(2 * i + 1);
     CFlow cf;
@@ -271,6 +291,10 @@ void Engine::init(const WeightSet& ws) {
     cf.proj = pack_conv(ws, p + ".proj.weight", p + ".proj.bias", 1, -1, false, 0, 0);
     if (cf.proj.rows != 3 * arch_[A_NBINS] - 1 || arch_[A_NBINS] != 10)
       throw std::runtime_error("spline with num_bins != 10 is not supported");
+    {
+      const HostTensor& w = ws.get(p + ".proj.weight");
+      cf.proj16 = pack16(w.data, (int)w.dims[0], (int)w.dims[1]);
+    }
     cflows_.push_back(cf);
   }
   {
@@ -420,8 +444,8 @@ void Engine::init(const WeightSet& ws) {
                          (const void*)mrf_fused_kernel<32, 4, 8, 320>, (const void*)mrf_fused_kernel<32, 4, 8, 384>,
                          (const void*)mrf_fused_kernel<64, 4, 8, 256>};
     for (const void* k : ks3) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    const void* ks4[] = {(const void*)mrf2_kernel<32, 16, 1, 2, 1, 368>, (const void*)mrf2_kernel<32, 16, 1, 2, 1, 400>,
-                         (const void*)mrf2_kernel<64, 16, 2, 1, 1, 240>};
+    const void* ks4[] = {(const void*)mrf2_kernel<32, 16, 1, 2, 1, 368, 2>, (const void*)mrf2_kernel<32, 16, 1, 2, 1, 400, 1>,
+                         (const void*)mrf2_kernel<64, 16, 2, 1, 1, 240, 1>};
     for (const void* k : ks4) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
   }
 #endif
@@ -440,6 +464,7 @@ void Engine::init(const WeightSet& ws) {
   if (const char* t = getenv("PIPER_HIP_SPLITK16")) splitk16_ = atoi(t);              // A/B knob
   if (const char* t = getenv("PIPER_HIP_WIDE_SPLITK")) wide_splitk_ = atoi(t);        // 0 off, 1 auto, 2 always (tests)
   if (const char* t = getenv("PIPER_HIP_DEBUG_KEEP")) debug_keep_ = atoi(t) != 0;     // tests: keep z_p for debug_tensor
+  if (const char* t = getenv("PIPER_HIP_FUSE_DP")) fuse_dp_ = atoi(t) != 0;           // A/B knob, tests
 }
 
 Engine::~Engine() { free_all(); }
@@ -851,12 +876,30 @@ void Engine::build_mrf2(UpStage& st) {
   // 32-channel stages: a wave owns one 16-row tile of 8 column groups; 64-channel stages: two row tiles (one B
   // operand feeds two MFMAs) of 8 column groups
   const int CP = ch <= 32 ? 32 : 64, MS = CP / 16, NCH = CP / KC, NW = 16, MSW = CP == 32 ? 1 : 2, NCG = NW / (MS / MSW);
-  const int STEPF = MS * 512, RINGF = 4 * 64 * NW, SEGSTEPS = RINGF / STEPF;
+  // halo of the stage (widest resblock chain) -> window geometry -> how large a weight-ring half fits in LDS
+  int hx = 0;
+  for (auto& hv : st.rb_host) {
+    int e = 0;
+    for (auto& h : hv) e += h.dil * (h.k - 1) / 2;
+    hx = std::max(hx, e);
+  }
+  const int hxa = rup(hx, 16);
+  int N = 0, WS = 0, NWR = 0;
+  {
+    const int cand[4][2] = {{256, 2}, {256, 1}, {128, 2}, {128, 1}};     // (output columns, float4 per thread per segment)
+    for (auto& c : cand) {
+      int ws = rup(hxa + c[0] + hx, 32) + 16;
+      if (ws - 32 >= hxa + c[0] + hx) ws -= 32;       // smallest value == 16 (mod 32) that covers the window
+      const size_t bytes = ((size_t)2 * 4 * 64 * NW * c[1] + (size_t)2 * CP * ws + 128 + 24 * 12 + 64 * 4) * sizeof(float);
+      if (bytes <= 160u * 1024u) { N = c[0]; WS = ws; NWR = c[1]; break; }
+    }
+  }
+  if (!N) return;
+  const int STEPF = MS * 512, RINGF = 4 * 64 * NW * NWR, SEGSTEPS = RINGF / STEPF;
   const bool rb1 = arch_[A_RESBLOCK] == 1;
   std::vector<Mrf2Phase> phases;
   std::vector<Mrf2Seg> segs;
   std::vector<float> wstream;
-  int hx = 0;
   for (size_t j = 0; j < st.rb_host.size(); ++j) {
     auto& hv = st.rb_host[j];
     const int n = (int)hv.size();
@@ -866,7 +909,6 @@ void Engine::build_mrf2(UpStage& st) {
       if (!(h.k & 1) || h.ci != ch || h.co != ch) return;
       e += h.dil * (h.k - 1) / 2;
     }
-    hx = std::max(hx, e);
     for (int i = 0; i < n; ++i) {
       const auto& h = hv[i];
       e -= h.dil * (h.k - 1) / 2;
@@ -908,24 +950,14 @@ void Engine::build_mrf2(UpStage& st) {
       phases.push_back(P);
     }
   }
-  // geometry: output columns per workgroup, window, units per wave -- the largest N whose LDS fits
-  const int hxa = rup(hx, 16);
-  int N = 0, WS = 0;
-  for (int n : {256, 128, 64}) {
-    int ws = hxa + n + hx;
-    ws = rup(ws, 32) + 16;
-    if (ws - 32 >= hxa + n + hx) ws -= 32;         // smallest value == 16 (mod 32) that covers the window
-    const size_t bytes = ((size_t)2 * RINGF + (size_t)2 * CP * ws + 128) * sizeof(float);
-    if (bytes <= 160u * 1024u) { N = n; WS = ws; break; }
-  }
-  if (!N) return;
+  if (!N || phases.size() > 24 || segs.size() > 64) return;
   const int cu_lo = (hxa - hx) / 16, cu_hi = (hxa + N + hx + 15) / 16;
   const int nleft = hxa / 16 - cu_lo, nhalo = cu_hi - cu_lo - N / 16;
   const int ou = N / 16 / NCG, hu = (nhalo + NCG - 1) / NCG;       // output / halo units per wave
   if (N % (16 * NCG) || ou < 1 || ou > 2 || hu > 2 || (ou == 2 && hu == 2)) return;
   {
-    const int key = CP * 1000000 + ou * 100000 + hu * 10000 + WS;       // the instantiated geometries (mrf2())
-    if (key != 32210368 && key != 32210400 && key != 64110240) return;
+    const int key = CP * 10000000 + ou * 1000000 + hu * 100000 + WS * 10 + NWR;   // the instantiated geometries (mrf2())
+    if (key != 322103682 && key != 322104001 && key != 641102401) return;
   }
   {
     // MFMA work relative to the unfused convs (halo recompute in 16-column units): fuse only when it stays moderate
@@ -951,6 +983,7 @@ void Engine::build_mrf2(UpStage& st) {
   weight_bytes_ += wstream.size() * sizeof(float);
   st.m2_nphases = (int)phases.size(); st.m2_nsegs = (int)segs.size(); st.m2_wfloats = (int)wstream.size();
   st.m2_cp = CP; st.m2_n = N; st.m2_ws = WS; st.m2_hxa = hxa; st.m2_cu_lo = cu_lo; st.m2_cu_hi = cu_hi;
+  st.m2_nwr = NWR;
   st.m2_ou = ou; st.m2_hu = std::max(hu, 1); st.m2_nleft = nleft; st.m2_nhalo = nhalo;
 }
 
@@ -977,18 +1010,19 @@ void Engine::mrf2(const UpStage& st, View x, View out, const int* lens, int len_
     kbytes = 8.0 * st.ch * cols + 4.0 * st.m2_wfloats;      // one read of x, one write of the mean, the weights once
   }
   const int NW = 16;
-  const size_t smem = ((size_t)2 * 4 * 64 * NW + (size_t)2 * st.m2_cp * st.m2_ws + 128) * sizeof(float);
+  const size_t smem = ((size_t)2 * 4 * 64 * NW * st.m2_nwr + (size_t)2 * st.m2_cp * st.m2_ws + 128 + 24 * 12 + 64 * 4) *
+                      sizeof(float);
   dim3 grid((Lmax + st.m2_n - 1) / st.m2_n, B_);
   char nm[64];
-  snprintf(nm, sizeof(nm), "mrf2_kernel<%d,%d,%d,%d,%d,%d>", st.m2_cp, NW, st.m2_cp == 32 ? 1 : 2, st.m2_ou, st.m2_hu,
-           st.m2_ws);
+  snprintf(nm, sizeof(nm), "mrf2_kernel<%d,%d,%d,%d,%d,%d,%d>", st.m2_cp, NW, st.m2_cp == 32 ? 1 : 2, st.m2_ou, st.m2_hu,
+           st.m2_ws, st.m2_nwr);
   const int kh = prof_level_ >= 2 ? kbegin(krow(std::string(nm)), kflops, kbytes) : -1;
-#define PE_MRF2(CP_, OU_, HU_, WS_) \
-  PE_LAUNCH((mrf2_kernel<CP_, 16, (CP_ == 32 ? 1 : 2), OU_, HU_, WS_>), grid, dim3(64 * NW), smem, ls_, p)
+#define PE_MRF2(CP_, OU_, HU_, WS_, NWR_) \
+  PE_LAUNCH((mrf2_kernel<CP_, 16, (CP_ == 32 ? 1 : 2), OU_, HU_, WS_, NWR_>), grid, dim3(64 * NW), smem, ls_, p)
   // instantiated geometries: medium / x-low (ResBlock2 3,5,7: halo 45) and high (ResBlock1 3,7,11: halo 60) stages
-  if (st.m2_cp == 32 && st.m2_ou == 2 && st.m2_hu == 1 && st.m2_ws == 368) PE_MRF2(32, 2, 1, 368);
-  else if (st.m2_cp == 32 && st.m2_ou == 2 && st.m2_hu == 1 && st.m2_ws == 400) PE_MRF2(32, 2, 1, 400);
-  else if (st.m2_cp == 64 && st.m2_ou == 1 && st.m2_hu == 1 && st.m2_ws == 240) PE_MRF2(64, 1, 1, 240);
+  if (st.m2_cp == 32 && st.m2_ou == 2 && st.m2_hu == 1 && st.m2_ws == 368 && st.m2_nwr == 2) PE_MRF2(32, 2, 1, 368, 2);
+  else if (st.m2_cp == 32 && st.m2_ou == 2 && st.m2_hu == 1 && st.m2_ws == 400 && st.m2_nwr == 1) PE_MRF2(32, 2, 1, 400, 1);
+  else if (st.m2_cp == 64 && st.m2_ou == 1 && st.m2_hu == 1 && st.m2_ws == 240 && st.m2_nwr == 1) PE_MRF2(64, 1, 1, 240, 1);
   else throw std::runtime_error("internal: no mrf2_kernel instantiation for this stage geometry");
 #undef PE_MRF2
   kend(kh);
@@ -1015,14 +1049,25 @@ void Engine::layer_norm(int mode, View in, View res, View out, const float* g, c
 
 // DDSConv.forward (modules.py:117-129): one fused launch per layer (dds_layer16_kernel), ping-ponging between
 // `out` and `tmp` so that the last layer lands in `out`; `in` must not alias the first layer's target.
-void Engine::dds(const DdsW& d, View in, View out, View tmp) {
+void Engine::dds(const DdsW& d, View in, View out, View tmp, const DdsOpt* opt) {
   int dil = 1;
   const int n = (int)d.c1x1.size();
   View cur = in;
   for (int i = 0; i < n; ++i) {
     const View dst = ((n - 1 - i) & 1) ? tmp : out;
     if (dst.p == cur.p) throw std::runtime_error("internal: DDSConv buffer aliasing");
-    DdsP p;
+    DdsP p{};
+    if (opt && i == 0 && opt->pre_z) {
+      p.pre_z = opt->pre_z; p.pre_z_bs = opt->pre_z_bs; p.pre_w = opt->pre_w; p.pre_b = opt->pre_b;
+    }
+    p.z_scale = opt ? opt->z_scale : 1.f;
+    if (opt && i == n - 1 && opt->post_w16) {
+      p.post_w16 = opt->post_w16; p.post_bias = opt->post_bias; p.post_rows = opt->post_rows;
+      p.post_out = opt->post_out.p; p.po_bs = opt->post_out.bs; p.po_cs = opt->post_out.cs;
+      p.zin = opt->zin; p.zin_bs = opt->zin_bs; p.z_cs = opt->z_cs; p.c0 = opt->c0; p.c1 = opt->c1;
+      p.zout = opt->zout; p.zout_bs = opt->zout_bs;
+      p.inv_sqrt_h = 1.0f / std::sqrt((float)H_);
+    }
     p.x = cur.p; p.x_bs = cur.bs; p.x_cs = cur.cs;
     p.out = dst.p; p.o_bs = dst.bs; p.o_cs = dst.cs;
     p.dw_w = d.dw_w[i]; p.dw_b = d.dw_b[i]; p.dw_k = ksz_; p.dw_dil = dil;
@@ -1242,40 +1287,59 @@ void Engine::issue_stage_a() {
   prof_begin();
   fl = 0;
   conv(dp_pre_, x, dy, d_tlens_, 1, T, EPI_STORE, 1.f, ACT_NONE, none, none, 0, 1.f, cb_dp, cond_bs_);
-  dds(dp_dds_, dy, dh, dy2);
-  conv(dp_proj_, dh, xg, d_tlens_, 1, T, EPI_STORE);
+  if (fuse_dp_) {
+    DdsOpt o;                      // dp.proj fused after the last DDSConv layer (models.py:65)
+    o.post_w16 = dp_proj16_; o.post_bias = dp_proj_.bias; o.post_rows = dp_proj_.rows; o.post_out = xg;
+    dds(dp_dds_, dy, dh, dy2, &o);
+  } else {
+    dds(dp_dds_, dy, dh, dy2);
+    conv(dp_proj_, dh, xg, d_tlens_, 1, T, EPI_STORE);
+  }
   fl += 2.0 * tsum * (2 + arch_[A_DDSLAYERS]) * dp_pre_.macs_per_col;
   // z = noise * noise_scale_w   [B][2][Ts]
   if (!have_noise_w_) {
     const long n = (long)B * 2 * Ts;
     PE_LAUNCH(randn_kernel, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, stream_, noise_w_, n, d_rng_, 0);
   }
-  {
+  if (!fuse_dp_) {
     const long n = (long)B * 2 * Ts;
     PE_LAUNCH(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream_, noise_w_, z2_, n, scales_[2]);
   }
   // Flip is folded into which physical channel is x0 (conditioning) and which is x1 (transformed):
   // logical = physical when an even number of flips has been applied.
   int flips = 0;
-  for (auto& cf : cflows_) {
+  for (size_t fi = 0; fi < cflows_.size(); ++fi) {
+    auto& cf = cflows_[fi];
     ++flips;
     const int c0 = (flips & 1) ? 1 : 0;     // physical channel holding logical x0
     const int c1 = 1 - c0;
-    PE_LAUNCH(cf_pre_kernel, dim3((T + 63) / 64, H_, B), dim3(64), 0, stream_, z2_ + (long)c0 * Ts, (long)2 * Ts,
-              cf.pre_w, cf.pre_b, xg_, (long)H_ * Ts, Ts, dy_, (long)H_ * Ts, Ts, d_tlens_, H_);
-    dds(cf.dds, dy, dh, dy2);
-    conv(cf.proj, dh, hproj, d_tlens_, 1, T, EPI_STORE);
-    PE_LAUNCH(spline_inverse_kernel, dim3((T + 63) / 64, B), dim3(64), 0, stream_, hproj_, (long)32 * Ts, Ts,
-              z2_ + (long)c1 * Ts, (long)2 * Ts, d_tlens_, 1.0f / std::sqrt((float)H_));
+    if (fuse_dp_) {
+      // One launch per DDSConv layer and nothing else: ConvFlow.pre (+ g) is folded into the first layer's input,
+      // proj and the spline run on the last layer's columns. The first flow reads the raw N(0,1) draw and applies
+      // noise_scale_w itself; its spline epilogue also moves the pass-through channel into z2_.
+      const float* zin = fi == 0 ? noise_w_ : z2_;
+      DdsOpt o;
+      o.pre_z = zin + (long)c0 * Ts; o.pre_z_bs = (long)2 * Ts; o.pre_w = cf.pre_w; o.pre_b = cf.pre_b;
+      o.z_scale = fi == 0 ? scales_[2] : 1.f;
+      o.post_w16 = cf.proj16; o.post_bias = cf.proj.bias; o.post_rows = cf.proj.rows;
+      o.zin = zin; o.zin_bs = (long)2 * Ts; o.z_cs = Ts; o.c0 = c0; o.c1 = c1; o.zout = z2_; o.zout_bs = (long)2 * Ts;
+      dds(cf.dds, xg, dh, dy2, &o);
+    } else {
+      PE_LAUNCH(cf_pre_kernel, dim3((T + 63) / 64, H_, B), dim3(64), 0, stream_, z2_ + (long)c0 * Ts, (long)2 * Ts,
+                cf.pre_w, cf.pre_b, xg_, (long)H_ * Ts, Ts, dy_, (long)H_ * Ts, Ts, d_tlens_, H_);
+      dds(cf.dds, dy, dh, dy2);
+      conv(cf.proj, dh, hproj, d_tlens_, 1, T, EPI_STORE);
+      PE_LAUNCH(spline_inverse_kernel, dim3((T + 63) / 64, B), dim3(64), 0, stream_, hproj_, (long)32 * Ts, Ts,
+                z2_ + (long)c1 * Ts, (long)2 * Ts, d_tlens_, 1.0f / std::sqrt((float)H_));
+    }
     fl += 2.0 * tsum * (arch_[A_DDSLAYERS] * dp_pre_.macs_per_col + cf.proj.macs_per_col);
   }
   ++flips;   // the Flip before ElementwiseAffine
   {
     const int c0 = (flips & 1) ? 1 : 0;     // physical channel holding logical channel 0 = logw
     PE_LAUNCH(duration_kernel, dim3(B), dim3(256), 0, stream_, z2_ + (long)c0 * Ts, (long)2 * Ts, ea_m0_, ea_es0_,
-              scales_[1], d_tlens_, d_dur_, d_cum_, Ts, d_frames_, logw_);
+              scales_[1], d_tlens_, d_dur_, d_cum_, Ts, d_frames_, logw_, h_frames_);
   }
-  PE_HIP(hipMemcpyAsync(h_frames_, d_frames_, B * sizeof(int), hipMemcpyDeviceToHost, stream_));
   prof_end(1, fl);
 }
 
@@ -1309,6 +1373,7 @@ void Engine::issue_flow() {
     rp.noise = noise_z_; rp.n_bs = (long)C_ * Fs; rp.n_cs = Fs;
     rp.noise_scale = scales_[0];
     rp.out = zp_; rp.o_bs = (long)C_ * Fs; rp.o_cs = Fs; rp.C = C_;
+    rp.absmax = absmax_;
     PE_LAUNCH(regulate_kernel, dim3((Fmax + 63) / 64, (C_ + 15) / 16, B), dim3(64), 0, stream_, rp);
     if (zp_keep_)     // tests: z_p, the flow's input (the flow transforms zp_ in place)
       PE_HIP(hipMemcpyAsync(zp_keep_, zp_, (size_t)B * C_ * Fs * sizeof(float), hipMemcpyDeviceToDevice, stream_));
@@ -1340,18 +1405,18 @@ void Engine::issue_stage_b() {
   issue_flow();
   double fsum = 0;
   for (int b = 0; b < B_; ++b) fsum += frames_h_[b];
-  issue_decoder(zp_, d_frames_, Fg_, fsum);
+  issue_decoder(zp_, d_frames_, Fg_, fsum, false);     // regulate_kernel zeroed the peak accumulators
 }
 
 // streaming: window of z -> window buffer -> generator (lens = window length, in device memory)
 void Engine::issue_window() {
   PE_LAUNCH(window_copy_kernel, dim3((s_wg_ + 63) / 64, C_), dim3(64), 0, stream_, zp_, Fs_, d_win_, zwin_, Fs_, C_);
-  issue_decoder(zwin_, d_win_ + 1, s_wg_, (double)s_wg_);
+  issue_decoder(zwin_, d_win_ + 1, s_wg_, (double)s_wg_, true);
 }
 
 // HiFiGAN generator + conv_post + int16 on z (already masked by its length semantics). `zsrc` is
 // [B][C][Fs_]; `lens` the per-utterance frame counts in device memory; Fmax the grid bound.
-void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double fsum) {
+void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double fsum, bool zero_absmax) {
   const int B = B_, Fs = Fs_;
   const View none{nullptr, 0, 0};
   const float* cb_dec = nspk_ > 1 ? cond_ + cond_off_dec_ : nullptr;
@@ -1463,7 +1528,7 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
 
     // ================= conv_post + tanh + peak, int16 (models.py:364-366; piper.cpp:410-431)
     prof_begin();
-    PE_HIP(hipMemsetAsync(absmax_, 0, B * sizeof(unsigned), stream_));
+    if (zero_absmax) PE_HIP(hipMemsetAsync(absmax_, 0, B * sizeof(unsigned), stream_));
     const int K = 7, Lmax = Fmax * hop_;
     PE_LAUNCH(conv_post_kernel, dim3((Lmax + 256 * POST_OPT - 1) / (256 * POST_OPT), B), dim3(256), 0, stream_, cur.p,
               cur.bs, cur.cs, post_w_, post_cin_, 0.01f, lens, hop_, audio_, Ss_, absmax_);

@@ -119,12 +119,23 @@ class Engine {
             int bias2_bs = 0);
   void layer_norm(int mode, View in, View res, View out, const float* g, const float* b, const float* dw_w,
                   const float* dw_b, int dw_k, int dw_dil, int C, const int* lens, int Lmax);
-  void dds(const DdsW& d, View in, View out, View tmp);
+  // options of one DDSConv run: ConvFlow.pre folded into the first layer, a 1x1 conv (+ spline) fused after the last
+  struct DdsOpt {
+    const float* pre_z = nullptr; long pre_z_bs = 0; const float* pre_w = nullptr; const float* pre_b = nullptr;
+    float z_scale = 1.f;
+    const float* post_w16 = nullptr; const float* post_bias = nullptr; int post_rows = 0;
+    View post_out{nullptr, 0, 0};
+    const float* zin = nullptr; long zin_bs = 0; int z_cs = 0, c0 = 0, c1 = 1; float* zout = nullptr; long zout_bs = 0;
+  };
+  void dds(const DdsW& d, View in, View out, View tmp, const DdsOpt* opt = nullptr);
+  float* pack16(const std::vector<float>& W, int rows, int K);    // [16-row tile][q][lane][4] (dds_layer16_kernel)
+  float* dp_proj16_ = nullptr;
+  bool fuse_dp_ = true;                     // PIPER_HIP_FUSE_DP=0: cf_pre / proj / spline as separate launches (A/B, tests)
   void issue_stage_a();
   void issue_stage_b();
   void issue_flow();
   void issue_window();
-  void issue_decoder(const float* zsrc, const int* lens, int Fmax, double fsum);
+  void issue_decoder(const float* zsrc, const int* lens, int Fmax, double fsum, bool zero_absmax);
   void run_stage(char which, const std::string& key);
   void dispatch_stage(char which);
   void drop_graphs();
@@ -153,6 +164,7 @@ class Engine {
     float *pre_w, *pre_b;
     DdsW dds;
     PackedConv proj;
+    float* proj16 = nullptr;             // proj in the 16x16x4 fragment order (fused after the last DDSConv layer)
   };
   std::vector<CFlow> cflows_;
   float ea_m0_ = 0, ea_es0_ = 1;
@@ -176,7 +188,7 @@ class Engine {
     std::vector<std::vector<HostConv>> rb_host;   // host copies of the resblock convs, dropped after build_mrf2
     void* m2_phases = nullptr; void* m2_segs = nullptr; float* m2_w = nullptr;
     int m2_nphases = 0, m2_nsegs = 0, m2_wfloats = 0, m2_cp = 0, m2_n = 0, m2_ws = 0, m2_hxa = 0, m2_cu_lo = 0,
-        m2_cu_hi = 0, m2_ou = 0, m2_hu = 0, m2_nleft = 0, m2_nhalo = 0;
+        m2_cu_hi = 0, m2_ou = 0, m2_hu = 0, m2_nleft = 0, m2_nhalo = 0, m2_nwr = 1;
     double m2_recompute = 0;
   };
   void build_mrf2(UpStage& st);

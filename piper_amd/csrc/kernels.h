@@ -1119,6 +1119,98 @@ __global__ __launch_bounds__(256) void ln_kernel(LnP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// ConvFlow.pre (1 -> H channels, 1x1) fused with DDSConv's "x = x + g" (modules.py:504-505,118-119):
+//   h[c][t] = w[c] * z0[t] + b[c] + g[c][t]
+__global__ void cf_pre_kernel(const float* z0, long z_bs, const float* w, const float* bia,
+                              const float* g, long g_bs, int g_cs, float* out, long o_bs, int o_cs,
+                              const int* lens, int H) {
+  const int b = blockIdx.z, c = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= lens[b] || c >= H) return;
+  out[(long)b * o_bs + (long)c * o_cs + t] =
+      fmaf(w[c], z0[(long)b * z_bs + t], bia[c]) + g[(long)b * g_bs + (long)c * g_cs + t];
+}
+
+// ------------------------------------------------------------------------------------------------
+// Inverse piecewise rational-quadratic spline with linear tails, 10 bins, bound 5
+// (transforms.py:50-98 unconstrained_rational_quadratic_spline(inverse=True) over :101-191;
+// the per-position parameters are ConvFlow.proj's 29 outputs, modules.py:508-517): one element.
+static constexpr int SPL_NB = 10;
+__device__ __forceinline__ float spline_inverse(const float (&raw)[3 * SPL_NB - 1], float x, float inv_sqrt_h) {
+  constexpr int NB = SPL_NB;
+  constexpr float TB = 5.0f, MINB = 1e-3f, MIND = 1e-3f;
+  if (!(x >= -TB && x <= TB)) return x;          // identity outside the interval
+  float uw[NB], uh[NB], dv[NB + 1];
+  float mw = -3.0e38f, mh = -3.0e38f;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    uw[i] = raw[i] * inv_sqrt_h;
+    uh[i] = raw[NB + i] * inv_sqrt_h;
+    mw = fmaxf(mw, uw[i]);
+    mh = fmaxf(mh, uh[i]);
+  }
+  float sw = 0.f, sh = 0.f;
+  for (int i = 0; i < NB; ++i) {
+    uw[i] = expf(uw[i] - mw); sw += uw[i];
+    uh[i] = expf(uh[i] - mh); sh += uh[i];
+  }
+  // derivatives: min + softplus(u), boundary u = log(exp(1-min)-1) -> derivative exactly ~1
+  const float ucst = logf(expf(1.f - MIND) - 1.f);
+  for (int i = 0; i <= NB; ++i) {
+    const float u = (i == 0 || i == NB) ? ucst : raw[2 * NB + i - 1];
+    dv[i] = MIND + (u > 20.f ? u : log1pf(expf(u)));
+  }
+  // cumulative widths / heights scaled to [-TB, TB], end knots pinned
+  float cw[NB + 1], ch[NB + 1];
+  cw[0] = -TB; ch[0] = -TB;
+  float aw = 0.f, ah = 0.f;
+  for (int i = 0; i < NB; ++i) {
+    aw += MINB + (1.f - MINB * NB) * (uw[i] / sw);
+    ah += MINB + (1.f - MINB * NB) * (uh[i] / sh);
+    cw[i + 1] = 2.f * TB * aw - TB;
+    ch[i + 1] = 2.f * TB * ah - TB;
+  }
+  cw[NB] = TB; ch[NB] = TB;
+  // searchsorted on heights (transforms.py:44-47): last edge + 1e-6
+  int bin = -1;
+  for (int i = 0; i <= NB; ++i) {
+    const float e = (i == NB) ? ch[i] + 1e-6f : ch[i];
+    bin += (x >= e) ? 1 : 0;
+  }
+  bin = bin < 0 ? 0 : (bin > NB - 1 ? NB - 1 : bin);
+  float in_cw = 0.f, in_w = 0.f, in_ch = 0.f, in_h = 0.f, d0 = 0.f, d1 = 0.f;
+  for (int i = 0; i < NB; ++i)
+    if (i == bin) {
+      in_cw = cw[i]; in_w = cw[i + 1] - cw[i];
+      in_ch = ch[i]; in_h = ch[i + 1] - ch[i];
+      d0 = dv[i]; d1 = dv[i + 1];
+    }
+  const float delta = in_h / in_w;
+  const float y = x - in_ch;
+  const float s = d0 + d1 - 2.f * delta;
+  const float a = y * s + in_h * (delta - d0);
+  const float bq = in_h * d0 - y * s;
+  const float c = -delta * y;
+  const float disc = bq * bq - 4.f * a * c;
+  const float root = (2.f * c) / (-bq - sqrtf(disc));
+  return root * in_w + in_cw;
+}
+// One thread per (utterance, position). z1 is transformed in place; z0 is the untouched half.
+__global__ void spline_inverse_kernel(const float* hproj, long h_bs, int h_cs, float* z1, long z_bs,
+                                      const int* lens, float inv_sqrt_h) {
+  const int b = blockIdx.y;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= lens[b]) return;
+  // all 3*NB-1 spline parameters of this element are requested together with x (one memory round trip)
+  const float* hp = hproj + (long)b * h_bs + t;
+  float raw[3 * SPL_NB - 1];
+#pragma unroll
+  for (int i = 0; i < 3 * SPL_NB - 1; ++i) raw[i] = hp[(long)i * h_cs];
+  const float x = z1[(long)b * z_bs + t];
+  z1[(long)b * z_bs + t] = spline_inverse(raw, x, inv_sqrt_h);
+}
+
+// ------------------------------------------------------------------------------------------------
 // One whole DDSConv layer (modules.py:119-128) per launch (out of place: neighbouring workgroups read each
 // other's halo columns of x, so the result goes to a second buffer):
 //     out = x + gelu(LN2(W1x1 . gelu(LN1(dwconv_dil(x) + b_dw)) + b_1x1))
@@ -1137,6 +1229,20 @@ struct DdsP {
   int nchunks;                              // ceil(H / 32)
   const int* lens;
   int H;
+  // Optional fold of ConvFlow.pre + DDSConv's "x = x + g" into the layer input (modules.py:504-505, 118-119), first
+  // layer of a ConvFlow: the input is  pre_w[c] * (z0[t] * z_scale) + pre_b[c] + x[c][t]  with x = the conditioning g.
+  const float* pre_z; long pre_z_bs;        // z0 row of utterance b (null: no fold)
+  const float* pre_w; const float* pre_b;
+  float z_scale;                            // noise_scale_w on the first flow (z is still the raw N(0,1) draw), else 1
+  // Optional second 1x1 conv on the layer's output columns (last layer of a DDSConv: dp.proj / ConvFlow.proj,
+  // models.py:65, modules.py:507), weights in the 16x16x4 fragment order; the layer output itself is then not stored.
+  const float* post_w16; const float* post_bias; int post_rows;
+  float* post_out; long po_bs; int po_cs;   // plain store of the post conv (dp.proj), or null
+  // Optional spline epilogue (ConvFlow, modules.py:508-526): the post conv's 29 rows are the per-position parameters;
+  // z1 <- rq_spline_inverse(z1 * z_scale), z0 <- z0 * z_scale (pass-through), both [2][Ts] tensors may alias.
+  const float* zin; long zin_bs; int z_cs; int c0, c1;
+  float* zout; long zout_bs;
+  float inv_sqrt_h;
 };
 // One workgroup = 16 time columns x all channels, 512 threads; the 1x1 conv runs on the 16x16x4 f32 MFMA: the GEMM's
 // N matches the column count, its 16-row tiles (Hp/16 = 12 for H = 192) spread evenly over the four SIMDs of the 8
@@ -1161,6 +1267,7 @@ __global__ __launch_bounds__(512) void dds_layer16_kernel(DdsP p) {
   const float* xb = p.x + (long)b * p.x_bs;
   float* ob = p.out + (long)b * p.o_bs;
   const int pad = (p.dw_k - 1) / 2 * p.dw_dil;
+  const bool fold = p.pre_z != nullptr;
 
   auto col_sum = [&](float v) -> float {       // sum over all channel lanes of this column
     v += __shfl_xor(v, 16);
@@ -1182,6 +1289,15 @@ __global__ __launch_bounds__(512) void dds_layer16_kernel(DdsP p) {
   float v[NVT], xc[NVT], gg[NVT], bb[NVT];
   {
     float xv[NVT][MAXK], ww[NVT][MAXK], wb[NVT];
+    // folded ConvFlow.pre: the three taps' z0 values and this channel's (w, b); zero-length descriptors when unused
+    const pe_rowsrc zd = pe_make_row(fold ? p.pre_z + (long)b * p.pre_z_bs : p.dw_b, fold ? L : 0);
+    const pe_rowsrc pwd = pe_make_row(fold ? p.pre_w : p.dw_b, fold ? H : 0), pbd = pe_make_row(fold ? p.pre_b : p.dw_b, fold ? H : 0);
+    float zt[MAXK], pw[NVT], pb[NVT];
+#pragma unroll
+    for (int kk = 0; kk < MAXK; ++kk) {
+      const int tt = t + kk * p.dw_dil - pad;
+      zt[kk] = pe_row_load(zd, (ok && kk < p.dw_k && tt >= 0 && tt < L) ? tt : -1) * p.z_scale;
+    }
 #pragma unroll
     for (int k = 0; k < NVT; ++k) {
       const int c = rl + 32 * k;
@@ -1196,6 +1312,18 @@ __global__ __launch_bounds__(512) void dds_layer16_kernel(DdsP p) {
       wb[k] = pe_row_load(bd, cv ? c : -1);
       gg[k] = pe_row_load(g1d, c < H ? c : -1);
       bb[k] = pe_row_load(b1d, c < H ? c : -1);
+      pw[k] = pe_row_load(pwd, cv ? c : -1);
+      pb[k] = pe_row_load(pbd, cv ? c : -1);
+    }
+    if (fold) {
+#pragma unroll
+      for (int k = 0; k < NVT; ++k)
+#pragma unroll
+        for (int kk = 0; kk < MAXK; ++kk) {
+          const int tt = t + kk * p.dw_dil - pad;
+          const bool tv = ok && rl + 32 * k < H && kk < p.dw_k && tt >= 0 && tt < L;
+          xv[k][kk] = tv ? fmaf(pw[k], zt[kk], pb[k]) + xv[k][kk] : 0.f;
+        }
     }
 #pragma unroll
     for (int k = 0; k < NVT; ++k) {
@@ -1280,100 +1408,74 @@ __global__ __launch_bounds__(512) void dds_layer16_kernel(DdsP p) {
   for (int k = 0; k < NVT; ++k)
     if (rl + 32 * k < H) { const float d = v[k] - mean; q = fmaf(d, d, q); }
   rstd = 1.f / sqrtf(col_sum(q) / (float)H + 1e-5f);
-  if (!ok) return;
+  if (p.post_w16 == nullptr) {
+    if (!ok) return;
+#pragma unroll
+    for (int k = 0; k < NVT; ++k) {
+      const int c = rl + 32 * k;
+      if (c < H) ob[(long)c * p.o_cs + t] = xc[k] + gelu_erf((v[k] - mean) * rstd * gg[k] + bb[k]);
+    }
+    return;
+  }
+  // ---- phase 4 (last layer of a DDSConv): the following 1x1 conv on this workgroup's columns, Y <- layer output
 #pragma unroll
   for (int k = 0; k < NVT; ++k) {
     const int c = rl + 32 * k;
-    if (c < H) ob[(long)c * p.o_cs + t] = xc[k] + gelu_erf((v[k] - mean) * rstd * gg[k] + bb[k]);
+    if (c < Hp) Y[c * NC + col] = (c < H && ok) ? xc[k] + gelu_erf((v[k] - mean) * rstd * gg[k] + bb[k]) : 0.f;
   }
-}
-
-// ------------------------------------------------------------------------------------------------
-// ConvFlow.pre (1 -> H channels, 1x1) fused with DDSConv's "x = x + g" (modules.py:504-505,118-119):
-//   h[c][t] = w[c] * z0[t] + b[c] + g[c][t]
-__global__ void cf_pre_kernel(const float* z0, long z_bs, const float* w, const float* bia,
-                              const float* g, long g_bs, int g_cs, float* out, long o_bs, int o_cs,
-                              const int* lens, int H) {
-  const int b = blockIdx.z, c = blockIdx.y;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= lens[b] || c >= H) return;
-  out[(long)b * o_bs + (long)c * o_cs + t] =
-      fmaf(w[c], z0[(long)b * z_bs + t], bia[c]) + g[(long)b * g_bs + (long)c * g_cs + t];
-}
-
-// ------------------------------------------------------------------------------------------------
-// Inverse piecewise rational-quadratic spline with linear tails, 10 bins, bound 5
-// (transforms.py:50-98 unconstrained_rational_quadratic_spline(inverse=True) over :101-191;
-// the per-position parameters are ConvFlow.proj's 29 outputs, modules.py:508-517).
-// One thread per (utterance, position). z1 is transformed in place; z0 is the untouched half.
-__global__ void spline_inverse_kernel(const float* hproj, long h_bs, int h_cs, float* z1, long z_bs,
-                                      const int* lens, float inv_sqrt_h) {
-  const int b = blockIdx.y;
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= lens[b]) return;
-  constexpr int NB = 10;
-  constexpr float TB = 5.0f, MINB = 1e-3f, MIND = 1e-3f;
-  // all 3*NB-1 spline parameters of this element are requested together with x (one memory round trip)
-  const float* hp = hproj + (long)b * h_bs + t;
-  float raw[3 * NB - 1];
+  __syncthreads();
+  {
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int ntile = (p.post_rows + 15) / 16, nq = Hp / 16;
+    const int tile_floats = nq * 256;
+    const pe_rowsrc biasd = pe_make_row(p.post_bias, p.post_bias ? p.post_rows : 0);
+    for (int mt = wv; mt < ntile; mt += 8) {
+      const pe_rowsrc wsrc = pe_make_row_u(p.post_w16 + (long)mt * tile_floats, tile_floats);
+      f32x4 acc;
 #pragma unroll
-  for (int i = 0; i < 3 * NB - 1; ++i) raw[i] = hp[(long)i * h_cs];
-  const float x = z1[(long)b * z_bs + t];
-  if (!(x >= -TB && x <= TB)) return;            // identity outside the interval
-  float uw[NB], uh[NB], dv[NB + 1];
-  float mw = -3.0e38f, mh = -3.0e38f;
+      for (int r = 0; r < 4; ++r) acc[r] = 0.f;
+      float bz[4];
 #pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    uw[i] = raw[i] * inv_sqrt_h;
-    uh[i] = raw[NB + i] * inv_sqrt_h;
-    mw = fmaxf(mw, uw[i]);
-    mh = fmaxf(mh, uh[i]);
-  }
-  float sw = 0.f, sh = 0.f;
-  for (int i = 0; i < NB; ++i) {
-    uw[i] = expf(uw[i] - mw); sw += uw[i];
-    uh[i] = expf(uh[i] - mh); sh += uh[i];
-  }
-  // derivatives: min + softplus(u), boundary u = log(exp(1-min)-1) -> derivative exactly ~1
-  const float ucst = logf(expf(1.f - MIND) - 1.f);
-  for (int i = 0; i <= NB; ++i) {
-    const float u = (i == 0 || i == NB) ? ucst : raw[2 * NB + i - 1];
-    dv[i] = MIND + (u > 20.f ? u : log1pf(expf(u)));
-  }
-  // cumulative widths / heights scaled to [-TB, TB], end knots pinned
-  float cw[NB + 1], ch[NB + 1];
-  cw[0] = -TB; ch[0] = -TB;
-  float aw = 0.f, ah = 0.f;
-  for (int i = 0; i < NB; ++i) {
-    aw += MINB + (1.f - MINB * NB) * (uw[i] / sw);
-    ah += MINB + (1.f - MINB * NB) * (uh[i] / sh);
-    cw[i + 1] = 2.f * TB * aw - TB;
-    ch[i + 1] = 2.f * TB * ah - TB;
-  }
-  cw[NB] = TB; ch[NB] = TB;
-  // searchsorted on heights (transforms.py:44-47): last edge + 1e-6
-  int bin = -1;
-  for (int i = 0; i <= NB; ++i) {
-    const float e = (i == NB) ? ch[i] + 1e-6f : ch[i];
-    bin += (x >= e) ? 1 : 0;
-  }
-  bin = bin < 0 ? 0 : (bin > NB - 1 ? NB - 1 : bin);
-  float in_cw = 0.f, in_w = 0.f, in_ch = 0.f, in_h = 0.f, d0 = 0.f, d1 = 0.f;
-  for (int i = 0; i < NB; ++i)
-    if (i == bin) {
-      in_cw = cw[i]; in_w = cw[i + 1] - cw[i];
-      in_ch = ch[i]; in_h = ch[i + 1] - ch[i];
-      d0 = dv[i]; d1 = dv[i + 1];
+      for (int r = 0; r < 4; ++r) bz[r] = pe_row_load(biasd, mt * 16 + 4 * lq + r);
+      for (int q0 = 0; q0 < nq; q0 += 4) {
+        float a[16], yv[16];
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          const f32x4 w4 = pe_row_load4(wsrc, (q0 + qq) * 256 + lane * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) a[4 * qq + j] = w4[j];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) yv[u] = (4 * q0 + u < Hp / 4) ? Y[(4 * (4 * q0 + u) + lq) * NC + l15] : 0.f;
+        PE_SCHED_FENCE();
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc = pe_mfma_16x16x4(a[u], yv[u], acc);
+        PE_SCHED_FENCE();
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) Z[(mt * 16 + 4 * lq + r) * NC + l15] = acc[r] + bz[r];
     }
-  const float delta = in_h / in_w;
-  const float y = x - in_ch;
-  const float s = d0 + d1 - 2.f * delta;
-  const float a = y * s + in_h * (delta - d0);
-  const float bq = in_h * d0 - y * s;
-  const float c = -delta * y;
-  const float disc = bq * bq - 4.f * a * c;
-  const float root = (2.f * c) / (-bq - sqrtf(disc));
-  z1[(long)b * z_bs + t] = root * in_w + in_cw;
+  }
+  __syncthreads();
+  if (!ok) return;
+  if (p.post_out) {
+    float* po = p.post_out + (long)b * p.po_bs;
+#pragma unroll
+    for (int k = 0; k < NVT; ++k) {
+      const int c = rl + 32 * k;
+      if (c < p.post_rows) po[(long)c * p.po_cs + t] = Z[c * NC + col];
+    }
+  }
+  if (p.zout && rl == 0) {        // one thread per column: ConvFlow's spline on z1, z0 passes through (scaled)
+    float raw[3 * SPL_NB - 1];
+#pragma unroll
+    for (int i = 0; i < 3 * SPL_NB - 1; ++i) raw[i] = Z[i * NC + col];
+    const float* zi = p.zin + (long)b * p.zin_bs;
+    float* zo = p.zout + (long)b * p.zout_bs;
+    const float x1 = zi[(long)p.c1 * p.z_cs + t] * p.z_scale, x0 = zi[(long)p.c0 * p.z_cs + t] * p.z_scale;
+    zo[(long)p.c1 * p.z_cs + t] = spline_inverse(raw, x1, p.inv_sqrt_h);
+    zo[(long)p.c0 * p.z_cs + t] = x0;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1385,7 +1487,8 @@ __global__ void spline_inverse_kernel(const float* hproj, long h_bs, int h_cs, f
 static constexpr int MAX_FRAMES = 60000;      // per-utterance activations stay below the 2 GiB descriptor range
 __global__ __launch_bounds__(256) void duration_kernel(const float* z0, long z_bs, float m0, float es0,
                                                        float length_scale, const int* lens, int* dur,
-                                                       int* cum, int d_bs, int* frames, float* logw_out) {
+                                                       int* cum, int d_bs, int* frames, float* logw_out,
+                                                       int* frames_host) {
   __shared__ long long part[256];
   const int b = blockIdx.x, T = lens[b], tid = threadIdx.x;
   const int per = (T + 255) / 256;
@@ -1406,7 +1509,11 @@ __global__ __launch_bounds__(256) void duration_kernel(const float* z0, long z_b
   if (tid == 0) {
     long long run = 0;
     for (int i = 0; i < 256; ++i) { const long long v = part[i]; part[i] = run; run += v; }
-    frames[b] = run < 1 ? 1 : (run > MAX_FRAMES ? MAX_FRAMES + 1 : (int)run);
+    const int f = run < 1 ? 1 : (run > MAX_FRAMES ? MAX_FRAMES + 1 : (int)run);
+    frames[b] = f;
+    // the host sizes stage B from this count: written straight into pinned host memory (visible once the stream is
+    // synchronised), which saves the device-to-host copy node behind this kernel
+    if (frames_host) frames_host[b] = f;
   }
   __syncthreads();
   long long run = part[tid];
@@ -1428,9 +1535,11 @@ struct RegP {
   float noise_scale;
   float* out; long o_bs; int o_cs;
   int C;
+  unsigned* absmax;                            // per-utterance peak accumulator of conv_post_kernel: zeroed here
 };
 __global__ void regulate_kernel(RegP p) {
   const int b = blockIdx.z;
+  if (p.absmax && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) p.absmax[b] = 0u;
   const int f = blockIdx.x * blockDim.x + threadIdx.x;
   const int F = p.frames[b], T = p.tlens[b];
   if (f >= F) return;

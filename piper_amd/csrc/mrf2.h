@@ -25,7 +25,7 @@ template <int V> struct pe_int { static constexpr int value = V; };
 
 enum { MRF2_RES = 1, MRF2_KEEP = 2, MRF2_FINAL = 4, MRF2_INIT = 8, MRF2_RESTAGE = 16 };
 
-struct Mrf2Phase {       // one conv of one resblock chain
+struct Mrf2Phase {       // one conv of one resblock chain; 12 ints wide (the kernel copies the table to LDS as ints)
   const float* bias;
   int ntaps, dil;
   int e;                 // columns of halo its OUTPUT still needs (0 for the last conv of a resblock)
@@ -33,7 +33,9 @@ struct Mrf2Phase {       // one conv of one resblock chain
   int flags;             // RES: + running x (registers); KEEP: result becomes the running x; FINAL: add to the MRF sum;
                          // INIT: running x = stage input (first conv of a resblock); RESTAGE: reload buffer 0 first
   int seg0, nseg;        // its weight segments in the stream
+  int pad0, pad1;
 };
+static_assert(sizeof(Mrf2Phase) == 48, "Mrf2Phase is read as 12 ints");
 struct Mrf2Seg { int step0, nsteps, woff, pad; };
 struct Mrf2P {
   const float* x; long x_bs; int x_cs;
@@ -55,10 +57,12 @@ struct Mrf2P {
 // block cg + NCG * u of the N / 16 output blocks (N == 16 * NCG * OU); unit OU + v is halo block h = cg + NCG * v of the
 // nhalo blocks around them (left ones first). With MSW = 2 (64-channel stages) one B operand feeds two MFMAs.
 // WS (LDS row stride, == 16 mod 32) is a compile-time constant: the eight k-rows of a step are immediates of one base.
-template <int CP, int NW, int MSW, int OU, int HU, int WS>
+// NWR = float4 per thread per weight segment (ring half = NWR * 16 KiB at 16 waves).
+template <int CP, int NW, int MSW, int OU, int HU, int WS, int NWR>
 __global__ __launch_bounds__(64 * NW) void mrf2_kernel(Mrf2P p) {
   constexpr int MS = CP / 16, NRG = MS / MSW, NCG = NW / NRG, NT = 64 * NW, UPW = OU + HU;
-  constexpr int RINGF = 4 * NT;                    // floats per ring half: one float4 per thread per segment
+  constexpr int RINGF = 4 * NT * NWR;              // floats per ring half
+  constexpr int MAXPH = 24, MAXSEG = 64;           // table capacities (engine.cpp: build_mrf2 checks them)
   static_assert(MS % MSW == 0 && NW % NRG == 0, "waves split evenly over the row groups");
   PE_DYN_SMEM(float, sm);
   const int b = blockIdx.y;
@@ -68,7 +72,10 @@ __global__ __launch_bounds__(64 * NW) void mrf2_kernel(Mrf2P p) {
   static_assert(WS % 32 == 16, "row stride == 16 (mod 32)");
   float* ring = sm;                                // 2 x RINGF
   float* bufs = sm + 2 * RINGF;                    // 2 x [CP][WS]; reads that leave a buffer on the left / right land
-  const int bufsz = CP * WS;                       // in the ring / the other buffer / the tail pad (unused columns only)
+  constexpr int bufsz = CP * WS;                   // in the ring / the other buffer / the tail pad (unused columns only)
+  // phase / segment tables: copied to LDS once, so that no phase or segment starts with a global-memory round trip
+  int* tph = reinterpret_cast<int*>(bufs + 2 * bufsz + 128);     // [MAXPH][12] ints (Mrf2Phase is 12 ints wide)
+  int* tsg = tph + MAXPH * 12;                                   // [MAXSEG][4]
   const int tid = threadIdx.x, lane = tid & 63, wv = PE_UNIFORM(tid >> 6);
   const int l15 = lane & 15, lq = lane >> 4;
   const int ms0 = (wv % NRG) * MSW, cg = wv / NRG;
@@ -78,32 +85,40 @@ __global__ __launch_bounds__(64 * NW) void mrf2_kernel(Mrf2P p) {
 
   // ---- weight stream: segment s -> ring half s & 1, one float4 per thread, fetched one segment ahead
   const pe_rowsrc wd = pe_make_row(p.wstream, p.wfloats);
-  f32x4 wreg;
-  auto wfetch = [&](int seg) {
-    const int woff = PE_UNIFORM(seg < p.nsegs ? p.segs[seg].woff : 0x3ffffff0);    // past the end: zeros
-    wreg = pe_row_load4(wd, woff + tid * 4);
+  f32x4 wreg[NWR];
+  auto wfetch_at = [&](int woff) {
+#pragma unroll
+    for (int k = 0; k < NWR; ++k) wreg[k] = pe_row_load4(wd, woff + (tid + k * NT) * 4);
   };
-  wfetch(0);
+  auto wfetch = [&](int seg) { wfetch_at(PE_UNIFORM(seg < p.nsegs ? tsg[seg * 4 + 2] : 0x3ffffff0)); };   // past the end: zeros
+  wfetch_at(0);                 // segment 0 starts the stream
+  {
+    const int* gp = reinterpret_cast<const int*>(p.phases);
+    const int* gs = reinterpret_cast<const int*>(p.segs);
+    for (int i = tid; i < p.nphases * 12; i += NT) tph[i] = gp[i];
+    for (int i = tid; i < p.nsegs * 4; i += NT) tsg[i] = gs[i];
+  }
 
   // ---- stage the activated input window: buffer 0 <- lrelu(x[g0 + c]), zero outside [0, L) and for rows >= C
   const float* xb = p.x + (long)b * p.x_bs;
-  auto stage_x = [&]() {
-    const int ncc = (WS + 63) / 64;
-    for (int row = wv; row < CP; row += NW) {
+  auto stage_x = [&]() {        // every load of the window in flight before the first store: one memory latency
+    constexpr int NCC = (WS + 63) / 64, RPW = CP / NW;
+    float v[RPW][NCC];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int row = wv + NW * i;
       const pe_rowsrc rd = pe_make_row(xb + (long)row * p.x_cs, row < C ? L : 0);
-      for (int cc = 0; cc < ncc; cc += 4) {
-        float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = pe_row_load(rd, g0 + lane + 64 * (cc + j));
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int c = lane + 64 * (cc + j);
-          if (c < WS) bufs[row * WS + c] = pe_lrelu(v[j], slope);
-        }
-      }
+      for (int j = 0; j < NCC; ++j) v[i][j] = pe_row_load(rd, g0 + lane + 64 * j);
     }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i)
+#pragma unroll
+      for (int j = 0; j < NCC; ++j) {
+        const int c = lane + 64 * j;
+        if (c < WS) bufs[(wv + NW * i) * WS + c] = pe_lrelu(v[i][j], slope);
+      }
   };
-  stage_x();
 
   // ---- this wave's units: window column block cu[u] (-1: the wave has no such unit) x row tiles ms0 + m
   f32x4 acc[MSW][UPW], rawx[MSW][UPW], rawc[MSW][UPW], tot[MSW][OU];
@@ -137,14 +152,20 @@ __global__ __launch_bounds__(64 * NW) void mrf2_kernel(Mrf2P p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) tot[m][u][r] = 0.f;
   }
+  stage_x();
+  __syncthreads();              // tables and window are in LDS
 
   int seg = 0;
   for (int ph = 0; ph < p.nphases; ++ph) {
-    Mrf2Phase P = p.phases[ph];
-    P.bias = pe_uniform_ptr(P.bias);
-    P.ntaps = PE_UNIFORM(P.ntaps); P.dil = PE_UNIFORM(P.dil); P.e = PE_UNIFORM(P.e);
-    P.src = PE_UNIFORM(P.src); P.dst = PE_UNIFORM(P.dst); P.flags = PE_UNIFORM(P.flags);
-    P.nseg = PE_UNIFORM(P.nseg);
+    Mrf2Phase P;
+    {
+      const int* t = tph + ph * 12;
+      const unsigned lo = PE_UNIFORM((unsigned)t[0]), hi = PE_UNIFORM((unsigned)t[1]);
+      P.bias = reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+      P.ntaps = PE_UNIFORM(t[2]); P.dil = PE_UNIFORM(t[3]); P.e = PE_UNIFORM(t[4]);
+      P.src = PE_UNIFORM(t[5]); P.dst = PE_UNIFORM(t[6]); P.flags = PE_UNIFORM(t[7]);
+      P.seg0 = PE_UNIFORM(t[8]); P.nseg = PE_UNIFORM(t[9]);
+    }
     if (P.flags & MRF2_RESTAGE) {       // ResBlock1 rewrites buffer 0 in place: a new chain starts from the stage input
       __syncthreads();
       stage_x();
@@ -179,9 +200,10 @@ __global__ __launch_bounds__(64 * NW) void mrf2_kernel(Mrf2P p) {
     auto k_loop = [&](auto maskc) {
       constexpr int MASK = decltype(maskc)::value;
       for (int s = 0; s < P.nseg; ++s, ++seg) {
-        const int step0 = PE_UNIFORM(p.segs[seg].step0), nsteps = PE_UNIFORM(p.segs[seg].nsteps);
+        const int step0 = PE_UNIFORM(tsg[seg * 4]), nsteps = PE_UNIFORM(tsg[seg * 4 + 1]);
         float* half = ring + (seg & 1) * RINGF;
-        *reinterpret_cast<f32x4*>(half + tid * 4) = wreg;
+#pragma unroll
+        for (int k = 0; k < NWR; ++k) *reinterpret_cast<f32x4*>(half + (tid + k * NT) * 4) = wreg[k];
         __syncthreads();      // this segment's weights (and the previous phase's activations) are visible; every wave
                               // is done with the segment before, whose ring half the NEXT store overwrites
         wfetch(seg + 1);

@@ -43,7 +43,7 @@ def make_engine(monkeypatch, cfg, w, env=None):
     from piper_amd.engine import Engine
     for k in ("PIPER_HIP_SPLITK_MAX", "PIPER_HIP_SMALL", "PIPER_HIP_WIDE_MIN", "PIPER_HIP_TPB", "PIPER_HIP_SPLITK16",
               "PIPER_HIP_WIDE_SPLITK", "PIPER_HIP_FUSE_MRF", "PIPER_HIP_DEBUG_KEEP", "PIPER_HIP_PAR_MRF",
-              "PIPER_HIP_FUSED", "PIPER_HIP_MRF2"):
+              "PIPER_HIP_FUSED", "PIPER_HIP_MRF2", "PIPER_HIP_FUSE_DP"):
         monkeypatch.delenv(k, raising=False)
     for k, v in (env or {}).items():
         monkeypatch.setenv(k, str(v))
@@ -118,8 +118,7 @@ def test_medium_b64_t128_matches_oracle(monkeypatch):
     names, worst = run_and_check(eng, cfg, w, ids, nw, nz, sample=[0, 7, 15, 23, 31, 42, 53, 63])
     eng.close()
     assert "conv_mfma_kernel<2,2,2,1,16,true,64>" in names, names
-    assert {"conv_mfma_kernel<2,2,1,1,16,false,64>", "conv_mfma_kernel<2,2,1,1,16,false,128>",
-            "conv_mfma_kernel<1,4,1,1,16,false,64>", "conv_mfma_kernel<1,4,1,1,16,false,128>"} <= names, names
+    assert {"conv_mfma_kernel<2,2,1,1,16,false,64>", "conv_mfma_kernel<2,2,1,1,16,false,128>"} <= names, names
     print("medium B=64 kernels:", sorted(names), "worst |d audio| %.2e" % worst)
 
 
@@ -138,19 +137,21 @@ def test_medium_b16_ragged_matches_oracle(monkeypatch):
 # variant on shapes where the default heuristics would pick another one. `expect`: instantiations that must run.
 FORCED = [
     # every conv of a single utterance through the TILED kernels (gate epilogue, 32-row and 64-row tiles, both halos)
-    ("medium", [128], {"PIPER_HIP_SPLITK_MAX": 0},
+    ("medium", [128], {"PIPER_HIP_SPLITK_MAX": 0, "PIPER_HIP_MRF2": 0},
      {"conv_mfma_kernel<2,2,2,1,16,true,64>", "conv_mfma_kernel<2,2,1,1,16,false,64>",
       "conv_mfma_kernel<1,4,1,1,16,false,64>", "conv_mfma_kernel<2,2,1,1,16,false,128>",
       "conv_mfma_kernel<1,4,1,1,16,false,128>"}),
     # large tiles (CFG_A 128x128 incl. its gate form, CFG_B 64x128) -- chosen only when PIPER_HIP_SMALL=0
-    ("medium", [128] * 16, {"PIPER_HIP_SMALL": 0},
+    ("medium", [128] * 16, {"PIPER_HIP_SMALL": 0, "PIPER_HIP_MRF2": 0},
      {"conv_mfma_kernel<2,2,2,2,8,true,64>", "conv_mfma_kernel<2,2,2,2,8,false,64>", "conv_mfma_kernel<1,4,2,1,16,false,64>"}),
-    ("x-low", [64] * 32, {"PIPER_HIP_SMALL": 0}, {"conv_mfma_kernel<1,4,2,1,16,true,64>"}),
+    ("x-low", [64] * 32, {"PIPER_HIP_SMALL": 0, "PIPER_HIP_MRF2": 0}, {"conv_mfma_kernel<1,4,2,1,16,true,64>"}),
     # 256-column tiles (CFG_C2 / CFG_B2)
-    ("medium", [128] * 16, {"PIPER_HIP_SMALL": 0, "PIPER_HIP_WIDE_MIN": 1},
+    ("medium", [128] * 16, {"PIPER_HIP_SMALL": 0, "PIPER_HIP_WIDE_MIN": 1, "PIPER_HIP_MRF2": 0},
      {"conv_mfma_kernel<1,4,1,2,16,false,64>", "conv_mfma_kernel<1,4,2,2,8,false,64>"}),
     # several column tiles per workgroup (in-kernel slab pipeline across tiles)
-    ("medium", [128, 40], {"PIPER_HIP_SPLITK_MAX": 0, "PIPER_HIP_TPB": 3}, set()),
+    ("medium", [128, 40], {"PIPER_HIP_SPLITK_MAX": 0, "PIPER_HIP_TPB": 3, "PIPER_HIP_MRF2": 0}, set()),
+    # the duration predictor with ConvFlow.pre / proj / spline as separate launches (default: fused into the DDSConv layers)
+    ("medium", [128, 31], {"PIPER_HIP_FUSE_DP": 0}, {"conv_splitk_kernel<1,false,8,4>"}),
     # split-K variants: 4/8-wave only (no 16-column form), 12-wave everywhere, 16-column form everywhere
     ("medium", [128], {"PIPER_HIP_SPLITK16": 0, "PIPER_HIP_WIDE_SPLITK": 0},
      {"conv_splitk_kernel<2,true,8,3>", "conv_splitk_kernel<1,false,8,4>", "conv_splitk_kernel<1,false,4,4>"}),
