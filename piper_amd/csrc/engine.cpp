@@ -230,7 +230,8 @@ Engine::Engine(const WeightSet& ws, int device) : device_(device) {
 }
 
 void Engine::init(const WeightSet& ws) {
-  if (const char* t = getenv("PIPER_HIP_MRF2")) mrf2_mode_ = atoi(t);     // A/B knob: 0 = conv-by-conv MRF stages
+  if (const char* t = getenv("PIPER_HIP_MRF2")) mrf2_mode_ = atoi(t);     // A/B knob: 0 = conv-by-conv MRF stages, 2 = always fused
+  if (const char* t = getenv("PIPER_HIP_MRF2_MAXF")) mrf2_max_frames_ = atol(t);
   memcpy(arch_, ws.arch, sizeof(arch_));
   PE_HIP(hipSetDevice(device_));
   PE_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
@@ -465,6 +466,7 @@ void Engine::init(const WeightSet& ws) {
   if (const char* t = getenv("PIPER_HIP_WIDE_SPLITK")) wide_splitk_ = atoi(t);        // 0 off, 1 auto, 2 always (tests)
   if (const char* t = getenv("PIPER_HIP_DEBUG_KEEP")) debug_keep_ = atoi(t) != 0;     // tests: keep z_p for debug_tensor
   if (const char* t = getenv("PIPER_HIP_FUSE_DP")) fuse_dp_ = atoi(t) != 0;           // A/B knob, tests
+  if (const char* t = getenv("PIPER_HIP_FOLD_LN")) fold_ln_ = atoi(t) != 0;           // A/B knob, tests
 }
 
 Engine::~Engine() { free_all(); }
@@ -615,6 +617,25 @@ void Engine::ensure_stage_b(int Fmax) {
 // launch helpers
 // ------------------------------------------------------------------------------------------------
 
+// Which kernel family a conv launch goes to (the policy conv() applies).
+int Engine::route(const PackedConv& pc, int ncols, int epi) const {
+  const int cfg = pc.cfg;
+  const long blocks = (long)((ncols + CFG_BN[cfg] - 1) / CFG_BN[cfg]) * (pc.mtiles * 32 / CFG_BM[cfg]) * B_;
+  if (!(blocks < splitk_max_blocks_ && (pc.ntaps - 1) * pc.dil <= 32)) return ROUTE_TILE;
+  const int units = pc.nchunks * pc.ntaps;
+  const bool k16 = pc.wp16 && epi != EPI_CONVT && ((pc.gate && splitk16_ >= 1) || (!pc.gate && splitk16_ >= 2)) &&
+                   (units >= 24 || splitk16_ >= 3);
+  return k16 ? ROUTE_SPLITK16 : ROUTE_SPLITK;
+}
+// LayerNorm-in needs every input channel of a column inside one workgroup at once: the plain split-K kernel with one
+// 32-channel chunk per wave.
+bool Engine::can_fold_ln(const PackedConv& pc, int ncols) const {
+  if (!fold_ln_ || pc.gate || wide_splitk_ == 2) return false;
+  if (route(pc, ncols, EPI_STORE) != ROUTE_SPLITK) return false;
+  const int NW = pc.nchunks >= 5 ? 8 : 4;
+  return pc.nchunks <= NW;
+}
+
 void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int len_mul, int Lmax, int epi,
                   float in_slope, int act, View res, View out2, int mode, float alpha, const float* bias2,
                   int bias2_bs) {
@@ -637,6 +658,10 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
   p.mode = mode; p.alpha = alpha;
   p.tpb = 1;
   p.tgroups = 1;
+  p.ln_g = ln_in_.g; p.ln_b = ln_in_.b;
+  p.ln_out = ln_in_.out.p; p.ln_o_bs = ln_in_.out.bs; p.ln_o_cs = ln_in_.out.cs;
+  const bool ln_in = ln_in_.g != nullptr;
+  ln_in_ = LnIn{};
   if ((epi == EPI_GATE) != pc.gate) throw std::runtime_error("internal: gate epilogue/packing mismatch");
 
   const int ncols = (epi == EPI_CONVT) ? Lmax + 1 : Lmax;
@@ -657,6 +682,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
                     (double)pc.rows * pc.Cin * pc.ntaps);
   }
   const long blocks = (long)((ncols + CFG_BN[cfg] - 1) / CFG_BN[cfg]) * (pc.mtiles * 32 / CFG_BM[cfg]) * B_;
+  if (ln_in && route(pc, ncols, epi) != ROUTE_SPLITK) throw std::runtime_error("internal: LayerNorm-in on a non split-K launch");
   if (blocks < splitk_max_blocks_ && p.xhalo <= 32) {
     // few columns (one utterance through encoder / duration predictor / flow): split K across the waves
     const int MT = pc.gate ? 2 : 1;
@@ -672,7 +698,8 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
       p.tgroups = pc.nchunks <= 6 ? 2 : 1;
     }
     dim3 grid((ncols + 31) / 32, pc.mtiles / MT, B_);
-    const size_t smem = std::max<size_t>((size_t)NW * KC * 64, (size_t)NW * MT * 16 * 64) * sizeof(float);
+    const size_t smem = (std::max<size_t>((size_t)NW * KC * 64, (size_t)NW * MT * 16 * 64) + (ln_in ? 2 * NW * 64 : 0)) *
+                        sizeof(float);
     const bool k16 = pc.wp16 && epi != EPI_CONVT && ((pc.gate && splitk16_ >= 1) || (!pc.gate && splitk16_ >= 2)) &&
                      (units >= 24 || splitk16_ >= 3);
     // profile rows carry the instantiation exactly as rocprofv3 prints it (minus spaces)
@@ -1253,8 +1280,17 @@ void Engine::issue_stage_a() {
   double fl = 0;
   PE_LAUNCH(embed_kernel, dim3((T + 63) / 64, (H_ + 15) / 16, B), dim3(64), 0, stream_, d_ids_, Ts, d_tlens_, emb_, H_,
             std::sqrt((float)H_), x_, (long)H_ * Ts, Ts, d_rng_);
+  // LayerNorm placement: norm_layers_1 feeds only FFN conv_1 (+ the residual of conv_2), norm_layers_2 only the next
+  // layer's q/k/v conv (or, after the last layer, proj) + the residual of conv_o. When those consumers run as split-K
+  // launches (a few utterances) the norm is computed while they stage x -- every workgroup of such a launch holds all
+  // H channels of its columns -- and row tile 0 writes LN(x) back for the residual readers: 2 launches fewer per layer.
+  const bool fold1 = can_fold_ln(enc_.empty() ? enc_proj_ : enc_[0].f1, T);
+  const bool fold2 = can_fold_ln(enc_.empty() ? enc_proj_ : enc_[0].qkv, T) && can_fold_ln(enc_proj_, T);
+  const float *pg = nullptr, *pb = nullptr;        // pending norm_layers_2 of the previous layer (input still in y)
   for (auto& e : enc_) {
-    conv(e.qkv, x, qkv, d_tlens_, 1, T, EPI_STORE);
+    if (pg) { ln_in_.g = pg; ln_in_.b = pb; ln_in_.out = x; }
+    conv(e.qkv, pg ? y : x, qkv, d_tlens_, 1, T, EPI_STORE);
+    pg = pb = nullptr;
     AttnP ap;
     ap.qkv = qkv_; ap.q_bs = (long)3 * H_ * Ts; ap.q_cs = Ts;
     ap.relk = e.relk; ap.relv = e.relv;
@@ -1272,14 +1308,21 @@ void Engine::issue_stage_a() {
     PE_LAUNCH(attn_kernel, dim3((T + ATT_QB - 1) / ATT_QB, nh_, B), dim3(256), smem, stream_, ap);
     kend(kh);
     conv(e.o, att, y, d_tlens_, 1, T, EPI_RESADD, 1.f, ACT_NONE, x);
-    layer_norm(0, y, none, x, e.g1, e.b1, nullptr, nullptr, 0, 0, H_, d_tlens_, T);
-    conv(e.f1, x, ffh, d_tlens_, 1, T, EPI_STORE, 1.f, ACT_RELU);
+    if (fold1) {
+      ln_in_.g = e.g1; ln_in_.b = e.b1; ln_in_.out = x;
+      conv(e.f1, y, ffh, d_tlens_, 1, T, EPI_STORE, 1.f, ACT_RELU);
+    } else {
+      layer_norm(0, y, none, x, e.g1, e.b1, nullptr, nullptr, 0, 0, H_, d_tlens_, T);
+      conv(e.f1, x, ffh, d_tlens_, 1, T, EPI_STORE, 1.f, ACT_RELU);
+    }
     conv(e.f2, ffh, y, d_tlens_, 1, T, EPI_RESADD, 1.f, ACT_NONE, x);
-    layer_norm(0, y, none, x, e.g2, e.b2, nullptr, nullptr, 0, 0, H_, d_tlens_, T);
+    if (fold2) { pg = e.g2; pb = e.b2; }
+    else layer_norm(0, y, none, x, e.g2, e.b2, nullptr, nullptr, 0, 0, H_, d_tlens_, T);
     fl += 2.0 * tsum * (e.qkv.macs_per_col + e.o.macs_per_col + e.f1.macs_per_col + e.f2.macs_per_col);
     for (int b = 0; b < B; ++b) fl += 2.0 * 2.0 * (double)tlens_h_[b] * tlens_h_[b] * H_;
   }
-  conv(enc_proj_, x, stats, d_tlens_, 1, T, EPI_STORE);
+  if (pg) { ln_in_.g = pg; ln_in_.b = pb; ln_in_.out = x; }
+  conv(enc_proj_, pg ? y : x, stats, d_tlens_, 1, T, EPI_STORE);
   fl += 2.0 * tsum * enc_proj_.macs_per_col;
   prof_end(0, fl);
 
@@ -1489,7 +1532,10 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
       const size_t need = (size_t)B * st.ch * Ls;
       const long blocks64 = (long)((Lmax + 63) / 64) * ((st.ch + 63) / 64) * B;
       const bool par = par_mrf_ && !prof_on_ && nk >= 2 && nk <= 3 && blocks64 < 700 && need <= side_floats_;
-      if (mrf2_mode_ && st.m2_phases && !fuse_mrf_) {
+      // One launch per stage wins while the stage is latency-bound (a few utterances: 6 launches of one wave
+      // generation each); from ~3 utterances up the conv-by-conv schedule fills the chip and its GEMM kernel is the
+      // faster one (profiles/r02_mrf2_ab.txt), so the choice goes by the frames in the batch.
+      if (mrf2_mode_ && st.m2_phases && !fuse_mrf_ && (mrf2_mode_ == 2 || fsum <= (double)mrf2_max_frames_)) {
         mrf2(st, u, xs, lens, mult, Lmax);
         for (auto& cv : st.rb)
           for (auto& c : cv) fl += 2.0 * fsum * mult * c.macs_per_col;

@@ -117,6 +117,13 @@ class Engine {
             float in_slope = 1.f, int act = 0, View res = View{nullptr, 0, 0},
             View out2 = View{nullptr, 0, 0}, int mode = 0, float alpha = 1.f, const float* bias2 = nullptr,
             int bias2_bs = 0);
+  // LayerNorm folded into the next conv() call's input staging (split-K launches only; see can_fold_ln)
+  struct LnIn { const float* g = nullptr; const float* b = nullptr; View out{nullptr, 0, 0}; };
+  LnIn ln_in_;
+  enum { ROUTE_TILE = 0, ROUTE_SPLITK = 1, ROUTE_SPLITK16 = 2 };
+  int route(const PackedConv& pc, int ncols, int epi) const;
+  bool can_fold_ln(const PackedConv& pc, int ncols) const;
+  bool fold_ln_ = true;                     // PIPER_HIP_FOLD_LN=0: encoder LayerNorms as their own launches (A/B, tests)
   void layer_norm(int mode, View in, View res, View out, const float* g, const float* b, const float* dw_w,
                   const float* dw_b, int dw_k, int dw_dil, int C, const int* lens, int Lmax);
   // options of one DDSConv run: ConvFlow.pre folded into the first layer, a 1x1 conv (+ spline) fused after the last
@@ -193,6 +200,7 @@ class Engine {
   };
   void build_mrf2(UpStage& st);
   void mrf2(const UpStage& st, View x, View out, const int* lens, int len_mul, int Lmax);
+  long mrf2_max_frames_ = 1100;             // batch frames up to which the fused stage kernel is used in mode 1
   int mrf2_mode_ = 1;                       // PIPER_HIP_MRF2: 0 off (conv by conv), 1 fused stage kernel where it applies
   void build_mrf(UpStage& st);
   void mrf(const UpStage& st, View x, View out, const int* lens, int len_mul, int Lmax);

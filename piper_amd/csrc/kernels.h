@@ -60,6 +60,11 @@ struct ConvP {
   float alpha;                                  // ACCUM last/only: scale
   int tpb;                                      // conv_mfma_kernel: column tiles walked by one workgroup
   int tgroups;                                  // conv_splitk_kernel: 1, or 2 = two halves of the waves split the taps
+  // conv_splitk_kernel only: LayerNorm over the input channels applied while staging x (modules.py:23-26; the encoder's
+  // norm_layers_1/2 folded into the conv that consumes them). The workgroups of row tile 0 write LN(x) back for the
+  // later residual readers. Requires one chunk per wave (Cin <= 32 * waves).
+  const float* ln_g; const float* ln_b;
+  float* ln_out; long ln_o_bs; int ln_o_cs;
 };
 
 // ---- shared epilogue of the conv GEMM kernels: one accumulator element (row, col) of utterance b.
@@ -457,6 +462,45 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk_kernel(ConvP p) {
   const int ncols = (p.epi == EPI_CONVT) ? L + 1 : L;
   if (n0 >= ncols) return;
   const EpiFlags ef = epi_flags(p);
+  if (!GATE && p.ln_g) {
+    // LayerNorm of the staged columns over ALL input channels: every wave holds one 32-channel chunk of the same 64
+    // columns (lane = column); two fixed-order cross-wave sums (mean, then centred second moment, like ln_kernel).
+    float* red1 = sm + NW * (KC * XW > MT * 16 * 64 ? KC * XW : MT * 16 * 64);     // behind the slabs / partial tiles
+    float* red2 = red1 + NW * 64;
+    const bool mine = myc > 0;
+    const int c0 = wi * KC;
+    float s1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < KC; ++r) s1 += (mine && c0 + r < p.Cin) ? xr[r] : 0.f;
+    red1[wv * 64 + lane] = s1;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tot += red1[w * 64 + lane];
+    const float mean = tot / (float)p.Cin;
+    float s2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < KC; ++r) {
+      const float dlt = xr[r] - mean;
+      s2 += (mine && c0 + r < p.Cin) ? dlt * dlt : 0.f;
+    }
+    red2[wv * 64 + lane] = s2;
+    __syncthreads();
+    float tot2 = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) tot2 += red2[w * 64 + lane];
+    const float rstd = 1.f / sqrtf(tot2 / (float)p.Cin + 1e-5f);
+    const bool wb = p.ln_out != nullptr && blockIdx.y == 0 && mine && xcol >= n0 && xcol < n0 + BN && xcol < L;
+    float* ob = p.ln_out + (long)b * p.ln_o_bs + xcol;
+#pragma unroll
+    for (int r = 0; r < KC; ++r) {
+      const int ci = c0 + r;
+      const bool cv = mine && ci < p.Cin;
+      const float g = cv ? p.ln_g[ci] : 0.f, be = cv ? p.ln_b[ci] : 0.f;      // wave-uniform: scalar loads
+      xr[r] = xcol >= 0 ? (xr[r] - mean) * rstd * g + be : 0.f;       // left halo: zero padding comes AFTER the norm
+      if (wb && cv) ob[(long)ci * p.ln_o_cs] = xr[r];
+    }
+  }
 
   // ---- epilogue operands of this wave's slots: four independent loads per slot, combined only in the
   // epilogue (adding them here would wait for each load in turn)
@@ -1136,30 +1180,15 @@ __global__ void cf_pre_kernel(const float* z0, long z_bs, const float* w, const 
 // (transforms.py:50-98 unconstrained_rational_quadratic_spline(inverse=True) over :101-191;
 // the per-position parameters are ConvFlow.proj's 29 outputs, modules.py:508-517): one element.
 static constexpr int SPL_NB = 10;
-__device__ __forceinline__ float spline_inverse(const float (&raw)[3 * SPL_NB - 1], float x, float inv_sqrt_h) {
+// The cheap, order-sensitive tail: from the un-normalised softmax terms ew / eh (= exp(u - max u)) and the derivatives dv
+// to the transformed value. Kept separate so that the ~40 transcendentals in front of it can be spread over lanes
+// (dds_layer16_kernel) while the sums keep the reference's sequential order.
+__device__ __forceinline__ float spline_finish(const float (&uw)[SPL_NB], const float (&uh)[SPL_NB],
+                                               const float (&dv)[SPL_NB + 1], float x) {
   constexpr int NB = SPL_NB;
-  constexpr float TB = 5.0f, MINB = 1e-3f, MIND = 1e-3f;
-  if (!(x >= -TB && x <= TB)) return x;          // identity outside the interval
-  float uw[NB], uh[NB], dv[NB + 1];
-  float mw = -3.0e38f, mh = -3.0e38f;
-#pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    uw[i] = raw[i] * inv_sqrt_h;
-    uh[i] = raw[NB + i] * inv_sqrt_h;
-    mw = fmaxf(mw, uw[i]);
-    mh = fmaxf(mh, uh[i]);
-  }
+  constexpr float TB = 5.0f, MINB = 1e-3f;
   float sw = 0.f, sh = 0.f;
-  for (int i = 0; i < NB; ++i) {
-    uw[i] = expf(uw[i] - mw); sw += uw[i];
-    uh[i] = expf(uh[i] - mh); sh += uh[i];
-  }
-  // derivatives: min + softplus(u), boundary u = log(exp(1-min)-1) -> derivative exactly ~1
-  const float ucst = logf(expf(1.f - MIND) - 1.f);
-  for (int i = 0; i <= NB; ++i) {
-    const float u = (i == 0 || i == NB) ? ucst : raw[2 * NB + i - 1];
-    dv[i] = MIND + (u > 20.f ? u : log1pf(expf(u)));
-  }
+  for (int i = 0; i < NB; ++i) { sw += uw[i]; sh += uh[i]; }
   // cumulative widths / heights scaled to [-TB, TB], end knots pinned
   float cw[NB + 1], ch[NB + 1];
   cw[0] = -TB; ch[0] = -TB;
@@ -1194,6 +1223,33 @@ __device__ __forceinline__ float spline_inverse(const float (&raw)[3 * SPL_NB - 
   const float disc = bq * bq - 4.f * a * c;
   const float root = (2.f * c) / (-bq - sqrtf(disc));
   return root * in_w + in_cw;
+}
+// derivative i of the spline (0 and NB are the linear tails' constant): min + softplus(u)
+__device__ __forceinline__ float spline_deriv(float u, bool boundary) {
+  constexpr float MIND = 1e-3f;
+  // boundary u = log(exp(1-min)-1) -> derivative exactly ~1
+  if (boundary) u = logf(expf(1.f - MIND) - 1.f);
+  return MIND + (u > 20.f ? u : log1pf(expf(u)));
+}
+__device__ __forceinline__ float spline_inverse(const float (&raw)[3 * SPL_NB - 1], float x, float inv_sqrt_h) {
+  constexpr int NB = SPL_NB;
+  constexpr float TB = 5.0f;
+  if (!(x >= -TB && x <= TB)) return x;          // identity outside the interval
+  float uw[NB], uh[NB], dv[NB + 1];
+  float mw = -3.0e38f, mh = -3.0e38f;
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    uw[i] = raw[i] * inv_sqrt_h;
+    uh[i] = raw[NB + i] * inv_sqrt_h;
+    mw = fmaxf(mw, uw[i]);
+    mh = fmaxf(mh, uh[i]);
+  }
+  for (int i = 0; i < NB; ++i) {
+    uw[i] = expf(uw[i] - mw);
+    uh[i] = expf(uh[i] - mh);
+  }
+  for (int i = 0; i <= NB; ++i) dv[i] = spline_deriv((i == 0 || i == NB) ? 0.f : raw[2 * NB + i - 1], i == 0 || i == NB);
+  return spline_finish(uw, uh, dv, x);
 }
 // One thread per (utterance, position). z1 is transformed in place; z0 is the untouched half.
 __global__ void spline_inverse_kernel(const float* hproj, long h_bs, int h_cs, float* z1, long z_bs,
@@ -1457,8 +1513,7 @@ __global__ __launch_bounds__(512) void dds_layer16_kernel(DdsP p) {
     }
   }
   __syncthreads();
-  if (!ok) return;
-  if (p.post_out) {
+  if (p.post_out && ok) {
     float* po = p.post_out + (long)b * p.po_bs;
 #pragma unroll
     for (int k = 0; k < NVT; ++k) {
@@ -1466,16 +1521,38 @@ __global__ __launch_bounds__(512) void dds_layer16_kernel(DdsP p) {
       if (c < p.post_rows) po[(long)c * p.po_cs + t] = Z[c * NC + col];
     }
   }
-  if (p.zout && rl == 0) {        // one thread per column: ConvFlow's spline on z1, z0 passes through (scaled)
-    float raw[3 * SPL_NB - 1];
+  if (p.zout) {
+    // ConvFlow's spline on z1 (z0 passes through, scaled). The ~40 transcendentals of one position are spread over 16
+    // lanes (lane j: softmax terms of bin j, derivative j), the order-sensitive sums run in one lane afterwards.
+    constexpr int NB = SPL_NB;
+    float* S = Y;                                      // Y is free: [16 cols][3][16]
+    const int scol = tid >> 4, j = tid & 15;           // first 256 threads: 16 consecutive lanes per column
+    const int st = t0 + scol;
+    if (tid < 256) {
+      const float uwj = j < NB ? Z[j * NC + scol] * p.inv_sqrt_h : -3.0e38f;
+      const float uhj = j < NB ? Z[(NB + j) * NC + scol] * p.inv_sqrt_h : -3.0e38f;
+      float mw = uwj, mh = uhj;
 #pragma unroll
-    for (int i = 0; i < 3 * SPL_NB - 1; ++i) raw[i] = Z[i * NC + col];
-    const float* zi = p.zin + (long)b * p.zin_bs;
-    float* zo = p.zout + (long)b * p.zout_bs;
-    const float x1 = zi[(long)p.c1 * p.z_cs + t] * p.z_scale, x0 = zi[(long)p.c0 * p.z_cs + t] * p.z_scale;
-    zo[(long)p.c1 * p.z_cs + t] = spline_inverse(raw, x1, p.inv_sqrt_h);
-    zo[(long)p.c0 * p.z_cs + t] = x0;
+      for (int m = 8; m >= 1; m >>= 1) { mw = fmaxf(mw, __shfl_xor(mw, m)); mh = fmaxf(mh, __shfl_xor(mh, m)); }
+      S[(scol * 3 + 0) * 16 + j] = j < NB ? expf(uwj - mw) : 0.f;
+      S[(scol * 3 + 1) * 16 + j] = j < NB ? expf(uhj - mh) : 0.f;
+      S[(scol * 3 + 2) * 16 + j] = j <= NB ? spline_deriv((j == 0 || j >= NB) ? 0.f : Z[(2 * NB + j - 1) * NC + scol], j == 0 || j >= NB) : 0.f;
+    }
+    __syncthreads();
+    if (tid < 256 && j == 0 && st < L) {
+      float uw[NB], uh[NB], dv[NB + 1];
+#pragma unroll
+      for (int i = 0; i < NB; ++i) { uw[i] = S[(scol * 3 + 0) * 16 + i]; uh[i] = S[(scol * 3 + 1) * 16 + i]; }
+#pragma unroll
+      for (int i = 0; i <= NB; ++i) dv[i] = S[(scol * 3 + 2) * 16 + i];
+      const float* zi = p.zin + (long)b * p.zin_bs;
+      float* zo = p.zout + (long)b * p.zout_bs;
+      const float x1 = zi[(long)p.c1 * p.z_cs + st] * p.z_scale, x0 = zi[(long)p.c0 * p.z_cs + st] * p.z_scale;
+      zo[(long)p.c1 * p.z_cs + st] = (x1 >= -5.0f && x1 <= 5.0f) ? spline_finish(uw, uh, dv, x1) : x1;
+      zo[(long)p.c0 * p.z_cs + st] = x0;
+    }
   }
+  (void)ok;
 }
 
 // ------------------------------------------------------------------------------------------------

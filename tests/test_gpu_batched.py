@@ -43,7 +43,8 @@ def make_engine(monkeypatch, cfg, w, env=None):
     from piper_amd.engine import Engine
     for k in ("PIPER_HIP_SPLITK_MAX", "PIPER_HIP_SMALL", "PIPER_HIP_WIDE_MIN", "PIPER_HIP_TPB", "PIPER_HIP_SPLITK16",
               "PIPER_HIP_WIDE_SPLITK", "PIPER_HIP_FUSE_MRF", "PIPER_HIP_DEBUG_KEEP", "PIPER_HIP_PAR_MRF",
-              "PIPER_HIP_FUSED", "PIPER_HIP_MRF2", "PIPER_HIP_FUSE_DP"):
+              "PIPER_HIP_FUSED", "PIPER_HIP_MRF2", "PIPER_HIP_FUSE_DP", "PIPER_HIP_FOLD_LN",
+              "PIPER_HIP_MRF2_MAXF"):
         monkeypatch.delenv(k, raising=False)
     for k, v in (env or {}).items():
         monkeypatch.setenv(k, str(v))
@@ -152,6 +153,8 @@ FORCED = [
     ("medium", [128, 40], {"PIPER_HIP_SPLITK_MAX": 0, "PIPER_HIP_TPB": 3, "PIPER_HIP_MRF2": 0}, set()),
     # the duration predictor with ConvFlow.pre / proj / spline as separate launches (default: fused into the DDSConv layers)
     ("medium", [128, 31], {"PIPER_HIP_FUSE_DP": 0}, {"conv_splitk_kernel<1,false,8,4>"}),
+    # the encoder's LayerNorms as their own launches (default for one or two utterances: folded into the consumer convs)
+    ("medium", [128, 50], {"PIPER_HIP_FOLD_LN": 0}, {"ln_kernel<0>"}),
     # split-K variants: 4/8-wave only (no 16-column form), 12-wave everywhere, 16-column form everywhere
     ("medium", [128], {"PIPER_HIP_SPLITK16": 0, "PIPER_HIP_WIDE_SPLITK": 0},
      {"conv_splitk_kernel<2,true,8,3>", "conv_splitk_kernel<1,false,8,4>", "conv_splitk_kernel<1,false,4,4>"}),
@@ -332,7 +335,7 @@ def test_fused_mrf2_stage_kernel_matches_unfused_and_oracle(monkeypatch, preset,
     and the MRF sum in registers) against the conv-by-conv schedule (PIPER_HIP_MRF2=0) and the oracle."""
     cfg, w = voice(preset)
     ids, nw, nz = batch_inputs(cfg, lens, seed=81)
-    fused = make_engine(monkeypatch, cfg, w)
+    fused = make_engine(monkeypatch, cfg, w, {"PIPER_HIP_MRF2": 2})      # 2 = also for batches (default: small ones only)
     names, worst = run_and_check(fused, cfg, w, ids, nw, nz, sample=sorted({0, len(lens) - 1}))
     assert any(n.startswith("mrf2_kernel<") for n in names), names
     a = fused.synthesize_batch(ids, SCALES, noise_w=nw, noise_z=nz)
