@@ -467,6 +467,7 @@ void Engine::init(const WeightSet& ws) {
   if (const char* t = getenv("PIPER_HIP_DEBUG_KEEP")) debug_keep_ = atoi(t) != 0;     // tests: keep z_p for debug_tensor
   if (const char* t = getenv("PIPER_HIP_FUSE_DP")) fuse_dp_ = atoi(t) != 0;           // A/B knob, tests
   if (const char* t = getenv("PIPER_HIP_FOLD_LN")) fold_ln_ = atoi(t) != 0;           // A/B knob, tests
+  if (const char* t = getenv("PIPER_HIP_SPEC")) spec_enable_ = atoi(t) != 0;          // speculative stage B (A/B, tests)
 }
 
 Engine::~Engine() { free_all(); }
@@ -531,6 +532,7 @@ void Engine::ensure_stage_a(int B, int Tmax) {
     d_dur_ = c.take<int>(Bc * T);
     d_cum_ = c.take<int>(Bc * T);
     d_frames_ = c.take<int>(Bc);
+    d_framesc_ = c.take<int>(Bc);
     absmax_ = c.take<unsigned>(Bc);
     x_ = c.take<float>(Bc * H_ * T);
     y_ = c.take<float>(Bc * H_ * T);
@@ -1381,7 +1383,7 @@ void Engine::issue_stage_a() {
   {
     const int c0 = (flips & 1) ? 1 : 0;     // physical channel holding logical channel 0 = logw
     PE_LAUNCH(duration_kernel, dim3(B), dim3(256), 0, stream_, z2_ + (long)c0 * Ts, (long)2 * Ts, ea_m0_, ea_es0_,
-              scales_[1], d_tlens_, d_dur_, d_cum_, Ts, d_frames_, logw_, h_frames_);
+              scales_[1], d_tlens_, d_dur_, d_cum_, Ts, d_frames_, logw_, h_frames_, d_framesc_, std::max(Fs_, 1));
   }
   prof_end(1, fl);
 }
@@ -1412,7 +1414,7 @@ void Engine::issue_flow() {
   {
     RegP rp;
     rp.stats = stats_; rp.s_bs = (long)2 * C_ * Ts; rp.s_cs = Ts;
-    rp.cum = d_cum_; rp.d_bs = Ts; rp.tlens = d_tlens_; rp.frames = d_frames_;
+    rp.cum = d_cum_; rp.d_bs = Ts; rp.tlens = d_tlens_; rp.frames = lens_b_;
     rp.noise = noise_z_; rp.n_bs = (long)C_ * Fs; rp.n_cs = Fs;
     rp.noise_scale = scales_[0];
     rp.out = zp_; rp.o_bs = (long)C_ * Fs; rp.o_cs = Fs; rp.C = C_;
@@ -1428,15 +1430,15 @@ void Engine::issue_flow() {
     Rcl& r = rcls_[ri];
     const View x0{zp_ + (long)r.in_off * Fs, (long)C_ * Fs, Fs};
     const View x1{zp_ + (long)r.out_off * Fs, (long)C_ * Fs, Fs};
-    conv(r.pre, x0, fh, d_frames_, 1, Fmax, EPI_STORE);
+    conv(r.pre, x0, fh, lens_b_, 1, Fmax, EPI_STORE);
     const int nl = (int)r.in.size();
     for (int i = 0; i < nl; ++i) {
       const float* b2 = nspk_ > 1 ? cond_ + cond_off_wn_[ri] + (long)i * 2 * H_ : nullptr;
-      conv(r.in[i], fh, facts, d_frames_, 1, Fmax, EPI_GATE, 1.f, ACT_NONE, none, none, 0, 1.f, b2, cond_bs_);
-      conv(r.rs[i], facts, fh, d_frames_, 1, Fmax, EPI_WNRS, 1.f, ACT_NONE, none, fskip, i == 0 ? 1 : 0);
+      conv(r.in[i], fh, facts, lens_b_, 1, Fmax, EPI_GATE, 1.f, ACT_NONE, none, none, 0, 1.f, b2, cond_bs_);
+      conv(r.rs[i], facts, fh, lens_b_, 1, Fmax, EPI_WNRS, 1.f, ACT_NONE, none, fskip, i == 0 ? 1 : 0);
       fl += 2.0 * fsum * (r.in[i].macs_per_col + r.rs[i].macs_per_col);
     }
-    conv(r.post, fskip, x1, d_frames_, 1, Fmax, EPI_SUBFROM);
+    conv(r.post, fskip, x1, lens_b_, 1, Fmax, EPI_SUBFROM);
     fl += 2.0 * fsum * (r.pre.macs_per_col + r.post.macs_per_col);
     (void)half;
   }
@@ -1448,7 +1450,7 @@ void Engine::issue_stage_b() {
   issue_flow();
   double fsum = 0;
   for (int b = 0; b < B_; ++b) fsum += frames_h_[b];
-  issue_decoder(zp_, d_frames_, Fg_, fsum, false);     // regulate_kernel zeroed the peak accumulators
+  issue_decoder(zp_, lens_b_, Fg_, fsum, false);     // regulate_kernel zeroed the peak accumulators
 }
 
 // streaming: window of z -> window buffer -> generator (lens = window length, in device memory)
@@ -1639,26 +1641,36 @@ void Engine::drop_graphs() {
 void Engine::run() {
   PE_HIP(hipSetDevice(device_));
   const int B = B_;
+  spec_pending_ = false;
   Tg_ = std::min(rup(Tmax_, 32), Ts_);
   run_launches_ = 0;
+  // speculative sizing of stage B from the previous run's frames-per-id ratio (see engine.h)
+  bool spec = spec_enable_ && B <= spec_max_batch_ && last_ratio_ > 0.f && !have_noise_z_ && use_graphs_ && !prof_on_;
+  int fguess = 0;
+  if (spec) {
+    fguess = rup((int)std::ceil(last_ratio_ * 1.25f * (float)Tmax_) + 1, 32);
+    if (fguess > MAX_FRAMES) spec = false;
+  }
+  if (spec) ensure_stage_b(fguess);              // before stage A is enqueued: growing the workspace drops every graph
   char key[160];
-  snprintf(key, sizeof(key), "A|%d|%d|%d|%a|%a|%d", B, Tg_, Ts_, scales_[1], scales_[2], (int)have_noise_w_);
+  snprintf(key, sizeof(key), "A|%d|%d|%d|%a|%a|%d|%d", B, Tg_, Ts_, scales_[1], scales_[2], (int)have_noise_w_, Fs_);
   run_stage('A', key);
   ++call_;                                    // mirrors the device-side counter bump of this run
+  if (spec) {
+    Fg_ = std::min(fguess, Fs_);
+    frames_h_.assign(B, Fg_);                 // placeholder for FLOP accounting while issuing; real counts in finish_run()
+    lens_b_ = d_framesc_;
+    snprintf(key, sizeof(key), "S|%d|%d|%d|%d|%a", B, Fg_, Fs_, Ts_, scales_[0]);
+    run_stage('B', key);
+    spec_pending_ = true;
+    spec_fg_ = Fg_;
+    return;
+  }
   PE_HIP(hipStreamSynchronize(stream_));      // the only data-dependent shape: F
-#ifdef PE_EMU
-  if (const char* pf = getenv("EMU_PLAN_FRAMES"))      // emulator plan-only mode (tests/emu): frames are not computed
-    for (int b = 0; b < B; ++b) h_frames_[b] = atoi(pf);
-#endif
-  frames_h_.assign(h_frames_, h_frames_ + B);
-  int Fmax = 1;
-  for (int b = 0; b < B; ++b) Fmax = std::max(Fmax, frames_h_[b]);
-  if (Fmax > MAX_FRAMES)
-    throw std::runtime_error("utterance too long: more than " + std::to_string(MAX_FRAMES) + " spectrogram frames "
-                             "(check length_scale)");
-  Fmax_ = Fmax;
-  ensure_stage_b(rup(Fmax, 32));
-  Fg_ = std::min(rup(Fmax, 32), Fs_);
+  finish_stage_b_sizes();
+  ensure_stage_b(rup(Fmax_, 32));
+  Fg_ = std::min(rup(Fmax_, 32), Fs_);
+  lens_b_ = d_frames_;
   if (have_noise_z_) {
     const long l0 = g_launches;
     issue_stage_b();                           // host-injected noise (tests): not graph-captured
@@ -1667,34 +1679,84 @@ void Engine::run() {
     snprintf(key, sizeof(key), "B|%d|%d|%d|%d|%a", B, Fg_, Fs_, Ts_, scales_[0]);
     run_stage('B', key);
   }
+}
+
+// Host view of the frame counts stage A produced (the stream is synchronised): frames, sample offsets, the ratio the
+// next run's guess is made from.
+void Engine::finish_stage_b_sizes() {
+  const int B = B_;
+#ifdef PE_EMU
+  if (const char* pf = getenv("EMU_PLAN_FRAMES"))      // emulator plan-only mode (tests/emu): frames are not computed
+    for (int b = 0; b < B; ++b) h_frames_[b] = atoi(pf);
+#endif
+  frames_h_.assign(h_frames_, h_frames_ + B);
+  int Fmax = 1;
+  float ratio = 0.f;
+  for (int b = 0; b < B; ++b) {
+    Fmax = std::max(Fmax, frames_h_[b]);
+    ratio = std::max(ratio, (float)frames_h_[b] / (float)tlens_h_[b]);
+  }
+  if (Fmax > MAX_FRAMES)
+    throw std::runtime_error("utterance too long: more than " + std::to_string(MAX_FRAMES) + " spectrogram frames "
+                             "(check length_scale)");
+  Fmax_ = Fmax;
+  last_ratio_ = ratio;
   sample_off_.assign(B + 1, 0);
   for (int b = 0; b < B; ++b) sample_off_[b + 1] = sample_off_[b] + (int64_t)frames_h_[b] * hop_;
 }
 
+bool Engine::finish_run() {
+  if (!spec_pending_) return true;
+  spec_pending_ = false;
+  PE_HIP(hipStreamSynchronize(stream_));
+  finish_stage_b_sizes();
+  if (Fmax_ <= spec_fg_) return true;          // the guessed bucket covered every utterance: the results stand
+  ++spec_misses_;
+  ensure_stage_b(rup(Fmax_, 32));
+  Fg_ = std::min(rup(Fmax_, 32), Fs_);
+  lens_b_ = d_frames_;
+  char key[160];
+  snprintf(key, sizeof(key), "B|%d|%d|%d|%d|%a", B_, Fg_, Fs_, Ts_, scales_[0]);
+  run_stage('B', key);
+  return false;
+}
+
 void Engine::download(bool want_audio, bool want_pcm) {
-  const size_t total = (size_t)sample_off_[B_];
-  if (want_audio) {
-    if (total > h_audio_cap_) {
+  auto grow = [&](size_t total) {
+    if (want_audio && total > h_audio_cap_) {
       if (h_audio_) PE_HIP(hipHostFree(h_audio_));
       h_audio_cap_ = total + total / 2;
       PE_HIP(hipHostMalloc((void**)&h_audio_, h_audio_cap_ * sizeof(float)));
     }
-    for (int b = 0; b < B_; ++b)
-      PE_HIP(hipMemcpyAsync(h_audio_ + sample_off_[b], audio_ + (size_t)b * Ss_,
-                            (size_t)(sample_off_[b + 1] - sample_off_[b]) * sizeof(float), hipMemcpyDeviceToHost,
-                            stream_));
-  }
-  if (want_pcm) {
-    if (total > h_pcm_cap_) {
+    if (want_pcm && total > h_pcm_cap_) {
       if (h_pcm_) PE_HIP(hipHostFree(h_pcm_));
       h_pcm_cap_ = total + total / 2;
       PE_HIP(hipHostMalloc((void**)&h_pcm_, h_pcm_cap_ * sizeof(int16_t)));
     }
+  };
+  if (spec_pending_ && B_ == 1 && (want_audio || want_pcm)) {
+    // one utterance, speculative run: the copies are enqueued for the guessed length (>= the real one when the guess
+    // holds) behind stage B, so that one synchronisation ends the whole call; the host view is trimmed afterwards
+    const size_t n = (size_t)spec_fg_ * hop_;
+    grow(n);
+    if (want_audio) PE_HIP(hipMemcpyAsync(h_audio_, audio_, n * sizeof(float), hipMemcpyDeviceToHost, stream_));
+    if (want_pcm) PE_HIP(hipMemcpyAsync(h_pcm_, pcm_, n * sizeof(int16_t), hipMemcpyDeviceToHost, stream_));
+    if (finish_run()) return;                  // synchronises; sample_off_ now holds the real length
+  } else {
+    finish_run();
+  }
+  const size_t total = (size_t)sample_off_[B_];
+  grow(total);
+  if (want_audio)
+    for (int b = 0; b < B_; ++b)
+      PE_HIP(hipMemcpyAsync(h_audio_ + sample_off_[b], audio_ + (size_t)b * Ss_,
+                            (size_t)(sample_off_[b + 1] - sample_off_[b]) * sizeof(float), hipMemcpyDeviceToHost,
+                            stream_));
+  if (want_pcm)
     for (int b = 0; b < B_; ++b)
       PE_HIP(hipMemcpyAsync(h_pcm_ + sample_off_[b], pcm_ + (size_t)b * Ss_,
                             (size_t)(sample_off_[b + 1] - sample_off_[b]) * sizeof(int16_t), hipMemcpyDeviceToHost,
                             stream_));
-  }
   PE_HIP(hipStreamSynchronize(stream_));
 }
 
@@ -1703,17 +1765,17 @@ int Engine::stream_begin(const int64_t* ids, int64_t n, const float scales[3], i
   const int64_t sids[1] = {sid < 0 ? 0 : sid};
   upload(ids, offs, 1, scales, sids, noise);
   PE_HIP(hipSetDevice(device_));
+  spec_pending_ = false;
   Tg_ = std::min(rup(Tmax_, 32), Ts_);
   char key[160];
-  snprintf(key, sizeof(key), "A|%d|%d|%d|%a|%a|%d", 1, Tg_, Ts_, scales_[1], scales_[2], (int)have_noise_w_);
+  snprintf(key, sizeof(key), "A|%d|%d|%d|%a|%a|%d|%d", 1, Tg_, Ts_, scales_[1], scales_[2], (int)have_noise_w_, Fs_);
   run_stage('A', key);
   ++call_;
   PE_HIP(hipStreamSynchronize(stream_));
-  frames_h_.assign(h_frames_, h_frames_ + 1);
-  Fmax_ = std::max(1, frames_h_[0]);
-  if (Fmax_ > MAX_FRAMES) throw std::runtime_error("utterance too long: more than " + std::to_string(MAX_FRAMES) + " frames");
+  finish_stage_b_sizes();
   ensure_stage_b(rup(Fmax_, 32));
   Fg_ = std::min(rup(Fmax_, 32), Fs_);
+  lens_b_ = d_frames_;
   if (have_noise_z_) {
     issue_flow();
   } else {
@@ -1770,6 +1832,7 @@ bool Engine::stream_next(int chunk_frames, const float** audio, const int16_t** 
 }
 
 const std::vector<int32_t>& Engine::durations_host() {
+  finish_run();
   std::vector<int> tmp((size_t)B_ * Ts_);
   PE_HIP(hipMemcpy(tmp.data(), d_dur_, tmp.size() * sizeof(int), hipMemcpyDeviceToHost));
   dur_h_.clear();
@@ -1799,6 +1862,7 @@ void Engine::debug_randn(int site, uint64_t call, int64_t n, float* out) {
 // Per-stage tensors for parity debugging (tests only): name in {x_enc, stats (m_p | logs_p), xg, logw, z_p, z, noise_w,
 // noise_z, audio}.
 void Engine::debug_tensor(const std::string& name, int b, std::vector<float>& out, int* rows, int* cols) {
+  finish_run();
   PE_HIP(hipStreamSynchronize(stream_));
   const float* src = nullptr;
   int R = 0, Cn = 0;

@@ -71,17 +71,18 @@ class Engine {
   int decoder_halo_frames() const { return halo_frames_; }
 
   int batch() const { return B_; }
-  const std::vector<int64_t>& sample_offsets() const { return sample_off_; }
+  const std::vector<int64_t>& sample_offsets() { finish_run(); return sample_off_; }
   const float* audio_host() const { return h_audio_; }
   const int16_t* pcm_host() const { return h_pcm_; }
   const std::vector<int32_t>& durations_host();   // concatenated per id, same offsets as ids
-  const std::vector<int32_t>& frames_host() const { return frames_h_; }
+  const std::vector<int32_t>& frames_host() { finish_run(); return frames_h_; }
   void debug_tensor(const std::string& name, int b, std::vector<float>& out, int* rows, int* cols);
   // test hook: n draws of the engine's N(0,1) generator (randn_kernel) at sampling site 0/1 with the engine's
   // seed and the given call counter, exactly what run() would draw at that counter
   void debug_randn(int site, uint64_t call, int64_t n, float* out);
   uint64_t rng_call() const { return call_; }
-  long run_launches() const { return run_launches_; }   // kernel launches (graph nodes) of the last run()
+  long run_launches() const { return run_launches_; }
+  long speculation_misses() const { return spec_misses_; }   // kernel launches (graph nodes) of the last run()
 
   void set_seed(uint64_t s) { seed_ = s; }
   void set_use_graphs(bool on) { use_graphs_ = on; }
@@ -123,7 +124,7 @@ class Engine {
   enum { ROUTE_TILE = 0, ROUTE_SPLITK = 1, ROUTE_SPLITK16 = 2 };
   int route(const PackedConv& pc, int ncols, int epi) const;
   bool can_fold_ln(const PackedConv& pc, int ncols) const;
-  bool fold_ln_ = true;                     // PIPER_HIP_FOLD_LN=0: encoder LayerNorms as their own launches (A/B, tests)
+  bool fold_ln_ = false;                    // PIPER_HIP_FOLD_LN=1: encoder LayerNorms folded into the consuming split-K convs (measured slower, profiles/r02_notes.md)
   void layer_norm(int mode, View in, View res, View out, const float* g, const float* b, const float* dw_w,
                   const float* dw_b, int dw_k, int dw_dil, int C, const int* lens, int Lmax);
   // options of one DDSConv run: ConvFlow.pre folded into the first layer, a 1x1 conv (+ spline) fused after the last
@@ -146,6 +147,19 @@ class Engine {
   void run_stage(char which, const std::string& key);
   void dispatch_stage(char which);
   void drop_graphs();
+  // Speculative stage B (one to spec_max_batch_ utterances): the frame count F is the path's only data-dependent
+  // shape and normally costs a host round trip in the middle of the pipeline. When a previous run of this engine gives
+  // a frames-per-id estimate, stage B is launched right behind stage A for a guessed bucket (kernels read the true
+  // lengths from device memory, clamped to the allocated capacity), and the guess is verified when the results are
+  // fetched; a wrong guess re-runs stage B with the right size.
+  bool finish_run();                 // completes a speculative run; false if stage B had to be re-run
+  void finish_stage_b_sizes();
+  bool spec_enable_ = true, spec_pending_ = false;
+  int spec_max_batch_ = 4, spec_fg_ = 0;
+  float last_ratio_ = 0.f;
+  long spec_misses_ = 0;
+  int* d_framesc_ = nullptr;
+  const int* lens_b_ = nullptr;      // frame counts stage B reads: d_frames_, or d_framesc_ on a speculative run
   void prof_begin();
   void prof_end(int row, double flops);
 

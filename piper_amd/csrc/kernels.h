@@ -1565,7 +1565,7 @@ static constexpr int MAX_FRAMES = 60000;      // per-utterance activations stay 
 __global__ __launch_bounds__(256) void duration_kernel(const float* z0, long z_bs, float m0, float es0,
                                                        float length_scale, const int* lens, int* dur,
                                                        int* cum, int d_bs, int* frames, float* logw_out,
-                                                       int* frames_host) {
+                                                       int* frames_host, int* frames_clamped, int frame_cap) {
   __shared__ long long part[256];
   const int b = blockIdx.x, T = lens[b], tid = threadIdx.x;
   const int per = (T + 255) / 256;
@@ -1591,6 +1591,8 @@ __global__ __launch_bounds__(256) void duration_kernel(const float* z0, long z_b
     // the host sizes stage B from this count: written straight into pinned host memory (visible once the stream is
     // synchronised), which saves the device-to-host copy node behind this kernel
     if (frames_host) frames_host[b] = f;
+    // speculative stage B (launched before the host has seen f): lengths clamped to the allocated frame capacity
+    frames_clamped[b] = f < frame_cap ? f : frame_cap;
   }
   __syncthreads();
   long long run = part[tid];

@@ -153,8 +153,8 @@ FORCED = [
     ("medium", [128, 40], {"PIPER_HIP_SPLITK_MAX": 0, "PIPER_HIP_TPB": 3, "PIPER_HIP_MRF2": 0}, set()),
     # the duration predictor with ConvFlow.pre / proj / spline as separate launches (default: fused into the DDSConv layers)
     ("medium", [128, 31], {"PIPER_HIP_FUSE_DP": 0}, {"conv_splitk_kernel<1,false,8,4>"}),
-    # the encoder's LayerNorms as their own launches (default for one or two utterances: folded into the consumer convs)
-    ("medium", [128, 50], {"PIPER_HIP_FOLD_LN": 0}, {"ln_kernel<0>"}),
+    # the encoder's LayerNorms folded into the consuming split-K convs (opt-in: measured slower than ln_kernel launches)
+    ("medium", [128, 50], {"PIPER_HIP_FOLD_LN": 1}, {"conv_splitk_kernel<1,false,8,4>"}),
     # split-K variants: 4/8-wave only (no 16-column form), 12-wave everywhere, 16-column form everywhere
     ("medium", [128], {"PIPER_HIP_SPLITK16": 0, "PIPER_HIP_WIDE_SPLITK": 0},
      {"conv_splitk_kernel<2,true,8,3>", "conv_splitk_kernel<1,false,8,4>", "conv_splitk_kernel<1,false,4,4>"}),
