@@ -454,7 +454,8 @@ void Engine::init(const WeightSet& ws) {
   for (auto n : rows) prof_.push_back(ProfileRow{n});
   PE_HIP(hipEventCreate(&ev0_));
   PE_HIP(hipEventCreate(&ev1_));
-  PE_HIP(hipHostMalloc((void**)&h_frames_, 4096 * sizeof(int)));
+  PE_HIP(hipHostMalloc((void**)&h_frames_, (4096 + 16) * sizeof(int)));     // [4096]: error word of the persistent kernels
+  h_frames_[4096] = 0;
   if (const char* ng = getenv("PIPER_HIP_NO_GRAPH")) use_graphs_ = !(ng[0] && ng[0] != '0');
   if (const char* t = getenv("PIPER_HIP_TPB")) tpb_override_ = atoi(t);     // tuning / test knob
   if (const char* t = getenv("PIPER_HIP_WIDE_MIN")) wide_min_blocks_ = atol(t);
@@ -468,6 +469,7 @@ void Engine::init(const WeightSet& ws) {
   if (const char* t = getenv("PIPER_HIP_FUSE_DP")) fuse_dp_ = atoi(t) != 0;           // A/B knob, tests
   if (const char* t = getenv("PIPER_HIP_FOLD_LN")) fold_ln_ = atoi(t) != 0;           // A/B knob, tests
   if (const char* t = getenv("PIPER_HIP_SPEC")) spec_enable_ = atoi(t) != 0;          // speculative stage B (A/B, tests)
+  if (const char* t = getenv("PIPER_HIP_PERSIST_DP")) persist_dp_ = atoi(t) != 0;     // persistent duration-predictor kernel
 }
 
 Engine::~Engine() { free_all(); }
@@ -550,6 +552,9 @@ void Engine::ensure_stage_a(int B, int Tmax) {
     noise_w_ = c.take<float>(Bc * 2 * T);
     cond_ = c.take<float>(Bc * (size_t)std::max(cond_bs_, 1));
     d_rng_ = c.take<unsigned long long>(4);
+    dp_prog_bs_ = (int)(T / 16);
+    dp_progress_ = c.take<unsigned>(Bc * (T / 16));
+    dp_state_ = c.take<unsigned>(4 + Bc);
     return c.off + 256;
   };
   if (grow || !wsA_) {
@@ -560,6 +565,10 @@ void Engine::ensure_stage_a(int B, int Tmax) {
     capB_F_ = 0;
     wsA_bytes_ = carve(nullptr);
     PE_HIP(hipMalloc((void**)&wsA_, wsA_bytes_));
+    carve(wsA_);
+    // progress words / counters of the persistent kernels start from zero and are never reset afterwards
+    PE_HIP(hipMemset(dp_progress_, 0, capA_B_ * (capA_T_ / 16) * sizeof(unsigned)));
+    PE_HIP(hipMemset(dp_state_, 0, (4 + capA_B_) * sizeof(unsigned)));
   }
   carve(wsA_);
 }
@@ -1078,7 +1087,7 @@ void Engine::layer_norm(int mode, View in, View res, View out, const float* g, c
 
 // DDSConv.forward (modules.py:117-129): one fused launch per layer (dds_layer16_kernel), ping-ponging between
 // `out` and `tmp` so that the last layer lands in `out`; `in` must not alias the first layer's target.
-void Engine::dds(const DdsW& d, View in, View out, View tmp, const DdsOpt* opt) {
+void Engine::dds_params(const DdsW& d, View in, View out, View tmp, const DdsOpt* opt, std::vector<DdsP>& list) {
   int dil = 1;
   const int n = (int)d.c1x1.size();
   View cur = in;
@@ -1105,6 +1114,16 @@ void Engine::dds(const DdsW& d, View in, View out, View tmp, const DdsOpt* opt) 
     p.wp16 = d.w16[i];
     p.nchunks = d.c1x1[i].nchunks;
     p.lens = d_tlens_; p.H = H_;
+    list.push_back(p);
+    dil *= ksz_;
+    cur = dst;
+  }
+}
+
+void Engine::dds(const DdsW& d, View in, View out, View tmp, const DdsOpt* opt) {
+  std::vector<DdsP> list;
+  dds_params(d, in, out, tmp, opt, list);
+  for (const DdsP& p : list) {
     const int kh = kbegin(prof_level_ >= 2 ? krow(p.nchunks <= 3 ? "dds_layer16_kernel<3>" : p.nchunks <= 6 ? "dds_layer16_kernel<6>"
                                                                                        : "dds_layer16_kernel<8>") : 0, 0.0);
     const dim3 grid16((Tg_ + 15) / 16, B_);
@@ -1113,8 +1132,6 @@ void Engine::dds(const DdsW& d, View in, View out, View tmp, const DdsOpt* opt) 
     else if (p.nchunks <= 6) PE_LAUNCH(dds_layer16_kernel<6>, grid16, dim3(512), smem16, stream_, p);
     else PE_LAUNCH(dds_layer16_kernel<8>, grid16, dim3(512), smem16, stream_, p);
     kend(kh);
-    dil *= ksz_;
-    cur = dst;
   }
 }
 
@@ -1332,10 +1349,18 @@ void Engine::issue_stage_a() {
   prof_begin();
   fl = 0;
   conv(dp_pre_, x, dy, d_tlens_, 1, T, EPI_STORE, 1.f, ACT_NONE, none, none, 0, 1.f, cb_dp, cond_bs_);
+  // One persistent launch for the whole DDSConv chain + durations when the grid fits one workgroup per CU (a few
+  // utterances): the layers hand halo columns to their neighbours in memory instead of ending the kernel
+  // (dp_persist_kernel). Otherwise one launch per layer.
+  const int ndds = arch_[A_DDSLAYERS] * (1 + (int)cflows_.size());
+  const bool persist = persist_dp_ && fuse_dp_ && ndds <= DP_MAX_LAYERS && (long)((T + 15) / 16) * B <= 256 &&
+                       !(prof_level_ >= 2 && getenv("PIPER_HIP_PROFILE_LAYERS"));
+  std::vector<DdsP> chain;
   if (fuse_dp_) {
     DdsOpt o;                      // dp.proj fused after the last DDSConv layer (models.py:65)
     o.post_w16 = dp_proj16_; o.post_bias = dp_proj_.bias; o.post_rows = dp_proj_.rows; o.post_out = xg;
-    dds(dp_dds_, dy, dh, dy2, &o);
+    if (persist) dds_params(dp_dds_, dy, dh, dy2, &o, chain);
+    else dds(dp_dds_, dy, dh, dy2, &o);
   } else {
     dds(dp_dds_, dy, dh, dy2);
     conv(dp_proj_, dh, xg, d_tlens_, 1, T, EPI_STORE);
@@ -1368,7 +1393,8 @@ void Engine::issue_stage_a() {
       o.z_scale = fi == 0 ? scales_[2] : 1.f;
       o.post_w16 = cf.proj16; o.post_bias = cf.proj.bias; o.post_rows = cf.proj.rows;
       o.zin = zin; o.zin_bs = (long)2 * Ts; o.z_cs = Ts; o.c0 = c0; o.c1 = c1; o.zout = z2_; o.zout_bs = (long)2 * Ts;
-      dds(cf.dds, xg, dh, dy2, &o);
+      if (persist) dds_params(cf.dds, xg, dh, dy2, &o, chain);
+      else dds(cf.dds, xg, dh, dy2, &o);
     } else {
       PE_LAUNCH(cf_pre_kernel, dim3((T + 63) / 64, H_, B), dim3(64), 0, stream_, z2_ + (long)c0 * Ts, (long)2 * Ts,
                 cf.pre_w, cf.pre_b, xg_, (long)H_ * Ts, Ts, dy_, (long)H_ * Ts, Ts, d_tlens_, H_);
@@ -1382,8 +1408,28 @@ void Engine::issue_stage_a() {
   ++flips;   // the Flip before ElementwiseAffine
   {
     const int c0 = (flips & 1) ? 1 : 0;     // physical channel holding logical channel 0 = logw
-    PE_LAUNCH(duration_kernel, dim3(B), dim3(256), 0, stream_, z2_ + (long)c0 * Ts, (long)2 * Ts, ea_m0_, ea_es0_,
-              scales_[1], d_tlens_, d_dur_, d_cum_, Ts, d_frames_, logw_, h_frames_, d_framesc_, std::max(Fs_, 1));
+    DurP dp{};
+    dp.z0 = z2_ + (long)c0 * Ts; dp.z_bs = (long)2 * Ts; dp.m0 = ea_m0_; dp.es0 = ea_es0_; dp.length_scale = scales_[1];
+    dp.lens = d_tlens_; dp.dur = d_dur_; dp.cum = d_cum_; dp.d_bs = Ts; dp.frames = d_frames_; dp.logw_out = logw_;
+    dp.frames_host = h_frames_; dp.frames_clamped = d_framesc_; dp.frame_cap = std::max(Fs_, 1);
+    if (persist) {
+      DpPersistP pp{};
+      for (size_t i = 0; i < chain.size(); ++i) pp.layer[i] = chain[i];
+      pp.nlayers = (int)chain.size();
+      pp.dur = dp;
+      pp.progress = dp_progress_; pp.prog_bs = dp_prog_bs_; pp.state = dp_state_; pp.err_host = h_frames_ + 4096;
+      const int nch = chain[0].nchunks;
+      const size_t smem = ((size_t)2 * nch * 32 * 16 + 8 * 16 + 16) * sizeof(float) + 2048;
+      const dim3 grid((T + 15) / 16, B);
+      const char* nm = nch <= 3 ? "dp_persist_kernel<3>" : nch <= 6 ? "dp_persist_kernel<6>" : "dp_persist_kernel<8>";
+      const int kh = kbegin(prof_level_ >= 2 ? krow(nm) : 0, 0.0);
+      if (nch <= 3) PE_LAUNCH_COOP(dp_persist_kernel<3>, grid, dim3(512), smem, stream_, pp);
+      else if (nch <= 6) PE_LAUNCH_COOP(dp_persist_kernel<6>, grid, dim3(512), smem, stream_, pp);
+      else PE_LAUNCH_COOP(dp_persist_kernel<8>, grid, dim3(512), smem, stream_, pp);
+      kend(kh);
+    } else {
+      PE_LAUNCH(duration_kernel, dim3(B), dim3(256), 0, stream_, dp);
+    }
   }
   prof_end(1, fl);
 }
@@ -1689,6 +1735,12 @@ void Engine::finish_stage_b_sizes() {
   if (const char* pf = getenv("EMU_PLAN_FRAMES"))      // emulator plan-only mode (tests/emu): frames are not computed
     for (int b = 0; b < B; ++b) h_frames_[b] = atoi(pf);
 #endif
+  if (h_frames_[4096]) {          // a persistent kernel gave up waiting for a neighbour workgroup (never on a resident grid)
+    h_frames_[4096] = 0;
+    PE_HIP(hipMemset(dp_progress_, 0, capA_B_ * (capA_T_ / 16) * sizeof(unsigned)));
+    PE_HIP(hipMemset(dp_state_, 0, (4 + capA_B_) * sizeof(unsigned)));
+    throw std::runtime_error("persistent duration-predictor kernel: neighbour wait timed out");
+  }
   frames_h_.assign(h_frames_, h_frames_ + B);
   int Fmax = 1;
   float ratio = 0.f;

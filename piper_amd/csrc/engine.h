@@ -136,6 +136,12 @@ class Engine {
     const float* zin = nullptr; long zin_bs = 0; int z_cs = 0, c0 = 0, c1 = 1; float* zout = nullptr; long zout_bs = 0;
   };
   void dds(const DdsW& d, View in, View out, View tmp, const DdsOpt* opt = nullptr);
+  // the DdsP of every layer of one DDSConv run, appended to `out` (dds() launches them; the persistent
+  // duration-predictor kernel takes all twelve at once)
+  void dds_params(const DdsW& d, View in, View out, View tmp, const DdsOpt* opt, std::vector<struct DdsP>& list);
+  bool persist_dp_ = true;                  // PIPER_HIP_PERSIST_DP=0: one launch per DDSConv layer
+  unsigned *dp_progress_ = nullptr, *dp_state_ = nullptr;
+  int dp_prog_bs_ = 0;
   float* pack16(const std::vector<float>& W, int rows, int K);    // [16-row tile][q][lane][4] (dds_layer16_kernel)
   float* dp_proj16_ = nullptr;
   bool fuse_dp_ = true;                     // PIPER_HIP_FUSE_DP=0: cf_pre / proj / spline as separate launches (A/B, tests)

@@ -1306,13 +1306,15 @@ struct DdsP {
 // 32x32x2 MFMA: six row tiles on eight waves put two tiles on two of the SIMDs; 17.3 vs 11.0 us per launch.) k runs
 // over the input channels in ascending order inside and across the instructions: the same fmaf chain. Weights: packed by engine.cpp pack_dds16 as
 // [16-row tile][q][lane][4] with lane -> (row = lane & 15, k = lane >> 4) and step s = 4q + j covering ci = 4s + k.
-template <int NVT>                              // channel slots per thread: ceil(Hp / 32)
-__global__ __launch_bounds__(512) void dds_layer16_kernel(DdsP p) {
-  constexpr int NC = 16;
-  PE_DYN_SMEM(float, sm);                       // Y[Hp][16] | Z[Hp][16] | red[8][16]
-  const int b = blockIdx.y, L = p.lens[b];
-  const int t0 = blockIdx.x * NC;
+// SC1: the layer's activations travel between workgroups of ONE launch (dp_persist_kernel): agent-scope loads / stores.
+template <int NVT, bool SC1>                    // NVT = channel slots per thread: ceil(Hp / 32)
+__device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b, float* sm) {
+  constexpr int NC = 16;                        // sm: Y[Hp][16] | Z[Hp][16] | red[8][16]
+  const int L = p.lens[b];
+  const int t0 = ctile * NC;
   if (t0 >= L) return;
+  auto ldx = [&](const pe_rowsrc& r, int idx) { return SC1 ? pe_row_load_sc1(r, idx) : pe_row_load(r, idx); };
+  auto stg = [&](float* q, float v) { if (SC1) pe_st_sc1(q, v); else *q = v; };
   const int H = p.H, Hp = p.nchunks * 32;
   float* Y = sm;
   float* Z = Y + Hp * NC;
@@ -1352,7 +1354,7 @@ __global__ __launch_bounds__(512) void dds_layer16_kernel(DdsP p) {
 #pragma unroll
     for (int kk = 0; kk < MAXK; ++kk) {
       const int tt = t + kk * p.dw_dil - pad;
-      zt[kk] = pe_row_load(zd, (ok && kk < p.dw_k && tt >= 0 && tt < L) ? tt : -1) * p.z_scale;
+      zt[kk] = ldx(zd, (ok && kk < p.dw_k && tt >= 0 && tt < L) ? tt : -1) * p.z_scale;
     }
 #pragma unroll
     for (int k = 0; k < NVT; ++k) {
@@ -1362,7 +1364,7 @@ __global__ __launch_bounds__(512) void dds_layer16_kernel(DdsP p) {
       for (int kk = 0; kk < MAXK; ++kk) {
         const int tt = t + kk * p.dw_dil - pad;
         const bool tv = cv && kk < p.dw_k && tt >= 0 && tt < L;
-        xv[k][kk] = pe_row_load(xd, tv ? c * p.x_cs + tt : -1);
+        xv[k][kk] = ldx(xd, tv ? c * p.x_cs + tt : -1);
         ww[k][kk] = pe_row_load(wd, tv ? c * p.dw_k + kk : -1);
       }
       wb[k] = pe_row_load(bd, cv ? c : -1);
@@ -1469,7 +1471,7 @@ __global__ __launch_bounds__(512) void dds_layer16_kernel(DdsP p) {
 #pragma unroll
     for (int k = 0; k < NVT; ++k) {
       const int c = rl + 32 * k;
-      if (c < H) ob[(long)c * p.o_cs + t] = xc[k] + gelu_erf((v[k] - mean) * rstd * gg[k] + bb[k]);
+      if (c < H) stg(ob + (long)c * p.o_cs + t, xc[k] + gelu_erf((v[k] - mean) * rstd * gg[k] + bb[k]));
     }
     return;
   }
@@ -1518,7 +1520,7 @@ __global__ __launch_bounds__(512) void dds_layer16_kernel(DdsP p) {
 #pragma unroll
     for (int k = 0; k < NVT; ++k) {
       const int c = rl + 32 * k;
-      if (c < p.post_rows) po[(long)c * p.po_cs + t] = Z[c * NC + col];
+      if (c < p.post_rows) stg(po + (long)c * p.po_cs + t, Z[c * NC + col]);
     }
   }
   if (p.zout) {
@@ -1547,12 +1549,19 @@ __global__ __launch_bounds__(512) void dds_layer16_kernel(DdsP p) {
       for (int i = 0; i <= NB; ++i) dv[i] = S[(scol * 3 + 2) * 16 + i];
       const float* zi = p.zin + (long)b * p.zin_bs;
       float* zo = p.zout + (long)b * p.zout_bs;
-      const float x1 = zi[(long)p.c1 * p.z_cs + st] * p.z_scale, x0 = zi[(long)p.c0 * p.z_cs + st] * p.z_scale;
-      zo[(long)p.c1 * p.z_cs + st] = (x1 >= -5.0f && x1 <= 5.0f) ? spline_finish(uw, uh, dv, x1) : x1;
-      zo[(long)p.c0 * p.z_cs + st] = x0;
+      const float x1 = (SC1 ? pe_ld_sc1(zi + (long)p.c1 * p.z_cs + st) : zi[(long)p.c1 * p.z_cs + st]) * p.z_scale;
+      const float x0 = (SC1 ? pe_ld_sc1(zi + (long)p.c0 * p.z_cs + st) : zi[(long)p.c0 * p.z_cs + st]) * p.z_scale;
+      stg(zo + (long)p.c1 * p.z_cs + st, (x1 >= -5.0f && x1 <= 5.0f) ? spline_finish(uw, uh, dv, x1) : x1);
+      stg(zo + (long)p.c0 * p.z_cs + st, x0);
     }
   }
   (void)ok;
+}
+
+template <int NVT>
+__global__ __launch_bounds__(512) void dds_layer16_kernel(DdsP p) {
+  PE_DYN_SMEM(float, sm);
+  dds_layer16_body<NVT, false>(p, blockIdx.x, blockIdx.y, sm);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1562,43 +1571,131 @@ __global__ __launch_bounds__(512) void dds_layer16_kernel(DdsP p) {
 // Sums run in 64 bits and are clamped to MAX_FRAMES + 1 (a single duration to 1e6): an absurd length_scale cannot
 // overflow `cum`, and the host rejects frames > MAX_FRAMES before sizing stage B from it.
 static constexpr int MAX_FRAMES = 60000;      // per-utterance activations stay below the 2 GiB descriptor range
-__global__ __launch_bounds__(256) void duration_kernel(const float* z0, long z_bs, float m0, float es0,
-                                                       float length_scale, const int* lens, int* dur,
-                                                       int* cum, int d_bs, int* frames, float* logw_out,
-                                                       int* frames_host, int* frames_clamped, int frame_cap) {
-  __shared__ long long part[256];
-  const int b = blockIdx.x, T = lens[b], tid = threadIdx.x;
+struct DurP {
+  const float* z0; long z_bs; float m0, es0, length_scale;
+  const int* lens; int* dur; int* cum; int d_bs; int* frames; float* logw_out;
+  int* frames_host; int* frames_clamped; int frame_cap;
+};
+// `part`: 256 long longs of LDS. The first 256 threads of the workgroup work, all of them must call (barriers).
+template <bool SC1>
+__device__ __forceinline__ void duration_body(const DurP& p, int b, long long* part) {
+  const int T = p.lens[b], tid = threadIdx.x;
   const int per = (T + 255) / 256;
   const int lo = tid * per, hi = (lo + per < T) ? lo + per : T;
   long long s = 0;
-  for (int t = lo; t < hi; ++t) {
-    const float logw = (z0[(long)b * z_bs + t] - m0) * es0;
-    const float w = expf(logw) * length_scale;
-    float c = ceilf(w);
-    c = c < 0.f ? 0.f : (c > 1.0e6f ? 1.0e6f : c);
-    const int d = (int)c;
-    dur[b * d_bs + t] = d;
-    if (logw_out) logw_out[(long)b * d_bs + t] = logw;
-    s += d;
+  if (tid < 256) {
+    for (int t = lo; t < hi; ++t) {
+      const float zv = SC1 ? pe_ld_sc1(p.z0 + (long)b * p.z_bs + t) : p.z0[(long)b * p.z_bs + t];
+      const float logw = (zv - p.m0) * p.es0;
+      const float w = expf(logw) * p.length_scale;
+      float c = ceilf(w);
+      c = c < 0.f ? 0.f : (c > 1.0e6f ? 1.0e6f : c);
+      const int d = (int)c;
+      p.dur[b * p.d_bs + t] = d;
+      if (p.logw_out) p.logw_out[(long)b * p.d_bs + t] = logw;
+      s += d;
+    }
+    part[tid] = s;
   }
-  part[tid] = s;
   __syncthreads();
   if (tid == 0) {
     long long run = 0;
     for (int i = 0; i < 256; ++i) { const long long v = part[i]; part[i] = run; run += v; }
     const int f = run < 1 ? 1 : (run > MAX_FRAMES ? MAX_FRAMES + 1 : (int)run);
-    frames[b] = f;
+    p.frames[b] = f;
     // the host sizes stage B from this count: written straight into pinned host memory (visible once the stream is
     // synchronised), which saves the device-to-host copy node behind this kernel
-    if (frames_host) frames_host[b] = f;
+    if (p.frames_host) p.frames_host[b] = f;
     // speculative stage B (launched before the host has seen f): lengths clamped to the allocated frame capacity
-    frames_clamped[b] = f < frame_cap ? f : frame_cap;
+    p.frames_clamped[b] = f < p.frame_cap ? f : p.frame_cap;
   }
   __syncthreads();
-  long long run = part[tid];
-  for (int t = lo; t < hi; ++t) {
-    run += dur[b * d_bs + t];
-    cum[b * d_bs + t] = run > MAX_FRAMES ? MAX_FRAMES + 1 : (int)run;
+  if (tid < 256) {
+    long long run = part[tid];
+    for (int t = lo; t < hi; ++t) {
+      run += p.dur[b * p.d_bs + t];
+      p.cum[b * p.d_bs + t] = run > MAX_FRAMES ? MAX_FRAMES + 1 : (int)run;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void duration_kernel(DurP p) {
+  __shared__ long long part[256];
+  duration_body<false>(p, blockIdx.x, part);
+}
+
+// ------------------------------------------------------------------------------------------------
+// The stochastic duration predictor's DDSConv chain as ONE launch (models.py:63-71,108-117; modules.py:117-129,
+// 496-527): every DDSConv layer of dp.convs and of the ConvFlows (with ConvFlow.pre folded in and dp.proj / proj +
+// spline fused behind, see dds_layer16_body) and the duration step at the end. A workgroup owns 16 time columns of one
+// utterance for the whole chain. The only thing a layer needs from other workgroups is the depthwise conv's halo
+// (<= 9 columns: the two neighbouring workgroups), so instead of a kernel boundary per layer (7-16 us each here,
+// profiles/r02_launch_floor.txt) the workgroups hand their columns to each other in memory -- agent-scope (sc1) stores
+// and loads -- and publish a per-(utterance, column tile) progress word that the neighbours poll (0.6-1.5 us per hop).
+// Progress words only ever grow (epoch * 64 + layers done), so nothing is reset between runs; the epoch lives in
+// device memory and is advanced by the workgroup that finishes last. Residency: the host launches this kernel only for
+// grids of at most one workgroup per CU. A neighbour that never shows up (cannot happen on a resident grid) ends the
+// spin after ~1e7 polls with an error code instead of a hang.
+static constexpr int DP_MAX_LAYERS = 12;
+struct DpPersistP {
+  DdsP layer[DP_MAX_LAYERS];
+  int nlayers;
+  DurP dur;
+  unsigned* progress; int prog_bs;      // [B][prog_bs] progress words
+  unsigned* state;                      // [0] epoch, [1] finished workgroups of this run, [2] error code, [4 + b] finished tiles of utterance b
+  int* err_host;                        // pinned host word: set when a neighbour wait gave up
+};
+template <int NVT>
+__global__ __launch_bounds__(512) void dp_persist_kernel(DpPersistP p) {
+  PE_DYN_SMEM(float, sm);
+  const int ct = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int L = p.layer[0].lens[b];
+  const int nct = (L + 15) / 16;
+  unsigned* flag = reinterpret_cast<unsigned*>(sm);          // LDS word 0: broadcast slot (the layer body uses sm from word 16 on)
+  float* lsm = sm + 16;
+  if (tid == 0) flag[0] = pe_ld_flag(p.state);
+  __syncthreads();
+  const unsigned epoch = flag[0];
+  const unsigned base = epoch * 64u;
+  __syncthreads();
+  if (ct < nct) {
+    unsigned* prog = p.progress + (long)b * p.prog_bs;
+    for (int l = 0; l < p.nlayers; ++l) {
+      if (l > 0) {
+        // the neighbours' columns of layer l-1 (its halo) must be in memory; their having finished l-1 also means they
+        // no longer read the buffer this layer overwrites (two buffers alternate)
+        if (tid < 2) {
+          const int n = ct + (tid == 0 ? -1 : 1);
+          if (n >= 0 && n < nct) {
+            long spins = 0;
+            while (pe_ld_flag(prog + n) < base + (unsigned)l) {
+              pe_spin_pause();
+              if (++spins > (1L << 23)) { pe_st_flag(p.state + 2, 1u); *p.err_host = 1; break; }
+            }
+          }
+        }
+        __syncthreads();
+      }
+      dds_layer16_body<NVT, true>(p.layer[l], ct, b, lsm);
+      pe_drain_stores();
+      __syncthreads();
+      if (tid == 0) pe_st_flag(prog + ct, base + (unsigned)(l + 1));
+    }
+    // ---- durations: the workgroup that completes the utterance's last tile (every spline epilogue is in memory then)
+    if (tid == 0) flag[0] = pe_atomic_inc(p.state + 4 + b);
+    __syncthreads();
+    const bool last_of_utt = flag[0] == (unsigned)(nct - 1);        // per-run counters: the run's last workgroup zeroes them
+    __syncthreads();
+    if (last_of_utt) duration_body<true>(p.dur, b, reinterpret_cast<long long*>(lsm));
+  }
+  // ---- the last workgroup of the run advances the epoch
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned done = pe_atomic_inc(p.state + 1);
+    if (done == (unsigned)(gridDim.x * gridDim.y) - 1u) {
+      for (unsigned i = 0; i < gridDim.y; ++i) pe_st_flag(p.state + 4 + i, 0u);
+      pe_st_flag(p.state + 1, 0u);
+      pe_st_flag(p.state, epoch + 1u);
+    }
   }
 }
 

@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE ONLY -- see hip_emu.h. Fiber scheduler for the HIP functional emulator.
 #include "hip_emu.h"
 
+#include <algorithm>
 #include <vector>
 
 emu_idx3 threadIdx, blockIdx, blockDim, gridDim;
@@ -41,20 +42,27 @@ struct Fiber {
   emu_idx3 tid;
 };
 
+// Fibers of ALL blocks that are live at once: one block (ordinary launches) or the whole grid (launch_coop).
 static constexpr size_t STACK = 96 * 1024;
 static constexpr int MAXT = 1024;
 static char* g_stacks = nullptr;
-static Fiber g_f[MAXT];
+static size_t g_nstacks = 0;
+static std::vector<Fiber> g_f;
 static void* g_sched_sp;
-static int g_cur = -1;
+static int g_cur = -1;            // global fiber index = block slot * nthreads + thread
 static int g_nthreads = 0;
 static const std::function<void()>* g_body = nullptr;
-static float g_wave_scratch[MAXT / 64][4][64];
+static std::vector<float> g_wave_scratch;      // [block slot][wave][4][64]
 static std::vector<char> g_smem;
+static size_t g_smem_stride = 0;
+static std::vector<emu_idx3> g_block_of;       // block index of each live block slot
 
-int lane() { return g_cur & 63; }
-int wave() { return g_cur >> 6; }
-float* wave_f(int slot) { return g_wave_scratch[g_cur >> 6][slot]; }
+int lane() { return (g_cur % g_nthreads) & 63; }
+int wave() { return (g_cur % g_nthreads) >> 6; }
+float* wave_f(int slot) {
+  const int nw = (g_nthreads + 63) / 64;
+  return &g_wave_scratch[(((size_t)(g_cur / g_nthreads) * nw + wave()) * 4 + slot) * 64];
+}
 
 static void yield_to_sched() { emu_switch(&g_f[g_cur].sp, g_sched_sp); }
 
@@ -66,6 +74,7 @@ void block_sync() {
   g_f[g_cur].st = WAIT_BLOCK;
   yield_to_sched();
 }
+void yield() { yield_to_sched(); }     // stays RUNNABLE: the scheduler comes back after everyone else had a turn
 
 static void fiber_main() {
   (*g_body)();
@@ -85,82 +94,123 @@ static void init_fiber(int i) {
   g_f[i].st = RUNNABLE;
 }
 
-static void run_block(unsigned nthreads) {
+// Runs the fibers of `nblocks` live blocks (slots) to completion, round-robin; barriers release per block, wave
+// collectives per wave.
+static void run_blocks(unsigned nthreads, int nblocks) {
   g_nthreads = (int)nthreads;
-  for (unsigned i = 0; i < nthreads; ++i) {
-    init_fiber((int)i);
-    unsigned bx = blockDim.x, by = blockDim.y;
-    g_f[i].tid = emu_idx3{i % bx, (i / bx) % by, i / (bx * by)};
+  const int total = (int)nthreads * nblocks;
+  if ((size_t)total > g_nstacks) {
+    free(g_stacks);
+    g_stacks = (char*)aligned_alloc(4096, STACK * (size_t)total);
+    if (!g_stacks) { fprintf(stderr, "hip_emu: cannot allocate %d fiber stacks\n", total); abort(); }
+    g_nstacks = (size_t)total;
   }
-  int nw = ((int)nthreads + 63) / 64;
+  g_f.assign(total, Fiber{});
+  const int nw = ((int)nthreads + 63) / 64;
+  g_wave_scratch.assign((size_t)nblocks * nw * 4 * 64, 0.f);
+  for (int i = 0; i < total; ++i) {
+    init_fiber(i);
+    const unsigned l = (unsigned)i % nthreads, bx = blockDim.x, by = blockDim.y;
+    g_f[i].tid = emu_idx3{l % bx, (l / bx) % by, l / (bx * by)};
+  }
   for (;;) {
     bool ran = false;
-    for (int i = 0; i < (int)nthreads; ++i) {
+    for (int i = 0; i < total; ++i) {
       if (g_f[i].st != RUNNABLE) continue;
       g_cur = i;
       threadIdx = g_f[i].tid;
+      blockIdx = g_block_of[i / (int)nthreads];
+      dyn_smem = (char*)(((uintptr_t)g_smem.data() + 63) & ~(uintptr_t)63) + (size_t)(i / (int)nthreads) * g_smem_stride;
       emu_switch(&g_sched_sp, g_f[i].sp);
       ran = true;
     }
-    int alive = 0, at_block = 0;
-    for (int i = 0; i < (int)nthreads; ++i) {
-      if (g_f[i].st != DONE) ++alive;
-      if (g_f[i].st == WAIT_BLOCK) ++at_block;
-    }
-    if (alive == 0) break;
+    int alive_all = 0;
     bool released = false;
-    for (int w = 0; w < nw; ++w) {
-      int lo = w * 64, hi = lo + 64 > (int)nthreads ? (int)nthreads : lo + 64;
-      int live = 0, ww = 0;
-      for (int i = lo; i < hi; ++i) {
-        if (g_f[i].st != DONE) ++live;
-        if (g_f[i].st == WAIT_WAVE) ++ww;
+    for (int blk = 0; blk < nblocks; ++blk) {
+      const int base = blk * (int)nthreads;
+      int alive = 0, at_block = 0;
+      for (int i = base; i < base + (int)nthreads; ++i) {
+        if (g_f[i].st != DONE) ++alive;
+        if (g_f[i].st == WAIT_BLOCK) ++at_block;
       }
-      if (ww > 0 && ww == live) {
-        if (live != hi - lo) {
-          fprintf(stderr, "hip_emu: wave collective with exited lanes (block %u,%u,%u wave %d)\n",
-                  blockIdx.x, blockIdx.y, blockIdx.z, w);
-          abort();
+      alive_all += alive;
+      for (int w = 0; w < nw; ++w) {
+        const int lo = base + w * 64, hi = std::min(lo + 64, base + (int)nthreads);
+        int live = 0, ww = 0;
+        for (int i = lo; i < hi; ++i) {
+          if (g_f[i].st != DONE) ++live;
+          if (g_f[i].st == WAIT_WAVE) ++ww;
         }
-        for (int i = lo; i < hi; ++i) g_f[i].st = RUNNABLE;
+        if (ww > 0 && ww == live) {
+          if (live != hi - lo) {
+            fprintf(stderr, "hip_emu: wave collective with exited lanes (block slot %d wave %d)\n", blk, w);
+            abort();
+          }
+          for (int i = lo; i < hi; ++i) g_f[i].st = RUNNABLE;
+          released = true;
+        }
+      }
+      if (at_block > 0 && at_block == alive) {
+        for (int i = base; i < base + (int)nthreads; ++i)
+          if (g_f[i].st == WAIT_BLOCK) g_f[i].st = RUNNABLE;
         released = true;
       }
     }
-    if (at_block > 0 && at_block == alive) {
-      for (int i = 0; i < (int)nthreads; ++i)
-        if (g_f[i].st == WAIT_BLOCK) g_f[i].st = RUNNABLE;
-      released = true;
-    }
+    if (alive_all == 0) break;
     if (!ran && !released) {
-      fprintf(stderr, "hip_emu: deadlock (divergent barrier) in block %u,%u,%u\n", blockIdx.x,
-              blockIdx.y, blockIdx.z);
+      fprintf(stderr, "hip_emu: deadlock (divergent barrier)\n");
       abort();
     }
   }
 }
 
-void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body) {
+static bool plan_only() {
   // EMU_PLAN_ONLY=1: record-only mode for checking the host's launch decisions (which instantiation, which grid) on
   // full-size shapes that would take hours to emulate; nothing is executed
-  static const bool plan_only = getenv("EMU_PLAN_ONLY") && atoi(getenv("EMU_PLAN_ONLY")) != 0;
-  if (plan_only) return;
+  static const bool v = getenv("EMU_PLAN_ONLY") && atoi(getenv("EMU_PLAN_ONLY")) != 0;
+  return v;
+}
+
+static void setup(dim3 grid, dim3 block, size_t smem, int nslots, const std::function<void()>& body) {
+  g_smem_stride = (smem + 127) / 64 * 64;
+  if (g_smem.size() < g_smem_stride * nslots + 128) g_smem.resize(g_smem_stride * nslots + 128);
+  g_body = &body;
+  gridDim = emu_idx3{grid.x, grid.y, grid.z};
+  blockDim = emu_idx3{block.x, block.y, block.z};
+}
+
+void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body) {
+  if (plan_only()) return;
   unsigned nthreads = block.x * block.y * block.z;
   if (nthreads == 0 || nthreads > MAXT) {
     fprintf(stderr, "hip_emu: bad block size %u\n", nthreads);
     abort();
   }
-  if (!g_stacks) g_stacks = (char*)aligned_alloc(4096, STACK * MAXT);
-  if (g_smem.size() < smem + 64) g_smem.resize(smem + 64);
-  dyn_smem = (char*)(((uintptr_t)g_smem.data() + 63) & ~(uintptr_t)63);
-  g_body = &body;
-  gridDim = emu_idx3{grid.x, grid.y, grid.z};
-  blockDim = emu_idx3{block.x, block.y, block.z};
+  setup(grid, block, smem, 1, body);
+  g_block_of.assign(1, emu_idx3{0, 0, 0});
   for (unsigned bz = 0; bz < grid.z; ++bz)
     for (unsigned by = 0; by < grid.y; ++by)
       for (unsigned bx = 0; bx < grid.x; ++bx) {
-        blockIdx = emu_idx3{bx, by, bz};
-        run_block(nthreads);
+        g_block_of[0] = emu_idx3{bx, by, bz};
+        run_blocks(nthreads, 1);
       }
+  g_body = nullptr;
+}
+
+void launch_coop(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body) {
+  if (plan_only()) return;
+  unsigned nthreads = block.x * block.y * block.z;
+  const size_t nblocks = (size_t)grid.x * grid.y * grid.z;
+  if (nthreads == 0 || nthreads > MAXT || nblocks == 0 || nblocks * nthreads > 65536) {
+    fprintf(stderr, "hip_emu: cooperative launch too large for the emulator (%zu blocks x %u threads)\n", nblocks, nthreads);
+    abort();
+  }
+  setup(grid, block, smem, (int)nblocks, body);
+  g_block_of.clear();
+  for (unsigned bz = 0; bz < grid.z; ++bz)
+    for (unsigned by = 0; by < grid.y; ++by)
+      for (unsigned bx = 0; bx < grid.x; ++bx) g_block_of.push_back(emu_idx3{bx, by, bz});
+  run_blocks(nthreads, (int)nblocks);
   g_body = nullptr;
 }
 

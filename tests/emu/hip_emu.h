@@ -47,6 +47,9 @@ typedef emu_event* hipEvent_t;
 namespace emu {
 extern char* dyn_smem;
 void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body);
+// every block of the grid at once (kernels whose workgroups wait for each other); no static __shared__ inside
+void launch_coop(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body);
+void yield();        // a spinning thread lets the others run
 void wave_sync();    // all live lanes of the calling fiber's wave
 void block_sync();
 int lane();

@@ -44,7 +44,7 @@ def make_engine(monkeypatch, cfg, w, env=None):
     for k in ("PIPER_HIP_SPLITK_MAX", "PIPER_HIP_SMALL", "PIPER_HIP_WIDE_MIN", "PIPER_HIP_TPB", "PIPER_HIP_SPLITK16",
               "PIPER_HIP_WIDE_SPLITK", "PIPER_HIP_FUSE_MRF", "PIPER_HIP_DEBUG_KEEP", "PIPER_HIP_PAR_MRF",
               "PIPER_HIP_FUSED", "PIPER_HIP_MRF2", "PIPER_HIP_FUSE_DP", "PIPER_HIP_FOLD_LN",
-              "PIPER_HIP_MRF2_MAXF"):
+              "PIPER_HIP_MRF2_MAXF", "PIPER_HIP_PERSIST_DP", "PIPER_HIP_SPEC"):
         monkeypatch.delenv(k, raising=False)
     for k, v in (env or {}).items():
         monkeypatch.setenv(k, str(v))
@@ -349,6 +349,63 @@ def test_fused_mrf2_stage_kernel_matches_unfused_and_oracle(monkeypatch, preset,
         assert a.audio[i].shape == b.audio[i].shape
         assert np.max(np.abs(a.audio[i] - b.audio[i])) < 2e-5
     print(preset, "mrf2 kernels:", sorted(n for n in names if n.startswith("mrf2")), "worst |d audio| %.2e" % worst)
+
+
+def test_persistent_duration_predictor_is_bit_identical_under_repetition(monkeypatch):
+    """dp_persist_kernel (the DDSConv chain + durations as one launch whose workgroups exchange halo columns through
+    memory with agent-scope accesses and progress words) must give bit-identical logw / durations / audio to the
+    one-launch-per-layer schedule -- over many back-to-back runs with changing shapes, which is what exposes a stale
+    cache line or a missed dependency (the arithmetic is the same code)."""
+    cfg, w = voice("medium")
+    pers = make_engine(monkeypatch, cfg, w, {"PIPER_HIP_SPEC": 0})
+    plain = make_engine(monkeypatch, cfg, w, {"PIPER_HIP_PERSIST_DP": 0, "PIPER_HIP_SPEC": 0})
+    rng = np.random.default_rng(91)
+    seen = False
+    for it in range(120):
+        B = int(rng.integers(1, 4))
+        lens = [int(rng.integers(1, 200)) for _ in range(B)]
+        ids, nw, _ = batch_inputs(cfg, lens, seed=200 + it, zcols=8)
+        scales = (0.0, float(rng.uniform(0.7, 1.3)), float(rng.uniform(0.0, 1.0)))
+        if it == 0:
+            pers.profile_enable(2)
+        a = pers.synthesize_batch(ids, scales, noise_w=nw)
+        if it == 0:
+            seen = any(r["name"].startswith("dp_persist_kernel") and r["launches"] for r in pers.profile())
+            SEEN.update(r["name"] for r in pers.profile()[5:] if r["launches"])
+            pers.profile_enable(0)
+        da = pers.durations()
+        la = [pers.debug_tensor("logw", b) for b in range(B)]
+        b_ = plain.synthesize_batch(ids, scales, noise_w=nw)
+        db = plain.durations()
+        assert np.array_equal(da, db), f"iteration {it}: durations differ"
+        for b in range(B):
+            assert np.array_equal(la[b], plain.debug_tensor("logw", b)), f"iteration {it}: logw differs"
+            assert np.array_equal(a.pcm[b], b_.pcm[b]), f"iteration {it}: pcm differs"
+    assert seen, "the persistent kernel did not run"
+    # and against the oracle once more at the end (state carried across 120 epochs)
+    ids, nw, nz = batch_inputs(cfg, [128, 77], seed=99)
+    run_and_check(pers, cfg, w, ids, nw, nz, sample=[0, 1])
+    pers.close()
+    plain.close()
+
+
+def test_speculative_stage_b_hits_and_misses(monkeypatch):
+    """Stage B launched for a guessed frame bucket before the host has seen the frame counts (<= 4 utterances): a
+    correct guess and a wrong one (length_scale jumps) must both end in the oracle's waveform."""
+    from oracle import vits_oracle as O
+    cfg, w = voice("medium")
+    eng = make_engine(monkeypatch, cfg, w)
+    wt = O.to_torch(w)
+    rng = np.random.default_rng(93)
+    for it, (T, ls) in enumerate([(100, 1.0), (100, 1.0), (120, 1.05), (120, 2.6), (60, 1.0), (150, 0.5), (128, 1.0)]):
+        ids = W.synthetic_phoneme_ids(T, it, id_max=129)
+        nw = rng.standard_normal((2, T)).astype(np.float32)
+        r = eng.synthesize(ids, (0.0, ls, 0.8), noise_w=nw)          # no injected prior noise: graphs + speculation
+        o = O.synthesize(wt, cfg, ids, (0.0, ls, 0.8), nw, None)
+        assert np.array_equal(eng.durations(), o["durations"])
+        assert r.audio[0].shape == o["audio"].shape, (it, r.audio[0].shape, o["audio"].shape)
+        assert np.max(np.abs(r.audio[0] - o["audio"])) < TIGHT_AUDIO_TOL
+    eng.close()
 
 
 def test_every_profiled_instantiation_is_parity_tested():
