@@ -1694,7 +1694,7 @@ void Engine::run() {
   bool spec = spec_enable_ && B <= spec_max_batch_ && last_ratio_ > 0.f && !have_noise_z_ && use_graphs_ && !prof_on_;
   int fguess = 0;
   if (spec) {
-    fguess = rup((int)std::ceil(last_ratio_ * 1.25f * (float)Tmax_) + 1, 32);
+    fguess = rup((int)std::ceil(last_ratio_ * 1.10f * (float)Tmax_) + 1, 32);
     if (fguess > MAX_FRAMES) spec = false;
   }
   if (spec) ensure_stage_b(fguess);              // before stage A is enqueued: growing the workspace drops every graph

@@ -139,7 +139,7 @@ class Engine {
   // the DdsP of every layer of one DDSConv run, appended to `out` (dds() launches them; the persistent
   // duration-predictor kernel takes all twelve at once)
   void dds_params(const DdsW& d, View in, View out, View tmp, const DdsOpt* opt, std::vector<struct DdsP>& list);
-  bool persist_dp_ = true;                  // PIPER_HIP_PERSIST_DP=0: one launch per DDSConv layer
+  bool persist_dp_ = false;                 // PIPER_HIP_PERSIST_DP=1: the DDSConv chain as one persistent launch (measured no faster, profiles/r02_notes.md)
   unsigned *dp_progress_ = nullptr, *dp_state_ = nullptr;
   int dp_prog_bs_ = 0;
   float* pack16(const std::vector<float>& W, int rows, int K);    // [16-row tile][q][lane][4] (dds_layer16_kernel)

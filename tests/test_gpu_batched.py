@@ -357,7 +357,7 @@ def test_persistent_duration_predictor_is_bit_identical_under_repetition(monkeyp
     one-launch-per-layer schedule -- over many back-to-back runs with changing shapes, which is what exposes a stale
     cache line or a missed dependency (the arithmetic is the same code)."""
     cfg, w = voice("medium")
-    pers = make_engine(monkeypatch, cfg, w, {"PIPER_HIP_SPEC": 0})
+    pers = make_engine(monkeypatch, cfg, w, {"PIPER_HIP_PERSIST_DP": 1, "PIPER_HIP_SPEC": 0})
     plain = make_engine(monkeypatch, cfg, w, {"PIPER_HIP_PERSIST_DP": 0, "PIPER_HIP_SPEC": 0})
     rng = np.random.default_rng(91)
     seen = False
