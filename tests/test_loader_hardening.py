@@ -1,0 +1,135 @@
+"""CPU tests: the structural .onnx loader (onnx_reader.cpp) against files rewritten the way post-export tooling
+rewrites real voices (SURVEY.md section 7 hard part A; TRAINING.md:234 recommends onnx-simplifier):
+numeral initialiser names, stripped node names, weights in Constant nodes, de-duplicated tensors, float_data
+encoding -- and, when the reference is available (build container), a freshly exported FULL-SIZE medium voice."""
+import ctypes as C
+import dataclasses
+import os
+
+import numpy as np
+import pytest
+
+from oracle import onnx_mutate as M
+from piper_amd import _lib as L
+from piper_amd import weights as W
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return L.get_lib()
+
+
+def load(lib, path):
+    blob, n = C.c_void_p(), C.c_size_t()
+    if lib.pe_onnx_to_blob(str(path).encode(), C.byref(blob), C.byref(n)):
+        raise RuntimeError(lib.pe_last_error().decode())
+    data = C.string_at(blob, n.value)
+    lib.pe_free(blob)
+    return W.unpack_blob(data)
+
+
+def check(cfg2, w2, cfg, w, tol=1e-6):
+    assert dataclasses.replace(cfg2, sample_rate=cfg.sample_rate) == cfg
+    assert set(w2) == set(w)
+    for k in w:
+        assert w2[k].shape == w[k].shape, k
+        assert np.max(np.abs(w2[k] - w[k])) <= tol, k
+
+
+VARIANTS = {
+    "numeral_names": lambda m: (m.rename_initializers_to_numerals(), m.strip_node_names()),
+    "all_constants": lambda m: m.initializers_to_constants(1),
+    "half_constants_numerals": lambda m: (m.rename_initializers_to_numerals(7), m.initializers_to_constants(2),
+                                          m.strip_node_names()),
+    "float_data": lambda m: m.float_data(),
+    "everything": lambda m: (m.float_data(), m.dedup(), m.rename_initializers_to_numerals(), m.initializers_to_constants(3),
+                             m.strip_node_names()),
+}
+
+
+@pytest.mark.parametrize("stem,preset", [("tiny_voice", "tiny"), ("tinyhms_voice", "tiny-high-ms")])
+@pytest.mark.parametrize("variant", sorted(VARIANTS))
+def test_rewritten_exports_load_identically(lib, tmp_path, stem, preset, variant):
+    cfg = W.preset(preset)
+    w = W.synthetic_weights(cfg, 1234)
+    m = M.Model(open(os.path.join(GOLD, stem + ".onnx"), "rb").read())
+    n_before = len(m.inits)
+    VARIANTS[variant](m)
+    out = tmp_path / f"{stem}_{variant}.onnx"
+    out.write_bytes(m.save())
+    if variant == "all_constants":
+        assert len(m.inits) == 0 and sum(1 for n in m.nodes if (4, 2, b"Constant") in n) >= n_before
+    cfg2, w2 = load(lib, out)
+    check(cfg2, w2, cfg, w)
+
+
+def test_deduplicated_layernorm_parameters(lib, tmp_path):
+    """An untrained-looking voice: every LayerNorm gain 1 / offset 0. A simplifier folds the ~60 identical vectors into
+    two initialisers that many nodes share; the loader assigns them by graph position, not by name or identity."""
+    cfg = W.preset("tiny")
+    w = dict(W.synthetic_weights(cfg, 1234))
+    m = M.Model(open(os.path.join(GOLD, "tiny_voice.onnx"), "rb").read())
+    touched = 0
+    for t in m.inits:
+        if t.name.endswith(".gamma"):
+            t.set_constant(1.0); touched += 1
+        elif t.name.endswith(".beta"):
+            t.set_constant(0.0); touched += 1
+    assert touched >= 20
+    for k in w:
+        if k.endswith(".gamma"):
+            w[k] = np.ones_like(w[k])
+        elif k.endswith(".beta"):
+            w[k] = np.zeros_like(w[k])
+    merged = m.dedup()
+    assert merged >= touched - 2
+    m.rename_initializers_to_numerals()
+    m.strip_node_names()
+    out = tmp_path / "dedup.onnx"
+    out.write_bytes(m.save())
+    cfg2, w2 = load(lib, out)
+    check(cfg2, w2, cfg, w)
+
+
+def test_resblock1_detected_without_names(lib, tmp_path):
+    """ResBlock1 vs ResBlock2 must be told apart from the dilation pattern once node / tensor names are gone."""
+    m = M.Model(open(os.path.join(GOLD, "tinyhms_voice.onnx"), "rb").read())
+    m.rename_initializers_to_numerals()
+    m.strip_node_names()
+    out = tmp_path / "anon.onnx"
+    out.write_bytes(m.save())
+    cfg2, _ = load(lib, out)
+    assert cfg2.resblock == 1 and cfg2.rb_kernel_sizes == (3, 7, 11)
+    m2 = M.Model(open(os.path.join(GOLD, "tiny_voice.onnx"), "rb").read())
+    m2.rename_initializers_to_numerals()
+    m2.strip_node_names()
+    out2 = tmp_path / "anon2.onnx"
+    out2.write_bytes(m2.save())
+    assert load(lib, out2)[0].resblock == 2
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src/python/piper_train"),
+                    reason="needs the reference's exporter (build container only)")
+def test_full_size_medium_export_loads(lib, tmp_path):
+    """A full-size en_US-lessac-medium-shaped voice written by the reference's own export path at test time (63 MB, not
+    committed), also after the rewrites above."""
+    import subprocess
+    import sys
+    prefix = str(tmp_path / "medium_voice")
+    subprocess.check_call([sys.executable, os.path.join(ROOT, "oracle", "make_voice.py"), "medium", prefix],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=1200)
+    size = os.path.getsize(prefix + ".onnx")
+    assert abs(size - 63201294) / 63201294 < 0.01          # voices.json: en_US-lessac-medium is 63 201 294 bytes
+    cfg = W.preset("medium")
+    w = W.synthetic_weights(cfg, 1234)
+    cfg2, w2 = load(lib, prefix + ".onnx")
+    check(cfg2, w2, cfg, w, tol=2e-6)
+    m = M.Model(open(prefix + ".onnx", "rb").read())
+    VARIANTS["everything"](m)
+    out = tmp_path / "medium_everything.onnx"
+    out.write_bytes(m.save())
+    cfg3, w3 = load(lib, out)
+    check(cfg3, w3, cfg, w, tol=2e-6)
