@@ -112,23 +112,15 @@ def main():
         assert dist.get_world_size() == args.gpus
 
     cfg = W.preset(preset)
-    # ---- voice: rank 0 builds / parses it, the others receive it over RCCL
+    # ---- voice: rank 0 builds / parses / packs it; the others lay out an identical weight arena from the blob header and
+    # receive the PACKED weights by one device-to-device broadcast into that arena (RCCL over xGMI)
     wts = W.synthetic_weights(cfg, 1234) if rank == 0 else None
     t_bcast, bcast_bytes = 0.0, 0
     if world > 1:
-        from piper_amd.dist import broadcast_blob
-        blob = W.pack_blob(cfg, wts) if rank == 0 else None
-        torch.cuda.synchronize()
-        dist.barrier()
-        t0 = time.perf_counter()
-        blob = broadcast_blob(blob, 0, cdev)
-        torch.cuda.synchronize()
-        t_bcast = time.perf_counter() - t0
-        bcast_bytes = len(blob)
+        from piper_amd.dist import load_sharded
+        eng, t_bcast, bcast_bytes = load_sharded(W.pack_blob(cfg, wts) if rank == 0 else None, 0, dev_index)
     else:
-        blob = W.pack_blob(cfg, wts)
-    eng = Engine(blob=blob, device=dev_index)
-    del blob
+        eng = Engine(blob=W.pack_blob(cfg, wts), device=dev_index)
 
     if args.stream_latency:
         stream_latency(eng, cfg, preset, T, args, rank)

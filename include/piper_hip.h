@@ -56,6 +56,21 @@ int pe_create(const char* onnx_path, int device, pe_engine** out);
  * other ranks of a multi-GPU job call after the RCCL broadcast of rank 0's blob. */
 int pe_create_from_blob(const void* blob, size_t nbytes, int device, pe_engine** out);
 
+/* Multi-GPU loading without a host round trip per rank (one RCCL broadcast of the voice at load).
+ * The packed weights of an engine live in ONE device arena whose layout follows from the tensor SHAPES alone:
+ *   every rank:  pe_weights_bound(header)            -> arena size to allocate (e.g. a torch / RCCL-registered buffer)
+ *   root rank:   pe_create_in_arena(blob, .., arena, bytes, skeleton = 0)   parses, packs, uploads into its arena
+ *   other ranks: pe_create_in_arena(header, .., arena, bytes, skeleton = 1) lays the arena out, touches no weight data
+ *   all:         broadcast the first pe_weights_used() bytes of the root's arena into the others' arenas (ncclBroadcast)
+ *   other ranks: pe_arena_ready()
+ * `header` = the first 8 + 4*64 + 8 + n_tensors*136 bytes of a PEBLOB01 (magic, architecture, tensor records).
+ * The arena must be 256-byte aligned and outlive the engine. */
+int pe_weights_bound(const void* blob_or_header, size_t nbytes, size_t* bound);
+int pe_create_in_arena(const void* blob_or_header, size_t nbytes, int device, void* arena, size_t arena_bytes,
+                       int skeleton, pe_engine** out);
+int pe_weights_used(pe_engine* e, size_t* used);
+int pe_arena_ready(pe_engine* e);
+
 /* .onnx -> PEBLOB01 in host memory (no GPU needed). Free with pe_free(). */
 int pe_onnx_to_blob(const char* onnx_path, void** blob, size_t* nbytes);
 void pe_free(void* p);

@@ -12,7 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libpiper_hip.so")
 
 SYMBOLS = [
-    "pe_create", "pe_create_from_blob", "pe_onnx_to_blob", "pe_free", "pe_synthesize",
+    "pe_create", "pe_create_from_blob", "pe_weights_bound", "pe_create_in_arena", "pe_weights_used", "pe_arena_ready",
+    "pe_onnx_to_blob", "pe_free", "pe_synthesize",
     "pe_synthesize_batch", "pe_upload", "pe_run", "pe_fetch", "pe_stream_begin", "pe_stream_next",
     "pe_get_durations", "pe_get_info",
     "pe_set_seed", "pe_profile_enable", "pe_profile_reset", "pe_profile_rows", "pe_profile_get", "pe_profile_bytes",
@@ -43,6 +44,10 @@ def bind(path: str) -> C.CDLL:
     lib.pe_last_error.restype = C.c_char_p
     lib.pe_create.argtypes = [C.c_char_p, C.c_int, C.POINTER(vp)]
     lib.pe_create_from_blob.argtypes = [vp, C.c_size_t, C.c_int, C.POINTER(vp)]
+    lib.pe_weights_bound.argtypes = [vp, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.pe_create_in_arena.argtypes = [vp, C.c_size_t, C.c_int, vp, C.c_size_t, C.c_int, C.POINTER(vp)]
+    lib.pe_weights_used.argtypes = [vp, C.POINTER(C.c_size_t)]
+    lib.pe_arena_ready.argtypes = [vp]
     lib.pe_onnx_to_blob.argtypes = [C.c_char_p, C.POINTER(vp), C.POINTER(C.c_size_t)]
     lib.pe_free.argtypes = [vp]
     lib.pe_free.restype = None

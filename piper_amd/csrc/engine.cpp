@@ -23,24 +23,41 @@ static const int CFG_BN[] = {128, 128, 128, 64, 64, 256, 256};
 // setup
 // ------------------------------------------------------------------------------------------------
 
-float* Engine::dev_copy(const std::vector<float>& v) {
-  void* d = nullptr;
-  size_t n = std::max<size_t>(v.size(), 1) * sizeof(float);
-  PE_HIP(hipMalloc(&d, n));
-  if (!v.empty()) PE_HIP(hipMemcpy(d, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
-  owned_.push_back(d);
-  weight_bytes_ += v.size() * sizeof(float);
-  return static_cast<float*>(d);
+// Every packed weight tensor is carved from ONE arena in a deterministic order, so that the arena of the rank that
+// parsed and packed the voice can be broadcast device-to-device into the identically laid-out arenas of the other ranks.
+float* Engine::dev_alloc(size_t nfloats, const float* src) {
+  arena_off_ = (arena_off_ + 255) / 256 * 256;
+  const size_t bytes = std::max<size_t>(nfloats, 1) * sizeof(float);
+  if (arena_off_ + bytes > arena_bytes_) throw std::runtime_error("internal: packed weights exceed the arena bound");
+  float* d = reinterpret_cast<float*>(arena_ + arena_off_);
+  arena_off_ += bytes;
+  if (src && nfloats && !skeleton_) PE_HIP(hipMemcpy(d, src, nfloats * sizeof(float), hipMemcpyHostToDevice));
+  weight_bytes_ += nfloats * sizeof(float);
+  return d;
+}
+float* Engine::dev_copy(const std::vector<float>& v) { return dev_alloc(v.size(), v.data()); }
+
+float* Engine::dev_tensor(const WeightSet& ws, const std::string& name) {
+  const HostTensor& t = ws.get(name);
+  return dev_alloc((size_t)t.numel(), t.data.empty() ? nullptr : t.data.data());
 }
 
-float* Engine::dev_tensor(const WeightSet& ws, const std::string& name) { return dev_copy(ws.get(name).data); }
+// Packed copies: conv weights once in 32x32x2 fragment order (rows padded to the block tile), long-K convs once more in
+// 16x16x4 order, DDSConv / proj matrices in 16x16x4 order, the <= 64-channel resblock convs as mrf2 streams, plus the raw
+// small tensors. 3.5x the raw floats + slack covers every architecture the loader accepts; checked while carving.
+size_t Engine::arena_bound(const WeightSet& ws) {
+  size_t n = 0;
+  for (auto& kv : ws.t) n += (size_t)kv.second.numel() + 64;
+  return (n * 7 / 2 + (4u << 20)) * sizeof(float);
+}
 
 // Packs a dense [rows][Cin][ntaps] matrix into the A-operand order of conv_mfma_kernel:
 //   [mtile][chunk][tap][q = 0..3][lane = 0..63][j = 0..3] with kk = 4q + j, lane -> row = mtile*32 + (lane&31),
 //   ci = chunk*32 + 2*kk + (lane>>5): the 16 fragments of a step are four 16-byte loads per lane. With gate=true the 32-row tiles alternate between the tanh
 //   half (rows [0,split)) and the sigmoid half (rows [split,2*split)) so that one wave owns both.
+// `bias`: nbias values or null (none). In skeleton mode W / bias are not read (only sizes matter).
 PackedConv Engine::pack_matrix(const std::vector<float>& W, int rows, int Cin, int ntaps,
-                               const std::vector<float>* bias, int dil, int padl, bool gate, int split) {
+                               const std::vector<float>* bias, int nbias, int dil, int padl, bool gate, int split) {
   PackedConv pc;
   pc.rows = rows;
   pc.Cin = Cin;
@@ -55,8 +72,9 @@ PackedConv Engine::pack_matrix(const std::vector<float>& W, int rows, int Cin, i
   else pc.cfg = (vt % 4 == 0) ? CFG_A : (vt % 2 == 0 ? CFG_B : CFG_C);
   const int tiles_per_block = CFG_BM[pc.cfg] / 32;
   pc.mtiles = rup(vt, tiles_per_block);
-  std::vector<float> P((size_t)pc.mtiles * pc.nchunks * ntaps * (KC / 2) * 64, 0.f);
-  for (int mt = 0; mt < pc.mtiles; ++mt)
+  const size_t np = (size_t)pc.mtiles * pc.nchunks * ntaps * (KC / 2) * 64;
+  std::vector<float> P(skeleton_ ? 0 : np, 0.f);
+  for (int mt = 0; mt < (skeleton_ ? 0 : pc.mtiles); ++mt)
     for (int c = 0; c < pc.nchunks; ++c)
       for (int tap = 0; tap < ntaps; ++tap)
         for (int kk = 0; kk < KC / 2; ++kk)
@@ -75,13 +93,14 @@ PackedConv Engine::pack_matrix(const std::vector<float>& W, int rows, int Cin, i
             // within a (tile, chunk, tap) step a lane's 16 values are four float4 (kk = 4q + j)
             P[(((size_t)mt * pc.nchunks + c) * ntaps + tap) * (KC / 2) * 64 + (kk >> 2) * 256 + lane * 4 + (kk & 3)] = v;
           }
-  pc.wp = dev_copy(P);
+  pc.wp = dev_alloc(np, skeleton_ ? nullptr : P.data());
   const char* f16 = getenv("PIPER_HIP_SPLITK16");          // 3 = every conv (tests)
   if (pc.nchunks * ntaps >= 24 || (f16 && atoi(f16) >= 3)) {
     // long-K convs may run through conv_splitk16_kernel: [16-row sub-tile][chunk][tap][q][lane][4], lane ->
     // (row = lane & 15, k = lane >> 4), float4 element j of group q = k-step 4q + j = input channel chunk*32 + 4s + k
-    std::vector<float> Q((size_t)pc.mtiles * 2 * pc.nchunks * ntaps * (KC / 4) * 64, 0.f);
-    for (int st = 0; st < pc.mtiles * 2; ++st)
+    const size_t nq = (size_t)pc.mtiles * 2 * pc.nchunks * ntaps * (KC / 4) * 64;
+    std::vector<float> Q(skeleton_ ? 0 : nq, 0.f);
+    for (int st = 0; st < (skeleton_ ? 0 : pc.mtiles * 2); ++st)
       for (int c = 0; c < pc.nchunks; ++c)
         for (int tap = 0; tap < ntaps; ++tap)
           for (int q = 0; q < KC / 16; ++q)
@@ -101,9 +120,9 @@ PackedConv Engine::pack_matrix(const std::vector<float>& W, int rows, int Cin, i
                   Q[((((size_t)st * pc.nchunks + c) * ntaps + tap) * (KC / 16) + q) * 256 + lane * 4 + j] =
                       W[((size_t)row * Cin + ci) * ntaps + tap];
               }
-    pc.wp16 = dev_copy(Q);
+    pc.wp16 = dev_alloc(nq, skeleton_ ? nullptr : Q.data());
   }
-  pc.bias = bias ? dev_copy(*bias) : nullptr;
+  pc.bias = bias ? dev_alloc((size_t)nbias, skeleton_ ? nullptr : bias->data()) : nullptr;
   pc.macs_per_col = (double)rows * Cin * ntaps;
   return pc;
 }
@@ -115,23 +134,28 @@ PackedConv Engine::pack_conv(const WeightSet& ws, const std::string& wname, cons
   const HostTensor& w = ws.get(wname);
   if (w.dims.size() != 3) throw std::runtime_error(wname + ": expected a rank-3 conv weight");
   const int Co = (int)w.dims[0], Ci = (int)w.dims[1], K = (int)w.dims[2];
-  std::vector<float> W(w.data.size());
-  for (int o = 0; o < Co; ++o)
-    for (int i = 0; i < Ci; ++i)
-      for (int k = 0; k < K; ++k) {
-        const int so = out_rev ? Co - 1 - o : o, si = in_rev ? Ci - 1 - i : i;
-        W[((size_t)o * Ci + i) * K + k] = w.data[((size_t)so * Ci + si) * K + k];
-      }
+  std::vector<float> W(skeleton_ ? 0 : (size_t)Co * Ci * K);
+  if (!skeleton_) {
+    if (w.data.size() != W.size()) throw std::runtime_error(wname + ": data size mismatch");
+    for (int o = 0; o < Co; ++o)
+      for (int i = 0; i < Ci; ++i)
+        for (int k = 0; k < K; ++k) {
+          const int so = out_rev ? Co - 1 - o : o, si = in_rev ? Ci - 1 - i : i;
+          W[((size_t)o * Ci + i) * K + k] = w.data[((size_t)so * Ci + si) * K + k];
+        }
+  }
   std::vector<float> bias;
   bool has_b = !bname.empty() && ws.has(bname);
   if (has_b) {
-    bias = ws.get(bname).data;
-    if ((int)bias.size() != Co) throw std::runtime_error(bname + ": bias size mismatch");
-    if (out_rev) std::reverse(bias.begin(), bias.end());
+    if (ws.get(bname).numel() != Co) throw std::runtime_error(bname + ": bias size mismatch");
+    if (!skeleton_) {
+      bias = ws.get(bname).data;
+      if (out_rev) std::reverse(bias.begin(), bias.end());
+    }
   }
   // "same" padding: get_padding (commons.py:17-18) == (K-1)*dil/2 ; FFN._same_padding left pad (K-1)/2
   const int padl = padl_override >= 0 ? padl_override : (K - 1) * dil / 2;
-  return pack_matrix(W, Co, Ci, K, has_b ? &bias : nullptr, dil, padl, gate, gate ? Co / 2 : 0);
+  return pack_matrix(W, Co, Ci, K, has_b ? &bias : nullptr, Co, dil, padl, gate, gate ? Co / 2 : 0);
 }
 
 PackedConv Engine::pack_qkv(const WeightSet& ws, const std::string& prefix) {
@@ -142,10 +166,12 @@ PackedConv Engine::pack_qkv(const WeightSet& ws, const std::string& prefix) {
     const HostTensor& w = ws.get(prefix + "." + n + ".weight");
     const HostTensor& b = ws.get(prefix + "." + n + ".bias");
     H = (int)w.dims[0];
-    W.insert(W.end(), w.data.begin(), w.data.end());
-    bias.insert(bias.end(), b.data.begin(), b.data.end());
+    if (!skeleton_) {
+      W.insert(W.end(), w.data.begin(), w.data.end());
+      bias.insert(bias.end(), b.data.begin(), b.data.end());
+    }
   }
-  return pack_matrix(W, 3 * H, H, 1, &bias, 1, 0, false, 0);
+  return pack_matrix(W, 3 * H, H, 1, &bias, 3 * H, 1, 0, false, 0);
 }
 
 // ConvTranspose1d weight [Cin][Cout][K] with K == 2*stride, padding (K-stride)/2 (models.py:321-332):
@@ -157,8 +183,8 @@ PackedConv Engine::pack_convT(const WeightSet& ws, const std::string& prefix, in
   if (K != 2 * stride || ((K - stride) & 1))
     throw std::runtime_error(prefix + ": ConvTranspose1d with kernel != 2*stride is not supported");
   const int rows = Co * stride;
-  std::vector<float> W((size_t)rows * Ci * 2);
-  for (int co = 0; co < Co; ++co)
+  std::vector<float> W(skeleton_ ? 0 : (size_t)rows * Ci * 2);
+  for (int co = 0; co < (skeleton_ ? 0 : Co); ++co)
     for (int ph = 0; ph < stride; ++ph)
       for (int ci = 0; ci < Ci; ++ci) {
         const size_t row = (size_t)co * stride + ph;
@@ -166,7 +192,7 @@ PackedConv Engine::pack_convT(const WeightSet& ws, const std::string& prefix, in
         W[(row * Ci + ci) * 2 + 1] = w.data[((size_t)ci * Co + co) * K + ph];
       }
   std::vector<float> bias = ws.get(prefix + ".bias").data;
-  PackedConv pc = pack_matrix(W, rows, Ci, 2, &bias, 1, 1, false, 0);
+  PackedConv pc = pack_matrix(W, rows, Ci, 2, &bias, Co, 1, 1, false, 0);
   pc.up = stride;
   pc.padT = (K - stride) / 2;
   return pc;
@@ -177,15 +203,16 @@ PackedConv Engine::pack_convT(const WeightSet& ws, const std::string& prefix, in
 // input channel 4 * (4q + j) + k. K is padded to a multiple of 32 (the kernel's Hp).
 float* Engine::pack16(const std::vector<float>& W, int rows, int K) {
   const int Kp = rup(K, 32), nq = Kp / 16, ntile = (rows + 15) / 16;
-  std::vector<float> P((size_t)ntile * nq * 256, 0.f);
-  for (int mt = 0; mt < ntile; ++mt)
+  const size_t np = (size_t)ntile * nq * 256;
+  std::vector<float> P(skeleton_ ? 0 : np, 0.f);
+  for (int mt = 0; mt < (skeleton_ ? 0 : ntile); ++mt)
     for (int q = 0; q < nq; ++q)
       for (int lane = 0; lane < 64; ++lane)
         for (int jj = 0; jj < 4; ++jj) {
           const int row = mt * 16 + (lane & 15), ci = 4 * (4 * q + jj) + (lane >> 4);
           if (row < rows && ci < K) P[(((size_t)mt * nq + q) * 64 + lane) * 4 + jj] = W[(size_t)row * K + ci];
         }
-  return dev_copy(P);
+  return dev_alloc(np, skeleton_ ? nullptr : P.data());
 }
 
 DdsW Engine::load_dds(const WeightSet& ws, const std::string& p) {
@@ -197,19 +224,8 @@ DdsW Engine::load_dds(const WeightSet& ws, const std::string& p) {
     d.c1x1.push_back(pack_conv(ws, p + ".convs_1x1." + s + ".weight", p + ".convs_1x1." + s + ".bias", 1, -1,
                                false, 0, 0));
     {
-      // the same matrix for dds_layer16_kernel: [16-row tile][q][lane][4], lane -> (row = lane & 15, k = lane >> 4),
-      // float4 element j of group q is k-step s = 4q + j, i.e. input channel 4s + k
       const HostTensor& w1 = ws.get(p + ".convs_1x1." + s + ".weight");
-      const int Hh = (int)w1.dims[0], Hp = rup(Hh, 32), nq = Hp / 16;
-      std::vector<float> P((size_t)(Hp / 16) * nq * 256, 0.f);
-      for (int mt = 0; mt < Hp / 16; ++mt)
-        for (int q = 0; q < nq; ++q)
-          for (int lane = 0; lane < 64; ++lane)
-            for (int jj = 0; jj < 4; ++jj) {
-              const int row = mt * 16 + (lane & 15), ci = 4 * (4 * q + jj) + (lane >> 4);
-              if (row < Hh && ci < Hh) P[(((size_t)mt * nq + q) * 64 + lane) * 4 + jj] = w1.data[(size_t)row * Hh + ci];
-            }
-      d.w16.push_back(dev_copy(P));
+      d.w16.push_back(pack16(w1.data, (int)w1.dims[0], (int)w1.dims[1]));     // the same matrix for dds_layer16_kernel
     }
     d.g1.push_back(dev_tensor(ws, p + ".norms_1." + s + ".gamma"));
     d.b1.push_back(dev_tensor(ws, p + ".norms_1." + s + ".beta"));
@@ -219,9 +235,21 @@ DdsW Engine::load_dds(const WeightSet& ws, const std::string& p) {
   return d;
 }
 
-Engine::Engine(const WeightSet& ws, int device) : device_(device) {
+Engine::Engine(const WeightSet& ws, int device, ArenaSpec arena) : device_(device) {
   // a constructor that throws does not run the destructor: release what was acquired so far
   try {
+    PE_HIP(hipSetDevice(device_));
+    skeleton_ = arena.skeleton;
+    if (arena.base) {
+      if (((uintptr_t)arena.base & 255) != 0) throw std::runtime_error("weight arena must be 256-byte aligned");
+      arena_ = static_cast<char*>(arena.base);
+      arena_bytes_ = arena.bytes;
+    } else {
+      if (skeleton_) throw std::runtime_error("a skeleton engine needs a caller-provided arena");
+      arena_bytes_ = arena_bound(ws);
+      PE_HIP(hipMalloc((void**)&arena_, arena_bytes_));
+      arena_owned_ = true;
+    }
     init(ws);
   } catch (...) {
     free_all();
@@ -299,12 +327,15 @@ void Engine::init(const WeightSet& ws) {
     cflows_.push_back(cf);
   }
   {
-    const HostTensor& m = ws.get("dp.flows.0.m");
-    const HostTensor& lg = ws.get("dp.flows.0.logs");
     // After the (odd number of) Flip/ConvFlow pairs and the final Flip, logical channel 0 is ...
-    // tracked in run(); here only the scalars of ElementwiseAffine channel 0 are needed.
-    ea_m0_ = m.data[0];
-    ea_es0_ = std::exp(-lg.data[0]);
+    // tracked in run(); here only the scalars of ElementwiseAffine channel 0 are needed. They are kernel arguments (host
+    // values); a copy sits in the arena so that a skeleton engine can fetch them once the arena has arrived.
+    ea_dev_m_ = dev_tensor(ws, "dp.flows.0.m");
+    ea_dev_logs_ = dev_tensor(ws, "dp.flows.0.logs");
+    if (!skeleton_) {
+      ea_m0_ = ws.get("dp.flows.0.m").data[0];
+      ea_es0_ = std::exp(-ws.get("dp.flows.0.logs").data[0]);
+    }
   }
 
   // ---- coupling flow, execution order = reversed module order, Flip folded into weights
@@ -332,7 +363,8 @@ void Engine::init(const WeightSet& ws) {
       rcls_.push_back(r);
       if (gin_) {
         const HostTensor& cw = ws.get(p + ".enc.cond_layer.weight");
-        cond_wn_.push_back(CondW{dev_copy(cw.data), dev_tensor(ws, p + ".enc.cond_layer.bias"), (int)cw.dims[0]});
+        cond_wn_.push_back(CondW{dev_tensor(ws, p + ".enc.cond_layer.weight"), dev_tensor(ws, p + ".enc.cond_layer.bias"),
+                                 (int)cw.dims[0]});
       }
     }
     if (flips & 1) throw std::runtime_error("odd number of flow layers is not supported");
@@ -380,7 +412,7 @@ void Engine::init(const WeightSet& ws) {
       ups_.push_back(st);
     }
     const HostTensor& pw = ws.get("dec.conv_post.weight");
-    post_w_ = dev_copy(pw.data);
+    post_w_ = dev_tensor(ws, "dec.conv_post.weight");
     post_cin_ = (int)pw.dims[1];
     if ((int)pw.dims[0] != 1 || post_cin_ != ch || (int)pw.dims[2] != POST_K)
       throw std::runtime_error("dec.conv_post shape mismatch");
@@ -391,9 +423,9 @@ void Engine::init(const WeightSet& ws) {
     if (!gin_) throw std::runtime_error("multi-speaker voice without gin_channels");
     emb_g_ = dev_tensor(ws, "emb_g.weight");
     const HostTensor& dw = ws.get("dp.cond.weight");
-    cond_dp_ = CondW{dev_copy(dw.data), dev_tensor(ws, "dp.cond.bias"), (int)dw.dims[0]};
+    cond_dp_ = CondW{dev_tensor(ws, "dp.cond.weight"), dev_tensor(ws, "dp.cond.bias"), (int)dw.dims[0]};
     const HostTensor& cw = ws.get("dec.cond.weight");
-    cond_dec_ = CondW{dev_copy(cw.data), dev_tensor(ws, "dec.cond.bias"), (int)cw.dims[0]};
+    cond_dec_ = CondW{dev_tensor(ws, "dec.cond.weight"), dev_tensor(ws, "dec.cond.bias"), (int)cw.dims[0]};
     cond_off_dp_ = 0;
     int off = cond_dp_.rows;
     for (auto& c : cond_wn_) { cond_off_wn_.push_back(off); off += c.rows; }
@@ -474,11 +506,23 @@ void Engine::init(const WeightSet& ws) {
 
 Engine::~Engine() { free_all(); }
 
+void Engine::arena_ready() {
+  PE_HIP(hipSetDevice(device_));
+  float m = 0.f, lg = 0.f;
+  PE_HIP(hipMemcpy(&m, ea_dev_m_, sizeof(float), hipMemcpyDeviceToHost));
+  PE_HIP(hipMemcpy(&lg, ea_dev_logs_, sizeof(float), hipMemcpyDeviceToHost));
+  ea_m0_ = m;
+  ea_es0_ = std::exp(-lg);
+  skeleton_ = false;
+}
+
 void Engine::free_all() {
   if (stream_) hipStreamSynchronize(stream_);
   drop_graphs();
   for (void* p : owned_) hipFree(p);
   owned_.clear();
+  if (arena_owned_ && arena_) hipFree(arena_);
+  arena_ = nullptr;
   if (wsA_) hipFree(wsA_);
   if (wsB_) hipFree(wsB_);
   if (h_audio_) hipHostFree(h_audio_);
@@ -970,7 +1014,7 @@ void Engine::build_mrf2(UpStage& st) {
         Mrf2Seg sg{};
         sg.step0 = s0; sg.nsteps = std::min(SEGSTEPS, nsteps - s0); sg.woff = (int)wstream.size();
         wstream.resize(wstream.size() + (size_t)sg.nsteps * STEPF, 0.f);
-        for (int st_i = 0; st_i < sg.nsteps; ++st_i) {
+        for (int st_i = 0; st_i < (skeleton_ ? 0 : sg.nsteps); ++st_i) {
           const int step = s0 + st_i, c = step / h.k, tap = step % h.k;
           for (int ms = 0; ms < MS; ++ms)
             for (int q = 0; q < 2; ++q)
@@ -1017,8 +1061,7 @@ void Engine::build_mrf2(UpStage& st) {
   };
   st.m2_phases = up(phases.data(), phases.size() * sizeof(Mrf2Phase));
   st.m2_segs = up(segs.data(), segs.size() * sizeof(Mrf2Seg));
-  st.m2_w = (float*)up(wstream.data(), wstream.size() * sizeof(float));
-  weight_bytes_ += wstream.size() * sizeof(float);
+  st.m2_w = dev_alloc(wstream.size(), wstream.data());      // weights: in the arena (travels with the broadcast)
   st.m2_nphases = (int)phases.size(); st.m2_nsegs = (int)segs.size(); st.m2_wfloats = (int)wstream.size();
   st.m2_cp = CP; st.m2_n = N; st.m2_ws = WS; st.m2_hxa = hxa; st.m2_cu_lo = cu_lo; st.m2_cu_hi = cu_hi;
   st.m2_nwr = NWR;

@@ -48,10 +48,24 @@ struct NoiseIn {            // optional injected N(0,1) draws (parity tests); ho
   int64_t z_stride = 0;
 };
 
+// Where the packed voice weights live. Default: one device allocation owned by the engine. A caller-provided arena
+// (multi-GPU: a device buffer the host framework can hand to RCCL) receives them instead; with `skeleton` the engine only
+// lays the arena out (same offsets as on the packing rank, derived from tensor shapes alone) and waits for its content
+// to be broadcast into it -- no parsing of weight data, no packing, no upload on that rank.
+struct ArenaSpec {
+  void* base = nullptr;
+  size_t bytes = 0;
+  bool skeleton = false;
+};
+
 class Engine {
  public:
-  Engine(const WeightSet& ws, int device);
+  Engine(const WeightSet& ws, int device, ArenaSpec arena = ArenaSpec{});
   ~Engine();
+  // upper bound of the packed-weight arena for a voice (from tensor shapes), and what the engine actually used
+  static size_t arena_bound(const WeightSet& ws);
+  size_t arena_used() const { return arena_off_; }
+  const void* arena_base() const { return arena_; }
 
   // Phase 1: copy inputs to HBM. ids: concatenated phoneme ids, offsets[B+1].
   void upload(const int64_t* ids, const int64_t* offsets, int B, const float scales[3],
@@ -101,13 +115,16 @@ class Engine {
   // ---- setup
   void init(const WeightSet& ws);
   float* dev_copy(const std::vector<float>& v);
+  float* dev_alloc(size_t nfloats, const float* src);   // bump allocation in the weight arena (+ upload unless skeleton)
+  char* arena_ = nullptr; size_t arena_bytes_ = 0, arena_off_ = 0;
+  bool arena_owned_ = false, skeleton_ = false;
   float* dev_tensor(const WeightSet& ws, const std::string& name);
   PackedConv pack_conv(const WeightSet& ws, const std::string& wname, const std::string& bname, int dil,
                        int padl_override, bool gate, int in_rev, int out_rev);
   PackedConv pack_qkv(const WeightSet& ws, const std::string& prefix);
   PackedConv pack_convT(const WeightSet& ws, const std::string& prefix, int stride);
   PackedConv pack_matrix(const std::vector<float>& W, int rows, int Cin, int ntaps,
-                         const std::vector<float>* bias, int dil, int padl, bool gate, int split);
+                         const std::vector<float>* bias, int nbias, int dil, int padl, bool gate, int split);
   DdsW load_dds(const WeightSet& ws, const std::string& prefix);
   void ensure_stage_a(int B, int Tmax);
   void ensure_stage_b(int Fmax);
@@ -195,6 +212,11 @@ class Engine {
   };
   std::vector<CFlow> cflows_;
   float ea_m0_ = 0, ea_es0_ = 1;
+  float *ea_dev_m_ = nullptr, *ea_dev_logs_ = nullptr;
+ public:
+  // skeleton engines: call once the arena content has been broadcast into place (fetches the few host-side scalars)
+  void arena_ready();
+ private:
   struct Rcl {
     PackedConv pre, post;
     std::vector<PackedConv> in, rs;

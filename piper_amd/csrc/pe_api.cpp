@@ -59,6 +59,44 @@ int pe_create_from_blob(const void* blob, size_t nbytes, int device, pe_engine**
   });
 }
 
+int pe_weights_bound(const void* blob, size_t nbytes, size_t* bound) {
+  return guard([&] {
+    if (!blob || !bound) throw std::runtime_error("null argument");
+    pe::WeightSet ws = pe::parse_blob(blob, nbytes, true);
+    *bound = pe::Engine::arena_bound(ws);
+  });
+}
+
+int pe_create_in_arena(const void* blob, size_t nbytes, int device, void* arena, size_t arena_bytes, int skeleton,
+                       pe_engine** out) {
+  return guard([&] {
+    if (!blob || !out || !arena) throw std::runtime_error("null argument");
+    pe::WeightSet ws = pe::parse_blob(blob, nbytes, skeleton != 0);
+    auto* h = new pe_engine{nullptr, {}};
+    try {
+      h->eng = new pe::Engine(ws, device, pe::ArenaSpec{arena, arena_bytes, skeleton != 0});
+    } catch (...) {
+      delete h;
+      throw;
+    }
+    *out = h;
+  });
+}
+
+int pe_weights_used(pe_engine* e, size_t* used) {
+  return guard([&] {
+    if (!e || !used) throw std::runtime_error("null argument");
+    *used = e->eng->arena_used();
+  });
+}
+
+int pe_arena_ready(pe_engine* e) {
+  return guard([&] {
+    if (!e) throw std::runtime_error("null engine");
+    e->eng->arena_ready();
+  });
+}
+
 int pe_create(const char* onnx_path, int device, pe_engine** out) {
   return guard([&] {
     if (!onnx_path || !out) throw std::runtime_error("null argument");

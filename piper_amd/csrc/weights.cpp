@@ -20,7 +20,17 @@ void WeightSet::put(const std::string& name, HostTensor&& ht) {
   t[name] = std::move(ht);
 }
 
-WeightSet parse_blob(const void* data, size_t nbytes) {
+size_t blob_header_bytes(const void* data, size_t nbytes) {
+  const uint8_t* p = static_cast<const uint8_t*>(data);
+  const size_t head = 8 + 4 * ARCH_INTS + 8;
+  if (nbytes < head || memcmp(p, MAGIC, 8) != 0) throw std::runtime_error("not a PEBLOB01 weight blob");
+  uint32_t n;
+  memcpy(&n, p + 8 + 4 * ARCH_INTS, 4);
+  if (nbytes < head + (size_t)n * REC_BYTES) throw std::runtime_error("truncated weight blob (records)");
+  return head + (size_t)n * REC_BYTES;
+}
+
+WeightSet parse_blob(const void* data, size_t nbytes, bool shapes_only) {
   const uint8_t* p = static_cast<const uint8_t*>(data);
   const size_t head = 8 + 4 * ARCH_INTS + 8;
   if (nbytes < head || memcmp(p, MAGIC, 8) != 0) throw std::runtime_error("not a PEBLOB01 weight blob");
@@ -42,7 +52,8 @@ WeightSet parse_blob(const void* data, size_t nbytes) {
     memcpy(&numel, r + NAME_BYTES + 32, 8);
     if (ndim < 0 || ndim > 4) throw std::runtime_error("bad tensor rank in blob");
     // overflow-safe: a corrupt blob (also one received over the weight broadcast) must not wrap the bound
-    if (off > nbytes || numel > (nbytes - off) / 4) throw std::runtime_error("truncated weight blob (data)");
+    if (!shapes_only && (off > nbytes || numel > (nbytes - off) / 4)) throw std::runtime_error("truncated weight blob (data)");
+    if (numel > ((uint64_t)1 << 34)) throw std::runtime_error("implausible tensor size in blob");
     HostTensor ht;
     uint64_t chk = 1;
     for (int d = 0; d < ndim; ++d) {
@@ -50,8 +61,10 @@ WeightSet parse_blob(const void* data, size_t nbytes) {
       chk *= (uint64_t)dims[d];
     }
     if (chk != numel) throw std::runtime_error(std::string("dims/numel mismatch for ") + name);
-    ht.data.resize(numel);
-    memcpy(ht.data.data(), p + off, numel * 4);
+    if (!shapes_only) {
+      ht.data.resize(numel);
+      memcpy(ht.data.data(), p + off, numel * 4);
+    }
     ws.put(name, std::move(ht));
   }
   return ws;

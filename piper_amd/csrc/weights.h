@@ -36,7 +36,10 @@ struct WeightSet {
   void put(const std::string& name, HostTensor&& ht);
 };
 
-WeightSet parse_blob(const void* data, size_t nbytes);
+// shapes_only: read the architecture header and the tensor records (names, dims) but no data -- `data` may then be
+// just the header part of a blob (what the ranks of a multi-GPU job receive before the packed weights arrive).
+WeightSet parse_blob(const void* data, size_t nbytes, bool shapes_only = false);
+size_t blob_header_bytes(const void* data, size_t nbytes);
 std::vector<uint8_t> serialize_blob(const WeightSet& ws);
 
 // onnx_reader.cpp: reads a Piper voice .onnx (export_onnx.py graph) and recovers the canonical tensors.

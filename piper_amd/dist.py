@@ -48,6 +48,58 @@ def broadcast_blob(blob: Optional[bytes], src: int = 0, device=None) -> bytes:
     return blob if rank == src else buf.cpu().numpy().tobytes()
 
 
+def blob_header(blob: bytes) -> bytes:
+    """Architecture + tensor records of a PEBLOB01 (no data): all a rank needs to lay its weight arena out."""
+    import struct
+    from . import weights as W
+    n = struct.unpack_from("<I", blob, 8 + 4 * W.ARCH_INTS)[0]
+    return blob[: 8 + 4 * W.ARCH_INTS + 8 + n * W.REC_BYTES]
+
+
+def load_sharded(blob: Optional[bytes], src: int = 0, device: Optional[int] = None, lib=None):
+    """One engine per rank with ONE device-to-device broadcast of the PACKED weights (RCCL over xGMI with the nccl
+    backend): rank `src` parses / packs / uploads the voice into its arena; every other rank receives only the small
+    blob header (tensor shapes), lays out an identical arena without touching weight data, and gets the arena's content
+    by `dist.broadcast` straight into it -- no host round trip, no packing outside `src`. The arena is a torch uint8
+    tensor (so the collective can take it as is); the engine keeps it alive. Returns (engine, seconds in the broadcast).
+    """
+    import time
+    import torch
+    import torch.distributed as dist
+    from . import _lib as L
+    from .engine import Engine
+    lib = lib if lib is not None else L.get_lib()
+    rank = dist.get_rank()
+    nccl = dist.get_backend() == "nccl"
+    if device is None:
+        device = torch.cuda.current_device() if nccl else 0
+    tdev = torch.device("cuda", device) if nccl else torch.device("cpu")
+    hdr = [blob_header(blob) if rank == src else None]
+    dist.broadcast_object_list(hdr, src)
+    header = hdr[0]
+    bound = C.c_size_t()
+    if lib.pe_weights_bound(header, len(header), C.byref(bound)):
+        raise RuntimeError(lib.pe_last_error().decode(errors="replace"))
+    arena = torch.empty(bound.value + 256, dtype=torch.uint8, device=tdev)
+    off = (-arena.data_ptr()) % 256
+    arena = arena[off:off + bound.value]
+    eng = Engine(blob=blob if rank == src else header, device=device, lib=lib,
+                 arena=(arena.data_ptr(), bound.value), skeleton=rank != src)
+    eng._arena = arena
+    used = eng.weights_used()
+    if nccl:
+        torch.cuda.synchronize()
+    dist.barrier()
+    t0 = time.perf_counter()
+    dist.broadcast(arena[:used], src)
+    if nccl:
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank != src:
+        eng.arena_ready()
+    return eng, dt, used
+
+
 def onnx_to_blob(onnx_path: str, lib=None) -> bytes:
     from . import _lib as L
     lib = lib if lib is not None else L.get_lib()
@@ -73,11 +125,8 @@ class ShardedSynthesizer:
                 if onnx_path is None:
                     raise ValueError("rank 0 needs onnx_path or blob")
                 blob = onnx_to_blob(onnx_path, lib)
-        blob = broadcast_blob(blob if self.rank == 0 else None, 0)
-        if device is None:
-            import torch
-            device = torch.cuda.current_device() if dist.get_backend() == "nccl" else 0
-        self.engine = Engine(blob=blob, device=device, lib=lib)
+        self.engine, self.broadcast_seconds, self.broadcast_bytes = load_sharded(blob if self.rank == 0 else None, 0,
+                                                                                 device, lib)
 
     def synthesize(self, id_lists: Sequence[Sequence[int]], scales=(0.667, 1.0, 0.8), sids=None,
                    noise_w=None, noise_z=None) -> Optional[List[np.ndarray]]:

@@ -31,13 +31,20 @@ class Synthesis:
 
 class Engine:
     def __init__(self, *, onnx_path: Optional[str] = None, blob: Optional[bytes] = None, device: int = 0,
-                 lib: Optional[C.CDLL] = None):
+                 lib: Optional[C.CDLL] = None, arena=None, skeleton: bool = False):
+        """``arena`` = (device pointer, bytes) of a caller-owned weight arena (multi-GPU loading: see
+        piper_amd.dist.load_sharded); with ``skeleton`` the blob may be just the header of a PEBLOB01 and the arena's
+        content is expected to arrive by broadcast before ``arena_ready()``."""
         self._lib = lib if lib is not None else L.get_lib()
         self._h = C.c_void_p()
         if (onnx_path is None) == (blob is None):
             raise ValueError("give exactly one of onnx_path / blob")
         if onnx_path is not None:
             rc = self._lib.pe_create(str(onnx_path).encode(), device, C.byref(self._h))
+        elif arena is not None:
+            self._blob = bytes(blob)
+            rc = self._lib.pe_create_in_arena(self._blob, len(self._blob), device, C.c_void_p(int(arena[0])), int(arena[1]),
+                                              int(bool(skeleton)), C.byref(self._h))
         else:
             self._blob = bytes(blob)
             rc = self._lib.pe_create_from_blob(self._blob, len(self._blob), device, C.byref(self._h))
@@ -47,6 +54,14 @@ class Engine:
                                           C.byref(wb)))
         self.sample_rate, self.hop, self.num_speakers, self.num_symbols = sr.value, hop.value, nspk.value, nsym.value
         self.weight_bytes = wb.value
+
+    def weights_used(self) -> int:
+        n = C.c_size_t()
+        self._check(self._lib.pe_weights_used(self._h, C.byref(n)))
+        return int(n.value)
+
+    def arena_ready(self):
+        self._check(self._lib.pe_arena_ready(self._h))
 
     def _check(self, rc: int):
         if rc != 0:
