@@ -1700,6 +1700,44 @@ __global__ __launch_bounds__(512) void dp_persist_kernel(DpPersistP p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Counter-based N(0,1) generator for the two sampling sites (models.py:111 and :718) when the caller
+// does not inject noise: Philox-4x32-10 keyed by the engine seed, Box-Muller on the four outputs.
+__device__ __forceinline__ void philox4x32(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
+                                           unsigned k1, unsigned* o) {
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
+    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+// state = {seed, call counter} in device memory (so a captured graph draws fresh noise on replay);
+// site 0 = duration noise, 1 = prior noise.
+// the four draws of counter block q (elements 4q .. 4q+3 of a site's flat stream)
+__device__ __forceinline__ void randn4(long q, const unsigned long long* state, int site, float (&g)[4]) {
+  const unsigned long long seed = state[0], stream = state[1] * 2ull + (unsigned long long)site;
+  unsigned r[4];
+  philox4x32((unsigned)q, (unsigned)((unsigned long long)q >> 32), (unsigned)stream, (unsigned)(stream >> 32),
+             (unsigned)seed, (unsigned)(seed >> 32), r);
+  for (int h = 0; h < 2; ++h) {
+    const float u1 = ((float)r[2 * h] + 1.0f) * 2.3283064365386963e-10f;   // (0,1]
+    const float u2 = (float)r[2 * h + 1] * 2.3283064365386963e-10f;
+    const float rad = sqrtf(-2.f * logf(u1));
+    g[2 * h] = rad * cosf(6.283185307179586f * u2);
+    g[2 * h + 1] = rad * sinf(6.283185307179586f * u2);
+  }
+}
+__global__ void randn_kernel(float* out, long n, const unsigned long long* state, int site) {
+  const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  float g[4];
+  randn4(i4 >> 2, state, site, g);
+  for (int k = 0; k < 4 && i4 + k < n; ++k) out[i4 + k] = g[k];
+}
+
+// ------------------------------------------------------------------------------------------------
 // Length regulator + prior sample (models.py:705-718, commons.py:116-129). The reference multiplies
 // by a one-hot path matrix; the same result is a gather: frame f takes id i with cum[i-1] <= f < cum[i].
 //   z_p[c][f] = m_p[c][i] + noise[c][f] * exp(logs_p[c][i]) * noise_scale
@@ -1712,7 +1750,9 @@ struct RegP {
   float* out; long o_bs; int o_cs;
   int C;
   unsigned* absmax;                            // per-utterance peak accumulator of conv_post_kernel: zeroed here
-};
+  const unsigned long long* rng;               // non-null: draw the prior noise here (site 1) instead of reading `noise`:
+  float* noise_keep;                           //   element (b, c, f) = flat index of the [B][C][n_cs] stream, as randn_kernel;
+};                                             //   noise_keep (tests): also store the draws
 __global__ void regulate_kernel(RegP p) {
   const int b = blockIdx.z;
   if (p.absmax && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) p.absmax[b] = 0u;
@@ -1732,7 +1772,16 @@ __global__ void regulate_kernel(RegP p) {
   for (int c = c0; c < c0 + 16 && c < p.C; ++c) {
     const float m = hit ? sb[(long)c * p.s_cs] : 0.f;
     const float lg = hit ? sb[(long)(p.C + c) * p.s_cs] : 0.f;
-    const float nz = p.noise ? p.noise[(long)b * p.n_bs + (long)c * p.n_cs + f] : 0.f;
+    float nz = 0.f;
+    if (p.rng) {
+      const long fi = (long)b * p.n_bs + (long)c * p.n_cs + f;
+      float g4[4];
+      randn4(fi >> 2, p.rng, 1, g4);
+      nz = g4[fi & 3];
+      if (p.noise_keep) p.noise_keep[fi] = nz;
+    } else if (p.noise) {
+      nz = p.noise[(long)b * p.n_bs + (long)c * p.n_cs + f];
+    }
     p.out[(long)b * p.o_bs + (long)c * p.o_cs + f] = m + nz * expf(lg) * p.noise_scale;
   }
 }
@@ -1802,40 +1851,6 @@ __global__ void pcm16_kernel(const float* audio, long a_bs, const unsigned* absm
   float v = audio[(long)b * a_bs + t] * scale;
   v = fminf(fmaxf(v, -32768.0f), 32767.0f);
   pcm[(long)b * p_bs + t] = (short)v;
-}
-
-// ------------------------------------------------------------------------------------------------
-// Counter-based N(0,1) generator for the two sampling sites (models.py:111 and :718) when the caller
-// does not inject noise: Philox-4x32-10 keyed by the engine seed, Box-Muller on the four outputs.
-__device__ __forceinline__ void philox4x32(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0,
-                                           unsigned k1, unsigned* o) {
-  for (int r = 0; r < 10; ++r) {
-    const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
-    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1;
-    const unsigned n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
-}
-// state = {seed, call counter} in device memory (so a captured graph draws fresh noise on replay);
-// site 0 = duration noise, 1 = prior noise.
-__global__ void randn_kernel(float* out, long n, const unsigned long long* state, int site) {
-  const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
-  if (i4 >= n) return;
-  const unsigned long long seed = state[0], stream = state[1] * 2ull + (unsigned long long)site;
-  unsigned r[4];
-  philox4x32((unsigned)(i4 >> 2), (unsigned)((unsigned long long)(i4 >> 2) >> 32), (unsigned)stream,
-             (unsigned)(stream >> 32), (unsigned)seed, (unsigned)(seed >> 32), r);
-  float g[4];
-  for (int h = 0; h < 2; ++h) {
-    const float u1 = ((float)r[2 * h] + 1.0f) * 2.3283064365386963e-10f;   // (0,1]
-    const float u2 = (float)r[2 * h + 1] * 2.3283064365386963e-10f;
-    const float rad = sqrtf(-2.f * logf(u1));
-    g[2 * h] = rad * cosf(6.283185307179586f * u2);
-    g[2 * h + 1] = rad * sinf(6.283185307179586f * u2);
-  }
-  for (int k = 0; k < 4 && i4 + k < n; ++k) out[i4 + k] = g[k];
 }
 
 // Streaming decode: copy frames [win[0], win[0]+win[1]) of z [C][zs] into the window buffer [C][ws]

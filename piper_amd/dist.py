@@ -68,12 +68,14 @@ def load_sharded(blob: Optional[bytes], src: int = 0, device: Optional[int] = No
     import torch.distributed as dist
     from . import _lib as L
     from .engine import Engine
+    real = lib is None or lib is L._lib          # the shipped GPU library (tests pass the emulator build explicitly)
     lib = lib if lib is not None else L.get_lib()
     rank = dist.get_rank()
     nccl = dist.get_backend() == "nccl"
+    on_gpu = real and torch.cuda.is_available()
     if device is None:
-        device = torch.cuda.current_device() if nccl else 0
-    tdev = torch.device("cuda", device) if nccl else torch.device("cpu")
+        device = torch.cuda.current_device() if on_gpu else 0
+    tdev = torch.device("cuda", device) if on_gpu else torch.device("cpu")
     hdr = [blob_header(blob) if rank == src else None]
     dist.broadcast_object_list(hdr, src)
     header = hdr[0]
@@ -87,12 +89,17 @@ def load_sharded(blob: Optional[bytes], src: int = 0, device: Optional[int] = No
                  arena=(arena.data_ptr(), bound.value), skeleton=rank != src)
     eng._arena = arena
     used = eng.weights_used()
-    if nccl:
+    if on_gpu:
         torch.cuda.synchronize()
     dist.barrier()
     t0 = time.perf_counter()
-    dist.broadcast(arena[:used], src)
-    if nccl:
+    if nccl or not on_gpu:
+        dist.broadcast(arena[:used], src)          # nccl: device to device (RCCL over xGMI)
+    else:                                          # gloo smoke test on a GPU box: the collective needs host tensors
+        tmp = arena[:used].cpu()
+        dist.broadcast(tmp, src)
+        arena[:used].copy_(tmp)
+    if on_gpu:
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if rank != src:

@@ -172,9 +172,10 @@ def test_absurd_length_scale_is_a_clean_error(emu_lib):
     assert r.pcm[0].size == int(r.frames[0]) * eng.hop
 
 
-def test_rng_counter_advances_per_run_on_emulator(emu_lib):
+def test_rng_counter_advances_per_run_on_emulator(emu_lib, monkeypatch):
     """Every run() draws fresh noise (the first kernel of the pipeline bumps the device-side counter), also when the
     inputs were uploaded once and run() is repeated -- what bench.py's timed loop does."""
+    monkeypatch.setenv("PIPER_HIP_DEBUG_KEEP", "1")      # regulate_kernel draws the prior noise inline; keep a copy
     cfg = W.preset("tiny")
     eng = Engine(blob=W.pack_blob(cfg, W.synthetic_weights(cfg, 1234)), lib=emu_lib)
     eng.set_seed(11)

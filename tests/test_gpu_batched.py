@@ -236,7 +236,7 @@ def test_product_path_draws_from_the_tested_generator(monkeypatch):
     """Without injected noise the pipeline's two sampling sites hold exactly what pe_debug_randn reports for the
     run counter, and the counter advances on every run (a replayed hipGraph draws fresh noise)."""
     cfg, w = voice("tiny")
-    eng = make_engine(monkeypatch, cfg, w)
+    eng = make_engine(monkeypatch, cfg, w, {"PIPER_HIP_DEBUG_KEEP": 1, "PIPER_HIP_SPEC": 0})   # the prior noise is drawn inside regulate_kernel
     eng.set_seed(77)
     ids = [W.synthetic_phoneme_ids(40, 3, id_max=cfg.n_vocab - 1), W.synthetic_phoneme_ids(25, 4, id_max=cfg.n_vocab - 1)]
     eng.upload(ids, SCALES)
