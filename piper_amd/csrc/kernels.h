@@ -879,6 +879,31 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
 #pragma unroll
     for (int u = 0; u < NKF; ++u) kf[u] = pe_row_load_so(kd, base, 2 * u * p.q_cs);
   };
+  // Every global operand of the kernel that does not depend on earlier phases is requested NOW, together: this wave's
+  // first key tile, the first V chunk, then Q and the relative-position tables -- one memory latency instead of three
+  // serialised ones (the barriers below wait for all of them anyway).
+  // V chunk staging: thread -> key jj = tid&63, channel group tid>>6
+  float vv[ATT_MAXDK / 32][8];
+  auto load_v = [&](int j0) {
+    const int jj = tid & 63;
+    const int base = (j0 + jj < T) ? (tid >> 6) * 8 * p.q_cs + j0 + jj : 0x3fffffff;   // rows >= dk read 0
+#pragma unroll
+    for (int g = 0; g < ATT_MAXDK / 32; ++g)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) vv[g][u] = pe_row_load_so(vd, base, (32 * g + u) * p.q_cs);
+  };
+  auto store_v = [&]() {
+    const int jj = tid & 63;
+#pragma unroll
+    for (int g = 0; g < ATT_MAXDK / 32; ++g)
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int d = (tid >> 6) * 8 + 32 * g + u;
+        if (d < dk) Vt[jj * VS + d] = vv[g][u];
+      }
+  };
+  load_k(wv);
+  load_v(0);
   {
     constexpr int NQ = ATT_MAXDK * ATT_QB / 256;     // 16 elements per thread at dk = 128
     float qv[NQ];
@@ -913,9 +938,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
       f32x16 acc;
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      // all K fragments of a key tile are requested at once (<= 64 loads), then each batch of 32 steps reads its
-      // Q operands from LDS in one go and issues its MFMAs back to back
-      load_k(kt);
+      // all K fragments of a key tile are requested at once (<= 64 loads; the wave's first tile already at kernel
+      // start), then each batch of 32 steps reads its Q operands from LDS in one go and issues its MFMAs back to back
+      if (kt != wv) load_k(kt);
 #pragma unroll
       for (int s0 = 0; s0 < NKF; s0 += 32) {
         if (s0 < nk2) {
@@ -958,27 +983,6 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
         S[i * SP + j] += (part[i * 16 + r] + part[(32 + i) * 16 + r]) + (part[(64 + i) * 16 + r] + part[(96 + i) * 16 + r]);
     }
   }
-  // the first V chunk travels while the softmax runs (thread -> key jj = tid&63, channel group tid>>6)
-  float vv[ATT_MAXDK / 32][8];
-  auto load_v = [&](int j0) {
-    const int jj = tid & 63;
-    const int base = (j0 + jj < T) ? (tid >> 6) * 8 * p.q_cs + j0 + jj : 0x3fffffff;   // rows >= dk read 0
-#pragma unroll
-    for (int g = 0; g < ATT_MAXDK / 32; ++g)
-#pragma unroll
-      for (int u = 0; u < 8; ++u) vv[g][u] = pe_row_load_so(vd, base, (32 * g + u) * p.q_cs);
-  };
-  auto store_v = [&]() {
-    const int jj = tid & 63;
-#pragma unroll
-    for (int g = 0; g < ATT_MAXDK / 32; ++g)
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int d = (tid >> 6) * 8 + 32 * g + u;
-        if (d < dk) Vt[jj * VS + d] = vv[g][u];
-      }
-  };
-  load_v(0);
   __syncthreads();
   // ---- 2b. softmax over valid keys: row = tid/8, 8 adjacent lanes per row (values stay in registers for the
   // common T <= 128)
@@ -1430,21 +1434,23 @@ __device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b
       float bz[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) bz[r] = pe_row_load(biasd, mt * 16 + 4 * lq + r);
-      // 16 k-steps (64 input channels) per batch: four float4 weight loads, sixteen LDS reads, sixteen MFMAs
-      for (int q0 = 0; q0 < nq; q0 += 4) {
-        float a[16], yv[16];
+      // the tile's whole weight row block is requested at once (2 * NVT float4 per lane: one memory latency per tile
+      // instead of one per 16 k-steps), then batches of 16 k-steps: sixteen LDS reads, sixteen MFMAs
+      f32x4 w4[2 * NVT];
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-          const f32x4 w4 = pe_row_load4(wsrc, (q0 + qq) * 256 + lane * 4);
+      for (int qq = 0; qq < 2 * NVT; ++qq) w4[qq] = pe_row_load4(wsrc, qq * 256 + lane * 4);     // past nq: zeros
+      PE_SCHED_FENCE();
 #pragma unroll
-          for (int j = 0; j < 4; ++j) a[4 * qq + j] = w4[j];
+      for (int q0 = 0; q0 < 2 * NVT; q0 += 4) {
+        if (q0 < nq) {
+          float yv[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) yv[u] = (4 * q0 + u < Hp / 4) ? Y[(4 * (4 * q0 + u) + lq) * NC + l15] : 0.f;
+          PE_SCHED_FENCE();
+#pragma unroll
+          for (int u = 0; u < 16; ++u) acc = pe_mfma_16x16x4(w4[q0 + (u >> 2)][u & 3], yv[u], acc);
+          PE_SCHED_FENCE();
         }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) yv[u] = (4 * q0 + u < Hp / 4) ? Y[(4 * (4 * q0 + u) + lq) * NC + l15] : 0.f;
-        PE_SCHED_FENCE();
-#pragma unroll
-        for (int u = 0; u < 16; ++u) acc = pe_mfma_16x16x4(a[u], yv[u], acc);
-        PE_SCHED_FENCE();
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) Z[(mt * 16 + 4 * lq + r) * NC + l15] = acc[r] + bz[r];
@@ -1495,20 +1501,21 @@ __device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b
       float bz[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) bz[r] = pe_row_load(biasd, mt * 16 + 4 * lq + r);
-      for (int q0 = 0; q0 < nq; q0 += 4) {
-        float a[16], yv[16];
+      f32x4 w4[2 * NVT];
 #pragma unroll
-        for (int qq = 0; qq < 4; ++qq) {
-          const f32x4 w4 = pe_row_load4(wsrc, (q0 + qq) * 256 + lane * 4);
+      for (int qq = 0; qq < 2 * NVT; ++qq) w4[qq] = pe_row_load4(wsrc, qq * 256 + lane * 4);     // past nq: zeros
+      PE_SCHED_FENCE();
 #pragma unroll
-          for (int j = 0; j < 4; ++j) a[4 * qq + j] = w4[j];
+      for (int q0 = 0; q0 < 2 * NVT; q0 += 4) {
+        if (q0 < nq) {
+          float yv[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) yv[u] = (4 * q0 + u < Hp / 4) ? Y[(4 * (4 * q0 + u) + lq) * NC + l15] : 0.f;
+          PE_SCHED_FENCE();
+#pragma unroll
+          for (int u = 0; u < 16; ++u) acc = pe_mfma_16x16x4(w4[q0 + (u >> 2)][u & 3], yv[u], acc);
+          PE_SCHED_FENCE();
         }
-#pragma unroll
-        for (int u = 0; u < 16; ++u) yv[u] = (4 * q0 + u < Hp / 4) ? Y[(4 * (4 * q0 + u) + lq) * NC + l15] : 0.f;
-        PE_SCHED_FENCE();
-#pragma unroll
-        for (int u = 0; u < 16; ++u) acc = pe_mfma_16x16x4(a[u], yv[u], acc);
-        PE_SCHED_FENCE();
       }
 #pragma unroll
       for (int r = 0; r < 4; ++r) Z[(mt * 16 + 4 * lq + r) * NC + l15] = acc[r] + bz[r];
