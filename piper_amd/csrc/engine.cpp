@@ -1496,7 +1496,12 @@ void Engine::issue_flow() {
         PE_HIP(hipMemcpyAsync(noise_z_ + ((size_t)b * C_ + c) * Fs,
                               h_noise_z_ + ((size_t)b * C_ + c) * h_noise_z_stride_,
                               frames_h_[b] * sizeof(float), hipMemcpyHostToDevice, stream_));
-  }     // otherwise regulate_kernel draws the prior noise itself (same counter stream as randn_kernel site 1)
+  } else {
+    // (drawing the noise inside regulate_kernel was tried: one launch fewer, but a Philox block + Box-Muller per element
+    // in its 16-channels-per-thread loop cost 21 us against this launch's 5, profiles/r02_notes.md)
+    const long n = (long)B * C_ * Fs;
+    PE_LAUNCH(randn_kernel, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, stream_, noise_z_, n, d_rng_, 1);
+  }
   {
     RegP rp;
     rp.stats = stats_; rp.s_bs = (long)2 * C_ * Ts; rp.s_cs = Ts;
@@ -1505,8 +1510,6 @@ void Engine::issue_flow() {
     rp.noise_scale = scales_[0];
     rp.out = zp_; rp.o_bs = (long)C_ * Fs; rp.o_cs = Fs; rp.C = C_;
     rp.absmax = absmax_;
-    rp.rng = have_noise_z_ ? nullptr : d_rng_;
-    rp.noise_keep = debug_keep_ ? noise_z_ : nullptr;
     PE_LAUNCH(regulate_kernel, dim3((Fmax + 63) / 64, (C_ + 15) / 16, B), dim3(64), 0, stream_, rp);
     if (zp_keep_)     // tests: z_p, the flow's input (the flow transforms zp_ in place)
       PE_HIP(hipMemcpyAsync(zp_keep_, zp_, (size_t)B * C_ * Fs * sizeof(float), hipMemcpyDeviceToDevice, stream_));

@@ -1757,9 +1757,7 @@ struct RegP {
   float* out; long o_bs; int o_cs;
   int C;
   unsigned* absmax;                            // per-utterance peak accumulator of conv_post_kernel: zeroed here
-  const unsigned long long* rng;               // non-null: draw the prior noise here (site 1) instead of reading `noise`:
-  float* noise_keep;                           //   element (b, c, f) = flat index of the [B][C][n_cs] stream, as randn_kernel;
-};                                             //   noise_keep (tests): also store the draws
+};
 __global__ void regulate_kernel(RegP p) {
   const int b = blockIdx.z;
   if (p.absmax && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) p.absmax[b] = 0u;
@@ -1779,16 +1777,7 @@ __global__ void regulate_kernel(RegP p) {
   for (int c = c0; c < c0 + 16 && c < p.C; ++c) {
     const float m = hit ? sb[(long)c * p.s_cs] : 0.f;
     const float lg = hit ? sb[(long)(p.C + c) * p.s_cs] : 0.f;
-    float nz = 0.f;
-    if (p.rng) {
-      const long fi = (long)b * p.n_bs + (long)c * p.n_cs + f;
-      float g4[4];
-      randn4(fi >> 2, p.rng, 1, g4);
-      nz = g4[fi & 3];
-      if (p.noise_keep) p.noise_keep[fi] = nz;
-    } else if (p.noise) {
-      nz = p.noise[(long)b * p.n_bs + (long)c * p.n_cs + f];
-    }
+    const float nz = p.noise ? p.noise[(long)b * p.n_bs + (long)c * p.n_cs + f] : 0.f;
     p.out[(long)b * p.o_bs + (long)c * p.o_cs + f] = m + nz * expf(lg) * p.noise_scale;
   }
 }
