@@ -215,6 +215,19 @@ float* Engine::pack16(const std::vector<float>& W, int rows, int K) {
   return dev_alloc(np, skeleton_ ? nullptr : P.data());
 }
 
+// A 1x1 conv weight [Co][Ci][1] (optionally with reversed input / output channels: the Flip folded in) in pack16 order
+float* Engine::pack16_conv(const WeightSet& ws, const std::string& wname, int in_rev, int out_rev) {
+  const HostTensor& w = ws.get(wname);
+  if (w.dims.size() != 3 || w.dims[2] != 1) throw std::runtime_error(wname + ": expected a 1x1 conv weight");
+  const int Co = (int)w.dims[0], Ci = (int)w.dims[1];
+  std::vector<float> W(skeleton_ ? 0 : (size_t)Co * Ci);
+  if (!skeleton_)
+    for (int o = 0; o < Co; ++o)
+      for (int i = 0; i < Ci; ++i)
+        W[(size_t)o * Ci + i] = w.data[(size_t)(out_rev ? Co - 1 - o : o) * Ci + (in_rev ? Ci - 1 - i : i)];
+  return pack16(W, Co, Ci);
+}
+
 DdsW Engine::load_dds(const WeightSet& ws, const std::string& p) {
   DdsW d;
   for (int i = 0; i < arch_[A_DDSLAYERS]; ++i) {
@@ -291,6 +304,7 @@ void Engine::init(const WeightSet& ws) {
     EncLayer e;
     e.qkv = pack_qkv(ws, a);
     e.o = pack_conv(ws, a + ".conv_o.weight", a + ".conv_o.bias", 1, -1, false, 0, 0);
+    e.o16 = pack16_conv(ws, a + ".conv_o.weight", 0, 0);
     e.relk = dev_tensor(ws, a + ".emb_rel_k");
     e.relv = dev_tensor(ws, a + ".emb_rel_v");
     e.g1 = dev_tensor(ws, "enc_p.encoder.norm_layers_1." + s + ".gamma");
@@ -360,6 +374,8 @@ void Engine::init(const WeightSet& ws) {
         (void)wnk;
       }
       r.post = pack_conv(ws, p + ".post.weight", p + ".post.bias", 1, -1, false, 0, odd);
+      r.pre16 = pack16_conv(ws, p + ".pre.weight", odd, 0);
+      r.post16 = pack16_conv(ws, p + ".post.weight", 0, odd);
       rcls_.push_back(r);
       if (gin_) {
         const HostTensor& cw = ws.get(p + ".enc.cond_layer.weight");
@@ -498,6 +514,7 @@ void Engine::init(const WeightSet& ws) {
   if (const char* t = getenv("PIPER_HIP_SPLITK16")) splitk16_ = atoi(t);              // A/B knob
   if (const char* t = getenv("PIPER_HIP_WIDE_SPLITK")) wide_splitk_ = atoi(t);        // 0 off, 1 auto, 2 always (tests)
   if (const char* t = getenv("PIPER_HIP_DEBUG_KEEP")) debug_keep_ = atoi(t) != 0;     // tests: keep z_p for debug_tensor
+  if (const char* t = getenv("PIPER_HIP_COLCHAIN")) colchain_ = atoi(t);              // A/B knob, tests
   if (const char* t = getenv("PIPER_HIP_FUSE_DP")) fuse_dp_ = atoi(t) != 0;           // A/B knob, tests
   if (const char* t = getenv("PIPER_HIP_FOLD_LN")) fold_ln_ = atoi(t) != 0;           // A/B knob, tests
   if (const char* t = getenv("PIPER_HIP_SPEC")) spec_enable_ = atoi(t) != 0;          // speculative stage B (A/B, tests)
@@ -1195,6 +1212,13 @@ int Engine::krow(const std::string& name) {
   prof_.push_back(ProfileRow{names_.back().c_str()});
   return (int)prof_.size() - 1;
 }
+void Engine::colchain(const ColP& p, int B, int Lmax, double flops) {
+  const int kh = kbegin(prof_level_ >= 2 ? krow("colchain_kernel<6>") : 0, flops);
+  const size_t smem = ((size_t)2 * 6 * 32 * 16 + 8 * 16) * sizeof(float);
+  PE_LAUNCH(colchain_kernel<6>, dim3((Lmax + 15) / 16, B), dim3(512), smem, stream_, p);
+  kend(kh);
+}
+
 int Engine::kbegin(int row, double flops, double bytes) {
   if (prof_level_ < 2) return -1;
   hipEvent_t a, b;
@@ -1369,8 +1393,24 @@ void Engine::issue_stage_a() {
     const int kh = kbegin(prof_level_ >= 2 ? krow("attn_kernel") : 0, afl);
     PE_LAUNCH(attn_kernel, dim3((T + ATT_QB - 1) / ATT_QB, nh_, B), dim3(256), smem, stream_, ap);
     kend(kh);
-    conv(e.o, att, y, d_tlens_, 1, T, EPI_RESADD, 1.f, ACT_NONE, x);
-    if (fold1) {
+    const bool chain_o = !fold1 && use_colchain(tsum, H_);
+    if (chain_o) {
+      // conv_o + residual + norm_layers_1 in one launch (the 192 x 192 GEMM fits one workgroup per 16 columns)
+      ColP cp{};
+      cp.in1 = att.p; cp.in1_bs = att.bs; cp.in1_cs = att.cs; cp.K1 = H_;
+      cp.w1 = e.o16; cp.b1 = e.o.bias; cp.rows1 = H_;
+      cp.mode = 0;
+      cp.res = x.p; cp.res_bs = x.bs; cp.res_cs = x.cs;
+      cp.gamma = e.g1; cp.beta = e.b1;
+      cp.out = x.p; cp.out_bs = x.bs; cp.out_cs = x.cs;
+      cp.lens = d_tlens_;
+      colchain(cp, B, T, 2.0 * tsum * e.o.macs_per_col);
+    } else {
+      conv(e.o, att, y, d_tlens_, 1, T, EPI_RESADD, 1.f, ACT_NONE, x);
+    }
+    if (chain_o) {
+      conv(e.f1, x, ffh, d_tlens_, 1, T, EPI_STORE, 1.f, ACT_RELU);
+    } else if (fold1) {
       ln_in_.g = e.g1; ln_in_.b = e.b1; ln_in_.out = x;
       conv(e.f1, y, ffh, d_tlens_, 1, T, EPI_STORE, 1.f, ACT_RELU);
     } else {
@@ -1517,11 +1557,12 @@ void Engine::issue_flow() {
   auto VF = [&](float* p, int ch) { return View{p, (long)ch * Fs, Fs}; };
   const View fh = VF(fh_, H_), facts = VF(facts_, H_), fskip = VF(fskip_, H_);
   const int half = C_ / 2;
+  const bool chain = use_colchain(fsum, std::max(H_, half));
   for (size_t ri = 0; ri < rcls_.size(); ++ri) {
     Rcl& r = rcls_[ri];
     const View x0{zp_ + (long)r.in_off * Fs, (long)C_ * Fs, Fs};
     const View x1{zp_ + (long)r.out_off * Fs, (long)C_ * Fs, Fs};
-    conv(r.pre, x0, fh, lens_b_, 1, Fmax, EPI_STORE);
+    if (!(chain && ri > 0)) conv(r.pre, x0, fh, lens_b_, 1, Fmax, EPI_STORE);     // else: written by the previous layer's chain
     const int nl = (int)r.in.size();
     for (int i = 0; i < nl; ++i) {
       const float* b2 = nspk_ > 1 ? cond_ + cond_off_wn_[ri] + (long)i * 2 * H_ : nullptr;
@@ -1529,9 +1570,25 @@ void Engine::issue_flow() {
       conv(r.rs[i], facts, fh, lens_b_, 1, Fmax, EPI_WNRS, 1.f, ACT_NONE, none, fskip, i == 0 ? 1 : 0);
       fl += 2.0 * fsum * (r.in[i].macs_per_col + r.rs[i].macs_per_col);
     }
-    conv(r.post, fskip, x1, lens_b_, 1, Fmax, EPI_SUBFROM);
+    if (chain) {
+      // post + "x1 -= m" + the next coupling layer's pre over the updated half, one launch
+      ColP cp{};
+      cp.in1 = fskip.p; cp.in1_bs = fskip.bs; cp.in1_cs = fskip.cs; cp.K1 = H_;
+      cp.w1 = r.post16; cp.b1 = r.post.bias; cp.rows1 = half;
+      cp.mode = 1;
+      cp.x1 = x1.p; cp.x1_bs = x1.bs; cp.x1_cs = x1.cs;
+      if (ri + 1 < rcls_.size()) {
+        const Rcl& nx = rcls_[ri + 1];
+        if (nx.in_off != r.out_off) throw std::runtime_error("coupling layers do not alternate halves");
+        cp.w2 = nx.pre16; cp.b2 = nx.pre.bias; cp.rows2 = H_;
+        cp.out2 = fh.p; cp.o2_bs = fh.bs; cp.o2_cs = fh.cs;
+      }
+      cp.lens = lens_b_;
+      colchain(cp, B, Fmax, 2.0 * fsum * (r.post.macs_per_col + (cp.w2 ? rcls_[ri + 1].pre.macs_per_col : 0)));
+    } else {
+      conv(r.post, fskip, x1, lens_b_, 1, Fmax, EPI_SUBFROM);
+    }
     fl += 2.0 * fsum * (r.pre.macs_per_col + r.post.macs_per_col);
-    (void)half;
   }
   prof_end(2, fl);
 

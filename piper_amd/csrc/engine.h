@@ -161,6 +161,13 @@ class Engine {
   int dp_prog_bs_ = 0;
   float* pack16(const std::vector<float>& W, int rows, int K);    // [16-row tile][q][lane][4] (dds_layer16_kernel)
   float* dp_proj16_ = nullptr;
+  int colchain_ = 1;                        // PIPER_HIP_COLCHAIN: 0 off, 1 small batches, 2 always (A/B, tests)
+  long colchain_max_cols_ = 1100;           // batch columns (ids or frames) up to which colchain_kernel replaces conv pairs
+  bool use_colchain(double cols, int kmax) const {
+    return colchain_ && kmax <= 192 && (colchain_ == 2 || cols <= (double)colchain_max_cols_);
+  }
+  void colchain(const struct ColP& p, int B, int Lmax, double flops);
+  float* pack16_conv(const WeightSet& ws, const std::string& wname, int in_rev, int out_rev);
   bool fuse_dp_ = true;                     // PIPER_HIP_FUSE_DP=0: cf_pre / proj / spline as separate launches (A/B, tests)
   void issue_stage_a();
   void issue_stage_b();
@@ -198,6 +205,7 @@ class Engine {
   float* emb_g_ = nullptr;
   struct EncLayer {
     PackedConv qkv, o, f1, f2;
+    float* o16 = nullptr;                        // conv_o in pack16 order (colchain_kernel)
     float *relk, *relv, *g1, *b1, *g2, *b2;
   };
   std::vector<EncLayer> enc_;
@@ -219,6 +227,7 @@ class Engine {
  private:
   struct Rcl {
     PackedConv pre, post;
+    float *pre16 = nullptr, *post16 = nullptr;   // the same two 1x1 convs in pack16 order (colchain_kernel)
     std::vector<PackedConv> in, rs;
     int in_off, out_off;             // channel offsets of x0 / x1 in the physical (unflipped) layout
   };

@@ -1304,6 +1304,66 @@ struct DdsP {
   float* zout; long zout_bs;
   float inv_sqrt_h;
 };
+// rows x Kp GEMM over the 16 columns in IN[Kp][16] on the 16x16x4 MFMA; sink(row, col, value + bias[row]).
+// Wave w owns the 16-row tiles w and w + 8 (then w + 16, w + 24, ...) and runs such a PAIR together: both weight row
+// blocks are requested up front (one memory latency per pair, 2 * NQMAX float4 per lane), the B fragments are read from
+// LDS once for both, and the two accumulator chains alternate on the MFMA pipe instead of each waiting on itself.
+// k ascends inside and across the instructions of a tile exactly as in a one-tile-at-a-time loop: same fmaf chain.
+template <int NQMAX, class Sink>
+__device__ __forceinline__ void col_gemm16(const float* wp16, const float* bias, int nbias, int rows, int Kp,
+                                           const float* IN, int wv, int lane, Sink&& sink) {
+  constexpr int NC = 16;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int nq = Kp / 16, ntile = (rows + 15) / 16, tile_floats = nq * 256;
+  const pe_rowsrc biasd = pe_make_row(bias ? bias : wp16, bias ? nbias : 0);
+  for (int mt = wv; mt < ntile; mt += 16) {
+    const bool two = PE_UNIFORM(mt + 8 < ntile);
+    const pe_rowsrc ws0 = pe_make_row_u(wp16 + (long)mt * tile_floats, tile_floats);
+    const pe_rowsrc ws1 = pe_make_row_u(wp16 + (long)(two ? mt + 8 : mt) * tile_floats, two ? tile_floats : 0);
+    f32x4 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc0[r] = acc1[r] = 0.f;
+    float bz0[4], bz1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      bz0[r] = pe_row_load(biasd, mt * 16 + 4 * lq + r);
+      bz1[r] = pe_row_load(biasd, two ? (mt + 8) * 16 + 4 * lq + r : -1);
+    }
+    f32x4 w0[NQMAX], w1[NQMAX];
+#pragma unroll
+    for (int qq = 0; qq < NQMAX; ++qq) w0[qq] = pe_row_load4(ws0, qq * 256 + lane * 4);     // past nq: zeros
+#pragma unroll
+    for (int qq = 0; qq < NQMAX; ++qq) w1[qq] = pe_row_load4(ws1, qq * 256 + lane * 4);
+    PE_SCHED_FENCE();
+#pragma unroll
+    for (int q0 = 0; q0 < NQMAX; q0 += 4) {
+      if (q0 < nq) {
+        float yv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) yv[u] = (4 * q0 + u < Kp / 4) ? IN[(4 * (4 * q0 + u) + lq) * NC + l15] : 0.f;
+        PE_SCHED_FENCE();
+        if (two) {
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            acc0 = pe_mfma_16x16x4(w0[q0 + (u >> 2)][u & 3], yv[u], acc0);
+            acc1 = pe_mfma_16x16x4(w1[q0 + (u >> 2)][u & 3], yv[u], acc1);
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 16; ++u) acc0 = pe_mfma_16x16x4(w0[q0 + (u >> 2)][u & 3], yv[u], acc0);
+        }
+        PE_SCHED_FENCE();
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sink(mt * 16 + 4 * lq + r, l15, acc0[r] + bz0[r]);
+    if (two) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sink((mt + 8) * 16 + 4 * lq + r, l15, acc1[r] + bz1[r]);
+    }
+  }
+}
+
 // One workgroup = 16 time columns x all channels, 512 threads; the 1x1 conv runs on the 16x16x4 f32 MFMA: the GEMM's
 // N matches the column count, its 16-row tiles (Hp/16 = 12 for H = 192) spread evenly over the four SIMDs of the 8
 // waves (three each), and a 128-id utterance still gives 8 workgroups. (A first version used 32 columns and the
@@ -1420,42 +1480,8 @@ __device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b
   }
   __syncthreads();
 
-  // ---- phase 2: Z = W1x1 . Y + bias on 16x16x4 MFMAs; wave w owns the 16-row tiles w, w+8, ...
-  {
-    const int l15 = lane & 15, lq = lane >> 4;
-    const int ntile = Hp / 16, nq = Hp / 16;           // k steps = Hp/4, float4 groups per lane = Hp/16
-    const int tile_floats = nq * 256;
-    const pe_rowsrc biasd = pe_make_row(p.bias, H);
-    for (int mt = wv; mt < ntile; mt += 8) {
-      const pe_rowsrc wsrc = pe_make_row_u(p.wp16 + (long)mt * tile_floats, tile_floats);
-      f32x4 acc;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = 0.f;
-      float bz[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bz[r] = pe_row_load(biasd, mt * 16 + 4 * lq + r);
-      // the tile's whole weight row block is requested at once (2 * NVT float4 per lane: one memory latency per tile
-      // instead of one per 16 k-steps), then batches of 16 k-steps: sixteen LDS reads, sixteen MFMAs
-      f32x4 w4[2 * NVT];
-#pragma unroll
-      for (int qq = 0; qq < 2 * NVT; ++qq) w4[qq] = pe_row_load4(wsrc, qq * 256 + lane * 4);     // past nq: zeros
-      PE_SCHED_FENCE();
-#pragma unroll
-      for (int q0 = 0; q0 < 2 * NVT; q0 += 4) {
-        if (q0 < nq) {
-          float yv[16];
-#pragma unroll
-          for (int u = 0; u < 16; ++u) yv[u] = (4 * q0 + u < Hp / 4) ? Y[(4 * (4 * q0 + u) + lq) * NC + l15] : 0.f;
-          PE_SCHED_FENCE();
-#pragma unroll
-          for (int u = 0; u < 16; ++u) acc = pe_mfma_16x16x4(w4[q0 + (u >> 2)][u & 3], yv[u], acc);
-          PE_SCHED_FENCE();
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Z[(mt * 16 + 4 * lq + r) * NC + l15] = acc[r] + bz[r];
-    }
-  }
+  // ---- phase 2: Z = W1x1 . Y + bias on 16x16x4 MFMAs (col_gemm16: tiles w and w+8 of a wave run as a pair)
+  col_gemm16<2 * NVT>(p.wp16, p.bias, H, Hp, Hp, Y, wv, lane, [&](int row, int cc, float val) { Z[row * NC + cc] = val; });
   __syncthreads();
 
   // ---- phase 3: LN2, GELU, residual -> out
@@ -1488,39 +1514,8 @@ __device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b
     if (c < Hp) Y[c * NC + col] = (c < H && ok) ? xc[k] + gelu_erf((v[k] - mean) * rstd * gg[k] + bb[k]) : 0.f;
   }
   __syncthreads();
-  {
-    const int l15 = lane & 15, lq = lane >> 4;
-    const int ntile = (p.post_rows + 15) / 16, nq = Hp / 16;
-    const int tile_floats = nq * 256;
-    const pe_rowsrc biasd = pe_make_row(p.post_bias, p.post_bias ? p.post_rows : 0);
-    for (int mt = wv; mt < ntile; mt += 8) {
-      const pe_rowsrc wsrc = pe_make_row_u(p.post_w16 + (long)mt * tile_floats, tile_floats);
-      f32x4 acc;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = 0.f;
-      float bz[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bz[r] = pe_row_load(biasd, mt * 16 + 4 * lq + r);
-      f32x4 w4[2 * NVT];
-#pragma unroll
-      for (int qq = 0; qq < 2 * NVT; ++qq) w4[qq] = pe_row_load4(wsrc, qq * 256 + lane * 4);     // past nq: zeros
-      PE_SCHED_FENCE();
-#pragma unroll
-      for (int q0 = 0; q0 < 2 * NVT; q0 += 4) {
-        if (q0 < nq) {
-          float yv[16];
-#pragma unroll
-          for (int u = 0; u < 16; ++u) yv[u] = (4 * q0 + u < Hp / 4) ? Y[(4 * (4 * q0 + u) + lq) * NC + l15] : 0.f;
-          PE_SCHED_FENCE();
-#pragma unroll
-          for (int u = 0; u < 16; ++u) acc = pe_mfma_16x16x4(w4[q0 + (u >> 2)][u & 3], yv[u], acc);
-          PE_SCHED_FENCE();
-        }
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) Z[(mt * 16 + 4 * lq + r) * NC + l15] = acc[r] + bz[r];
-    }
-  }
+  col_gemm16<2 * NVT>(p.post_w16, p.post_bias, p.post_rows, p.post_rows, Hp, Y, wv, lane,
+                      [&](int row, int cc, float val) { Z[row * NC + cc] = val; });
   __syncthreads();
   if (p.post_out && ok) {
     float* po = p.post_out + (long)b * p.po_bs;
@@ -1569,6 +1564,129 @@ template <int NVT>
 __global__ __launch_bounds__(512) void dds_layer16_kernel(DdsP p) {
   PE_DYN_SMEM(float, sm);
   dds_layer16_body<NVT, false>(p, blockIdx.x, blockIdx.y, sm);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Short chains of 1x1 convs whose GEMMs are small enough for one workgroup to own ALL output rows of a 16-column tile,
+// so that what follows the GEMM (a LayerNorm over channels, or a second GEMM over the result) needs no second launch
+// and no trip through HBM. Small batches only (the tiled conv kernels win when there are columns to fill the chip):
+//   mode 0   out = LN(res + W1.in + b1)              attention conv_o + residual + norm_layers_1 (attentions.py:70-72)
+//   mode 1   x1 -= W1.in + b1 ; out2 = W2.x1 + b2    ResidualCouplingLayer.post + mean-only reverse update, then the
+//                                                    NEXT coupling layer's pre over the updated half -- the Flip between
+//                                                    them is folded into the packed weights (modules.py:455-466, 433)
+// Same 16x16x4 MFMA GEMM as dds_layer16_kernel: weights in pack16 order, B operand = the input columns in LDS.
+struct ColP {
+  const float* in1; long in1_bs; int in1_cs; int K1;
+  const float* w1; const float* b1; int rows1;
+  int mode;
+  const float* res; long res_bs; int res_cs;            // mode 0
+  const float* gamma; const float* beta;
+  float* out; long out_bs; int out_cs;
+  float* x1; long x1_bs; int x1_cs;                     // mode 1 (updated in place)
+  const float* w2; const float* b2; int rows2;          // w2 == null: no second GEMM (last coupling layer)
+  float* out2; long o2_bs; int o2_cs;
+  const int* lens;
+};
+
+template <int NVT>                              // NVT = channel slots per thread: every channel count on the chain <= 32 * NVT
+__global__ __launch_bounds__(512) void colchain_kernel(ColP p) {
+  constexpr int NC = 16;
+  PE_DYN_SMEM(float, sm);                       // IN[32 NVT][16] | Z[32 NVT][16] | red[8][16]
+  const int b = blockIdx.y, L = p.lens[b];
+  const int t0 = blockIdx.x * NC;
+  if (t0 >= L) return;
+  float* IN = sm;
+  float* Z = IN + 32 * NVT * NC;
+  float* red = Z + 32 * NVT * NC;
+  const int tid = threadIdx.x, col = tid & 15, rl = tid >> 4, wv = PE_UNIFORM(tid >> 6), lane = tid & 63;
+  const int t = t0 + col;
+  const bool ok = t < L;
+  const int K1p = (p.K1 + 31) & ~31;
+
+  // operands of the step after the first GEMM are requested before it: residual / previous x1, LN gains
+  float ov[NVT], gg[NVT], bb[NVT];
+  {
+    const pe_rowsrc ind = pe_make_row(p.in1 + (long)b * p.in1_bs, p.K1 * p.in1_cs);
+    const int nrow = p.mode == 0 ? p.rows1 : p.rows1;
+    const float* ob = p.mode == 0 ? p.res + (long)b * p.res_bs : p.x1 + (long)b * p.x1_bs;
+    const int ocs = p.mode == 0 ? p.res_cs : p.x1_cs;
+    const pe_rowsrc od = pe_make_row(ob, nrow * ocs);
+    const pe_rowsrc gd = pe_make_row(p.mode == 0 ? p.gamma : p.w1, p.mode == 0 ? p.rows1 : 0);
+    const pe_rowsrc bd = pe_make_row(p.mode == 0 ? p.beta : p.w1, p.mode == 0 ? p.rows1 : 0);
+    float xin[NVT];
+#pragma unroll
+    for (int k = 0; k < NVT; ++k) {
+      const int c = rl + 32 * k;
+      xin[k] = pe_row_load(ind, (ok && c < p.K1) ? c * p.in1_cs + t : -1);
+      ov[k] = pe_row_load(od, (ok && c < nrow) ? c * ocs + t : -1);
+      gg[k] = pe_row_load(gd, c < p.rows1 ? c : -1);
+      bb[k] = pe_row_load(bd, c < p.rows1 ? c : -1);
+    }
+#pragma unroll
+    for (int k = 0; k < NVT; ++k) {
+      const int c = rl + 32 * k;
+      if (c < K1p) IN[c * NC + col] = xin[k];
+    }
+  }
+  __syncthreads();
+  col_gemm16<2 * NVT>(p.w1, p.b1, p.rows1, p.rows1, K1p, IN, wv, lane, [&](int row, int cc, float v) { Z[row * NC + cc] = v; });
+  __syncthreads();
+
+  if (p.mode == 0) {
+    auto col_sum = [&](float v) -> float {
+      v += __shfl_xor(v, 16);
+      v += __shfl_xor(v, 32);
+      __syncthreads();
+      if (lane < NC) red[wv * NC + col] = v;
+      __syncthreads();
+      float s = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) s += red[w * NC + col];
+      return s;
+    };
+    const int H = p.rows1;
+    float v[NVT];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < NVT; ++k) {
+      const int c = rl + 32 * k;
+      v[k] = (ok && c < H) ? Z[c * NC + col] + ov[k] : 0.f;
+      s += v[k];
+    }
+    const float mean = col_sum(s) / (float)H;
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < NVT; ++k)
+      if (rl + 32 * k < H) { const float d = v[k] - mean; q = fmaf(d, d, q); }
+    const float rstd = 1.f / sqrtf(col_sum(q) / (float)H + 1e-5f);
+    if (!ok) return;
+    float* ob = p.out + (long)b * p.out_bs;
+#pragma unroll
+    for (int k = 0; k < NVT; ++k) {
+      const int c = rl + 32 * k;
+      if (c < H) ob[(long)c * p.out_cs + t] = (v[k] - mean) * rstd * gg[k] + bb[k];
+    }
+    return;
+  }
+
+  // mode 1: x1 <- x1 - (post + bias); the updated half is the next layer's x0
+  {
+    float* xb = p.x1 + (long)b * p.x1_bs;
+    const int K2p = (p.rows1 + 31) & ~31;
+#pragma unroll
+    for (int k = 0; k < NVT; ++k) {
+      const int c = rl + 32 * k;
+      const float xn = (ok && c < p.rows1) ? ov[k] - Z[c * NC + col] : 0.f;
+      if (ok && c < p.rows1) xb[(long)c * p.x1_cs + t] = xn;
+      if (c < K2p) IN[c * NC + col] = xn;
+    }
+    if (!p.w2) return;
+    __syncthreads();
+    float* o2 = p.out2 + (long)b * p.o2_bs;
+    col_gemm16<2 * NVT>(p.w2, p.b2, p.rows2, p.rows2, K2p, IN, wv, lane, [&](int row, int cc, float v) {
+      if (row < p.rows2 && t0 + cc < L) o2[(long)row * p.o2_cs + t0 + cc] = v;
+    });
+  }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -44,7 +44,7 @@ def make_engine(monkeypatch, cfg, w, env=None):
     for k in ("PIPER_HIP_SPLITK_MAX", "PIPER_HIP_SMALL", "PIPER_HIP_WIDE_MIN", "PIPER_HIP_TPB", "PIPER_HIP_SPLITK16",
               "PIPER_HIP_WIDE_SPLITK", "PIPER_HIP_FUSE_MRF", "PIPER_HIP_DEBUG_KEEP", "PIPER_HIP_PAR_MRF",
               "PIPER_HIP_FUSED", "PIPER_HIP_MRF2", "PIPER_HIP_FUSE_DP", "PIPER_HIP_FOLD_LN",
-              "PIPER_HIP_MRF2_MAXF", "PIPER_HIP_PERSIST_DP", "PIPER_HIP_SPEC"):
+              "PIPER_HIP_MRF2_MAXF", "PIPER_HIP_PERSIST_DP", "PIPER_HIP_SPEC", "PIPER_HIP_COLCHAIN"):
         monkeypatch.delenv(k, raising=False)
     for k, v in (env or {}).items():
         monkeypatch.setenv(k, str(v))
@@ -155,6 +155,9 @@ FORCED = [
     ("medium", [128, 31], {"PIPER_HIP_FUSE_DP": 0}, {"conv_splitk_kernel<1,false,8,4>"}),
     # the encoder's LayerNorms folded into the consuming split-K convs (opt-in: measured slower than ln_kernel launches)
     ("medium", [128, 50], {"PIPER_HIP_FOLD_LN": 1}, {"conv_splitk_kernel<1,false,8,4>"}),
+    # conv_o + LN and coupling post + next pre as single launches (colchain_kernel): forced on for a batch, and off
+    ("medium", [128, 77, 16, 33], {"PIPER_HIP_COLCHAIN": 2}, {"colchain_kernel<6>"}),
+    ("medium", [128, 31], {"PIPER_HIP_COLCHAIN": 0}, {"ln_kernel<0>", "conv_splitk_kernel<1,false,4,4>"}),
     # split-K variants: 4/8-wave only (no 16-column form), 12-wave everywhere, 16-column form everywhere
     ("medium", [128], {"PIPER_HIP_SPLITK16": 0, "PIPER_HIP_WIDE_SPLITK": 0},
      {"conv_splitk_kernel<2,true,8,3>", "conv_splitk_kernel<1,false,8,4>", "conv_splitk_kernel<1,false,4,4>"}),
