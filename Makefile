@@ -15,6 +15,11 @@ $(LIB): $(SRCS) $(HDRS)
 
 emu: $(EMULIB)
 
+# tuning build: the same library with phase timestamps in the small kernels (scripts/stamps.py); never shipped
+stamps: piper_amd/libpiper_hip_stamps.so
+piper_amd/libpiper_hip_stamps.so: $(SRCS) $(HDRS)
+	$(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -DPE_STAMPS -x hip $(SRCS) -o $@ -Wno-unused-result -Wno-unused-value
+
 $(EMULIB): $(SRCS) $(HDRS) tests/emu/hip_emu.cpp tests/emu/hip_emu.h
 	$(CXX_EMU) -DPE_EMU -O2 -g -std=c++17 -Wno-psabi -fPIC -shared -Itests/emu $(SRCS) tests/emu/hip_emu.cpp -o $@
 
@@ -26,4 +31,4 @@ tests/cpp/test_piper_emu: tests/cpp/test_piper.cpp $(EMULIB) include/piper.hpp
 
 clean:
 	rm -f $(LIB) $(EMULIB) tests/cpp/test_piper tests/cpp/test_piper_emu
-.PHONY: all emu clean
+.PHONY: all emu stamps clean

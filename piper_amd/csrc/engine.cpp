@@ -1726,7 +1726,7 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
     prof_begin();
     if (zero_absmax) PE_HIP(hipMemsetAsync(absmax_, 0, B * sizeof(unsigned), stream_));
     const int K = 7, Lmax = Fmax * hop_;
-    PE_LAUNCH(conv_post_kernel, dim3((Lmax + 256 * POST_OPT - 1) / (256 * POST_OPT), B), dim3(256), 0, stream_, cur.p,
+    PE_LAUNCH(conv_post_kernel, dim3((Lmax + POST_SPB - 1) / POST_SPB, B), dim3(256), 0, stream_, cur.p,
               cur.bs, cur.cs, post_w_, post_cin_, 0.01f, lens, hop_, audio_, Ss_, absmax_);
     PE_LAUNCH(pcm16_kernel, dim3((Lmax + 255) / 256, B), dim3(256), 0, stream_, audio_, Ss_, absmax_, lens, hop_,
               pcm_, Ss_);
@@ -2042,3 +2042,10 @@ void Engine::debug_tensor(const std::string& name, int b, std::vector<float>& ou
 }
 
 }  // namespace pe
+
+#ifdef PE_STAMPS
+// tuning build only (`make stamps`): the phase timestamps of pe_rt.h's PE_STAMP, [PE_NSTAMP_K][PE_NSTAMP_I] 100 MHz ticks
+extern "C" int pe_debug_stamps(long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pe_stamps), sizeof(long long) * PE_NSTAMP_K * PE_NSTAMP_I);
+}
+#endif

@@ -21,6 +21,7 @@ inline unsigned pe_atomic_inc(unsigned* p) { const unsigned o = *p; *p = o + 1; 
 inline void pe_spin_pause() { emu::yield(); }
 inline void pe_drain_stores() {}
 #define PE_DYN_SMEM(type, name) type* name = reinterpret_cast<type*>(emu::dyn_smem)
+#define PE_STAMP(k, i) ((void)0)
 #define pe_mfma_32x32x2(a, b, c) emu_mfma_32x32x2((a), (b), (c))
 #define pe_mfma_16x16x4(a, b, c) emu_mfma_16x16x4((a), (b), (c))
 #define PE_WAVE_SYNC() emu::wave_sync()
@@ -56,6 +57,17 @@ inline float pe_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 #define PE_DYN_SMEM(type, name) \
   extern __shared__ __attribute__((aligned(16))) unsigned char pe_dyn_smem_raw[]; \
   type* name = reinterpret_cast<type*>(pe_dyn_smem_raw)
+// Phase timestamps for kernel tuning (`make stamps`, scripts/stamps.py; NOT in the shipped library): thread 0 of
+// workgroup (0,0,0) records the 100 MHz wall clock at phase boundaries of the latency-critical small kernels.
+#ifdef PE_STAMPS
+#define PE_NSTAMP_K 8
+#define PE_NSTAMP_I 24
+static __device__ long long pe_stamps[PE_NSTAMP_K][PE_NSTAMP_I];   // one copy per translation unit; engine.cpp (kernels + reader) uses its own
+#define PE_STAMP(k, i) \
+  do { if ((threadIdx.x | blockIdx.x | blockIdx.y | blockIdx.z) == 0) pe_stamps[k][i] = (long long)wall_clock64(); } while (0)
+#else
+#define PE_STAMP(k, i) do {} while (0)
+#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define pe_mfma_32x32x2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
