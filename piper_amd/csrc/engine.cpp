@@ -2048,4 +2048,15 @@ void Engine::debug_tensor(const std::string& name, int b, std::vector<float>& ou
 extern "C" int pe_debug_stamps(long long* out) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pe_stamps), sizeof(long long) * PE_NSTAMP_K * PE_NSTAMP_I);
 }
+// per-launch trace: copies [PE_NTRACE][5] records (id, wall in, wall out, clock in, clock out) and the launch counter,
+// then resets the counter
+extern "C" int pe_debug_trace(long long* out, unsigned* count) {
+  hipDeviceSynchronize();
+  int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pe_trace), sizeof(long long) * PE_NTRACE * 5);
+  if (rc) return rc;
+  rc = (int)hipMemcpyFromSymbol(count, HIP_SYMBOL(pe_trace_seq), sizeof(unsigned));
+  if (rc) return rc;
+  const unsigned zero = 0;
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(pe_trace_seq), &zero, sizeof(unsigned));
+}
 #endif

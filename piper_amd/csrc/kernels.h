@@ -218,6 +218,7 @@ __device__ __forceinline__ void conv_store_gate(const ConvP& p, int b, int ch, i
 template <int WM, int WN, int MT, int NT, int KS, bool GATE, int HALO>
 __global__ __launch_bounds__(256, (MT * NT == 1 ? ((HALO == 128 && WN == 4) ? 3 : 4) : ((GATE && MT * NT == 2) ? 3 : 2)))
 void conv_mfma_kernel(ConvP p) {
+  PE_KTRACE(11);
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
   constexpr int NCOL = (BN + HALO + 63) / 64;    // staging columns per lane; (taps-1)*dilation <= HALO
   constexpr int KH = KC / 2;
@@ -386,6 +387,7 @@ void conv_mfma_kernel(ConvP p) {
 //   * partial tiles are summed through LDS in a fixed order (deterministic).
 template <int MT, bool GATE, int NW, int D>
 __global__ __launch_bounds__(64 * NW) void conv_splitk_kernel(ConvP p) {
+  PE_KTRACE(1);
   constexpr int BN = 32, XW = 64, KH = KC / 2;
   constexpr int NS = GATE ? (16 + NW - 1) / NW : (MT * 16 + NW - 1) / NW;    // epilogue slots per wave
   PE_DYN_SMEM(float, sm);                         // NW x [KC][XW] slabs, then NW x [MT*16][64] partial tiles
@@ -630,6 +632,7 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk_kernel(ConvP p) {
 // same fmaf chain as the 32x32x2 form.
 template <bool GATE, int NW, int D>
 __global__ __launch_bounds__(64 * NW) void conv_splitk16_kernel(ConvP p) {
+  PE_KTRACE(4);
   constexpr int BN = 16, XW = 64, KS8 = KC / 4, MT16 = GATE ? 4 : 2;
   constexpr int NSLOT = GATE ? 8 : MT16 * 4;                  // result slots per lane position (gate: tanh/sigmoid pairs)
   constexpr int NS = (NSLOT + NW - 1) / NW;                   // epilogue slots per wave
@@ -803,7 +806,6 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk16_kernel(ConvP p) {
       }
     }
   }
-  PE_STAMP(4, 4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -812,6 +814,7 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk16_kernel(ConvP p) {
 // the run read afterwards, so a replayed graph draws fresh noise on every run without a host copy.
 __global__ void embed_kernel(const int* ids, int ids_bs, const int* lens, const float* emb, int H,
                              float scale, float* out, long o_bs, int o_cs, unsigned long long* rng_state) {
+  PE_KTRACE(10);
   if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) rng_state[1] += 1ull;
   const int b = blockIdx.z;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -852,6 +855,7 @@ static constexpr int ATT_MAXDK = 128;
 //      from the score slab with an odd stride), wave w owns channel tiles w, w+4, ...; banded
 //      relative-value term added before the coalesced store.
 __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
+  PE_KTRACE(0);
   PE_DYN_SMEM(float, sm);
   PE_STAMP(0, 0);
   const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * ATT_QB;
@@ -1123,6 +1127,7 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + er
 
 template <int MODE>
 __global__ __launch_bounds__(256) void ln_kernel(LnP p) {
+  PE_KTRACE(5);
   __shared__ float red[4][LN_COLS];
   PE_STAMP(5, 0);
   const int b = blockIdx.y, L = p.lens[b];
@@ -1193,6 +1198,7 @@ __global__ __launch_bounds__(256) void ln_kernel(LnP p) {
 __global__ void cf_pre_kernel(const float* z0, long z_bs, const float* w, const float* bia,
                               const float* g, long g_bs, int g_cs, float* out, long o_bs, int o_cs,
                               const int* lens, int H) {
+  PE_KTRACE(12);
   const int b = blockIdx.z, c = blockIdx.y;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= lens[b] || c >= H) return;
@@ -1279,6 +1285,7 @@ __device__ __forceinline__ float spline_inverse(const float (&raw)[3 * SPL_NB - 
 // One thread per (utterance, position). z1 is transformed in place; z0 is the untouched half.
 __global__ void spline_inverse_kernel(const float* hproj, long h_bs, int h_cs, float* z1, long z_bs,
                                       const int* lens, float inv_sqrt_h) {
+  PE_KTRACE(21);
   const int b = blockIdx.y;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= lens[b]) return;
@@ -1591,6 +1598,7 @@ __device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b
 
 template <int NVT>
 __global__ __launch_bounds__(512) void dds_layer16_kernel(DdsP p) {
+  PE_KTRACE(2);
   PE_DYN_SMEM(float, sm);
   dds_layer16_body<NVT, false>(p, blockIdx.x, blockIdx.y, sm);
 }
@@ -1619,6 +1627,7 @@ struct ColP {
 
 template <int NVT>                              // NVT = channel slots per thread: every channel count on the chain <= 32 * NVT
 __global__ __launch_bounds__(512) void colchain_kernel(ColP p) {
+  PE_KTRACE(3);
   constexpr int NC = 16;
   PE_DYN_SMEM(float, sm);                       // IN[32 NVT][16] | Z[32 NVT][16] | red[8][16]
   PE_STAMP(p.mode == 0 ? 3 : (p.w2 ? 6 : 7), 0);
@@ -1782,6 +1791,7 @@ __device__ __forceinline__ void duration_body(const DurP& p, int b, long long* p
   }
 }
 __global__ __launch_bounds__(256) void duration_kernel(DurP p) {
+  PE_KTRACE(13);
   __shared__ long long part[256];
   duration_body<false>(p, blockIdx.x, part);
 }
@@ -1809,6 +1819,7 @@ struct DpPersistP {
 };
 template <int NVT>
 __global__ __launch_bounds__(512) void dp_persist_kernel(DpPersistP p) {
+  PE_KTRACE(14);
   PE_DYN_SMEM(float, sm);
   const int ct = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int L = p.layer[0].lens[b];
@@ -1893,6 +1904,7 @@ __device__ __forceinline__ void randn4(long q, const unsigned long long* state, 
   }
 }
 __global__ void randn_kernel(float* out, long n, const unsigned long long* state, int site) {
+  PE_KTRACE(15);
   const long i4 = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i4 >= n) return;
   float g[4];
@@ -1918,6 +1930,7 @@ struct RegP {
 // leaves the CU) and the 3 x 16 operands of a thread's channels are requested together through row descriptors.
 static constexpr int REG_MAXT = 4096;          // ids whose cumulative durations fit the LDS copy; longer: search in global memory
 __global__ __launch_bounds__(64) void regulate_kernel(RegP p) {
+  PE_KTRACE(16);
   __shared__ int scum[REG_MAXT];
   const int b = blockIdx.z;
   if (p.absmax && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) p.absmax[b] = 0u;
@@ -1965,22 +1978,24 @@ __global__ __launch_bounds__(64) void regulate_kernel(RegP p) {
 // ------------------------------------------------------------------------------------------------
 // Generator tail (models.py:364-366): leaky_relu(0.01) -> conv_post (k=7, no bias, 1 output channel)
 // -> tanh, fused with the per-utterance max|x| that the int16 conversion needs (piper.cpp:410-418).
-// HBM-bound (4*Cin bytes in, 4 out per sample), and at batch 1 a latency chain: a workgroup = 128 samples x 8 channel
-// groups; a thread owns POST_OPT consecutive samples of POST_CU channels per pass (one pass for Cin <= 32) and requests
-// all its POST_CU * (POST_OPT + 6) inputs at once through row descriptors (zero padding = range check; neighbouring
-// threads' overlap is served by L1). The weights are wave-uniform scalars. The 8 channel-group partials meet in LDS
-// and are summed in a fixed order. (A first version walked all channels in one thread: 8 dependent memory round
+// HBM-bound (4*Cin bytes in, 4 out per sample), and at batch 1 a latency chain: a workgroup = 256 samples x 4 channel
+// groups (one wave each); a thread owns POST_OPT consecutive samples of POST_CU channels per pass (one pass for
+// Cin <= 32) and requests all its POST_CU * (POST_OPT + 6) inputs at once through row descriptors (zero padding = range
+// check; neighbouring threads' overlap is served by L1). The weights are wave-uniform scalars. The channel-group
+// partials meet in LDS and are summed in a fixed order; one peak atomic per workgroup. (A first version walked all channels in one thread: 8 dependent memory round
 // trips and 104 workgroups for a 4.8 s utterance, 22.9 us; profiles/r02_notes.md.)
-static constexpr int POST_K = 7, POST_OPT = 4, POST_CU = 4, POST_CG = 8, POST_SPB = 256 / POST_CG * POST_OPT;
+static constexpr int POST_K = 7, POST_OPT = 4, POST_CU = 8, POST_CG = 4, POST_SPB = 64 * POST_OPT;
 __global__ __launch_bounds__(256) void conv_post_kernel(const float* x, long x_bs, int x_cs, const float* __restrict__ w,
                                                         int Cin, float slope, const int* lens,
                                                         int len_mul, float* audio, long a_bs,
                                                         unsigned* absmax) {
+  PE_KTRACE(17);
   constexpr int NIN = POST_OPT + POST_K - 1;
   __shared__ float part[POST_CG][POST_SPB];
+  PE_STAMP(4, 0);
   const int b = blockIdx.y, L = lens[b] * len_mul;
   if (blockIdx.x * POST_SPB >= L) return;
-  const int sg = threadIdx.x & 31, cg = PE_UNIFORM(threadIdx.x >> 5) ;
+  const int sg = threadIdx.x & 63, cg = PE_UNIFORM(threadIdx.x >> 6);
   const int t0 = blockIdx.x * POST_SPB + sg * POST_OPT;
   const float* xb = x + (long)b * x_bs;
   float acc[POST_OPT];
@@ -2009,8 +2024,10 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* x, long x_b
   }
 #pragma unroll
   for (int o = 0; o < POST_OPT; ++o) part[cg][sg * POST_OPT + o] = acc[o];
+  __shared__ float wmax[4];
+  PE_STAMP(4, 1);
   __syncthreads();
-  if (threadIdx.x >= POST_SPB) return;             // waves 0 and 1 finish the 128 samples
+  PE_STAMP(4, 2);
   const int t = blockIdx.x * POST_SPB + threadIdx.x;
   float sum = 0.f;
 #pragma unroll
@@ -2022,12 +2039,18 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* x, long x_b
     m = fabsf(y);
   }
   for (int o = 32; o >= 1; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-  if ((threadIdx.x & 63) == 0) atomicMax(absmax + b, __float_as_uint(m));
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  PE_STAMP(4, 3);
+  __syncthreads();
+  if (threadIdx.x == 0)
+    atomicMax(absmax + b, __float_as_uint(fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]))));
+  PE_STAMP(4, 4);
 }
 
 // float -> int16 exactly as piper.cpp:420-431 (scale 32767/max(0.01,peak), clamp, truncate)
 __global__ void pcm16_kernel(const float* audio, long a_bs, const unsigned* absmax, const int* lens,
                              int len_mul, short* pcm, long p_bs) {
+  PE_KTRACE(18);
   const int b = blockIdx.y, L = lens[b] * len_mul;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= L) return;
@@ -2089,6 +2112,7 @@ struct MrfP {
 
 template <int CP, int NT, int NW, int WS>
 __global__ __launch_bounds__(64 * NW, 2) void mrf_fused_kernel(MrfP p) {
+  PE_KTRACE(20);
   constexpr int N = NT * 32, MTL = CP / 32, NCH = CP / KC;
   constexpr int FU = (NT * MTL + NW - 1) / NW;     // output tiles owned by one wave
   constexpr int RG = 4, NCC = WS / 64;             // staging: rows per register batch, 64-column groups per row

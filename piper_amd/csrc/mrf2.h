@@ -60,6 +60,7 @@ struct Mrf2P {
 // NWR = float4 per thread per weight segment (ring half = NWR * 16 KiB at 16 waves).
 template <int CP, int NW, int MSW, int OU, int HU, int WS, int NWR>
 __global__ __launch_bounds__(64 * NW) void mrf2_kernel(Mrf2P p) {
+  PE_KTRACE(19);
   constexpr int MS = CP / 16, NRG = MS / MSW, NCG = NW / NRG, NT = 64 * NW, UPW = OU + HU;
   constexpr int RINGF = 4 * NT * NWR;              // floats per ring half
   constexpr int MAXPH = 24, MAXSEG = 64;           // table capacities (engine.cpp: build_mrf2 checks them)

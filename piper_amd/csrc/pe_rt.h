@@ -22,6 +22,7 @@ inline void pe_spin_pause() { emu::yield(); }
 inline void pe_drain_stores() {}
 #define PE_DYN_SMEM(type, name) type* name = reinterpret_cast<type*>(emu::dyn_smem)
 #define PE_STAMP(k, i) ((void)0)
+#define PE_KTRACE(id) ((void)0)
 #define pe_mfma_32x32x2(a, b, c) emu_mfma_32x32x2((a), (b), (c))
 #define pe_mfma_16x16x4(a, b, c) emu_mfma_16x16x4((a), (b), (c))
 #define PE_WAVE_SYNC() emu::wave_sync()
@@ -65,8 +66,33 @@ inline float pe_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 static __device__ long long pe_stamps[PE_NSTAMP_K][PE_NSTAMP_I];   // one copy per translation unit; engine.cpp (kernels + reader) uses its own
 #define PE_STAMP(k, i) \
   do { if ((threadIdx.x | blockIdx.x | blockIdx.y | blockIdx.z) == 0) pe_stamps[k][i] = (long long)wall_clock64(); } while (0)
+// per-launch trace: workgroup (0,0,0) of EVERY launch takes the next slot and records kernel id, wall clock at entry and
+// at exit (RAII: every return path) and the shader clock at both ends (clock frequency = d clock / d wall)
+#define PE_NTRACE 2048
+static __device__ unsigned pe_trace_seq;
+static __device__ long long pe_trace[PE_NTRACE][5];
+struct PeTrace {
+  int slot;
+  __device__ __forceinline__ explicit PeTrace(int id) : slot(-1) {
+    if ((threadIdx.x | blockIdx.x | blockIdx.y | blockIdx.z) == 0) {
+      slot = (int)(atomicAdd(&pe_trace_seq, 1u) % PE_NTRACE);
+      pe_trace[slot][0] = id;
+      pe_trace[slot][2] = 0;
+      pe_trace[slot][3] = (long long)clock64();
+      pe_trace[slot][1] = (long long)wall_clock64();
+    }
+  }
+  __device__ __forceinline__ ~PeTrace() {
+    if (slot >= 0) {
+      pe_trace[slot][2] = (long long)wall_clock64();
+      pe_trace[slot][4] = (long long)clock64();
+    }
+  }
+};
+#define PE_KTRACE(id) PeTrace pe_ktrace_obj(id)
 #else
 #define PE_STAMP(k, i) do {} while (0)
+#define PE_KTRACE(id) do {} while (0)
 #endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
