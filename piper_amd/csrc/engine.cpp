@@ -487,7 +487,9 @@ void Engine::init(const WeightSet& ws) {
                          (const void*)conv_splitk_kernel<2, true, 12, 2>, (const void*)conv_splitk_kernel<1, false, 12, 4>,
                          (const void*)conv_splitk16_kernel<true, 12, 2>, (const void*)conv_splitk16_kernel<false, 8, 4>};
     for (const void* k : ks2) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    PE_HIP(hipFuncSetAttribute((const void*)attn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    PE_HIP(hipFuncSetAttribute((const void*)attn_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    PE_HIP(hipFuncSetAttribute((const void*)attn_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    PE_HIP(hipFuncSetAttribute((const void*)attn_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     const void* ks3[] = {(const void*)mrf_fused_kernel<32, 4, 4, 256>, (const void*)mrf_fused_kernel<32, 4, 4, 320>,
                          (const void*)mrf_fused_kernel<32, 4, 4, 384>, (const void*)mrf_fused_kernel<32, 4, 8, 256>,
                          (const void*)mrf_fused_kernel<32, 4, 8, 320>, (const void*)mrf_fused_kernel<32, 4, 8, 384>,
@@ -1184,12 +1186,13 @@ void Engine::dds(const DdsW& d, View in, View out, View tmp, const DdsOpt* opt) 
   std::vector<DdsP> list;
   dds_params(d, in, out, tmp, opt, list);
   for (const DdsP& p : list) {
-    const int kh = kbegin(prof_level_ >= 2 ? krow(p.nchunks <= 3 ? "dds_layer16_kernel<3>" : p.nchunks <= 6 ? "dds_layer16_kernel<6>"
+    const int kh = kbegin(prof_level_ >= 2 ? krow(p.nchunks == 3 ? "dds_layer16_kernel<3>" : p.nchunks == 6 ? "dds_layer16_kernel<6>"
                                                                                        : "dds_layer16_kernel<8>") : 0, 0.0);
     const dim3 grid16((Tg_ + 15) / 16, B_);
     const size_t smem16 = ((size_t)2 * p.nchunks * 32 * 16 + 8 * 16) * sizeof(float);
-    if (p.nchunks <= 3) PE_LAUNCH(dds_layer16_kernel<3>, grid16, dim3(512), smem16, stream_, p);
-    else if (p.nchunks <= 6) PE_LAUNCH(dds_layer16_kernel<6>, grid16, dim3(512), smem16, stream_, p);
+    // <3> / <6> are compiled for exactly 96 / 192 padded channels; <8> takes any width up to 256
+    if (p.nchunks == 3) PE_LAUNCH(dds_layer16_kernel<3>, grid16, dim3(512), smem16, stream_, p);
+    else if (p.nchunks == 6) PE_LAUNCH(dds_layer16_kernel<6>, grid16, dim3(512), smem16, stream_, p);
     else PE_LAUNCH(dds_layer16_kernel<8>, grid16, dim3(512), smem16, stream_, p);
     kend(kh);
   }
@@ -1390,8 +1393,11 @@ void Engine::issue_stage_a() {
     if (smem > 160 * 1024) throw std::runtime_error("utterance too long for the attention score tile");
     double afl = 0;
     for (int b = 0; b < B; ++b) afl += 4.0 * (double)tlens_h_[b] * tlens_h_[b] * H_;
-    const int kh = kbegin(prof_level_ >= 2 ? krow("attn_kernel") : 0, afl);
-    PE_LAUNCH(attn_kernel, dim3((T + ATT_QB - 1) / ATT_QB, nh_, B), dim3(256), smem, stream_, ap);
+    const int kh = kbegin(prof_level_ >= 2 ? krow(ap.dk == 96 ? "attn_kernel<96>" : ap.dk == 48 ? "attn_kernel<48>" : "attn_kernel<0>") : 0, afl);
+    const dim3 agrid((T + ATT_QB - 1) / ATT_QB, nh_, B);
+    if (ap.dk == 96) PE_LAUNCH(attn_kernel<96>, agrid, dim3(256), smem, stream_, ap);
+    else if (ap.dk == 48) PE_LAUNCH(attn_kernel<48>, agrid, dim3(256), smem, stream_, ap);
+    else PE_LAUNCH(attn_kernel<0>, agrid, dim3(256), smem, stream_, ap);
     kend(kh);
     const bool chain_o = !fold1 && use_colchain(tsum, H_);
     if (chain_o) {
@@ -1504,10 +1510,10 @@ void Engine::issue_stage_a() {
       const int nch = chain[0].nchunks;
       const size_t smem = ((size_t)2 * nch * 32 * 16 + 8 * 16 + 16) * sizeof(float) + 2048;
       const dim3 grid((T + 15) / 16, B);
-      const char* nm = nch <= 3 ? "dp_persist_kernel<3>" : nch <= 6 ? "dp_persist_kernel<6>" : "dp_persist_kernel<8>";
+      const char* nm = nch == 3 ? "dp_persist_kernel<3>" : nch == 6 ? "dp_persist_kernel<6>" : "dp_persist_kernel<8>";
       const int kh = kbegin(prof_level_ >= 2 ? krow(nm) : 0, 0.0);
-      if (nch <= 3) PE_LAUNCH_COOP(dp_persist_kernel<3>, grid, dim3(512), smem, stream_, pp);
-      else if (nch <= 6) PE_LAUNCH_COOP(dp_persist_kernel<6>, grid, dim3(512), smem, stream_, pp);
+      if (nch == 3) PE_LAUNCH_COOP(dp_persist_kernel<3>, grid, dim3(512), smem, stream_, pp);
+      else if (nch == 6) PE_LAUNCH_COOP(dp_persist_kernel<6>, grid, dim3(512), smem, stream_, pp);
       else PE_LAUNCH_COOP(dp_persist_kernel<8>, grid, dim3(512), smem, stream_, pp);
       kend(kh);
     } else {

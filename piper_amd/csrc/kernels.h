@@ -854,7 +854,12 @@ static constexpr int ATT_MAXDK = 128;
 //   3. O^T = V P^T on the MFMAs (V chunk transposed through LDS so the A fragment is contiguous; P read
 //      from the score slab with an odd stride), wave w owns channel tiles w, w+4, ...; banded
 //      relative-value term added before the coalesced store.
+// DKT: channels per head known at compile time (96 for the 192-channel voices, 48 for x-low): every unrolled loop has its
+// exact trip count. DKT = 0: any even dk <= ATT_MAXDK, loops sized for the maximum and guarded per step (on the common
+// shapes those guards were ~190 scalar branches per workgroup, a third of the kernel's time).
+template <int DKT>
 __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
+  constexpr int MAXDK = DKT ? DKT : ATT_MAXDK;
   PE_KTRACE(0);
   PE_DYN_SMEM(float, sm);
   PE_STAMP(0, 0);
@@ -862,7 +867,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
   const int T = p.lens[b];
   if (i0 >= T) return;
   PE_STAMP(0, 1);
-  const int dk = p.dk, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int dk = DKT ? DKT : p.dk, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
   const int SP = p.SP, VS = dk + 1 + (dk & 1);       // odd strides -> conflict-free column reads
   float* S = sm;                                      // [32][SP]
@@ -881,7 +886,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
   // all global reads go through buffer descriptors with index -1 for masked elements (hardware returns 0), so
   // each staging step issues its loads back to back: one memory latency per step instead of one per element
   const pe_rowsrc qd = pe_make_row(qb, dk * p.q_cs), kd = pe_make_row(kb, dk * p.q_cs), vd = pe_make_row(vb, dk * p.q_cs);
-  constexpr int NKF = ATT_MAXDK / 2;
+  constexpr int NKF = MAXDK / 2;
   float kf[NKF];
   auto load_k = [&](int kt) {
     // one per-lane base (channel parity, key) + a wave-uniform 2*u*stride in an SGPR: no VALU per load; rows
@@ -895,19 +900,19 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
   // first key tile, the first V chunk, then Q and the relative-position tables -- one memory latency instead of three
   // serialised ones (the barriers below wait for all of them anyway).
   // V chunk staging: thread -> key jj = tid&63, channel group tid>>6
-  float vv[ATT_MAXDK / 32][8];
+  float vv[(MAXDK + 31) / 32][8];
   auto load_v = [&](int j0) {
     const int jj = tid & 63;
     const int base = (j0 + jj < T) ? (tid >> 6) * 8 * p.q_cs + j0 + jj : 0x3fffffff;   // rows >= dk read 0
 #pragma unroll
-    for (int g = 0; g < ATT_MAXDK / 32; ++g)
+    for (int g = 0; g < (MAXDK + 31) / 32; ++g)
 #pragma unroll
       for (int u = 0; u < 8; ++u) vv[g][u] = pe_row_load_so(vd, base, (32 * g + u) * p.q_cs);
   };
   auto store_v = [&]() {
     const int jj = tid & 63;
 #pragma unroll
-    for (int g = 0; g < ATT_MAXDK / 32; ++g)
+    for (int g = 0; g < (MAXDK + 31) / 32; ++g)
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int d = (tid >> 6) * 8 + 32 * g + u;
@@ -917,7 +922,7 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
   load_k(wv);
   load_v(0);
   {
-    constexpr int NQ = ATT_MAXDK * ATT_QB / 256;     // 16 elements per thread at dk = 128
+    constexpr int NQ = MAXDK * ATT_QB / 256;     // 16 elements per thread at dk = 128
     float qv[NQ];
 #pragma unroll
     for (int u = 0; u < NQ; ++u) {
@@ -1337,11 +1342,14 @@ struct DdsP {
 // blocks are requested up front (one memory latency per pair, 2 * NQMAX float4 per lane), the B fragments are read from
 // LDS once for both, and the two accumulator chains alternate on the MFMA pipe instead of each waiting on itself.
 // k ascends inside and across the instructions of a tile exactly as in a one-tile-at-a-time loop: same fmaf chain.
-template <int NQMAX, class Sink>
-__device__ __forceinline__ void col_gemm16(const float* wp16, const float* bias, int nbias, int rows, int Kp,
+// EXACT: Kp == 16 * NQMAX is known at compile time (no per-step guards in the unrolled loops: on the common shapes the
+// guards were a scalar branch per LDS read, ~200 per launch).
+template <int NQMAX, bool EXACT, class Sink>
+__device__ __forceinline__ void col_gemm16(const float* wp16, const float* bias, int nbias, int rows, int Kp_rt,
                                            const float* IN, int wv, int lane, Sink&& sink) {
   constexpr int NC = 16;
   const int l15 = lane & 15, lq = lane >> 4;
+  const int Kp = EXACT ? 16 * NQMAX : Kp_rt;
   const int nq = Kp / 16, ntile = (rows + 15) / 16, tile_floats = nq * 256;
   const pe_rowsrc biasd = pe_make_row(bias ? bias : wp16, bias ? nbias : 0);
   for (int mt = wv; mt < ntile; mt += 16) {
@@ -1409,7 +1417,8 @@ __device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b
   PE_STAMP(2, 1);
   auto ldx = [&](const pe_rowsrc& r, int idx) { return SC1 ? pe_row_load_sc1(r, idx) : pe_row_load(r, idx); };
   auto stg = [&](float* q, float v) { if (SC1) pe_st_sc1(q, v); else *q = v; };
-  const int H = p.H, Hp = p.nchunks * 32;
+  // NVT = 3 / 6: instantiated for exactly Hp = 32 * NVT (the launcher checks); NVT = 8 is the generic form (any Hp <= 256)
+  const int H = p.H, Hp = NVT != 8 ? 32 * NVT : p.nchunks * 32;
   float* Y = sm;
   float* Z = Y + Hp * NC;
   float* red = Z + Hp * NC;
@@ -1514,7 +1523,7 @@ __device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b
 
   // ---- phase 2: Z = W1x1 . Y + bias on 16x16x4 MFMAs (col_gemm16: tiles w and w+8 of a wave run as a pair)
   PE_STAMP(2, 4);
-  col_gemm16<2 * NVT>(p.wp16, p.bias, H, Hp, Hp, Y, wv, lane, [&](int row, int cc, float val) { Z[row * NC + cc] = val; });
+  col_gemm16<2 * NVT, NVT != 8>(p.wp16, p.bias, H, Hp, Hp, Y, wv, lane, [&](int row, int cc, float val) { Z[row * NC + cc] = val; });
   PE_STAMP(2, 5);
   __syncthreads();
   PE_STAMP(2, 6);
@@ -1550,7 +1559,7 @@ __device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b
     if (c < Hp) Y[c * NC + col] = (c < H && ok) ? xc[k] + gelu_erf((v[k] - mean) * rstd * gg[k] + bb[k]) : 0.f;
   }
   __syncthreads();
-  col_gemm16<2 * NVT>(p.post_w16, p.post_bias, p.post_rows, p.post_rows, Hp, Y, wv, lane,
+  col_gemm16<2 * NVT, NVT != 8>(p.post_w16, p.post_bias, p.post_rows, p.post_rows, Hp, Y, wv, lane,
                       [&](int row, int cc, float val) { Z[row * NC + cc] = val; });
   __syncthreads();
   if (p.post_out && ok) {
@@ -1671,7 +1680,10 @@ __global__ __launch_bounds__(512) void colchain_kernel(ColP p) {
   PE_STAMP(p.mode == 0 ? 3 : (p.w2 ? 6 : 7), 2);
   __syncthreads();
   PE_STAMP(p.mode == 0 ? 3 : (p.w2 ? 6 : 7), 3);
-  col_gemm16<2 * NVT>(p.w1, p.b1, p.rows1, p.rows1, K1p, IN, wv, lane, [&](int row, int cc, float v) { Z[row * NC + cc] = v; });
+  if (K1p == 32 * NVT)
+    col_gemm16<2 * NVT, true>(p.w1, p.b1, p.rows1, p.rows1, K1p, IN, wv, lane, [&](int row, int cc, float v) { Z[row * NC + cc] = v; });
+  else
+    col_gemm16<2 * NVT, false>(p.w1, p.b1, p.rows1, p.rows1, K1p, IN, wv, lane, [&](int row, int cc, float v) { Z[row * NC + cc] = v; });
   PE_STAMP(p.mode == 0 ? 3 : (p.w2 ? 6 : 7), 4);
   __syncthreads();
   PE_STAMP(p.mode == 0 ? 3 : (p.w2 ? 6 : 7), 5);
@@ -1729,9 +1741,11 @@ __global__ __launch_bounds__(512) void colchain_kernel(ColP p) {
     __syncthreads();
     PE_STAMP(p.mode == 0 ? 3 : (p.w2 ? 6 : 7), 7);
     float* o2 = p.out2 + (long)b * p.o2_bs;
-    col_gemm16<2 * NVT>(p.w2, p.b2, p.rows2, p.rows2, K2p, IN, wv, lane, [&](int row, int cc, float v) {
+    auto st2 = [&](int row, int cc, float v) {
       if (row < p.rows2 && t0 + cc < L) o2[(long)row * p.o2_cs + t0 + cc] = v;
-    });
+    };
+    if (K2p == 16 * NVT) col_gemm16<NVT, true>(p.w2, p.b2, p.rows2, p.rows2, K2p, IN, wv, lane, st2);   // half the channels
+    else col_gemm16<2 * NVT, false>(p.w2, p.b2, p.rows2, p.rows2, K2p, IN, wv, lane, st2);
     PE_STAMP(p.mode == 0 ? 3 : (p.w2 ? 6 : 7), 8);
   }
 }
