@@ -487,6 +487,8 @@ void Engine::init(const WeightSet& ws) {
                          (const void*)conv_splitk_kernel<2, true, 12, 2>, (const void*)conv_splitk_kernel<1, false, 12, 4>,
                          (const void*)conv_splitk16_kernel<true, 12, 2>, (const void*)conv_splitk16_kernel<false, 8, 4>};
     for (const void* k : ks2) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    PE_HIP(hipFuncSetAttribute((const void*)conv_splitk_group_kernel<8, 4, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    PE_HIP(hipFuncSetAttribute((const void*)conv_splitk_group_kernel<8, 4, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     PE_HIP(hipFuncSetAttribute((const void*)attn_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     PE_HIP(hipFuncSetAttribute((const void*)attn_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     PE_HIP(hipFuncSetAttribute((const void*)attn_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
@@ -511,6 +513,7 @@ void Engine::init(const WeightSet& ws) {
   if (const char* t = getenv("PIPER_HIP_WIDE_MIN")) wide_min_blocks_ = atol(t);
   if (const char* t = getenv("PIPER_HIP_SMALL")) small_tiles_ = atoi(t) != 0;
   if (const char* t = getenv("PIPER_HIP_PAR_MRF")) par_mrf_ = atoi(t) != 0;
+  if (const char* t = getenv("PIPER_HIP_GROUP_MRF")) group_mrf_ = atoi(t);
   if (const char* t = getenv("PIPER_HIP_FUSE_MRF")) fuse_mrf_ = atoi(t) != 0;   // A/B knob: 1 = fused MRF stage kernel
   if (const char* t = getenv("PIPER_HIP_SPLITK_MAX")) splitk_max_blocks_ = atol(t);   // tuning knob
   if (const char* t = getenv("PIPER_HIP_SPLITK16")) splitk16_ = atoi(t);              // A/B knob
@@ -677,8 +680,10 @@ void Engine::ensure_stage_b(int Fmax) {
   carve(wsB_);
   // per-branch buffers of the parallel MRF schedule (only used while a stage is small): allocated here,
   // outside any graph capture
-  const size_t want = std::min<size_t>(Bc * hmax, ((size_t)64 << 20) / sizeof(float));
-  if (par_mrf_ && side_floats_ < want) {
+  // (the grouped schedule only applies below 700 64x64 blocks per stage: 700 * 4096 floats bound its buffers)
+  const size_t want = par_mrf_ ? std::min<size_t>(Bc * hmax, ((size_t)64 << 20) / sizeof(float))
+                               : std::min<size_t>(Bc * hmax, (size_t)700 * 4096);
+  if ((par_mrf_ || group_mrf_) && side_floats_ < want) {
     PE_HIP(hipStreamSynchronize(stream_));
     drop_graphs();
     for (float*& sp : side_) { if (sp) PE_HIP(hipFree(sp)); sp = nullptr; }
@@ -690,6 +695,42 @@ void Engine::ensure_stage_b(int Fmax) {
 // ------------------------------------------------------------------------------------------------
 // launch helpers
 // ------------------------------------------------------------------------------------------------
+
+// A conv that may ride in a grouped split-K launch: few enough column tiles that the launch is latency- rather than
+// throughput-bound, and a halo the 128-column slab covers.
+bool Engine::can_group(const PackedConv& pc, int ncols) const {
+  const long blocks = (long)((ncols + CFG_BN[pc.cfg] - 1) / CFG_BN[pc.cfg]) * (pc.mtiles * 32 / CFG_BM[pc.cfg]) * B_;
+  return !pc.gate && !pc.up && blocks < splitk_max_blocks_ && (pc.ntaps - 1) * pc.dil <= 96;
+}
+void Engine::group_begin() {
+  grouping_ = true;
+  group_.clear();
+  group_flops_ = group_bytes_ = 0;
+}
+void Engine::group_end() {
+  grouping_ = false;
+  if (group_.empty()) return;
+  ConvG g{};
+  int halo = 0, mt = 0;
+  for (size_t i = 0; i < group_.size(); ++i) {
+    g.c[i] = group_[i];
+    halo = std::max(halo, group_[i].xhalo);
+    mt = std::max(mt, (group_[i].rows + 31) / 32);
+  }
+  g.n = (int)group_.size();
+  g.B = B_;
+  constexpr int NW = 8;
+  const bool wide = halo > 32;
+  const int XW = wide ? 128 : 64;
+  const size_t smem = std::max<size_t>((size_t)NW * KC * XW, (size_t)NW * 16 * 64) * sizeof(float);
+  const dim3 grid((group_ncols_ + 31) / 32, mt, g.n * B_);
+  const int kh = kbegin(prof_level_ >= 2 ? krow(wide ? "conv_splitk_group_kernel<8,4,128>" : "conv_splitk_group_kernel<8,4,64>") : 0,
+                        group_flops_, group_bytes_);
+  if (wide) PE_LAUNCH((conv_splitk_group_kernel<8, 4, 128>), grid, dim3(64 * NW), smem, ls_, g);
+  else PE_LAUNCH((conv_splitk_group_kernel<8, 4, 64>), grid, dim3(64 * NW), smem, ls_, g);
+  kend(kh);
+  group_.clear();
+}
 
 // Which kernel family a conv launch goes to (the policy conv() applies).
 int Engine::route(const PackedConv& pc, int ncols, int epi) const {
@@ -757,6 +798,17 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
   }
   const long blocks = (long)((ncols + CFG_BN[cfg] - 1) / CFG_BN[cfg]) * (pc.mtiles * 32 / CFG_BM[cfg]) * B_;
   if (ln_in && route(pc, ncols, epi) != ROUTE_SPLITK) throw std::runtime_error("internal: LayerNorm-in on a non split-K launch");
+  if (grouping_) {
+    if (!can_group(pc, ncols) || epi == EPI_CONVT || epi == EPI_GATE || ln_in || group_.size() >= 3 ||
+        (!group_.empty() && group_ncols_ != ncols))
+      throw std::runtime_error("internal: conv does not fit a grouped launch");
+    p.tgroups = pc.nchunks <= 4 ? 2 : 1;          // 8 waves: <= 4 chunk lanes leave room to split the taps
+    group_.push_back(p);
+    group_ncols_ = ncols;
+    group_flops_ += kflops;
+    group_bytes_ += kbytes;
+    return;
+  }
   if (blocks < splitk_max_blocks_ && p.xhalo <= 32) {
     // few columns (one utterance through encoder / duration predictor / flow): split K across the waves
     const int MT = pc.gate ? 2 : 1;
@@ -1688,6 +1740,11 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
       const size_t need = (size_t)B * st.ch * Ls;
       const long blocks64 = (long)((Lmax + 63) / 64) * ((st.ch + 63) / 64) * B;
       const bool par = par_mrf_ && !prof_on_ && nk >= 2 && nk <= 3 && blocks64 < 700 && need <= side_floats_;
+      bool grp = group_mrf_ && nk >= 2 && nk <= 3 && blocks64 < 700 && need <= side_floats_;
+      for (auto& cv : st.rb) {
+        if (cv.size() != st.rb[0].size()) grp = false;
+        for (auto& c : cv) grp = grp && can_group(c, Lmax);
+      }
       // One launch per stage wins while the stage is latency-bound (a few utterances: 6 launches of one wave
       // generation each); from ~3 utterances up the conv-by-conv schedule fills the chip and its GEMM kernel is the
       // faster one (profiles/r02_mrf2_ab.txt), so the choice goes by the frames in the batch.
@@ -1699,6 +1756,32 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
         mrf(st, u, xs, lens, mult, Lmax);
         for (auto& cv : st.rb)
           for (auto& c : cv) fl += 2.0 * fsum * mult * c.macs_per_col;
+      } else if (grp) {
+        // step d of every resblock in one grouped launch; each resblock keeps its own buffers, one pass sums them
+        auto SV = [&](int k) { return View{side_[k], (long)st.ch * Ls, (int)Ls}; };
+        View xin[3] = {u, u, u};
+        const int nsteps = (int)st.rb[0].size();
+        const bool rb1 = arch_[A_RESBLOCK] == 1;
+        for (int d = 0; d < nsteps; ++d) {
+          group_begin();
+          for (int j = 0; j < nk; ++j) {
+            auto& cv = st.rb[j];
+            const View t0 = j == 0 ? tb : SV(4 * (j - 1)), t1 = j == 0 ? ta : SV(4 * (j - 1) + 1),
+                       t2 = j == 0 ? tc : SV(4 * (j - 1) + 2), dst = j == 0 ? SV(8) : SV(4 * (j - 1) + 3);
+            if (rb1 && !(d & 1)) {
+              conv(cv[d], xin[j], t0, lens, mult, Lmax, EPI_STORE, 0.1f);
+            } else {
+              const int dd = rb1 ? d / 2 : d, nd = rb1 ? nsteps / 2 : nsteps;
+              const View o = dd < nd - 1 ? ((dd & 1) ? t2 : t1) : dst;
+              conv(cv[d], rb1 ? t0 : xin[j], o, lens, mult, Lmax, EPI_RESADD, 0.1f, ACT_NONE, xin[j]);
+              xin[j] = o;
+            }
+            fl += 2.0 * fsum * mult * cv[d].macs_per_col;
+          }
+          group_end();
+        }
+        PE_LAUNCH(mrf_sum_kernel, dim3((Lmax + 255) / 256, st.ch, B), dim3(256), 0, stream_, side_[8], side_[3],
+                  nk == 3 ? side_[7] : (const float*)nullptr, xs.p, xs.bs, xs.cs, lens, mult, inv_nk);
       } else if (par) {
         auto SV = [&](int k) { return View{side_[k], (long)st.ch * Ls, (int)Ls}; };
         PE_HIP(hipEventRecord(ev_fork_, stream_));

@@ -135,6 +135,16 @@ class Engine {
             float in_slope = 1.f, int act = 0, View res = View{nullptr, 0, 0},
             View out2 = View{nullptr, 0, 0}, int mode = 0, float alpha = 1.f, const float* bias2 = nullptr,
             int bias2_bs = 0);
+  // Grouped launches (conv_splitk_group_kernel): between group_begin() and group_end() conv() records the launch instead
+  // of issuing it; group_end() issues all of them (<= 3 independent convs of one launch shape) as one launch.
+  bool grouping_ = false;
+  std::vector<struct ConvP> group_;
+  double group_flops_ = 0, group_bytes_ = 0;
+  int group_ncols_ = 0;
+  bool can_group(const PackedConv& pc, int ncols) const;
+  void group_begin();
+  void group_end();
+  int group_mrf_ = 1;                        // PIPER_HIP_GROUP_MRF=0: sibling resblock convs one launch each (A/B, tests)
   // LayerNorm folded into the next conv() call's input staging (split-K launches only; see can_fold_ln)
   struct LnIn { const float* g = nullptr; const float* b = nullptr; View out{nullptr, 0, 0}; };
   LnIn ln_in_;

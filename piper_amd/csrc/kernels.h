@@ -385,14 +385,14 @@ void conv_mfma_kernel(ConvP p) {
 //     unconditionally (past the end the descriptor returns zeros) so that the wait counts stay exact and a
 //     wave with <= D steps has its whole K range in flight at once;
 //   * partial tiles are summed through LDS in a fixed order (deterministic).
-template <int MT, bool GATE, int NW, int D>
-__global__ __launch_bounds__(64 * NW) void conv_splitk_kernel(ConvP p) {
-  PE_KTRACE(1);
-  constexpr int BN = 32, XW = 64, KH = KC / 2;
+// XW: columns of a wave's x slab: 64 (halo (taps-1)*dil <= 32), or 128 for the long-dilation resblock convs that are
+// launched in a group with their siblings (halo <= 96).
+template <int MT, bool GATE, int NW, int D, int XW>
+__device__ __forceinline__ void conv_splitk_body(const ConvP& p, const int b, float* sm) {
+  constexpr int BN = 32, KH = KC / 2, XB = XW / 64;
   constexpr int NS = GATE ? (16 + NW - 1) / NW : (MT * 16 + NW - 1) / NW;    // epilogue slots per wave
-  PE_DYN_SMEM(float, sm);                         // NW x [KC][XW] slabs, then NW x [MT*16][64] partial tiles
+  // sm: NW x [KC][XW] slabs, then NW x [MT*16][64] partial tiles
   PE_STAMP(1, 0);
-  const int b = blockIdx.z;
   // The utterance length lives in device memory (one graph per shape bucket). Nothing below touches it until the
   // x slab and the first weight fragments are requested, so its latency overlaps theirs instead of preceding them.
   const int L = p.lens[b] * p.len_mul;
@@ -406,7 +406,7 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk_kernel(ConvP p) {
   const float* xb = p.x + (long)b * p.x_bs;
   const float slope = p.in_slope;
   const pe_rowsrc wsrc = pe_make_row(p.wp + (long)mtile0 * wstride_mt, MT * wstride_mt);
-  float* xw = sm + wv * KC * XW;                  // this wave's slab: 32 channels x 64 columns
+  float* xw = sm + wv * KC * XW;                  // this wave's slab: 32 channels x XW columns
   // K is dealt to the waves as (chunk lane, tap group): with p.tgroups == 1 wave w takes chunks w, w+NW, ...
   // and every tap; with 2 groups the waves form two halves that share the chunks and split the taps (a 5-tap
   // conv with 6 chunks then keeps 12 waves busy with 3 / 2 steps each instead of 6 waves with 5)
@@ -420,21 +420,28 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk_kernel(ConvP p) {
 
   // x slab: one descriptor over the utterance's [Cin][stride] tensor, a per-lane column offset (poisoned outside
   // the row) and a wave-uniform row offset -- independent of L; columns >= L are zeroed when the slab is stored
-  float xr[KC];
+  float xr[XB][KC];
   const pe_rowsrc xd = pe_make_row(xb, p.Cin * p.x_cs);
   const int xcol = n0 - p.padl + lane;
-  const int xoff = (xcol >= 0 && xcol < p.x_cs) ? xcol : 0x3fffffff;
+  int xoff[XB];
+#pragma unroll
+  for (int h = 0; h < XB; ++h) xoff[h] = (xcol + 64 * h >= 0 && xcol + 64 * h < p.x_cs) ? xcol + 64 * h : 0x3fffffff;
   auto load_x = [&](int c) {
 #pragma unroll
-    for (int r = 0; r < KC; ++r) xr[r] = pe_row_load_so(xd, xoff, (c * KC + r) * p.x_cs);
+    for (int h = 0; h < XB; ++h)
+#pragma unroll
+      for (int r = 0; r < KC; ++r) xr[h][r] = pe_row_load_so(xd, xoff[h], (c * KC + r) * p.x_cs);
   };
   auto store_x = [&]() {
-    const bool live = xcol < L;
 #pragma unroll
-    for (int r = 0; r < KC; ++r) {
-      float v = live ? xr[r] : 0.f;
-      v = v > 0.f ? v : v * slope;
-      xw[r * XW + lane] = v;
+    for (int h = 0; h < XB; ++h) {
+      const bool live = xcol + 64 * h < L;
+#pragma unroll
+      for (int r = 0; r < KC; ++r) {
+        float v = live ? xr[h][r] : 0.f;
+        v = v > 0.f ? v : v * slope;
+        xw[r * XW + 64 * h + lane] = v;
+      }
     }
   };
   // weight ring: slot d holds the fragments of step (s with s % D == d); the load cursor runs D steps ahead
@@ -466,7 +473,7 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk_kernel(ConvP p) {
   if (n0 >= ncols) return;
   PE_STAMP(1, 1);
   const EpiFlags ef = epi_flags(p);
-  if (!GATE && p.ln_g) {
+  if (!GATE && XW == 64 && p.ln_g) {
     // LayerNorm of the staged columns over ALL input channels: every wave holds one 32-channel chunk of the same 64
     // columns (lane = column); two fixed-order cross-wave sums (mean, then centred second moment, like ln_kernel).
     float* red1 = sm + NW * (KC * XW > MT * 16 * 64 ? KC * XW : MT * 16 * 64);     // behind the slabs / partial tiles
@@ -475,7 +482,7 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk_kernel(ConvP p) {
     const int c0 = wi * KC;
     float s1 = 0.f;
 #pragma unroll
-    for (int r = 0; r < KC; ++r) s1 += (mine && c0 + r < p.Cin) ? xr[r] : 0.f;
+    for (int r = 0; r < KC; ++r) s1 += (mine && c0 + r < p.Cin) ? xr[0][r] : 0.f;
     red1[wv * 64 + lane] = s1;
     __syncthreads();
     float tot = 0.f;
@@ -485,7 +492,7 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk_kernel(ConvP p) {
     float s2 = 0.f;
 #pragma unroll
     for (int r = 0; r < KC; ++r) {
-      const float dlt = xr[r] - mean;
+      const float dlt = xr[0][r] - mean;
       s2 += (mine && c0 + r < p.Cin) ? dlt * dlt : 0.f;
     }
     red2[wv * 64 + lane] = s2;
@@ -501,8 +508,8 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk_kernel(ConvP p) {
       const int ci = c0 + r;
       const bool cv = mine && ci < p.Cin;
       const float g = cv ? p.ln_g[ci] : 0.f, be = cv ? p.ln_b[ci] : 0.f;      // wave-uniform: scalar loads
-      xr[r] = xcol >= 0 ? (xr[r] - mean) * rstd * g + be : 0.f;       // left halo: zero padding comes AFTER the norm
-      if (wb && cv) ob[(long)ci * p.ln_o_cs] = xr[r];
+      xr[0][r] = xcol >= 0 ? (xr[0][r] - mean) * rstd * g + be : 0.f;       // left halo: zero padding comes AFTER the norm
+      if (wb && cv) ob[(long)ci * p.ln_o_cs] = xr[0][r];
     }
   }
 
@@ -620,6 +627,30 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk_kernel(ConvP p) {
     }
   }
   PE_STAMP(1, 4);
+}
+
+template <int MT, bool GATE, int NW, int D>
+__global__ __launch_bounds__(64 * NW) void conv_splitk_kernel(ConvP p) {
+  PE_KTRACE(1);
+  PE_DYN_SMEM(float, sm);
+  conv_splitk_body<MT, GATE, NW, D, 64>(p, blockIdx.z, sm);
+}
+
+// Up to three INDEPENDENT convs of the same launch shape in one launch (grid.z = group x utterance): the sibling
+// resblocks of an MRF stage read the same input and are each a latency chain of ~10 us on a fraction of the CUs when
+// launched one after the other; together they fill the chip once (models.py:356-363 runs them in a Python loop).
+struct ConvG {
+  ConvP c[3];
+  int n, B;
+};
+template <int NW, int D, int XW>
+__global__ __launch_bounds__(64 * NW) void conv_splitk_group_kernel(ConvG g) {
+  PE_KTRACE(6);
+  PE_DYN_SMEM(float, sm);
+  const int gi = PE_UNIFORM((int)blockIdx.z / g.B);
+  const ConvP& p = g.c[gi];
+  if ((int)blockIdx.y * 32 >= p.rows) return;              // a sibling with fewer row tiles than the grid
+  conv_splitk_body<1, false, NW, D, XW>(p, (int)blockIdx.z - gi * g.B, sm);
 }
 
 // The split-K kernel on 16 output columns with the 16x16x4 f32 MFMA, for launches that are MFMA-pipe bound inside a

@@ -44,7 +44,7 @@ def make_engine(monkeypatch, cfg, w, env=None):
     for k in ("PIPER_HIP_SPLITK_MAX", "PIPER_HIP_SMALL", "PIPER_HIP_WIDE_MIN", "PIPER_HIP_TPB", "PIPER_HIP_SPLITK16",
               "PIPER_HIP_WIDE_SPLITK", "PIPER_HIP_FUSE_MRF", "PIPER_HIP_DEBUG_KEEP", "PIPER_HIP_PAR_MRF",
               "PIPER_HIP_FUSED", "PIPER_HIP_MRF2", "PIPER_HIP_FUSE_DP", "PIPER_HIP_FOLD_LN",
-              "PIPER_HIP_MRF2_MAXF", "PIPER_HIP_PERSIST_DP", "PIPER_HIP_SPEC", "PIPER_HIP_COLCHAIN"):
+              "PIPER_HIP_MRF2_MAXF", "PIPER_HIP_PERSIST_DP", "PIPER_HIP_SPEC", "PIPER_HIP_COLCHAIN", "PIPER_HIP_GROUP_MRF"):
         monkeypatch.delenv(k, raising=False)
     for k, v in (env or {}).items():
         monkeypatch.setenv(k, str(v))
@@ -158,6 +158,10 @@ FORCED = [
     # conv_o + LN and coupling post + next pre as single launches (colchain_kernel): forced on for a batch, and off
     ("medium", [128, 77, 16, 33], {"PIPER_HIP_COLCHAIN": 2}, {"colchain_kernel<6>"}),
     ("medium", [128, 31], {"PIPER_HIP_COLCHAIN": 0}, {"ln_kernel<0>", "conv_splitk_kernel<1,false,4,4>"}),
+    # sibling resblock convs of the 128-channel stage as grouped launches (64- and 128-column slabs), and one by one
+    ("medium", [128, 40], {}, {"conv_splitk_group_kernel<8,4,64>", "conv_splitk_group_kernel<8,4,128>"}),
+    ("high", [40], {}, {"conv_splitk_group_kernel<8,4,64>"}),
+    ("medium", [128], {"PIPER_HIP_GROUP_MRF": 0}, {"conv_splitk_kernel<1,false,4,4>"}),
     # split-K variants: 4/8-wave only (no 16-column form), 12-wave everywhere, 16-column form everywhere
     ("medium", [128], {"PIPER_HIP_SPLITK16": 0, "PIPER_HIP_WIDE_SPLITK": 0},
      {"conv_splitk_kernel<2,true,8,3>", "conv_splitk_kernel<1,false,8,4>", "conv_splitk_kernel<1,false,4,4>"}),
@@ -171,7 +175,7 @@ FORCED = [
 
 
 @pytest.mark.parametrize("preset,lens,env,expect", FORCED,
-                         ids=[f"{p}-B{len(l)}-" + "-".join(f"{k[10:]}{v}" for k, v in e.items()) for p, l, e, _ in FORCED])
+                         ids=[f"{p}-B{len(l)}-" + ("-".join(f"{k[10:]}{v}" for k, v in e.items()) or "default") for p, l, e, _ in FORCED])
 def test_forced_kernel_variants_match_oracle(monkeypatch, preset, lens, env, expect):
     cfg, w = voice(preset)
     eng = make_engine(monkeypatch, cfg, w, env)
