@@ -487,8 +487,8 @@ void Engine::init(const WeightSet& ws) {
                          (const void*)conv_splitk_kernel<2, true, 12, 2>, (const void*)conv_splitk_kernel<1, false, 12, 4>,
                          (const void*)conv_splitk16_kernel<true, 12, 2>, (const void*)conv_splitk16_kernel<false, 8, 4>};
     for (const void* k : ks2) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    PE_HIP(hipFuncSetAttribute((const void*)conv_splitk_group_kernel<8, 4, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    PE_HIP(hipFuncSetAttribute((const void*)conv_splitk_group_kernel<8, 4, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    PE_HIP(hipFuncSetAttribute((const void*)conv_splitk_group_kernel<4, 4, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    PE_HIP(hipFuncSetAttribute((const void*)conv_splitk_group_kernel<4, 4, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     PE_HIP(hipFuncSetAttribute((const void*)attn_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     PE_HIP(hipFuncSetAttribute((const void*)attn_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     PE_HIP(hipFuncSetAttribute((const void*)attn_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
@@ -719,15 +719,17 @@ void Engine::group_end() {
   }
   g.n = (int)group_.size();
   g.B = B_;
-  constexpr int NW = 8;
+  // 4 waves per workgroup: 32 / 64 KB of slabs, so 5 / 2 workgroups share a CU and the <= 3 x ~420 workgroups of a
+  // group run in one or two rounds (8 waves: 64 / 128 KB, five rounds, slower than one launch per conv)
+  constexpr int NW = 4;
   const bool wide = halo > 32;
   const int XW = wide ? 128 : 64;
   const size_t smem = std::max<size_t>((size_t)NW * KC * XW, (size_t)NW * 16 * 64) * sizeof(float);
   const dim3 grid((group_ncols_ + 31) / 32, mt, g.n * B_);
-  const int kh = kbegin(prof_level_ >= 2 ? krow(wide ? "conv_splitk_group_kernel<8,4,128>" : "conv_splitk_group_kernel<8,4,64>") : 0,
+  const int kh = kbegin(prof_level_ >= 2 ? krow(wide ? "conv_splitk_group_kernel<4,4,128>" : "conv_splitk_group_kernel<4,4,64>") : 0,
                         group_flops_, group_bytes_);
-  if (wide) PE_LAUNCH((conv_splitk_group_kernel<8, 4, 128>), grid, dim3(64 * NW), smem, ls_, g);
-  else PE_LAUNCH((conv_splitk_group_kernel<8, 4, 64>), grid, dim3(64 * NW), smem, ls_, g);
+  if (wide) PE_LAUNCH((conv_splitk_group_kernel<4, 4, 128>), grid, dim3(64 * NW), smem, ls_, g);
+  else PE_LAUNCH((conv_splitk_group_kernel<4, 4, 64>), grid, dim3(64 * NW), smem, ls_, g);
   kend(kh);
   group_.clear();
 }
@@ -802,7 +804,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     if (!can_group(pc, ncols) || epi == EPI_CONVT || epi == EPI_GATE || ln_in || group_.size() >= 3 ||
         (!group_.empty() && group_ncols_ != ncols))
       throw std::runtime_error("internal: conv does not fit a grouped launch");
-    p.tgroups = pc.nchunks <= 4 ? 2 : 1;          // 8 waves: <= 4 chunk lanes leave room to split the taps
+    p.tgroups = 1;
     group_.push_back(p);
     group_ncols_ = ncols;
     group_flops_ += kflops;
