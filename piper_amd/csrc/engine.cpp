@@ -158,7 +158,7 @@ PackedConv Engine::pack_conv(const WeightSet& ws, const std::string& wname, cons
   return pack_matrix(W, Co, Ci, K, has_b ? &bias : nullptr, Co, dil, padl, gate, gate ? Co / 2 : 0);
 }
 
-PackedConv Engine::pack_qkv(const WeightSet& ws, const std::string& prefix) {
+PackedConv Engine::pack_qkv(const WeightSet& ws, const std::string& prefix, float** out16) {
   // conv_q / conv_k / conv_v (attentions.py:216-218) share their input: one GEMM with 3H rows.
   std::vector<float> W, bias;
   int H = 0;
@@ -171,6 +171,7 @@ PackedConv Engine::pack_qkv(const WeightSet& ws, const std::string& prefix) {
       bias.insert(bias.end(), b.data.begin(), b.data.end());
     }
   }
+  if (out16) *out16 = pack16(W, 3 * H, H);
   return pack_matrix(W, 3 * H, H, 1, &bias, 3 * H, 1, 0, false, 0);
 }
 
@@ -302,7 +303,7 @@ void Engine::init(const WeightSet& ws) {
     const std::string s = std::to_string(l), a = "enc_p.encoder.attn_layers." + s,
                       f = "enc_p.encoder.ffn_layers." + s;
     EncLayer e;
-    e.qkv = pack_qkv(ws, a);
+    e.qkv = pack_qkv(ws, a, &e.qkv16);
     e.o = pack_conv(ws, a + ".conv_o.weight", a + ".conv_o.bias", 1, -1, false, 0, 0);
     e.o16 = pack16_conv(ws, a + ".conv_o.weight", 0, 0);
     e.relk = dev_tensor(ws, a + ".emb_rel_k");
@@ -316,6 +317,7 @@ void Engine::init(const WeightSet& ws) {
     enc_.push_back(e);
   }
   enc_proj_ = pack_conv(ws, "enc_p.proj.weight", "enc_p.proj.bias", 1, -1, false, 0, 0);
+  enc_proj16_ = pack16_conv(ws, "enc_p.proj.weight", 0, 0);
 
   // ---- duration predictor (reverse path)
   dp_pre_ = pack_conv(ws, "dp.pre.weight", "dp.pre.bias", 1, -1, false, 0, 0);
@@ -1269,6 +1271,21 @@ int Engine::krow(const std::string& name) {
   prof_.push_back(ProfileRow{names_.back().c_str()});
   return (int)prof_.size() - 1;
 }
+void Engine::lngemm(View y, const float* g, const float* b, View x, const float* w16, const float* bias, int rows,
+                    View out, int T, double flops) {
+  LnGemmP p{};
+  p.in = y.p; p.in_bs = y.bs; p.in_cs = y.cs;
+  p.gamma = g; p.beta = b;
+  p.xout = x.p; p.x_bs = x.bs; p.x_cs = x.cs;
+  p.w16 = w16; p.bias = bias; p.rows = rows;
+  p.out = out.p; p.o_bs = out.bs; p.o_cs = out.cs;
+  p.lens = d_tlens_;
+  const int kh = kbegin(prof_level_ >= 2 ? krow("lngemm_kernel<6>") : 0, flops);
+  const size_t smem = ((size_t)192 * 16 + 8 * 16) * sizeof(float);
+  PE_LAUNCH(lngemm_kernel<6>, dim3((T + 15) / 16, B_, (rows + 191) / 192), dim3(512), smem, stream_, p);
+  kend(kh);
+}
+
 void Engine::colchain(const ColP& p, int B, int Lmax, double flops) {
   const int kh = kbegin(prof_level_ >= 2 ? krow("colchain_kernel<6>") : 0, flops);
   const size_t smem = ((size_t)2 * 6 * 32 * 16 + 8 * 16) * sizeof(float);
@@ -1430,9 +1447,15 @@ void Engine::issue_stage_a() {
   const bool fold1 = can_fold_ln(enc_.empty() ? enc_proj_ : enc_[0].f1, T);
   const bool fold2 = can_fold_ln(enc_.empty() ? enc_proj_ : enc_[0].qkv, T) && can_fold_ln(enc_proj_, T);
   const float *pg = nullptr, *pb = nullptr;        // pending norm_layers_2 of the previous layer (input still in y)
+  // small batches with the 192-channel encoder: norm_layers_2 + the q/k/v (or proj) conv as one launch (lngemm_kernel)
+  const bool chain_q = !fold2 && use_colchain(tsum, H_, 96);
   for (auto& e : enc_) {
-    if (pg) { ln_in_.g = pg; ln_in_.b = pb; ln_in_.out = x; }
-    conv(e.qkv, pg ? y : x, qkv, d_tlens_, 1, T, EPI_STORE);
+    if (pg && chain_q) {
+      lngemm(y, pg, pb, x, e.qkv16, e.qkv.bias, 3 * H_, qkv, T, 2.0 * tsum * e.qkv.macs_per_col);
+    } else {
+      if (pg) { ln_in_.g = pg; ln_in_.b = pb; ln_in_.out = x; }
+      conv(e.qkv, pg ? y : x, qkv, d_tlens_, 1, T, EPI_STORE);
+    }
     pg = pb = nullptr;
     AttnP ap;
     ap.qkv = qkv_; ap.q_bs = (long)3 * H_ * Ts; ap.q_cs = Ts;
@@ -1453,7 +1476,7 @@ void Engine::issue_stage_a() {
     else if (ap.dk == 48) PE_LAUNCH(attn_kernel<48>, agrid, dim3(256), smem, stream_, ap);
     else PE_LAUNCH(attn_kernel<0>, agrid, dim3(256), smem, stream_, ap);
     kend(kh);
-    const bool chain_o = !fold1 && use_colchain(tsum, H_);
+    const bool chain_o = !fold1 && use_colchain(tsum, H_, 96);
     if (chain_o) {
       // conv_o + residual + norm_layers_1 in one launch (the 192 x 192 GEMM fits one workgroup per 16 columns)
       ColP cp{};
@@ -1478,13 +1501,17 @@ void Engine::issue_stage_a() {
       conv(e.f1, x, ffh, d_tlens_, 1, T, EPI_STORE, 1.f, ACT_RELU);
     }
     conv(e.f2, ffh, y, d_tlens_, 1, T, EPI_RESADD, 1.f, ACT_NONE, x);
-    if (fold2) { pg = e.g2; pb = e.b2; }
+    if (fold2 || chain_q) { pg = e.g2; pb = e.b2; }
     else layer_norm(0, y, none, x, e.g2, e.b2, nullptr, nullptr, 0, 0, H_, d_tlens_, T);
     fl += 2.0 * tsum * (e.qkv.macs_per_col + e.o.macs_per_col + e.f1.macs_per_col + e.f2.macs_per_col);
     for (int b = 0; b < B; ++b) fl += 2.0 * 2.0 * (double)tlens_h_[b] * tlens_h_[b] * H_;
   }
-  if (pg) { ln_in_.g = pg; ln_in_.b = pb; ln_in_.out = x; }
-  conv(enc_proj_, pg ? y : x, stats, d_tlens_, 1, T, EPI_STORE);
+  if (pg && chain_q) {
+    lngemm(y, pg, pb, x, enc_proj16_, enc_proj_.bias, enc_proj_.rows, stats, T, 2.0 * tsum * enc_proj_.macs_per_col);
+  } else {
+    if (pg) { ln_in_.g = pg; ln_in_.b = pb; ln_in_.out = x; }
+    conv(enc_proj_, pg ? y : x, stats, d_tlens_, 1, T, EPI_STORE);
+  }
   fl += 2.0 * tsum * enc_proj_.macs_per_col;
   prof_end(0, fl);
 
@@ -1617,7 +1644,7 @@ void Engine::issue_flow() {
   auto VF = [&](float* p, int ch) { return View{p, (long)ch * Fs, Fs}; };
   const View fh = VF(fh_, H_), facts = VF(facts_, H_), fskip = VF(fskip_, H_);
   const int half = C_ / 2;
-  const bool chain = use_colchain(fsum, std::max(H_, half));
+  const bool chain = use_colchain(fsum, H_, half);
   for (size_t ri = 0; ri < rcls_.size(); ++ri) {
     Rcl& r = rcls_[ri];
     const View x0{zp_ + (long)r.in_off * Fs, (long)C_ * Fs, Fs};

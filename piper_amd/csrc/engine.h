@@ -121,7 +121,7 @@ class Engine {
   float* dev_tensor(const WeightSet& ws, const std::string& name);
   PackedConv pack_conv(const WeightSet& ws, const std::string& wname, const std::string& bname, int dil,
                        int padl_override, bool gate, int in_rev, int out_rev);
-  PackedConv pack_qkv(const WeightSet& ws, const std::string& prefix);
+  PackedConv pack_qkv(const WeightSet& ws, const std::string& prefix, float** out16 = nullptr);
   PackedConv pack_convT(const WeightSet& ws, const std::string& prefix, int stride);
   PackedConv pack_matrix(const std::vector<float>& W, int rows, int Cin, int ntaps,
                          const std::vector<float>* bias, int nbias, int dil, int padl, bool gate, int split);
@@ -173,10 +173,13 @@ class Engine {
   float* dp_proj16_ = nullptr;
   int colchain_ = 1;                        // PIPER_HIP_COLCHAIN: 0 off, 1 small batches, 2 always (A/B, tests)
   long colchain_max_cols_ = 1100;           // batch columns (ids or frames) up to which colchain_kernel replaces conv pairs
-  bool use_colchain(double cols, int kmax) const {
-    return colchain_ && kmax <= 192 && (colchain_ == 2 || cols <= (double)colchain_max_cols_);
+  // colchain_kernel<6> is compiled for exactly 192 input channels (and 96 = half of them in the coupling layers)
+  bool use_colchain(double cols, int k1, int half) const {
+    return colchain_ && k1 == 192 && half == 96 && (colchain_ == 2 || cols <= (double)colchain_max_cols_);
   }
   void colchain(const struct ColP& p, int B, int Lmax, double flops);
+  void lngemm(View y, const float* g, const float* b, View x, const float* w16, const float* bias, int rows, View out,
+              int T, double flops);
   float* pack16_conv(const WeightSet& ws, const std::string& wname, int in_rev, int out_rev);
   bool fuse_dp_ = true;                     // PIPER_HIP_FUSE_DP=0: cf_pre / proj / spline as separate launches (A/B, tests)
   void issue_stage_a();
@@ -216,10 +219,12 @@ class Engine {
   struct EncLayer {
     PackedConv qkv, o, f1, f2;
     float* o16 = nullptr;                        // conv_o in pack16 order (colchain_kernel)
+    float* qkv16 = nullptr;                      // the fused q/k/v matrix in pack16 order (lngemm_kernel)
     float *relk, *relv, *g1, *b1, *g2, *b2;
   };
   std::vector<EncLayer> enc_;
   PackedConv enc_proj_;
+  float* enc_proj16_ = nullptr;                  // pack16 order (lngemm_kernel)
   PackedConv dp_pre_, dp_proj_;
   DdsW dp_dds_;
   struct CFlow {

@@ -1375,33 +1375,46 @@ struct DdsP {
 // k ascends inside and across the instructions of a tile exactly as in a one-tile-at-a-time loop: same fmaf chain.
 // EXACT: Kp == 16 * NQMAX is known at compile time (no per-step guards in the unrolled loops: on the common shapes the
 // guards were a scalar branch per LDS read, ~200 per launch).
-template <int NQMAX, bool EXACT, class Sink>
+// The weights do not depend on anything the kernel computes: col_gemm16_fetch requests the first pair's row blocks (the
+// only pair for <= 256 rows) wherever the caller likes -- at kernel entry, under the phase that produces IN -- and
+// col_gemm16<..., PRE = true> starts from them, so the GEMM phase does not open with a memory round trip.
+template <int NQMAX>
+struct ColW {
+  f32x4 w0[NQMAX], w1[NQMAX];
+  float bz0[4], bz1[4];
+};
+template <int NQMAX>
+__device__ __forceinline__ void col_gemm16_fetch(ColW<NQMAX>& w, const float* wp16, const float* bias, int nbias,
+                                                 int rows, int Kp, int mt, int lane) {
+  const int lq = lane >> 4;
+  const int nq = Kp / 16, ntile = (rows + 15) / 16, tile_floats = nq * 256;
+  const pe_rowsrc biasd = pe_make_row(bias ? bias : wp16, bias ? nbias : 0);
+  const bool one = PE_UNIFORM(mt < ntile), two = PE_UNIFORM(mt + 8 < ntile);
+  const pe_rowsrc ws0 = pe_make_row_u(wp16 + (long)(one ? mt : 0) * tile_floats, one ? tile_floats : 0);
+  const pe_rowsrc ws1 = pe_make_row_u(wp16 + (long)(two ? mt + 8 : 0) * tile_floats, two ? tile_floats : 0);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    w.bz0[r] = pe_row_load(biasd, one ? mt * 16 + 4 * lq + r : -1);
+    w.bz1[r] = pe_row_load(biasd, two ? (mt + 8) * 16 + 4 * lq + r : -1);
+  }
+#pragma unroll
+  for (int qq = 0; qq < NQMAX; ++qq) w.w0[qq] = pe_row_load4(ws0, qq * 256 + lane * 4);     // past nq: zeros
+#pragma unroll
+  for (int qq = 0; qq < NQMAX; ++qq) w.w1[qq] = pe_row_load4(ws1, qq * 256 + lane * 4);
+  PE_SCHED_FENCE();
+}
+template <int NQMAX, bool EXACT, bool PRE = false, class Sink>
 __device__ __forceinline__ void col_gemm16(const float* wp16, const float* bias, int nbias, int rows, int Kp_rt,
-                                           const float* IN, int wv, int lane, Sink&& sink) {
+                                           const float* IN, int wv, int lane, Sink&& sink, ColW<NQMAX>* pre = nullptr) {
   constexpr int NC = 16;
   const int l15 = lane & 15, lq = lane >> 4;
   const int Kp = EXACT ? 16 * NQMAX : Kp_rt;
-  const int nq = Kp / 16, ntile = (rows + 15) / 16, tile_floats = nq * 256;
-  const pe_rowsrc biasd = pe_make_row(bias ? bias : wp16, bias ? nbias : 0);
-  for (int mt = wv; mt < ntile; mt += 16) {
+  const int nq = Kp / 16, ntile = (rows + 15) / 16;
+  auto run_pair = [&](const int mt, const ColW<NQMAX>& W) {
     const bool two = PE_UNIFORM(mt + 8 < ntile);
-    const pe_rowsrc ws0 = pe_make_row_u(wp16 + (long)mt * tile_floats, tile_floats);
-    const pe_rowsrc ws1 = pe_make_row_u(wp16 + (long)(two ? mt + 8 : mt) * tile_floats, two ? tile_floats : 0);
     f32x4 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc0[r] = acc1[r] = 0.f;
-    float bz0[4], bz1[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      bz0[r] = pe_row_load(biasd, mt * 16 + 4 * lq + r);
-      bz1[r] = pe_row_load(biasd, two ? (mt + 8) * 16 + 4 * lq + r : -1);
-    }
-    f32x4 w0[NQMAX], w1[NQMAX];
-#pragma unroll
-    for (int qq = 0; qq < NQMAX; ++qq) w0[qq] = pe_row_load4(ws0, qq * 256 + lane * 4);     // past nq: zeros
-#pragma unroll
-    for (int qq = 0; qq < NQMAX; ++qq) w1[qq] = pe_row_load4(ws1, qq * 256 + lane * 4);
-    PE_SCHED_FENCE();
 #pragma unroll
     for (int q0 = 0; q0 < NQMAX; q0 += 4) {
       if (q0 < nq) {
@@ -1412,22 +1425,32 @@ __device__ __forceinline__ void col_gemm16(const float* wp16, const float* bias,
         if (two) {
 #pragma unroll
           for (int u = 0; u < 16; ++u) {
-            acc0 = pe_mfma_16x16x4(w0[q0 + (u >> 2)][u & 3], yv[u], acc0);
-            acc1 = pe_mfma_16x16x4(w1[q0 + (u >> 2)][u & 3], yv[u], acc1);
+            acc0 = pe_mfma_16x16x4(W.w0[q0 + (u >> 2)][u & 3], yv[u], acc0);
+            acc1 = pe_mfma_16x16x4(W.w1[q0 + (u >> 2)][u & 3], yv[u], acc1);
           }
         } else {
 #pragma unroll
-          for (int u = 0; u < 16; ++u) acc0 = pe_mfma_16x16x4(w0[q0 + (u >> 2)][u & 3], yv[u], acc0);
+          for (int u = 0; u < 16; ++u) acc0 = pe_mfma_16x16x4(W.w0[q0 + (u >> 2)][u & 3], yv[u], acc0);
         }
         PE_SCHED_FENCE();
       }
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sink(mt * 16 + 4 * lq + r, l15, acc0[r] + bz0[r]);
+    for (int r = 0; r < 4; ++r) sink(mt * 16 + 4 * lq + r, l15, acc0[r] + W.bz0[r]);
     if (two) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sink((mt + 8) * 16 + 4 * lq + r, l15, acc1[r] + bz1[r]);
+      for (int r = 0; r < 4; ++r) sink((mt + 8) * 16 + 4 * lq + r, l15, acc1[r] + W.bz1[r]);
     }
+  };
+  int mt = wv;
+  if (PRE) {
+    if (mt < ntile) run_pair(mt, *pre);
+    mt += 16;
+  }
+  for (; mt < ntile; mt += 16) {
+    ColW<NQMAX> wl;
+    col_gemm16_fetch<NQMAX>(wl, wp16, bias, nbias, rows, Kp, mt, lane);
+    run_pair(mt, wl);
   }
 }
 
@@ -1460,6 +1483,9 @@ __device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b
   float* ob = p.out + (long)b * p.o_bs;
   const int pad = (p.dw_k - 1) / 2 * p.dw_dil;
   const bool fold = p.pre_z != nullptr;
+  // this wave's 1x1-conv weight row blocks: in flight under phase 1
+  ColW<2 * NVT> gw;
+  col_gemm16_fetch<2 * NVT>(gw, p.wp16, p.bias, H, Hp, Hp, wv, lane);
 
   auto col_sum = [&](float v) -> float {       // sum over all channel lanes of this column
     v += __shfl_xor(v, 16);
@@ -1554,7 +1580,7 @@ __device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b
 
   // ---- phase 2: Z = W1x1 . Y + bias on 16x16x4 MFMAs (col_gemm16: tiles w and w+8 of a wave run as a pair)
   PE_STAMP(2, 4);
-  col_gemm16<2 * NVT, NVT != 8>(p.wp16, p.bias, H, Hp, Hp, Y, wv, lane, [&](int row, int cc, float val) { Z[row * NC + cc] = val; });
+  col_gemm16<2 * NVT, NVT != 8, true>(p.wp16, p.bias, H, Hp, Hp, Y, wv, lane, [&](int row, int cc, float val) { Z[row * NC + cc] = val; }, &gw);
   PE_STAMP(2, 5);
   __syncthreads();
   PE_STAMP(2, 6);
@@ -1681,7 +1707,9 @@ __global__ __launch_bounds__(512) void colchain_kernel(ColP p) {
   const int tid = threadIdx.x, col = tid & 15, rl = tid >> 4, wv = PE_UNIFORM(tid >> 6), lane = tid & 63;
   const int t = t0 + col;
   const bool ok = t < L;
-  const int K1p = (p.K1 + 31) & ~31;
+  constexpr int K1p = 32 * NVT;                  // the launcher checks: K1 == 32 NVT, and rows1 == 16 NVT in mode 1
+  ColW<2 * NVT> gw;                              // first GEMM's weight row blocks, in flight under the input staging
+  col_gemm16_fetch<2 * NVT>(gw, p.w1, p.b1, p.rows1, p.rows1, K1p, wv, lane);
 
   // operands of the step after the first GEMM are requested before it: residual / previous x1, LN gains
   float ov[NVT], gg[NVT], bb[NVT];
@@ -1711,10 +1739,12 @@ __global__ __launch_bounds__(512) void colchain_kernel(ColP p) {
   PE_STAMP(p.mode == 0 ? 3 : (p.w2 ? 6 : 7), 2);
   __syncthreads();
   PE_STAMP(p.mode == 0 ? 3 : (p.w2 ? 6 : 7), 3);
-  if (K1p == 32 * NVT)
-    col_gemm16<2 * NVT, true>(p.w1, p.b1, p.rows1, p.rows1, K1p, IN, wv, lane, [&](int row, int cc, float v) { Z[row * NC + cc] = v; });
-  else
-    col_gemm16<2 * NVT, false>(p.w1, p.b1, p.rows1, p.rows1, K1p, IN, wv, lane, [&](int row, int cc, float v) { Z[row * NC + cc] = v; });
+  col_gemm16<2 * NVT, true, true>(p.w1, p.b1, p.rows1, p.rows1, K1p, IN, wv, lane, [&](int row, int cc, float v) { Z[row * NC + cc] = v; }, &gw);
+  // second GEMM's weights (the next layer's pre): in flight under the x1 update
+  ColW<NVT> gw2;
+  constexpr int K2p = 16 * NVT;
+  const bool second = p.mode == 1 && p.w2;
+  if (second) col_gemm16_fetch<NVT>(gw2, p.w2, p.b2, p.rows2, p.rows2, K2p, wv, lane);
   PE_STAMP(p.mode == 0 ? 3 : (p.w2 ? 6 : 7), 4);
   __syncthreads();
   PE_STAMP(p.mode == 0 ? 3 : (p.w2 ? 6 : 7), 5);
@@ -1760,7 +1790,6 @@ __global__ __launch_bounds__(512) void colchain_kernel(ColP p) {
   // mode 1: x1 <- x1 - (post + bias); the updated half is the next layer's x0
   {
     float* xb = p.x1 + (long)b * p.x1_bs;
-    const int K2p = (p.rows1 + 31) & ~31;
 #pragma unroll
     for (int k = 0; k < NVT; ++k) {
       const int c = rl + 32 * k;
@@ -1768,17 +1797,94 @@ __global__ __launch_bounds__(512) void colchain_kernel(ColP p) {
       if (ok && c < p.rows1) xb[(long)c * p.x1_cs + t] = xn;
       if (c < K2p) IN[c * NC + col] = xn;
     }
-    if (!p.w2) return;
+    if (!second) return;
     __syncthreads();
     PE_STAMP(p.mode == 0 ? 3 : (p.w2 ? 6 : 7), 7);
     float* o2 = p.out2 + (long)b * p.o2_bs;
     auto st2 = [&](int row, int cc, float v) {
       if (row < p.rows2 && t0 + cc < L) o2[(long)row * p.o2_cs + t0 + cc] = v;
     };
-    if (K2p == 16 * NVT) col_gemm16<NVT, true>(p.w2, p.b2, p.rows2, p.rows2, K2p, IN, wv, lane, st2);   // half the channels
-    else col_gemm16<2 * NVT, false>(p.w2, p.b2, p.rows2, p.rows2, K2p, IN, wv, lane, st2);
+    col_gemm16<NVT, true, true>(p.w2, p.b2, p.rows2, p.rows2, K2p, IN, wv, lane, st2, &gw2);   // K = half the channels
     PE_STAMP(p.mode == 0 ? 3 : (p.w2 ? 6 : 7), 8);
   }
+}
+
+// ------------------------------------------------------------------------------------------------
+// norm_layers_2 of an encoder layer fused with the 1x1 conv that consumes it -- the next layer's q/k/v conv, or proj
+// after the last layer (attentions.py:73-74, 60-69; models.py:207): one workgroup = 16 columns x one 192-row part of
+// the GEMM (grid.z = parts: 3 for q/k/v, 2 for proj). Every part normalises its 16 columns itself (cheap next to a
+// launch); part 0 also writes LN(y) back for the residual readers. Small batches only, like colchain_kernel.
+struct LnGemmP {
+  const float* in; long in_bs; int in_cs;        // y = x + ffn(x)
+  const float* gamma; const float* beta;
+  float* xout; long x_bs; int x_cs;              // LN(y)
+  const float* w16; const float* bias; int rows; // pack16 order, all parts; part z owns rows [32 NVT z, 32 NVT (z + 1))
+  float* out; long o_bs; int o_cs;
+  const int* lens;
+};
+template <int NVT>                              // channels == 32 * NVT exactly (the launcher checks)
+__global__ __launch_bounds__(512) void lngemm_kernel(LnGemmP p) {
+  PE_KTRACE(7);
+  constexpr int NC = 16, H = 32 * NVT;
+  PE_DYN_SMEM(float, sm);                       // IN[H][16] | red[8][16]
+  const int b = blockIdx.y, L = p.lens[b];
+  const int t0 = blockIdx.x * NC;
+  if (t0 >= L) return;
+  float* IN = sm;
+  float* red = IN + H * NC;
+  const int tid = threadIdx.x, col = tid & 15, rl = tid >> 4, wv = PE_UNIFORM(tid >> 6), lane = tid & 63;
+  const int t = t0 + col;
+  const bool ok = t < L;
+  const int part = blockIdx.z, row0 = part * H;
+  const int rows_here = p.rows - row0 < H ? p.rows - row0 : H;
+  const float* wpart = p.w16 + (long)part * (2 * NVT) * (2 * NVT) * 256;      // 2 NVT row tiles of 2 NVT * 256 floats each
+  const float* bpart = p.bias ? p.bias + row0 : nullptr;
+  ColW<2 * NVT> gw;
+  col_gemm16_fetch<2 * NVT>(gw, wpart, bpart, rows_here, rows_here, H, wv, lane);
+  float v[NVT], gg[NVT], bb[NVT];
+  {
+    const pe_rowsrc ind = pe_make_row(p.in + (long)b * p.in_bs, H * p.in_cs);
+    const pe_rowsrc gd = pe_make_row(p.gamma, H), bd = pe_make_row(p.beta, H);
+#pragma unroll
+    for (int k = 0; k < NVT; ++k) {
+      const int c = rl + 32 * k;
+      v[k] = pe_row_load(ind, ok ? c * p.in_cs + t : -1);
+      gg[k] = pe_row_load(gd, c);
+      bb[k] = pe_row_load(bd, c);
+    }
+  }
+  auto col_sum = [&](float x) -> float {
+    x += __shfl_xor(x, 16);
+    x += __shfl_xor(x, 32);
+    __syncthreads();
+    if (lane < NC) red[wv * NC + col] = x;
+    __syncthreads();
+    float s = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) s += red[w * NC + col];
+    return s;
+  };
+  float s = 0.f;
+#pragma unroll
+  for (int k = 0; k < NVT; ++k) s += v[k];
+  const float mean = col_sum(s) / (float)H;
+  float q = 0.f;
+#pragma unroll
+  for (int k = 0; k < NVT; ++k) { const float d = v[k] - mean; q = fmaf(d, d, q); }
+  const float rstd = 1.f / sqrtf(col_sum(q) / (float)H + 1e-5f);
+  float* xo = p.xout + (long)b * p.x_bs;
+#pragma unroll
+  for (int k = 0; k < NVT; ++k) {
+    const int c = rl + 32 * k;
+    const float y = ok ? (v[k] - mean) * rstd * gg[k] + bb[k] : 0.f;
+    IN[c * NC + col] = y;
+    if (part == 0 && ok) xo[(long)c * p.x_cs + t] = y;
+  }
+  __syncthreads();
+  float* ob = p.out + (long)b * p.o_bs + (long)row0 * p.o_cs;
+  col_gemm16<2 * NVT, true, true>(wpart, bpart, rows_here, rows_here, H, IN, wv, lane, [&](int row, int cc, float val) {
+    if (row < rows_here && t0 + cc < L) ob[(long)row * p.o_cs + t0 + cc] = val;
+  }, &gw);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -156,7 +156,7 @@ FORCED = [
     # the encoder's LayerNorms folded into the consuming split-K convs (opt-in: measured slower than ln_kernel launches)
     ("medium", [128, 50], {"PIPER_HIP_FOLD_LN": 1}, {"conv_splitk_kernel<1,false,8,4>"}),
     # conv_o + LN and coupling post + next pre as single launches (colchain_kernel): forced on for a batch, and off
-    ("medium", [128, 77, 16, 33], {"PIPER_HIP_COLCHAIN": 2}, {"colchain_kernel<6>"}),
+    ("medium", [128, 77, 16, 33], {"PIPER_HIP_COLCHAIN": 2}, {"colchain_kernel<6>", "lngemm_kernel<6>"}),
     ("medium", [128, 31], {"PIPER_HIP_COLCHAIN": 0}, {"ln_kernel<0>", "conv_splitk_kernel<1,false,4,4>"}),
     # sibling resblock convs of the 128-channel stage as grouped launches (64- and 128-column slabs), and one by one
     ("medium", [128, 40], {}, {"conv_splitk_group_kernel<4,4,64>", "conv_splitk_group_kernel<4,4,128>"}),
