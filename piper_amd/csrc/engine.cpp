@@ -1891,6 +1891,7 @@ void Engine::dispatch_stage(char which) {
   switch (which) {
     case 'A': issue_stage_a(); break;
     case 'B': issue_stage_b(); break;
+    case 'C': issue_stage_a(); issue_stage_b(); break;
     case 'F': issue_flow(); break;
     default: issue_window(); break;
   }
@@ -1918,20 +1919,24 @@ void Engine::run() {
     if (fguess > MAX_FRAMES) spec = false;
   }
   if (spec) ensure_stage_b(fguess);              // before stage A is enqueued: growing the workspace drops every graph
-  char key[160];
-  snprintf(key, sizeof(key), "A|%d|%d|%d|%a|%a|%d|%d", B, Tg_, Ts_, scales_[1], scales_[2], (int)have_noise_w_, Fs_);
-  run_stage('A', key);
-  ++call_;                                    // mirrors the device-side counter bump of this run
+  char key[200];
   if (spec) {
+    // the whole utterance -- text encoder to int16 -- as ONE graph: stage B is issued right behind stage A for the
+    // guessed frame bucket (the kernels read the real frame counts from device memory, clamped to the bucket)
     Fg_ = std::min(fguess, Fs_);
     frames_h_.assign(B, Fg_);                 // placeholder for FLOP accounting while issuing; real counts in finish_run()
     lens_b_ = d_framesc_;
-    snprintf(key, sizeof(key), "S|%d|%d|%d|%d|%a", B, Fg_, Fs_, Ts_, scales_[0]);
-    run_stage('B', key);
+    snprintf(key, sizeof(key), "C|%d|%d|%d|%a|%a|%d|%d|%d|%a", B, Tg_, Ts_, scales_[1], scales_[2], (int)have_noise_w_,
+             Fs_, Fg_, scales_[0]);
+    run_stage('C', key);
+    ++call_;                                  // mirrors the device-side counter bump of this run
     spec_pending_ = true;
     spec_fg_ = Fg_;
     return;
   }
+  snprintf(key, sizeof(key), "A|%d|%d|%d|%a|%a|%d|%d", B, Tg_, Ts_, scales_[1], scales_[2], (int)have_noise_w_, Fs_);
+  run_stage('A', key);
+  ++call_;                                    // mirrors the device-side counter bump of this run
   PE_HIP(hipStreamSynchronize(stream_));      // the only data-dependent shape: F
   finish_stage_b_sizes();
   ensure_stage_b(rup(Fmax_, 32));
