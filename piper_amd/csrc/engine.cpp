@@ -489,8 +489,8 @@ void Engine::init(const WeightSet& ws) {
                          (const void*)conv_splitk_kernel<2, true, 12, 2>, (const void*)conv_splitk_kernel<1, false, 12, 4>,
                          (const void*)conv_splitk16_kernel<true, 12, 2>, (const void*)conv_splitk16_kernel<false, 8, 4>};
     for (const void* k : ks2) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    PE_HIP(hipFuncSetAttribute((const void*)conv_splitk_group_kernel<4, 4, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    PE_HIP(hipFuncSetAttribute((const void*)conv_splitk_group_kernel<4, 4, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    PE_HIP(hipFuncSetAttribute((const void*)conv_splitk_group_kernel<4, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    PE_HIP(hipFuncSetAttribute((const void*)conv_splitk_group_kernel<4, 2, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     PE_HIP(hipFuncSetAttribute((const void*)attn_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     PE_HIP(hipFuncSetAttribute((const void*)attn_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     PE_HIP(hipFuncSetAttribute((const void*)attn_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
@@ -712,27 +712,31 @@ void Engine::group_begin() {
 void Engine::group_end() {
   grouping_ = false;
   if (group_.empty()) return;
-  ConvG g{};
-  int halo = 0, mt = 0;
-  for (size_t i = 0; i < group_.size(); ++i) {
-    g.c[i] = group_[i];
-    halo = std::max(halo, group_[i].xhalo);
-    mt = std::max(mt, (group_[i].rows + 31) / 32);
-  }
-  g.n = (int)group_.size();
-  g.B = B_;
-  // 4 waves per workgroup: 32 / 64 KB of slabs, so 5 / 2 workgroups share a CU and the <= 3 x ~420 workgroups of a
-  // group run in one or two rounds (8 waves: 64 / 128 KB, five rounds, slower than one launch per conv)
+  // 4 waves per workgroup: 32 / 64 KB of slabs, so 4 / 2 workgroups share a CU and the <= 3 x ~420 workgroups of a
+  // group run in one or two rounds (8 waves: 64 / 128 KB, five rounds, slower than one launch per conv). The convs that
+  // need the 128-column slab go in a launch of their own: two resident workgroups per CU carry ~420 of them, not 1260.
   constexpr int NW = 4;
-  const bool wide = halo > 32;
-  const int XW = wide ? 128 : 64;
-  const size_t smem = std::max<size_t>((size_t)NW * KC * XW, (size_t)NW * 16 * 64) * sizeof(float);
-  const dim3 grid((group_ncols_ + 31) / 32, mt, g.n * B_);
-  const int kh = kbegin(prof_level_ >= 2 ? krow(wide ? "conv_splitk_group_kernel<4,4,128>" : "conv_splitk_group_kernel<4,4,64>") : 0,
-                        group_flops_, group_bytes_);
-  if (wide) PE_LAUNCH((conv_splitk_group_kernel<4, 4, 128>), grid, dim3(64 * NW), smem, ls_, g);
-  else PE_LAUNCH((conv_splitk_group_kernel<4, 4, 64>), grid, dim3(64 * NW), smem, ls_, g);
-  kend(kh);
+  for (int wide = 0; wide < 2; ++wide) {
+    ConvG g{};
+    int n = 0, mt = 0;
+    for (const ConvP& c : group_)
+      if ((c.xhalo > 32) == (wide == 1)) {
+        g.c[n++] = c;
+        mt = std::max(mt, (c.rows + 31) / 32);
+      }
+    if (!n) continue;
+    g.n = n;
+    g.B = B_;
+    const int XW = wide ? 128 : 64;
+    const size_t smem = std::max<size_t>((size_t)NW * KC * XW, (size_t)NW * 16 * 64) * sizeof(float);
+    const dim3 grid((group_ncols_ + 31) / 32, mt, n * B_);
+    const double share = (double)n / (double)group_.size();
+    const int kh = kbegin(prof_level_ >= 2 ? krow(wide ? "conv_splitk_group_kernel<4,2,128>" : "conv_splitk_group_kernel<4,2,64>") : 0,
+                          group_flops_ * share, group_bytes_ * share);
+    if (wide) PE_LAUNCH((conv_splitk_group_kernel<4, 2, 128>), grid, dim3(64 * NW), smem, ls_, g);
+    else PE_LAUNCH((conv_splitk_group_kernel<4, 2, 64>), grid, dim3(64 * NW), smem, ls_, g);
+    kend(kh);
+  }
   group_.clear();
 }
 
