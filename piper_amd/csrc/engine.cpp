@@ -1249,7 +1249,7 @@ void Engine::dds(const DdsW& d, View in, View out, View tmp, const DdsOpt* opt) 
     const int kh = kbegin(prof_level_ >= 2 ? krow(p.nchunks == 3 ? "dds_layer16_kernel<3>" : p.nchunks == 6 ? "dds_layer16_kernel<6>"
                                                                                        : "dds_layer16_kernel<8>") : 0, 0.0);
     const dim3 grid16((Tg_ + 15) / 16, B_);
-    const size_t smem16 = ((size_t)2 * p.nchunks * 32 * 16 + 8 * 16) * sizeof(float);
+    const size_t smem16 = ((size_t)2 * p.nchunks * 32 * 16 + 16 * 16) * sizeof(float);
     // <3> / <6> are compiled for exactly 96 / 192 padded channels; <8> takes any width up to 256
     if (p.nchunks == 3) PE_LAUNCH(dds_layer16_kernel<3>, grid16, dim3(512), smem16, stream_, p);
     else if (p.nchunks == 6) PE_LAUNCH(dds_layer16_kernel<6>, grid16, dim3(512), smem16, stream_, p);
@@ -1285,14 +1285,14 @@ void Engine::lngemm(View y, const float* g, const float* b, View x, const float*
   p.out = out.p; p.o_bs = out.bs; p.o_cs = out.cs;
   p.lens = d_tlens_;
   const int kh = kbegin(prof_level_ >= 2 ? krow("lngemm_kernel<6>") : 0, flops);
-  const size_t smem = ((size_t)192 * 16 + 8 * 16) * sizeof(float);
+  const size_t smem = ((size_t)192 * 16 + 16 * 16) * sizeof(float);
   PE_LAUNCH(lngemm_kernel<6>, dim3((T + 15) / 16, B_, (rows + 191) / 192), dim3(512), smem, stream_, p);
   kend(kh);
 }
 
 void Engine::colchain(const ColP& p, int B, int Lmax, double flops) {
   const int kh = kbegin(prof_level_ >= 2 ? krow("colchain_kernel<6>") : 0, flops);
-  const size_t smem = ((size_t)2 * 6 * 32 * 16 + 8 * 16) * sizeof(float);
+  const size_t smem = ((size_t)2 * 6 * 32 * 16 + 16 * 16) * sizeof(float);
   PE_LAUNCH(colchain_kernel<6>, dim3((Lmax + 15) / 16, B), dim3(512), smem, stream_, p);
   kend(kh);
 }
@@ -1593,7 +1593,7 @@ void Engine::issue_stage_a() {
       pp.dur = dp;
       pp.progress = dp_progress_; pp.prog_bs = dp_prog_bs_; pp.state = dp_state_; pp.err_host = h_frames_ + 4096;
       const int nch = chain[0].nchunks;
-      const size_t smem = ((size_t)2 * nch * 32 * 16 + 8 * 16 + 16) * sizeof(float) + 2048;
+      const size_t smem = ((size_t)2 * nch * 32 * 16 + 16 * 16 + 16) * sizeof(float) + 2048;
       const dim3 grid((T + 15) / 16, B);
       const char* nm = nch == 3 ? "dp_persist_kernel<3>" : nch == 6 ? "dp_persist_kernel<6>" : "dp_persist_kernel<8>";
       const int kh = kbegin(prof_level_ >= 2 ? krow(nm) : 0, 0.0);

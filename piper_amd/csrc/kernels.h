@@ -1370,6 +1370,23 @@ struct DdsP {
   float* zout; long zout_bs;
   float inv_sqrt_h;
 };
+// Sum over the 32 channel lanes x 8 waves that share a column (512-thread, 16-column workgroups): lane pairs by
+// shuffle, waves through `red` ([2][8][16] floats). The two halves of `red` alternate between calls, so a call costs
+// ONE block barrier: half h is rewritten two calls after it was read, and the barrier of the call in between orders that.
+__device__ __forceinline__ float pe_col_sum16(float v, float* red, int& flip, int wv, int lane, int col) {
+  constexpr int NC = 16;
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  float* r = red + flip * 8 * NC;
+  flip ^= 1;
+  if (lane < NC) r[wv * NC + col] = v;
+  __syncthreads();
+  float s = 0.f;
+#pragma unroll
+  for (int w = 0; w < 8; ++w) s += r[w * NC + col];
+  return s;
+}
+
 // rows x Kp GEMM over the 16 columns in IN[Kp][16] on the 16x16x4 MFMA; sink(row, col, value + bias[row]).
 // Wave w owns the 16-row tiles w and w + 8 (then w + 16, w + 24, ...) and runs such a PAIR together: both weight row
 // blocks are requested up front (one memory latency per pair, 2 * NQMAX float4 per lane), the B fragments are read from
@@ -1465,7 +1482,7 @@ __device__ __forceinline__ void col_gemm16(const float* wp16, const float* bias,
 // SC1: the layer's activations travel between workgroups of ONE launch (dp_persist_kernel): agent-scope loads / stores.
 template <int NVT, bool SC1>                    // NVT = channel slots per thread: ceil(Hp / 32)
 __device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b, float* sm) {
-  constexpr int NC = 16;                        // sm: Y[Hp][16] | Z[Hp][16] | red[8][16]
+  constexpr int NC = 16;                        // sm: Y[Hp][16] | Z[Hp][16] | red[2][8][16]
   PE_STAMP(2, 0);
   const int L = p.lens[b];
   const int t0 = ctile * NC;
@@ -1489,17 +1506,8 @@ __device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b
   ColW<2 * NVT> gw;
   col_gemm16_fetch<2 * NVT>(gw, p.wp16, p.bias, H, Hp, Hp, wv, lane);
 
-  auto col_sum = [&](float v) -> float {       // sum over all channel lanes of this column
-    v += __shfl_xor(v, 16);
-    v += __shfl_xor(v, 32);
-    __syncthreads();
-    if (lane < NC) red[wv * NC + col] = v;
-    __syncthreads();
-    float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) s += red[w * NC + col];
-    return s;
-  };
+  int red_flip = 0;
+  auto col_sum = [&](float x) -> float { return pe_col_sum16(x, red, red_flip, wv, lane, col); };
 
   // ---- phase 1: depthwise conv, LN1, GELU -> Y (all operands requested up front through descriptors)
   constexpr int MAXK = 3;
@@ -1697,7 +1705,7 @@ template <int NVT>                              // NVT = channel slots per threa
 __global__ __launch_bounds__(512) void colchain_kernel(ColP p) {
   PE_KTRACE(3);
   constexpr int NC = 16;
-  PE_DYN_SMEM(float, sm);                       // IN[32 NVT][16] | Z[32 NVT][16] | red[8][16]
+  PE_DYN_SMEM(float, sm);                       // IN[32 NVT][16] | Z[32 NVT][16] | red[2][8][16]
   PE_STAMP(p.mode == 0 ? 3 : (p.w2 ? 6 : 7), 0);
   const int b = blockIdx.y, L = p.lens[b];
   const int t0 = blockIdx.x * NC;
@@ -1752,17 +1760,8 @@ __global__ __launch_bounds__(512) void colchain_kernel(ColP p) {
   PE_STAMP(p.mode == 0 ? 3 : (p.w2 ? 6 : 7), 5);
 
   if (p.mode == 0) {
-    auto col_sum = [&](float v) -> float {
-      v += __shfl_xor(v, 16);
-      v += __shfl_xor(v, 32);
-      __syncthreads();
-      if (lane < NC) red[wv * NC + col] = v;
-      __syncthreads();
-      float s = 0.f;
-#pragma unroll
-      for (int w = 0; w < 8; ++w) s += red[w * NC + col];
-      return s;
-    };
+    int red_flip = 0;
+    auto col_sum = [&](float x) -> float { return pe_col_sum16(x, red, red_flip, wv, lane, col); };
     const int H = p.rows1;
     float v[NVT];
     float s = 0.f;
@@ -1828,7 +1827,7 @@ template <int NVT>                              // channels == 32 * NVT exactly 
 __global__ __launch_bounds__(512) void lngemm_kernel(LnGemmP p) {
   PE_KTRACE(7);
   constexpr int NC = 16, H = 32 * NVT;
-  PE_DYN_SMEM(float, sm);                       // IN[H][16] | red[8][16]
+  PE_DYN_SMEM(float, sm);                       // IN[H][16] | red[2][8][16]
   const int b = blockIdx.y, L = p.lens[b];
   const int t0 = blockIdx.x * NC;
   if (t0 >= L) return;
@@ -1855,17 +1854,8 @@ __global__ __launch_bounds__(512) void lngemm_kernel(LnGemmP p) {
       bb[k] = pe_row_load(bd, c);
     }
   }
-  auto col_sum = [&](float x) -> float {
-    x += __shfl_xor(x, 16);
-    x += __shfl_xor(x, 32);
-    __syncthreads();
-    if (lane < NC) red[wv * NC + col] = x;
-    __syncthreads();
-    float s = 0.f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) s += red[w * NC + col];
-    return s;
-  };
+  int red_flip = 0;
+  auto col_sum = [&](float x) -> float { return pe_col_sum16(x, red, red_flip, wv, lane, col); };
   float s = 0.f;
 #pragma unroll
   for (int k = 0; k < NVT; ++k) s += v[k];
