@@ -22,6 +22,8 @@ run_prof() {  # name, bench args
 }
 run_prof b1 --steps 50
 python scripts/trace_gaps.py $O/st_b1 > $O/trace_gaps_b1.txt 2>&1
+# in-kernel phase stamps + per-launch device trace of one replayed step (tuning build of the same sources)
+[ -f piper_amd/libpiper_hip_stamps.so ] && timeout 300 python scripts/stamps.py medium 128 > $O/stamps_b1.txt 2>> $O/err.log
 run_prof b16 --batch 16 --steps 5 --warmup 2
 run_prof high_b8 --preset high --batch 8 --steps 3 --warmup 1
 python scripts/pmc_traffic.py medium/b1/t128 $O/pmc_fetch_b1 $O/pmc_write_b1 $O/r02_pmc_traffic.json "rocprofv3 --kernel-trace --pmc FETCH_SIZE (and, separately, WRITE_SIZE) -- python bench.py --no-cpu-baseline --no-roofline --steps 50" > $O/traffic.log 2>&1
