@@ -18,6 +18,8 @@ SYMBOLS = [
     "pe_get_durations", "pe_get_info",
     "pe_set_seed", "pe_profile_enable", "pe_profile_reset", "pe_profile_rows", "pe_profile_get", "pe_profile_bytes",
     "pe_stream", "pe_debug_tensor", "pe_debug_randn", "pe_rng_calls", "pe_run_launches", "pe_last_error", "pe_destroy",
+    "pe_group_create", "pe_group_size", "pe_group_engine", "pe_group_synthesize_batch", "pe_group_assignment",
+    "pe_group_destroy",
 ]
 
 
@@ -77,6 +79,15 @@ def bind(path: str) -> C.CDLL:
     lib.pe_rng_calls.restype = C.c_uint64
     lib.pe_run_launches.argtypes = [vp]
     lib.pe_run_launches.restype = C.c_int64
+    lib.pe_group_create.argtypes = [vp, C.c_size_t, i32p, C.c_int32, C.POINTER(vp)]
+    lib.pe_group_size.argtypes = [vp]
+    lib.pe_group_size.restype = C.c_int32
+    lib.pe_group_engine.argtypes = [vp, C.c_int32]
+    lib.pe_group_engine.restype = vp
+    lib.pe_group_synthesize_batch.argtypes = [vp, i64p, i64p, C.c_int32, f32p, i64p, C.POINTER(PeResult)]
+    lib.pe_group_assignment.argtypes = [vp, i32p, C.c_int64]
+    lib.pe_group_destroy.argtypes = [vp]
+    lib.pe_group_destroy.restype = None
     lib.pe_destroy.argtypes = [vp]
     lib.pe_destroy.restype = None
     return lib

@@ -10,7 +10,7 @@
 
 namespace pe {
 
-long g_launches = 0;
+thread_local long g_launches = 0;
 
 static inline int rup(int v, int m) { return (v + m - 1) / m * m; }
 

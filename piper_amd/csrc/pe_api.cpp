@@ -5,7 +5,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <algorithm>
+#include <numeric>
 #include <string>
+#include <thread>
 
 #include "engine.h"
 
@@ -300,5 +303,196 @@ int pe_debug_randn(pe_engine* e, int32_t site, uint64_t call, int64_t n, float* 
 uint64_t pe_rng_calls(pe_engine* e) { return e ? e->eng->rng_call() : 0; }
 
 int64_t pe_run_launches(pe_engine* e) { return e ? (int64_t)e->eng->run_launches() : 0; }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// pe_group_*: one engine / stream / worker thread per device in ONE process (include/piper_hip.h)
+// ---------------------------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+struct pe_group {
+  std::vector<pe_engine*> eng;
+  std::vector<int> device;
+  std::vector<void*> arena;               // one packed-weight arena per engine, on its device
+  // last call, caller order
+  std::vector<int32_t> assign;
+  std::vector<int64_t> sample_off;
+  std::vector<int16_t> pcm;
+  std::vector<int32_t> frames;
+};
+
+namespace {
+void group_free(pe_group* g) {
+  if (!g) return;
+  for (pe_engine* e : g->eng) pe_destroy(e);
+  for (size_t i = 0; i < g->arena.size(); ++i)
+    if (g->arena[i]) {
+      hipSetDevice(g->device[i]);
+      hipFree(g->arena[i]);
+    }
+  delete g;
+}
+
+// Longest-first onto the least-loaded engine, ties to the lower index: the same deterministic table as
+// piper_amd/dist.py::shard_indices (load = phoneme ids; frames per id vary little within a voice).
+std::vector<std::vector<int>> lpt(const int64_t* offsets, int batch, int n) {
+  std::vector<int> order(batch);
+  std::iota(order.begin(), order.end(), 0);
+  std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+    return offsets[a + 1] - offsets[a] > offsets[b + 1] - offsets[b];
+  });
+  std::vector<std::vector<int>> shard(n);
+  std::vector<int64_t> load(n, 0);
+  for (int u : order) {
+    int best = 0;
+    for (int i = 1; i < n; ++i)
+      if (load[i] < load[best]) best = i;
+    shard[best].push_back(u);
+    load[best] += offsets[u + 1] - offsets[u];
+  }
+  for (auto& s : shard) std::sort(s.begin(), s.end());      // caller order inside a shard
+  return shard;
+}
+}  // namespace
+
+extern "C" {
+
+int pe_group_create(const void* blob, size_t nbytes, const int32_t* devices, int32_t n_devices, pe_group** out) {
+  pe_group* g = nullptr;
+  const int rc = guard([&] {
+    if (!blob || !devices || !out || n_devices < 1) throw std::runtime_error("null argument");
+    size_t bound = 0;
+    {
+      pe::WeightSet ws = pe::parse_blob(blob, nbytes, true);
+      bound = pe::Engine::arena_bound(ws);
+    }
+    const size_t header = pe::blob_header_bytes(blob, nbytes);
+    g = new pe_group();
+    g->device.assign(devices, devices + n_devices);
+    g->arena.assign(n_devices, nullptr);
+    for (int i = 0; i < n_devices; ++i) {
+      PE_HIP(hipSetDevice(devices[i]));
+      PE_HIP(hipMalloc(&g->arena[i], bound));
+      pe_engine* e = nullptr;
+      // engine 0 parses, packs and uploads; the others only lay their arena out (no weight data is read)
+      if (pe_create_in_arena(blob, i == 0 ? nbytes : header, devices[i], g->arena[i], bound, i == 0 ? 0 : 1, &e))
+        throw std::runtime_error(g_err);
+      g->eng.push_back(e);
+    }
+    size_t used = 0;
+    if (pe_weights_used(g->eng[0], &used)) throw std::runtime_error(g_err);
+    for (int i = 1; i < n_devices; ++i) {
+      size_t u = 0;
+      if (pe_weights_used(g->eng[i], &u)) throw std::runtime_error(g_err);
+      if (u != used) throw std::runtime_error("internal: arena layouts differ between devices");
+      if (devices[i] != devices[0]) {
+        int can = 0;
+        PE_HIP(hipDeviceCanAccessPeer(&can, devices[i], devices[0]));
+        if (can) {
+          PE_HIP(hipSetDevice(devices[i]));
+          hipDeviceEnablePeerAccess(devices[0], 0);       // "already enabled" is fine
+          (void)hipGetLastError();
+        }
+        PE_HIP(hipMemcpyPeer(g->arena[i], devices[i], g->arena[0], devices[0], used));   // staged by the runtime without P2P
+      } else {
+        PE_HIP(hipSetDevice(devices[i]));
+        PE_HIP(hipMemcpy(g->arena[i], g->arena[0], used, hipMemcpyDeviceToDevice));
+      }
+      PE_HIP(hipDeviceSynchronize());
+      if (pe_arena_ready(g->eng[i])) throw std::runtime_error(g_err);
+    }
+    *out = g;
+  });
+  if (rc) {
+    const std::string keep = g_err;
+    group_free(g);
+    g_err = keep;
+  }
+  return rc;
+}
+
+int32_t pe_group_size(pe_group* g) { return g ? (int32_t)g->eng.size() : 0; }
+
+pe_engine* pe_group_engine(pe_group* g, int32_t i) {
+  return (g && i >= 0 && i < (int32_t)g->eng.size()) ? g->eng[i] : nullptr;
+}
+
+int pe_group_synthesize_batch(pe_group* g, const int64_t* ids, const int64_t* offsets, int32_t batch,
+                              const float scales[3], const int64_t* sids, pe_result* result) {
+  return guard([&] {
+    if (!g || !ids || !offsets || !scales || batch < 1) throw std::runtime_error("null argument");
+    const auto t0 = std::chrono::steady_clock::now();
+    const int n = (int)g->eng.size();
+    const std::vector<std::vector<int>> shard = lpt(offsets, batch, n);
+    g->assign.assign(batch, 0);
+    struct Work {
+      std::vector<int64_t> ids, off, sids;
+      pe_result res{};
+      int rc = 0;
+      std::string err;
+    };
+    std::vector<Work> work(n);
+    for (int i = 0; i < n; ++i) {
+      Work& w = work[i];
+      w.off.push_back(0);
+      for (int u : shard[i]) {
+        g->assign[u] = i;
+        w.ids.insert(w.ids.end(), ids + offsets[u], ids + offsets[u + 1]);
+        w.off.push_back((int64_t)w.ids.size());
+        if (sids) w.sids.push_back(sids[u]);
+      }
+    }
+    auto run = [&](int i) {
+      Work& w = work[i];
+      if (shard[i].empty()) return;
+      w.rc = pe_synthesize_batch(g->eng[i], w.ids.data(), w.off.data(), (int32_t)shard[i].size(), scales,
+                                 sids ? w.sids.data() : nullptr, nullptr, &w.res);
+      if (w.rc) w.err = g_err;               // the message lives in the worker's thread-local slot
+    };
+#ifdef PE_EMU
+    for (int i = 0; i < n; ++i) run(i);      // the emulator is single-threaded
+#else
+    std::vector<std::thread> th;
+    for (int i = 1; i < n; ++i) th.emplace_back(run, i);
+    run(0);
+    for (auto& t : th) t.join();
+#endif
+    for (int i = 0; i < n; ++i)
+      if (work[i].rc) throw std::runtime_error("device " + std::to_string(g->device[i]) + ": " + work[i].err);
+    // gather in the caller's order
+    g->frames.assign(batch, 0);
+    g->sample_off.assign(batch + 1, 0);
+    for (int i = 0; i < n; ++i)
+      for (size_t k = 0; k < shard[i].size(); ++k) g->frames[shard[i][k]] = work[i].res.frames[k];
+    std::vector<int64_t> len(batch, 0);
+    for (int i = 0; i < n; ++i)
+      for (size_t k = 0; k < shard[i].size(); ++k)
+        len[shard[i][k]] = work[i].res.sample_offsets[k + 1] - work[i].res.sample_offsets[k];
+    for (int u = 0; u < batch; ++u) g->sample_off[u + 1] = g->sample_off[u] + len[u];
+    g->pcm.resize((size_t)g->sample_off[batch]);
+    for (int i = 0; i < n; ++i)
+      for (size_t k = 0; k < shard[i].size(); ++k) {
+        const int u = shard[i][k];
+        memcpy(g->pcm.data() + g->sample_off[u], work[i].res.pcm + work[i].res.sample_offsets[k], len[u] * sizeof(int16_t));
+      }
+    if (result) {
+      result->batch = batch;
+      result->sample_offsets = g->sample_off.data();
+      result->audio = nullptr;
+      result->pcm = g->pcm.data();
+      result->frames = g->frames.data();
+      result->infer_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    }
+  });
+}
+
+int pe_group_assignment(pe_group* g, int32_t* engine_index, int64_t capacity) {
+  return guard([&] {
+    if (!g || !engine_index) throw std::runtime_error("null argument");
+    if (capacity < (int64_t)g->assign.size()) throw std::runtime_error("assignment buffer too small");
+    memcpy(engine_index, g->assign.data(), g->assign.size() * sizeof(int32_t));
+  });
+}
+
+void pe_group_destroy(pe_group* g) { group_free(g); }
 
 }  // extern "C"

@@ -3,7 +3,7 @@
 // library is never built that way.)
 #pragma once
 
-namespace pe { extern long g_launches; }   // kernel launches issued by this library (captured launches count once)
+namespace pe { extern thread_local long g_launches; }   // kernel launches issued by this thread (captured launches count once)
 #ifdef PE_EMU
 #include "hip_emu.h"
 #define PE_LAUNCH(kernel, grid, block, smem, stream, ...) \

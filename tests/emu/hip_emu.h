@@ -141,6 +141,9 @@ inline hipError_t hipHostMalloc(void** p, size_t n, unsigned = 0) { return hipMa
 inline hipError_t hipHostFree(void* p) { free(p); return 0; }
 inline hipError_t hipMemcpy(void* d, const void* s, size_t n, int) { memcpy(d, s, n); return 0; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, int, hipStream_t) { memcpy(d, s, n); return 0; }
+inline hipError_t hipMemcpyPeer(void* d, int, const void* s, int, size_t n) { memcpy(d, s, n); return 0; }
+inline hipError_t hipDeviceCanAccessPeer(int* can, int, int) { *can = 1; return 0; }
+inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return 0; }
 inline hipError_t hipMemset(void* d, int v, size_t n) { memset(d, v, n); return 0; }
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return 0; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return 0; }

@@ -235,3 +235,32 @@ print(json.dumps(out))
     assert plan["medium/1"]["launches"] <= 140
     assert any(n.startswith("conv_mfma_kernel<2,2,2,1,16,true,") for n in plan["medium/64"]["names"])
     assert any(n.startswith("conv_mfma_kernel<2,2,2,1,16,true,") for n in plan["high/64"]["names"])
+
+
+def test_engine_group_matches_single_engine(emu_lib):
+    """pe_group_*: two engines in one process (here both on the emulator's only device), weights packed once and copied
+    arena to arena; utterances dealt longest-first. With the noise scales at 0 the result is deterministic, so every
+    utterance must equal what one engine computes for it, in the caller's order; the deal is dist.shard_indices'."""
+    from piper_amd import dist
+    from piper_amd.group import EngineGroup
+    cfg = W.preset("tiny")
+    blob = W.pack_blob(cfg, W.synthetic_weights(cfg, 7))
+    lens = [9, 33, 5, 21, 17]
+    ids = [W.synthetic_phoneme_ids(T, 40 + i, id_max=cfg.n_vocab - 1) for i, T in enumerate(lens)]
+    scales = (0.0, 1.1, 0.0)
+    grp = EngineGroup(blob, [0, 0], lib=emu_lib)
+    assert len(grp) == 2
+    rg = grp.synthesize_batch(ids, scales)
+    assign = grp.assignment(len(ids))
+    table = dist.shard_indices(lens, 2)
+    assert [assign[i] for i in table[0]] == [0] * len(table[0]) and [assign[i] for i in table[1]] == [1] * len(table[1])
+    eng = Engine(blob=blob, lib=emu_lib)
+    rs = eng.synthesize_batch(ids, scales)
+    assert list(rg.frames) == list(rs.frames)
+    for a, b in zip(rg.pcm, rs.pcm):
+        assert np.array_equal(a, b)
+    # a second call with another shape reuses the engines
+    rg2 = grp.synthesize_batch(ids[:2], scales)
+    assert np.array_equal(rg2.pcm[1], rs.pcm[1])
+    eng.close()
+    grp.close()
