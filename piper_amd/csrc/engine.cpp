@@ -620,8 +620,10 @@ void Engine::ensure_stage_a(int B, int Tmax) {
     noise_w_ = c.take<float>(Bc * 2 * T);
     cond_ = c.take<float>(Bc * (size_t)std::max(cond_bs_, 1));
     d_rng_ = c.take<unsigned long long>(4);
-    dp_prog_bs_ = (int)(T / 16);
-    dp_progress_ = c.take<unsigned>(Bc * (T / 16));
+    // halo granules of the persistent duration predictor: [256 tiles][3 slots][2 sides][channels][9] + z's [2][2][2]
+    dp_gx_ts_ = (size_t)3 * 2 * rup(H_, 32) * DDS_HALO;
+    dp_gx_ = c.take<unsigned long long>(persist_dp_ ? 256 * dp_gx_ts_ : 8);
+    dp_gz_ = c.take<unsigned long long>(256 * 8);
     dp_state_ = c.take<unsigned>(4 + Bc);
     return c.off + 256;
   };
@@ -634,11 +636,18 @@ void Engine::ensure_stage_a(int B, int Tmax) {
     wsA_bytes_ = carve(nullptr);
     PE_HIP(hipMalloc((void**)&wsA_, wsA_bytes_));
     carve(wsA_);
-    // progress words / counters of the persistent kernels start from zero and are never reset afterwards
-    PE_HIP(hipMemset(dp_progress_, 0, capA_B_ * (capA_T_ / 16) * sizeof(unsigned)));
-    PE_HIP(hipMemset(dp_state_, 0, (4 + capA_B_) * sizeof(unsigned)));
+    // granule tags / counters of the persistent kernel start from zero; tags only grow afterwards
+    dp_reset_granules();
   }
   carve(wsA_);
+}
+
+void Engine::dp_reset_granules() {
+  PE_HIP(hipStreamSynchronize(stream_));
+  PE_HIP(hipMemset(dp_gx_, 0, (persist_dp_ ? 256 * dp_gx_ts_ : 8) * sizeof(unsigned long long)));
+  PE_HIP(hipMemset(dp_gz_, 0, 256 * 8 * sizeof(unsigned long long)));
+  PE_HIP(hipMemset(dp_state_, 0, (4 + capA_B_) * sizeof(unsigned)));
+  dp_runs_ = 0;
 }
 
 void Engine::ensure_stage_b(int Fmax) {
@@ -1591,7 +1600,35 @@ void Engine::issue_stage_a() {
       for (size_t i = 0; i < chain.size(); ++i) pp.layer[i] = chain[i];
       pp.nlayers = (int)chain.size();
       pp.dur = dp;
-      pp.progress = dp_progress_; pp.prog_bs = dp_prog_bs_; pp.state = dp_state_; pp.err_host = h_frames_ + 4096;
+      pp.state = dp_state_; pp.err_host = h_frames_ + 4096;
+      {
+        // halo plan: which slot / tag every layer reads and publishes (kernels.h DdsP)
+        const int nct = (T + 15) / 16;
+        pp.g.gx = dp_gx_; pp.g.gx_ts = (int)dp_gx_ts_; pp.g.gx_bs = (long)nct * (long)dp_gx_ts_;
+        pp.g.gz = dp_gz_; pp.g.gz_ts = 8; pp.g.gz_bs = (long)nct * 8;
+        int xg_tag = 0, last_spline = -1, flow = -1;
+        for (int l = 0; l < pp.nlayers; ++l) {
+          DdsP& q = pp.layer[l];
+          const bool fold = q.pre_z != nullptr, post = q.post_w16 != nullptr;
+          if (fold) ++flow;
+          q.gin_slot = l == 0 ? -1 : (fold ? 2 : (signed char)((l - 1) & 1));
+          q.gin_tag = (unsigned char)(fold ? xg_tag : l);
+          q.gout_slot = post ? -1 : (signed char)(l & 1);
+          q.gout_tag = (unsigned char)(l + 1);
+          q.gout_d = (signed char)(l + 1 < pp.nlayers ? pp.layer[l + 1].dw_dil * ((pp.layer[l + 1].dw_k - 1) / 2) : 0);
+          q.pg_slot = (post && q.post_out) ? 2 : -1;
+          q.pg_tag = (unsigned char)(l + 1);
+          if (q.pg_slot >= 0) xg_tag = l + 1;
+          // z: the first flow reads the noise an earlier kernel wrote; later ones the previous flow's spline output
+          q.zin_par = (fold && last_spline >= 0) ? (signed char)((flow - 1) & 1) : -1;
+          q.zin_tag = (unsigned char)(last_spline + 1);
+          q.zin_row = (signed char)(fold ? (q.pre_z - (fold && last_spline < 0 ? noise_w_ : z2_)) / Ts : 0);
+          q.zout_par = (post && q.zout) ? (signed char)(flow & 1) : -1;
+          q.zout_tag = (unsigned char)(l + 1);
+          if (q.zout_par >= 0) last_spline = l;
+          if (q.gout_d > DDS_HALO || (fold && q.dw_dil != 1)) throw std::runtime_error("internal: DDSConv halo plan");
+        }
+      }
       const int nch = chain[0].nchunks;
       const size_t smem = ((size_t)2 * nch * 32 * 16 + 16 * 16 + 16) * sizeof(float) + 2048;
       const dim3 grid((T + 15) / 16, B);
@@ -1915,6 +1952,7 @@ void Engine::run() {
   spec_pending_ = false;
   Tg_ = std::min(rup(Tmax_, 32), Ts_);
   run_launches_ = 0;
+  if (persist_dp_ && ++dp_runs_ >= (1ull << 24)) dp_reset_granules();     // epoch * 64 + layer must stay below 2^32
   // speculative sizing of stage B from the previous run's frames-per-id ratio (see engine.h)
   bool spec = spec_enable_ && B <= spec_max_batch_ && last_ratio_ > 0.f && !have_noise_z_ && use_graphs_ && !prof_on_;
   int fguess = 0;
@@ -1966,8 +2004,7 @@ void Engine::finish_stage_b_sizes() {
 #endif
   if (h_frames_[4096]) {          // a persistent kernel gave up waiting for a neighbour workgroup (never on a resident grid)
     h_frames_[4096] = 0;
-    PE_HIP(hipMemset(dp_progress_, 0, capA_B_ * (capA_T_ / 16) * sizeof(unsigned)));
-    PE_HIP(hipMemset(dp_state_, 0, (4 + capA_B_) * sizeof(unsigned)));
+    dp_reset_granules();
     throw std::runtime_error("persistent duration-predictor kernel: neighbour wait timed out");
   }
   frames_h_.assign(h_frames_, h_frames_ + B);

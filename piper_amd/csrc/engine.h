@@ -167,8 +167,13 @@ class Engine {
   // duration-predictor kernel takes all twelve at once)
   void dds_params(const DdsW& d, View in, View out, View tmp, const DdsOpt* opt, std::vector<struct DdsP>& list);
   bool persist_dp_ = false;                 // PIPER_HIP_PERSIST_DP=1: the DDSConv chain as one persistent launch (measured no faster, profiles/r02_notes.md)
-  unsigned *dp_progress_ = nullptr, *dp_state_ = nullptr;
-  int dp_prog_bs_ = 0;
+  // dp_persist_kernel: halo granule arenas (256 column tiles: the kernel only runs on grids of <= 1 workgroup per CU),
+  // epoch / counters; dp_runs_ counts launches so that the arenas are cleared long before the 32-bit tags wrap
+  unsigned long long *dp_gx_ = nullptr, *dp_gz_ = nullptr;
+  size_t dp_gx_ts_ = 0;
+  unsigned* dp_state_ = nullptr;
+  uint64_t dp_runs_ = 0;
+  void dp_reset_granules();
   float* pack16(const std::vector<float>& W, int rows, int K);    // [16-row tile][q][lane][4] (dds_layer16_kernel)
   float* dp_proj16_ = nullptr;
   int colchain_ = 1;                        // PIPER_HIP_COLCHAIN: 0 off, 1 small batches, 2 always (A/B, tests)

@@ -1369,7 +1369,39 @@ struct DdsP {
   const float* zin; long zin_bs; int z_cs; int c0, c1;
   float* zout; long zout_bs;
   float inv_sqrt_h;
+  // Halo exchange between the column tiles of ONE launch (dp_persist_kernel): a tile reads its own columns from the
+  // tensors above and its neighbours' boundary columns from 8-byte {tag, value} granules the neighbours publish --
+  // [utterance][tile][slot][side][channel][9]; side 0 = the owner's columns 0..8, side 1 = its columns 7..15.
+  // Slots 0 / 1: layer outputs (alternating), 2: the conditioning g (dp.proj output). Tags = epoch base + layer + 1.
+  // The flow variable z ([2][T]): [utterance][tile][parity][side][row] granules of its columns 0 and 15.
+  // (The arenas themselves are in DdsG, shared by the layers; per layer only these few bytes.)
+  signed char gin_slot;                     // input halo (-1: the input was written by an EARLIER kernel: plain loads)
+  signed char gout_slot, gout_d;            // layer output: slot (-1: not published), columns per side the reader needs
+  signed char pg_slot;                      // post_out (g) boundary columns (-1: none)
+  signed char zin_par, zout_par;            // z read by the folded ConvFlow.pre (-1: written by an earlier kernel) / published
+  signed char zin_row;                      // physical row of z the folded ConvFlow.pre reads (pre_z points at it)
+  unsigned char gin_tag, gout_tag, pg_tag, zin_tag, zout_tag;
 };
+struct DdsG {
+  unsigned long long* gx; long gx_bs; int gx_ts;
+  unsigned long long* gz; long gz_bs; int gz_ts;
+};
+static constexpr int DDS_HALO = 9;          // widest depthwise halo of the duration predictor (kernel 3, dilation 9)
+// Spin until a granule carries the wanted tag (tags of a slot only grow); gives up after ~1e7 polls (never on a
+// resident grid) and reports through `err`.
+__device__ __forceinline__ float pe_gran_wait(const unsigned long long* g, unsigned want, int* err) {
+  long spins = 0;
+  unsigned long long v = pe_ld_gran(g);
+  while ((unsigned)(v >> 32) < want) {
+    pe_spin_pause();
+    if (++spins > (1L << 23)) { *err = 1; break; }
+    v = pe_ld_gran(g);
+  }
+  return __uint_as_float((unsigned)v);
+}
+__device__ __forceinline__ unsigned long long pe_gran(unsigned tag, float v) {
+  return ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
+}
 // Sum over the 32 channel lanes x 8 waves that share a column (512-thread, 16-column workgroups): lane pairs by
 // shuffle, waves through `red` ([2][8][16] floats). The two halves of `red` alternate between calls, so a call costs
 // ONE block barrier: half h is rewritten two calls after it was read, and the barrier of the call in between orders that.
@@ -1481,17 +1513,30 @@ __device__ __forceinline__ void col_gemm16(const float* wp16, const float* bias,
 // [16-row tile][q][lane][4] with lane -> (row = lane & 15, k = lane >> 4) and step s = 4q + j covering ci = 4s + k.
 // SC1: the layer's activations travel between workgroups of ONE launch (dp_persist_kernel): agent-scope loads / stores.
 template <int NVT, bool SC1>                    // NVT = channel slots per thread: ceil(Hp / 32)
-__device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b, float* sm) {
+__device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b, float* sm, const DdsG* G = nullptr,
+                                                 unsigned gbase = 0, int* gerr = nullptr) {
   constexpr int NC = 16;                        // sm: Y[Hp][16] | Z[Hp][16] | red[2][8][16]
   PE_STAMP(2, 0);
   const int L = p.lens[b];
   const int t0 = ctile * NC;
   if (t0 >= L) return;
   PE_STAMP(2, 1);
-  auto ldx = [&](const pe_rowsrc& r, int idx) { return SC1 ? pe_row_load_sc1(r, idx) : pe_row_load(r, idx); };
-  auto stg = [&](float* q, float v) { if (SC1) pe_st_sc1(q, v); else *q = v; };
+  // SC1 = the layer runs inside dp_persist_kernel: its own columns travel through memory between the waves of this
+  // workgroup only (plain stores and loads: a CU's vector L1 is coherent for its own waves, workgroup scope needs no
+  // cache policy), its neighbours' boundary columns arrive as granules, and only z -- which the duration step of ANOTHER
+  // workgroup reads at the end -- uses agent-scope accesses.
+  auto ldx = [&](const pe_rowsrc& r, int idx) { return pe_row_load(r, idx); };
+  auto stg = [&](float* q, float v) { *q = v; };
+  auto stz = [&](float* q, float v) { if (SC1) pe_st_sc1(q, v); else *q = v; };
   // NVT = 3 / 6: instantiated for exactly Hp = 32 * NVT (the launcher checks); NVT = 8 is the generic form (any Hp <= 256)
   const int H = p.H, Hp = NVT != 8 ? 32 * NVT : p.nchunks * 32;
+  // granule (slot, side, channel c, j) of column tile `tile`; z granule (parity, side, row)
+  auto gxa = [&](int tile, int slot, int side, int c, int j) {
+    return G->gx + (long)b * G->gx_bs + (long)tile * G->gx_ts + ((long)(slot * 2 + side) * Hp + c) * DDS_HALO + j;
+  };
+  auto gza = [&](int tile, int par, int side, int row) {
+    return G->gz + (long)b * G->gz_bs + (long)tile * G->gz_ts + (par * 2 + side) * 2 + row;
+  };
   float* Y = sm;
   float* Z = Y + Hp * NC;
   float* red = Z + Hp * NC;
@@ -1521,10 +1566,16 @@ __device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b
     const pe_rowsrc zd = pe_make_row(fold ? p.pre_z + (long)b * p.pre_z_bs : p.dw_b, fold ? L : 0);
     const pe_rowsrc pwd = pe_make_row(fold ? p.pre_w : p.dw_b, fold ? H : 0), pbd = pe_make_row(fold ? p.pre_b : p.dw_b, fold ? H : 0);
     float zt[MAXK], pw[NVT], pb[NVT];
+    // taps outside this workgroup's 16 columns (kk = 0 and kk = 2 only: the halo is at most 9 columns) come from
+    // the neighbours' granules when the producer ran in THIS launch
+    const bool xhalo = SC1 && p.gin_slot >= 0, zhalo = SC1 && fold && p.zin_par >= 0;
+    auto own = [&](int tt) { return tt >= t0 && tt < t0 + NC; };
 #pragma unroll
     for (int kk = 0; kk < MAXK; ++kk) {
       const int tt = t + kk * p.dw_dil - pad;
-      zt[kk] = ldx(zd, (ok && kk < p.dw_k && tt >= 0 && tt < L) ? tt : -1) * p.z_scale;
+      const bool tv = ok && kk < p.dw_k && tt >= 0 && tt < L && (!zhalo || own(tt));
+      zt[kk] = (SC1 && fold && p.zin_par >= 0 ? (tv ? pe_ld_sc1(p.pre_z + (long)b * p.pre_z_bs + tt) : 0.f)
+                                              : ldx(zd, tv ? tt : -1)) * p.z_scale;
     }
 #pragma unroll
     for (int k = 0; k < NVT; ++k) {
@@ -1534,7 +1585,7 @@ __device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b
       for (int kk = 0; kk < MAXK; ++kk) {
         const int tt = t + kk * p.dw_dil - pad;
         const bool tv = cv && kk < p.dw_k && tt >= 0 && tt < L;
-        xv[k][kk] = ldx(xd, tv ? c * p.x_cs + tt : -1);
+        xv[k][kk] = ldx(xd, (tv && (!xhalo || own(tt))) ? c * p.x_cs + tt : -1);
         ww[k][kk] = pe_row_load(wd, tv ? c * p.dw_k + kk : -1);
       }
       wb[k] = pe_row_load(bd, cv ? c : -1);
@@ -1542,6 +1593,49 @@ __device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b
       bb[k] = pe_row_load(b1d, c < H ? c : -1);
       pw[k] = pe_row_load(pwd, cv ? c : -1);
       pb[k] = pe_row_load(pbd, cv ? c : -1);
+    }
+    if (SC1 && (xhalo || zhalo)) {
+      // all granule loads go out together; the ones whose tag is still old are re-read until it arrives
+      const unsigned long long* ga[NVT + 1][2];
+      unsigned long long gv[NVT + 1][2];
+      unsigned want[NVT + 1];
+#pragma unroll
+      for (int k = 0; k <= NVT; ++k) {
+        const bool isz = k == NVT;
+        const int c = rl + 32 * k;
+        want[k] = gbase + (isz ? p.zin_tag : p.gin_tag);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int tt = t + 2 * h * p.dw_dil - pad;
+          const bool need = ok && p.dw_k == 3 && tt >= 0 && tt < L && !own(tt) && (isz ? zhalo : (xhalo && c < H));
+          const int side = h == 0 ? 1 : 0, tile = ctile + (h == 0 ? -1 : 1);
+          const int j = h == 0 ? tt - (t0 - NC) - (NC - DDS_HALO) : tt - (t0 + NC);
+          ga[k][h] = need ? (isz ? gza(tile, p.zin_par, side, p.zin_row) : gxa(tile, p.gin_slot, side, c, j)) : nullptr;
+          gv[k][h] = need ? pe_ld_gran(ga[k][h]) : 0ull;
+        }
+      }
+      for (long spins = 0;; ++spins) {
+        bool all = true;
+#pragma unroll
+        for (int k = 0; k <= NVT; ++k)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            if (ga[k][h] && (unsigned)(gv[k][h] >> 32) < want[k]) {
+              all = false;
+              gv[k][h] = pe_ld_gran(ga[k][h]);
+            }
+        if (all) break;
+        pe_spin_pause();
+        if (spins > (1L << 23)) { if (gerr) *gerr = 1; break; }
+      }
+#pragma unroll
+      for (int k = 0; k < NVT; ++k)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+          if (ga[k][h]) xv[k][2 * h] = __uint_as_float((unsigned)gv[k][h]);
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+        if (ga[NVT][h]) zt[2 * h] = __uint_as_float((unsigned)gv[NVT][h]) * p.z_scale;
     }
     if (fold) {
 #pragma unroll
@@ -1614,7 +1708,15 @@ __device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b
 #pragma unroll
     for (int k = 0; k < NVT; ++k) {
       const int c = rl + 32 * k;
-      if (c < H) stg(ob + (long)c * p.o_cs + t, xc[k] + gelu_erf((v[k] - mean) * rstd * gg[k] + bb[k]));
+      if (c < H) {
+        const float y = xc[k] + gelu_erf((v[k] - mean) * rstd * gg[k] + bb[k]);
+        stg(ob + (long)c * p.o_cs + t, y);
+        if (SC1 && p.gout_slot >= 0) {       // boundary columns for the neighbours' next layer
+          if (col < p.gout_d) pe_st_gran(gxa(ctile, p.gout_slot, 0, c, col), pe_gran(gbase + p.gout_tag, y));
+          if (col >= NC - p.gout_d)
+            pe_st_gran(gxa(ctile, p.gout_slot, 1, c, col - (NC - DDS_HALO)), pe_gran(gbase + p.gout_tag, y));
+        }
+      }
     }
     PE_STAMP(2, 7);
     return;
@@ -1634,7 +1736,14 @@ __device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b
 #pragma unroll
     for (int k = 0; k < NVT; ++k) {
       const int c = rl + 32 * k;
-      if (c < p.post_rows) stg(po + (long)c * p.po_cs + t, Z[c * NC + col]);
+      if (c < p.post_rows) {
+        const float y = Z[c * NC + col];
+        stg(po + (long)c * p.po_cs + t, y);
+        if (SC1 && p.pg_slot >= 0) {         // g is read with a one-column halo by every flow's first layer
+          if (col == 0) pe_st_gran(gxa(ctile, p.pg_slot, 0, c, 0), pe_gran(gbase + p.pg_tag, y));
+          if (col == NC - 1) pe_st_gran(gxa(ctile, p.pg_slot, 1, c, DDS_HALO - 1), pe_gran(gbase + p.pg_tag, y));
+        }
+      }
     }
   }
   if (p.zout) {
@@ -1665,8 +1774,14 @@ __device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b
       float* zo = p.zout + (long)b * p.zout_bs;
       const float x1 = (SC1 ? pe_ld_sc1(zi + (long)p.c1 * p.z_cs + st) : zi[(long)p.c1 * p.z_cs + st]) * p.z_scale;
       const float x0 = (SC1 ? pe_ld_sc1(zi + (long)p.c0 * p.z_cs + st) : zi[(long)p.c0 * p.z_cs + st]) * p.z_scale;
-      stg(zo + (long)p.c1 * p.z_cs + st, (x1 >= -5.0f && x1 <= 5.0f) ? spline_finish(uw, uh, dv, x1) : x1);
-      stg(zo + (long)p.c0 * p.z_cs + st, x0);
+      const float y1 = (x1 >= -5.0f && x1 <= 5.0f) ? spline_finish(uw, uh, dv, x1) : x1;
+      stz(zo + (long)p.c1 * p.z_cs + st, y1);
+      stz(zo + (long)p.c0 * p.z_cs + st, x0);
+      if (SC1 && p.zout_par >= 0 && (scol == 0 || scol == NC - 1)) {
+        const int side = scol == 0 ? 0 : 1;
+        pe_st_gran(gza(ctile, p.zout_par, side, p.c1), pe_gran(gbase + p.zout_tag, y1));
+        pe_st_gran(gza(ctile, p.zout_par, side, p.c0), pe_gran(gbase + p.zout_tag, x0));
+      }
     }
   }
   (void)ok;
@@ -1943,23 +2058,28 @@ __global__ __launch_bounds__(256) void duration_kernel(DurP p) {
 // The stochastic duration predictor's DDSConv chain as ONE launch (models.py:63-71,108-117; modules.py:117-129,
 // 496-527): every DDSConv layer of dp.convs and of the ConvFlows (with ConvFlow.pre folded in and dp.proj / proj +
 // spline fused behind, see dds_layer16_body) and the duration step at the end. A workgroup owns 16 time columns of one
-// utterance for the whole chain. The only thing a layer needs from other workgroups is the depthwise conv's halo
-// (<= 9 columns: the two neighbouring workgroups), so instead of a kernel boundary per layer (7-16 us each here,
-// profiles/r02_launch_floor.txt) the workgroups hand their columns to each other in memory -- agent-scope (sc1) stores
-// and loads -- and publish a per-(utterance, column tile) progress word that the neighbours poll (0.6-1.5 us per hop).
-// Progress words only ever grow (epoch * 64 + layers done), so nothing is reset between runs; the epoch lives in
-// device memory and is advanced by the workgroup that finishes last. Residency: the host launches this kernel only for
-// grids of at most one workgroup per CU. A neighbour that never shows up (cannot happen on a resident grid) ends the
-// spin after ~1e7 polls with an error code instead of a hang.
+// utterance for the whole chain and keeps reading / writing them itself (plain accesses, own L2). The only thing a layer
+// needs from other workgroups is the depthwise conv's halo -- <= 9 boundary columns of the two neighbouring tiles -- and
+// those travel as 8-byte {tag, value} granules: the producer stores them (relaxed, agent scope) right behind its own
+// columns, the consumer issues all its granule loads at once and re-reads the ones whose tag is still old. The data is
+// its own flag: ONE fabric round trip per layer, no drain, no fence, no progress word (a first version -- payload,
+// drain, flag, poll, reload -- cost three round trips per layer and was no faster than 12 launches,
+// profiles/r02_notes.md). Tags = epoch * 64 + layer + 1 only ever grow inside a slot, so nothing is reset between runs;
+// the epoch lives in device memory and is advanced by the workgroup that finishes last (the host clears the arenas
+// every 2^24 runs, long before the 32-bit tag wraps). Slot reuse is safe because a tile can publish layer l + 2 only
+// after it has read its neighbours' layer l + 1, which they published after reading this tile's layer l. Residency: the
+// host launches this kernel only for grids of at most one workgroup per CU. A neighbour that never shows up (cannot
+// happen on a resident grid) ends the spin after ~1e7 polls with an error code instead of a hang.
 static constexpr int DP_MAX_LAYERS = 12;
 struct DpPersistP {
   DdsP layer[DP_MAX_LAYERS];
   int nlayers;
   DurP dur;
-  unsigned* progress; int prog_bs;      // [B][prog_bs] progress words
+  DdsG g;                               // halo granule arenas
   unsigned* state;                      // [0] epoch, [1] finished workgroups of this run, [2] error code, [4 + b] finished tiles of utterance b
   int* err_host;                        // pinned host word: set when a neighbour wait gave up
 };
+static_assert(sizeof(DpPersistP) <= 4096, "kernel arguments are limited to 4 KB");
 template <int NVT>
 __global__ __launch_bounds__(512) void dp_persist_kernel(DpPersistP p) {
   PE_KTRACE(14);
@@ -1975,28 +2095,14 @@ __global__ __launch_bounds__(512) void dp_persist_kernel(DpPersistP p) {
   const unsigned base = epoch * 64u;
   __syncthreads();
   if (ct < nct) {
-    unsigned* prog = p.progress + (long)b * p.prog_bs;
+    int gerr = 0;
     for (int l = 0; l < p.nlayers; ++l) {
-      if (l > 0) {
-        // the neighbours' columns of layer l-1 (its halo) must be in memory; their having finished l-1 also means they
-        // no longer read the buffer this layer overwrites (two buffers alternate)
-        if (tid < 2) {
-          const int n = ct + (tid == 0 ? -1 : 1);
-          if (n >= 0 && n < nct) {
-            long spins = 0;
-            while (pe_ld_flag(prog + n) < base + (unsigned)l) {
-              pe_spin_pause();
-              if (++spins > (1L << 23)) { pe_st_flag(p.state + 2, 1u); *p.err_host = 1; break; }
-            }
-          }
-        }
-        __syncthreads();
-      }
-      dds_layer16_body<NVT, true>(p.layer[l], ct, b, lsm);
+      dds_layer16_body<NVT, true>(p.layer[l], ct, b, lsm, &p.g, base, &gerr);
+      // the layer's own columns are re-read by other waves of this workgroup in the next layer (plain stores -> plain loads)
       pe_drain_stores();
       __syncthreads();
-      if (tid == 0) pe_st_flag(prog + ct, base + (unsigned)(l + 1));
     }
+    if (gerr) { pe_st_flag(p.state + 2, 1u); *p.err_host = 1; }
     // ---- durations: the workgroup that completes the utterance's last tile (every spline epilogue is in memory then)
     if (tid == 0) flag[0] = pe_atomic_inc(p.state + 4 + b);
     __syncthreads();

@@ -15,6 +15,8 @@ namespace pe { extern thread_local long g_launches; }   // kernel launches issue
 // agent-scope accesses / polling helpers (GPU: sc1 cache policy, see below)
 inline float pe_ld_sc1(const float* p) { return *p; }
 inline void pe_st_sc1(float* p, float v) { *p = v; }
+inline unsigned long long pe_ld_gran(const unsigned long long* p) { return *(volatile const unsigned long long*)p; }
+inline void pe_st_gran(unsigned long long* p, unsigned long long v) { *(volatile unsigned long long*)p = v; }
 inline unsigned pe_ld_flag(const unsigned* p) { return *(volatile const unsigned*)p; }
 inline void pe_st_flag(unsigned* p, unsigned v) { *(volatile unsigned*)p = v; }
 inline unsigned pe_atomic_inc(unsigned* p) { const unsigned o = *p; *p = o + 1; return o; }
@@ -150,6 +152,13 @@ __device__ __forceinline__ float pe_ld_sc1(const float* p) {
 }
 __device__ __forceinline__ void pe_st_sc1(float* p, float v) {
   __hip_atomic_store(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// 8-byte {tag, value} granules: the data is its own flag (one fabric round trip per hand-off, no drain, no fence)
+__device__ __forceinline__ unsigned long long pe_ld_gran(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void pe_st_gran(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ unsigned pe_ld_flag(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void pe_st_flag(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

@@ -435,3 +435,32 @@ def test_every_profiled_instantiation_is_parity_tested():
     missing = sorted(profiled - SEEN)
     assert not missing, f"profiled but never compared with the oracle: {missing}; seen: {sorted(SEEN)}"
 
+
+
+def test_engine_group_two_engines_on_one_gpu(monkeypatch):
+    """pe_group_* on hardware: two engines of one process (the box has one GPU, so both on device 0) with the packed
+    weights copied arena to arena, shards run by two host threads concurrently. Noise scales 0 make the result
+    deterministic: every utterance must equal what a single engine returns, in the caller's order."""
+    from piper_amd import dist
+    from piper_amd.group import EngineGroup
+    cfg, w = voice("medium")
+    blob = W.pack_blob(cfg, w)
+    lens = [128, 40, 77, 9, 101, 64]
+    ids = [W.synthetic_phoneme_ids(T, 300 + i, id_max=129) for i, T in enumerate(lens)]
+    scales = (0.0, 1.0, 0.0)
+    grp = EngineGroup(blob, [0, 0])
+    rg = grp.synthesize_batch(ids, scales)
+    assign = grp.assignment(len(ids))
+    table = dist.shard_indices(lens, 2)
+    assert all(assign[i] == 0 for i in table[0]) and all(assign[i] == 1 for i in table[1])
+    eng = make_engine(monkeypatch, cfg, w)
+    rs = eng.synthesize_batch(ids, scales)
+    assert list(rg.frames) == list(rs.frames)
+    for i, (a, b) in enumerate(zip(rg.pcm, rs.pcm)):
+        # (the shards are other batch shapes than the single call: other kernel routes, last-bit float differences)
+        assert a.shape == b.shape and np.max(np.abs(a.astype(np.int32) - b.astype(np.int32))) <= 2, f"utterance {i}"
+    for _ in range(3):                                   # repeated calls, other shapes
+        r2 = grp.synthesize_batch(ids[::-1][:3], scales)
+        assert np.max(np.abs(r2.pcm[0].astype(np.int32) - rs.pcm[5].astype(np.int32))) <= 2
+    eng.close()
+    grp.close()
