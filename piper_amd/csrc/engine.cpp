@@ -1902,7 +1902,9 @@ void Engine::run_stage(char which, const std::string& key) {
     auto it = graphs_.find(key);
     if (it == graphs_.end()) {
       hipGraph_t g = nullptr;
-      PE_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+      // relaxed: engines of one process (pe_group_*) allocate / synchronise on their own threads while another one
+      // captures; nothing inside a capture region here is one of the calls the stricter modes guard against
+      PE_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeRelaxed));
       try {
         dispatch_stage(which);
       } catch (...) {

@@ -1547,9 +1547,10 @@ __device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b
   float* ob = p.out + (long)b * p.o_bs;
   const int pad = (p.dw_k - 1) / 2 * p.dw_dil;
   const bool fold = p.pre_z != nullptr;
-  // this wave's 1x1-conv weight row blocks: in flight under phase 1
+  // this wave's 1x1-conv weight row blocks: in flight under phase 1 (in the persistent kernel they are requested after
+  // the halo granules have arrived: the granule bookkeeping and 96 weight registers do not fit together)
   ColW<2 * NVT> gw;
-  col_gemm16_fetch<2 * NVT>(gw, p.wp16, p.bias, H, Hp, Hp, wv, lane);
+  if (!SC1) col_gemm16_fetch<2 * NVT>(gw, p.wp16, p.bias, H, Hp, Hp, wv, lane);
 
   int red_flip = 0;
   auto col_sum = [&](float x) -> float { return pe_col_sum16(x, red, red_flip, wv, lane, col); };
@@ -1595,34 +1596,35 @@ __device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b
       pb[k] = pe_row_load(pbd, cv ? c : -1);
     }
     if (SC1 && (xhalo || zhalo)) {
-      // all granule loads go out together; the ones whose tag is still old are re-read until it arrives
-      const unsigned long long* ga[NVT + 1][2];
+      // all granule loads go out together; the ones whose tag is still old are re-read until it arrives. Slot k = NVT
+      // is z; bit 2k + h of `need` = tap h (0: left, 1: right) of slot k comes from a neighbour.
+      auto gaddr = [&](int k, int h) -> const unsigned long long* {
+        const int tt = t + 2 * h * p.dw_dil - pad;
+        const int side = h == 0 ? 1 : 0, tile = ctile + (h == 0 ? -1 : 1);
+        const int j = h == 0 ? tt - (t0 - NC) - (NC - DDS_HALO) : tt - (t0 + NC);
+        return k == NVT ? gza(tile, p.zin_par, side, p.zin_row) : gxa(tile, p.gin_slot, side, rl + 32 * k, j);
+      };
       unsigned long long gv[NVT + 1][2];
-      unsigned want[NVT + 1];
+      unsigned need = 0;
+      const unsigned wantx = gbase + p.gin_tag, wantz = gbase + p.zin_tag;
 #pragma unroll
-      for (int k = 0; k <= NVT; ++k) {
-        const bool isz = k == NVT;
-        const int c = rl + 32 * k;
-        want[k] = gbase + (isz ? p.zin_tag : p.gin_tag);
+      for (int k = 0; k <= NVT; ++k)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int tt = t + 2 * h * p.dw_dil - pad;
-          const bool need = ok && p.dw_k == 3 && tt >= 0 && tt < L && !own(tt) && (isz ? zhalo : (xhalo && c < H));
-          const int side = h == 0 ? 1 : 0, tile = ctile + (h == 0 ? -1 : 1);
-          const int j = h == 0 ? tt - (t0 - NC) - (NC - DDS_HALO) : tt - (t0 + NC);
-          ga[k][h] = need ? (isz ? gza(tile, p.zin_par, side, p.zin_row) : gxa(tile, p.gin_slot, side, c, j)) : nullptr;
-          gv[k][h] = need ? pe_ld_gran(ga[k][h]) : 0ull;
+          const bool nd = ok && p.dw_k == 3 && tt >= 0 && tt < L && !own(tt) && (k == NVT ? zhalo : (xhalo && rl + 32 * k < H));
+          if (nd) need |= 1u << (2 * k + h);
+          gv[k][h] = nd ? pe_ld_gran(gaddr(k, h)) : 0ull;
         }
-      }
       for (long spins = 0;; ++spins) {
         bool all = true;
 #pragma unroll
         for (int k = 0; k <= NVT; ++k)
 #pragma unroll
           for (int h = 0; h < 2; ++h)
-            if (ga[k][h] && (unsigned)(gv[k][h] >> 32) < want[k]) {
+            if (((need >> (2 * k + h)) & 1u) && (unsigned)(gv[k][h] >> 32) < (k == NVT ? wantz : wantx)) {
               all = false;
-              gv[k][h] = pe_ld_gran(ga[k][h]);
+              gv[k][h] = pe_ld_gran(gaddr(k, h));
             }
         if (all) break;
         pe_spin_pause();
@@ -1632,11 +1634,12 @@ __device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b
       for (int k = 0; k < NVT; ++k)
 #pragma unroll
         for (int h = 0; h < 2; ++h)
-          if (ga[k][h]) xv[k][2 * h] = __uint_as_float((unsigned)gv[k][h]);
+          if ((need >> (2 * k + h)) & 1u) xv[k][2 * h] = __uint_as_float((unsigned)gv[k][h]);
 #pragma unroll
       for (int h = 0; h < 2; ++h)
-        if (ga[NVT][h]) zt[2 * h] = __uint_as_float((unsigned)gv[NVT][h]) * p.z_scale;
+        if ((need >> (2 * NVT + h)) & 1u) zt[2 * h] = __uint_as_float((unsigned)gv[NVT][h]) * p.z_scale;
     }
+    if (SC1) col_gemm16_fetch<2 * NVT>(gw, p.wp16, p.bias, H, Hp, Hp, wv, lane);
     if (fold) {
 #pragma unroll
       for (int k = 0; k < NVT; ++k)
