@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <shared_mutex>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -11,6 +12,17 @@
 namespace pe {
 
 thread_local long g_launches = 0;
+
+// Engines that share a process (pe_group_*: one per device, each on its own thread) must not be inside a HIP call while
+// another one CAPTURES a graph: allocations / synchronising copies on a second thread invalidate a capture in progress on
+// this runtime, whatever the capture mode. Every public entry holds this lock shared; a capture takes it exclusively.
+// A single engine per process never contends.
+static std::shared_mutex g_capture_mu;
+static thread_local int g_entry_depth = 0;
+struct EntryLock {
+  EntryLock() { if (g_entry_depth++ == 0) g_capture_mu.lock_shared(); }
+  ~EntryLock() { if (--g_entry_depth == 0) g_capture_mu.unlock_shared(); }
+};
 
 static inline int rup(int v, int m) { return (v + m - 1) / m * m; }
 
@@ -1364,6 +1376,7 @@ void Engine::prof_end(int row, double flops) {
 
 void Engine::upload(const int64_t* ids, const int64_t* offsets, int B, const float scales[3],
                     const int64_t* sids, const NoiseIn* noise) {
+  EntryLock entry_lock;
   if (B <= 0 || B > 4096) throw std::runtime_error("batch size must be in [1, 4096]");
   PE_HIP(hipSetDevice(device_));
   B_ = B;
@@ -1902,20 +1915,29 @@ void Engine::run_stage(char which, const std::string& key) {
     auto it = graphs_.find(key);
     if (it == graphs_.end()) {
       hipGraph_t g = nullptr;
-      // relaxed: engines of one process (pe_group_*) allocate / synchronise on their own threads while another one
-      // captures; nothing inside a capture region here is one of the calls the stricter modes guard against
-      PE_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeRelaxed));
+      hipGraphExec_t ex = nullptr;
+      // exclusive: no other engine of this process is inside a HIP call while this one captures (see g_capture_mu)
+      g_capture_mu.unlock_shared();
+      g_capture_mu.lock();
       try {
-        dispatch_stage(which);
+        PE_HIP(hipStreamBeginCapture(stream_, hipStreamCaptureModeThreadLocal));
+        try {
+          dispatch_stage(which);
+        } catch (...) {
+          hipStreamEndCapture(stream_, &g);
+          if (g) hipGraphDestroy(g);
+          throw;
+        }
+        PE_HIP(hipStreamEndCapture(stream_, &g));
+        PE_HIP(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+        PE_HIP(hipGraphDestroy(g));
       } catch (...) {
-        hipStreamEndCapture(stream_, &g);
-        if (g) hipGraphDestroy(g);
+        g_capture_mu.unlock();
+        g_capture_mu.lock_shared();
         throw;
       }
-      PE_HIP(hipStreamEndCapture(stream_, &g));
-      hipGraphExec_t ex = nullptr;
-      PE_HIP(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
-      PE_HIP(hipGraphDestroy(g));
+      g_capture_mu.unlock();
+      g_capture_mu.lock_shared();
       if (graphs_.size() > 64) drop_graphs();
       it = graphs_.emplace(key, ex).first;
       graph_launches_[key] = g_launches - l0;
@@ -1949,6 +1971,7 @@ void Engine::drop_graphs() {
 }
 
 void Engine::run() {
+  EntryLock entry_lock;
   PE_HIP(hipSetDevice(device_));
   const int B = B_;
   spec_pending_ = false;
@@ -2026,6 +2049,7 @@ void Engine::finish_stage_b_sizes() {
 }
 
 bool Engine::finish_run() {
+  EntryLock entry_lock;
   if (!spec_pending_) return true;
   spec_pending_ = false;
   PE_HIP(hipStreamSynchronize(stream_));
@@ -2042,6 +2066,7 @@ bool Engine::finish_run() {
 }
 
 void Engine::download(bool want_audio, bool want_pcm) {
+  EntryLock entry_lock;
   auto grow = [&](size_t total) {
     if (want_audio && total > h_audio_cap_) {
       if (h_audio_) PE_HIP(hipHostFree(h_audio_));
@@ -2081,6 +2106,7 @@ void Engine::download(bool want_audio, bool want_pcm) {
 }
 
 int Engine::stream_begin(const int64_t* ids, int64_t n, const float scales[3], int64_t sid, const NoiseIn* noise) {
+  EntryLock entry_lock;
   const int64_t offs[2] = {0, n};
   const int64_t sids[1] = {sid < 0 ? 0 : sid};
   upload(ids, offs, 1, scales, sids, noise);
@@ -2110,6 +2136,7 @@ int Engine::stream_begin(const int64_t* ids, int64_t n, const float scales[3], i
 }
 
 bool Engine::stream_next(int chunk_frames, const float** audio, const int16_t** pcm, int64_t* nsamples) {
+  EntryLock entry_lock;
   if (!s_active_ || s_pos_ >= s_frames_) {
     s_active_ = false;
     if (nsamples) *nsamples = 0;
