@@ -266,7 +266,7 @@ def test_engine_group_matches_single_engine(emu_lib):
     grp.close()
 
 
-@pytest.mark.parametrize("preset,lens", [("tiny", [37, 16, 5]), ("medium", [40])])
+@pytest.mark.parametrize("preset,lens", [("tiny", [37, 16]), ("medium", [24])])
 def test_persistent_duration_predictor_is_bit_identical(emu_lib, monkeypatch, preset, lens):
     """dp_persist_kernel (the 12 DDSConv layers + durations as one launch, column tiles exchanging halo granules) against
     one launch per layer, on the emulator's concurrent-block scheduler: same logw bits, same durations, repeated runs
@@ -277,8 +277,8 @@ def test_persistent_duration_predictor_is_bit_identical(emu_lib, monkeypatch, pr
     pers = Engine(blob=blob, lib=emu_lib)
     monkeypatch.setenv("PIPER_HIP_PERSIST_DP", "0")
     plain = Engine(blob=blob, lib=emu_lib)
-    for rep in range(3):
-        use = lens if rep != 1 else lens[:1]
+    for rep in range(2):
+        use = lens if rep == 0 else lens[:1]
         ids = [W.synthetic_phoneme_ids(T, 70 + i + rep, id_max=cfg.n_vocab - 1) for i, T in enumerate(use)]
         nw, nz = _noise(cfg, len(use), max(use), 5 + rep)
         a = pers.synthesize_batch(ids, (0.667, 1.0, 0.8), noise_w=nw, noise_z=nz)
