@@ -436,6 +436,18 @@ void Engine::init(const WeightSet& ws) {
         st.rb.push_back(cv);
         st.rb_host.push_back(std::move(hv));
       }
+      {
+        // sum of the resblocks' last biases: the K-concatenated last step adds it once
+        std::vector<float> bs(skeleton_ ? 0 : (size_t)ch, 0.f);
+        for (int j = 0; j < nk; ++j) {
+          const std::string rb = "dec.resblocks." + std::to_string(i * nk + j);
+          const std::string bn = rb + (arch_[A_RESBLOCK] == 1 ? ".convs2." : ".convs.") + std::to_string(nd - 1) + ".bias";
+          if (!ws.has(bn) || ws.get(bn).numel() != ch) throw std::runtime_error(bn + ": bias size mismatch");
+          if (!skeleton_)
+            for (int c = 0; c < ch; ++c) bs[c] += ws.get(bn).data[c];
+        }
+        st.last_bias_sum = dev_alloc((size_t)ch, skeleton_ ? nullptr : bs.data());
+      }
       build_mrf(st);
       build_mrf2(st);
       st.rb_host.clear();
@@ -503,6 +515,7 @@ void Engine::init(const WeightSet& ws) {
     for (const void* k : ks2) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     PE_HIP(hipFuncSetAttribute((const void*)conv_splitk_group_kernel<4, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     PE_HIP(hipFuncSetAttribute((const void*)conv_splitk_group_kernel<4, 2, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    PE_HIP(hipFuncSetAttribute((const void*)conv_splitk_sum_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     PE_HIP(hipFuncSetAttribute((const void*)attn_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     PE_HIP(hipFuncSetAttribute((const void*)attn_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     PE_HIP(hipFuncSetAttribute((const void*)attn_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
@@ -758,6 +771,39 @@ void Engine::group_end() {
     else PE_LAUNCH((conv_splitk_group_kernel<4, 2, 64>), grid, dim3(64 * NW), smem, ls_, g);
     kend(kh);
   }
+  group_.clear();
+}
+
+bool Engine::can_group_sum() const {
+  if (group_.size() < 2 || group_.size() > 3) return false;
+  const ConvP& a = group_[0];
+  for (const ConvP& c : group_)
+    if (c.rows != a.rows || c.Cin != a.Cin || c.nchunks != a.nchunks || c.x_bs != a.x_bs || c.x_cs != a.x_cs ||
+        c.r_bs != a.r_bs || c.r_cs != a.r_cs || c.in_slope != a.in_slope || c.epi != EPI_RESADD || c.xhalo > 96)
+      return false;
+  return true;
+}
+void Engine::group_end_sum(View out, const float* bias_sum, float alpha) {
+  grouping_ = false;
+  if (!can_group_sum()) throw std::runtime_error("internal: convs do not fit a K-concatenated launch");
+  ConvP q = group_[0];
+  q.nseg = (int)group_.size();
+  for (int i = 0; i < q.nseg; ++i) {
+    q.seg_x[i] = group_[i].x; q.seg_wp[i] = group_[i].wp;
+    q.seg_ntaps[i] = group_[i].ntaps; q.seg_dil[i] = group_[i].dil; q.seg_padl[i] = group_[i].padl;
+  }
+  q.res2 = group_[1].res;
+  q.res3 = q.nseg > 2 ? group_[2].res : nullptr;
+  q.bias = bias_sum;
+  q.out = out.p; q.o_bs = out.bs; q.o_cs = out.cs;
+  q.epi = EPI_ACCUM; q.mode = 3; q.alpha = alpha;      // (acc + bias + residuals) * alpha, nothing read back
+  q.tgroups = 1;
+  constexpr int NW = 4;
+  const size_t smem = std::max<size_t>((size_t)NW * KC * 128, (size_t)NW * 16 * 64) * sizeof(float);
+  const dim3 grid((group_ncols_ + 31) / 32, (q.rows + 31) / 32, B_);
+  const int kh = kbegin(prof_level_ >= 2 ? krow("conv_splitk_sum_kernel<4,2>") : 0, group_flops_, group_bytes_);
+  PE_LAUNCH((conv_splitk_sum_kernel<4, 2>), grid, dim3(64 * NW), smem, ls_, q);
+  kend(kh);
   group_.clear();
 }
 
@@ -1843,6 +1889,7 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
         // step d of every resblock in one grouped launch; each resblock keeps its own buffers, one pass sums them
         auto SV = [&](int k) { return View{side_[k], (long)st.ch * Ls, (int)Ls}; };
         View xin[3] = {u, u, u};
+        bool summed = false;
         const int nsteps = (int)st.rb[0].size();
         const bool rb1 = arch_[A_RESBLOCK] == 1;
         for (int d = 0; d < nsteps; ++d) {
@@ -1861,10 +1908,17 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
             }
             fl += 2.0 * fsum * mult * cv[d].macs_per_col;
           }
-          group_end();
+          // the last step's outputs are only ever summed: one GEMM over the concatenated K writes the mean directly
+          if (d == nsteps - 1 && group_mrf_ != 2 && can_group_sum()) {
+            group_end_sum(xs, st.last_bias_sum, inv_nk);
+            summed = true;
+          } else {
+            group_end();
+          }
         }
-        PE_LAUNCH(mrf_sum_kernel, dim3((Lmax + 255) / 256, st.ch, B), dim3(256), 0, stream_, side_[8], side_[3],
-                  nk == 3 ? side_[7] : (const float*)nullptr, xs.p, xs.bs, xs.cs, lens, mult, inv_nk);
+        if (!summed)
+          PE_LAUNCH(mrf_sum_kernel, dim3((Lmax + 255) / 256, st.ch, B), dim3(256), 0, stream_, side_[8], side_[3],
+                    nk == 3 ? side_[7] : (const float*)nullptr, xs.p, xs.bs, xs.cs, lens, mult, inv_nk);
       } else if (par) {
         auto SV = [&](int k) { return View{side_[k], (long)st.ch * Ls, (int)Ls}; };
         PE_HIP(hipEventRecord(ev_fork_, stream_));

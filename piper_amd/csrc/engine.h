@@ -144,6 +144,9 @@ class Engine {
   bool can_group(const PackedConv& pc, int ncols) const;
   void group_begin();
   void group_end();
+  // the recorded convs as ONE GEMM over their concatenated K, summed: out = (sum_j (res_j + conv_j)) * alpha
+  bool can_group_sum() const;
+  void group_end_sum(View out, const float* bias_sum, float alpha);
   int group_mrf_ = 1;                        // PIPER_HIP_GROUP_MRF=0: sibling resblock convs one launch each (A/B, tests)
   // LayerNorm folded into the next conv() call's input staging (split-K launches only; see can_fold_ln)
   struct LnIn { const float* g = nullptr; const float* b = nullptr; View out{nullptr, 0, 0}; };
@@ -257,6 +260,7 @@ class Engine {
     PackedConv up;
     int rate, ch;
     std::vector<std::vector<PackedConv>> rb;   // [resblock][conv] (ResBlock1: c1_0,c2_0,c1_1,...)
+    float* last_bias_sum = nullptr;            // sum over the resblocks of their LAST conv's bias (conv_splitk_sum_kernel)
     // fused MRF stage (mrf_fused_kernel): device step table, or null when the stage runs conv by conv
     void* mrf_steps = nullptr;
     int mrf_nsteps = 0, mrf_hx = 0, mrf_ws = 0, mrf_cp = 0, mrf_nbuf = 0;

@@ -65,6 +65,12 @@ struct ConvP {
   // later residual readers. Requires one chunk per wave (Cin <= 32 * waves).
   const float* ln_g; const float* ln_b;
   float* ln_out; long ln_o_bs; int ln_o_cs;
+  // conv_splitk_body<..., MS = true> only: K = the concatenation of nseg convs of one shape whose outputs are summed
+  // (segment 0 repeats x / wp / ntaps / dil / padl); res2 / res3 = the residual tensors of segments 1 / 2
+  int nseg;
+  const float* seg_x[3]; const float* seg_wp[3];
+  int seg_ntaps[3], seg_dil[3], seg_padl[3];
+  const float* res2; const float* res3;
 };
 
 // ---- shared epilogue of the conv GEMM kernels: one accumulator element (row, col) of utterance b.
@@ -387,7 +393,11 @@ void conv_mfma_kernel(ConvP p) {
 //   * partial tiles are summed through LDS in a fixed order (deterministic).
 // XW: columns of a wave's x slab: 64 (halo (taps-1)*dil <= 32), or 128 for the long-dilation resblock convs that are
 // launched in a group with their siblings (halo <= 96).
-template <int MT, bool GATE, int NW, int D, int XW>
+// MS (multi-segment): the K dimension is the concatenation of up to three convs that share the launch shape and are
+// SUMMED -- the last convs of an MRF stage's sibling resblocks, out = (sum_j (t_j + c_j(lrelu(t_j)))) / n -- each with its
+// own input tensor, kernel size, dilation and weights (ConvP::seg*): chunk c of the virtual 3 * Cin channels belongs to
+// segment c / nchunks. With 4 chunk lanes and 4 chunks per segment every wave gets one chunk of each conv.
+template <int MT, bool GATE, int NW, int D, int XW, bool MS = false>
 __device__ __forceinline__ void conv_splitk_body(const ConvP& p, const int b, float* sm) {
   constexpr int BN = 32, KH = KC / 2, XB = XW / 64;
   constexpr int NS = GATE ? (16 + NW - 1) / NW : (MT * 16 + NW - 1) / NW;    // epilogue slots per wave
@@ -401,11 +411,14 @@ __device__ __forceinline__ void conv_splitk_body(const ConvP& p, const int b, fl
   const int l31 = lane & 31, lhi = lane >> 5;
   const int mtile0 = blockIdx.y * MT;
   const int col = n0 + l31;
-  const int ntaps = p.ntaps, nchunks = p.nchunks;
-  const int wstride_mt = nchunks * ntaps * KH * 64;
+  const int ntaps = p.ntaps, nchunks = MS ? p.nchunks * p.nseg : p.nchunks;     // MS: chunks of the concatenated K
+  const int wstride_mt = p.nchunks * ntaps * KH * 64;
   const float* xb = p.x + (long)b * p.x_bs;
   const float slope = p.in_slope;
   const pe_rowsrc wsrc = pe_make_row(p.wp + (long)mtile0 * wstride_mt, MT * wstride_mt);
+  // per-segment views (MS): taps, dilation, left padding, weights, input of the segment that owns global chunk c
+  auto seg_of = [&](int c) { return MS ? c / p.nchunks : 0; };
+  auto taps_of = [&](int sg) { return MS ? p.seg_ntaps[sg] : ntaps; };
   float* xw = sm + wv * KC * XW;                  // this wave's slab: 32 channels x XW columns
   // K is dealt to the waves as (chunk lane, tap group): with p.tgroups == 1 wave w takes chunks w, w+NW, ...
   // and every tap; with 2 groups the waves form two halves that share the chunks and split the taps (a 5-tap
@@ -416,23 +429,39 @@ __device__ __forceinline__ void conv_splitk_body(const ConvP& p, const int b, fl
   const int tap_lo = wg * tpg, tap_hi = (tap_lo + tpg < ntaps) ? tap_lo + tpg : ntaps;
   const int mytaps = tap_hi > tap_lo ? tap_hi - tap_lo : 0;
   const int myc = (wi < nchunks && mytaps > 0) ? (nchunks - wi + CL - 1) / CL : 0;   // chunks wi, wi+CL, ...
-  const int nsteps = myc * mytaps;
+  int nsteps = myc * mytaps;
+  if (MS) {                                       // every tap of every chunk (tgroups == 1), taps differ per segment
+    nsteps = 0;
+    for (int k = 0; k < myc; ++k) nsteps += taps_of(seg_of(wi + CL * k));
+  }
 
   // x slab: one descriptor over the utterance's [Cin][stride] tensor, a per-lane column offset (poisoned outside
   // the row) and a wave-uniform row offset -- independent of L; columns >= L are zeroed when the slab is stored
   float xr[XB][KC];
-  const pe_rowsrc xd = pe_make_row(xb, p.Cin * p.x_cs);
-  const int xcol = n0 - p.padl + lane;
+  pe_rowsrc xd = pe_make_row(xb, p.Cin * p.x_cs);
+  int xcol = n0 - p.padl + lane;
   int xoff[XB];
 #pragma unroll
   for (int h = 0; h < XB; ++h) xoff[h] = (xcol + 64 * h >= 0 && xcol + 64 * h < p.x_cs) ? xcol + 64 * h : 0x3fffffff;
+  int ld_dil = p.dil, cur_dil = p.dil;            // dilation of the chunk in xr / of the chunk in the LDS slab
   auto load_x = [&](int c) {
+    int cc = c;
+    if (MS) {
+      const int sgr = seg_of(c), sg = sgr < p.nseg ? sgr : 0;
+      cc = sgr < p.nseg ? c - sg * p.nchunks : p.nchunks;      // (a wave without work loads "chunk nchunks": zeros)
+      xd = pe_make_row(p.seg_x[sg] + (long)b * p.x_bs, p.Cin * p.x_cs);
+      xcol = n0 - p.seg_padl[sg] + lane;
+      ld_dil = p.seg_dil[sg];
+#pragma unroll
+      for (int h = 0; h < XB; ++h) xoff[h] = (xcol + 64 * h >= 0 && xcol + 64 * h < p.x_cs) ? xcol + 64 * h : 0x3fffffff;
+    }
 #pragma unroll
     for (int h = 0; h < XB; ++h)
 #pragma unroll
-      for (int r = 0; r < KC; ++r) xr[h][r] = pe_row_load_so(xd, xoff[h], (c * KC + r) * p.x_cs);
+      for (int r = 0; r < KC; ++r) xr[h][r] = pe_row_load_so(xd, xoff[h], (cc * KC + r) * p.x_cs);
   };
   auto store_x = [&]() {
+    cur_dil = ld_dil;
 #pragma unroll
     for (int h = 0; h < XB; ++h) {
       const bool live = xcol + 64 * h < L;
@@ -448,6 +477,17 @@ __device__ __forceinline__ void conv_splitk_body(const ConvP& p, const int b, fl
   float a[D][MT][KH];
   int lk = 0, ltap = tap_lo;
   auto load_ring = [&](float (&dst)[MT][KH]) {
+    if (MS) {
+      const int c = wi + CL * lk, sgr = seg_of(c), sg = sgr < p.nseg ? sgr : 0;
+      const int nt = p.seg_ntaps[sg], ws = p.nchunks * nt * KH * 64;
+      // past the last chunk the descriptor has length 0: zeros, like the single-conv form's reads beyond its matrix
+      const pe_rowsrc wsg = pe_make_row(p.seg_wp[sg] + (long)mtile0 * ws, sgr < p.nseg ? MT * ws : 0);
+      const int off = PE_UNIFORM(((c - sg * p.nchunks) * nt + ltap) * (KH * 64));
+#pragma unroll
+      for (int i = 0; i < MT; ++i) load_frags<KH>(wsg, off + i * ws, lane, dst[i]);
+      if (++ltap >= nt) { ltap = 0; ++lk; }
+      return;
+    }
     const int off = PE_UNIFORM(((wi + CL * lk) * ntaps + ltap) * (KH * 64));
 #pragma unroll
     for (int i = 0; i < MT; ++i) load_frags<KH>(wsrc, off + i * wstride_mt, lane, dst[i]);
@@ -455,7 +495,7 @@ __device__ __forceinline__ void conv_splitk_body(const ConvP& p, const int b, fl
   };
   f32x16 acc[MT];
   auto mma = [&](int tap, const float (&af)[MT][KH]) {
-    const float* xp = xw + lhi * XW + tap * p.dil + l31;
+    const float* xp = xw + lhi * XW + tap * (MS ? cur_dil : p.dil) + l31;
     float bv[KH];
 #pragma unroll
     for (int kk = 0; kk < KH; ++kk) bv[kk] = xp[2 * kk * XW];
@@ -473,7 +513,7 @@ __device__ __forceinline__ void conv_splitk_body(const ConvP& p, const int b, fl
   if (n0 >= ncols) return;
   PE_STAMP(1, 1);
   const EpiFlags ef = epi_flags(p);
-  if (!GATE && XW == 64 && p.ln_g) {
+  if (!GATE && XW == 64 && !MS && p.ln_g) {
     // LayerNorm of the staged columns over ALL input channels: every wave holds one 32-channel chunk of the same 64
     // columns (lane = column); two fixed-order cross-wave sums (mean, then centred second moment, like ln_kernel).
     float* red1 = sm + NW * (KC * XW > MT * 16 * 64 ? KC * XW : MT * 16 * 64);     // behind the slabs / partial tiles
@@ -554,6 +594,8 @@ __device__ __forceinline__ void conv_splitk_body(const ConvP& p, const int b, fl
                              : p.out + (long)b * p.o_bs + (long)row * p.o_cs + col;
           if (rd_old) e_o1[i] = *d;
           if (ef.use_res) e_o2[i] = p.res[(long)b * p.r_bs + (long)row * p.r_cs + col];
+          if (MS && p.res2) e_b2[i] = p.res2[(long)b * p.r_bs + (long)row * p.r_cs + col];     // the other segments' residuals
+          if (MS && p.res3) e_o1[i] = p.res3[(long)b * p.r_bs + (long)row * p.r_cs + col];
           e_dst[i] = d;
         }
       }
@@ -578,7 +620,7 @@ __device__ __forceinline__ void conv_splitk_body(const ConvP& p, const int b, fl
             if (k + 1 < myc) load_x(wi + CL * (k + 1));
           }
           mma(tap, a[d]);
-          if (++tap >= tap_hi) { tap = tap_lo; ++k; }
+          if (++tap >= (MS ? taps_of(seg_of(wi + CL * k)) : tap_hi)) { tap = tap_lo; ++k; }
         }
         PE_SCHED_FENCE();
         load_ring(a[d]);
@@ -653,6 +695,14 @@ __global__ __launch_bounds__(64 * NW, XW == 64 ? 4 : 2) void conv_splitk_group_k
   const ConvP& p = g.c[gi];
   if ((int)blockIdx.y * 32 >= p.rows) return;              // a sibling with fewer row tiles than the grid
   conv_splitk_body<1, false, NW, D, XW>(p, (int)blockIdx.z - gi * g.B, sm);
+}
+// The siblings' LAST convs, whose outputs the MRF sums: one GEMM over the concatenated K (MS form of the body), one
+// output tensor -- no per-sibling outputs, no summing pass.
+template <int NW, int D>
+__global__ __launch_bounds__(64 * NW, 2) void conv_splitk_sum_kernel(ConvP p) {
+  PE_KTRACE(8);
+  PE_DYN_SMEM(float, sm);
+  conv_splitk_body<1, false, NW, D, 128, true>(p, blockIdx.z, sm);
 }
 
 // The split-K kernel on 16 output columns with the 16x16x4 f32 MFMA, for launches that are MFMA-pipe bound inside a

@@ -159,8 +159,10 @@ FORCED = [
     ("medium", [128, 77, 16, 33], {"PIPER_HIP_COLCHAIN": 2}, {"colchain_kernel<6>", "lngemm_kernel<6>"}),
     ("medium", [128, 31], {"PIPER_HIP_COLCHAIN": 0}, {"ln_kernel<0>", "conv_splitk_kernel<1,false,4,4>"}),
     # sibling resblock convs of the 128-channel stage as grouped launches (64- and 128-column slabs), and one by one
-    ("medium", [128, 40], {}, {"conv_splitk_group_kernel<4,2,64>", "conv_splitk_group_kernel<4,2,128>"}),
-    ("high", [40], {}, {"conv_splitk_group_kernel<4,2,64>"}),
+    # (the last step, whose outputs the MRF only sums, is one GEMM over the concatenated K; GROUP_MRF=2: kept apart)
+    ("medium", [128, 40], {}, {"conv_splitk_group_kernel<4,2,64>", "conv_splitk_sum_kernel<4,2>"}),
+    ("medium", [100], {"PIPER_HIP_GROUP_MRF": 2}, {"conv_splitk_group_kernel<4,2,64>", "conv_splitk_group_kernel<4,2,128>"}),
+    ("high", [40], {}, {"conv_splitk_group_kernel<4,2,64>", "conv_splitk_sum_kernel<4,2>"}),
     ("medium", [128], {"PIPER_HIP_GROUP_MRF": 0}, {"conv_splitk_kernel<1,false,4,4>"}),
     # split-K variants: 4/8-wave only (no 16-column form), 12-wave everywhere, 16-column form everywhere
     ("medium", [128], {"PIPER_HIP_SPLITK16": 0, "PIPER_HIP_WIDE_SPLITK": 0},
