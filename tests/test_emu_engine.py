@@ -245,7 +245,7 @@ def test_engine_group_matches_single_engine(emu_lib):
     from piper_amd.group import EngineGroup
     cfg = W.preset("tiny")
     blob = W.pack_blob(cfg, W.synthetic_weights(cfg, 7))
-    lens = [9, 33, 5, 21, 17]
+    lens = [9, 21, 5]
     ids = [W.synthetic_phoneme_ids(T, 40 + i, id_max=cfg.n_vocab - 1) for i, T in enumerate(lens)]
     scales = (0.0, 1.1, 0.0)
     grp = EngineGroup(blob, [0, 0], lib=emu_lib)
@@ -260,18 +260,20 @@ def test_engine_group_matches_single_engine(emu_lib):
     for a, b in zip(rg.pcm, rs.pcm):
         assert np.array_equal(a, b)
     # a second call with another shape reuses the engines
-    rg2 = grp.synthesize_batch(ids[:2], scales)
-    assert np.array_equal(rg2.pcm[1], rs.pcm[1])
+    rg2 = grp.synthesize_batch(ids[2:], scales)
+    assert np.array_equal(rg2.pcm[0], rs.pcm[2])
     eng.close()
     grp.close()
 
 
-@pytest.mark.parametrize("preset,lens", [("tiny", [37, 16]), ("medium", [24])])
+@pytest.mark.parametrize("preset,lens", [("tiny", [20, 9]), ("medium-dp", [17])])
 def test_persistent_duration_predictor_is_bit_identical(emu_lib, monkeypatch, preset, lens):
     """dp_persist_kernel (the 12 DDSConv layers + durations as one launch, column tiles exchanging halo granules) against
-    one launch per layer, on the emulator's concurrent-block scheduler: same logw bits, same durations, repeated runs
-    (the tags must keep growing across runs) and a changing batch shape."""
-    cfg = W.preset(preset)
+    one launch per layer, on the emulator's concurrent-block scheduler: same logw bits, same durations, a second run
+    (the tags must keep growing across runs) with another batch shape. "medium-dp" = the medium text encoder / duration
+    predictor (192 channels: the exact-width kernels) in front of a two-stage toy vocoder, to keep the emulator fast."""
+    cfg = (W.preset("medium", up_rates=(4, 4), up_kernel_sizes=(8, 8), up_initial=32, n_layers=1)
+           if preset == "medium-dp" else W.preset(preset))
     blob = W.pack_blob(cfg, W.synthetic_weights(cfg, 11))
     monkeypatch.setenv("PIPER_HIP_PERSIST_DP", "1")
     pers = Engine(blob=blob, lib=emu_lib)
@@ -279,7 +281,7 @@ def test_persistent_duration_predictor_is_bit_identical(emu_lib, monkeypatch, pr
     plain = Engine(blob=blob, lib=emu_lib)
     for rep in range(2):
         use = lens if rep == 0 else lens[:1]
-        ids = [W.synthetic_phoneme_ids(T, 70 + i + rep, id_max=cfg.n_vocab - 1) for i, T in enumerate(use)]
+        ids = [W.synthetic_phoneme_ids(T, 70 + i + rep, id_max=min(cfg.n_vocab - 1, 129)) for i, T in enumerate(use)]
         nw, nz = _noise(cfg, len(use), max(use), 5 + rep)
         a = pers.synthesize_batch(ids, (0.667, 1.0, 0.8), noise_w=nw, noise_z=nz)
         da = pers.durations()
