@@ -29,7 +29,7 @@ inline void pe_drain_stores() {}
 #define pe_mfma_16x16x4(a, b, c) emu_mfma_16x16x4((a), (b), (c))
 #define PE_WAVE_SYNC() emu::wave_sync()
 #define PE_OPAQUE(x) ((void)0)
-#define PE_UNIFORM(x) (x)
+#define PE_UNIFORM(x) (emu::uniform_check((long long)(x)), (x))     // checked: readfirstlane on the GPU
 #define PE_SCHED_FENCE() ((void)0)
 template <class T> inline T* pe_uniform_ptr(T* p) { return p; }
 // bounds-checked row load: element idx of a row of n floats, 0 outside [0, n)

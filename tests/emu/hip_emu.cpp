@@ -40,6 +40,7 @@ struct Fiber {
   void* sp;
   State st;
   emu_idx3 tid;
+  unsigned useq;                  // PE_UNIFORM calls made so far (uniform_check)
 };
 
 // Fibers of ALL blocks that are live at once: one block (ordinary launches) or the whole grid (launch_coop).
@@ -56,6 +57,7 @@ static std::vector<float> g_wave_scratch;      // [block slot][wave][4][64]
 static std::vector<char> g_smem;
 static size_t g_smem_stride = 0;
 static std::vector<emu_idx3> g_block_of;       // block index of each live block slot
+static std::vector<std::vector<long long>> g_uniform;   // [block slot * waves + wave]: values seen at the wave's PE_UNIFORM calls
 
 int lane() { return (g_cur % g_nthreads) & 63; }
 int wave() { return (g_cur % g_nthreads) >> 6; }
@@ -75,6 +77,21 @@ void block_sync() {
   yield_to_sched();
 }
 void yield() { yield_to_sched(); }     // stays RUNNABLE: the scheduler comes back after everyone else had a turn
+
+// PE_UNIFORM(x) is readfirstlane on the GPU: every lane silently gets lane 0's value. Here every lane of a wave must
+// present the SAME value at its n-th PE_UNIFORM call, or the kernel would compute something else on hardware.
+void uniform_check(long long v) {
+  const int nw = (g_nthreads + 63) / 64;
+  std::vector<long long>& seen = g_uniform[(size_t)(g_cur / g_nthreads) * nw + wave()];
+  const unsigned s = g_f[g_cur].useq++;
+  if (s == seen.size()) { seen.push_back(v); return; }
+  if (s > seen.size() || seen[s] != v) {
+    fprintf(stderr, "hip_emu: PE_UNIFORM call %u of wave %d is not wave-uniform (lane %d has %lld, an earlier lane %lld): "
+                    "readfirstlane would change the result on the GPU\n", s, wave(), lane(), v,
+            s < seen.size() ? seen[s] : -1LL);
+    abort();
+  }
+}
 
 static void fiber_main() {
   (*g_body)();
@@ -108,6 +125,7 @@ static void run_blocks(unsigned nthreads, int nblocks) {
   g_f.assign(total, Fiber{});
   const int nw = ((int)nthreads + 63) / 64;
   g_wave_scratch.assign((size_t)nblocks * nw * 4 * 64, 0.f);
+  g_uniform.assign((size_t)nblocks * nw, std::vector<long long>());
   for (int i = 0; i < total; ++i) {
     init_fiber(i);
     const unsigned l = (unsigned)i % nthreads, bx = blockDim.x, by = blockDim.y;

@@ -51,6 +51,7 @@ void launch(dim3 grid, dim3 block, size_t smem, const std::function<void()>& bod
 void launch_coop(dim3 grid, dim3 block, size_t smem, const std::function<void()>& body);
 void yield();        // a spinning thread lets the others run
 void wave_sync();    // all live lanes of the calling fiber's wave
+void uniform_check(long long v);   // PE_UNIFORM: aborts when the lanes of a wave disagree
 void block_sync();
 int lane();
 int wave();
