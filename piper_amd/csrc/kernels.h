@@ -1567,10 +1567,13 @@ __device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b
                                                  unsigned gbase = 0, int* gerr = nullptr) {
   constexpr int NC = 16;                        // sm: Y[Hp][16] | Z[Hp][16] | red[2][8][16]
   PE_STAMP(2, 0);
+  // The utterance length lives in device memory. As a separate launch (!SC1) nothing below uses it until every operand
+  // load has been issued against the row stride instead (Lb): its latency overlaps theirs, and the taps beyond the
+  // length are zeroed afterwards -- the conv's zero padding at the end of the utterance.
   const int L = p.lens[b];
   const int t0 = ctile * NC;
-  if (t0 >= L) return;
-  PE_STAMP(2, 1);
+  if (SC1 && t0 >= L) return;
+  const int Lb = SC1 ? L : p.x_cs;
   // SC1 = the layer runs inside dp_persist_kernel: its own columns travel through memory between the waves of this
   // workgroup only (plain stores and loads: a CU's vector L1 is coherent for its own waves, workgroup scope needs no
   // cache policy), its neighbours' boundary columns arrive as granules, and only z -- which the duration step of ANOTHER
@@ -1592,7 +1595,7 @@ __device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b
   float* red = Z + Hp * NC;
   const int tid = threadIdx.x, col = tid & 15, rl = tid >> 4, wv = PE_UNIFORM(tid >> 6), lane = tid & 63;
   const int t = t0 + col;
-  const bool ok = t < L;
+  const bool okb = t < Lb;
   const float* xb = p.x + (long)b * p.x_bs;
   float* ob = p.out + (long)b * p.o_bs;
   const int pad = (p.dw_k - 1) / 2 * p.dw_dil;
@@ -1611,10 +1614,11 @@ __device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b
   const pe_rowsrc wd = pe_make_row(p.dw_w, H * p.dw_k), bd = pe_make_row(p.dw_b, H);
   const pe_rowsrc g1d = pe_make_row(p.g1, H), b1d = pe_make_row(p.b1, H);
   float v[NVT], xc[NVT], gg[NVT], bb[NVT];
+  bool ok;                                        // t < L, set once the operand loads are in flight
   {
     float xv[NVT][MAXK], ww[NVT][MAXK], wb[NVT];
     // folded ConvFlow.pre: the three taps' z0 values and this channel's (w, b); zero-length descriptors when unused
-    const pe_rowsrc zd = pe_make_row(fold ? p.pre_z + (long)b * p.pre_z_bs : p.dw_b, fold ? L : 0);
+    const pe_rowsrc zd = pe_make_row(fold ? p.pre_z + (long)b * p.pre_z_bs : p.dw_b, fold ? Lb : 0);
     const pe_rowsrc pwd = pe_make_row(fold ? p.pre_w : p.dw_b, fold ? H : 0), pbd = pe_make_row(fold ? p.pre_b : p.dw_b, fold ? H : 0);
     float zt[MAXK], pw[NVT], pb[NVT];
     // taps outside this workgroup's 16 columns (kk = 0 and kk = 2 only: the halo is at most 9 columns) come from
@@ -1624,18 +1628,18 @@ __device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b
 #pragma unroll
     for (int kk = 0; kk < MAXK; ++kk) {
       const int tt = t + kk * p.dw_dil - pad;
-      const bool tv = ok && kk < p.dw_k && tt >= 0 && tt < L && (!zhalo || own(tt));
+      const bool tv = okb && kk < p.dw_k && tt >= 0 && tt < Lb && (!zhalo || own(tt));
       zt[kk] = (SC1 && fold && p.zin_par >= 0 ? (tv ? pe_ld_sc1(p.pre_z + (long)b * p.pre_z_bs + tt) : 0.f)
                                               : ldx(zd, tv ? tt : -1)) * p.z_scale;
     }
 #pragma unroll
     for (int k = 0; k < NVT; ++k) {
       const int c = rl + 32 * k;
-      const bool cv = ok && c < H;
+      const bool cv = okb && c < H;
 #pragma unroll
       for (int kk = 0; kk < MAXK; ++kk) {
         const int tt = t + kk * p.dw_dil - pad;
-        const bool tv = cv && kk < p.dw_k && tt >= 0 && tt < L;
+        const bool tv = cv && kk < p.dw_k && tt >= 0 && tt < Lb;
         xv[k][kk] = ldx(xd, (tv && (!xhalo || own(tt))) ? c * p.x_cs + tt : -1);
         ww[k][kk] = pe_row_load(wd, tv ? c * p.dw_k + kk : -1);
       }
@@ -1645,6 +1649,20 @@ __device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b
       pw[k] = pe_row_load(pwd, cv ? c : -1);
       pb[k] = pe_row_load(pbd, cv ? c : -1);
     }
+    if (!SC1) {
+      // first use of the length
+      if (t0 >= L) return;
+      PE_STAMP(2, 1);
+#pragma unroll
+      for (int kk = 0; kk < MAXK; ++kk) {
+        const int tt = t + kk * p.dw_dil - pad;
+        const bool in = t < L && tt < L;
+        zt[kk] = in ? zt[kk] : 0.f;
+#pragma unroll
+        for (int k = 0; k < NVT; ++k) xv[k][kk] = in ? xv[k][kk] : 0.f;
+      }
+    }
+    ok = t < L;
     if (SC1 && (xhalo || zhalo)) {
       // all granule loads go out together; the ones whose tag is still old are re-read until it arrives. Slot k = NVT
       // is z; bit 2k + h of `need` = tap h (0: left, 1: right) of slot k comes from a neighbour.
