@@ -750,6 +750,9 @@ void Engine::group_end() {
   // group run in one or two rounds (8 waves: 64 / 128 KB, five rounds, slower than one launch per conv). The convs that
   // need the 128-column slab go in a launch of their own: two resident workgroups per CU carry ~420 of them, not 1260.
   constexpr int NW = 4;
+  // workgroups are dispatched in grid order (z slowest): the conv with the most taps goes first so that the longest
+  // workgroups do not form the tail of the launch
+  std::stable_sort(group_.begin(), group_.end(), [](const ConvP& a, const ConvP& b) { return a.ntaps > b.ntaps; });
   for (int wide = 0; wide < 2; ++wide) {
     ConvG g{};
     int n = 0, mt = 0;
@@ -801,6 +804,7 @@ void Engine::group_end_sum(View out, const float* bias_sum, float alpha) {
   constexpr int NW = 4;
   const size_t smem = std::max<size_t>((size_t)NW * KC * 128, (size_t)NW * 16 * 64) * sizeof(float);
   const dim3 grid((group_ncols_ + 31) / 32, (q.rows + 31) / 32, B_);
+  // (a 4-deep weight ring measured slower than 2: hifigan stage 0.345 vs 0.338 ms)
   const int kh = kbegin(prof_level_ >= 2 ? krow("conv_splitk_sum_kernel<4,2>") : 0, group_flops_, group_bytes_);
   PE_LAUNCH((conv_splitk_sum_kernel<4, 2>), grid, dim3(64 * NW), smem, ls_, q);
   kend(kh);
