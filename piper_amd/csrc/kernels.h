@@ -1437,18 +1437,6 @@ struct DdsG {
   unsigned long long* gz; long gz_bs; int gz_ts;
 };
 static constexpr int DDS_HALO = 9;          // widest depthwise halo of the duration predictor (kernel 3, dilation 9)
-// Spin until a granule carries the wanted tag (tags of a slot only grow); gives up after ~1e7 polls (never on a
-// resident grid) and reports through `err`.
-__device__ __forceinline__ float pe_gran_wait(const unsigned long long* g, unsigned want, int* err) {
-  long spins = 0;
-  unsigned long long v = pe_ld_gran(g);
-  while ((unsigned)(v >> 32) < want) {
-    pe_spin_pause();
-    if (++spins > (1L << 23)) { *err = 1; break; }
-    v = pe_ld_gran(g);
-  }
-  return __uint_as_float((unsigned)v);
-}
 __device__ __forceinline__ unsigned long long pe_gran(unsigned tag, float v) {
   return ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(v);
 }
