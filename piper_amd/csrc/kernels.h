@@ -1035,6 +1035,23 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
   PE_STAMP(0, 2);
   __syncthreads();
   PE_STAMP(0, 3);
+  // relative-key partial products R[q][r] = Q . rel_k^T (a 32 x (2w+1) GEMM over dk, a quarter of the channel steps
+  // per wave): computed here, next to the score tiles -- both only need Q and the tables in LDS -- so that one barrier
+  // publishes the scores and the partials together; they are added onto the band in step 2a
+  float* part = RV + nrel * dk;                        // [4 waves][32 queries][16 offsets]
+  {
+    f32x16 racc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) racc[r] = 0.f;
+    for (int s2 = wv; s2 < nk2; s2 += 4) {
+      const int d = 2 * s2 + lhi;
+      racc = pe_mfma_32x32x2(Qs[d * ATT_QB + l31], l31 < nrel ? RK[l31 * dk + d] : 0.f, racc);
+    }
+    if (l31 < 16) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) part[(wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * 16 + l31] = racc[r];
+    }
+  }
   {
     for (int kt = wv; kt < nkt; kt += 4) {
       f32x16 acc;
@@ -1063,23 +1080,9 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
   PE_STAMP(0, 4);
   __syncthreads();
   PE_STAMP(0, 5);
-  // ---- 2a. relative-key band: S[i][i+r-w] += (q_i/sqrt(dk)) . rel_k[r].  R[q][r] = Q . rel_k^T is a 32 x (2w+1)
-  // GEMM over dk: each wave takes a quarter of the channel steps on the MFMA, the four partial tiles meet in LDS
-  // and are scattered onto the band.
+  // ---- 2a. relative-key band: S[i][i+r-w] += (q_i/sqrt(dk)) . rel_k[r]: the four waves' partial tiles (above) meet
+  // here and are scattered onto the band.
   {
-    float* part = RV + nrel * dk;                      // [4 waves][32 queries][16 offsets]
-    f32x16 racc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) racc[r] = 0.f;
-    for (int s2 = wv; s2 < nk2; s2 += 4) {
-      const int d = 2 * s2 + lhi;
-      racc = pe_mfma_32x32x2(Qs[d * ATT_QB + l31], l31 < nrel ? RK[l31 * dk + d] : 0.f, racc);
-    }
-    if (l31 < 16) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) part[(wv * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * 16 + l31] = racc[r];
-    }
-    __syncthreads();
     PE_STAMP(0, 6);
     for (int e = tid; e < ATT_QB * nrel; e += 256) {
       const int i = e % ATT_QB, r = e / ATT_QB;
