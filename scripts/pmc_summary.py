@@ -13,7 +13,7 @@ for d in sys.argv[1:]:
                 seen.add(key); calls[k] += 1
     names = sorted({c for k in acc for c in acc[k]})
     print('#', d, names)
-    for k, n in calls.most_common(14):
+    for k, n in calls.most_common(30):
         a = acc[k]
         line = '%-48s calls %5d' % (k[:48], n)
         if 'SQ_WAVE_CYCLES' in a:
