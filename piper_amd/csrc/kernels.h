@@ -417,8 +417,9 @@ __device__ __forceinline__ void conv_splitk_body(const ConvP& p, const int b, fl
   const float slope = p.in_slope;
   const pe_rowsrc wsrc = pe_make_row(p.wp + (long)mtile0 * wstride_mt, MT * wstride_mt);
   // per-segment views (MS): taps, dilation, left padding, weights, input of the segment that owns global chunk c
-  auto seg_of = [&](int c) { return MS ? c / p.nchunks : 0; };
-  auto taps_of = [&](int sg) { return MS ? p.seg_ntaps[sg] : ntaps; };
+  // (no integer division on the step path: nseg <= 3, two compares)
+  auto seg_of = [&](int c) { return MS ? (c >= p.nchunks) + (c >= 2 * p.nchunks) + (c >= 3 * p.nchunks) : 0; };
+  auto taps_of = [&](int sg) { return MS ? p.seg_ntaps[sg < 3 ? sg : 0] : ntaps; };
   float* xw = sm + wv * KC * XW;                  // this wave's slab: 32 channels x XW columns
   // K is dealt to the waves as (chunk lane, tap group): with p.tgroups == 1 wave w takes chunks w, w+NW, ...
   // and every tap; with 2 groups the waves form two halves that share the chunks and split the taps (a 5-tap
