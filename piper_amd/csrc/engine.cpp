@@ -541,6 +541,7 @@ void Engine::init(const WeightSet& ws) {
   if (const char* t = getenv("PIPER_HIP_SMALL")) small_tiles_ = atoi(t) != 0;
   if (const char* t = getenv("PIPER_HIP_PAR_MRF")) par_mrf_ = atoi(t) != 0;
   if (const char* t = getenv("PIPER_HIP_GROUP_MRF")) group_mrf_ = atoi(t);
+  if (const char* t = getenv("PIPER_HIP_PCM_ZC")) pcm_zc_ = atoi(t) != 0;
   if (const char* t = getenv("PIPER_HIP_FUSE_MRF")) fuse_mrf_ = atoi(t) != 0;   // A/B knob: 1 = fused MRF stage kernel
   if (const char* t = getenv("PIPER_HIP_SPLITK_MAX")) splitk_max_blocks_ = atol(t);   // tuning knob
   if (const char* t = getenv("PIPER_HIP_SPLITK16")) splitk16_ = atoi(t);              // A/B knob
@@ -576,6 +577,7 @@ void Engine::free_all() {
   if (wsB_) hipFree(wsB_);
   if (h_audio_) hipHostFree(h_audio_);
   if (h_pcm_) hipHostFree(h_pcm_);
+  if (h_pcm_zc_) hipHostFree(h_pcm_zc_);
   if (h_frames_) hipHostFree(h_frames_);
   if (ev0_) hipEventDestroy(ev0_);
   if (ev1_) hipEventDestroy(ev1_);
@@ -592,7 +594,7 @@ void Engine::free_all() {
   if (ev_fork_) hipEventDestroy(ev_fork_);
   for (float*& p : side_) { if (p) hipFree(p); p = nullptr; }
   if (stream_) hipStreamDestroy(stream_);
-  wsA_ = wsB_ = nullptr; h_audio_ = nullptr; h_pcm_ = nullptr; h_frames_ = nullptr;
+  wsA_ = wsB_ = nullptr; h_audio_ = nullptr; h_pcm_ = nullptr; h_pcm_zc_ = nullptr; h_frames_ = nullptr;
   ev0_ = ev1_ = ev_fork_ = nullptr; stream_ = nullptr;
 }
 
@@ -714,6 +716,13 @@ void Engine::ensure_stage_b(int Fmax) {
     PE_HIP(hipMalloc((void**)&wsB_, wsB_bytes_));
   }
   carve(wsB_);
+  if (pcm_zc_ && h_pcm_zc_cap_ < (size_t)Ss_) {       // one utterance's samples (the zero-copy path is B == 1 only)
+    PE_HIP(hipStreamSynchronize(stream_));
+    drop_graphs();                                     // the pointer is a kernel argument inside the graphs
+    if (h_pcm_zc_) PE_HIP(hipHostFree(h_pcm_zc_));
+    h_pcm_zc_cap_ = (size_t)Ss_;
+    PE_HIP(hipHostMalloc((void**)&h_pcm_zc_, h_pcm_zc_cap_ * sizeof(int16_t)));
+  }
   // per-branch buffers of the parallel MRF schedule (only used while a stage is small): allocated here,
   // outside any graph capture
   // (the grouped schedule only applies below 700 64x64 blocks per stage: 700 * 4096 floats bound its buffers)
@@ -1958,8 +1967,10 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
     const int K = 7, Lmax = Fmax * hop_;
     PE_LAUNCH(conv_post_kernel, dim3((Lmax + POST_SPB - 1) / POST_SPB, B), dim3(256), 0, stream_, cur.p,
               cur.bs, cur.cs, post_w_, post_cin_, 0.01f, lens, hop_, audio_, Ss_, absmax_);
+    // (zero_absmax marks the streaming window path, which delivers per chunk from the device buffer)
+    int16_t* zc = (pcm_zc_ && B == 1 && !zero_absmax) ? h_pcm_zc_ : nullptr;
     PE_LAUNCH(pcm16_kernel, dim3((Lmax + 255) / 256, B), dim3(256), 0, stream_, audio_, Ss_, absmax_, lens, hop_,
-              pcm_, Ss_);
+              pcm_, Ss_, zc);
     prof_end(4, 2.0 * fsum * hop_ * post_cin_ * K);
   }
 }
@@ -2137,14 +2148,21 @@ void Engine::download(bool want_audio, bool want_pcm) {
       PE_HIP(hipHostMalloc((void**)&h_pcm_, h_pcm_cap_ * sizeof(int16_t)));
     }
   };
+  // one utterance: pcm16_kernel already wrote the samples into pinned host memory (zero-copy); nothing to enqueue
+  const bool zc = pcm_zc_ && B_ == 1 && h_pcm_zc_ != nullptr;
+  pcm_zc_live_ = false;
   if (spec_pending_ && B_ == 1 && (want_audio || want_pcm)) {
     // one utterance, speculative run: the copies are enqueued for the guessed length (>= the real one when the guess
     // holds) behind stage B, so that one synchronisation ends the whole call; the host view is trimmed afterwards
     const size_t n = (size_t)spec_fg_ * hop_;
     grow(n);
     if (want_audio) PE_HIP(hipMemcpyAsync(h_audio_, audio_, n * sizeof(float), hipMemcpyDeviceToHost, stream_));
-    if (want_pcm) PE_HIP(hipMemcpyAsync(h_pcm_, pcm_, n * sizeof(int16_t), hipMemcpyDeviceToHost, stream_));
-    if (finish_run()) return;                  // synchronises; sample_off_ now holds the real length
+    if (want_pcm && !zc) PE_HIP(hipMemcpyAsync(h_pcm_, pcm_, n * sizeof(int16_t), hipMemcpyDeviceToHost, stream_));
+    if (finish_run()) {                        // synchronises; sample_off_ now holds the real length
+      pcm_zc_live_ = zc;
+      return;
+    }
+    // the guess missed: stage B was re-issued (its pcm16_kernel writes the host buffer again); copies below
   } else {
     finish_run();
   }
@@ -2155,12 +2173,13 @@ void Engine::download(bool want_audio, bool want_pcm) {
       PE_HIP(hipMemcpyAsync(h_audio_ + sample_off_[b], audio_ + (size_t)b * Ss_,
                             (size_t)(sample_off_[b + 1] - sample_off_[b]) * sizeof(float), hipMemcpyDeviceToHost,
                             stream_));
-  if (want_pcm)
+  if (want_pcm && !zc)
     for (int b = 0; b < B_; ++b)
       PE_HIP(hipMemcpyAsync(h_pcm_ + sample_off_[b], pcm_ + (size_t)b * Ss_,
                             (size_t)(sample_off_[b + 1] - sample_off_[b]) * sizeof(int16_t), hipMemcpyDeviceToHost,
                             stream_));
   PE_HIP(hipStreamSynchronize(stream_));
+  pcm_zc_live_ = zc;
 }
 
 int Engine::stream_begin(const int64_t* ids, int64_t n, const float scales[3], int64_t sid, const NoiseIn* noise) {

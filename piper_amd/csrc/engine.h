@@ -87,7 +87,7 @@ class Engine {
   int batch() const { return B_; }
   const std::vector<int64_t>& sample_offsets() { finish_run(); return sample_off_; }
   const float* audio_host() const { return h_audio_; }
-  const int16_t* pcm_host() const { return h_pcm_; }
+  const int16_t* pcm_host() const { return pcm_zc_live_ ? h_pcm_zc_ : h_pcm_; }
   const std::vector<int32_t>& durations_host();   // concatenated per id, same offsets as ids
   const std::vector<int32_t>& frames_host() { finish_run(); return frames_h_; }
   void debug_tensor(const std::string& name, int b, std::vector<float>& out, int* rows, int* cols);
@@ -347,6 +347,11 @@ class Engine {
   // host pinned
   float* h_audio_ = nullptr; size_t h_audio_cap_ = 0;
   int16_t* h_pcm_ = nullptr; size_t h_pcm_cap_ = 0;
+  // One utterance per call: pcm16_kernel also writes the samples straight into this pinned host buffer (zero-copy), so
+  // delivering the PCM costs no copy launch behind the graph -- the call ends with one stream synchronisation.
+  int16_t* h_pcm_zc_ = nullptr; size_t h_pcm_zc_cap_ = 0;
+  bool pcm_zc_live_ = false;                // the last run's PCM is in h_pcm_zc_
+  bool pcm_zc_ = true;                      // PIPER_HIP_PCM_ZC=0: always copy (A/B, tests)
   int* h_frames_ = nullptr;
 
   // profiling

@@ -2360,8 +2360,9 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* x, long x_b
 }
 
 // float -> int16 exactly as piper.cpp:420-431 (scale 32767/max(0.01,peak), clamp, truncate)
+// `host`: pinned host memory that also receives utterance 0's samples (zero-copy delivery of a one-utterance call), or null
 __global__ void pcm16_kernel(const float* audio, long a_bs, const unsigned* absmax, const int* lens,
-                             int len_mul, short* pcm, long p_bs) {
+                             int len_mul, short* pcm, long p_bs, short* host) {
   PE_KTRACE(18);
   const int b = blockIdx.y, L = lens[b] * len_mul;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2371,6 +2372,7 @@ __global__ void pcm16_kernel(const float* audio, long a_bs, const unsigned* absm
   float v = audio[(long)b * a_bs + t] * scale;
   v = fminf(fmaxf(v, -32768.0f), 32767.0f);
   pcm[(long)b * p_bs + t] = (short)v;
+  if (host && b == 0) host[t] = (short)v;
 }
 
 // Streaming decode: copy frames [win[0], win[0]+win[1]) of z [C][zs] into the window buffer [C][ws]
