@@ -1533,7 +1533,7 @@ void Engine::issue_stage_a() {
   const bool fold2 = can_fold_ln(enc_.empty() ? enc_proj_ : enc_[0].qkv, T) && can_fold_ln(enc_proj_, T);
   const float *pg = nullptr, *pb = nullptr;        // pending norm_layers_2 of the previous layer (input still in y)
   // small batches with the 192-channel encoder: norm_layers_2 + the q/k/v (or proj) conv as one launch (lngemm_kernel)
-  const bool chain_q = !fold2 && use_colchain(tsum, H_, 96);
+  const bool chain_q = !fold2 && use_colchain(tsum, colchain_max_ids_, H_, 96);
   for (auto& e : enc_) {
     if (pg && chain_q) {
       lngemm(y, pg, pb, x, e.qkv16, e.qkv.bias, 3 * H_, qkv, T, 2.0 * tsum * e.qkv.macs_per_col);
@@ -1561,7 +1561,7 @@ void Engine::issue_stage_a() {
     else if (ap.dk == 48) PE_LAUNCH(attn_kernel<48>, agrid, dim3(256), smem, stream_, ap);
     else PE_LAUNCH(attn_kernel<0>, agrid, dim3(256), smem, stream_, ap);
     kend(kh);
-    const bool chain_o = !fold1 && use_colchain(tsum, H_, 96);
+    const bool chain_o = !fold1 && use_colchain(tsum, colchain_max_ids_, H_, 96);
     if (chain_o) {
       // conv_o + residual + norm_layers_1 in one launch (the 192 x 192 GEMM fits one workgroup per 16 columns)
       ColP cp{};
@@ -1757,7 +1757,7 @@ void Engine::issue_flow() {
   auto VF = [&](float* p, int ch) { return View{p, (long)ch * Fs, Fs}; };
   const View fh = VF(fh_, H_), facts = VF(facts_, H_), fskip = VF(fskip_, H_);
   const int half = C_ / 2;
-  const bool chain = use_colchain(fsum, H_, half);
+  const bool chain = use_colchain(fsum, colchain_max_frames_, H_, half);
   for (size_t ri = 0; ri < rcls_.size(); ++ri) {
     Rcl& r = rcls_[ri];
     const View x0{zp_ + (long)r.in_off * Fs, (long)C_ * Fs, Fs};
@@ -1882,7 +1882,9 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
       const size_t need = (size_t)B * st.ch * Ls;
       const long blocks64 = (long)((Lmax + 63) / 64) * ((st.ch + 63) / 64) * B;
       const bool par = par_mrf_ && !prof_on_ && nk >= 2 && nk <= 3 && blocks64 < 700 && need <= side_floats_;
-      bool grp = group_mrf_ && nk >= 2 && nk <= 3 && blocks64 < 700 && need <= side_floats_;
+      // grouped sibling launches are a single-utterance latency measure: measured -24 us (medium) / -4 % (high) at
+      // B=1, but +1..2 % at B=2 and B=4, where every conv already fills the chip on its own
+      bool grp = group_mrf_ && B == 1 && nk >= 2 && nk <= 3 && blocks64 < 700 && need <= side_floats_;
       for (auto& cv : st.rb) {
         if (cv.size() != st.rb[0].size()) grp = false;
         for (auto& c : cv) grp = grp && can_group(c, Lmax);

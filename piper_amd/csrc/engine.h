@@ -179,11 +179,13 @@ class Engine {
   void dp_reset_granules();
   float* pack16(const std::vector<float>& W, int rows, int K);    // [16-row tile][q][lane][4] (dds_layer16_kernel)
   float* dp_proj16_ = nullptr;
-  int colchain_ = 1;                        // PIPER_HIP_COLCHAIN: 0 off, 1 small batches, 2 always (A/B, tests)
-  long colchain_max_cols_ = 1100;           // batch columns (ids or frames) up to which colchain_kernel replaces conv pairs
+  int colchain_ = 1;                        // PIPER_HIP_COLCHAIN: 0 off, 1 by batch size, 2 always (A/B, tests)
+  // batch columns up to which colchain_kernel / lngemm_kernel replace conv + LayerNorm pairs: ids for the encoder,
+  // frames for the flow. Measured (profiles/r02_notes.md): -3.5 % at B=1, -2.5 % at B=16, neutral at B=32, +1 % at B=64.
+  long colchain_max_ids_ = 4096, colchain_max_frames_ = 8192;
   // colchain_kernel<6> is compiled for exactly 192 input channels (and 96 = half of them in the coupling layers)
-  bool use_colchain(double cols, int k1, int half) const {
-    return colchain_ && k1 == 192 && half == 96 && (colchain_ == 2 || cols <= (double)colchain_max_cols_);
+  bool use_colchain(double cols, long max_cols, int k1, int half) const {
+    return colchain_ && k1 == 192 && half == 96 && (colchain_ == 2 || cols <= (double)max_cols);
   }
   void colchain(const struct ColP& p, int B, int Lmax, double flops);
   void lngemm(View y, const float* g, const float* b, View x, const float* w16, const float* bias, int rows, View out,

@@ -160,7 +160,7 @@ FORCED = [
     ("medium", [128, 31], {"PIPER_HIP_COLCHAIN": 0}, {"ln_kernel<0>", "conv_splitk_kernel<1,false,4,4>"}),
     # sibling resblock convs of the 128-channel stage as grouped launches (64- and 128-column slabs), and one by one
     # (the last step, whose outputs the MRF only sums, is one GEMM over the concatenated K; GROUP_MRF=2: kept apart)
-    ("medium", [128, 40], {}, {"conv_splitk_group_kernel<4,2,64>", "conv_splitk_sum_kernel<4,2>"}),
+    ("medium", [117], {}, {"conv_splitk_group_kernel<4,2,64>", "conv_splitk_sum_kernel<4,2>"}),
     ("medium", [100], {"PIPER_HIP_GROUP_MRF": 2}, {"conv_splitk_group_kernel<4,2,64>", "conv_splitk_group_kernel<4,2,128>"}),
     ("high", [40], {}, {"conv_splitk_group_kernel<4,2,64>", "conv_splitk_sum_kernel<4,2>"}),
     ("medium", [128], {"PIPER_HIP_GROUP_MRF": 0}, {"conv_splitk_kernel<1,false,4,4>"}),
