@@ -163,6 +163,13 @@ class Engine:
         self._check(self._lib.pe_fetch(self._h, int(want_audio), int(want_pcm), C.byref(res)))
         return self._collect(res, want_audio, want_pcm)
 
+    def fetch_views(self, want_audio=True, want_pcm=True) -> "L.PeResult":
+        """Like fetch() but returns the C ABI's result views as they are (pointers into the engine's pinned host
+        buffers, valid until the next call) -- what a C / C++ caller gets; no numpy copies."""
+        res = L.PeResult()
+        self._check(self._lib.pe_fetch(self._h, int(want_audio), int(want_pcm), C.byref(res)))
+        return res
+
     def stream(self, ids, scales=(0.667, 1.0, 0.8), sid=None, chunk_frames: int = 45, noise_w=None, noise_z=None):
         """Generator over (float_audio, int16_pcm) chunks of one utterance: encoder/flow once, then the
         vocoder on exact-halo windows of `chunk_frames` frames (reference default 45). Concatenating
