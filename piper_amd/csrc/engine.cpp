@@ -716,11 +716,13 @@ void Engine::ensure_stage_b(int Fmax) {
     PE_HIP(hipMalloc((void**)&wsB_, wsB_bytes_));
   }
   carve(wsB_);
-  if (pcm_zc_ && h_pcm_zc_cap_ < (size_t)Ss_) {       // one utterance's samples (the zero-copy path is B == 1 only)
+  // zero-copy PCM: room for every utterance of the batch capacity, up to 256 MiB of pinned memory (beyond: copies)
+  const size_t zc_want = Bc * (size_t)Ss_;
+  if (pcm_zc_ && zc_want * sizeof(int16_t) <= ((size_t)256 << 20) && h_pcm_zc_cap_ < zc_want) {
     PE_HIP(hipStreamSynchronize(stream_));
     drop_graphs();                                     // the pointer is a kernel argument inside the graphs
     if (h_pcm_zc_) PE_HIP(hipHostFree(h_pcm_zc_));
-    h_pcm_zc_cap_ = (size_t)Ss_;
+    h_pcm_zc_cap_ = zc_want;
     PE_HIP(hipHostMalloc((void**)&h_pcm_zc_, h_pcm_zc_cap_ * sizeof(int16_t)));
   }
   // per-branch buffers of the parallel MRF schedule (only used while a stage is small): allocated here,
@@ -1970,7 +1972,7 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
     PE_LAUNCH(conv_post_kernel, dim3((Lmax + POST_SPB - 1) / POST_SPB, B), dim3(256), 0, stream_, cur.p,
               cur.bs, cur.cs, post_w_, post_cin_, 0.01f, lens, hop_, audio_, Ss_, absmax_);
     // (zero_absmax marks the streaming window path, which delivers per chunk from the device buffer)
-    int16_t* zc = (pcm_zc_ && B == 1 && !zero_absmax) ? h_pcm_zc_ : nullptr;
+    int16_t* zc = (pcm_zc_ && !zero_absmax && h_pcm_zc_cap_ >= (size_t)B * (size_t)Ss_) ? h_pcm_zc_ : nullptr;
     PE_LAUNCH(pcm16_kernel, dim3((Lmax + 255) / 256, B), dim3(256), 0, stream_, audio_, Ss_, absmax_, lens, hop_,
               pcm_, Ss_, zc);
     prof_end(4, 2.0 * fsum * hop_ * post_cin_ * K);
@@ -2150,8 +2152,8 @@ void Engine::download(bool want_audio, bool want_pcm) {
       PE_HIP(hipHostMalloc((void**)&h_pcm_, h_pcm_cap_ * sizeof(int16_t)));
     }
   };
-  // one utterance: pcm16_kernel already wrote the samples into pinned host memory (zero-copy); nothing to enqueue
-  const bool zc = pcm_zc_ && B_ == 1 && h_pcm_zc_ != nullptr;
+  // pcm16_kernel already wrote the samples into pinned host memory (zero-copy), packed back to back: nothing to enqueue
+  const bool zc = pcm_zc_ && h_pcm_zc_ != nullptr && h_pcm_zc_cap_ >= (size_t)B_ * (size_t)Ss_;
   pcm_zc_live_ = false;
   if (spec_pending_ && B_ == 1 && (want_audio || want_pcm)) {
     // one utterance, speculative run: the copies are enqueued for the guessed length (>= the real one when the guess

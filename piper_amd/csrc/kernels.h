@@ -2360,7 +2360,7 @@ __global__ __launch_bounds__(256) void conv_post_kernel(const float* x, long x_b
 }
 
 // float -> int16 exactly as piper.cpp:420-431 (scale 32767/max(0.01,peak), clamp, truncate)
-// `host`: pinned host memory that also receives utterance 0's samples (zero-copy delivery of a one-utterance call), or null
+// `host`: pinned host memory that also receives the samples, utterances packed back to back (zero-copy delivery), or null
 __global__ void pcm16_kernel(const float* audio, long a_bs, const unsigned* absmax, const int* lens,
                              int len_mul, short* pcm, long p_bs, short* host) {
   PE_KTRACE(18);
@@ -2372,7 +2372,12 @@ __global__ void pcm16_kernel(const float* audio, long a_bs, const unsigned* absm
   float v = audio[(long)b * a_bs + t] * scale;
   v = fminf(fmaxf(v, -32768.0f), 32767.0f);
   pcm[(long)b * p_bs + t] = (short)v;
-  if (host && b == 0) host[t] = (short)v;
+  if (host) {
+    // the utterances are packed back to back in the host buffer, as pe_result.sample_offsets describes them
+    long off = 0;
+    for (int u = 0; u < b; ++u) off += (long)lens[u] * len_mul;
+    host[off + t] = (short)v;
+  }
 }
 
 // Streaming decode: copy frames [win[0], win[0]+win[1]) of z [C][zs] into the window buffer [C][ws]
