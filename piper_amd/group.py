@@ -39,6 +39,8 @@ class EngineGroup:
 
     def synthesize_batch(self, id_lists: Sequence[Sequence[int]], scales=(0.667, 1.0, 0.8),
                          sids: Optional[Sequence[int]] = None) -> Synthesis:
+        if len(id_lists) == 0:
+            raise EngineError("empty batch")
         ids = np.concatenate([np.asarray(x, dtype=np.int64) for x in id_lists])
         off = np.zeros(len(id_lists) + 1, dtype=np.int64)
         off[1:] = np.cumsum([len(x) for x in id_lists])

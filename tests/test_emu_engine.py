@@ -2,6 +2,7 @@
 emulator build (tests/emu/libpiper_hip_emu.so: same sources compiled with -DPE_EMU, fibers instead of
 GPU threads, emulated f32 MFMA fragment layouts). This is a development check, not a product path:
 piper_amd never loads the emulator. The real parity tests are tests/test_gpu_parity.py (-m gpu)."""
+import ctypes as C
 import os
 import subprocess
 
@@ -293,3 +294,28 @@ def test_persistent_duration_predictor_is_bit_identical(emu_lib, monkeypatch, pr
             assert np.array_equal(a.pcm[b], b_.pcm[b])
     pers.close()
     plain.close()
+
+
+def test_engine_group_argument_errors_and_single_device(emu_lib):
+    """pe_group_*: null / empty arguments are clean errors (message through pe_last_error), a one-device group behaves
+    like an engine, and the views returned by a call stay valid until the next one."""
+    from piper_amd.group import EngineGroup
+    cfg = W.preset("tiny")
+    blob = W.pack_blob(cfg, W.synthetic_weights(cfg, 7))
+    h = C.c_void_p()
+    assert emu_lib.pe_group_create(blob, len(blob), None, 0, C.byref(h)) != 0
+    assert b"null" in emu_lib.pe_last_error()
+    assert emu_lib.pe_group_size(None) == 0 and not emu_lib.pe_group_engine(None, 0)
+    with pytest.raises(EngineError):
+        EngineGroup(blob[:100], [0], lib=emu_lib)               # truncated blob
+    grp = EngineGroup(blob, [0], lib=emu_lib)
+    assert len(grp) == 1
+    ids = [W.synthetic_phoneme_ids(7, 3, id_max=cfg.n_vocab - 1)]
+    r = grp.synthesize_batch(ids, (0.0, 1.0, 0.0))
+    eng = Engine(blob=blob, lib=emu_lib)
+    s = eng.synthesize_batch(ids, (0.0, 1.0, 0.0))
+    assert np.array_equal(r.pcm[0], s.pcm[0]) and grp.assignment(1) == [0]
+    with pytest.raises(EngineError):
+        grp.synthesize_batch([], (0.0, 1.0, 0.0))
+    eng.close()
+    grp.close()
