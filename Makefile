@@ -4,7 +4,7 @@ HIPCC ?= $(ROCM)/bin/hipcc
 CXX_EMU ?= $(ROCM)/lib/llvm/bin/clang++
 CSRC := piper_amd/csrc
 SRCS := $(CSRC)/engine.cpp $(CSRC)/pe_api.cpp $(CSRC)/weights.cpp $(CSRC)/onnx_reader.cpp $(CSRC)/piper_shim.cpp
-HDRS := include/piper.hpp $(CSRC)/engine.h $(CSRC)/kernels.h $(CSRC)/pe_rt.h $(CSRC)/weights.h include/piper_hip.h
+HDRS := include/piper.hpp $(CSRC)/engine.h $(wildcard $(CSRC)/kernels/*.h) $(CSRC)/pe_rt.h $(CSRC)/weights.h include/piper_hip.h
 LIB := piper_amd/libpiper_hip.so
 EMULIB := tests/emu/libpiper_hip_emu.so
 

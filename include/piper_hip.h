@@ -134,14 +134,24 @@ int pe_debug_tensor(pe_engine* e, const char* name, int32_t b, float* out, int64
                     int32_t* cols);
 
 /* Test hooks for the N(0,1) generator behind the graph's two RandomNormalLike sites (models.py:111, :718) when no
- * noise is injected: pe_debug_randn fills out[n] with what site 0/1 draws at run counter `call` under the current
- * seed; pe_rng_calls is the number of pipeline runs so far (the counter the next run will use is that + 1). */
-int pe_debug_randn(pe_engine* e, int32_t site, uint64_t call, int64_t n, float* out);
+ * noise is injected. A site's stream is a logical [row][65536] array, row = utterance * channels + channel (2 channels
+ * at site 0, inter_channels at site 1), column = phoneme id / frame: the value the pipeline uses there depends on
+ * (seed, run counter, site, row, column) only -- not on batch buckets or workspace sizes. pe_debug_randn fills out[n]
+ * with draws row * 65536 .. + n of site 0/1 at run counter `call` under the current seed; pe_rng_calls is the number
+ * of pipeline runs so far (the counter the next run will use is that + 1). */
+int pe_debug_randn(pe_engine* e, int32_t site, uint64_t call, int64_t row, int64_t n, float* out);
 uint64_t pe_rng_calls(pe_engine* e);
 
 /* Kernel launches (hipGraph kernel nodes) the last pe_run / pe_synthesize* issued: the length of the dependent
  * launch chain one utterance costs (the latency figure of merit at batch 1). */
 int64_t pe_run_launches(pe_engine* e);
+
+/* Calls of <= 4 utterances enqueue the second half of the pipeline (flow + vocoder) for a GUESSED frame bucket right
+ * behind the first half -- the frame count is the graph's only data-dependent shape (reference models.py:702-716) and
+ * would otherwise cost a host round trip mid-pipeline. The guess (running maximum of frames per id x an adaptive
+ * margin) is verified when the results are fetched; a miss re-runs the second half. runs = calls issued that way since
+ * pe_create, misses = guesses that were too small (each cost one extra pass of the second half). */
+int pe_speculation_stats(pe_engine* e, int64_t* runs, int64_t* misses);
 
 /* In-process multi-GPU synthesis for C / C++ callers (the reference runs the phrases of a text one
  * after the other on one session, src/cpp/piper.cpp:549-582 -- they are independent, so they shard). One engine, one

@@ -1,6 +1,13 @@
 #include "engine.h"
-#include "kernels.h"
-#include "mrf2.h"
+#include "kernels/attention.h"
+#include "kernels/colchain.h"
+#include "kernels/conv_mfma.h"
+#include "kernels/conv_splitk.h"
+#include "kernels/dds.h"
+#include "kernels/duration.h"
+#include "kernels/layernorm.h"
+#include "kernels/mrf2.h"
+#include "kernels/post.h"
 
 #include <algorithm>
 #include <cmath>
@@ -12,6 +19,15 @@
 namespace pe {
 
 thread_local long g_launches = 0;
+
+// a launch on the engine's stream with a level-2 profile row of its own (the element-wise / integer glue kernels; the
+// conv / attention / fused-stage launchers bracket themselves and also carry FLOP and byte counts)
+#define PE_LAUNCH_K(kname, kernel, grid, block, smem, stream, ...)               \
+  do {                                                                           \
+    const int kh_ = kbegin(prof_level_ >= 2 ? krow(kname) : 0, 0.0);             \
+    PE_LAUNCH(kernel, grid, block, smem, stream, __VA_ARGS__);                   \
+    kend(kh_);                                                                   \
+  } while (0)
 
 // Engines that share a process (pe_group_*: one per device, each on its own thread) must not be inside a HIP call while
 // another one CAPTURES a graph: allocations / synchronising copies on a second thread invalidate a capture in progress on
@@ -262,6 +278,7 @@ DdsW Engine::load_dds(const WeightSet& ws, const std::string& p) {
 }
 
 Engine::Engine(const WeightSet& ws, int device, ArenaSpec arena) : device_(device) {
+  EntryLock entry_lock;       // allocations / synchronising copies must not overlap another engine's graph capture
   // a constructor that throws does not run the destructor: release what was acquired so far
   try {
     PE_HIP(hipSetDevice(device_));
@@ -290,11 +307,6 @@ void Engine::init(const WeightSet& ws) {
   PE_HIP(hipSetDevice(device_));
   PE_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
   ls_ = stream_;
-  for (int i = 0; i < 2; ++i) {
-    PE_HIP(hipStreamCreateWithFlags(&side_stream_[i], hipStreamNonBlocking));
-    PE_HIP(hipEventCreateWithFlags(&ev_join_[i], hipEventDisableTiming));
-  }
-  PE_HIP(hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming));
   H_ = arch_[A_HIDDEN]; C_ = arch_[A_INTER]; FC_ = arch_[A_FILTER]; nh_ = arch_[A_NHEADS];
   nlayers_ = arch_[A_NLAYERS]; ksz_ = arch_[A_KSIZE]; window_ = arch_[A_WINDOW]; U_ = arch_[A_UPINIT];
   gin_ = arch_[A_GIN]; nspk_ = arch_[A_NSPK];
@@ -448,7 +460,6 @@ void Engine::init(const WeightSet& ws) {
         }
         st.last_bias_sum = dev_alloc((size_t)ch, skeleton_ ? nullptr : bs.data());
       }
-      build_mrf(st);
       build_mrf2(st);
       st.rb_host.clear();
       ups_.push_back(st);
@@ -519,11 +530,6 @@ void Engine::init(const WeightSet& ws) {
     PE_HIP(hipFuncSetAttribute((const void*)attn_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     PE_HIP(hipFuncSetAttribute((const void*)attn_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     PE_HIP(hipFuncSetAttribute((const void*)attn_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    const void* ks3[] = {(const void*)mrf_fused_kernel<32, 4, 4, 256>, (const void*)mrf_fused_kernel<32, 4, 4, 320>,
-                         (const void*)mrf_fused_kernel<32, 4, 4, 384>, (const void*)mrf_fused_kernel<32, 4, 8, 256>,
-                         (const void*)mrf_fused_kernel<32, 4, 8, 320>, (const void*)mrf_fused_kernel<32, 4, 8, 384>,
-                         (const void*)mrf_fused_kernel<64, 4, 8, 256>};
-    for (const void* k : ks3) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     const void* ks4[] = {(const void*)mrf2_kernel<32, 16, 1, 2, 1, 368, 2>, (const void*)mrf2_kernel<32, 16, 1, 2, 1, 400, 1>,
                          (const void*)mrf2_kernel<64, 16, 2, 1, 1, 240, 1>};
     for (const void* k : ks4) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
@@ -533,30 +539,26 @@ void Engine::init(const WeightSet& ws) {
   for (auto n : rows) prof_.push_back(ProfileRow{n});
   PE_HIP(hipEventCreate(&ev0_));
   PE_HIP(hipEventCreate(&ev1_));
-  PE_HIP(hipHostMalloc((void**)&h_frames_, (4096 + 16) * sizeof(int)));     // [4096]: error word of the persistent kernels
-  h_frames_[4096] = 0;
+  PE_HIP(hipHostMalloc((void**)&h_frames_, 4096 * sizeof(int)));
   if (const char* ng = getenv("PIPER_HIP_NO_GRAPH")) use_graphs_ = !(ng[0] && ng[0] != '0');
   if (const char* t = getenv("PIPER_HIP_TPB")) tpb_override_ = atoi(t);     // tuning / test knob
   if (const char* t = getenv("PIPER_HIP_WIDE_MIN")) wide_min_blocks_ = atol(t);
   if (const char* t = getenv("PIPER_HIP_SMALL")) small_tiles_ = atoi(t) != 0;
-  if (const char* t = getenv("PIPER_HIP_PAR_MRF")) par_mrf_ = atoi(t) != 0;
   if (const char* t = getenv("PIPER_HIP_GROUP_MRF")) group_mrf_ = atoi(t);
   if (const char* t = getenv("PIPER_HIP_PCM_ZC")) pcm_zc_ = atoi(t) != 0;
-  if (const char* t = getenv("PIPER_HIP_FUSE_MRF")) fuse_mrf_ = atoi(t) != 0;   // A/B knob: 1 = fused MRF stage kernel
   if (const char* t = getenv("PIPER_HIP_SPLITK_MAX")) splitk_max_blocks_ = atol(t);   // tuning knob
   if (const char* t = getenv("PIPER_HIP_SPLITK16")) splitk16_ = atoi(t);              // A/B knob
   if (const char* t = getenv("PIPER_HIP_WIDE_SPLITK")) wide_splitk_ = atoi(t);        // 0 off, 1 auto, 2 always (tests)
   if (const char* t = getenv("PIPER_HIP_DEBUG_KEEP")) debug_keep_ = atoi(t) != 0;     // tests: keep z_p for debug_tensor
   if (const char* t = getenv("PIPER_HIP_COLCHAIN")) colchain_ = atoi(t);              // A/B knob, tests
   if (const char* t = getenv("PIPER_HIP_FUSE_DP")) fuse_dp_ = atoi(t) != 0;           // A/B knob, tests
-  if (const char* t = getenv("PIPER_HIP_FOLD_LN")) fold_ln_ = atoi(t) != 0;           // A/B knob, tests
   if (const char* t = getenv("PIPER_HIP_SPEC")) spec_enable_ = atoi(t) != 0;          // speculative stage B (A/B, tests)
-  if (const char* t = getenv("PIPER_HIP_PERSIST_DP")) persist_dp_ = atoi(t) != 0;     // persistent duration-predictor kernel
 }
 
 Engine::~Engine() { free_all(); }
 
 void Engine::arena_ready() {
+  EntryLock entry_lock;
   PE_HIP(hipSetDevice(device_));
   float m = 0.f, lg = 0.f;
   PE_HIP(hipMemcpy(&m, ea_dev_m_, sizeof(float), hipMemcpyDeviceToHost));
@@ -567,6 +569,7 @@ void Engine::arena_ready() {
 }
 
 void Engine::free_all() {
+  EntryLock entry_lock;
   if (stream_) hipStreamSynchronize(stream_);
   drop_graphs();
   for (void* p : owned_) hipFree(p);
@@ -585,17 +588,10 @@ void Engine::free_all() {
   kev_.clear();
   for (hipEvent_t e : ev_pool_) hipEventDestroy(e);
   ev_pool_.clear();
-  for (int i = 0; i < 2; ++i) {
-    if (side_stream_[i]) hipStreamSynchronize(side_stream_[i]);
-    if (ev_join_[i]) hipEventDestroy(ev_join_[i]);
-    if (side_stream_[i]) hipStreamDestroy(side_stream_[i]);
-    ev_join_[i] = nullptr; side_stream_[i] = nullptr;
-  }
-  if (ev_fork_) hipEventDestroy(ev_fork_);
   for (float*& p : side_) { if (p) hipFree(p); p = nullptr; }
   if (stream_) hipStreamDestroy(stream_);
   wsA_ = wsB_ = nullptr; h_audio_ = nullptr; h_pcm_ = nullptr; h_pcm_zc_ = nullptr; h_frames_ = nullptr;
-  ev0_ = ev1_ = ev_fork_ = nullptr; stream_ = nullptr;
+  ev0_ = ev1_ = nullptr; stream_ = nullptr;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -647,11 +643,6 @@ void Engine::ensure_stage_a(int B, int Tmax) {
     noise_w_ = c.take<float>(Bc * 2 * T);
     cond_ = c.take<float>(Bc * (size_t)std::max(cond_bs_, 1));
     d_rng_ = c.take<unsigned long long>(4);
-    // halo granules of the persistent duration predictor: [256 tiles][3 slots][2 sides][channels][9] + z's [2][2][2]
-    dp_gx_ts_ = (size_t)3 * 2 * rup(H_, 32) * DDS_HALO;
-    dp_gx_ = c.take<unsigned long long>(persist_dp_ ? 256 * dp_gx_ts_ : 8);
-    dp_gz_ = c.take<unsigned long long>(256 * 8);
-    dp_state_ = c.take<unsigned>(4 + Bc);
     return c.off + 256;
   };
   if (grow || !wsA_) {
@@ -663,18 +654,8 @@ void Engine::ensure_stage_a(int B, int Tmax) {
     wsA_bytes_ = carve(nullptr);
     PE_HIP(hipMalloc((void**)&wsA_, wsA_bytes_));
     carve(wsA_);
-    // granule tags / counters of the persistent kernel start from zero; tags only grow afterwards
-    dp_reset_granules();
   }
   carve(wsA_);
-}
-
-void Engine::dp_reset_granules() {
-  PE_HIP(hipStreamSynchronize(stream_));
-  PE_HIP(hipMemset(dp_gx_, 0, (persist_dp_ ? 256 * dp_gx_ts_ : 8) * sizeof(unsigned long long)));
-  PE_HIP(hipMemset(dp_gz_, 0, 256 * 8 * sizeof(unsigned long long)));
-  PE_HIP(hipMemset(dp_state_, 0, (4 + capA_B_) * sizeof(unsigned)));
-  dp_runs_ = 0;
 }
 
 void Engine::ensure_stage_b(int Fmax) {
@@ -725,12 +706,10 @@ void Engine::ensure_stage_b(int Fmax) {
     h_pcm_zc_cap_ = zc_want;
     PE_HIP(hipHostMalloc((void**)&h_pcm_zc_, h_pcm_zc_cap_ * sizeof(int16_t)));
   }
-  // per-branch buffers of the parallel MRF schedule (only used while a stage is small): allocated here,
-  // outside any graph capture
-  // (the grouped schedule only applies below 700 64x64 blocks per stage: 700 * 4096 floats bound its buffers)
-  const size_t want = par_mrf_ ? std::min<size_t>(Bc * hmax, ((size_t)64 << 20) / sizeof(float))
-                               : std::min<size_t>(Bc * hmax, (size_t)700 * 4096);
-  if ((par_mrf_ || group_mrf_) && side_floats_ < want) {
+  // per-resblock buffers of the grouped sibling schedule (one-utterance calls, first generator stage): allocated
+  // here, outside any graph capture; the schedule only applies below 700 64x64 blocks per stage
+  const size_t want = std::min<size_t>(Bc * hmax, (size_t)700 * 4096);
+  if (group_mrf_ && side_floats_ < want) {
     PE_HIP(hipStreamSynchronize(stream_));
     drop_graphs();
     for (float*& sp : side_) { if (sp) PE_HIP(hipFree(sp)); sp = nullptr; }
@@ -832,15 +811,6 @@ int Engine::route(const PackedConv& pc, int ncols, int epi) const {
                    (units >= 24 || splitk16_ >= 3);
   return k16 ? ROUTE_SPLITK16 : ROUTE_SPLITK;
 }
-// LayerNorm-in needs every input channel of a column inside one workgroup at once: the plain split-K kernel with one
-// 32-channel chunk per wave.
-bool Engine::can_fold_ln(const PackedConv& pc, int ncols) const {
-  if (!fold_ln_ || pc.gate || wide_splitk_ == 2) return false;
-  if (route(pc, ncols, EPI_STORE) != ROUTE_SPLITK) return false;
-  const int NW = pc.nchunks >= 5 ? 8 : 4;
-  return pc.nchunks <= NW;
-}
-
 void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int len_mul, int Lmax, int epi,
                   float in_slope, int act, View res, View out2, int mode, float alpha, const float* bias2,
                   int bias2_bs) {
@@ -863,10 +833,6 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
   p.mode = mode; p.alpha = alpha;
   p.tpb = 1;
   p.tgroups = 1;
-  p.ln_g = ln_in_.g; p.ln_b = ln_in_.b;
-  p.ln_out = ln_in_.out.p; p.ln_o_bs = ln_in_.out.bs; p.ln_o_cs = ln_in_.out.cs;
-  const bool ln_in = ln_in_.g != nullptr;
-  ln_in_ = LnIn{};
   if ((epi == EPI_GATE) != pc.gate) throw std::runtime_error("internal: gate epilogue/packing mismatch");
 
   const int ncols = (epi == EPI_CONVT) ? Lmax + 1 : Lmax;
@@ -887,9 +853,8 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
                     (double)pc.rows * pc.Cin * pc.ntaps);
   }
   const long blocks = (long)((ncols + CFG_BN[cfg] - 1) / CFG_BN[cfg]) * (pc.mtiles * 32 / CFG_BM[cfg]) * B_;
-  if (ln_in && route(pc, ncols, epi) != ROUTE_SPLITK) throw std::runtime_error("internal: LayerNorm-in on a non split-K launch");
   if (grouping_) {
-    if (!can_group(pc, ncols) || epi == EPI_CONVT || epi == EPI_GATE || ln_in || group_.size() >= 3 ||
+    if (!can_group(pc, ncols) || epi == EPI_CONVT || epi == EPI_GATE || group_.size() >= 3 ||
         (!group_.empty() && group_ncols_ != ncols))
       throw std::runtime_error("internal: conv does not fit a grouped launch");
     p.tgroups = 1;
@@ -914,8 +879,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
       p.tgroups = pc.nchunks <= 6 ? 2 : 1;
     }
     dim3 grid((ncols + 31) / 32, pc.mtiles / MT, B_);
-    const size_t smem = (std::max<size_t>((size_t)NW * KC * 64, (size_t)NW * MT * 16 * 64) + (ln_in ? 2 * NW * 64 : 0)) *
-                        sizeof(float);
+    const size_t smem = std::max<size_t>((size_t)NW * KC * 64, (size_t)NW * MT * 16 * 64) * sizeof(float);
     const bool k16 = pc.wp16 && epi != EPI_CONVT && ((pc.gate && splitk16_ >= 1) || (!pc.gate && splitk16_ >= 2)) &&
                      (units >= 24 || splitk16_ >= 3);
     // profile rows carry the instantiation exactly as rocprofv3 prints it (minus spaces)
@@ -1011,105 +975,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
   kend(kh);
 }
 
-// Flattens one MRF stage (all resblocks of an upsampling stage) into the step table of mrf_fused_kernel.
-// ResBlock2 (modules.py:355-364): x <- x + c_d(lrelu(x));   ResBlock1 (:301-314): x <- x + c2_d(lrelu(c1_d(lrelu(x)))).
-// Buffer 0 holds the stage input for every resblock; 1 and 2 carry the chain. Stages whose window does not
-// fit the 160 KiB of LDS (or with > 64 channels) keep the conv-by-conv schedule.
-static constexpr int MRF_NT = 4;            // 128 output columns per workgroup
-void Engine::build_mrf(UpStage& st) {
-  const int ch = st.ch;
-  if (ch > 64 || st.rb.empty()) return;
-  const int CP = ch <= 32 ? 32 : 64;
-  const bool rb1 = arch_[A_RESBLOCK] == 1;
-  std::vector<MrfStep> steps;
-  int hx = 0, nbuf = 2;
-  double macs = 0;
-  for (auto& cv : st.rb) {
-    const int n = (int)cv.size();
-    if (n == 0 || (rb1 && (n & 1))) return;
-    std::vector<int> h(n);
-    for (int i = 0; i < n; ++i) {
-      const PackedConv& c = cv[i];
-      if (!(c.ntaps & 1) || c.Cin != ch || c.rows != ch || c.padl != c.dil * (c.ntaps - 1) / 2 ||
-          c.nchunks != CP / KC || c.mtiles < CP / 32 || c.gate)
-        return;
-      h[i] = c.padl;
-      macs += c.macs_per_col;
-    }
-    int e = 0;
-    for (int i = 0; i < n; ++i) e += h[i];
-    hx = std::max(hx, e);
-    int xcur = 0;                            // buffer holding the running x of this chain
-    for (int i = 0; i < n; ++i) {
-      e -= h[i];
-      MrfStep s;
-      s.wp = cv[i].wp; s.bias = cv[i].bias; s.ntaps = cv[i].ntaps; s.dil = cv[i].dil; s.e = e;
-      const bool last = i == n - 1;
-      if (rb1) {
-        if (!(i & 1)) { s.src = xcur; s.res = -1; s.dst = 1; }
-        else { s.src = 1; s.res = xcur; s.dst = last ? -1 : 2; xcur = 2; nbuf = std::max(nbuf, last ? 2 : 3); }
-      } else {
-        s.src = xcur; s.res = xcur; s.dst = last ? -1 : (xcur == 1 ? 2 : 1);
-        if (!last) { xcur = s.dst; nbuf = std::max(nbuf, xcur + 1); }
-      }
-      steps.push_back(s);
-    }
-  }
-  const int N = MRF_NT * 32;
-  const int ws = std::max(256, rup(N + 2 * hx + 32, 64));
-  if (ws < 256 || ws > 384 || (size_t)nbuf * CP * ws * sizeof(float) > 160u * 1024u) return;
-  if (CP == 64 && ws != 256) return;       // instantiated strides: 32 channels 256/320/384, 64 channels 256
-  void* d = nullptr;
-  PE_HIP(hipMalloc(&d, steps.size() * sizeof(MrfStep)));
-  PE_HIP(hipMemcpy(d, steps.data(), steps.size() * sizeof(MrfStep), hipMemcpyHostToDevice));
-  owned_.push_back(d);
-  st.mrf_steps = d;
-  st.mrf_nsteps = (int)steps.size();
-  st.mrf_hx = hx; st.mrf_ws = ws; st.mrf_cp = CP; st.mrf_nbuf = nbuf;
-  st.mrf_macs_per_col = macs;
-}
-
-void Engine::mrf(const UpStage& st, View x, View out, const int* lens, int len_mul, int Lmax) {
-  MrfP p;
-  p.x = x.p; p.x_bs = x.bs; p.x_cs = x.cs;
-  p.out = out.p; p.o_bs = out.bs; p.o_cs = out.cs;
-  p.lens = lens; p.len_mul = len_mul;
-  p.steps = static_cast<const MrfStep*>(st.mrf_steps); p.nsteps = st.mrf_nsteps;
-  p.C = st.ch; p.hx = st.mrf_hx;
-  p.slope = 0.1f;                            // modules.py LRELU_SLOPE
-  p.alpha = 1.0f / (float)st.rb.size();
-  double kflops = 0;
-  if (prof_level_ >= 2) {
-    double cols = 0;
-    for (int b = 0; b < B_; ++b) cols += (double)frames_h_[b] * len_mul;
-    kflops = 2.0 * st.mrf_macs_per_col * cols;
-  }
-  const size_t smem = (size_t)st.mrf_nbuf * st.mrf_cp * st.mrf_ws * sizeof(float);
-  dim3 grid((Lmax + MRF_NT * 32 - 1) / (MRF_NT * 32), 1, B_);
-  // 32-channel stages whose window allows two workgroups per CU run 4 waves each, otherwise 8 (either way
-  // two waves per SIMD)
-  const bool two = 2 * smem <= 160u * 1024u;
-  const char* kname = st.mrf_cp == 64 ? "mrf_fused_kernel<64,4,8,256>"
-                      : two ? (st.mrf_ws == 256 ? "mrf_fused_kernel<32,4,4,256>"
-                               : st.mrf_ws == 320 ? "mrf_fused_kernel<32,4,4,320>" : "mrf_fused_kernel<32,4,4,384>")
-                            : (st.mrf_ws == 256 ? "mrf_fused_kernel<32,4,8,256>"
-                               : st.mrf_ws == 320 ? "mrf_fused_kernel<32,4,8,320>" : "mrf_fused_kernel<32,4,8,384>");
-  const int kh = kbegin(prof_level_ >= 2 ? krow(kname) : 0, kflops);
-#define PE_MRF32(WS_)                                                                                     \
-  do {                                                                                                    \
-    if (two) PE_LAUNCH((mrf_fused_kernel<32, MRF_NT, 4, WS_>), grid, dim3(256), smem, ls_, p);          \
-    else PE_LAUNCH((mrf_fused_kernel<32, MRF_NT, 8, WS_>), grid, dim3(512), smem, ls_, p);              \
-  } while (0)
-  if (st.mrf_cp == 64) PE_LAUNCH((mrf_fused_kernel<64, MRF_NT, 8, 256>), grid, dim3(512), smem, ls_, p);
-  else if (st.mrf_ws == 256) PE_MRF32(256);
-  else if (st.mrf_ws == 320) PE_MRF32(320);
-  else PE_MRF32(384);
-#undef PE_MRF32
-  kend(kh);
-}
-
-
-// Second-generation fused MRF stage (mrf2.h): flattens the resblocks of a <= 64-channel stage into phases (one per
+// Fused MRF stage (kernels/mrf2.h): flattens the resblocks of a <= 64-channel stage into phases (one per
 // conv), cuts every conv's (chunk, tap) steps into weight segments of at most one ring half, and writes the weights as
 // one stream in execution order. ResBlock2 (modules.py:355-364): x <- x + c_d(lrelu(x)); ResBlock1 (:301-314):
 // x <- x + c2_d(lrelu(c1_d(lrelu(x)))).
@@ -1270,22 +1136,16 @@ void Engine::mrf2(const UpStage& st, View x, View out, const int* lens, int len_
   kend(kh);
 }
 
-void Engine::layer_norm(int mode, View in, View res, View out, const float* g, const float* b,
-                        const float* dw_w, const float* dw_b, int dw_k, int dw_dil, int C, const int* lens,
-                        int Lmax) {
+void Engine::layer_norm(View in, View out, const float* g, const float* b, int C, const int* lens, int Lmax) {
   LnP p;
   p.in = in.p; p.i_bs = in.bs; p.i_cs = in.cs;
-  p.res = res.p; p.r_bs = res.bs; p.r_cs = res.cs;
   p.out = out.p; p.o_bs = out.bs; p.o_cs = out.cs;
   p.gamma = g; p.beta = b;
-  p.dw_w = dw_w; p.dw_b = dw_b; p.dw_k = dw_k; p.dw_dil = dw_dil;
   p.lens = lens; p.C = C;
   if (C > LN_COLS * 32) throw std::runtime_error("LayerNorm over more than 256 channels is not supported");
   dim3 grid((Lmax + LN_COLS - 1) / LN_COLS, B_);
-  const int kh = kbegin(prof_level_ >= 2 ? krow(mode == 0 ? "ln_kernel<0>" : mode == 1 ? "ln_kernel<1>" : "ln_kernel<2>") : 0, 0.0);
-  if (mode == 0) PE_LAUNCH(ln_kernel<0>, grid, dim3(256), 0, stream_, p);
-  else if (mode == 1) PE_LAUNCH(ln_kernel<1>, grid, dim3(256), 0, stream_, p);
-  else PE_LAUNCH(ln_kernel<2>, grid, dim3(256), 0, stream_, p);
+  const int kh = kbegin(prof_level_ >= 2 ? krow("ln_kernel") : 0, 0.0);
+  PE_LAUNCH(ln_kernel, grid, dim3(256), 0, stream_, p);
   kend(kh);
 }
 
@@ -1513,7 +1373,7 @@ void Engine::issue_stage_a() {
   const float* cb_dp = nullptr;
   if (nspk_ > 1) {
     auto cond = [&](const CondW& c, int off) {
-      PE_LAUNCH(cond_kernel, dim3((c.rows + 127) / 128, B), dim3(128), 0, stream_, emb_g_, gin_, d_sids_, c.w, c.b,
+      PE_LAUNCH_K("cond_kernel", cond_kernel, dim3((c.rows + 127) / 128, B), dim3(128), 0, stream_, emb_g_, gin_, d_sids_, c.w, c.b,
                 c.rows, cond_ + off, cond_bs_);
     };
     cond(cond_dp_, cond_off_dp_);
@@ -1525,24 +1385,16 @@ void Engine::issue_stage_a() {
   // ================= text encoder (models.py:198-209, attentions.py:60-74)
   prof_begin();
   double fl = 0;
-  PE_LAUNCH(embed_kernel, dim3((T + 63) / 64, (H_ + 15) / 16, B), dim3(64), 0, stream_, d_ids_, Ts, d_tlens_, emb_, H_,
+  PE_LAUNCH_K("embed_kernel", embed_kernel, dim3((T + 63) / 64, (H_ + 15) / 16, B), dim3(64), 0, stream_, d_ids_, Ts, d_tlens_, emb_, H_,
             std::sqrt((float)H_), x_, (long)H_ * Ts, Ts, d_rng_);
-  // LayerNorm placement: norm_layers_1 feeds only FFN conv_1 (+ the residual of conv_2), norm_layers_2 only the next
-  // layer's q/k/v conv (or, after the last layer, proj) + the residual of conv_o. When those consumers run as split-K
-  // launches (a few utterances) the norm is computed while they stage x -- every workgroup of such a launch holds all
-  // H channels of its columns -- and row tile 0 writes LN(x) back for the residual readers: 2 launches fewer per layer.
-  const bool fold1 = can_fold_ln(enc_.empty() ? enc_proj_ : enc_[0].f1, T);
-  const bool fold2 = can_fold_ln(enc_.empty() ? enc_proj_ : enc_[0].qkv, T) && can_fold_ln(enc_proj_, T);
+  // norm_layers_2 of a layer feeds only the next layer's q/k/v conv (or, after the last layer, proj) + the residual of
+  // conv_o. Small batches with the 192-channel encoder run norm_layers_2 + that conv as one launch (lngemm_kernel), and
+  // conv_o + residual + norm_layers_1 as another (colchain_kernel); otherwise conv, then ln_kernel.
   const float *pg = nullptr, *pb = nullptr;        // pending norm_layers_2 of the previous layer (input still in y)
-  // small batches with the 192-channel encoder: norm_layers_2 + the q/k/v (or proj) conv as one launch (lngemm_kernel)
-  const bool chain_q = !fold2 && use_colchain(tsum, colchain_max_ids_, H_, 96);
+  const bool chain_q = use_colchain(tsum, colchain_max_ids_, H_, 96);
   for (auto& e : enc_) {
-    if (pg && chain_q) {
-      lngemm(y, pg, pb, x, e.qkv16, e.qkv.bias, 3 * H_, qkv, T, 2.0 * tsum * e.qkv.macs_per_col);
-    } else {
-      if (pg) { ln_in_.g = pg; ln_in_.b = pb; ln_in_.out = x; }
-      conv(e.qkv, pg ? y : x, qkv, d_tlens_, 1, T, EPI_STORE);
-    }
+    if (pg) lngemm(y, pg, pb, x, e.qkv16, e.qkv.bias, 3 * H_, qkv, T, 2.0 * tsum * e.qkv.macs_per_col);
+    else conv(e.qkv, x, qkv, d_tlens_, 1, T, EPI_STORE);
     pg = pb = nullptr;
     AttnP ap;
     ap.qkv = qkv_; ap.q_bs = (long)3 * H_ * Ts; ap.q_cs = Ts;
@@ -1563,7 +1415,7 @@ void Engine::issue_stage_a() {
     else if (ap.dk == 48) PE_LAUNCH(attn_kernel<48>, agrid, dim3(256), smem, stream_, ap);
     else PE_LAUNCH(attn_kernel<0>, agrid, dim3(256), smem, stream_, ap);
     kend(kh);
-    const bool chain_o = !fold1 && use_colchain(tsum, colchain_max_ids_, H_, 96);
+    const bool chain_o = chain_q;
     if (chain_o) {
       // conv_o + residual + norm_layers_1 in one launch (the 192 x 192 GEMM fits one workgroup per 16 columns)
       ColP cp{};
@@ -1578,27 +1430,16 @@ void Engine::issue_stage_a() {
     } else {
       conv(e.o, att, y, d_tlens_, 1, T, EPI_RESADD, 1.f, ACT_NONE, x);
     }
-    if (chain_o) {
-      conv(e.f1, x, ffh, d_tlens_, 1, T, EPI_STORE, 1.f, ACT_RELU);
-    } else if (fold1) {
-      ln_in_.g = e.g1; ln_in_.b = e.b1; ln_in_.out = x;
-      conv(e.f1, y, ffh, d_tlens_, 1, T, EPI_STORE, 1.f, ACT_RELU);
-    } else {
-      layer_norm(0, y, none, x, e.g1, e.b1, nullptr, nullptr, 0, 0, H_, d_tlens_, T);
-      conv(e.f1, x, ffh, d_tlens_, 1, T, EPI_STORE, 1.f, ACT_RELU);
-    }
+    if (!chain_o) layer_norm(y, x, e.g1, e.b1, H_, d_tlens_, T);
+    conv(e.f1, x, ffh, d_tlens_, 1, T, EPI_STORE, 1.f, ACT_RELU);
     conv(e.f2, ffh, y, d_tlens_, 1, T, EPI_RESADD, 1.f, ACT_NONE, x);
-    if (fold2 || chain_q) { pg = e.g2; pb = e.b2; }
-    else layer_norm(0, y, none, x, e.g2, e.b2, nullptr, nullptr, 0, 0, H_, d_tlens_, T);
+    if (chain_q) { pg = e.g2; pb = e.b2; }
+    else layer_norm(y, x, e.g2, e.b2, H_, d_tlens_, T);
     fl += 2.0 * tsum * (e.qkv.macs_per_col + e.o.macs_per_col + e.f1.macs_per_col + e.f2.macs_per_col);
     for (int b = 0; b < B; ++b) fl += 2.0 * 2.0 * (double)tlens_h_[b] * tlens_h_[b] * H_;
   }
-  if (pg && chain_q) {
-    lngemm(y, pg, pb, x, enc_proj16_, enc_proj_.bias, enc_proj_.rows, stats, T, 2.0 * tsum * enc_proj_.macs_per_col);
-  } else {
-    if (pg) { ln_in_.g = pg; ln_in_.b = pb; ln_in_.out = x; }
-    conv(enc_proj_, pg ? y : x, stats, d_tlens_, 1, T, EPI_STORE);
-  }
+  if (pg) lngemm(y, pg, pb, x, enc_proj16_, enc_proj_.bias, enc_proj_.rows, stats, T, 2.0 * tsum * enc_proj_.macs_per_col);
+  else conv(enc_proj_, x, stats, d_tlens_, 1, T, EPI_STORE);
   fl += 2.0 * tsum * enc_proj_.macs_per_col;
   prof_end(0, fl);
 
@@ -1606,31 +1447,22 @@ void Engine::issue_stage_a() {
   prof_begin();
   fl = 0;
   conv(dp_pre_, x, dy, d_tlens_, 1, T, EPI_STORE, 1.f, ACT_NONE, none, none, 0, 1.f, cb_dp, cond_bs_);
-  // One persistent launch for the whole DDSConv chain + durations when the grid fits one workgroup per CU (a few
-  // utterances): the layers hand halo columns to their neighbours in memory instead of ending the kernel
-  // (dp_persist_kernel). Otherwise one launch per layer.
-  const int ndds = arch_[A_DDSLAYERS] * (1 + (int)cflows_.size());
-  const bool persist = persist_dp_ && fuse_dp_ && ndds <= DP_MAX_LAYERS && (long)((T + 15) / 16) * B <= 256 &&
-                       !(prof_level_ >= 2 && getenv("PIPER_HIP_PROFILE_LAYERS"));
-  std::vector<DdsP> chain;
   if (fuse_dp_) {
     DdsOpt o;                      // dp.proj fused after the last DDSConv layer (models.py:65)
     o.post_w16 = dp_proj16_; o.post_bias = dp_proj_.bias; o.post_rows = dp_proj_.rows; o.post_out = xg;
-    if (persist) dds_params(dp_dds_, dy, dh, dy2, &o, chain);
-    else dds(dp_dds_, dy, dh, dy2, &o);
+    dds(dp_dds_, dy, dh, dy2, &o);
   } else {
     dds(dp_dds_, dy, dh, dy2);
     conv(dp_proj_, dh, xg, d_tlens_, 1, T, EPI_STORE);
   }
   fl += 2.0 * tsum * (2 + arch_[A_DDSLAYERS]) * dp_pre_.macs_per_col;
   // z = noise * noise_scale_w   [B][2][Ts]
-  if (!have_noise_w_) {
-    const long n = (long)B * 2 * Ts;
-    PE_LAUNCH(randn_kernel, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, stream_, noise_w_, n, d_rng_, 0);
-  }
+  if (!have_noise_w_)
+    PE_LAUNCH_K("randn_kernel", randn_kernel, dim3(randn_blocks((long)B * 2, T)), dim3(256), 0, stream_, noise_w_, (long)B * 2, T, (long)Ts,
+              0L, d_rng_, 0);
   if (!fuse_dp_) {
     const long n = (long)B * 2 * Ts;
-    PE_LAUNCH(scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream_, noise_w_, z2_, n, scales_[2]);
+    PE_LAUNCH_K("scale_kernel", scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream_, noise_w_, z2_, n, scales_[2]);
   }
   // Flip is folded into which physical channel is x0 (conditioning) and which is x1 (transformed):
   // logical = physical when an even number of flips has been applied.
@@ -1650,14 +1482,13 @@ void Engine::issue_stage_a() {
       o.z_scale = fi == 0 ? scales_[2] : 1.f;
       o.post_w16 = cf.proj16; o.post_bias = cf.proj.bias; o.post_rows = cf.proj.rows;
       o.zin = zin; o.zin_bs = (long)2 * Ts; o.z_cs = Ts; o.c0 = c0; o.c1 = c1; o.zout = z2_; o.zout_bs = (long)2 * Ts;
-      if (persist) dds_params(cf.dds, xg, dh, dy2, &o, chain);
-      else dds(cf.dds, xg, dh, dy2, &o);
+      dds(cf.dds, xg, dh, dy2, &o);
     } else {
-      PE_LAUNCH(cf_pre_kernel, dim3((T + 63) / 64, H_, B), dim3(64), 0, stream_, z2_ + (long)c0 * Ts, (long)2 * Ts,
+      PE_LAUNCH_K("cf_pre_kernel", cf_pre_kernel, dim3((T + 63) / 64, H_, B), dim3(64), 0, stream_, z2_ + (long)c0 * Ts, (long)2 * Ts,
                 cf.pre_w, cf.pre_b, xg_, (long)H_ * Ts, Ts, dy_, (long)H_ * Ts, Ts, d_tlens_, H_);
       dds(cf.dds, dy, dh, dy2);
       conv(cf.proj, dh, hproj, d_tlens_, 1, T, EPI_STORE);
-      PE_LAUNCH(spline_inverse_kernel, dim3((T + 63) / 64, B), dim3(64), 0, stream_, hproj_, (long)32 * Ts, Ts,
+      PE_LAUNCH_K("spline_inverse_kernel", spline_inverse_kernel, dim3((T + 63) / 64, B), dim3(64), 0, stream_, hproj_, (long)32 * Ts, Ts,
                 z2_ + (long)c1 * Ts, (long)2 * Ts, d_tlens_, 1.0f / std::sqrt((float)H_));
     }
     fl += 2.0 * tsum * (arch_[A_DDSLAYERS] * dp_pre_.macs_per_col + cf.proj.macs_per_col);
@@ -1669,51 +1500,8 @@ void Engine::issue_stage_a() {
     dp.z0 = z2_ + (long)c0 * Ts; dp.z_bs = (long)2 * Ts; dp.m0 = ea_m0_; dp.es0 = ea_es0_; dp.length_scale = scales_[1];
     dp.lens = d_tlens_; dp.dur = d_dur_; dp.cum = d_cum_; dp.d_bs = Ts; dp.frames = d_frames_; dp.logw_out = logw_;
     dp.frames_host = h_frames_; dp.frames_clamped = d_framesc_; dp.frame_cap = std::max(Fs_, 1);
-    if (persist) {
-      DpPersistP pp{};
-      for (size_t i = 0; i < chain.size(); ++i) pp.layer[i] = chain[i];
-      pp.nlayers = (int)chain.size();
-      pp.dur = dp;
-      pp.state = dp_state_; pp.err_host = h_frames_ + 4096;
-      {
-        // halo plan: which slot / tag every layer reads and publishes (kernels.h DdsP)
-        const int nct = (T + 15) / 16;
-        pp.g.gx = dp_gx_; pp.g.gx_ts = (int)dp_gx_ts_; pp.g.gx_bs = (long)nct * (long)dp_gx_ts_;
-        pp.g.gz = dp_gz_; pp.g.gz_ts = 8; pp.g.gz_bs = (long)nct * 8;
-        int xg_tag = 0, last_spline = -1, flow = -1;
-        for (int l = 0; l < pp.nlayers; ++l) {
-          DdsP& q = pp.layer[l];
-          const bool fold = q.pre_z != nullptr, post = q.post_w16 != nullptr;
-          if (fold) ++flow;
-          q.gin_slot = l == 0 ? -1 : (fold ? 2 : (signed char)((l - 1) & 1));
-          q.gin_tag = (unsigned char)(fold ? xg_tag : l);
-          q.gout_slot = post ? -1 : (signed char)(l & 1);
-          q.gout_tag = (unsigned char)(l + 1);
-          q.gout_d = (signed char)(l + 1 < pp.nlayers ? pp.layer[l + 1].dw_dil * ((pp.layer[l + 1].dw_k - 1) / 2) : 0);
-          q.pg_slot = (post && q.post_out) ? 2 : -1;
-          q.pg_tag = (unsigned char)(l + 1);
-          if (q.pg_slot >= 0) xg_tag = l + 1;
-          // z: the first flow reads the noise an earlier kernel wrote; later ones the previous flow's spline output
-          q.zin_par = (fold && last_spline >= 0) ? (signed char)((flow - 1) & 1) : -1;
-          q.zin_tag = (unsigned char)(last_spline + 1);
-          q.zin_row = (signed char)(fold ? (q.pre_z - (fold && last_spline < 0 ? noise_w_ : z2_)) / Ts : 0);
-          q.zout_par = (post && q.zout) ? (signed char)(flow & 1) : -1;
-          q.zout_tag = (unsigned char)(l + 1);
-          if (q.zout_par >= 0) last_spline = l;
-          if (q.gout_d > DDS_HALO || (fold && q.dw_dil != 1)) throw std::runtime_error("internal: DDSConv halo plan");
-        }
-      }
-      const int nch = chain[0].nchunks;
-      const size_t smem = ((size_t)2 * nch * 32 * 16 + 16 * 16 + 16) * sizeof(float) + 2048;
-      const dim3 grid((T + 15) / 16, B);
-      const char* nm = nch == 3 ? "dp_persist_kernel<3>" : nch == 6 ? "dp_persist_kernel<6>" : "dp_persist_kernel<8>";
-      const int kh = kbegin(prof_level_ >= 2 ? krow(nm) : 0, 0.0);
-      if (nch == 3) PE_LAUNCH_COOP(dp_persist_kernel<3>, grid, dim3(512), smem, stream_, pp);
-      else if (nch == 6) PE_LAUNCH_COOP(dp_persist_kernel<6>, grid, dim3(512), smem, stream_, pp);
-      else PE_LAUNCH_COOP(dp_persist_kernel<8>, grid, dim3(512), smem, stream_, pp);
-      kend(kh);
-    } else {
-      PE_LAUNCH(duration_kernel, dim3(B), dim3(256), 0, stream_, dp);
+    {
+      PE_LAUNCH_K("duration_kernel", duration_kernel, dim3(B), dim3(256), 0, stream_, dp);
     }
   }
   prof_end(1, fl);
@@ -1741,8 +1529,8 @@ void Engine::issue_flow() {
   } else {
     // (drawing the noise inside regulate_kernel was tried: one launch fewer, but a Philox block + Box-Muller per element
     // in its 16-channels-per-thread loop cost 21 us against this launch's 5, profiles/r02_notes.md)
-    const long n = (long)B * C_ * Fs;
-    PE_LAUNCH(randn_kernel, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, stream_, noise_z_, n, d_rng_, 1);
+    PE_LAUNCH_K("randn_kernel", randn_kernel, dim3(randn_blocks((long)B * C_, Fmax)), dim3(256), 0, stream_, noise_z_, (long)B * C_, Fmax,
+              (long)Fs, 0L, d_rng_, 1);
   }
   {
     RegP rp;
@@ -1752,7 +1540,7 @@ void Engine::issue_flow() {
     rp.noise_scale = scales_[0];
     rp.out = zp_; rp.o_bs = (long)C_ * Fs; rp.o_cs = Fs; rp.C = C_;
     rp.absmax = absmax_;
-    PE_LAUNCH(regulate_kernel, dim3((Fmax + 63) / 64, (C_ + 15) / 16, B), dim3(64), 0, stream_, rp);
+    PE_LAUNCH_K("regulate_kernel", regulate_kernel, dim3((Fmax + 63) / 64, (C_ + 15) / 16, B), dim3(64), 0, stream_, rp);
     if (zp_keep_)     // tests: z_p, the flow's input (the flow transforms zp_ in place)
       PE_HIP(hipMemcpyAsync(zp_keep_, zp_, (size_t)B * C_ * Fs * sizeof(float), hipMemcpyDeviceToDevice, stream_));
   }
@@ -1805,7 +1593,7 @@ void Engine::issue_stage_b() {
 
 // streaming: window of z -> window buffer -> generator (lens = window length, in device memory)
 void Engine::issue_window() {
-  PE_LAUNCH(window_copy_kernel, dim3((s_wg_ + 63) / 64, C_), dim3(64), 0, stream_, zp_, Fs_, d_win_, zwin_, Fs_, C_);
+  PE_LAUNCH_K("window_copy_kernel", window_copy_kernel, dim3((s_wg_ + 63) / 64, C_), dim3(64), 0, stream_, zp_, Fs_, d_win_, zwin_, Fs_, C_);
   issue_decoder(zwin_, d_win_ + 1, s_wg_, (double)s_wg_, true);
 }
 
@@ -1844,11 +1632,10 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
       // xs accumulates into the buffer that held the stage input (free once the up-conv is done)
       const View xs{hb_[cur_buf], (long)st.ch * Ls, (int)Ls};
       const int Lmax = Fmax * mult;
-      // One resblock chain. `t` = {c1 output, ping, pong}; the chain's result goes to `dst` either as a plain
-      // residual add (parallel schedule) or accumulated into xs with the MRF mode (sequential schedule).
-      auto chain = [&](int j, const View (&t)[3], View dst, bool accumulate, int accmode) {
+      // One resblock chain, accumulated into xs with the MRF mode. `t` = {c1 output, ping, pong}.
+      auto chain = [&](int j, const View (&t)[3], View dst, int accmode) {
         auto& cv = st.rb[j];
-        const int last_epi = accumulate ? EPI_ACCUM : EPI_RESADD;
+        const int last_epi = EPI_ACCUM;
         View xin = u;
         if (arch_[A_RESBLOCK] == 1) {
           // ResBlock1 (modules.py:301-314): x = x + c2(lrelu(c1(lrelu(x)))) per dilation
@@ -1879,11 +1666,8 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
           }
         }
       };
-      // Small launches (one utterance, early stages) leave most CUs idle: run the resblocks of the MRF as
-      // parallel graph branches on side streams, each into its own buffer, and combine them in one pass.
       const size_t need = (size_t)B * st.ch * Ls;
       const long blocks64 = (long)((Lmax + 63) / 64) * ((st.ch + 63) / 64) * B;
-      const bool par = par_mrf_ && !prof_on_ && nk >= 2 && nk <= 3 && blocks64 < 700 && need <= side_floats_;
       // grouped sibling launches are a single-utterance latency measure: measured -24 us (medium) / -4 % (high) at
       // B=1, but +1..2 % at B=2 and B=4, where every conv already fills the chip on its own
       bool grp = group_mrf_ && B == 1 && nk >= 2 && nk <= 3 && blocks64 < 700 && need <= side_floats_;
@@ -1894,12 +1678,8 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
       // One launch per stage wins while the stage is latency-bound (a few utterances: 6 launches of one wave
       // generation each); from ~3 utterances up the conv-by-conv schedule fills the chip and its GEMM kernel is the
       // faster one (profiles/r02_mrf2_ab.txt), so the choice goes by the frames in the batch.
-      if (mrf2_mode_ && st.m2_phases && !fuse_mrf_ && (mrf2_mode_ == 2 || fsum <= (double)mrf2_max_frames_)) {
+      if (mrf2_mode_ && st.m2_phases && (mrf2_mode_ == 2 || fsum <= (double)mrf2_max_frames_)) {
         mrf2(st, u, xs, lens, mult, Lmax);
-        for (auto& cv : st.rb)
-          for (auto& c : cv) fl += 2.0 * fsum * mult * c.macs_per_col;
-      } else if (fuse_mrf_ && st.mrf_steps) {
-        mrf(st, u, xs, lens, mult, Lmax);
         for (auto& cv : st.rb)
           for (auto& c : cv) fl += 2.0 * fsum * mult * c.macs_per_col;
       } else if (grp) {
@@ -1934,31 +1714,13 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
           }
         }
         if (!summed)
-          PE_LAUNCH(mrf_sum_kernel, dim3((Lmax + 255) / 256, st.ch, B), dim3(256), 0, stream_, side_[8], side_[3],
+          PE_LAUNCH_K("mrf_sum_kernel", mrf_sum_kernel, dim3((Lmax + 255) / 256, st.ch, B), dim3(256), 0, stream_, side_[8], side_[3],
                     nk == 3 ? side_[7] : (const float*)nullptr, xs.p, xs.bs, xs.cs, lens, mult, inv_nk);
-      } else if (par) {
-        auto SV = [&](int k) { return View{side_[k], (long)st.ch * Ls, (int)Ls}; };
-        PE_HIP(hipEventRecord(ev_fork_, stream_));
-        for (int j = 1; j < nk; ++j) {
-          PE_HIP(hipStreamWaitEvent(side_stream_[j - 1], ev_fork_, 0));
-          ls_ = side_stream_[j - 1];
-          const View t[3] = {SV(4 * (j - 1)), SV(4 * (j - 1) + 1), SV(4 * (j - 1) + 2)};
-          chain(j, t, SV(4 * (j - 1) + 3), false, 0);
-          PE_HIP(hipEventRecord(ev_join_[j - 1], side_stream_[j - 1]));
-        }
-        ls_ = stream_;
-        {
-          const View t[3] = {tb, ta, tc};
-          chain(0, t, SV(8), false, 0);
-        }
-        for (int j = 1; j < nk; ++j) PE_HIP(hipStreamWaitEvent(stream_, ev_join_[j - 1], 0));
-        PE_LAUNCH(mrf_sum_kernel, dim3((Lmax + 255) / 256, st.ch, B), dim3(256), 0, stream_, side_[8], side_[3],
-                  nk == 3 ? side_[7] : (const float*)nullptr, xs.p, xs.bs, xs.cs, lens, mult, inv_nk);
       } else {
         for (int j = 0; j < nk; ++j) {
           const int accmode = nk == 1 ? 3 : (j == 0 ? 0 : (j == nk - 1 ? 2 : 1));
           const View t[3] = {tb, ta, tc};
-          chain(j, t, xs, true, accmode);
+          chain(j, t, xs, accmode);
         }
       }
       cur = xs;      // same buffer index cur_buf, new shape
@@ -1969,11 +1731,11 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
     prof_begin();
     if (zero_absmax) PE_HIP(hipMemsetAsync(absmax_, 0, B * sizeof(unsigned), stream_));
     const int K = 7, Lmax = Fmax * hop_;
-    PE_LAUNCH(conv_post_kernel, dim3((Lmax + POST_SPB - 1) / POST_SPB, B), dim3(256), 0, stream_, cur.p,
+    PE_LAUNCH_K("conv_post_kernel", conv_post_kernel, dim3((Lmax + POST_SPB - 1) / POST_SPB, B), dim3(256), 0, stream_, cur.p,
               cur.bs, cur.cs, post_w_, post_cin_, 0.01f, lens, hop_, audio_, Ss_, absmax_);
     // (zero_absmax marks the streaming window path, which delivers per chunk from the device buffer)
     int16_t* zc = (pcm_zc_ && !zero_absmax && h_pcm_zc_cap_ >= (size_t)B * (size_t)Ss_) ? h_pcm_zc_ : nullptr;
-    PE_LAUNCH(pcm16_kernel, dim3((Lmax + 255) / 256, B), dim3(256), 0, stream_, audio_, Ss_, absmax_, lens, hop_,
+    PE_LAUNCH_K("pcm16_kernel", pcm16_kernel, dim3((Lmax + 255) / 256, B), dim3(256), 0, stream_, audio_, Ss_, absmax_, lens, hop_,
               pcm_, Ss_, zc);
     prof_end(4, 2.0 * fsum * hop_ * post_cin_ * K);
   }
@@ -2050,12 +1812,12 @@ void Engine::run() {
   spec_pending_ = false;
   Tg_ = std::min(rup(Tmax_, 32), Ts_);
   run_launches_ = 0;
-  if (persist_dp_ && ++dp_runs_ >= (1ull << 24)) dp_reset_granules();     // epoch * 64 + layer must stay below 2^32
   // speculative sizing of stage B from the previous run's frames-per-id ratio (see engine.h)
   bool spec = spec_enable_ && B <= spec_max_batch_ && last_ratio_ > 0.f && !have_noise_z_ && use_graphs_ && !prof_on_;
+  if (spec && spec_cooldown_ > 0) { --spec_cooldown_; spec = false; }
   int fguess = 0;
   if (spec) {
-    fguess = rup((int)std::ceil(last_ratio_ * 1.10f * (float)Tmax_) + 1, 32);
+    fguess = rup((int)std::ceil(last_ratio_ * spec_margin_ * (float)Tmax_) + 1, 32);
     if (fguess > MAX_FRAMES) spec = false;
   }
   if (spec) ensure_stage_b(fguess);              // before stage A is enqueued: growing the workspace drops every graph
@@ -2072,6 +1834,7 @@ void Engine::run() {
     ++call_;                                  // mirrors the device-side counter bump of this run
     spec_pending_ = true;
     spec_fg_ = Fg_;
+    ++spec_runs_;
     return;
   }
   snprintf(key, sizeof(key), "A|%d|%d|%d|%a|%a|%d|%d", B, Tg_, Ts_, scales_[1], scales_[2], (int)have_noise_w_, Fs_);
@@ -2100,11 +1863,6 @@ void Engine::finish_stage_b_sizes() {
   if (const char* pf = getenv("EMU_PLAN_FRAMES"))      // emulator plan-only mode (tests/emu): frames are not computed
     for (int b = 0; b < B; ++b) h_frames_[b] = atoi(pf);
 #endif
-  if (h_frames_[4096]) {          // a persistent kernel gave up waiting for a neighbour workgroup (never on a resident grid)
-    h_frames_[4096] = 0;
-    dp_reset_granules();
-    throw std::runtime_error("persistent duration-predictor kernel: neighbour wait timed out");
-  }
   frames_h_.assign(h_frames_, h_frames_ + B);
   int Fmax = 1;
   float ratio = 0.f;
@@ -2116,7 +1874,9 @@ void Engine::finish_stage_b_sizes() {
     throw std::runtime_error("utterance too long: more than " + std::to_string(MAX_FRAMES) + " spectrogram frames "
                              "(check length_scale)");
   Fmax_ = Fmax;
-  last_ratio_ = ratio;
+  // decaying maximum: one long-winded utterance keeps the estimate up for a while, a lasting change of voice / scales
+  // is followed within ~50 calls
+  last_ratio_ = std::max(ratio, last_ratio_ * 0.98f + ratio * 0.02f);
   sample_off_.assign(B + 1, 0);
   for (int b = 0; b < B; ++b) sample_off_[b + 1] = sample_off_[b] + (int64_t)frames_h_[b] * hop_;
 }
@@ -2127,8 +1887,15 @@ bool Engine::finish_run() {
   spec_pending_ = false;
   PE_HIP(hipStreamSynchronize(stream_));
   finish_stage_b_sizes();
-  if (Fmax_ <= spec_fg_) return true;          // the guessed bucket covered every utterance: the results stand
+  if (++spec_recent_runs_ >= 16) { spec_recent_runs_ = 0; spec_recent_misses_ = 0; }
+  if (Fmax_ <= spec_fg_) {                     // the guessed bucket covered every utterance: the results stand
+    if (++spec_hit_streak_ >= 32) { spec_hit_streak_ = 0; spec_margin_ = std::max(1.10f, spec_margin_ / 1.05f); }
+    return true;
+  }
   ++spec_misses_;
+  spec_hit_streak_ = 0;
+  spec_margin_ = std::min(1.5f, spec_margin_ * 1.15f);
+  if (++spec_recent_misses_ >= 4) { spec_recent_misses_ = 0; spec_recent_runs_ = 0; spec_cooldown_ = 64; }
   ensure_stage_b(rup(Fmax_, 32));
   Fg_ = std::min(rup(Fmax_, 32), Fs_);
   lens_b_ = d_frames_;
@@ -2260,6 +2027,7 @@ bool Engine::stream_next(int chunk_frames, const float** audio, const int16_t** 
 }
 
 const std::vector<int32_t>& Engine::durations_host() {
+  EntryLock entry_lock;
   finish_run();
   std::vector<int> tmp((size_t)B_ * Ts_);
   PE_HIP(hipMemcpy(tmp.data(), d_dur_, tmp.size() * sizeof(int), hipMemcpyDeviceToHost));
@@ -2270,17 +2038,21 @@ const std::vector<int32_t>& Engine::durations_host() {
 }
 
 // Test hook: what randn_kernel draws for (seed_, call, site) -- the generator of the product path when the caller
-// injects no noise.
-void Engine::debug_randn(int site, uint64_t call, int64_t n, float* out) {
-  if (n <= 0 || !out || site < 0 || site > 1) throw std::runtime_error("debug_randn: bad arguments");
+// injects no noise: draws [row * RNG_PITCH, row * RNG_PITCH + n) of the site's stream (kernels.h: the pipeline's noise
+// for column f of logical row r = utterance * channels + channel is draw r * RNG_PITCH + f).
+void Engine::debug_randn(int site, uint64_t call, int64_t row, int64_t n, float* out) {
+  if (n <= 0 || row < 0 || !out || site < 0 || site > 1) throw std::runtime_error("debug_randn: bad arguments");
+  EntryLock entry_lock;
   PE_HIP(hipSetDevice(device_));
   float* d = nullptr;
   unsigned long long* st = nullptr;
-  PE_HIP(hipMalloc((void**)&d, (size_t)n * sizeof(float)));
+  const long rows = (long)((n + RNG_PITCH - 1) / RNG_PITCH);
+  const int cols = rows > 1 ? RNG_PITCH : (int)n;
+  PE_HIP(hipMalloc((void**)&d, (size_t)rows * cols * sizeof(float)));
   if (hipMalloc((void**)&st, 16) != hipSuccess) { hipFree(d); throw std::runtime_error("debug_randn: out of memory"); }
   const unsigned long long hst[2] = {seed_, call};
   hipMemcpy(st, hst, sizeof(hst), hipMemcpyHostToDevice);
-  PE_LAUNCH(randn_kernel, dim3((unsigned)((n / 4 + 255) / 256 + 1)), dim3(256), 0, stream_, d, (long)n, st, site);
+  PE_LAUNCH(randn_kernel, dim3(randn_blocks(rows, cols)), dim3(256), 0, stream_, d, rows, cols, (long)cols, (long)row, st, site);
   hipStreamSynchronize(stream_);
   hipMemcpy(out, d, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
   hipFree(d);
@@ -2290,6 +2062,7 @@ void Engine::debug_randn(int site, uint64_t call, int64_t n, float* out) {
 // Per-stage tensors for parity debugging (tests only): name in {x_enc, stats (m_p | logs_p), xg, logw, z_p, z, noise_w,
 // noise_z, audio}.
 void Engine::debug_tensor(const std::string& name, int b, std::vector<float>& out, int* rows, int* cols) {
+  EntryLock entry_lock;
   finish_run();
   PE_HIP(hipStreamSynchronize(stream_));
   const float* src = nullptr;

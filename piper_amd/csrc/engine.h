@@ -92,11 +92,15 @@ class Engine {
   const std::vector<int32_t>& frames_host() { finish_run(); return frames_h_; }
   void debug_tensor(const std::string& name, int b, std::vector<float>& out, int* rows, int* cols);
   // test hook: n draws of the engine's N(0,1) generator (randn_kernel) at sampling site 0/1 with the engine's
-  // seed and the given call counter, exactly what run() would draw at that counter
-  void debug_randn(int site, uint64_t call, int64_t n, float* out);
+  // seed and the given call counter, starting at logical row `row` of the site's stream: exactly what run() would draw
+  // at that counter for (utterance, channel) = row, columns 0 .. n-1
+  void debug_randn(int site, uint64_t call, int64_t row, int64_t n, float* out);
   uint64_t rng_call() const { return call_; }
-  long run_launches() const { return run_launches_; }
-  long speculation_misses() const { return spec_misses_; }   // kernel launches (graph nodes) of the last run()
+  long run_launches() const { return run_launches_; }          // kernel launches (graph nodes) of the last run()
+  // speculative stage-B sizing (see below): runs issued with a guessed frame bucket / guesses that were too small and
+  // cost a second pass of stage B, since the engine was created
+  long speculation_runs() const { return spec_runs_; }
+  long speculation_misses() const { return spec_misses_; }
 
   void set_seed(uint64_t s) { seed_ = s; }
   void set_use_graphs(bool on) { use_graphs_ = on; }
@@ -148,15 +152,9 @@ class Engine {
   bool can_group_sum() const;
   void group_end_sum(View out, const float* bias_sum, float alpha);
   int group_mrf_ = 1;                        // PIPER_HIP_GROUP_MRF=0: sibling resblock convs one launch each (A/B, tests)
-  // LayerNorm folded into the next conv() call's input staging (split-K launches only; see can_fold_ln)
-  struct LnIn { const float* g = nullptr; const float* b = nullptr; View out{nullptr, 0, 0}; };
-  LnIn ln_in_;
   enum { ROUTE_TILE = 0, ROUTE_SPLITK = 1, ROUTE_SPLITK16 = 2 };
   int route(const PackedConv& pc, int ncols, int epi) const;
-  bool can_fold_ln(const PackedConv& pc, int ncols) const;
-  bool fold_ln_ = false;                    // PIPER_HIP_FOLD_LN=1: encoder LayerNorms folded into the consuming split-K convs (measured slower, profiles/r02_notes.md)
-  void layer_norm(int mode, View in, View res, View out, const float* g, const float* b, const float* dw_w,
-                  const float* dw_b, int dw_k, int dw_dil, int C, const int* lens, int Lmax);
+  void layer_norm(View in, View out, const float* g, const float* b, int C, const int* lens, int Lmax);
   // options of one DDSConv run: ConvFlow.pre folded into the first layer, a 1x1 conv (+ spline) fused after the last
   struct DdsOpt {
     const float* pre_z = nullptr; long pre_z_bs = 0; const float* pre_w = nullptr; const float* pre_b = nullptr;
@@ -166,17 +164,7 @@ class Engine {
     const float* zin = nullptr; long zin_bs = 0; int z_cs = 0, c0 = 0, c1 = 1; float* zout = nullptr; long zout_bs = 0;
   };
   void dds(const DdsW& d, View in, View out, View tmp, const DdsOpt* opt = nullptr);
-  // the DdsP of every layer of one DDSConv run, appended to `out` (dds() launches them; the persistent
-  // duration-predictor kernel takes all twelve at once)
   void dds_params(const DdsW& d, View in, View out, View tmp, const DdsOpt* opt, std::vector<struct DdsP>& list);
-  bool persist_dp_ = false;                 // PIPER_HIP_PERSIST_DP=1: the DDSConv chain as one persistent launch (measured no faster, profiles/r02_notes.md)
-  // dp_persist_kernel: halo granule arenas (256 column tiles: the kernel only runs on grids of <= 1 workgroup per CU),
-  // epoch / counters; dp_runs_ counts launches so that the arenas are cleared long before the 32-bit tags wrap
-  unsigned long long *dp_gx_ = nullptr, *dp_gz_ = nullptr;
-  size_t dp_gx_ts_ = 0;
-  unsigned* dp_state_ = nullptr;
-  uint64_t dp_runs_ = 0;
-  void dp_reset_granules();
   float* pack16(const std::vector<float>& W, int rows, int K);    // [16-row tile][q][lane][4] (dds_layer16_kernel)
   float* dp_proj16_ = nullptr;
   int colchain_ = 1;                        // PIPER_HIP_COLCHAIN: 0 off, 1 by batch size, 2 always (A/B, tests)
@@ -209,8 +197,12 @@ class Engine {
   void finish_stage_b_sizes();
   bool spec_enable_ = true, spec_pending_ = false;
   int spec_max_batch_ = 4, spec_fg_ = 0;
-  float last_ratio_ = 0.f;
-  long spec_misses_ = 0;
+  // The guess = (slowly decaying maximum of the frames-per-id ratios seen so far) x margin. The margin adapts: a miss
+  // widens it (x 1.15, up to 1.5), 32 hits in a row narrow it again (down to 1.10); four misses within 16 speculative
+  // runs switch speculation off for the next 64 calls (texts whose lengths vary too much for the estimate to hold).
+  float last_ratio_ = 0.f, spec_margin_ = 1.10f;
+  long spec_misses_ = 0, spec_runs_ = 0;
+  int spec_hit_streak_ = 0, spec_recent_misses_ = 0, spec_recent_runs_ = 0, spec_cooldown_ = 0;
   int* d_framesc_ = nullptr;
   const int* lens_b_ = nullptr;      // frame counts stage B reads: d_frames_, or d_framesc_ on a speculative run
   void prof_begin();
@@ -263,11 +255,7 @@ class Engine {
     int rate, ch;
     std::vector<std::vector<PackedConv>> rb;   // [resblock][conv] (ResBlock1: c1_0,c2_0,c1_1,...)
     float* last_bias_sum = nullptr;            // sum over the resblocks of their LAST conv's bias (conv_splitk_sum_kernel)
-    // fused MRF stage (mrf_fused_kernel): device step table, or null when the stage runs conv by conv
-    void* mrf_steps = nullptr;
-    int mrf_nsteps = 0, mrf_hx = 0, mrf_ws = 0, mrf_cp = 0, mrf_nbuf = 0;
-    double mrf_macs_per_col = 0;
-    // second-generation fused MRF stage (mrf2_kernel, mrf2.h): device tables, or null
+    // fused MRF stage (mrf2_kernel, kernels/mrf2.h): device tables, or null when the stage runs conv by conv
     struct HostConv { std::vector<float> w; int co = 0, ci = 0, k = 0, dil = 1; const float* bias = nullptr; };
     std::vector<std::vector<HostConv>> rb_host;   // host copies of the resblock convs, dropped after build_mrf2
     void* m2_phases = nullptr; void* m2_segs = nullptr; float* m2_w = nullptr;
@@ -279,12 +267,6 @@ class Engine {
   void mrf2(const UpStage& st, View x, View out, const int* lens, int len_mul, int Lmax);
   long mrf2_max_frames_ = 1100;             // batch frames up to which the fused stage kernel is used in mode 1
   int mrf2_mode_ = 1;                       // PIPER_HIP_MRF2: 0 off (conv by conv), 1 fused stage kernel where it applies
-  void build_mrf(UpStage& st);
-  void mrf(const UpStage& st, View x, View out, const int* lens, int len_mul, int Lmax);
-  // The fused MRF stage kernel moves ~3x fewer HBM bytes but is LDS-capacity bound to 2 waves per SIMD; since the
-  // conv GEMM kernel's prefetch/epilogue rework the conv-by-conv schedule is faster at every batch size measured
-  // (profiles/r01_mrf_ab.txt), so it is opt-in (PIPER_HIP_FUSE_MRF=1).
-  bool fuse_mrf_ = false;
   int splitk16_ = 2;                        // 16-column split-K: 0 off, 1 WN gate conv, 2 also long-K plain convs, 3 all (tests)
   int wide_splitk_ = 1;                     // 12-wave split-K workgroups for long-K launches
   long splitk_max_blocks_ = 96;             // launches with fewer tile-kernel workgroups use conv_splitk_kernel
@@ -330,13 +312,10 @@ class Engine {
   int cond_off_dp_ = 0, cond_off_dec_ = 0;
   float *zp_ = nullptr, *fh_ = nullptr, *facts_ = nullptr, *fskip_ = nullptr, *noise_z_ = nullptr;
   float* hb_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-  // parallel MRF branches (small launches only): side streams, fork/join events, per-branch buffers
-  hipStream_t side_stream_[2] = {nullptr, nullptr};
-  hipStream_t ls_ = nullptr;       // stream conv()/layer launches go to (stream_ or a side stream)
-  hipEvent_t ev_fork_ = nullptr, ev_join_[2] = {nullptr, nullptr};
+  hipStream_t ls_ = nullptr;       // stream conv()/layer launches go to
+  // per-resblock buffers of the grouped sibling schedule (one-utterance calls)
   float* side_[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   size_t side_floats_ = 0;
-  bool par_mrf_ = false;            // measured no gain at B=1 (profiles/r01_notes.md); PIPER_HIP_PAR_MRF=1 enables
   float* zwin_ = nullptr;          // streaming: current window of z, [C][Fs]
   int* d_win_ = nullptr;           // streaming: {start, length} of the window in frames
   int halo_frames_ = 0, s_frames_ = 0, s_pos_ = 0, s_wg_ = 0;

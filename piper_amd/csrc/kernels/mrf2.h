@@ -17,7 +17,8 @@
 //     the only barrier is one per segment (it also orders the activation buffers between phases).
 // Every step is the same k-ordered f32 fmaf chain as the conv kernels (chunk-major, tap-minor, ascending channel).
 #pragma once
-#include "pe_rt.h"
+#include "../pe_rt.h"
+#include "conv_common.h"
 
 namespace pe {
 

@@ -293,16 +293,24 @@ int pe_debug_tensor(pe_engine* e, const char* name, int32_t b, float* out, int64
   });
 }
 
-int pe_debug_randn(pe_engine* e, int32_t site, uint64_t call, int64_t n, float* out) {
+int pe_debug_randn(pe_engine* e, int32_t site, uint64_t call, int64_t row, int64_t n, float* out) {
   return guard([&] {
     if (!e || !out) throw std::runtime_error("null argument");
-    e->eng->debug_randn(site, call, n, out);
+    e->eng->debug_randn(site, call, row, n, out);
   });
 }
 
 uint64_t pe_rng_calls(pe_engine* e) { return e ? e->eng->rng_call() : 0; }
 
 int64_t pe_run_launches(pe_engine* e) { return e ? (int64_t)e->eng->run_launches() : 0; }
+
+int pe_speculation_stats(pe_engine* e, int64_t* runs, int64_t* misses) {
+  return guard([&] {
+    if (!e) throw std::runtime_error("null engine");
+    if (runs) *runs = (int64_t)e->eng->speculation_runs();
+    if (misses) *misses = (int64_t)e->eng->speculation_misses();
+  });
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 // pe_group_*: one engine / stream / worker thread per device in ONE process (include/piper_hip.h)
@@ -419,9 +427,19 @@ pe_engine* pe_group_engine(pe_group* g, int32_t i) {
 int pe_group_synthesize_batch(pe_group* g, const int64_t* ids, const int64_t* offsets, int32_t batch,
                               const float scales[3], const int64_t* sids, pe_result* result) {
   return guard([&] {
-    if (!g || !ids || !offsets || !scales || batch < 1) throw std::runtime_error("null argument");
-    const auto t0 = std::chrono::steady_clock::now();
+    if (!g || !ids || !offsets || !scales) throw std::runtime_error("null argument");
     const int n = (int)g->eng.size();
+    // the offsets are the caller's: check them BEFORE they size a copy (the same rules and messages as Engine::upload,
+    // which would only see them after the deal)
+    if (batch < 1 || (int64_t)batch > (int64_t)4096 * n)
+      throw std::runtime_error("batch size must be in [1, 4096 per engine]");
+    if (offsets[0] < 0) throw std::runtime_error("negative phoneme id offset");
+    for (int u = 0; u < batch; ++u) {
+      const int64_t T = offsets[u + 1] - offsets[u];
+      if (T <= 0) throw std::runtime_error("empty phoneme id sequence");
+      if (T > 8192) throw std::runtime_error("phoneme id sequence longer than 8192");
+    }
+    const auto t0 = std::chrono::steady_clock::now();
     const std::vector<std::vector<int>> shard = lpt(offsets, batch, n);
     g->assign.assign(batch, 0);
     struct Work {
@@ -441,20 +459,42 @@ int pe_group_synthesize_batch(pe_group* g, const int64_t* ids, const int64_t* of
         if (sids) w.sids.push_back(sids[u]);
       }
     }
+    // a shard = upload + device pipeline + int16 PCM to the host; the float waveform stays on the device (the group
+    // result carries no `audio`)
     auto run = [&](int i) {
       Work& w = work[i];
       if (shard[i].empty()) return;
-      w.rc = pe_synthesize_batch(g->eng[i], w.ids.data(), w.off.data(), (int32_t)shard[i].size(), scales,
-                                 sids ? w.sids.data() : nullptr, nullptr, &w.res);
-      if (w.rc) w.err = g_err;               // the message lives in the worker's thread-local slot
+      try {
+        pe::Engine* e = g->eng[i]->eng;
+        e->upload(w.ids.data(), w.off.data(), (int)shard[i].size(), scales, sids ? w.sids.data() : nullptr, nullptr);
+        e->run();
+        e->download(false, true);
+        fill_result(g->eng[i], &w.res, 0.0);
+      } catch (const std::exception& ex) {
+        w.rc = 1;
+        w.err = ex.what();
+      } catch (...) {
+        w.rc = 1;
+        w.err = "unknown error";
+      }
     };
 #ifdef PE_EMU
     for (int i = 0; i < n; ++i) run(i);      // the emulator is single-threaded
 #else
-    std::vector<std::thread> th;
-    for (int i = 1; i < n; ++i) th.emplace_back(run, i);
-    run(0);
-    for (auto& t : th) t.join();
+    {
+      // joins whatever was started, also when starting a later thread throws (a joinable std::thread that is destroyed
+      // terminates the process)
+      struct Joiner {
+        std::vector<std::thread> th;
+        ~Joiner() {
+          for (auto& t : th)
+            if (t.joinable()) t.join();
+        }
+      } joiner;
+      joiner.th.reserve(n);
+      for (int i = 1; i < n; ++i) joiner.th.emplace_back(run, i);
+      run(0);
+    }
 #endif
     for (int i = 0; i < n; ++i)
       if (work[i].rc) throw std::runtime_error("device " + std::to_string(g->device[i]) + ": " + work[i].err);

@@ -8,20 +8,6 @@ namespace pe { extern thread_local long g_launches; }   // kernel launches issue
 #include "hip_emu.h"
 #define PE_LAUNCH(kernel, grid, block, smem, stream, ...) \
   (++pe::g_launches, emu::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); }))
-// a launch whose workgroups synchronise with each other inside the kernel (all of them must be resident): the emulator
-// runs every block of such a launch concurrently
-#define PE_LAUNCH_COOP(kernel, grid, block, smem, stream, ...) \
-  (++pe::g_launches, emu::launch_coop((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); }))
-// agent-scope accesses / polling helpers (GPU: sc1 cache policy, see below)
-inline float pe_ld_sc1(const float* p) { return *p; }
-inline void pe_st_sc1(float* p, float v) { *p = v; }
-inline unsigned long long pe_ld_gran(const unsigned long long* p) { return *(volatile const unsigned long long*)p; }
-inline void pe_st_gran(unsigned long long* p, unsigned long long v) { *(volatile unsigned long long*)p = v; }
-inline unsigned pe_ld_flag(const unsigned* p) { return *(volatile const unsigned*)p; }
-inline void pe_st_flag(unsigned* p, unsigned v) { *(volatile unsigned*)p = v; }
-inline unsigned pe_atomic_inc(unsigned* p) { const unsigned o = *p; *p = o + 1; return o; }
-inline void pe_spin_pause() { emu::yield(); }
-inline void pe_drain_stores() {}
 #define PE_DYN_SMEM(type, name) type* name = reinterpret_cast<type*>(emu::dyn_smem)
 #define PE_STAMP(k, i) ((void)0)
 #define PE_KTRACE(id) ((void)0)
@@ -48,15 +34,11 @@ inline f32x4 pe_row_load4(const pe_rowsrc& r, int idx) {
   for (int j = 0; j < 4; ++j) v[j] = (idx + j >= 0 && idx + j < r.n) ? r.p[idx + j] : 0.f;
   return v;
 }
-inline float pe_row_load_sc1(const pe_rowsrc& r, int idx) { return pe_row_load(r, idx); }
 inline float pe_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 #else
 #include <hip/hip_runtime.h>
 #define PE_LAUNCH(kernel, grid, block, smem, stream, ...) \
   do { ++pe::g_launches; hipLaunchKernelGGL(kernel, (grid), (block), (smem), (stream), __VA_ARGS__); } while (0)
-// a launch whose workgroups synchronise with each other inside the kernel: a plain launch -- residency comes from the
-// grid size alone (the callers keep such grids <= one workgroup per CU)
-#define PE_LAUNCH_COOP(kernel, grid, block, smem, stream, ...) PE_LAUNCH(kernel, grid, block, smem, stream, __VA_ARGS__)
 #define PE_DYN_SMEM(type, name) \
   extern __shared__ __attribute__((aligned(16))) unsigned char pe_dyn_smem_raw[]; \
   type* name = reinterpret_cast<type*>(pe_dyn_smem_raw)
@@ -139,34 +121,6 @@ __device__ __forceinline__ float pe_row_load_so(pe_rowsrc r, int vidx, int sidx)
 __device__ __forceinline__ void pe_row_store_so(pe_rowsrc r, int vidx, int sidx, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)((unsigned)vidx * 4u), sidx * 4, 0);
 }
-// ---- data exchanged between workgroups INSIDE one launch (persistent kernels). Per-XCD L2s are not coherent and a CU's L1
-// is never refreshed by another CU's stores: producer stores and consumer loads both carry the agent-scope (sc1) cache
-// policy -- write-through on the store side, L1 bypass on the load side -- and a flag / counter written after
-// `s_waitcnt vmcnt(0)` orders them (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility",
-// valid form "sc1 payload -> drained -> flag; consumer: relaxed poll -> sc1 loads").
-__device__ __forceinline__ float pe_row_load_sc1(pe_rowsrc r, int idx) {
-  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)((unsigned)idx * 4u), 0, 16));   // aux 16 = sc1
-}
-__device__ __forceinline__ float pe_ld_sc1(const float* p) {
-  return __builtin_bit_cast(float, __hip_atomic_load(reinterpret_cast<const unsigned*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-}
-__device__ __forceinline__ void pe_st_sc1(float* p, float v) {
-  __hip_atomic_store(reinterpret_cast<unsigned*>(p), __builtin_bit_cast(unsigned, v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// 8-byte {tag, value} granules: the data is its own flag (one fabric round trip per hand-off, no drain, no fence)
-__device__ __forceinline__ unsigned long long pe_ld_gran(const unsigned long long* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void pe_st_gran(unsigned long long* p, unsigned long long v) {
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ unsigned pe_ld_flag(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void pe_st_flag(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned pe_atomic_inc(unsigned* p) { return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void pe_spin_pause() { __builtin_amdgcn_s_sleep(1); }
-// every wave that stored payload drains its stores before the workgroup's flag goes out (inline asm: the compiler must
-// not drop the wait, MI355X_MICROARCH.md "Compiler hazard")
-__device__ __forceinline__ void pe_drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // four consecutive floats (16-byte aligned index) in one instruction
 __device__ __forceinline__ f32x4 pe_row_load4(pe_rowsrc r, int idx) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, idx * 4, 0, 0));

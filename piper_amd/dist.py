@@ -61,7 +61,10 @@ def load_sharded(blob: Optional[bytes], src: int = 0, device: Optional[int] = No
     backend): rank `src` parses / packs / uploads the voice into its arena; every other rank receives only the small
     blob header (tensor shapes), lays out an identical arena without touching weight data, and gets the arena's content
     by `dist.broadcast` straight into it -- no host round trip, no packing outside `src`. The arena is a torch uint8
-    tensor (so the collective can take it as is); the engine keeps it alive. Returns (engine, seconds in the broadcast).
+    tensor (so the collective can take it as is); the engine keeps it alive. Every rank checks that its arena layout
+    (bytes used) equals the source's before the collective: the layout depends on the library build and on launcher
+    knobs read from the environment, and a mismatch would otherwise hang the broadcast or scatter the weights.
+    Returns (engine, seconds in the broadcast, bytes broadcast).
     """
     import time
     import torch
@@ -89,6 +92,13 @@ def load_sharded(blob: Optional[bytes], src: int = 0, device: Optional[int] = No
                  arena=(arena.data_ptr(), bound.value), skeleton=rank != src)
     eng._arena = arena
     used = eng.weights_used()
+    ref = [used if rank == src else None]
+    dist.broadcast_object_list(ref, src)
+    ok = torch.tensor([1 if ref[0] == used else 0], dtype=torch.int32, device=tdev if nccl else torch.device("cpu"))
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)             # every rank learns of a mismatch anywhere: nobody hangs
+    if int(ok.item()) != 1:
+        raise RuntimeError(f"rank {rank}: packed-weight arena uses {used} bytes but rank {src}'s uses {ref[0]}: the ranks "
+                           "run different builds of libpiper_hip.so or different PIPER_HIP_* settings")
     if on_gpu:
         torch.cuda.synchronize()
     dist.barrier()

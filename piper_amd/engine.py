@@ -219,10 +219,13 @@ class Engine:
                          "bytes": by.value})
         return rows
 
-    def debug_randn(self, site: int, call: int, n: int) -> np.ndarray:
-        """Test hook: n draws of the engine's own N(0,1) generator at sampling site 0/1, run counter `call`."""
+    RNG_PITCH = 65536
+
+    def debug_randn(self, site: int, call: int, n: int, row: int = 0) -> np.ndarray:
+        """Test hook: n draws of the engine's own N(0,1) generator at sampling site 0/1, run counter `call`, from
+        logical row `row` of the site's [row][65536] stream (row = utterance * channels + channel, column = id / frame)."""
         out = np.zeros(int(n), np.float32)
-        self._check(self._lib.pe_debug_randn(self._h, int(site), int(call), int(n),
+        self._check(self._lib.pe_debug_randn(self._h, int(site), int(call), int(row), int(n),
                                              out.ctypes.data_as(C.POINTER(C.c_float))))
         return out
 
@@ -230,6 +233,13 @@ class Engine:
     def run_launches(self) -> int:
         """Kernel launches (graph nodes) of the last run: the dependent launch chain of one step."""
         return int(self._lib.pe_run_launches(self._h))
+
+    @property
+    def speculation_stats(self):
+        """(runs, misses) of the speculative stage-B sizing since the engine was created (include/piper_hip.h)."""
+        runs, miss = C.c_int64(), C.c_int64()
+        self._check(self._lib.pe_speculation_stats(self._h, C.byref(runs), C.byref(miss)))
+        return int(runs.value), int(miss.value)
 
     @property
     def rng_calls(self) -> int:

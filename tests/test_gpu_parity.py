@@ -265,32 +265,6 @@ def test_all_zero_durations_give_one_frame():
     assert np.max(np.abs(r.audio[0] - o["audio"])) < TIGHT_AUDIO_TOL
 
 
-@pytest.mark.parametrize("preset,T", [("medium", 40), ("high", 24)])
-def test_optional_fused_mrf_stage_kernel_matches(monkeypatch, preset, T):
-    """PIPER_HIP_FUSE_MRF=1 runs the <=64-channel generator stages through mrf_fused_kernel (one launch per
-    stage, halo recompute out of LDS); it must agree with the default conv-by-conv schedule and the oracle."""
-    from oracle import vits_oracle as O
-    from piper_amd.engine import Engine
-    cfg, w, eng = engine_for(preset)
-    ids = [W.synthetic_phoneme_ids(n, i, id_max=cfg.n_vocab - 1) for i, n in enumerate((T, 5))]
-    nws, nzs = zip(*[noise_for(cfg, T, seed=21 + i) for i in range(2)])
-    nw, nz = np.stack(nws), np.stack(nzs)
-    scales = (0.667, 1.0, 0.8)
-    base = eng.synthesize_batch(ids, scales, noise_w=nw, noise_z=nz)
-    monkeypatch.setenv("PIPER_HIP_FUSE_MRF", "1")
-    fe = Engine(blob=W.pack_blob(cfg, w), device=0)
-    fe.profile_enable(2)
-    fused = fe.synthesize_batch(ids, scales, noise_w=nw, noise_z=nz)
-    assert any(r["name"].startswith("mrf_fused_kernel") for r in fe.profile())
-    fe.close()
-    for i in range(2):
-        assert fused.audio[i].shape == base.audio[i].shape
-        assert np.max(np.abs(fused.audio[i] - base.audio[i])) < 1e-5
-    o = O.synthesize(w, cfg, ids[0], scales, nw[0], nz[0])
-    assert np.max(np.abs(fused.audio[0] - o["audio"])) < TIGHT_AUDIO_TOL
-    assert pcm_rms(fused.pcm[0], O.audio_float_to_int16(o["audio"])) <= RMS_TOL
-
-
 def test_streaming_export_directory_is_the_same_voice():
     """encoder.onnx + decoder.onnx (reference export_onnx_streaming.py) loaded as a directory give the waveform
     of the single-file export of the same weights, also through the chunked streaming API."""

@@ -199,7 +199,8 @@ def test_null_handles_are_errors_not_crashes(lib):
     r, c = C.c_int32(), C.c_int32()
     buf = (C.c_float * 4)()
     assert lib.pe_debug_tensor(None, b"z", 0, buf, 4, C.byref(r), C.byref(c)) != 0
-    assert lib.pe_debug_randn(None, 0, 1, 4, buf) != 0
+    assert lib.pe_debug_randn(None, 0, 1, 0, 4, buf) != 0
+    assert lib.pe_speculation_stats(None, None, None) != 0
     assert lib.pe_rng_calls(None) == 0 and lib.pe_run_launches(None) == 0
     lib.pe_destroy(None)
 
