@@ -75,6 +75,12 @@ def self_launch(args):
     raise SystemExit(subprocess.call(cmd, env=env))
 
 
+def dbg(msg):
+    """Progress markers on stderr (PIPER_BENCH_DEBUG=1): where a run that ends without its JSON line stopped."""
+    if os.environ.get("PIPER_BENCH_DEBUG") == "1":
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 class Ctx:
     """Process-wide state of one bench run: rank / world, the torch.distributed handle (or None), device."""
     def __init__(self):
@@ -218,6 +224,7 @@ def main():
             dist.init_process_group(ctx.backend, rank=ctx.rank, world_size=ctx.world)
         assert dist.get_world_size() == args.gpus
         ctx.dist = dist
+        dbg(f"process group up: backend {ctx.backend}, world {ctx.world}")
 
     cfg = W.preset(preset)
     # ---- voice: rank 0 builds / parses / packs it; the others lay out an identical weight arena from the blob header and
@@ -229,6 +236,7 @@ def main():
         eng, t_bcast, bcast_bytes = load_sharded(W.pack_blob(cfg, wts) if ctx.rank == 0 else None, 0, ctx.dev_index)
     else:
         eng = Engine(blob=W.pack_blob(cfg, wts), device=ctx.dev_index)
+    dbg(f"engine ready (broadcast {bcast_bytes} bytes in {t_bcast:.3f} s)")
 
     if args.stream_latency:
         out = stream_latency(eng, cfg, preset, T, args.steps, args.warmup, ctx.rank)
@@ -248,6 +256,7 @@ def main():
         ctx.barrier()
 
     leg = timed_leg(ctx, eng, cfg, preset, B, T, args.steps, args.warmup)
+    dbg(f"timed leg done: {leg['ms_per_step']:.3f} ms/step")
     frames, id_lists, noise_w = leg["frames"], leg["id_lists"], leg["noise_w"]
 
     # ---- sustained: keep the GPU busy for >= --min-seconds in total (same step), reported separately
@@ -330,8 +339,10 @@ def main():
             not (args.preset or args.batch or args.ids):
         out["extra_configs"] = extra_configs(ctx, eng, cfg, args)
     if ctx.rank == 0:
+        dbg("printing the result line")
         print(json.dumps(out), flush=True)
     finish(ctx)
+    dbg("done")
 
 
 def finish(ctx):

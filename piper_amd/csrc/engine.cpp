@@ -6,7 +6,7 @@
 #include "kernels/dds.h"
 #include "kernels/duration.h"
 #include "kernels/layernorm.h"
-#include "kernels/mrf2.h"
+#include "kernels/mrf.h"
 #include "kernels/post.h"
 
 #include <algorithm>
@@ -71,7 +71,7 @@ float* Engine::dev_tensor(const WeightSet& ws, const std::string& name) {
 }
 
 // Packed copies: conv weights once in 32x32x2 fragment order (rows padded to the block tile), long-K convs once more in
-// 16x16x4 order, DDSConv / proj matrices in 16x16x4 order, the <= 64-channel resblock convs as mrf2 streams, plus the raw
+// 16x16x4 order, DDSConv / proj matrices in 16x16x4 order, the <= 64-channel resblock convs as mrf_kernel weight streams, plus the raw
 // small tensors. 3.5x the raw floats + slack covers every architecture the loader accepts; checked while carving.
 size_t Engine::arena_bound(const WeightSet& ws) {
   size_t n = 0;
@@ -301,8 +301,9 @@ Engine::Engine(const WeightSet& ws, int device, ArenaSpec arena) : device_(devic
 }
 
 void Engine::init(const WeightSet& ws) {
-  if (const char* t = getenv("PIPER_HIP_MRF2")) mrf2_mode_ = atoi(t);     // A/B knob: 0 = conv-by-conv MRF stages, 2 = always fused
-  if (const char* t = getenv("PIPER_HIP_MRF2_MAXF")) mrf2_max_frames_ = atol(t);
+  if (const char* t = getenv("PIPER_HIP_MRF")) mrf_mode_ = atoi(t);       // A/B knob: 0 = conv-by-conv MRF stages, 2 = always fused
+  if (const char* t = getenv("PIPER_HIP_MRF_MAXF")) mrf_rb1_max_frames_ = atol(t);
+  if (const char* t = getenv("PIPER_HIP_MRF_OU")) mrf_ou_ = atoi(t);
   memcpy(arch_, ws.arch, sizeof(arch_));
   PE_HIP(hipSetDevice(device_));
   PE_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
@@ -460,7 +461,7 @@ void Engine::init(const WeightSet& ws) {
         }
         st.last_bias_sum = dev_alloc((size_t)ch, skeleton_ ? nullptr : bs.data());
       }
-      build_mrf2(st);
+      build_mrf(st);
       st.rb_host.clear();
       ups_.push_back(st);
     }
@@ -530,9 +531,9 @@ void Engine::init(const WeightSet& ws) {
     PE_HIP(hipFuncSetAttribute((const void*)attn_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     PE_HIP(hipFuncSetAttribute((const void*)attn_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
     PE_HIP(hipFuncSetAttribute((const void*)attn_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    const void* ks4[] = {(const void*)mrf2_kernel<32, 16, 1, 2, 1, 368, 2>, (const void*)mrf2_kernel<32, 16, 1, 2, 1, 400, 1>,
-                         (const void*)mrf2_kernel<64, 16, 2, 1, 1, 240, 1>};
-    for (const void* k : ks4) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+    const void* ks5[] = {(const void*)mrf_kernel<32, 1, 1>, (const void*)mrf_kernel<32, 2, 1>, (const void*)mrf_kernel<32, 3, 1>,
+                         (const void*)mrf_kernel<64, 1, 2>, (const void*)mrf_kernel<64, 2, 2>, (const void*)mrf_kernel<64, 3, 2>};
+    for (const void* k : ks5) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
   }
 #endif
   static const char* rows[] = {"text_encoder", "duration_predictor", "regulate+flow", "hifigan", "post+pcm"};
@@ -975,39 +976,24 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
   kend(kh);
 }
 
-// Fused MRF stage (kernels/mrf2.h): flattens the resblocks of a <= 64-channel stage into phases (one per
-// conv), cuts every conv's (chunk, tap) steps into weight segments of at most one ring half, and writes the weights as
-// one stream in execution order. ResBlock2 (modules.py:355-364): x <- x + c_d(lrelu(x)); ResBlock1 (:301-314):
+// Fused MRF stage (kernels/mrf.h): flattens the resblocks of a <= 64-channel stage into phases (one per conv) and writes
+// the weights as one stream in execution order: per phase its (chunk, tap) steps, chunk-major, each step =
+// [16-row tile][q][lane][4] with lane -> (row = lane & 15, k = lane >> 4), float4 element jj of group q = k-step 4q + jj =
+// input channel chunk*32 + 4*(4q + jj) + k. ResBlock2 (modules.py:355-364): x <- x + c_d(lrelu(x)); ResBlock1 (:301-314):
 // x <- x + c2_d(lrelu(c1_d(lrelu(x)))).
-void Engine::build_mrf2(UpStage& st) {
+void Engine::build_mrf(UpStage& st) {
   const int ch = st.ch;
-  if (!mrf2_mode_ || ch > 64 || st.rb_host.empty()) return;
-  // 32-channel stages: a wave owns one 16-row tile of 8 column groups; 64-channel stages: two row tiles (one B
-  // operand feeds two MFMAs) of 8 column groups
-  const int CP = ch <= 32 ? 32 : 64, MS = CP / 16, NCH = CP / KC, NW = 16, MSW = CP == 32 ? 1 : 2, NCG = NW / (MS / MSW);
-  // halo of the stage (widest resblock chain) -> window geometry -> how large a weight-ring half fits in LDS
-  int hx = 0;
+  if (!mrf_mode_ || ch > 64 || st.rb_host.empty()) return;
+  const int CP = ch <= 32 ? 32 : 64, MS = CP / 16, NCH = CP / KC, STEPF = MS * 512;
+  const bool rb1 = arch_[A_RESBLOCK] == 1;
+  int hx = 0;                              // halo of the stage = the widest resblock chain
   for (auto& hv : st.rb_host) {
     int e = 0;
     for (auto& h : hv) e += h.dil * (h.k - 1) / 2;
     hx = std::max(hx, e);
   }
   const int hxa = rup(hx, 16);
-  int N = 0, WS = 0, NWR = 0;
-  {
-    const int cand[4][2] = {{256, 2}, {256, 1}, {128, 2}, {128, 1}};     // (output columns, float4 per thread per segment)
-    for (auto& c : cand) {
-      int ws = rup(hxa + c[0] + hx, 32) + 16;
-      if (ws - 32 >= hxa + c[0] + hx) ws -= 32;       // smallest value == 16 (mod 32) that covers the window
-      const size_t bytes = ((size_t)2 * 4 * 64 * NW * c[1] + (size_t)2 * CP * ws + 128 + 24 * 12 + 64 * 4) * sizeof(float);
-      if (bytes <= 160u * 1024u) { N = c[0]; WS = ws; NWR = c[1]; break; }
-    }
-  }
-  if (!N) return;
-  const int STEPF = MS * 512, RINGF = 4 * 64 * NW * NWR, SEGSTEPS = RINGF / STEPF;
-  const bool rb1 = arch_[A_RESBLOCK] == 1;
-  std::vector<Mrf2Phase> phases;
-  std::vector<Mrf2Seg> segs;
+  std::vector<MrfPhase> phases;
   std::vector<float> wstream;
   for (size_t j = 0; j < st.rb_host.size(); ++j) {
     auto& hv = st.rb_host[j];
@@ -1021,90 +1007,98 @@ void Engine::build_mrf2(UpStage& st) {
     for (int i = 0; i < n; ++i) {
       const auto& h = hv[i];
       e -= h.dil * (h.k - 1) / 2;
-      Mrf2Phase P{};
+      MrfPhase P{};
       P.bias = h.bias; P.ntaps = h.k; P.dil = h.dil; P.e = e;
       const bool last = i == n - 1;
       if (rb1) {
         if (!(i & 1)) { P.src = 0; P.dst = 1; P.flags = 0; }
-        else { P.src = 1; P.dst = last ? -1 : 0; P.flags = MRF2_RES | MRF2_KEEP; }
+        else { P.src = 1; P.dst = last ? -1 : 0; P.flags = MRF_RES | MRF_KEEP; }
       } else {
-        P.src = i == 0 ? 0 : 1; P.dst = last ? -1 : 1; P.flags = MRF2_RES | MRF2_KEEP;
+        P.src = i == 0 ? 0 : 1; P.dst = last ? -1 : 1; P.flags = MRF_RES | MRF_KEEP;
         if (n > 2) return;             // a longer ResBlock2 chain would need ping-pong chain buffers
       }
-      if (last) P.flags |= MRF2_FINAL;
-      if (i == 0) P.flags |= MRF2_INIT | ((rb1 && j > 0) ? MRF2_RESTAGE : 0);
-      // weight segments: steps = (chunk, tap), chunk-major; one step = [16-row tile][q][lane][4] with lane ->
-      // (row = lane & 15, k = lane >> 4), float4 element jj of group q = k-step 4q + jj = input channel chunk*32 + 4s + k
-      P.seg0 = (int)segs.size();
+      if (last) P.flags |= MRF_FINAL;
+      if (i == 0) P.flags |= MRF_INIT | ((rb1 && j > 0) ? MRF_RESTAGE : 0);
       const int nsteps = NCH * h.k;
-      for (int s0 = 0; s0 < nsteps; s0 += SEGSTEPS) {
-        Mrf2Seg sg{};
-        sg.step0 = s0; sg.nsteps = std::min(SEGSTEPS, nsteps - s0); sg.woff = (int)wstream.size();
-        wstream.resize(wstream.size() + (size_t)sg.nsteps * STEPF, 0.f);
-        for (int st_i = 0; st_i < (skeleton_ ? 0 : sg.nsteps); ++st_i) {
-          const int step = s0 + st_i, c = step / h.k, tap = step % h.k;
-          for (int ms = 0; ms < MS; ++ms)
-            for (int q = 0; q < 2; ++q)
-              for (int lane = 0; lane < 64; ++lane)
-                for (int jj = 0; jj < 4; ++jj) {
-                  const int row = ms * 16 + (lane & 15), ci = c * KC + 4 * (4 * q + jj) + (lane >> 4);
-                  if (row < ch && ci < ch)
-                    wstream[sg.woff + ((size_t)(st_i * MS + ms) * 2 + q) * 256 + lane * 4 + jj] =
-                        h.w[((size_t)row * ch + ci) * h.k + tap];
-                }
-        }
-        segs.push_back(sg);
+      const size_t w0 = wstream.size();
+      wstream.resize(w0 + (size_t)nsteps * STEPF, 0.f);
+      for (int step = 0; step < (skeleton_ ? 0 : nsteps); ++step) {
+        const int c = step / h.k, tap = step % h.k;
+        for (int ms = 0; ms < MS; ++ms)
+          for (int q = 0; q < 2; ++q)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int jj = 0; jj < 4; ++jj) {
+                const int row = ms * 16 + (lane & 15), ci = c * KC + 4 * (4 * q + jj) + (lane >> 4);
+                if (row < ch && ci < ch)
+                  wstream[w0 + ((size_t)(step * MS + ms) * 2 + q) * 256 + lane * 4 + jj] = h.w[((size_t)row * ch + ci) * h.k + tap];
+              }
       }
-      P.nseg = (int)segs.size() - P.seg0;
       phases.push_back(P);
     }
   }
-  if (!N || phases.size() > 24 || segs.size() > 64) return;
-  const int cu_lo = (hxa - hx) / 16, cu_hi = (hxa + N + hx + 15) / 16;
-  const int nleft = hxa / 16 - cu_lo, nhalo = cu_hi - cu_lo - N / 16;
-  const int ou = N / 16 / NCG, hu = (nhalo + NCG - 1) / NCG;       // output / halo units per wave
-  if (N % (16 * NCG) || ou < 1 || ou > 2 || hu > 2 || (ou == 2 && hu == 2)) return;
+  if ((int)phases.size() > MRF_MAXPH) return;
   {
-    const int key = CP * 10000000 + ou * 1000000 + hu * 100000 + WS * 10 + NWR;   // the instantiated geometries (mrf2())
-    if (key != 322103682 && key != 322104001 && key != 641102401) return;
+    // some N = 16 * NCG * OU must fit the kernel's fixed row stride and its halo-unit capacity
+    const int NCG = CP == 32 ? 8 : 4, HU = CP == 32 ? 1 : 2, n1 = 16 * NCG;
+    const int nh = (hxa + n1 + hx + 15) / 16 - (hxa - hx) / 16 - n1 / 16;
+    if (hxa + n1 + hx > mrf_ws(CP) || nh > NCG * HU) return;
   }
-  {
-    // MFMA work relative to the unfused convs (halo recompute in 16-column units): fuse only when it stays moderate
-    double done = 0, need = 0;
-    for (auto& P : phases) {
-      const int lo = (hxa - P.e) / 16, hi = (hxa + N + P.e + 15) / 16;
-      done += (double)(hi - lo) * 16 * P.ntaps;
-      need += (double)N * P.ntaps;
-    }
-    st.m2_recompute = done / need;
-    if (mrf2_mode_ == 1 && st.m2_recompute > 1.6) return;          // PIPER_HIP_MRF2=2 forces it (tests)
-  }
-  auto up = [&](const void* src, size_t bytes) {
-    void* d = nullptr;
-    PE_HIP(hipMalloc(&d, bytes));
-    PE_HIP(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
-    owned_.push_back(d);
-    return d;
-  };
-  st.m2_phases = up(phases.data(), phases.size() * sizeof(Mrf2Phase));
-  st.m2_segs = up(segs.data(), segs.size() * sizeof(Mrf2Seg));
-  st.m2_w = dev_alloc(wstream.size(), wstream.data());      // weights: in the arena (travels with the broadcast)
-  st.m2_nphases = (int)phases.size(); st.m2_nsegs = (int)segs.size(); st.m2_wfloats = (int)wstream.size();
-  st.m2_cp = CP; st.m2_n = N; st.m2_ws = WS; st.m2_hxa = hxa; st.m2_cu_lo = cu_lo; st.m2_cu_hi = cu_hi;
-  st.m2_nwr = NWR;
-  st.m2_ou = ou; st.m2_hu = std::max(hu, 1); st.m2_nleft = nleft; st.m2_nhalo = nhalo;
+  void* d = nullptr;
+  PE_HIP(hipMalloc(&d, phases.size() * sizeof(MrfPhase)));
+  PE_HIP(hipMemcpy(d, phases.data(), phases.size() * sizeof(MrfPhase), hipMemcpyHostToDevice));
+  owned_.push_back(d);
+  st.mrf_phases = d;
+  st.mrf_w = dev_alloc(wstream.size(), wstream.data());      // weights: in the arena (travels with the broadcast)
+  st.mrf_wfloats = (int)wstream.size();
+  st.mrf_cp = CP;
+  st.mrf_ph = phases;
+  st.mrf_hx = hx;
+  st.mrf_rb1 = rb1;
+  st.mrf_ok = true;
 }
 
-void Engine::mrf2(const UpStage& st, View x, View out, const int* lens, int len_mul, int Lmax) {
-  Mrf2P p;
+// mrf_kernel launch: the window geometry -- output columns per workgroup N = 16 * NCG * OU -- is chosen here. Few
+// utterances: the launch is one or two rounds of workgroups over the 256 CUs, so the workgroup count should sit just under
+// a multiple of 256 and a workgroup should be short; batches: many rounds, so large N (less halo recompute, fewer
+// prologues) wins. Cost model: rounds x (MFMA columns of one workgroup incl. recompute + a fixed prologue / epilogue).
+void Engine::mrf(const UpStage& st, View x, View out, const int* lens, int len_mul, int Lmax) {
+  const int CP = st.mrf_cp, NCG = CP == 32 ? 8 : 4, HU = CP == 32 ? 1 : 2, WSC = mrf_ws(CP);
+  const int hx = st.mrf_hx, hxa = rup(hx, 16);
+  struct Geo { int ou, N, cu_lo, cu_hi, nleft, nhalo; };
+  auto geo = [&](int ou, Geo& g) {
+    g.ou = ou; g.N = 16 * NCG * ou;
+    if (hxa + g.N + hx > WSC) return false;
+    g.cu_lo = (hxa - hx) / 16; g.cu_hi = (hxa + g.N + hx + 15) / 16;
+    g.nleft = hxa / 16 - g.cu_lo; g.nhalo = g.cu_hi - g.cu_lo - g.N / 16;
+    return g.nhalo <= NCG * HU;
+  };
+  Geo best{};
+  double best_cost = 0;
+  Geo forced;
+  const int force = (mrf_ou_ >= 1 && mrf_ou_ <= 3 && geo(mrf_ou_, forced)) ? mrf_ou_ : 0;     // (tests / A-B; ignored when it does not fit)
+  for (int ou = 1; ou <= 3; ++ou) {
+    Geo g;
+    if ((force && ou != force) || !geo(ou, g)) continue;
+    double wgs = 0;
+    for (int b = 0; b < B_; ++b) wgs += (double)(((long)frames_h_[b] * len_mul + g.N - 1) / g.N);
+    double work = 0, taps = 0;
+    for (auto& P : st.mrf_ph) {
+      const int lo = (hxa - P.e) / 16, hi = (hxa + g.N + P.e + 15) / 16;
+      work += (double)(hi - lo) * 16 * P.ntaps;
+      taps += P.ntaps;
+    }
+    const double cost = std::ceil(wgs / 256.0) * (work + 16.0 * taps);      // prologue + epilogue ~ 16 columns' worth
+    if (!best.ou || cost < best_cost) { best = g; best_cost = cost; }
+  }
+  if (!best.ou) throw std::runtime_error("internal: no mrf_kernel geometry for this stage");
+  MrfP p;
   p.x = x.p; p.x_bs = x.bs; p.x_cs = x.cs;
   p.out = out.p; p.o_bs = out.bs; p.o_cs = out.cs;
   p.lens = lens; p.len_mul = len_mul;
-  p.phases = static_cast<const Mrf2Phase*>(st.m2_phases); p.nphases = st.m2_nphases;
-  p.segs = static_cast<const Mrf2Seg*>(st.m2_segs); p.nsegs = st.m2_nsegs;
-  p.wstream = st.m2_w; p.wfloats = st.m2_wfloats;
-  p.C = st.ch; p.N = st.m2_n; p.WS = st.m2_ws; p.hxa = st.m2_hxa; p.cu_lo = st.m2_cu_lo; p.cu_hi = st.m2_cu_hi;
-  p.nleft = st.m2_nleft; p.nhalo = st.m2_nhalo;
+  p.phases = static_cast<const MrfPhase*>(st.mrf_phases); p.nphases = (int)st.mrf_ph.size();
+  p.wstream = st.mrf_w; p.wfloats = st.mrf_wfloats;
+  p.C = st.ch; p.N = best.N; p.wcols = hxa + best.N + hx; p.hxa = hxa; p.cu_lo = best.cu_lo; p.cu_hi = best.cu_hi;
+  p.nleft = best.nleft; p.nhalo = best.nhalo;
   p.slope = 0.1f;                            // modules.py LRELU_SLOPE
   p.alpha = 1.0f / (float)st.rb.size();
   double kflops = 0, kbytes = 0;
@@ -1115,24 +1109,20 @@ void Engine::mrf2(const UpStage& st, View x, View out, const int* lens, int len_
     for (auto& cv : st.rb)
       for (auto& c : cv) macs += c.macs_per_col;
     kflops = 2.0 * macs * cols;
-    kbytes = 8.0 * st.ch * cols + 4.0 * st.m2_wfloats;      // one read of x, one write of the mean, the weights once
+    kbytes = 8.0 * st.ch * cols + 4.0 * st.mrf_wfloats;      // one read of x, one write of the mean, the weights once
   }
-  const int NW = 16;
-  const size_t smem = ((size_t)2 * 4 * 64 * NW * st.m2_nwr + (size_t)2 * st.m2_cp * st.m2_ws + 128 + 24 * 12 + 64 * 4) *
-                      sizeof(float);
-  dim3 grid((Lmax + st.m2_n - 1) / st.m2_n, B_);
+  const size_t smem = mrf_smem_bytes(CP);
+  dim3 grid((Lmax + best.N - 1) / best.N, B_);
   char nm[64];
-  snprintf(nm, sizeof(nm), "mrf2_kernel<%d,%d,%d,%d,%d,%d,%d>", st.m2_cp, NW, st.m2_cp == 32 ? 1 : 2, st.m2_ou, st.m2_hu,
-           st.m2_ws, st.m2_nwr);
+  snprintf(nm, sizeof(nm), "mrf_kernel<%d,%d,%d>", CP, best.ou, HU);
   const int kh = prof_level_ >= 2 ? kbegin(krow(std::string(nm)), kflops, kbytes) : -1;
-#define PE_MRF2(CP_, OU_, HU_, WS_, NWR_) \
-  PE_LAUNCH((mrf2_kernel<CP_, 16, (CP_ == 32 ? 1 : 2), OU_, HU_, WS_, NWR_>), grid, dim3(64 * NW), smem, ls_, p)
-  // instantiated geometries: medium / x-low (ResBlock2 3,5,7: halo 45) and high (ResBlock1 3,7,11: halo 60) stages
-  if (st.m2_cp == 32 && st.m2_ou == 2 && st.m2_hu == 1 && st.m2_ws == 368 && st.m2_nwr == 2) PE_MRF2(32, 2, 1, 368, 2);
-  else if (st.m2_cp == 32 && st.m2_ou == 2 && st.m2_hu == 1 && st.m2_ws == 400 && st.m2_nwr == 1) PE_MRF2(32, 2, 1, 400, 1);
-  else if (st.m2_cp == 64 && st.m2_ou == 1 && st.m2_hu == 1 && st.m2_ws == 240 && st.m2_nwr == 1) PE_MRF2(64, 1, 1, 240, 1);
-  else throw std::runtime_error("internal: no mrf2_kernel instantiation for this stage geometry");
-#undef PE_MRF2
+#define PE_MRF(CP_, OU_, HU_) PE_LAUNCH((mrf_kernel<CP_, OU_, HU_>), grid, dim3(64 * MRF_NW), smem, ls_, p)
+  if (CP == 32) {
+    if (best.ou == 1) PE_MRF(32, 1, 1); else if (best.ou == 2) PE_MRF(32, 2, 1); else PE_MRF(32, 3, 1);
+  } else {
+    if (best.ou == 1) PE_MRF(64, 1, 2); else if (best.ou == 2) PE_MRF(64, 2, 2); else PE_MRF(64, 3, 2);
+  }
+#undef PE_MRF
   kend(kh);
 }
 
@@ -1675,11 +1665,14 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
         if (cv.size() != st.rb[0].size()) grp = false;
         for (auto& c : cv) grp = grp && can_group(c, Lmax);
       }
-      // One launch per stage wins while the stage is latency-bound (a few utterances: 6 launches of one wave
-      // generation each); from ~3 utterances up the conv-by-conv schedule fills the chip and its GEMM kernel is the
-      // faster one (profiles/r02_mrf2_ab.txt), so the choice goes by the frames in the batch.
-      if (mrf2_mode_ && st.m2_phases && (mrf2_mode_ == 2 || fsum <= (double)mrf2_max_frames_)) {
-        mrf2(st, u, xs, lens, mult, Lmax);
+      // One launch per stage (mrf_kernel). Measured (profiles/r03_notes.md): ResBlock2 stages (medium / x-low) win at every
+      // batch size (B=1 -3 %, B=16 / 64 +4.5 % end to end over the conv-by-conv schedule); ResBlock1 stages (high) tie at
+      // one utterance and lose at batch (its 64-channel stage: 86 vs ~110 TFLOP/s for the conv GEMM kernel on K = 64 * 11
+      // convs), so those are fused for one or two utterances and on 32 channels only.
+      const bool fuse = mrf_mode_ && st.mrf_ok &&
+                        (mrf_mode_ == 2 || !st.mrf_rb1 || (st.mrf_cp == 32 && fsum <= (double)mrf_rb1_max_frames_));
+      if (fuse) {
+        mrf(st, u, xs, lens, mult, Lmax);
         for (auto& cv : st.rb)
           for (auto& c : cv) fl += 2.0 * fsum * mult * c.macs_per_col;
       } else if (grp) {

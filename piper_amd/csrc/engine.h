@@ -255,18 +255,19 @@ class Engine {
     int rate, ch;
     std::vector<std::vector<PackedConv>> rb;   // [resblock][conv] (ResBlock1: c1_0,c2_0,c1_1,...)
     float* last_bias_sum = nullptr;            // sum over the resblocks of their LAST conv's bias (conv_splitk_sum_kernel)
-    // fused MRF stage (mrf2_kernel, kernels/mrf2.h): device tables, or null when the stage runs conv by conv
+    // fused MRF stage (mrf_kernel, kernels/mrf.h): device phase table + weight stream, or not ok: the stage runs conv by conv
     struct HostConv { std::vector<float> w; int co = 0, ci = 0, k = 0, dil = 1; const float* bias = nullptr; };
-    std::vector<std::vector<HostConv>> rb_host;   // host copies of the resblock convs, dropped after build_mrf2
-    void* m2_phases = nullptr; void* m2_segs = nullptr; float* m2_w = nullptr;
-    int m2_nphases = 0, m2_nsegs = 0, m2_wfloats = 0, m2_cp = 0, m2_n = 0, m2_ws = 0, m2_hxa = 0, m2_cu_lo = 0,
-        m2_cu_hi = 0, m2_ou = 0, m2_hu = 0, m2_nleft = 0, m2_nhalo = 0, m2_nwr = 1;
-    double m2_recompute = 0;
+    std::vector<std::vector<HostConv>> rb_host;   // host copies of the resblock convs, dropped after build_mrf
+    void* mrf_phases = nullptr; float* mrf_w = nullptr;
+    int mrf_wfloats = 0, mrf_cp = 0, mrf_hx = 0;  // padded channels (32 / 64), halo of the stage (widest resblock chain)
+    std::vector<struct MrfPhase> mrf_ph;          // host copy of the phases (cost model of the geometry choice)
+    bool mrf_ok = false, mrf_rb1 = false;
   };
-  void build_mrf2(UpStage& st);
-  void mrf2(const UpStage& st, View x, View out, const int* lens, int len_mul, int Lmax);
-  long mrf2_max_frames_ = 1100;             // batch frames up to which the fused stage kernel is used in mode 1
-  int mrf2_mode_ = 1;                       // PIPER_HIP_MRF2: 0 off (conv by conv), 1 fused stage kernel where it applies
+  void build_mrf(UpStage& st);
+  void mrf(const UpStage& st, View x, View out, const int* lens, int len_mul, int Lmax);
+  int mrf_mode_ = 1;                        // PIPER_HIP_MRF: 0 off (conv by conv), 1 by the measured policy, 2 wherever it applies
+  long mrf_rb1_max_frames_ = 1100;          // ResBlock1 stages: batch frames up to which the fused kernel is used in mode 1
+  int mrf_ou_ = 0;                          // PIPER_HIP_MRF_OU=1..3 forces the output units per wave (tests); 0 = cost model
   int splitk16_ = 2;                        // 16-column split-K: 0 off, 1 WN gate conv, 2 also long-K plain convs, 3 all (tests)
   int wide_splitk_ = 1;                     // 12-wave split-K workgroups for long-K launches
   long splitk_max_blocks_ = 96;             // launches with fewer tile-kernel workgroups use conv_splitk_kernel

@@ -1,0 +1,364 @@
+// One whole MRF stage of the HiFiGAN generator per launch (models.py:356-363: xs = sum_j resblock_j(x) / n;
+// modules.py:301-314 ResBlock1, :355-364 ResBlock2) for stages with <= 64 channels.
+//
+// A workgroup owns N output columns of one utterance and runs every conv of every resblock of the stage out of LDS
+// (halo recompute on shrinking windows), so the stage costs ONE launch, one read of x and one write of the MRF mean
+// instead of one launch and ~3 tensor round trips per conv:
+//   * LDS holds the ACTIVATED tensors (leaky-relu applied once, by the producer): the MFMA B operand is a plain ds_read,
+//     no VALU on the read side. Residuals never come from LDS: a wave owns the same 16x16 output units
+//     (v_mfma_f32_16x16x4_f32) in every phase (static map unit -> wave), so the raw running x of a resblock chain and the
+//     MRF sum stay in its registers; the raw stage input of a chain is re-read from L2 when the chain starts.
+//   * 8 waves of <= 256 registers: a wave owns two 16-row tiles x (OU + HU) column units (one B operand feeds two MFMAs),
+//     up to 80 MFMAs per (chunk, tap) step from 4 + 40 operand registers.
+//   * Weights never touch LDS: they are one flat stream in execution order ([phase][step][16-row tile][2][lane][4], step =
+//     one (32-channel chunk, tap)) and every wave reads its own A fragments of the NEXT step straight from L2 (a few
+//     hundred KB shared by all workgroups; the waves of a row group hit the same lines in L1) into a second register set
+//     while the current step's MFMAs issue. The only workgroup barriers are the phase boundaries.
+//   * B operands (LDS) are software-pipelined the same way, and the loads of step s + 1 are INTERLEAVED between the MFMAs
+//     of step s (sched_group_barrier): the two waves of a SIMD run in lockstep, so a block of loads in front of the MFMA
+//     burst would be a bubble in both at once. All prefetches sit at unconditional positions of the 2x unrolled ping-pong
+//     step loop (exact wait counts); the fragments of the next PHASE's first step are fetched during the last step.
+//   * The K loop is specialised at compile time on which halo units take part in a phase; (chunk, tap) are counters.
+//   * The row stride WS is a per-width constant (immediates for the 8 k-rows of a step); the number of output units per
+//     wave (OU = 1..3 -> N = 16 * NCG * OU columns per workgroup) is picked per launch (engine.cpp: Engine::mrf).
+// Every step is the same k-ordered f32 fmaf chain as the conv kernels (chunk-major, tap-minor, ascending channel).
+// History (profiles/r02_notes.md, r03_notes.md): generation 1 applied the leaky-relu on the read side (3 VALU per MFMA);
+// generation 2 staged the weights through a double-buffered LDS ring with one workgroup barrier per segment (16 waves,
+// matrix pipe 61 % busy); this is generation 3 (70 %).
+#pragma once
+#include "../pe_rt.h"
+#include "conv_common.h"
+
+namespace pe {
+
+template <int V> struct pe_int { static constexpr int value = V; };
+
+enum { MRF_RES = 1, MRF_KEEP = 2, MRF_FINAL = 4, MRF_INIT = 8, MRF_RESTAGE = 16 };
+
+struct MrfPhase {        // one conv of one resblock chain; 12 ints wide (the kernel copies the table to LDS as ints)
+  const float* bias;
+  int ntaps, dil;
+  int e;                 // columns of halo its OUTPUT still needs (0 for the last conv of a resblock)
+  int src, dst;          // LDS activation buffers (0 = stage input window, 1 = chain buffer); dst < 0: none
+  int flags;             // RES: + running x (registers); KEEP: result becomes the running x; FINAL: add to the MRF sum;
+                         // INIT: running x = stage input (first conv of a resblock); RESTAGE: reload buffer 0 first
+  int pad[4];
+};
+static_assert(sizeof(MrfPhase) == 48, "MrfPhase is read as 12 ints");
+struct MrfP {
+  const float* x; long x_bs; int x_cs;
+  float* out; long o_bs; int o_cs;
+  const int* lens; int len_mul;
+  const MrfPhase* phases; int nphases;
+  const float* wstream; int wfloats;
+  int C;                 // real channels (<= CP)
+  int N;                 // output columns per workgroup (16 * NCG * OU)
+  int wcols;             // window columns in use: hxa + N + the stage's halo (<= the row stride)
+  int hxa;               // window column of the first output column (halo rounded up to 16)
+  int cu_lo, cu_hi;      // 16-column units any phase needs: [cu_lo, cu_hi)
+  int nleft, nhalo;      // halo units left of the output columns / in total
+  float slope, alpha;
+};
+
+// element (vidx + sidx) .. + 3: vidx per lane, sidx wave-uniform (SGPR offset)
+#ifdef PE_EMU
+inline f32x4 pe_row_load4_so(const pe_rowsrc& r, int vidx, int sidx) { return pe_row_load4(r, vidx + sidx); }
+#else
+__device__ __forceinline__ f32x4 pe_row_load4_so(pe_rowsrc r, int vidx, int sidx) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, vidx * 4, sidx * 4, 0));
+}
+#endif
+
+// One step's schedule: the NEXT step's loads (NVM weight fetches, then NDS LDS reads) spread between this step's NMF
+// MFMAs, K MFMAs per load. The two waves of a SIMD run in lockstep (same work, fair pipe arbitration), so a block of
+// loads in front of the MFMA burst is a bubble in BOTH at the same time; a load issued while the wave waits for the
+// matrix pipe anyway costs nothing.
+template <int NVM, int NDS, int K>
+__device__ __forceinline__ void mrf_interleave() {
+  if constexpr (NVM + NDS > 0) {
+    PE_SCHED_GROUP(0x8, K);
+    if constexpr (NVM > 0) {
+      PE_SCHED_GROUP(0x20, 1);
+      mrf_interleave<NVM - 1, NDS, K>();
+    } else {
+      PE_SCHED_GROUP(0x100, 1);
+      mrf_interleave<0, NDS - 1, K>();
+    }
+  }
+}
+
+static constexpr int MRF_NW = 8, MRF_PAD = 128, MRF_MAXPH = 24;
+static constexpr int mrf_ws(int cp) { return cp == 32 ? 528 : 304; }
+static constexpr size_t mrf_smem_bytes(int cp) {
+  return ((size_t)2 * MRF_PAD + (size_t)2 * cp * mrf_ws(cp) + MRF_MAXPH * 12) * sizeof(float);
+}
+
+template <int CP, int OU, int HU>
+__global__ __launch_bounds__(64 * MRF_NW) void mrf_kernel(MrfP p) {
+  PE_KTRACE(20);
+  constexpr int NW = MRF_NW, WS = mrf_ws(CP), MS = CP / 16, MSW = 2, NRG = MS / MSW, NCG = NW / NRG, NT = 64 * NW;
+  constexpr int UPW = OU + HU, NCH = CP / KC, STEPF = MS * 512;
+  static_assert(MS % MSW == 0 && NW % NRG == 0, "waves split evenly over the row groups");
+  static_assert(WS % 32 == 16, "row stride == 16 (mod 32): the two k rows of a half-wave hit disjoint banks");
+  PE_DYN_SMEM(float, sm);
+  const int b = blockIdx.y;
+  const int L = p.lens[b] * p.len_mul;
+  const int n0 = blockIdx.x * p.N;
+  if (n0 >= L) return;
+  // LDS: [pad][buffer 0: CP x WS][buffer 1][pad][phase table]. Reads of never-used columns may leave a buffer on the
+  // left / right: they land in the pads / the neighbouring buffer.
+  float* bufs = sm + MRF_PAD;
+  constexpr int bufsz = CP * WS;
+  int* tph = reinterpret_cast<int*>(bufs + 2 * bufsz + MRF_PAD);       // [MAXPH][12] ints (MrfPhase is 12 ints wide)
+  const int tid = threadIdx.x, lane = tid & 63, wv = PE_UNIFORM(tid >> 6);
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int ms0 = (wv % NRG) * MSW, cg = wv / NRG;
+  const int g0 = n0 - p.hxa;                       // global column of window column 0
+  const float slope = p.slope;
+  const int C = p.C;
+  const int wcols = p.wcols;
+
+  // ---- weight stream: this wave's A fragments of a step = MSW tiles x 2 float4 per lane
+  const pe_rowsrc wd = pe_make_row(p.wstream, p.wfloats);
+  const int wlane = ms0 * 512 + lane * 4;
+  auto load_a = [&](int woff, f32x4 (&a)[MSW][2]) {        // past the end of the stream: zeros
+#pragma unroll
+    for (int m = 0; m < MSW; ++m)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) a[m][q] = pe_row_load4_so(wd, wlane + (m * 2 + q) * 256, woff);
+  };
+  f32x4 aA[MSW][2], aB[MSW][2];
+  int wnext = 0;                                   // float offset of the next step to fetch (the stream is in execution order)
+  load_a(wnext, aA);
+  wnext += STEPF;
+  {
+    const int* gp = reinterpret_cast<const int*>(p.phases);
+    for (int i = tid; i < p.nphases * 12; i += NT) tph[i] = gp[i];
+    if (tid < MRF_PAD) { sm[tid] = 0.f; bufs[2 * bufsz + tid] = 0.f; }
+  }
+
+  // ---- stage the activated input window: buffer 0 <- lrelu(x[g0 + c]), zero outside [0, L) and for rows >= C
+  const float* xb = p.x + (long)b * p.x_bs;
+  auto stage_x = [&]() {        // every load of the window in flight before the first store: one memory latency
+    constexpr int NCC = (WS + 63) / 64, RPW = CP / NW;
+    float v[RPW][NCC];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+      const int row = wv + NW * i;
+      const pe_rowsrc rd = pe_make_row(xb + (long)row * p.x_cs, row < C ? L : 0);
+#pragma unroll
+      for (int j = 0; j < NCC; ++j) v[i][j] = pe_row_load(rd, (lane + 64 * j < wcols) ? g0 + lane + 64 * j : -1);
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i)
+#pragma unroll
+      for (int j = 0; j < NCC; ++j) {
+        const int c = lane + 64 * j;
+        if (c < WS) bufs[(wv + NW * i) * WS + c] = pe_lrelu(v[i][j], slope);
+      }
+  };
+
+  // ---- this wave's units: window column block cu[u] (-1: the wave has no such unit) x row tiles ms0 + m
+  f32x4 acc[MSW][UPW], rawc[MSW][UPW], tot[MSW][OU];
+  int cu[UPW];
+  {
+    const int cuo0 = p.hxa / 16, nout = p.N / 16;
+#pragma unroll
+    for (int u = 0; u < OU; ++u) cu[u] = cuo0 + cg + NCG * u;
+#pragma unroll
+    for (int v = 0; v < HU; ++v) {
+      const int h = cg + NCG * v;
+      cu[OU + v] = h >= p.nhalo ? -1 : (h < p.nleft ? p.cu_lo + h : cuo0 + nout + (h - p.nleft));
+    }
+#pragma unroll
+    for (int m = 0; m < MSW; ++m) {
+#pragma unroll
+      for (int u = 0; u < UPW; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rawc[m][u][r] = 0.f;
+#pragma unroll
+      for (int u = 0; u < OU; ++u)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) tot[m][u][r] = 0.f;
+    }
+  }
+  const pe_rowsrc xd = pe_make_row(xb, C * p.x_cs);
+  stage_x();
+
+  for (int ph = 0; ph < p.nphases; ++ph) {
+    __syncthreads();            // table + window (first phase) / the previous phase's activations are in LDS
+    MrfPhase P;
+    {
+      const int* t = tph + ph * 12;
+      const unsigned lo = PE_UNIFORM((unsigned)t[0]), hi = PE_UNIFORM((unsigned)t[1]);
+      P.bias = reinterpret_cast<const float*>(((unsigned long long)hi << 32) | lo);
+      P.ntaps = PE_UNIFORM(t[2]); P.dil = PE_UNIFORM(t[3]); P.e = PE_UNIFORM(t[4]);
+      P.src = PE_UNIFORM(t[5]); P.dst = PE_UNIFORM(t[6]); P.flags = PE_UNIFORM(t[7]);
+    }
+    if (P.flags & MRF_RESTAGE) {       // ResBlock1 rewrites buffer 0 in place: a new chain starts from the stage input
+      stage_x();
+      __syncthreads();
+    }
+    if (P.flags & MRF_INIT) {          // running x of the chain <- raw stage input of the owned units (L2-hot; used in the
+                                        // epilogue, so the loads fly under the K loop). One lane offset per unit + an SGPR
+                                        // row offset: no per-element address registers (rows >= C: beyond the descriptor)
+#pragma unroll
+      for (int u = 0; u < UPW; ++u) {
+        const int g = g0 + 16 * cu[u] + l15;
+        int voff = (cu[u] >= 0 && g >= 0 && g < L) ? 4 * lq * p.x_cs + g : 0x3fffffff;
+        PE_OPAQUE(voff);
+#pragma unroll
+        for (int m = 0; m < MSW; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) rawc[m][u][r] = pe_row_load_so(xd, voff, ((ms0 + m) * 16 + r) * p.x_cs);
+      }
+    }
+    const pe_rowsrc bd = pe_make_row(P.bias, P.bias ? C : 0);
+    float bz[MSW][4];
+#pragma unroll
+    for (int m = 0; m < MSW; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bz[m][r] = pe_row_load(bd, (ms0 + m) * 16 + 4 * lq + r);
+    const int hh = P.dil * (P.ntaps - 1) / 2;
+    const int wlo = p.hxa - P.e, whi = p.hxa + p.N + P.e;          // columns this phase must produce
+    bool act[UPW];
+#pragma unroll
+    for (int u = 0; u < UPW; ++u) {
+      act[u] = cu[u] >= 0 && 16 * cu[u] < whi && 16 * cu[u] + 16 > wlo;
+#pragma unroll
+      for (int m = 0; m < MSW; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[m][u][r] = 0.f;
+    }
+    const float* src = bufs + P.src * bufsz;
+    // The K loop, specialised at compile time on WHICH halo units take part in this phase (bit v of MASK = halo unit
+    // v; output units always do): the hot loop is straight-line code, the choice is one wave-uniform switch per phase.
+    // Every variant issues the same weight fetches.
+    auto k_loop = [&](auto maskc) {
+      constexpr int MASK = decltype(maskc)::value;
+      const int nsteps = NCH * P.ntaps;
+      // per-unit LDS base of (row lq, tap 0): the step adds chunk * KC * WS + tap * dil
+      const float* ub[UPW];
+#pragma unroll
+      for (int u = 0; u < UPW; ++u) ub[u] = src + lq * WS + l15 + 16 * (cu[u] < 0 ? 0 : cu[u]) - hh;
+      auto read_b = [&](int soff, float (&bv)[UPW][8]) {
+#pragma unroll
+        for (int u = 0; u < UPW; ++u)
+          if (u < OU || ((MASK >> (u - OU)) & 1)) {
+            const float* bp = ub[u] + soff;
+#pragma unroll
+            for (int s8 = 0; s8 < 8; ++s8) bv[u][s8] = bp[4 * s8 * WS];
+          }
+      };
+      auto mma = [&](const f32x4 (&a)[MSW][2], const float (&bv)[UPW][8]) {
+        // unit-interleaved: consecutive MFMAs hit different accumulators (no dependent-issue stall)
+#pragma unroll
+        for (int s8 = 0; s8 < 8; ++s8)
+#pragma unroll
+          for (int u = 0; u < UPW; ++u)
+            if (u < OU || ((MASK >> (u - OU)) & 1)) {
+#pragma unroll
+              for (int m = 0; m < MSW; ++m) acc[m][u] = pe_mfma_16x16x4(a[m][s8 >> 2][s8 & 3], bv[u][s8], acc[m][u]);
+            }
+      };
+      // (chunk, tap) of the NEXT step as an LDS offset; wraps to step 0 behind the last one (a harmless re-read)
+      int ntap = 0, nchunk = 0;
+      auto advance = [&]() -> int {
+        if (++ntap == P.ntaps) { ntap = 0; if (++nchunk == NCH) nchunk = 0; }
+        return PE_UNIFORM(nchunk * KC * WS + ntap * P.dil);
+      };
+      constexpr int NU = OU + ((MASK & 1) ? 1 : 0) + ((MASK & 2) ? 1 : 0);       // units taking part
+      constexpr int NMF = 8 * MSW * NU, NVM = 2 * MSW, NDS = 4 * NU;             // MFMAs / weight fetches / ds_read2 per step
+      constexpr int KI = NMF / (NVM + NDS + 1);
+      float bA[UPW][8], bB[UPW][8];
+      read_b(0, bA);
+      int st = 0;
+      for (; st + 1 < nsteps; st += 2) {
+        PE_SCHED_FENCE();
+        load_a(wnext, aB);
+        read_b(advance(), bB);
+        wnext += STEPF;
+        mma(aA, bA);
+        mrf_interleave<NVM, NDS, KI>();
+        PE_SCHED_FENCE();
+        load_a(wnext, aA);      // behind the phase's last step: the first step of the next phase
+        read_b(advance(), bA);
+        wnext += STEPF;
+        mma(aB, bB);
+        mrf_interleave<NVM, NDS, KI>();
+        PE_SCHED_FENCE();
+      }
+      if (st < nsteps) {        // odd step count: the last step, and the next phase's first fragments move to aA
+        load_a(wnext, aB);
+        wnext += STEPF;
+        mma(aA, bA);
+        mrf_interleave<NVM, 0, KI>();
+        PE_SCHED_FENCE();
+#pragma unroll
+        for (int m = 0; m < MSW; ++m)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) aA[m][q] = aB[m][q];
+      }
+    };
+    {
+      int mask = 0;
+#pragma unroll
+      for (int v = 0; v < HU; ++v) mask |= act[OU + v] ? (1 << v) : 0;
+      mask = PE_UNIFORM(mask);
+      if (HU == 1) {
+        if (mask) k_loop(pe_int<1>{}); else k_loop(pe_int<0>{});
+      } else {
+        switch (mask) {
+          case 0: k_loop(pe_int<0>{}); break;
+          case 1: k_loop(pe_int<1>{}); break;
+          case 2: k_loop(pe_int<2>{}); break;
+          default: k_loop(pe_int<3>{}); break;
+        }
+      }
+    }
+    // ---- epilogue of the phase
+    float* dstb = bufs + (P.dst < 0 ? 0 : P.dst) * bufsz;
+#pragma unroll
+    for (int u = 0; u < UPW; ++u)
+      if (act[u]) {
+        const int col = 16 * cu[u] + l15;
+        const int g = g0 + col;
+        const bool inside = g >= 0 && g < L;           // intermediates only exist on [0, L): zero padding
+#pragma unroll
+        for (int m = 0; m < MSW; ++m) {
+          f32x4 v;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float t = acc[m][u][r] + bz[m][r];
+            if (P.flags & MRF_RES) t += rawc[m][u][r];
+            v[r] = inside ? t : 0.f;
+          }
+          if (P.flags & MRF_KEEP) rawc[m][u] = v;
+          if (u < OU && (P.flags & MRF_FINAL)) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tot[m][u < OU ? u : 0][r] += v[r];
+          }
+          if (P.dst >= 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dstb[((ms0 + m) * 16 + 4 * lq + r) * WS + col] = pe_lrelu(v[r], slope);
+          }
+        }
+      }
+  }
+  // ---- MRF mean of the owned output units
+  float* ob = p.out + (long)b * p.o_bs;
+#pragma unroll
+  for (int u = 0; u < OU; ++u) {
+    const int g = g0 + 16 * cu[u] + l15;
+    if (g >= L) continue;
+#pragma unroll
+    for (int m = 0; m < MSW; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = (ms0 + m) * 16 + 4 * lq + r;
+        if (row < C) ob[(long)row * p.o_cs + g] = tot[m][u][r] * p.alpha;
+      }
+  }
+}
+
+}  // namespace pe

@@ -17,6 +17,7 @@ namespace pe { extern thread_local long g_launches; }   // kernel launches issue
 #define PE_OPAQUE(x) ((void)0)
 #define PE_UNIFORM(x) (emu::uniform_check((long long)(x)), (x))     // checked: readfirstlane on the GPU
 #define PE_SCHED_FENCE() ((void)0)
+#define PE_SCHED_GROUP(mask, n) ((void)0)
 template <class T> inline T* pe_uniform_ptr(T* p) { return p; }
 // bounds-checked row load: element idx of a row of n floats, 0 outside [0, n)
 struct pe_rowsrc { const float* p; int n; };
@@ -93,6 +94,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // nothing is scheduled across this point: keeps a block of prefetch loads ahead of the MFMAs they overlap
 // with (the machine scheduler otherwise sinks each load next to its use to save registers)
 #define PE_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// the next `n` instructions of class `mask` (LLVM SchedGroupMask: MFMA 0x8, VMEM read 0x20, DS read 0x100) of the
+// enclosing scheduling region, in the order these calls appear: a compile-time interleave of loads between MFMAs
+#define PE_SCHED_GROUP(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
 template <class T> __device__ __forceinline__ T* pe_uniform_ptr(T* p) {
   const unsigned long long v = (unsigned long long)p;
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);

@@ -433,59 +433,132 @@ void textToAudio(PiperConfig& config, Voice& voice, std::string text, std::vecto
     phonemize_codepoints(text, sentences);
   }
 
-  std::vector<PhonemeId> phonemeIds;
+  // ---- host side first: every sentence -> phrases (split at the phoneme_silence phonemes, piper.cpp:497-546) -> ids
+  struct Phrase {
+    std::vector<PhonemeId> ids;
+    std::size_t silenceAfter = 0;       // samples of phoneme silence appended behind the phrase
+    std::size_t sentence = 0;
+  };
+  std::vector<Phrase> phrases;
   std::map<Phoneme, std::size_t> missingPhonemes;
-  for (auto& sentence : sentences) {
-    std::vector<std::vector<Phoneme>> phrases;
-    std::vector<std::size_t> phraseSilence;
+  for (std::size_t si = 0; si < sentences.size(); ++si) {
+    std::vector<std::vector<Phoneme>> parts;
+    std::vector<std::size_t> partSilence;
     if (sc.phonemeSilenceSeconds) {
-      phrases.emplace_back();
-      for (Phoneme p : sentence) {
-        phrases.back().push_back(p);
+      parts.emplace_back();
+      for (Phoneme p : sentences[si]) {
+        parts.back().push_back(p);
         auto it = sc.phonemeSilenceSeconds->find(p);
         if (it != sc.phonemeSilenceSeconds->end()) {
-          phraseSilence.push_back((std::size_t)(it->second * sc.sampleRate * sc.channels));
-          phrases.emplace_back();
+          partSilence.push_back((std::size_t)(it->second * sc.sampleRate * sc.channels));
+          parts.emplace_back();
         }
       }
     } else {
-      phrases.push_back(sentence);
+      parts.push_back(sentences[si]);
     }
-    phraseSilence.resize(phrases.size(), 0);
-    // The reference runs one session.Run() per phrase (piper.cpp:548-575); the phrases of a sentence are
-    // independent, so here they go through the engine as one batch and are appended in order.
-    std::vector<std::vector<PhonemeId>> idLists;
-    std::vector<std::size_t> owner;
-    for (std::size_t i = 0; i < phrases.size(); ++i) {
-      if (phrases[i].empty()) continue;
-      phonemes_to_ids(phrases[i], voice.phonemizeConfig, phonemeIds, missingPhonemes);
-      idLists.push_back(phonemeIds);
-      owner.push_back(i);
-      phonemeIds.clear();
+    partSilence.resize(parts.size(), 0);
+    for (std::size_t i = 0; i < parts.size(); ++i) {
+      if (parts[i].empty()) continue;
+      Phrase ph;
+      phonemes_to_ids(parts[i], voice.phonemizeConfig, ph.ids, missingPhonemes);
+      ph.silenceAfter = partSilence[i];
+      ph.sentence = si;
+      phrases.push_back(std::move(ph));
     }
-    if (idLists.size() == 1) {
-      SynthesisResult pr;
-      synthesize(idLists[0], voice.synthesisConfig, voice.session, audioBuffer, pr);
-      audioBuffer.insert(audioBuffer.end(), phraseSilence[owner[0]], (int16_t)0);
-      result.audioSeconds += pr.audioSeconds;
-      result.inferSeconds += pr.inferSeconds;
-    } else if (!idLists.empty()) {
-      SynthesisResult pr;
-      std::vector<std::vector<int16_t>> parts;
-      synthesizeBatch(idLists, voice.synthesisConfig, voice.session, parts, pr);
-      for (std::size_t k = 0; k < parts.size(); ++k) {
-        audioBuffer.insert(audioBuffer.end(), parts[k].begin(), parts[k].end());
-        audioBuffer.insert(audioBuffer.end(), phraseSilence[owner[k]], (int16_t)0);
-      }
-      result.audioSeconds += pr.audioSeconds;
-      result.inferSeconds += pr.inferSeconds;
+  }
+
+  // ---- device side. The reference runs one session.Run() per phrase, one after the other (piper.cpp:548-575, the
+  // call at :570). Phrases are independent utterances, so they go through the engine in batches:
+  //   * no audioCallback (textToWavFile, piper.cpp:619-634): every phrase of every sentence in ONE call (a 16-sentence
+  //     text costs about one batch-16 call instead of 16 latency-bound ones);
+  //   * with a callback (audio is consumed sentence by sentence): sentence groups of 1, 2, 4, ... -- the first sentence
+  //     alone, for the time to first audio -- and while the caller's callbacks consume group g the engine already runs
+  //     group g + 1 (its upload + launch are enqueued first; the PCM of g was copied out of the engine's buffer before).
+  // Either way the caller sees the reference's sequence: per sentence its phrases + silences appended to audioBuffer,
+  // then audioCallback(), then the buffer cleared (piper.cpp:577-595).
+  struct Group { std::size_t p0 = 0, p1 = 0; };       // phrases [p0, p1): whole sentences, except beyond 4096 phrases
+  std::vector<Group> groups;
+  {
+    std::size_t p = 0, s = 0, want = audioCallback ? 1 : sentences.size();
+    while (s < sentences.size()) {
+      Group g;
+      g.p0 = p;
+      const std::size_t s1 = std::min(sentences.size(), s + std::max<std::size_t>(want, 1));
+      while (p < phrases.size() && phrases[p].sentence < s1 && p - g.p0 < 4096) ++p;      // 4096 = the engine's batch limit
+      g.p1 = p;
+      groups.push_back(g);
+      s = (p < phrases.size() && phrases[p].sentence < s1) ? phrases[p].sentence : s1;   // limit hit: go on from there
+      if (audioCallback) want = std::min<std::size_t>(want * 2, 64);
     }
+  }
+  const float scales[3] = {sc.noiseScale, sc.lengthScale, sc.noiseW};
+  auto enqueue = [&](const Group& g) -> double {          // upload + launch; returns the host seconds spent
+    if (g.p1 == g.p0) return 0.0;
+    std::vector<PhonemeId> flat;
+    std::vector<int64_t> offsets(1, 0), sids(g.p1 - g.p0, sc.speakerId.value_or(0));
+    for (std::size_t k = g.p0; k < g.p1; ++k) {
+      flat.insert(flat.end(), phrases[k].ids.begin(), phrases[k].ids.end());
+      offsets.push_back((int64_t)flat.size());
+    }
+    const auto t0 = std::chrono::steady_clock::now();
+    check(pe_upload(voice.session.engine, flat.data(), offsets.data(), (int32_t)(g.p1 - g.p0), scales,
+                    sc.speakerId ? sids.data() : nullptr, nullptr));
+    check(pe_run(voice.session.engine));
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  };
+  // the finished group's PCM, copied out of the engine's (reused) host buffer: per phrase
+  auto collect = [&](const Group& g, std::vector<std::vector<int16_t>>& out) -> double {
+    out.clear();
+    if (g.p1 == g.p0) return 0.0;
+    const auto t0 = std::chrono::steady_clock::now();
+    pe_result r;
+    check(pe_fetch(voice.session.engine, 0, 1, &r));
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    out.resize(g.p1 - g.p0);
+    for (std::size_t k = 0; k < out.size(); ++k) out[k].assign(r.pcm + r.sample_offsets[k], r.pcm + r.sample_offsets[k + 1]);
+    result.audioSeconds += (double)r.sample_offsets[out.size()] / (double)sc.sampleRate;
+    return dt;
+  };
+  if (!voice.session.engine) throw std::runtime_error("voice model is not loaded");
+  std::size_t open_sentence = (std::size_t)-1;     // sentence whose audio is being assembled in audioBuffer
+  auto close_sentence = [&]() {
+    if (open_sentence == (std::size_t)-1) return;
     if (sentenceSilenceSamples > 0) audioBuffer.insert(audioBuffer.end(), sentenceSilenceSamples, (int16_t)0);
     if (audioCallback) {
       audioCallback();      // the callback must copy: the buffer is cleared afterwards (piper.cpp:591-595)
       audioBuffer.clear();
     }
+    open_sentence = (std::size_t)-1;
+  };
+  // sentences without a single phrase (empty) still get their silence + callback, in order
+  std::size_t next_sentence = 0;
+  auto emit = [&](const Group& g, const std::vector<std::vector<int16_t>>& pcm) {
+    for (std::size_t k = g.p0; k < g.p1; ++k) {
+      const std::size_t si = phrases[k].sentence;
+      if (si != open_sentence) {
+        close_sentence();
+        for (; next_sentence < si; ++next_sentence) { open_sentence = next_sentence; close_sentence(); }
+        open_sentence = si;
+        next_sentence = si + 1;
+      }
+      audioBuffer.insert(audioBuffer.end(), pcm[k - g.p0].begin(), pcm[k - g.p0].end());
+      audioBuffer.insert(audioBuffer.end(), phrases[k].silenceAfter, (int16_t)0);
+    }
+  };
+  std::vector<std::vector<int16_t>> cur, prev;
+  if (!groups.empty()) result.inferSeconds += enqueue(groups[0]);
+  for (std::size_t gi = 0; gi < groups.size(); ++gi) {
+    result.inferSeconds += collect(groups[gi], cur);                        // waits for group gi
+    if (gi + 1 < groups.size()) result.inferSeconds += enqueue(groups[gi + 1]);   // the engine starts on gi + 1 ...
+    emit(groups[gi], cur);                                                  // ... while the caller consumes gi
+    // a sentence is closed (silence, callback) as soon as no later group continues it
+    if (gi + 1 == groups.size() || groups[gi + 1].p0 >= phrases.size() ||
+        phrases[groups[gi + 1].p0].sentence != open_sentence)
+      close_sentence();
   }
+  close_sentence();
+  for (; next_sentence < sentences.size(); ++next_sentence) { open_sentence = next_sentence; close_sentence(); }
   if (!missingPhonemes.empty()) {     // piper.cpp:600-610
     auto warn = [&](const std::string& m) {
       if (config.warn) config.warn(m);

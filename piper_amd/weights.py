@@ -276,12 +276,31 @@ def tensor_specs(cfg: ArchConfig) -> List[Tuple[str, Tuple[int, ...], str]]:
     return s
 
 
-def synthetic_weights(cfg: ArchConfig, seed: int = 1234) -> Dict[str, np.ndarray]:
+def synthetic_weights(cfg: ArchConfig, seed: int = 1234, family: str = "gauss") -> Dict[str, np.ndarray]:
     """Seeded random voice with every tensor non-trivial (the reference zero-initialises
     ``post``/``proj`` convs -- modules.py:443-444,519-520 -- which would make parity tests blind
     to the coupling and spline arithmetic). Scales are chosen so activations stay O(1) and
-    durations land near the 2.5-3 frames/id of real voices."""
+    durations land near the 2.5-3 frames/id of real voices.
+
+    ``family="heavy"`` (parity tests only): the same layer variances drawn from a heavy-tailed law (Student-t, 3
+    degrees of freedom: weights of 10+ standard deviations occur in every large tensor) with a log-normal gain per
+    output channel (sigma 0.6, i.e. channels a factor ~4 apart) and 4x larger biases -- closer to the dynamic range
+    of trained, weight-normed layers than i.i.d. Gaussians are. Real voices are not available offline."""
+    if family not in ("gauss", "heavy"):
+        raise ValueError(f"unknown weight family {family!r}")
     rng = np.random.default_rng(seed)
+    heavy = family == "heavy"
+
+    def draw(shape, std):
+        if not heavy:
+            return rng.standard_normal(shape) * std
+        a = rng.standard_t(3, size=shape) / np.sqrt(3.0)               # unit variance
+        if len(shape) >= 2:                                            # per-output-channel gain, mean square 1
+            g = np.exp(0.6 * rng.standard_normal(shape[0]))
+            g /= np.sqrt(np.mean(g * g))
+            a = a * g.reshape((-1,) + (1,) * (len(shape) - 1))
+        return a * std
+
     w: Dict[str, np.ndarray] = {}
     for name, shape, kind in tensor_specs(cfg):
         if kind in ("conv", "dw", "convT"):
@@ -289,19 +308,19 @@ def synthetic_weights(cfg: ArchConfig, seed: int = 1234) -> Dict[str, np.ndarray
                 fan_in = shape[0] * shape[2] / max(1, _stride_of(cfg, name))
             else:
                 fan_in = shape[1] * shape[2]
-            a = rng.standard_normal(shape) * (0.8 / np.sqrt(fan_in))
+            a = draw(shape, 0.8 / np.sqrt(fan_in))
         elif kind == "post":
-            a = rng.standard_normal(shape) * (0.5 / np.sqrt(shape[1]))
+            a = draw(shape, 0.5 / np.sqrt(shape[1]))
         elif kind == "spline_proj":
-            a = rng.standard_normal(shape) * (2.0 / np.sqrt(shape[1]))
+            a = draw(shape, 2.0 / np.sqrt(shape[1]))
         elif kind == "bias":
-            a = rng.standard_normal(shape) * 0.05
+            a = rng.standard_normal(shape) * (0.2 if heavy else 0.05)
         elif kind == "gamma":
-            a = 1.0 + rng.standard_normal(shape) * 0.1
+            a = 1.0 + rng.standard_normal(shape) * (0.3 if heavy else 0.1)
         elif kind == "beta":
-            a = rng.standard_normal(shape) * 0.1
+            a = rng.standard_normal(shape) * (0.4 if heavy else 0.1)
         elif kind == "emb":
-            a = rng.standard_normal(shape) * (shape[1] ** -0.5)
+            a = draw(shape, shape[1] ** -0.5)
         elif kind == "emb_g":
             a = rng.standard_normal(shape) * 0.3
         elif kind == "rel":

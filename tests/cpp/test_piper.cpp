@@ -1,7 +1,11 @@
 // Mirror of the reference's only test (src/cpp/test.cpp:15-60): load a voice, synthesise
 // "This is a test." to a WAV stream through the piper:: API, require a non-trivial file. Extended with
 // the direct phoneme-id path and the config values, printed for the pytest wrapper to check.
-//   usage: test_piper <voice.onnx> <out.wav>
+//   usage: test_piper <voice.onnx> <out.wav> [dump-prefix]
+// With a dump prefix the int16 PCM of piper::synthesize (ids 1 0 10 0 11 0 12 0 2) and of piper::textToAudio
+// ("hello there"), both with the noise switched off, are written to <prefix>.synth.pcm / <prefix>.text.pcm for the pytest
+// wrapper, which compares them with the CPU oracle.
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -44,6 +48,12 @@ int main(int argc, char** argv) {
       std::cerr << "ERROR: synthesize() contract violated\n";
       return 1;
     }
+    auto dump = [&](const char* what, const int16_t* p, std::size_t n) {
+      if (argc < 4) return;
+      std::ofstream f(std::string(argv[3]) + "." + what + ".pcm", std::ios::binary);
+      f.write(reinterpret_cast<const char*>(p), (std::streamsize)(n * sizeof(int16_t)));
+    };
+    dump("synth", audio.data() + 7, audio.size() - 7);
     std::vector<piper::PhonemeId> pid;
     std::map<piper::Phoneme, std::size_t> missing;
     piper::phonemes_to_ids({U'a', U'☃', U'b'}, voice.phonemizeConfig, pid, missing);
@@ -113,6 +123,7 @@ int main(int argc, char** argv) {
         std::cerr << "ERROR: upper-case text differs from its case-folded form (" << u.size() << " vs " << l.size() << ")\n";
         return 1;
       }
+      dump("text", l.data(), l.size());
       // a phoneme without an id is dropped AND reported (piper.cpp:600-610)
       std::vector<int16_t> m;
       piper::textToAudio(config, voice, "ab\xE2\x98\x83\xE2\x98\x83", m, rl, nullptr);
@@ -163,6 +174,41 @@ int main(int argc, char** argv) {
       if (callbacks != 2 || !got.empty() || all.empty() || seenVoice.empty() || r5.inferSeconds <= 0 || r5.audioSeconds <= 0) {
         std::cerr << "ERROR: phonemizer slot / per-sentence callback contract (" << callbacks << " callbacks)\n";
         return 1;
+      }
+      // ---- several sentences: without a callback the whole text is ONE engine call, with a callback the sentences go
+      // in groups of 1, 2, 4, ... (the next group runs while the callbacks consume the previous one). Both must give
+      // what the reference's sequential loop gives: per sentence synthesize() + sentence silence (piper.cpp:548-598).
+      {
+        const std::string text = "ab cd. ef gh ab. a. bcd efg. hi. abc abc abc. de. fgh";      // 8 sentences, one of them ~empty
+        std::vector<int16_t> whole, parts, expect, buf;
+        piper::SynthesisResult ra, rb;
+        piper::textToAudio(ec, ev, text, whole, ra, nullptr);
+        int ncb = 0;
+        piper::textToAudio(ec, ev, text, buf, rb, [&] { ++ncb; parts.insert(parts.end(), buf.begin(), buf.end()); });
+        std::vector<std::vector<piper::Phoneme>> sents;
+        ec.phonemizer(text, "", sents);
+        const std::size_t ssil = (std::size_t)(ev.synthesisConfig.sentenceSilenceSeconds * ev.synthesisConfig.sampleRate *
+                                               ev.synthesisConfig.channels);
+        for (auto& sp : sents) {
+          std::vector<piper::PhonemeId> sid3;
+          std::map<piper::Phoneme, std::size_t> miss3;
+          piper::phonemes_to_ids(sp, ev.phonemizeConfig, sid3, miss3);
+          piper::SynthesisResult r6;
+          if (!sp.empty()) piper::synthesize(sid3, ev.synthesisConfig, ev.session, expect, r6);
+          expect.insert(expect.end(), ssil, (int16_t)0);
+        }
+        auto maxdiff = [](const std::vector<int16_t>& a, const std::vector<int16_t>& b) {
+          long m = a.size() == b.size() ? 0 : 1 << 20;
+          for (std::size_t i = 0; i < a.size() && i < b.size(); ++i) m = std::max(m, std::labs((long)a[i] - (long)b[i]));
+          return m;
+        };
+        if (ncb != (int)sents.size() || !buf.empty() || maxdiff(whole, expect) > 2 || maxdiff(parts, expect) > 2 ||
+            ra.audioSeconds <= 0 || rb.inferSeconds <= 0) {
+          std::cerr << "ERROR: multi-sentence text: " << ncb << " callbacks for " << sents.size() << " sentences, |whole - seq| = "
+                    << maxdiff(whole, expect) << ", |callback parts - seq| = " << maxdiff(parts, expect) << " (sizes "
+                    << whole.size() << " / " << parts.size() << " / " << expect.size() << ")\n";
+          return 1;
+        }
       }
       // single-speaker voice: no speaker id is fed (reference omits the "sid" input)
       if (ev.synthesisConfig.speakerId) { std::cerr << "ERROR: speakerId set on a single-speaker voice\n"; return 1; }

@@ -262,5 +262,25 @@ def test_engine_group_argument_errors_and_single_device(emu_lib):
     assert np.array_equal(r.pcm[0], s.pcm[0]) and grp.assignment(1) == [0]
     with pytest.raises(EngineError):
         grp.synthesize_batch([], (0.0, 1.0, 0.0))
+    # hostile offsets through the raw C ABI: they are the caller's and are checked BEFORE they size a copy --
+    # reversed, negative, empty and oversized ranges are clean errors with the single-engine call's messages, not reads
+    # outside `ids` or enormous allocations
+    i64p, f32p = C.POINTER(C.c_int64), C.POINTER(C.c_float)
+    idbuf = np.ascontiguousarray(ids[0], np.int64)
+    sc = np.asarray((0.0, 1.0, 0.0), np.float32)
+    res = L.PeResult()
+
+    def call(offsets, batch):
+        off = np.asarray(offsets, np.int64)
+        return emu_lib.pe_group_synthesize_batch(grp._h, idbuf.ctypes.data_as(i64p), off.ctypes.data_as(i64p), batch,
+                                                 sc.ctypes.data_as(f32p), None, C.byref(res))
+    for offsets, batch, msg in (([0, 7], 0, b"batch size"), ([0, 7], -3, b"batch size"), ([0, 7], 5000, b"batch size"),
+                                ([7, 0], 1, b"empty"), ([0, 0], 1, b"empty"), ([-4, 3], 1, b"negative"),
+                                ([0, 3, 2], 2, b"empty"), ([0, 1 << 40], 1, b"longer than 8192"),
+                                ([0, 4, 4 + (1 << 33)], 2, b"longer than 8192")):
+        assert call(offsets, batch) != 0, (offsets, batch)
+        assert msg in emu_lib.pe_last_error(), (offsets, batch, emu_lib.pe_last_error())
+    assert call([0, 7], 1) == 0                                # and the group still works afterwards
+    assert res.batch == 1 and res.sample_offsets[1] == r.pcm[0].size
     eng.close()
     grp.close()

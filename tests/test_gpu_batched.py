@@ -42,8 +42,9 @@ def voice(preset, seed=1234, **over):
 def make_engine(monkeypatch, cfg, w, env=None):
     from piper_amd.engine import Engine
     for k in ("PIPER_HIP_SPLITK_MAX", "PIPER_HIP_SMALL", "PIPER_HIP_WIDE_MIN", "PIPER_HIP_TPB", "PIPER_HIP_SPLITK16",
-              "PIPER_HIP_WIDE_SPLITK", "PIPER_HIP_DEBUG_KEEP", "PIPER_HIP_MRF2", "PIPER_HIP_FUSE_DP",
-              "PIPER_HIP_MRF2_MAXF", "PIPER_HIP_SPEC", "PIPER_HIP_COLCHAIN", "PIPER_HIP_GROUP_MRF"):
+              "PIPER_HIP_WIDE_SPLITK", "PIPER_HIP_DEBUG_KEEP", "PIPER_HIP_MRF", "PIPER_HIP_FUSE_DP",
+              "PIPER_HIP_MRF_MAXF", "PIPER_HIP_SPEC", "PIPER_HIP_COLCHAIN", "PIPER_HIP_GROUP_MRF", 
+              "PIPER_HIP_MRF_OU"):
         monkeypatch.delenv(k, raising=False)
     for k, v in (env or {}).items():
         monkeypatch.setenv(k, str(v))
@@ -137,19 +138,19 @@ def test_medium_b16_ragged_matches_oracle(monkeypatch):
 # variant on shapes where the default heuristics would pick another one. `expect`: instantiations that must run.
 FORCED = [
     # every conv of a single utterance through the TILED kernels (gate epilogue, 32-row and 64-row tiles, both halos)
-    ("medium", [128], {"PIPER_HIP_SPLITK_MAX": 0, "PIPER_HIP_MRF2": 0},
+    ("medium", [128], {"PIPER_HIP_SPLITK_MAX": 0, "PIPER_HIP_MRF": 0},
      {"conv_mfma_kernel<2,2,2,1,16,true,64>", "conv_mfma_kernel<2,2,1,1,16,false,64>",
       "conv_mfma_kernel<1,4,1,1,16,false,64>", "conv_mfma_kernel<2,2,1,1,16,false,128>",
       "conv_mfma_kernel<1,4,1,1,16,false,128>"}),
     # large tiles (CFG_A 128x128 incl. its gate form, CFG_B 64x128) -- chosen only when PIPER_HIP_SMALL=0
-    ("medium", [128] * 16, {"PIPER_HIP_SMALL": 0, "PIPER_HIP_MRF2": 0},
+    ("medium", [128] * 16, {"PIPER_HIP_SMALL": 0, "PIPER_HIP_MRF": 0},
      {"conv_mfma_kernel<2,2,2,2,8,true,64>", "conv_mfma_kernel<2,2,2,2,8,false,64>", "conv_mfma_kernel<1,4,2,1,16,false,64>"}),
-    ("x-low", [64] * 32, {"PIPER_HIP_SMALL": 0, "PIPER_HIP_MRF2": 0}, {"conv_mfma_kernel<1,4,2,1,16,true,64>"}),
+    ("x-low", [64] * 32, {"PIPER_HIP_SMALL": 0, "PIPER_HIP_MRF": 0}, {"conv_mfma_kernel<1,4,2,1,16,true,64>"}),
     # 256-column tiles (CFG_C2 / CFG_B2)
-    ("medium", [128] * 16, {"PIPER_HIP_SMALL": 0, "PIPER_HIP_WIDE_MIN": 1, "PIPER_HIP_MRF2": 0},
+    ("medium", [128] * 16, {"PIPER_HIP_SMALL": 0, "PIPER_HIP_WIDE_MIN": 1, "PIPER_HIP_MRF": 0},
      {"conv_mfma_kernel<1,4,1,2,16,false,64>", "conv_mfma_kernel<1,4,2,2,8,false,64>"}),
     # several column tiles per workgroup (in-kernel slab pipeline across tiles)
-    ("medium", [128, 40], {"PIPER_HIP_SPLITK_MAX": 0, "PIPER_HIP_TPB": 3, "PIPER_HIP_MRF2": 0}, set()),
+    ("medium", [128, 40], {"PIPER_HIP_SPLITK_MAX": 0, "PIPER_HIP_TPB": 3, "PIPER_HIP_MRF": 0}, set()),
     # the duration predictor with ConvFlow.pre / proj / spline as separate launches (default: fused into the DDSConv layers)
     ("medium", [128, 31], {"PIPER_HIP_FUSE_DP": 0}, {"conv_splitk_kernel<1,false,8,4>"}),
     # conv_o + LN and coupling post + next pre as single launches (colchain_kernel): forced on for a batch, and off
@@ -361,26 +362,33 @@ def test_randomised_stress_sweep(monkeypatch):
     print("stress sweep worst |d audio| = %.2e" % worst)
 
 
-@pytest.mark.parametrize("preset,lens", [("medium", [128, 37]), ("medium", [100] * 12), ("high", [64, 9]), ("x-low", [64])])
-def test_fused_mrf2_stage_kernel_matches_unfused_and_oracle(monkeypatch, preset, lens):
-    """mrf2_kernel (one launch per <= 64-channel MRF stage: every resblock conv out of LDS, activated tensors, residuals
-    and the MRF sum in registers) against the conv-by-conv schedule (PIPER_HIP_MRF2=0) and the oracle."""
+@pytest.mark.parametrize("preset,lens,ou", [("medium", [128, 37], 0), ("medium", [100] * 12, 0), ("medium", [77, 128], 1),
+                                            ("medium", [128], 2), ("medium", [90, 31], 3), ("high", [64, 9], 0),
+                                            ("high", [40], 1), ("high", [33, 20, 50], 3), ("x-low", [64], 0)])
+def test_fused_mrf_stage_kernel_matches_unfused_and_oracle(monkeypatch, preset, lens, ou):
+    """mrf_kernel (one launch per <= 64-channel MRF stage: every resblock conv out of LDS, activated tensors, residuals
+    and the MRF sum in registers, weights prefetched from L2 into registers) against the conv-by-conv schedule
+    (PIPER_HIP_MRF=0) and the oracle, for every window geometry (`ou` output units per wave; 0 = the launcher's cost
+    model)."""
     cfg, w = voice(preset)
     ids, nw, nz = batch_inputs(cfg, lens, seed=81)
-    fused = make_engine(monkeypatch, cfg, w, {"PIPER_HIP_MRF2": 2})      # 2 = also for batches (default: small ones only)
+    env = {"PIPER_HIP_MRF": 2}                                           # 2 = wherever the kernel applies (default: measured policy)
+    if ou:
+        env["PIPER_HIP_MRF_OU"] = ou
+    fused = make_engine(monkeypatch, cfg, w, env)
     names, worst = run_and_check(fused, cfg, w, ids, nw, nz, sample=sorted({0, len(lens) - 1}))
-    assert any(n.startswith("mrf2_kernel<") for n in names), names
+    assert any(n.startswith("mrf_kernel<") for n in names), names
     a = fused.synthesize_batch(ids, SCALES, noise_w=nw, noise_z=nz)
     fused.close()
-    plain = make_engine(monkeypatch, cfg, w, {"PIPER_HIP_MRF2": 0})
+    plain = make_engine(monkeypatch, cfg, w, {"PIPER_HIP_MRF": 0})
     names0, _ = run_and_check(plain, cfg, w, ids, nw, nz, sample=[0])
-    assert not any(n.startswith("mrf2_kernel<") for n in names0)
+    assert not any(n.startswith("mrf_kernel<") for n in names0)
     b = plain.synthesize_batch(ids, SCALES, noise_w=nw, noise_z=nz)
     plain.close()
     for i in range(len(lens)):
         assert a.audio[i].shape == b.audio[i].shape
         assert np.max(np.abs(a.audio[i] - b.audio[i])) < 2e-5
-    print(preset, "mrf2 kernels:", sorted(n for n in names if n.startswith("mrf2")), "worst |d audio| %.2e" % worst)
+    print(preset, "fused stage kernels:", sorted(n for n in names if n.startswith("mrf")), "worst |d audio| %.2e" % worst)
 
 
 def test_speculative_stage_b_hits_and_misses(monkeypatch):
@@ -428,18 +436,40 @@ def test_every_profiled_instantiation_is_parity_tested():
 
 
 
-def test_engine_group_two_engines_on_one_gpu(monkeypatch):
-    """pe_group_* on hardware: two engines of one process (the box has one GPU, so both on device 0) with the packed
-    weights copied arena to arena, shards run by two host threads concurrently. Noise scales 0 make the result
-    deterministic: every utterance must equal what a single engine returns, in the caller's order."""
+def test_rccl_load_path_at_world_size_one(tmp_path):
+    """The multi-GPU load path on the single-GPU box: `PIPER_BENCH_DIST=1 python bench.py` initialises the "nccl" (RCCL)
+    process group with ONE rank and goes through piper_amd.dist.load_sharded -- layout check, arena as a torch tensor,
+    dist.broadcast of the packed weights -- before the timed loop. (More ranks need more GPUs: the driver's scaling run.)"""
+    import subprocess
+    import sys
+    env = dict(os.environ, PIPER_BENCH_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-extra", "--no-cpu-baseline", "--no-roofline",
+                          "--steps", "5", "--warmup", "2", "--min-seconds", "0"], capture_output=True, text=True, timeout=600,
+                         env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 1 and d["value"] > 1e6
+    assert d["weight_broadcast_bytes"] > 50e6, d["weight_broadcast_bytes"]      # the medium voice's packed arena
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 1]])
+def test_engine_group_two_engines(monkeypatch, devices):
+    """pe_group_* on hardware: two engines of one process -- on two GPUs when the box has them (hipMemcpyPeer over xGMI),
+    else both on device 0 -- with the packed weights copied arena to arena, shards run by two host threads concurrently.
+    Noise scales 0 make the result deterministic: every utterance must equal what a single engine returns, in the
+    caller's order."""
+    import torch
     from piper_amd import dist
     from piper_amd.group import EngineGroup
+    if max(devices) >= torch.cuda.device_count():
+        pytest.skip(f"needs {max(devices) + 1} GPUs")
     cfg, w = voice("medium")
     blob = W.pack_blob(cfg, w)
     lens = [128, 40, 77, 9, 101, 64]
     ids = [W.synthetic_phoneme_ids(T, 300 + i, id_max=129) for i, T in enumerate(lens)]
     scales = (0.0, 1.0, 0.0)
-    grp = EngineGroup(blob, [0, 0])
+    grp = EngineGroup(blob, devices)
     rg = grp.synthesize_batch(ids, scales)
     assign = grp.assignment(len(ids))
     table = dist.shard_indices(lens, 2)
