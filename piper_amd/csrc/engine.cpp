@@ -1,13 +1,5 @@
 #include "engine.h"
-#include "kernels/attention.h"
-#include "kernels/colchain.h"
-#include "kernels/conv_mfma.h"
-#include "kernels/conv_splitk.h"
-#include "kernels/dds.h"
-#include "kernels/duration.h"
-#include "kernels/layernorm.h"
-#include "kernels/mrf.h"
-#include "kernels/post.h"
+#include "kernels/launch.h"
 
 #include <algorithm>
 #include <cmath>
@@ -20,12 +12,12 @@ namespace pe {
 
 thread_local long g_launches = 0;
 
-// a launch on the engine's stream with a level-2 profile row of its own (the element-wise / integer glue kernels; the
-// conv / attention / fused-stage launchers bracket themselves and also carry FLOP and byte counts)
-#define PE_LAUNCH_K(kname, kernel, grid, block, smem, stream, ...)               \
+// a launch with a level-2 profile row of its own (the element-wise / integer glue kernels; the conv / attention /
+// fused-stage launchers bracket themselves and also carry FLOP and byte counts)
+#define PE_LAUNCH_K(kname, call)                                                 \
   do {                                                                           \
     const int kh_ = kbegin(prof_level_ >= 2 ? krow(kname) : 0, 0.0);             \
-    PE_LAUNCH(kernel, grid, block, smem, stream, __VA_ARGS__);                   \
+    call;                                                                        \
     kend(kh_);                                                                   \
   } while (0)
 
@@ -509,33 +501,9 @@ void Engine::init(const WeightSet& ws) {
     }
     halo_frames_ = (int)(r + 3);
   }
-#ifndef PE_EMU
-  {
-    // allow > 64 KiB of dynamic LDS (gfx950: 160 KiB per workgroup)
-    const int lim = 160 * 1024;
-#define PE_K2(WM, WN, MT, NT, KS, G) (const void*)conv_mfma_kernel<WM, WN, MT, NT, KS, G, 64>, (const void*)conv_mfma_kernel<WM, WN, MT, NT, KS, G, 128>
-    const void* ks[] = {PE_K2(2, 2, 2, 2, 8, false), PE_K2(1, 4, 2, 1, 16, false), PE_K2(1, 4, 1, 1, 16, false),
-                        PE_K2(2, 2, 1, 1, 16, false), PE_K2(2, 2, 2, 1, 16, false), PE_K2(1, 4, 1, 2, 16, false),
-                        PE_K2(1, 4, 2, 2, 8, false), PE_K2(2, 2, 2, 2, 8, true), PE_K2(1, 4, 2, 1, 16, true),
-                        PE_K2(2, 2, 2, 1, 16, true)};
-#undef PE_K2
-    for (const void* k : ks) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    const void* ks2[] = {(const void*)conv_splitk_kernel<2, true, 8, 3>, (const void*)conv_splitk_kernel<2, true, 4, 3>,
-                         (const void*)conv_splitk_kernel<1, false, 8, 4>, (const void*)conv_splitk_kernel<1, false, 4, 4>,
-                         (const void*)conv_splitk_kernel<2, true, 12, 2>, (const void*)conv_splitk_kernel<1, false, 12, 4>,
-                         (const void*)conv_splitk16_kernel<true, 12, 2>, (const void*)conv_splitk16_kernel<false, 8, 4>};
-    for (const void* k : ks2) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    PE_HIP(hipFuncSetAttribute((const void*)conv_splitk_group_kernel<4, 2, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    PE_HIP(hipFuncSetAttribute((const void*)conv_splitk_group_kernel<4, 2, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    PE_HIP(hipFuncSetAttribute((const void*)conv_splitk_sum_kernel<4, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    PE_HIP(hipFuncSetAttribute((const void*)attn_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    PE_HIP(hipFuncSetAttribute((const void*)attn_kernel<48>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    PE_HIP(hipFuncSetAttribute((const void*)attn_kernel<96>, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-    const void* ks5[] = {(const void*)mrf_kernel<32, 1, 1>, (const void*)mrf_kernel<32, 2, 1>, (const void*)mrf_kernel<32, 3, 1>,
-                         (const void*)mrf_kernel<64, 1, 2>, (const void*)mrf_kernel<64, 2, 2>, (const void*)mrf_kernel<64, 3, 2>};
-    for (const void* k : ks5) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
-  }
-#endif
+  launch::init_conv();
+  launch::init_front();
+  launch::init_tail();
   static const char* rows[] = {"text_encoder", "duration_predictor", "regulate+flow", "hifigan", "post+pcm"};
   for (auto n : rows) prof_.push_back(ProfileRow{n});
   PE_HIP(hipEventCreate(&ev0_));
@@ -761,8 +729,7 @@ void Engine::group_end() {
     const double share = (double)n / (double)group_.size();
     const int kh = kbegin(prof_level_ >= 2 ? krow(wide ? "conv_splitk_group_kernel<4,2,128>" : "conv_splitk_group_kernel<4,2,64>") : 0,
                           group_flops_ * share, group_bytes_ * share);
-    if (wide) PE_LAUNCH((conv_splitk_group_kernel<4, 2, 128>), grid, dim3(64 * NW), smem, ls_, g);
-    else PE_LAUNCH((conv_splitk_group_kernel<4, 2, 64>), grid, dim3(64 * NW), smem, ls_, g);
+    launch::conv_group(wide != 0, grid, smem, ls_, g);
     kend(kh);
   }
   group_.clear();
@@ -797,7 +764,7 @@ void Engine::group_end_sum(View out, const float* bias_sum, float alpha) {
   const dim3 grid((group_ncols_ + 31) / 32, (q.rows + 31) / 32, B_);
   // (a 4-deep weight ring measured slower than 2: hifigan stage 0.345 vs 0.338 ms)
   const int kh = kbegin(prof_level_ >= 2 ? krow("conv_splitk_sum_kernel<4,2>") : 0, group_flops_, group_bytes_);
-  PE_LAUNCH((conv_splitk_sum_kernel<4, 2>), grid, dim3(64 * NW), smem, ls_, q);
+  launch::conv_group_sum(grid, smem, ls_, q);
   kend(kh);
   group_.clear();
 }
@@ -895,27 +862,13 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     // MFMA-pipe bound inside the workgroup (>= 24 chunk-tap units) although most CUs idle: 16 output columns
     if (k16) {
       dim3 grid16((ncols + 15) / 16, pc.mtiles / MT, B_);
-      if (pc.gate) {
-        const int nw = 12;
-        p.tgroups = pc.nchunks <= 6 ? 2 : 1;
-        PE_LAUNCH((conv_splitk16_kernel<true, 12, 2>), grid16, dim3(64 * nw), (size_t)nw * KC * 64 * sizeof(float), ls_, p);
-      } else {
-        const int nw = 8;
-        p.tgroups = 1;
-        PE_LAUNCH((conv_splitk16_kernel<false, 8, 4>), grid16, dim3(64 * nw), (size_t)nw * KC * 64 * sizeof(float), ls_, p);
-      }
+      const int nw = pc.gate ? 12 : 8;
+      p.tgroups = pc.gate ? (pc.nchunks <= 6 ? 2 : 1) : 1;
+      launch::conv_splitk16(pc.gate, grid16, (size_t)nw * KC * 64 * sizeof(float), ls_, p);
       kend(kh);
       return;
     }
-    if (pc.gate) {
-      if (NW == 12) PE_LAUNCH((conv_splitk_kernel<2, true, 12, 2>), grid, dim3(768), smem, ls_, p);
-      else if (NW == 8) PE_LAUNCH((conv_splitk_kernel<2, true, 8, 3>), grid, dim3(512), smem, ls_, p);
-      else PE_LAUNCH((conv_splitk_kernel<2, true, 4, 3>), grid, dim3(256), smem, ls_, p);
-    } else {
-      if (NW == 12) PE_LAUNCH((conv_splitk_kernel<1, false, 12, 4>), grid, dim3(768), smem, ls_, p);
-      else if (NW == 8) PE_LAUNCH((conv_splitk_kernel<1, false, 8, 4>), grid, dim3(512), smem, ls_, p);
-      else PE_LAUNCH((conv_splitk_kernel<1, false, 4, 4>), grid, dim3(256), smem, ls_, p);
-    }
+    launch::conv_splitk(pc.gate, NW, grid, smem, ls_, p);
     kend(kh);
     return;
   }
@@ -950,29 +903,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     snprintf(nm, sizeof(nm), "conv_mfma_kernel<%s,%s,%d>", knames[cfg], pc.gate ? "true" : "false", HALO);
     kh = kbegin(krow(std::string(nm)), kflops, kbytes);
   }
-#define PE_CONV_LAUNCH(WM, WN, MT, NT, KS, G)                                                                  \
-  do {                                                                                                         \
-    if (HALO == 64) PE_LAUNCH((conv_mfma_kernel<WM, WN, MT, NT, KS, G, 64>), grid, dim3(256), smem, ls_, p); \
-    else PE_LAUNCH((conv_mfma_kernel<WM, WN, MT, NT, KS, G, 128>), grid, dim3(256), smem, ls_, p);          \
-  } while (0)
-  if (pc.gate) {
-    switch (cfg) {
-      case CFG_A: PE_CONV_LAUNCH(2, 2, 2, 2, 8, true); break;
-      case CFG_B: PE_CONV_LAUNCH(1, 4, 2, 1, 16, true); break;
-      default:    PE_CONV_LAUNCH(2, 2, 2, 1, 16, true); break;
-    }
-  } else {
-    switch (cfg) {
-      case CFG_A: PE_CONV_LAUNCH(2, 2, 2, 2, 8, false); break;
-      case CFG_B: PE_CONV_LAUNCH(1, 4, 2, 1, 16, false); break;
-      case CFG_C: PE_CONV_LAUNCH(1, 4, 1, 1, 16, false); break;
-      case CFG_S: PE_CONV_LAUNCH(2, 2, 1, 1, 16, false); break;
-      case CFG_C2: PE_CONV_LAUNCH(1, 4, 1, 2, 16, false); break;
-      case CFG_B2: PE_CONV_LAUNCH(1, 4, 2, 2, 8, false); break;
-      default:    PE_CONV_LAUNCH(2, 2, 2, 1, 16, false); break;
-    }
-  }
-#undef PE_CONV_LAUNCH
+  launch::conv_tile(cfg, pc.gate, HALO, grid, smem, ls_, p);
   kend(kh);
 }
 
@@ -1111,18 +1042,11 @@ void Engine::mrf(const UpStage& st, View x, View out, const int* lens, int len_m
     kflops = 2.0 * macs * cols;
     kbytes = 8.0 * st.ch * cols + 4.0 * st.mrf_wfloats;      // one read of x, one write of the mean, the weights once
   }
-  const size_t smem = mrf_smem_bytes(CP);
   dim3 grid((Lmax + best.N - 1) / best.N, B_);
   char nm[64];
   snprintf(nm, sizeof(nm), "mrf_kernel<%d,%d,%d>", CP, best.ou, HU);
   const int kh = prof_level_ >= 2 ? kbegin(krow(std::string(nm)), kflops, kbytes) : -1;
-#define PE_MRF(CP_, OU_, HU_) PE_LAUNCH((mrf_kernel<CP_, OU_, HU_>), grid, dim3(64 * MRF_NW), smem, ls_, p)
-  if (CP == 32) {
-    if (best.ou == 1) PE_MRF(32, 1, 1); else if (best.ou == 2) PE_MRF(32, 2, 1); else PE_MRF(32, 3, 1);
-  } else {
-    if (best.ou == 1) PE_MRF(64, 1, 2); else if (best.ou == 2) PE_MRF(64, 2, 2); else PE_MRF(64, 3, 2);
-  }
-#undef PE_MRF
+  launch::mrf(CP, best.ou, grid, ls_, p);
   kend(kh);
 }
 
@@ -1135,7 +1059,7 @@ void Engine::layer_norm(View in, View out, const float* g, const float* b, int C
   if (C > LN_COLS * 32) throw std::runtime_error("LayerNorm over more than 256 channels is not supported");
   dim3 grid((Lmax + LN_COLS - 1) / LN_COLS, B_);
   const int kh = kbegin(prof_level_ >= 2 ? krow("ln_kernel") : 0, 0.0);
-  PE_LAUNCH(ln_kernel, grid, dim3(256), 0, stream_, p);
+  launch::layer_norm(grid, stream_, p);
   kend(kh);
 }
 
@@ -1183,9 +1107,7 @@ void Engine::dds(const DdsW& d, View in, View out, View tmp, const DdsOpt* opt) 
     const dim3 grid16((Tg_ + 15) / 16, B_);
     const size_t smem16 = ((size_t)2 * p.nchunks * 32 * 16 + 16 * 16) * sizeof(float);
     // <3> / <6> are compiled for exactly 96 / 192 padded channels; <8> takes any width up to 256
-    if (p.nchunks == 3) PE_LAUNCH(dds_layer16_kernel<3>, grid16, dim3(512), smem16, stream_, p);
-    else if (p.nchunks == 6) PE_LAUNCH(dds_layer16_kernel<6>, grid16, dim3(512), smem16, stream_, p);
-    else PE_LAUNCH(dds_layer16_kernel<8>, grid16, dim3(512), smem16, stream_, p);
+    launch::dds_layer(p.nchunks, grid16, smem16, stream_, p);
     kend(kh);
   }
 }
@@ -1218,14 +1140,14 @@ void Engine::lngemm(View y, const float* g, const float* b, View x, const float*
   p.lens = d_tlens_;
   const int kh = kbegin(prof_level_ >= 2 ? krow("lngemm_kernel<6>") : 0, flops);
   const size_t smem = ((size_t)192 * 16 + 16 * 16) * sizeof(float);
-  PE_LAUNCH(lngemm_kernel<6>, dim3((T + 15) / 16, B_, (rows + 191) / 192), dim3(512), smem, stream_, p);
+  launch::lngemm(dim3((T + 15) / 16, B_, (rows + 191) / 192), smem, stream_, p);
   kend(kh);
 }
 
 void Engine::colchain(const ColP& p, int B, int Lmax, double flops) {
   const int kh = kbegin(prof_level_ >= 2 ? krow("colchain_kernel<6>") : 0, flops);
   const size_t smem = ((size_t)2 * 6 * 32 * 16 + 16 * 16) * sizeof(float);
-  PE_LAUNCH(colchain_kernel<6>, dim3((Lmax + 15) / 16, B), dim3(512), smem, stream_, p);
+  launch::colchain(dim3((Lmax + 15) / 16, B), smem, stream_, p);
   kend(kh);
 }
 
@@ -1363,8 +1285,7 @@ void Engine::issue_stage_a() {
   const float* cb_dp = nullptr;
   if (nspk_ > 1) {
     auto cond = [&](const CondW& c, int off) {
-      PE_LAUNCH_K("cond_kernel", cond_kernel, dim3((c.rows + 127) / 128, B), dim3(128), 0, stream_, emb_g_, gin_, d_sids_, c.w, c.b,
-                c.rows, cond_ + off, cond_bs_);
+      PE_LAUNCH_K("cond_kernel", launch::cond(dim3((c.rows + 127) / 128, B), stream_, emb_g_, gin_, d_sids_, c.w, c.b, c.rows, cond_ + off, cond_bs_));
     };
     cond(cond_dp_, cond_off_dp_);
     for (size_t i = 0; i < cond_wn_.size(); ++i) cond(cond_wn_[i], cond_off_wn_[i]);
@@ -1375,8 +1296,7 @@ void Engine::issue_stage_a() {
   // ================= text encoder (models.py:198-209, attentions.py:60-74)
   prof_begin();
   double fl = 0;
-  PE_LAUNCH_K("embed_kernel", embed_kernel, dim3((T + 63) / 64, (H_ + 15) / 16, B), dim3(64), 0, stream_, d_ids_, Ts, d_tlens_, emb_, H_,
-            std::sqrt((float)H_), x_, (long)H_ * Ts, Ts, d_rng_);
+  PE_LAUNCH_K("embed_kernel", launch::embed(dim3((T + 63) / 64, (H_ + 15) / 16, B), stream_, d_ids_, Ts, d_tlens_, emb_, H_, std::sqrt((float)H_), x_, (long)H_ * Ts, Ts, d_rng_));
   // norm_layers_2 of a layer feeds only the next layer's q/k/v conv (or, after the last layer, proj) + the residual of
   // conv_o. Small batches with the 192-channel encoder run norm_layers_2 + that conv as one launch (lngemm_kernel), and
   // conv_o + residual + norm_layers_1 as another (colchain_kernel); otherwise conv, then ln_kernel.
@@ -1401,9 +1321,7 @@ void Engine::issue_stage_a() {
     for (int b = 0; b < B; ++b) afl += 4.0 * (double)tlens_h_[b] * tlens_h_[b] * H_;
     const int kh = kbegin(prof_level_ >= 2 ? krow(ap.dk == 96 ? "attn_kernel<96>" : ap.dk == 48 ? "attn_kernel<48>" : "attn_kernel<0>") : 0, afl);
     const dim3 agrid((T + ATT_QB - 1) / ATT_QB, nh_, B);
-    if (ap.dk == 96) PE_LAUNCH(attn_kernel<96>, agrid, dim3(256), smem, stream_, ap);
-    else if (ap.dk == 48) PE_LAUNCH(attn_kernel<48>, agrid, dim3(256), smem, stream_, ap);
-    else PE_LAUNCH(attn_kernel<0>, agrid, dim3(256), smem, stream_, ap);
+    launch::attention(ap.dk, agrid, smem, stream_, ap);
     kend(kh);
     const bool chain_o = chain_q;
     if (chain_o) {
@@ -1448,11 +1366,10 @@ void Engine::issue_stage_a() {
   fl += 2.0 * tsum * (2 + arch_[A_DDSLAYERS]) * dp_pre_.macs_per_col;
   // z = noise * noise_scale_w   [B][2][Ts]
   if (!have_noise_w_)
-    PE_LAUNCH_K("randn_kernel", randn_kernel, dim3(randn_blocks((long)B * 2, T)), dim3(256), 0, stream_, noise_w_, (long)B * 2, T, (long)Ts,
-              0L, d_rng_, 0);
+    PE_LAUNCH_K("randn_kernel", launch::randn(stream_, noise_w_, (long)B * 2, T, (long)Ts, 0L, d_rng_, 0));
   if (!fuse_dp_) {
     const long n = (long)B * 2 * Ts;
-    PE_LAUNCH_K("scale_kernel", scale_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream_, noise_w_, z2_, n, scales_[2]);
+    PE_LAUNCH_K("scale_kernel", launch::scale(dim3((unsigned)((n + 255) / 256)), stream_, noise_w_, z2_, n, scales_[2]));
   }
   // Flip is folded into which physical channel is x0 (conditioning) and which is x1 (transformed):
   // logical = physical when an even number of flips has been applied.
@@ -1474,12 +1391,10 @@ void Engine::issue_stage_a() {
       o.zin = zin; o.zin_bs = (long)2 * Ts; o.z_cs = Ts; o.c0 = c0; o.c1 = c1; o.zout = z2_; o.zout_bs = (long)2 * Ts;
       dds(cf.dds, xg, dh, dy2, &o);
     } else {
-      PE_LAUNCH_K("cf_pre_kernel", cf_pre_kernel, dim3((T + 63) / 64, H_, B), dim3(64), 0, stream_, z2_ + (long)c0 * Ts, (long)2 * Ts,
-                cf.pre_w, cf.pre_b, xg_, (long)H_ * Ts, Ts, dy_, (long)H_ * Ts, Ts, d_tlens_, H_);
+      PE_LAUNCH_K("cf_pre_kernel", launch::cf_pre(dim3((T + 63) / 64, H_, B), stream_, z2_ + (long)c0 * Ts, (long)2 * Ts, cf.pre_w, cf.pre_b, xg_, (long)H_ * Ts, Ts, dy_, (long)H_ * Ts, Ts, d_tlens_, H_));
       dds(cf.dds, dy, dh, dy2);
       conv(cf.proj, dh, hproj, d_tlens_, 1, T, EPI_STORE);
-      PE_LAUNCH_K("spline_inverse_kernel", spline_inverse_kernel, dim3((T + 63) / 64, B), dim3(64), 0, stream_, hproj_, (long)32 * Ts, Ts,
-                z2_ + (long)c1 * Ts, (long)2 * Ts, d_tlens_, 1.0f / std::sqrt((float)H_));
+      PE_LAUNCH_K("spline_inverse_kernel", launch::spline_inverse(dim3((T + 63) / 64, B), stream_, hproj_, (long)32 * Ts, Ts, z2_ + (long)c1 * Ts, (long)2 * Ts, d_tlens_, 1.0f / std::sqrt((float)H_)));
     }
     fl += 2.0 * tsum * (arch_[A_DDSLAYERS] * dp_pre_.macs_per_col + cf.proj.macs_per_col);
   }
@@ -1491,7 +1406,7 @@ void Engine::issue_stage_a() {
     dp.lens = d_tlens_; dp.dur = d_dur_; dp.cum = d_cum_; dp.d_bs = Ts; dp.frames = d_frames_; dp.logw_out = logw_;
     dp.frames_host = h_frames_; dp.frames_clamped = d_framesc_; dp.frame_cap = std::max(Fs_, 1);
     {
-      PE_LAUNCH_K("duration_kernel", duration_kernel, dim3(B), dim3(256), 0, stream_, dp);
+      PE_LAUNCH_K("duration_kernel", launch::duration(dim3(B), stream_, dp));
     }
   }
   prof_end(1, fl);
@@ -1519,8 +1434,7 @@ void Engine::issue_flow() {
   } else {
     // (drawing the noise inside regulate_kernel was tried: one launch fewer, but a Philox block + Box-Muller per element
     // in its 16-channels-per-thread loop cost 21 us against this launch's 5, profiles/r02_notes.md)
-    PE_LAUNCH_K("randn_kernel", randn_kernel, dim3(randn_blocks((long)B * C_, Fmax)), dim3(256), 0, stream_, noise_z_, (long)B * C_, Fmax,
-              (long)Fs, 0L, d_rng_, 1);
+    PE_LAUNCH_K("randn_kernel", launch::randn(stream_, noise_z_, (long)B * C_, Fmax, (long)Fs, 0L, d_rng_, 1));
   }
   {
     RegP rp;
@@ -1530,7 +1444,7 @@ void Engine::issue_flow() {
     rp.noise_scale = scales_[0];
     rp.out = zp_; rp.o_bs = (long)C_ * Fs; rp.o_cs = Fs; rp.C = C_;
     rp.absmax = absmax_;
-    PE_LAUNCH_K("regulate_kernel", regulate_kernel, dim3((Fmax + 63) / 64, (C_ + 15) / 16, B), dim3(64), 0, stream_, rp);
+    PE_LAUNCH_K("regulate_kernel", launch::regulate(dim3((Fmax + 63) / 64, (C_ + 15) / 16, B), stream_, rp));
     if (zp_keep_)     // tests: z_p, the flow's input (the flow transforms zp_ in place)
       PE_HIP(hipMemcpyAsync(zp_keep_, zp_, (size_t)B * C_ * Fs * sizeof(float), hipMemcpyDeviceToDevice, stream_));
   }
@@ -1583,7 +1497,7 @@ void Engine::issue_stage_b() {
 
 // streaming: window of z -> window buffer -> generator (lens = window length, in device memory)
 void Engine::issue_window() {
-  PE_LAUNCH_K("window_copy_kernel", window_copy_kernel, dim3((s_wg_ + 63) / 64, C_), dim3(64), 0, stream_, zp_, Fs_, d_win_, zwin_, Fs_, C_);
+  PE_LAUNCH_K("window_copy_kernel", launch::window_copy(dim3((s_wg_ + 63) / 64, C_), stream_, zp_, Fs_, d_win_, zwin_, Fs_, C_));
   issue_decoder(zwin_, d_win_ + 1, s_wg_, (double)s_wg_, true);
 }
 
@@ -1707,8 +1621,7 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
           }
         }
         if (!summed)
-          PE_LAUNCH_K("mrf_sum_kernel", mrf_sum_kernel, dim3((Lmax + 255) / 256, st.ch, B), dim3(256), 0, stream_, side_[8], side_[3],
-                    nk == 3 ? side_[7] : (const float*)nullptr, xs.p, xs.bs, xs.cs, lens, mult, inv_nk);
+          PE_LAUNCH_K("mrf_sum_kernel", launch::mrf_sum(dim3((Lmax + 255) / 256, st.ch, B), stream_, side_[8], side_[3], nk == 3 ? side_[7] : (const float*)nullptr, xs.p, xs.bs, xs.cs, lens, mult, inv_nk));
       } else {
         for (int j = 0; j < nk; ++j) {
           const int accmode = nk == 1 ? 3 : (j == 0 ? 0 : (j == nk - 1 ? 2 : 1));
@@ -1724,12 +1637,10 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
     prof_begin();
     if (zero_absmax) PE_HIP(hipMemsetAsync(absmax_, 0, B * sizeof(unsigned), stream_));
     const int K = 7, Lmax = Fmax * hop_;
-    PE_LAUNCH_K("conv_post_kernel", conv_post_kernel, dim3((Lmax + POST_SPB - 1) / POST_SPB, B), dim3(256), 0, stream_, cur.p,
-              cur.bs, cur.cs, post_w_, post_cin_, 0.01f, lens, hop_, audio_, Ss_, absmax_);
+    PE_LAUNCH_K("conv_post_kernel", launch::conv_post(dim3((Lmax + POST_SPB - 1) / POST_SPB, B), stream_, cur.p, cur.bs, cur.cs, post_w_, post_cin_, 0.01f, lens, hop_, audio_, Ss_, absmax_));
     // (zero_absmax marks the streaming window path, which delivers per chunk from the device buffer)
     int16_t* zc = (pcm_zc_ && !zero_absmax && h_pcm_zc_cap_ >= (size_t)B * (size_t)Ss_) ? h_pcm_zc_ : nullptr;
-    PE_LAUNCH_K("pcm16_kernel", pcm16_kernel, dim3((Lmax + 255) / 256, B), dim3(256), 0, stream_, audio_, Ss_, absmax_, lens, hop_,
-              pcm_, Ss_, zc);
+    PE_LAUNCH_K("pcm16_kernel", launch::pcm16(dim3((Lmax + 255) / 256, B), stream_, audio_, Ss_, absmax_, lens, hop_, pcm_, Ss_, zc));
     prof_end(4, 2.0 * fsum * hop_ * post_cin_ * K);
   }
 }
@@ -2045,7 +1956,7 @@ void Engine::debug_randn(int site, uint64_t call, int64_t row, int64_t n, float*
   if (hipMalloc((void**)&st, 16) != hipSuccess) { hipFree(d); throw std::runtime_error("debug_randn: out of memory"); }
   const unsigned long long hst[2] = {seed_, call};
   hipMemcpy(st, hst, sizeof(hst), hipMemcpyHostToDevice);
-  PE_LAUNCH(randn_kernel, dim3(randn_blocks(rows, cols)), dim3(256), 0, stream_, d, rows, cols, (long)cols, (long)row, st, site);
+  launch::randn(stream_, d, rows, cols, (long)cols, (long)row, st, site);
   hipStreamSynchronize(stream_);
   hipMemcpy(out, d, (size_t)n * sizeof(float), hipMemcpyDeviceToHost);
   hipFree(d);

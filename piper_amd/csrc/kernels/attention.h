@@ -3,6 +3,7 @@
 // /root/reference/src/python/piper_train/vits/.)
 #pragma once
 #include "../pe_rt.h"
+#include "params.h"
 
 namespace pe {
 
@@ -32,18 +33,6 @@ __global__ void embed_kernel(const int* ids, int ids_bs, const int* lens, const 
 // absolute" trick is evaluated directly as a band: logits[i][j] += q_i . rel_k[j-i+w] and
 // out_i += sum_r p[i][i+r] rel_v[r+w] for |r| <= w. Masked keys (>= len) get weight exactly 0, which is
 // what the reference's -1e4 fill yields in fp32.
-struct AttnP {
-  const float* qkv; long q_bs; int q_cs;
-  const float* relk; const float* relv;     // [2w+1][dk]
-  float* out; long o_bs; int o_cs;
-  const int* lens;
-  int H, dk, window;
-  int SP;                                   // score row stride in LDS: odd, >= round_up(max len, 64)
-  float qscale;
-};
-static constexpr int ATT_QB = 32;           // queries per workgroup (one MFMA tile)
-static constexpr int ATT_KCH = 64;          // keys staged per V chunk
-static constexpr int ATT_MAXDK = 128;
 
 // One workgroup = 32 queries of one (utterance, head); 4 waves.
 //   1. S = (q/sqrt(dk)) k^T on the f32 MFMAs: wave w owns key tiles w, w+4, ...; both operands are read

@@ -14,18 +14,6 @@ namespace pe {
 //                                                    NEXT coupling layer's pre over the updated half -- the Flip between
 //                                                    them is folded into the packed weights (modules.py:455-466, 433)
 // Same 16x16x4 MFMA GEMM as dds_layer16_kernel: weights in pack16 order, B operand = the input columns in LDS.
-struct ColP {
-  const float* in1; long in1_bs; int in1_cs; int K1;
-  const float* w1; const float* b1; int rows1;
-  int mode;
-  const float* res; long res_bs; int res_cs;            // mode 0
-  const float* gamma; const float* beta;
-  float* out; long out_bs; int out_cs;
-  float* x1; long x1_bs; int x1_cs;                     // mode 1 (updated in place)
-  const float* w2; const float* b2; int rows2;          // w2 == null: no second GEMM (last coupling layer)
-  float* out2; long o2_bs; int o2_cs;
-  const int* lens;
-};
 
 template <int NVT>                              // NVT = channel slots per thread: every channel count on the chain <= 32 * NVT
 __global__ __launch_bounds__(512) void colchain_kernel(ColP p) {
@@ -141,14 +129,6 @@ __global__ __launch_bounds__(512) void colchain_kernel(ColP p) {
 // after the last layer (attentions.py:73-74, 60-69; models.py:207): one workgroup = 16 columns x one 192-row part of
 // the GEMM (grid.z = parts: 3 for q/k/v, 2 for proj). Every part normalises its 16 columns itself (cheap next to a
 // launch); part 0 also writes LN(y) back for the residual readers. Small batches only, like colchain_kernel.
-struct LnGemmP {
-  const float* in; long in_bs; int in_cs;        // y = x + ffn(x)
-  const float* gamma; const float* beta;
-  float* xout; long x_bs; int x_cs;              // LN(y)
-  const float* w16; const float* bias; int rows; // pack16 order, all parts; part z owns rows [32 NVT z, 32 NVT (z + 1))
-  float* out; long o_bs; int o_cs;
-  const int* lens;
-};
 template <int NVT>                              // channels == 32 * NVT exactly (the launcher checks)
 __global__ __launch_bounds__(512) void lngemm_kernel(LnGemmP p) {
   PE_KTRACE(7);

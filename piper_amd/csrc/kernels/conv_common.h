@@ -3,10 +3,10 @@
 // /root/reference/src/python/piper_train/vits/.)
 #pragma once
 #include "../pe_rt.h"
+#include "params.h"
 
 namespace pe {
 
-static constexpr int KC = 32;           // input channels staged per K-chunk of the conv GEMM
 
 // A-operand fragments (engine.cpp: pack_matrix). One (m tile, chunk, tap) step is 1024 floats:
 // [q = 0..3][lane][j = 0..3] holds fragment kk = 4q + j of `lane`, so NK fragments are NK/4 float4 loads.
@@ -29,40 +29,7 @@ __device__ __forceinline__ void load_frags(const pe_rowsrc& w, int step_off, int
   }
 }
 
-enum Epi { EPI_STORE = 0, EPI_RESADD = 1, EPI_GATE = 2, EPI_WNRS = 3, EPI_SUBFROM = 4,
-           EPI_ACCUM = 5, EPI_CONVT = 6 };
-enum Act { ACT_NONE = 0, ACT_RELU = 1 };
 
-struct ConvP {
-  const float* x; long x_bs; int x_cs;          // input  x[b][ci][t]
-  const float* wp;                              // packed weights (engine.cpp: pack_conv)
-  const float* wp16;                            // conv_splitk16_kernel: the same in 16x16x4 fragment order, or null
-  const float* bias;                            // per output channel or null
-  const float* bias2; int bias2_bs;             // per-utterance extra bias (speaker cond) or null
-  float* out; long o_bs; int o_cs;
-  const float* res; long r_bs; int r_cs;        // residual input (may alias out)
-  float* out2; long o2_bs; int o2_cs;           // second output (WN skip accumulator)
-  const int* lens; int len_mul;                 // valid input length = lens[b]*len_mul
-  int Cin, rows;                                // real input channels; GEMM rows (Cout, or Cout*up)
-  int nchunks;                                  // ceil(Cin/KC)
-  int ntaps, dil, padl;                         // tap k reads x[t + k*dil - padl]
-  int xhalo;                                    // (ntaps-1)*dil
-  float in_slope;                               // leaky-relu slope applied to x while staging (1 = none)
-  int epi, act;
-  int split;                                    // GATE: H ; WNRS: rows < split go to h, rest to skip
-  int up, padT;                                 // CONVT: stride and padding
-  unsigned up_magic;                            // CONVT: ceil(2^32 / up): row / up == (row * up_magic) >> 32 for row < 2^16
-  int mode;                                     // ACCUM: 0 first,1 middle,2 last,3 only ; WNRS: 1 = first layer
-  float alpha;                                  // ACCUM last/only: scale
-  int tpb;                                      // conv_mfma_kernel: column tiles walked by one workgroup
-  int tgroups;                                  // conv_splitk_kernel: 1, or 2 = two halves of the waves split the taps
-  // conv_splitk_body<..., MS = true> only: K = the concatenation of nseg convs of one shape whose outputs are summed
-  // (segment 0 repeats x / wp / ntaps / dil / padl); res2 / res3 = the residual tensors of segments 1 / 2
-  int nseg;
-  const float* seg_x[3]; const float* seg_wp[3];
-  int seg_ntaps[3], seg_dil[3], seg_padl[3];
-  const float* res2; const float* res3;
-};
 
 // ---- shared epilogue of the conv GEMM kernels: one accumulator element (row, col) of utterance b.
 // Every non-transposed mode is the same straight-line form

@@ -269,10 +269,6 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk_kernel(ConvP p) {
 // Up to three INDEPENDENT convs of the same launch shape in one launch (grid.z = group x utterance): the sibling
 // resblocks of an MRF stage read the same input and are each a latency chain of ~10 us on a fraction of the CUs when
 // launched one after the other; together they fill the chip once (models.py:356-363 runs them in a Python loop).
-struct ConvG {
-  ConvP c[3];
-  int n, B;
-};
 // Launch bounds ask for 4 workgroups per CU with the 64-column slab (<= 128 registers, 32 KB of LDS each): a group of
 // 3 x ~420 workgroups then runs as ~1.2 rounds over the chip instead of 1.6-2.5.
 template <int NW, int D, int XW>

@@ -15,31 +15,6 @@ namespace pe {
 // the f32 MFMAs with the activations in LDS and the pre-packed weights read from L2, LN2 + GELU + residual
 // read the GEMM tile back from LDS. Replaces three launches (ln_kernel<2>, conv, ln_kernel<1>) and two
 // round trips of the [H x T] activations through memory.
-struct DdsP {
-  const float* x; long x_bs; int x_cs;
-  float* out; long o_bs; int o_cs;
-  const float* dw_w; const float* dw_b; int dw_k, dw_dil;
-  const float* g1; const float* b1; const float* g2; const float* b2;
-  const float* bias;                        // 1x1 conv bias
-  const float* wp16;                        // 1x1 conv weights in the 16x16x4 fragment order (engine.cpp)
-  int nchunks;                              // ceil(H / 32)
-  const int* lens;
-  int H;
-  // Optional fold of ConvFlow.pre + DDSConv's "x = x + g" into the layer input (modules.py:504-505, 118-119), first
-  // layer of a ConvFlow: the input is  pre_w[c] * (z0[t] * z_scale) + pre_b[c] + x[c][t]  with x = the conditioning g.
-  const float* pre_z; long pre_z_bs;        // z0 row of utterance b (null: no fold)
-  const float* pre_w; const float* pre_b;
-  float z_scale;                            // noise_scale_w on the first flow (z is still the raw N(0,1) draw), else 1
-  // Optional second 1x1 conv on the layer's output columns (last layer of a DDSConv: dp.proj / ConvFlow.proj,
-  // models.py:65, modules.py:507), weights in the 16x16x4 fragment order; the layer output itself is then not stored.
-  const float* post_w16; const float* post_bias; int post_rows;
-  float* post_out; long po_bs; int po_cs;   // plain store of the post conv (dp.proj), or null
-  // Optional spline epilogue (ConvFlow, modules.py:508-526): the post conv's 29 rows are the per-position parameters;
-  // z1 <- rq_spline_inverse(z1 * z_scale), z0 <- z0 * z_scale (pass-through), both [2][Ts] tensors may alias.
-  const float* zin; long zin_bs; int z_cs; int c0, c1;
-  float* zout; long zout_bs;
-  float inv_sqrt_h;
-};
 // Sum over the 32 channel lanes x 8 waves that share a column (512-thread, 16-column workgroups): lane pairs by
 // shuffle, waves through `red` ([2][8][16] floats). The two halves of `red` alternate between calls, so a call costs
 // ONE block barrier: half h is rewritten two calls after it was read, and the barrier of the call in between orders that.

@@ -3,6 +3,7 @@
 // /root/reference/src/python/piper_train/vits/.)
 #pragma once
 #include "../pe_rt.h"
+#include "params.h"
 
 namespace pe {
 
@@ -11,12 +12,6 @@ namespace pe {
 //   cum = inclusive prefix sum; frames = max(sum d, 1).   One block per utterance.
 // Sums run in 64 bits and are clamped to MAX_FRAMES + 1 (a single duration to 1e6): an absurd length_scale cannot
 // overflow `cum`, and the host rejects frames > MAX_FRAMES before sizing stage B from it.
-static constexpr int MAX_FRAMES = 60000;      // per-utterance activations stay below the 2 GiB descriptor range
-struct DurP {
-  const float* z0; long z_bs; float m0, es0, length_scale;
-  const int* lens; int* dur; int* cum; int d_bs; int* frames; float* logw_out;
-  int* frames_host; int* frames_clamped; int frame_cap;
-};
 __global__ __launch_bounds__(256) void duration_kernel(DurP p) {
   PE_KTRACE(13);
   __shared__ long long part[256];
@@ -96,7 +91,6 @@ __device__ __forceinline__ void randn4(long q, const unsigned long long* state, 
 // written to -- so for a given (seed, run counter) the noise of frame f of channel c of utterance b does not depend on
 // workspace capacities, shape buckets or whether the frame count was speculated. One thread = one Philox block = four
 // consecutive columns of one row; `row0` = first logical row (test hook: any window of the stream).
-static constexpr int RNG_PITCH = 65536;       // >= MAX_FRAMES and >= the longest id sequence
 __global__ void randn_kernel(float* out, long rows, int cols, long stride, long row0, const unsigned long long* state,
                              int site) {
   PE_KTRACE(15);
@@ -108,25 +102,13 @@ __global__ void randn_kernel(float* out, long rows, int cols, long stride, long 
   randn4(((row0 + row) * RNG_PITCH + c4) >> 2, state, site, g);
   for (int k = 0; k < 4 && c4 + k < cols; ++k) out[row * stride + c4 + k] = g[k];
 }
-static inline unsigned randn_blocks(long rows, int cols) { return (unsigned)(rows * ((cols + 1023) / 1024)); }
 
 // ------------------------------------------------------------------------------------------------
 // Length regulator + prior sample (models.py:705-718, commons.py:116-129). The reference multiplies
 // by a one-hot path matrix; the same result is a gather: frame f takes id i with cum[i-1] <= f < cum[i].
 //   z_p[c][f] = m_p[c][i] + noise[c][f] * exp(logs_p[c][i]) * noise_scale
-struct RegP {
-  const float* stats; long s_bs; int s_cs;     // [B][2C][Ts]: m_p rows [0,C), logs_p rows [C,2C)
-  const int* cum; int d_bs;
-  const int* tlens; const int* frames;
-  const float* noise; long n_bs; int n_cs;     // [B][C][>=F] or null
-  float noise_scale;
-  float* out; long o_bs; int o_cs;
-  int C;
-  unsigned* absmax;                            // per-utterance peak accumulator of conv_post_kernel: zeroed here
-};
 // At batch 1 this launch is a latency chain, so: `cum` is copied to LDS once (the 7-step binary search then never
 // leaves the CU) and the 3 x 16 operands of a thread's channels are requested together through row descriptors.
-static constexpr int REG_MAXT = 4096;          // ids whose cumulative durations fit the LDS copy; longer: search in global memory
 __global__ __launch_bounds__(64) void regulate_kernel(RegP p) {
   PE_KTRACE(16);
   __shared__ int scum[REG_MAXT];

@@ -1,0 +1,56 @@
+// Host-side launchers of the kernels, one translation unit per kernel family (launch_conv.cpp, launch_front.cpp,
+// launch_tail.cpp) so that the library builds in parallel: engine.cpp sees only the parameter structs (params.h) and
+// these prototypes. A launcher picks the template instantiation for its runtime arguments and issues ONE launch on
+// `stream` (counted in pe::g_launches). `init()` of a family raises the dynamic-LDS limit of its kernels (160 KiB per
+// workgroup on gfx950) and must run once per process before the first launch.
+#pragma once
+#include "../pe_rt.h"
+#include "params.h"
+
+namespace pe {
+namespace launch {
+
+// ---- conv GEMM family (launch_conv.cpp)
+void init_conv();
+// tiled implicit GEMM: cfg = tile configuration id (engine.cpp CFG_*), halo = 64 | 128 columns of staging slack
+void conv_tile(int cfg, bool gate, int halo, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p);
+// split-K forms: nw = 4 | 8 | 12 waves
+void conv_splitk(bool gate, int nw, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p);
+void conv_splitk16(bool gate, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p);
+void conv_group(bool wide, dim3 grid, size_t smem, hipStream_t stream, const ConvG& g);
+void conv_group_sum(dim3 grid, size_t smem, hipStream_t stream, const ConvP& p);
+
+// ---- text encoder / duration predictor / flow glue (launch_front.cpp)
+void init_front();
+void embed(dim3 grid, hipStream_t stream, const int* ids, int ids_bs, const int* lens, const float* emb, int H, float scale,
+           float* out, long o_bs, int o_cs, unsigned long long* rng);
+void attention(int dk, dim3 grid, size_t smem, hipStream_t stream, const AttnP& p);
+void layer_norm(dim3 grid, hipStream_t stream, const LnP& p);
+void dds_layer(int nchunks, dim3 grid, size_t smem, hipStream_t stream, const DdsP& p);
+void colchain(dim3 grid, size_t smem, hipStream_t stream, const ColP& p);
+void lngemm(dim3 grid, size_t smem, hipStream_t stream, const LnGemmP& p);
+void cf_pre(dim3 grid, hipStream_t stream, const float* z0, long z_bs, const float* w, const float* bias, const float* xg,
+            long g_bs, int g_cs, float* out, long o_bs, int o_cs, const int* lens, int H);
+void spline_inverse(dim3 grid, hipStream_t stream, const float* hproj, long h_bs, int h_cs, float* z1, long z_bs,
+                    const int* lens, float inv_sqrt_h);
+void scale(dim3 grid, hipStream_t stream, const float* in, float* out, long n, float s);
+void duration(dim3 grid, hipStream_t stream, const DurP& p);
+void randn(hipStream_t stream, float* out, long rows, int cols, long stride, long row0, const unsigned long long* state,
+           int site);
+void regulate(dim3 grid, hipStream_t stream, const RegP& p);
+void cond(dim3 grid, hipStream_t stream, const float* emb_g, int gin, const int* sids, const float* w, const float* bias,
+          int rows, float* out, int o_bs);
+
+// ---- vocoder stage kernels and the generator tail (launch_tail.cpp)
+void init_tail();
+void mrf(int cp, int ou, dim3 grid, hipStream_t stream, const MrfP& p);
+void mrf_sum(dim3 grid, hipStream_t stream, const float* r0, const float* r1, const float* r2, float* out, long bs, int cs,
+             const int* lens, int len_mul, float scale);
+void conv_post(dim3 grid, hipStream_t stream, const float* x, long x_bs, int x_cs, const float* w, int Cin, float slope,
+               const int* lens, int len_mul, float* audio, long a_bs, unsigned* absmax);
+void pcm16(dim3 grid, hipStream_t stream, const float* audio, long a_bs, const unsigned* absmax, const int* lens,
+           int len_mul, short* pcm, long p_bs, short* host);
+void window_copy(dim3 grid, hipStream_t stream, const float* z, int zs, const int* win, float* out, int ws, int C);
+
+}  // namespace launch
+}  // namespace pe

@@ -1,0 +1,83 @@
+// Launchers of the conv GEMM kernels (conv_mfma.h, conv_splitk.h): one translation unit of the library build.
+#include "launch.h"
+
+#include "conv_mfma.h"
+#include "conv_splitk.h"
+
+namespace pe {
+namespace launch {
+
+void init_conv() {
+#ifndef PE_EMU
+  const int lim = 160 * 1024;       // > 64 KiB of dynamic LDS needs the attribute (gfx950: 160 KiB per workgroup)
+#define PE_K2(WM, WN, MT, NT, KS, G) (const void*)conv_mfma_kernel<WM, WN, MT, NT, KS, G, 64>, (const void*)conv_mfma_kernel<WM, WN, MT, NT, KS, G, 128>
+  const void* ks[] = {PE_K2(2, 2, 2, 2, 8, false), PE_K2(1, 4, 2, 1, 16, false), PE_K2(1, 4, 1, 1, 16, false),
+                      PE_K2(2, 2, 1, 1, 16, false), PE_K2(2, 2, 2, 1, 16, false), PE_K2(1, 4, 1, 2, 16, false),
+                      PE_K2(1, 4, 2, 2, 8, false), PE_K2(2, 2, 2, 2, 8, true), PE_K2(1, 4, 2, 1, 16, true),
+                      PE_K2(2, 2, 2, 1, 16, true),
+                      (const void*)conv_splitk_kernel<2, true, 8, 3>, (const void*)conv_splitk_kernel<2, true, 4, 3>,
+                      (const void*)conv_splitk_kernel<1, false, 8, 4>, (const void*)conv_splitk_kernel<1, false, 4, 4>,
+                      (const void*)conv_splitk_kernel<2, true, 12, 2>, (const void*)conv_splitk_kernel<1, false, 12, 4>,
+                      (const void*)conv_splitk16_kernel<true, 12, 2>, (const void*)conv_splitk16_kernel<false, 8, 4>,
+                      (const void*)conv_splitk_group_kernel<4, 2, 64>, (const void*)conv_splitk_group_kernel<4, 2, 128>,
+                      (const void*)conv_splitk_sum_kernel<4, 2>};
+#undef PE_K2
+  for (const void* k : ks) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
+#endif
+}
+
+// tile configurations {WM, WN, MT, NT, KS}: ids as engine.cpp's CFG_* (A, B, C, S, G, C2, B2)
+void conv_tile(int cfg, bool gate, int halo, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p) {
+#define PE_CONV_LAUNCH(WM, WN, MT, NT, KS, G)                                                                  \
+  do {                                                                                                         \
+    if (halo == 64) PE_LAUNCH((conv_mfma_kernel<WM, WN, MT, NT, KS, G, 64>), grid, dim3(256), smem, stream, p); \
+    else PE_LAUNCH((conv_mfma_kernel<WM, WN, MT, NT, KS, G, 128>), grid, dim3(256), smem, stream, p);          \
+  } while (0)
+  if (gate) {
+    switch (cfg) {
+      case 0: PE_CONV_LAUNCH(2, 2, 2, 2, 8, true); break;
+      case 1: PE_CONV_LAUNCH(1, 4, 2, 1, 16, true); break;
+      default: PE_CONV_LAUNCH(2, 2, 2, 1, 16, true); break;
+    }
+  } else {
+    switch (cfg) {
+      case 0: PE_CONV_LAUNCH(2, 2, 2, 2, 8, false); break;
+      case 1: PE_CONV_LAUNCH(1, 4, 2, 1, 16, false); break;
+      case 2: PE_CONV_LAUNCH(1, 4, 1, 1, 16, false); break;
+      case 3: PE_CONV_LAUNCH(2, 2, 1, 1, 16, false); break;
+      case 5: PE_CONV_LAUNCH(1, 4, 1, 2, 16, false); break;
+      case 6: PE_CONV_LAUNCH(1, 4, 2, 2, 8, false); break;
+      default: PE_CONV_LAUNCH(2, 2, 2, 1, 16, false); break;
+    }
+  }
+#undef PE_CONV_LAUNCH
+}
+
+void conv_splitk(bool gate, int nw, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p) {
+  if (gate) {
+    if (nw == 12) PE_LAUNCH((conv_splitk_kernel<2, true, 12, 2>), grid, dim3(768), smem, stream, p);
+    else if (nw == 8) PE_LAUNCH((conv_splitk_kernel<2, true, 8, 3>), grid, dim3(512), smem, stream, p);
+    else PE_LAUNCH((conv_splitk_kernel<2, true, 4, 3>), grid, dim3(256), smem, stream, p);
+  } else {
+    if (nw == 12) PE_LAUNCH((conv_splitk_kernel<1, false, 12, 4>), grid, dim3(768), smem, stream, p);
+    else if (nw == 8) PE_LAUNCH((conv_splitk_kernel<1, false, 8, 4>), grid, dim3(512), smem, stream, p);
+    else PE_LAUNCH((conv_splitk_kernel<1, false, 4, 4>), grid, dim3(256), smem, stream, p);
+  }
+}
+
+void conv_splitk16(bool gate, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p) {
+  if (gate) PE_LAUNCH((conv_splitk16_kernel<true, 12, 2>), grid, dim3(64 * 12), smem, stream, p);
+  else PE_LAUNCH((conv_splitk16_kernel<false, 8, 4>), grid, dim3(64 * 8), smem, stream, p);
+}
+
+void conv_group(bool wide, dim3 grid, size_t smem, hipStream_t stream, const ConvG& g) {
+  if (wide) PE_LAUNCH((conv_splitk_group_kernel<4, 2, 128>), grid, dim3(256), smem, stream, g);
+  else PE_LAUNCH((conv_splitk_group_kernel<4, 2, 64>), grid, dim3(256), smem, stream, g);
+}
+
+void conv_group_sum(dim3 grid, size_t smem, hipStream_t stream, const ConvP& p) {
+  PE_LAUNCH((conv_splitk_sum_kernel<4, 2>), grid, dim3(256), smem, stream, p);
+}
+
+}  // namespace launch
+}  // namespace pe

@@ -3,6 +3,7 @@
 // /root/reference/src/python/piper_train/vits/.)
 #pragma once
 #include "../pe_rt.h"
+#include "params.h"
 
 namespace pe {
 
@@ -10,14 +11,6 @@ namespace pe {
 // One workgroup = 8 time columns x all channels; thread (col = tid&7, rl = tid>>3) keeps channels
 // rl, rl+32, ... in registers (C <= 256), so the input is read once. (Batched calls and encoder widths other than
 // 192: small calls of the 192-channel voices fold the norms into colchain_kernel / lngemm_kernel.)
-struct LnP {
-  const float* in; long i_bs; int i_cs;
-  float* out; long o_bs; int o_cs;
-  const float* gamma; const float* beta;
-  const int* lens;
-  int C;
-};
-static constexpr int LN_COLS = 8, LN_NV = 8;
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
 

@@ -27,38 +27,14 @@
 // matrix pipe 61 % busy); this is generation 3 (70 %).
 #pragma once
 #include "../pe_rt.h"
+#include "params.h"
 #include "conv_common.h"
 
 namespace pe {
 
 template <int V> struct pe_int { static constexpr int value = V; };
 
-enum { MRF_RES = 1, MRF_KEEP = 2, MRF_FINAL = 4, MRF_INIT = 8, MRF_RESTAGE = 16 };
 
-struct MrfPhase {        // one conv of one resblock chain; 12 ints wide (the kernel copies the table to LDS as ints)
-  const float* bias;
-  int ntaps, dil;
-  int e;                 // columns of halo its OUTPUT still needs (0 for the last conv of a resblock)
-  int src, dst;          // LDS activation buffers (0 = stage input window, 1 = chain buffer); dst < 0: none
-  int flags;             // RES: + running x (registers); KEEP: result becomes the running x; FINAL: add to the MRF sum;
-                         // INIT: running x = stage input (first conv of a resblock); RESTAGE: reload buffer 0 first
-  int pad[4];
-};
-static_assert(sizeof(MrfPhase) == 48, "MrfPhase is read as 12 ints");
-struct MrfP {
-  const float* x; long x_bs; int x_cs;
-  float* out; long o_bs; int o_cs;
-  const int* lens; int len_mul;
-  const MrfPhase* phases; int nphases;
-  const float* wstream; int wfloats;
-  int C;                 // real channels (<= CP)
-  int N;                 // output columns per workgroup (16 * NCG * OU)
-  int wcols;             // window columns in use: hxa + N + the stage's halo (<= the row stride)
-  int hxa;               // window column of the first output column (halo rounded up to 16)
-  int cu_lo, cu_hi;      // 16-column units any phase needs: [cu_lo, cu_hi)
-  int nleft, nhalo;      // halo units left of the output columns / in total
-  float slope, alpha;
-};
 
 // element (vidx + sidx) .. + 3: vidx per lane, sidx wave-uniform (SGPR offset)
 #ifdef PE_EMU
@@ -87,11 +63,6 @@ __device__ __forceinline__ void mrf_interleave() {
   }
 }
 
-static constexpr int MRF_NW = 8, MRF_PAD = 128, MRF_MAXPH = 24;
-static constexpr int mrf_ws(int cp) { return cp == 32 ? 528 : 304; }
-static constexpr size_t mrf_smem_bytes(int cp) {
-  return ((size_t)2 * MRF_PAD + (size_t)2 * cp * mrf_ws(cp) + MRF_MAXPH * 12) * sizeof(float);
-}
 
 template <int CP, int OU, int HU>
 __global__ __launch_bounds__(64 * MRF_NW) void mrf_kernel(MrfP p) {

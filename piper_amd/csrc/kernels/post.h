@@ -3,6 +3,7 @@
 // /root/reference/src/python/piper_train/vits/.)
 #pragma once
 #include "../pe_rt.h"
+#include "params.h"
 
 namespace pe {
 
@@ -15,7 +16,6 @@ namespace pe {
 // check; neighbouring threads' overlap is served by L1). The weights are wave-uniform scalars. The channel-group
 // partials meet in LDS and are summed in a fixed order; one peak atomic per workgroup. (A first version walked all channels in one thread: 8 dependent memory round
 // trips and 104 workgroups for a 4.8 s utterance, 22.9 us; profiles/r02_notes.md.)
-static constexpr int POST_K = 7, POST_OPT = 4, POST_CU = 8, POST_CG = 4, POST_SPB = 64 * POST_OPT;
 __global__ __launch_bounds__(256) void conv_post_kernel(const float* x, long x_bs, int x_cs, const float* __restrict__ w,
                                                         int Cin, float slope, const int* lens,
                                                         int len_mul, float* audio, long a_bs,
@@ -117,25 +117,6 @@ __global__ void mrf_sum_kernel(const float* r0, const float* r1, const float* r2
   float v = r0[i] + r1[i];
   if (r2) v += r2[i];
   out[i] = v * scale;
-}
-
-__global__ void scale_kernel(const float* in, float* out, long n, float s) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) out[i] = in[i] * s;
-}
-
-// Speaker conditioning (models.py:692-696 emb_g; :66-68 dp.cond; modules.py:188-199 WN.cond_layer;
-// models.py:349-351 dec.cond): g is a length-1 sequence, so every 1x1 cond conv reduces to a
-// per-utterance bias vector  out[b][r] = W[r][:] . emb_g[sid_b] + bias[r].
-__global__ void cond_kernel(const float* emb_g, int gin, const int* sids, const float* w, const float* bias,
-                            int rows, float* out, int o_bs) {
-  const int b = blockIdx.y;
-  const int r = blockIdx.x * blockDim.x + threadIdx.x;
-  if (r >= rows) return;
-  const float* g = emb_g + (long)sids[b] * gin;
-  float s = bias ? bias[r] : 0.f;
-  for (int i = 0; i < gin; ++i) s = fmaf(w[(long)r * gin + i], g[i], s);
-  out[(long)b * o_bs + r] = s;
 }
 
 }  // namespace pe

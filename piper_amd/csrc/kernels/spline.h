@@ -3,6 +3,7 @@
 // /root/reference/src/python/piper_train/vits/.)
 #pragma once
 #include "../pe_rt.h"
+#include "params.h"
 
 namespace pe {
 
@@ -23,7 +24,6 @@ __global__ void cf_pre_kernel(const float* z0, long z_bs, const float* w, const 
 // Inverse piecewise rational-quadratic spline with linear tails, 10 bins, bound 5
 // (transforms.py:50-98 unconstrained_rational_quadratic_spline(inverse=True) over :101-191;
 // the per-position parameters are ConvFlow.proj's 29 outputs, modules.py:508-517): one element.
-static constexpr int SPL_NB = 10;
 // The cheap, order-sensitive tail: from the un-normalised softmax terms ew / eh (= exp(u - max u)) and the derivatives dv
 // to the transformed value. Kept separate so that the ~40 transcendentals in front of it can be spread over lanes
 // (dds_layer16_kernel) while the sums keep the reference's sequential order.
