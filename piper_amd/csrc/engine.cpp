@@ -68,7 +68,27 @@ float* Engine::dev_tensor(const WeightSet& ws, const std::string& name) {
 size_t Engine::arena_bound(const WeightSet& ws) {
   size_t n = 0;
   for (auto& kv : ws.t) n += (size_t)kv.second.numel() + 64;
-  return (n * 7 / 2 + (4u << 20)) * sizeof(float);
+  // matrix mode bf16x3: the flow / generator conv weights once more as split bf16 fragments (same size as the f32 packing)
+  return (n * (env_bf3() ? 10 : 7) / 2 + (4u << 20)) * sizeof(float);
+}
+bool Engine::env_bf3() {
+  const char* t = getenv("PIPER_HIP_MATRIX");
+  if (!t || !t[0] || !strcmp(t, "f32")) return false;
+  if (!strcmp(t, "bf16x3")) return true;
+  throw std::runtime_error("PIPER_HIP_MATRIX: expected f32 or bf16x3");
+}
+
+static inline uint16_t bf16_rne(float v) {
+  uint32_t u;
+  memcpy(&u, &v, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+static inline float bf16_to_f32(uint16_t h) {
+  const uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
 }
 
 // Packs a dense [rows][Cin][ntaps] matrix into the A-operand order of conv_mfma_kernel:
@@ -141,6 +161,37 @@ PackedConv Engine::pack_matrix(const std::vector<float>& W, int rows, int Cin, i
                       W[((size_t)row * Cin + ci) * ntaps + tap];
               }
     pc.wp16 = dev_alloc(nq, skeleton_ ? nullptr : Q.data());
+  }
+  if (pack_bf3_now_) {
+    // conv_bf3_kernel (kernels/conv_bf3.h): every weight as hi = bf16(w), lo = bf16(w - hi), in the A-operand order of
+    // v_mfma_f32_32x32x16_bf16: [m tile][chunk][tap][part hi|lo][k-step][lane][8], lane -> row = lane & 31, input channel
+    // chunk*32 + 8*(2*kstep + (lane >> 5)) + e. One (tile, chunk, tap) step = 1024 floats, like the f32 packing.
+    std::vector<uint16_t> R(skeleton_ ? 0 : np * 2, 0);
+    for (int mt = 0; mt < (skeleton_ ? 0 : pc.mtiles); ++mt)
+      for (int c = 0; c < pc.nchunks; ++c)
+        for (int tap = 0; tap < ntaps; ++tap) {
+          const size_t step = (((size_t)mt * pc.nchunks + c) * ntaps + tap) * 2048;      // in bf16 elements
+          for (int ks = 0; ks < 2; ++ks)
+            for (int lane = 0; lane < 64; ++lane) {
+              int r = lane & 31, row;
+              if (gate) {
+                int q = mt >> 1, ch = q * 32 + r;
+                row = (ch < split) ? ((mt & 1) ? split + ch : ch) : -1;
+              } else {
+                row = mt * 32 + r;
+                if (row >= rows) row = -1;
+              }
+              for (int e = 0; e < 8; ++e) {
+                const int ci = c * KC + 8 * (2 * ks + (lane >> 5)) + e;
+                if (row < 0 || ci >= Cin) continue;
+                const float v = W[((size_t)row * Cin + ci) * ntaps + tap];
+                const uint16_t hi = bf16_rne(v), lo = bf16_rne(v - bf16_to_f32(hi));
+                R[step + ((size_t)(0 * 2 + ks) * 64 + lane) * 8 + e] = hi;
+                R[step + ((size_t)(1 * 2 + ks) * 64 + lane) * 8 + e] = lo;
+              }
+            }
+        }
+    pc.wpb = dev_alloc(np, skeleton_ ? nullptr : reinterpret_cast<const float*>(R.data()));
   }
   pc.bias = bias ? dev_alloc((size_t)nbias, skeleton_ ? nullptr : bias->data()) : nullptr;
   pc.macs_per_col = (double)rows * Cin * ntaps;
@@ -296,6 +347,8 @@ void Engine::init(const WeightSet& ws) {
   if (const char* t = getenv("PIPER_HIP_MRF")) mrf_mode_ = atoi(t);       // A/B knob: 0 = conv-by-conv MRF stages, 2 = always fused
   if (const char* t = getenv("PIPER_HIP_MRF_MAXF")) mrf_rb1_max_frames_ = atol(t);
   if (const char* t = getenv("PIPER_HIP_MRF_OU")) mrf_ou_ = atoi(t);
+  matrix_bf3_ = env_bf3();
+  if (const char* t = getenv("PIPER_HIP_BF3_MINF")) bf3_min_frames_ = atol(t);
   memcpy(arch_, ws.arch, sizeof(arch_));
   PE_HIP(hipSetDevice(device_));
   PE_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
@@ -372,6 +425,7 @@ void Engine::init(const WeightSet& ws) {
   }
 
   // ---- coupling flow, execution order = reversed module order, Flip folded into weights
+  pack_bf3_now_ = matrix_bf3_;           // from here on (flow + generator) the convs are also packed for conv_bf3_kernel
   {
     const int nf = arch_[A_FLOWN], half = C_ / 2, wnl = arch_[A_WNLAYERS], wnk = arch_[A_WNK];
     int flips = 0;
@@ -464,6 +518,7 @@ void Engine::init(const WeightSet& ws) {
       throw std::runtime_error("dec.conv_post shape mismatch");
   }
 
+  pack_bf3_now_ = false;
   // ---- speaker conditioning
   if (nspk_ > 1) {
     if (!gin_) throw std::runtime_error("multi-speaker voice without gin_channels");
@@ -502,6 +557,7 @@ void Engine::init(const WeightSet& ws) {
     halo_frames_ = (int)(r + 3);
   }
   launch::init_conv();
+  launch::init_bf3();
   launch::init_front();
   launch::init_tail();
   static const char* rows[] = {"text_encoder", "duration_predictor", "regulate+flow", "hifigan", "post+pcm"};
@@ -784,7 +840,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
                   int bias2_bs) {
   ConvP p;
   p.x = x.p; p.x_bs = x.bs; p.x_cs = x.cs;
-  p.wp = pc.wp; p.wp16 = pc.wp16; p.bias = pc.bias;
+  p.wp = pc.wp; p.wp16 = pc.wp16; p.wpb = pc.wpb; p.bias = pc.bias;
   p.bias2 = bias2; p.bias2_bs = bias2_bs;
   p.out = out.p; p.o_bs = out.bs; p.o_cs = out.cs;
   p.res = res.p; p.r_bs = res.bs; p.r_cs = res.cs;
@@ -869,6 +925,29 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
       return;
     }
     launch::conv_splitk(pc.gate, NW, grid, smem, ls_, p);
+    kend(kh);
+    return;
+  }
+  if (matrix_bf3_ && pc.wpb && p.xhalo <= 128) {
+    // matrix mode bf16x3: 128 x 128 / 64 x 128 / 32 x 256 tiles (two 32x32 MFMA tiles per wave at least: the bf16 pipe
+    // is fast enough that operand traffic per MFMA matters more than workgroup count)
+    static const int BF3_BM[] = {128, 64, 32}, BF3_BN[] = {128, 128, 256};
+    static const char* bnames[] = {"2,2,2,2", "2,2,1,2", "1,4,1,2"};
+    const int bc = cfg == CFG_A ? 0 : (cfg == CFG_B ? 1 : 2);
+    if (pc.gate && bc == 2) throw std::runtime_error("internal: gate conv packed for 32-row blocks");
+    const int BM = BF3_BM[bc], BN = BF3_BN[bc];
+    const int HALO = p.xhalo <= 64 ? 64 : 128;
+    const int nbuf = pc.nchunks == 1 ? 1 : 2;
+    const size_t smem = (size_t)nbuf * 128 * ((BN + HALO + 63) / 64 * 64);       // [2 parts][4 k groups][XS] x 16 B
+    dim3 grid((ncols + BN - 1) / BN, pc.mtiles * 32 / BM, B_);
+    int kh = -1;
+    if (prof_level_ >= 2) {
+      char nm[96];
+      snprintf(nm, sizeof(nm), "conv_bf3_kernel<%s,%s,%d>", (pc.gate && bc == 1) ? "1,4,2,1" : bnames[bc],
+               pc.gate ? "true" : "false", HALO);
+      kh = kbegin(krow(std::string(nm)), kflops, kbytes);
+    }
+    launch::conv_bf3(bc, pc.gate, HALO, grid, smem, ls_, p);
     kend(kh);
     return;
   }
@@ -1583,7 +1662,8 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
       // batch size (B=1 -3 %, B=16 / 64 +4.5 % end to end over the conv-by-conv schedule); ResBlock1 stages (high) tie at
       // one utterance and lose at batch (its 64-channel stage: 86 vs ~110 TFLOP/s for the conv GEMM kernel on K = 64 * 11
       // convs), so those are fused for one or two utterances and on 32 channels only.
-      const bool fuse = mrf_mode_ && st.mrf_ok &&
+      // (matrix mode bf16x3: the fused kernel is f32; from a few utterances up the conv-by-conv schedule on the bf16 pipe is faster)
+      const bool fuse = mrf_mode_ && st.mrf_ok && !(matrix_bf3_ && mrf_mode_ != 2 && fsum >= (double)bf3_min_frames_) &&
                         (mrf_mode_ == 2 || !st.mrf_rb1 || (st.mrf_cp == 32 && fsum <= (double)mrf_rb1_max_frames_));
       if (fuse) {
         mrf(st, u, xs, lens, mult, Lmax);

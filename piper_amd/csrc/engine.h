@@ -16,6 +16,7 @@ namespace pe {
 struct PackedConv {
   float* wp = nullptr;      // device, packed for conv_mfma_kernel
   float* wp16 = nullptr;    // device, the same in 16x16x4 fragment order (conv_splitk16_kernel), long-K convs only
+  float* wpb = nullptr;     // device, bf16 hi/lo split fragments (conv_bf3_kernel), matrix mode bf16x3 only
   float* bias = nullptr;    // device or null
   int rows = 0;             // GEMM rows (real)
   int mtiles = 0;           // packed 32-row tiles (padded to the block tile)
@@ -268,6 +269,17 @@ class Engine {
   int mrf_mode_ = 1;                        // PIPER_HIP_MRF: 0 off (conv by conv), 1 by the measured policy, 2 wherever it applies
   long mrf_rb1_max_frames_ = 1100;          // ResBlock1 stages: batch frames up to which the fused kernel is used in mode 1
   int mrf_ou_ = 0;                          // PIPER_HIP_MRF_OU=1..3 forces the output units per wave (tests); 0 = cost model
+  // Opt-in matrix mode PIPER_HIP_MATRIX=bf16x3 (read at engine creation): the tiled conv GEMMs of the coupling flow and
+  // the generator run on the bf16 matrix pipe with split operands (kernels/conv_bf3.h; ~16 mantissa bits per operand,
+  // f32 accumulate, 3 MFMAs at 16x the f32 rate). The text encoder and the duration predictor stay f32 (the integer
+  // durations are those of the f32 path), and so does every latency-bound split-K launch. Default: off, all f32.
+  bool matrix_bf3_ = false, pack_bf3_now_ = false;
+  long bf3_min_frames_ = 1100;              // batch frames from which the <= 64-channel MRF stages run conv by conv on
+                                            // the bf16 pipe instead of the fused f32 stage kernel (PIPER_HIP_BF3_MINF)
+  static bool env_bf3();
+ public:
+  bool matrix_bf3() const { return matrix_bf3_; }
+ private:
   int splitk16_ = 2;                        // 16-column split-K: 0 off, 1 WN gate conv, 2 also long-K plain convs, 3 all (tests)
   int wide_splitk_ = 1;                     // 12-wave split-K workgroups for long-K launches
   long splitk_max_blocks_ = 96;             // launches with fewer tile-kernel workgroups use conv_splitk_kernel

@@ -20,6 +20,11 @@ void conv_splitk16(bool gate, dim3 grid, size_t smem, hipStream_t stream, const 
 void conv_group(bool wide, dim3 grid, size_t smem, hipStream_t stream, const ConvG& g);
 void conv_group_sum(dim3 grid, size_t smem, hipStream_t stream, const ConvP& p);
 
+// ---- split-bf16 tiled conv GEMM (launch_bf3.cpp; opt-in matrix mode PIPER_HIP_MATRIX=bf16x3)
+void init_bf3();
+// cfg: 0 = 128 x 128 tile, 1 = 64 x 128, 2 = 32 x 256 (engine.cpp BF3_BM / BF3_BN); gate needs cfg 0 or 1
+void conv_bf3(int cfg, bool gate, int halo, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p);
+
 // ---- text encoder / duration predictor / flow glue (launch_front.cpp)
 void init_front();
 void embed(dim3 grid, hipStream_t stream, const int* ids, int ids_bs, const int* lens, const float* emb, int H, float scale,

@@ -15,6 +15,7 @@ struct ConvP {
   const float* x; long x_bs; int x_cs;          // input  x[b][ci][t]
   const float* wp;                              // packed weights (engine.cpp: pack_conv)
   const float* wp16;                            // conv_splitk16_kernel: the same in 16x16x4 fragment order, or null
+  const float* wpb;                             // conv_bf3_kernel: bf16 hi/lo split fragments (engine.cpp pack_bf3), or null
   const float* bias;                            // per output channel or null
   const float* bias2; int bias2_bs;             // per-utterance extra bias (speaker cond) or null
   float* out; long o_bs; int o_cs;

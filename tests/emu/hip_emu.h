@@ -121,6 +121,42 @@ inline f32x4 emu_mfma_16x16x4(float a, float b, f32x4 c) {
   return c;
 }
 
+// v_mfma_f32_32x32x16_bf16: lane l gives A[i=l&31][k = 8*(l>>5) + e], B[k = 8*(l>>5) + e][j=l&31], e = 0..7 (four dwords
+// of two bf16 each); D as the f32 32x32 form. Products of bf16 values are exact in f32; f32 accumulation.
+typedef __bf16 emu_bf16x8 __attribute__((ext_vector_type(8)));
+inline f32x16 emu_mfma_bf16_32x32x16(emu_bf16x8 a, emu_bf16x8 b, f32x16 c) {
+  float* sa = emu::wave_f(1);
+  float* sb = emu::wave_f(2);
+  const int l = emu::lane(), j = l & 31;
+  float au[4], bu[4];
+  memcpy(au, &a, 16);
+  memcpy(bu, &b, 16);
+  for (int d = 0; d < 4; ++d) {
+    sa[l] = au[d];
+    sb[l] = bu[d];
+    emu::wave_sync();
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+      float acc = c[r];
+      for (int h = 0; h < 2; ++h) {
+        unsigned ua, ub;
+        memcpy(&ua, &sa[32 * h + i], 4);
+        memcpy(&ub, &sb[32 * h + j], 4);
+        for (int e = 0; e < 2; ++e) {
+          const unsigned xa = (ua >> (16 * e)) << 16, xb = (ub >> (16 * e)) << 16;
+          float fa, fb;
+          memcpy(&fa, &xa, 4);
+          memcpy(&fb, &xb, 4);
+          acc = fmaf(fa, fb, acc);
+        }
+      }
+      c[r] = acc;
+    }
+    emu::wave_sync();
+  }
+  return c;
+}
+
 // ---- atomics (single-threaded: plain read-modify-write) ------------------------------------------
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <class T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }

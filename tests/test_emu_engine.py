@@ -284,3 +284,40 @@ def test_engine_group_argument_errors_and_single_device(emu_lib):
     assert res.batch == 1 and res.sample_offsets[1] == r.pcm[0].size
     eng.close()
     grp.close()
+
+
+@pytest.mark.parametrize("preset,seed", [("tiny", 1234), ("tiny-high", 7), ("tiny-ms", 5)])
+def test_emulated_bf16x3_matrix_mode(emu_lib, monkeypatch, preset, seed):
+    """Opt-in matrix mode PIPER_HIP_MATRIX=bf16x3 (conv_bf3_kernel: flow + generator convs as three bf16 MFMAs on split
+    operands) with every conv forced through the tiled kernels: integer durations are those of the f32 path (the text
+    encoder / duration predictor stay f32), the waveform is within the north-star tolerance (1e-3 RMS on the PCM scale;
+    observed ~1e-5) but NOT bit-equal to f32."""
+    cfg = W.preset(preset)
+    w = W.synthetic_weights(cfg, seed)
+    Ts = (9, 4)
+    ids = [W.synthetic_phoneme_ids(T, i, id_max=cfg.n_vocab - 1) for i, T in enumerate(Ts)]
+    nw, nz = _noise(cfg, 2, max(Ts), 21)
+    sids = [1, 2] if cfg.n_speakers > 1 else None
+    scales = (0.6, 1.0, 0.7)
+    monkeypatch.setenv("PIPER_HIP_SPLITK_MAX", "0")          # tiled kernels for every launch
+    outs, durs = {}, {}
+    for mode in ("f32", "bf16x3"):
+        monkeypatch.setenv("PIPER_HIP_MATRIX", mode)
+        eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
+        r = eng.synthesize_batch(ids, scales, sids=sids, noise_w=nw, noise_z=nz)
+        outs[mode] = [a.copy() for a in r.audio]
+        durs[mode] = eng.durations().copy()
+        eng.close()
+    assert np.array_equal(durs["f32"], durs["bf16x3"])
+    differs = False
+    for i in range(2):
+        o = O.synthesize(w, cfg, ids[i], scales, nw[i], nz[i], sid=sids[i] if sids else None)
+        a = outs["bf16x3"][i]
+        assert a.shape == o["audio"].shape
+        assert np.sqrt(np.mean((a - o["audio"]) ** 2)) < 2e-4
+        assert np.max(np.abs(a - o["audio"])) < 2e-3
+        differs |= not np.array_equal(a, outs["f32"][i])
+    assert differs          # the mode really ran different arithmetic
+    with pytest.raises(EngineError):
+        monkeypatch.setenv("PIPER_HIP_MATRIX", "fp8")
+        Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
