@@ -34,6 +34,16 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32
+# opt-in matrix mode bf16x3 (kernels/conv_bf3.h): three v_mfma_f32_32x32x16_bf16 per f32-equivalent product, dense bf16
+# peak ~2500 TFLOP/s (same guide) -> 833 TFLOP/s of algorithmic (f32-equivalent) FLOPs for the kernels that use it
+BF16X3_PEAK_TFLOPS = 2500.0 / 3.0
+HBM_PEAK_GBPS = 8000.0              # same guide: HBM3E ~8 TB/s
+DTYPE_BF3 = ("bf16x3 (flow + generator conv GEMMs: f32 operands split into two bf16 terms, 3 bf16 MFMAs, f32 accumulate; "
+             "text encoder, duration predictor and all small-batch split-K launches f32)")
+
+
+def kernel_peak(name):
+    return BF16X3_PEAK_TFLOPS if name.startswith("conv_bf3_kernel") else FP32_MATRIX_PEAK_TFLOPS
 SCALES = (0.667, 1.0, 0.8)
 
 # BASELINE.json configs (1-based like SURVEY.md section 8d): preset, utterances per GPU, ids per utterance
@@ -54,6 +64,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel event passes (profiling runs)")
     ap.add_argument("--no-extra", action="store_true", help="headline only: skip the extra_configs legs")
+    ap.add_argument("--matrix", default="f32", choices=["f32", "bf16x3"],
+                    help="matrix mode of the engine (PIPER_HIP_MATRIX): f32 = the reference's arithmetic (default, the "
+                         "headline); bf16x3 = opt-in split-bf16 conv GEMMs for flow + generator")
     ap.add_argument("--stream-latency", action="store_true",
                     help="BASELINE configs[4]: p50 time to the first chunk of a chunked (45-frame) decode, then exit")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -226,6 +239,7 @@ def main():
         ctx.dist = dist
         dbg(f"process group up: backend {ctx.backend}, world {ctx.world}")
 
+    os.environ["PIPER_HIP_MATRIX"] = args.matrix          # read once, at engine creation
     cfg = W.preset(preset)
     # ---- voice: rank 0 builds / parses / packs it; the others lay out an identical weight arena from the blob header and
     # receive the PACKED weights by one device-to-device broadcast into that arena (RCCL over xGMI)
@@ -311,7 +325,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.matrix == "f32" else DTYPE_BF3,
             "data": "synthetic (seeded random-weight voice of the named architecture, synthetic phoneme ids)",
             "config": {"workload": workload_text(cfgno, preset, cfg, B, T),
                        "frames_per_step": int(frames.sum()), "samples_per_step": leg["samples_per_step"],
@@ -359,12 +373,12 @@ def extra_configs(ctx, eng_medium, cfg_medium, args):
     from piper_amd.engine import Engine
     legs = []
 
-    def batched(cfgno, eng, cfg, preset, B, T, steps, warmup):
+    def batched(cfgno, eng, cfg, preset, B, T, steps, warmup, dtype="f32"):
         l = timed_leg(ctx, eng, cfg, preset, B, T, steps, warmup, sync_ranks=False)
         dev_ms = device_only_ms(eng, l["id_lists"], l["noise_w"], max(2, min(5, steps)))
         e = {"config": {"workload": workload_text(cfgno, preset, cfg, B, T), "frames_per_step": int(l["frames"].sum()),
                         "samples_per_step": l["samples_per_step"], "kernel_launches_per_step": l["launches"]},
-             "metric": "audio samples/sec", "value": l["value"], "unit": "samples/s", "dtype": "f32",
+             "metric": "audio samples/sec", "value": l["value"], "unit": "samples/s", "dtype": dtype,
              "x_realtime": l["value"] / cfg.sample_rate, "ms_per_step": l["ms_per_step"], "steps": steps,
              "warmup": warmup, "device_pipeline_only_ms_per_step": dev_ms}
         if not args.no_roofline:
@@ -396,6 +410,24 @@ def extra_configs(ctx, eng_medium, cfg_medium, args):
     if "eng" in hi:
         guarded("configs[4]", lambda: stream_latency(hi["eng"], hi["cfg"], "high", 128, 100, 5, 0))
         hi["eng"].close()
+
+    # ---- the same two throughput configurations in the opt-in matrix mode bf16x3 (separately labelled dtype and peak;
+    # the headline and the legs above stay f32). Parity gate of the mode: tests/test_gpu_batched.py
+    # test_bf16x3_matrix_mode_matches_oracle (integer durations equal, int16 PCM within 1e-3 RMS of the oracle).
+    def bf3_leg(cfgno, preset, steps, warmup):
+        os.environ["PIPER_HIP_MATRIX"] = "bf16x3"
+        try:
+            c = W.preset(preset)
+            e = Engine(blob=W.pack_blob(c, W.synthetic_weights(c, 1234)), device=ctx.dev_index)
+        finally:
+            os.environ["PIPER_HIP_MATRIX"] = "f32"
+        try:
+            return batched(cfgno, e, c, preset, 64, 128, steps, warmup, dtype=DTYPE_BF3)
+        finally:
+            e.close()
+
+    guarded("configs[3] per-GPU share, matrix mode bf16x3", lambda: bf3_leg(4, "medium", 10, 3))
+    guarded("configs[2], matrix mode bf16x3", lambda: bf3_leg(3, "high", 5, 2))
     return legs
 
 
@@ -473,9 +505,10 @@ def roofline(eng, preset, B, T, id_lists, noise_w, steps, ms_per_step, dev_ms):
         tf = r["flops"] / r["launches"] / (us * 1e-6) / 1e12
         kernels[r["name"]] = {"ms_per_step": us * 1e-3 * r["launches"] / nprof, "launches_per_step": r["launches"] / nprof,
                               "avg_launch_us": us, "avg_launch_us_event_pair": raw_us, "tflops": tf,
-                              "frac_of_mfma_peak": tf / FP32_MATRIX_PEAK_TFLOPS,
+                              "frac_of_mfma_peak": tf / kernel_peak(r["name"]), "peak": kernel_peak(r["name"]),
                               "algorithmic_gflop_per_launch": r["flops"] / r["launches"] / 1e9,
-                              "algorithmic_bytes_per_launch": (r["bytes"] / r["launches"] if r.get("bytes") else None)}
+                              "algorithmic_bytes_per_launch": (r["bytes"] / r["launches"] if r.get("bytes") else None),
+                              "algorithmic_gb_per_s": (r["bytes"] / r["launches"] / (us * 1e-6) / 1e9 if r.get("bytes") else None)}
     ksum = sum(k["ms_per_step"] for k in kernels.values())
     top = max(kernels, key=lambda n: kernels[n]["ms_per_step"])
     k = kernels[top]
@@ -492,16 +525,23 @@ def roofline(eng, preset, B, T, id_lists, noise_w, steps, ms_per_step, dev_ms):
     families = {f: {"share_of_profiled_kernel_time": d["ms"] / ksum, "launches_per_step": d["launches"],
                     "tflops": d["flops"] / (d["ms"] * 1e-3) / 1e12 if d["ms"] > 0 else 0.0} for f, d in fam.items()}
     step_tf = step_flops / (ms_per_step * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": top,
+    # the bound of the dominant kernel = the roof it sits closer to (algorithmic bytes over HBM peak vs algorithmic FLOPs
+    # over the matrix peak of its instruction)
+    hbm_frac = (k["algorithmic_gb_per_s"] or 0.0) / HBM_PEAK_GBPS
+    mfma_frac = k["tflops"] / kernel_peak(top)
+    hbm_bound = hbm_frac > mfma_frac
+    return {"bound": "hbm" if hbm_bound else "mfma", "kernel": top,
             "share_of_profiled_kernel_time": k["ms_per_step"] / ksum if ksum else 0.0,
-            "achieved": k["tflops"], "peak": FP32_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": k["tflops"] / FP32_MATRIX_PEAK_TFLOPS, "traffic": traffic,
+            "achieved": k["algorithmic_gb_per_s"] if hbm_bound else k["tflops"],
+            "peak": HBM_PEAK_GBPS if hbm_bound else kernel_peak(top), "unit": "GB/s" if hbm_bound else "TFLOP/s",
+            "frac": hbm_frac if hbm_bound else mfma_frac, "frac_mfma": mfma_frac, "frac_hbm": hbm_frac, "traffic": traffic,
             "avg_launch_us": k["avg_launch_us"], "launches_per_step": k["launches_per_step"],
             "event_pair_overhead_us": ov_us,
             "timing": "HIP event pairs on the engine's stream around every launch, minus the calibrated per-pair overhead "
                       "(sum of pairs - replayed pipeline time) / launches",
             "step": {"algorithmic_gflop": step_flops / 1e9, "achieved": step_tf, "frac": step_tf / FP32_MATRIX_PEAK_TFLOPS,
-                     "what": "all algorithmic FLOPs of one step over the timed ms_per_step"},
+                     "what": "all algorithmic FLOPs of one step over the timed ms_per_step, against the f32 matrix peak "
+                             "(157.3 TFLOP/s) in every matrix mode: > 1 is possible in mode bf16x3"},
             "families": families, "kernels": kernels, "stage_ms": stage_ms, "stage_tflops": stage_tf}
 
 

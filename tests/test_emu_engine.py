@@ -321,3 +321,4 @@ def test_emulated_bf16x3_matrix_mode(emu_lib, monkeypatch, preset, seed):
     with pytest.raises(EngineError):
         monkeypatch.setenv("PIPER_HIP_MATRIX", "fp8")
         Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
+
