@@ -347,6 +347,7 @@ void Engine::init(const WeightSet& ws) {
   if (const char* t = getenv("PIPER_HIP_MRF")) mrf_mode_ = atoi(t);       // A/B knob: 0 = conv-by-conv MRF stages, 2 = always fused
   if (const char* t = getenv("PIPER_HIP_MRF_MAXF")) mrf_rb1_max_frames_ = atol(t);
   if (const char* t = getenv("PIPER_HIP_MRF_OU")) mrf_ou_ = atoi(t);
+  if (const char* t = getenv("PIPER_HIP_MRF_TAIL")) mrf_tail_ = atoi(t) != 0;   // A/B knob, tests: conv_post inside the last mrf_kernel
   matrix_bf3_ = env_bf3();
   if (const char* t = getenv("PIPER_HIP_BF3_MINF")) bf3_min_frames_ = atol(t);
   memcpy(arch_, ws.arch, sizeof(arch_));
@@ -1071,13 +1072,14 @@ void Engine::build_mrf(UpStage& st) {
 // utterances: the launch is one or two rounds of workgroups over the 256 CUs, so the workgroup count should sit just under
 // a multiple of 256 and a workgroup should be short; batches: many rounds, so large N (less halo recompute, fewer
 // prologues) wins. Cost model: rounds x (MFMA columns of one workgroup incl. recompute + a fixed prologue / epilogue).
-void Engine::mrf(const UpStage& st, View x, View out, const int* lens, int len_mul, int Lmax) {
-  const int CP = st.mrf_cp, NCG = CP == 32 ? 8 : 4, HU = CP == 32 ? 1 : 2, WSC = mrf_ws(CP);
+void Engine::mrf(const UpStage& st, View x, View out, const int* lens, int len_mul, int Lmax, bool tail) {
+  const int CP = st.mrf_cp, NCG = CP == 32 ? 8 : 4, HU = CP == 32 ? 1 : 2;
+  const int OUMAX = CP == 32 ? 4 : 3;      // 32 channels: 4 units per wave (N = 512) fill the 160 KB of LDS
   const int hx = st.mrf_hx, hxa = rup(hx, 16);
   struct Geo { int ou, N, cu_lo, cu_hi, nleft, nhalo; };
   auto geo = [&](int ou, Geo& g) {
     g.ou = ou; g.N = 16 * NCG * ou;
-    if (hxa + g.N + hx > WSC) return false;
+    if (hxa + g.N + hx > mrf_ws(CP, ou)) return false;
     g.cu_lo = (hxa - hx) / 16; g.cu_hi = (hxa + g.N + hx + 15) / 16;
     g.nleft = hxa / 16 - g.cu_lo; g.nhalo = g.cu_hi - g.cu_lo - g.N / 16;
     return g.nhalo <= NCG * HU;
@@ -1085,19 +1087,24 @@ void Engine::mrf(const UpStage& st, View x, View out, const int* lens, int len_m
   Geo best{};
   double best_cost = 0;
   Geo forced;
-  const int force = (mrf_ou_ >= 1 && mrf_ou_ <= 3 && geo(mrf_ou_, forced)) ? mrf_ou_ : 0;     // (tests / A-B; ignored when it does not fit)
-  for (int ou = 1; ou <= 3; ++ou) {
+  const int force = (mrf_ou_ >= 1 && mrf_ou_ <= OUMAX && geo(mrf_ou_, forced)) ? mrf_ou_ : 0;     // (tests / A-B; ignored when it does not fit)
+  for (int ou = 1; ou <= OUMAX; ++ou) {
     Geo g;
     if ((force && ou != force) || !geo(ou, g)) continue;
     double wgs = 0;
-    for (int b = 0; b < B_; ++b) wgs += (double)(((long)frames_h_[b] * len_mul + g.N - 1) / g.N);
+    const int stride = tail ? g.N - (POST_K - 1) : g.N;
+    for (int b = 0; b < B_; ++b) wgs += (double)(((long)frames_h_[b] * len_mul + stride - 1) / stride);
     double work = 0, taps = 0;
     for (auto& P : st.mrf_ph) {
       const int lo = (hxa - P.e) / 16, hi = (hxa + g.N + P.e + 15) / 16;
       work += (double)(hi - lo) * 16 * P.ntaps;
       taps += P.ntaps;
     }
-    const double cost = std::ceil(wgs / 256.0) * (work + 16.0 * taps);      // prologue + epilogue ~ 16 columns' worth
+    double cost = std::ceil(wgs / 256.0) * (work + 16.0 * taps);      // prologue + epilogue ~ 16 columns' worth
+    // 4 units per wave run at the register limit (a few spilled VGPRs): measured 3-5 % slower per column than 3 units at
+    // batch (B=16: 1108 vs 1082 us, B=64: 4.29 vs 4.25 ms), but one round instead of two for a single utterance's last
+    // stage (B=1: 84.6 vs 93.4 us) -- profiles/r03_notes.md
+    if (ou == 4) cost *= 1.06;
     if (!best.ou || cost < best_cost) { best = g; best_cost = cost; }
   }
   if (!best.ou) throw std::runtime_error("internal: no mrf_kernel geometry for this stage");
@@ -1111,6 +1118,12 @@ void Engine::mrf(const UpStage& st, View x, View out, const int* lens, int len_m
   p.nleft = best.nleft; p.nhalo = best.nhalo;
   p.slope = 0.1f;                            // modules.py LRELU_SLOPE
   p.alpha = 1.0f / (float)st.rb.size();
+  p.stride = best.N; p.n0off = 0;
+  p.post_w = nullptr; p.audio = nullptr; p.a_bs = 0; p.absmax = nullptr; p.post_slope = 0.01f;
+  if (tail) {       // generator tail inside the stage kernel: windows overlap by the conv_post taps
+    p.stride = best.N - (POST_K - 1); p.n0off = (POST_K - 1) / 2;
+    p.post_w = post_w_; p.audio = audio_; p.a_bs = Ss_; p.absmax = absmax_;
+  }
   double kflops = 0, kbytes = 0;
   if (prof_level_ >= 2) {
     double cols = 0;
@@ -1120,8 +1133,12 @@ void Engine::mrf(const UpStage& st, View x, View out, const int* lens, int len_m
       for (auto& c : cv) macs += c.macs_per_col;
     kflops = 2.0 * macs * cols;
     kbytes = 8.0 * st.ch * cols + 4.0 * st.mrf_wfloats;      // one read of x, one write of the mean, the weights once
+    if (tail) {
+      kflops += 2.0 * cols * st.ch * POST_K;
+      kbytes = 4.0 * (st.ch + 1) * cols + 4.0 * st.mrf_wfloats;   // one read of x, one write of the waveform
+    }
   }
-  dim3 grid((Lmax + best.N - 1) / best.N, B_);
+  dim3 grid((Lmax + p.stride - 1) / p.stride, B_);
   char nm[64];
   snprintf(nm, sizeof(nm), "mrf_kernel<%d,%d,%d>", CP, best.ou, HU);
   const int kh = prof_level_ >= 2 ? kbegin(krow(std::string(nm)), kflops, kbytes) : -1;
@@ -1587,6 +1604,9 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
   const View none{nullptr, 0, 0};
   const float* cb_dec = nspk_ > 1 ? cond_ + cond_off_dec_ : nullptr;
   double fl = 0;
+  bool tail_done = false;      // conv_post + tanh + peak computed inside the last stage's mrf_kernel
+  // (zero_absmax marks the streaming window path; the whole-utterance path clears the peaks in regulate_kernel)
+  if (zero_absmax) PE_HIP(hipMemsetAsync(absmax_, 0, B * sizeof(unsigned), stream_));
   // ================= HiFiGAN generator (models.py:348-368)
   prof_begin();
   fl = 0;
@@ -1666,9 +1686,15 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
       const bool fuse = mrf_mode_ && st.mrf_ok && !(matrix_bf3_ && mrf_mode_ != 2 && fsum >= (double)bf3_min_frames_) &&
                         (mrf_mode_ == 2 || !st.mrf_rb1 || (st.mrf_cp == 32 && fsum <= (double)mrf_rb1_max_frames_));
       if (fuse) {
-        mrf(st, u, xs, lens, mult, Lmax);
+        // the last stage also runs the generator tail (conv_post, tanh, peak) on its MRF mean while it is still on chip
+        const bool tail = mrf_tail_ && &st == &ups_.back() && st.mrf_cp == 32 && st.ch == post_cin_ && mult == hop_;
+        mrf(st, u, xs, lens, mult, Lmax, tail);
         for (auto& cv : st.rb)
           for (auto& c : cv) fl += 2.0 * fsum * mult * c.macs_per_col;
+        if (tail) {
+          tail_done = true;
+          fl += 2.0 * fsum * hop_ * post_cin_ * POST_K;
+        }
       } else if (grp) {
         // step d of every resblock in one grouped launch; each resblock keeps its own buffers, one pass sums them
         auto SV = [&](int k) { return View{side_[k], (long)st.ch * Ls, (int)Ls}; };
@@ -1715,13 +1741,13 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
 
     // ================= conv_post + tanh + peak, int16 (models.py:364-366; piper.cpp:410-431)
     prof_begin();
-    if (zero_absmax) PE_HIP(hipMemsetAsync(absmax_, 0, B * sizeof(unsigned), stream_));
     const int K = 7, Lmax = Fmax * hop_;
-    PE_LAUNCH_K("conv_post_kernel", launch::conv_post(dim3((Lmax + POST_SPB - 1) / POST_SPB, B), stream_, cur.p, cur.bs, cur.cs, post_w_, post_cin_, 0.01f, lens, hop_, audio_, Ss_, absmax_));
-    // (zero_absmax marks the streaming window path, which delivers per chunk from the device buffer)
+    if (!tail_done)
+      PE_LAUNCH_K("conv_post_kernel", launch::conv_post(dim3((Lmax + POST_SPB - 1) / POST_SPB, B), stream_, cur.p, cur.bs, cur.cs, post_w_, post_cin_, 0.01f, lens, hop_, audio_, Ss_, absmax_));
+    // (the streaming window path delivers per chunk from the device buffer)
     int16_t* zc = (pcm_zc_ && !zero_absmax && h_pcm_zc_cap_ >= (size_t)B * (size_t)Ss_) ? h_pcm_zc_ : nullptr;
     PE_LAUNCH_K("pcm16_kernel", launch::pcm16(dim3((Lmax + 255) / 256, B), stream_, audio_, Ss_, absmax_, lens, hop_, pcm_, Ss_, zc));
-    prof_end(4, 2.0 * fsum * hop_ * post_cin_ * K);
+    prof_end(4, tail_done ? 0.0 : 2.0 * fsum * hop_ * post_cin_ * K);
   }
 }
 

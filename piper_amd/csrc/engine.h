@@ -265,10 +265,11 @@ class Engine {
     bool mrf_ok = false, mrf_rb1 = false;
   };
   void build_mrf(UpStage& st);
-  void mrf(const UpStage& st, View x, View out, const int* lens, int len_mul, int Lmax);
+  void mrf(const UpStage& st, View x, View out, const int* lens, int len_mul, int Lmax, bool tail = false);
   int mrf_mode_ = 1;                        // PIPER_HIP_MRF: 0 off (conv by conv), 1 by the measured policy, 2 wherever it applies
   long mrf_rb1_max_frames_ = 1100;          // ResBlock1 stages: batch frames up to which the fused kernel is used in mode 1
-  int mrf_ou_ = 0;                          // PIPER_HIP_MRF_OU=1..3 forces the output units per wave (tests); 0 = cost model
+  bool mrf_tail_ = true;                    // PIPER_HIP_MRF_TAIL=0: conv_post_kernel as its own launch behind a fused last stage
+  int mrf_ou_ = 0;                          // PIPER_HIP_MRF_OU=1..4 forces the output units per wave (tests); 0 = cost model
   // Opt-in matrix mode PIPER_HIP_MATRIX=bf16x3 (read at engine creation): the tiled conv GEMMs of the coupling flow and
   // the generator run on the bf16 matrix pipe with split operands (kernels/conv_bf3.h; ~16 mantissa bits per operand,
   // f32 accumulate, 3 MFMAs at 16x the f32 rate). The text encoder and the duration predictor stay f32 (the integer

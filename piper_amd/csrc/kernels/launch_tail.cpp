@@ -10,7 +10,7 @@ namespace launch {
 void init_tail() {
 #ifndef PE_EMU
   const int lim = 160 * 1024;
-  const void* ks[] = {(const void*)mrf_kernel<32, 1, 1>, (const void*)mrf_kernel<32, 2, 1>, (const void*)mrf_kernel<32, 3, 1>,
+  const void* ks[] = {(const void*)mrf_kernel<32, 1, 1>, (const void*)mrf_kernel<32, 2, 1>, (const void*)mrf_kernel<32, 3, 1>, (const void*)mrf_kernel<32, 4, 1>,
                       (const void*)mrf_kernel<64, 1, 2>, (const void*)mrf_kernel<64, 2, 2>, (const void*)mrf_kernel<64, 3, 2>};
   for (const void* k : ks) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
 #endif
@@ -19,10 +19,10 @@ void init_tail() {
 // cp = padded channels (32: one row group of 8 column groups, 1 halo unit per wave; 64: two row groups of 4 column
 // groups, 2 halo units per wave); ou = output units per wave (N = 16 * column groups * ou)
 void mrf(int cp, int ou, dim3 grid, hipStream_t stream, const MrfP& p) {
-  const size_t smem = mrf_smem_bytes(cp);
+  const size_t smem = mrf_smem_bytes(cp, ou);
 #define PE_MRF(CP_, OU_, HU_) PE_LAUNCH((mrf_kernel<CP_, OU_, HU_>), grid, dim3(64 * MRF_NW), smem, stream, p)
   if (cp == 32) {
-    if (ou == 1) PE_MRF(32, 1, 1); else if (ou == 2) PE_MRF(32, 2, 1); else PE_MRF(32, 3, 1);
+    if (ou == 1) PE_MRF(32, 1, 1); else if (ou == 2) PE_MRF(32, 2, 1); else if (ou == 3) PE_MRF(32, 3, 1); else PE_MRF(32, 4, 1);
   } else {
     if (ou == 1) PE_MRF(64, 1, 2); else if (ou == 2) PE_MRF(64, 2, 2); else PE_MRF(64, 3, 2);
   }

@@ -67,15 +67,15 @@ __device__ __forceinline__ void mrf_interleave() {
 template <int CP, int OU, int HU>
 __global__ __launch_bounds__(64 * MRF_NW) void mrf_kernel(MrfP p) {
   PE_KTRACE(20);
-  constexpr int NW = MRF_NW, WS = mrf_ws(CP), MS = CP / 16, MSW = 2, NRG = MS / MSW, NCG = NW / NRG, NT = 64 * NW;
+  constexpr int NW = MRF_NW, WS = mrf_ws(CP, OU), MS = CP / 16, MSW = 2, NRG = MS / MSW, NCG = NW / NRG, NT = 64 * NW;
   constexpr int UPW = OU + HU, NCH = CP / KC, STEPF = MS * 512;
   static_assert(MS % MSW == 0 && NW % NRG == 0, "waves split evenly over the row groups");
   static_assert(WS % 32 == 16, "row stride == 16 (mod 32): the two k rows of a half-wave hit disjoint banks");
   PE_DYN_SMEM(float, sm);
   const int b = blockIdx.y;
   const int L = p.lens[b] * p.len_mul;
-  const int n0 = blockIdx.x * p.N;
-  if (n0 >= L) return;
+  if (blockIdx.x * p.stride >= L) return;
+  const int n0 = blockIdx.x * p.stride - p.n0off;     // first column of the window's N output columns (fused tail: -3 + ...)
   // LDS: [pad][buffer 0: CP x WS][buffer 1][pad][phase table]. Reads of never-used columns may leave a buffer on the
   // left / right: they land in the pads / the neighbouring buffer.
   float* bufs = sm + MRF_PAD;
@@ -316,19 +316,91 @@ __global__ __launch_bounds__(64 * MRF_NW) void mrf_kernel(MrfP p) {
         }
       }
   }
-  // ---- MRF mean of the owned output units
-  float* ob = p.out + (long)b * p.o_bs;
+  if (p.post_w == nullptr) {
+    // ---- MRF mean of the owned output units
+    float* ob = p.out + (long)b * p.o_bs;
+#pragma unroll
+    for (int u = 0; u < OU; ++u) {
+      const int g = g0 + 16 * cu[u] + l15;
+      if (g >= L) continue;
+#pragma unroll
+      for (int m = 0; m < MSW; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = (ms0 + m) * 16 + 4 * lq + r;
+          if (row < C) ob[(long)row * p.o_cs + g] = tot[m][u][r] * p.alpha;
+        }
+    }
+    return;
+  }
+  // ---- last stage with the generator tail fused (models.py:364-366: leaky_relu(0.01) -> conv_post (k = 7, one output
+  // channel, no bias) -> tanh; piper.cpp:410-418: the utterance's max |sample|): the MRF mean never leaves the chip. The
+  // windows of neighbouring workgroups overlap by POST_K - 1 columns (launch stride N - 6, first window at column -3), so
+  // every tap of the workgroup's N - 6 samples is one of its own N mean columns: no halo units, no exchange. Arithmetic
+  // and summation order are conv_post_kernel's (post.h): four channel groups of POST_CU channels, channel-major /
+  // tap-minor fmaf chains, partials summed in group order -- bit-identical to the separate launch.
+  __syncthreads();                       // every wave is done with the activation buffers
+  float* mb = bufs;                      // buffer 0 <- lrelu(mean, 0.01) on window columns [hxa, hxa + N)
+  float* part = bufs + bufsz;            // buffer 1 <- [POST_CG][N] partial sums
 #pragma unroll
   for (int u = 0; u < OU; ++u) {
-    const int g = g0 + 16 * cu[u] + l15;
-    if (g >= L) continue;
+    const int col = 16 * cu[u] + l15;
 #pragma unroll
     for (int m = 0; m < MSW; ++m)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = (ms0 + m) * 16 + 4 * lq + r;
-        if (row < C) ob[(long)row * p.o_cs + g] = tot[m][u][r] * p.alpha;
+      for (int r = 0; r < 4; ++r) mb[((ms0 + m) * 16 + 4 * lq + r) * WS + col] = pe_lrelu(tot[m][u][r] * p.alpha, p.post_slope);
+  }
+  __syncthreads();
+  static_assert(POST_CG * POST_CU == 32 && POST_OPT == 4 && POST_K == 7, "tail mapping: 4 channel groups x 128 threads x 4 samples");
+  const int nsamp = p.N - (POST_K - 1);  // samples of this workgroup: global n0 + 3 + j, j in [0, nsamp)
+  {
+    const int pg = PE_UNIFORM(tid >> 7), ct = tid & 127;     // channel group (two waves each), 4 consecutive samples
+    if (4 * ct < nsamp) {
+      float a4[POST_OPT];
+#pragma unroll
+      for (int o = 0; o < POST_OPT; ++o) a4[o] = 0.f;
+#pragma unroll
+      for (int cc = 0; cc < POST_CU; ++cc) {
+        const int c = pg * POST_CU + cc;
+        if (c < C) {
+          const float* rp = mb + c * WS + p.hxa + 4 * ct;    // 16-byte aligned: taps of sample j = rp[j .. j + 6]
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(rp), v1 = *reinterpret_cast<const f32x4*>(rp + 4);
+          const float v[POST_OPT + POST_K - 1] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3], rp[8], rp[9]};
+          const float* wc = p.post_w + c * POST_K;
+#pragma unroll
+          for (int k = 0; k < POST_K; ++k) {
+            const float wk = wc[k];
+#pragma unroll
+            for (int o = 0; o < POST_OPT; ++o) a4[o] = fmaf(wk, v[o + k], a4[o]);
+          }
+        }
       }
+#pragma unroll
+      for (int o = 0; o < POST_OPT; ++o) part[pg * p.N + 4 * ct + o] = a4[o];
+    }
+  }
+  __syncthreads();
+  float pk = 0.f;
+  if (tid < nsamp) {
+    float sum = 0.f;
+#pragma unroll
+    for (int g = 0; g < POST_CG; ++g) sum += part[g * p.N + tid];
+    const float y = tanhf(sum);
+    const int n = n0 + (POST_K - 1) / 2 + tid;
+    if (n < L) {
+      p.audio[(long)b * p.a_bs + n] = y;
+      pk = fabsf(y);
+    }
+  }
+  for (int o = 32; o >= 1; o >>= 1) pk = fmaxf(pk, __shfl_xor(pk, o));
+  float* wmax = part + POST_CG * p.N;
+  if (lane == 0) wmax[wv] = pk;
+  __syncthreads();
+  if (tid == 0) {
+    float m = wmax[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) m = fmaxf(m, wmax[w]);
+    atomicMax(p.absmax + b, __float_as_uint(m));
   }
 }
 

@@ -174,11 +174,17 @@ struct MrfP {
   int cu_lo, cu_hi;      // 16-column units any phase needs: [cu_lo, cu_hi)
   int nleft, nhalo;      // halo units left of the output columns / in total
   float slope, alpha;
+  int stride, n0off;     // workgroup bx owns window output columns [bx * stride - n0off, ... + N): (N, 0) without the tail
+  // generator tail fused into the last stage (post_w != nullptr; out is not written): conv_post weights [C][7], waveform,
+  // per-utterance peak (post.h: conv_post_kernel); stride = N - 6, n0off = 3
+  const float* post_w; float* audio; long a_bs; unsigned* absmax; float post_slope;
 };
 static constexpr int MRF_NW = 8, MRF_PAD = 128, MRF_MAXPH = 24;
-static constexpr int mrf_ws(int cp) { return cp == 32 ? 528 : 304; }
-static constexpr size_t mrf_smem_bytes(int cp) {
-  return ((size_t)2 * MRF_PAD + (size_t)2 * cp * mrf_ws(cp) + MRF_MAXPH * 12) * sizeof(float);
+// row stride of the LDS window (== 16 mod 32). 32 channels with 4 output units per wave (N = 512, one utterance's last
+// stage in ONE round over the chip) take the whole 160 KB: 2 x 32 x 624 floats + pads + table = 161 920 B
+static constexpr int mrf_ws(int cp, int ou = 1) { return cp == 32 ? (ou >= 4 ? 624 : 528) : 304; }
+static constexpr size_t mrf_smem_bytes(int cp, int ou = 1) {
+  return ((size_t)2 * MRF_PAD + (size_t)2 * cp * mrf_ws(cp, ou) + MRF_MAXPH * 12) * sizeof(float);
 }
 
 }  // namespace pe

@@ -322,3 +322,32 @@ def test_emulated_bf16x3_matrix_mode(emu_lib, monkeypatch, preset, seed):
         monkeypatch.setenv("PIPER_HIP_MATRIX", "fp8")
         Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
 
+
+
+def test_emulated_generator_tail_inside_the_last_stage_kernel(emu_lib, monkeypatch):
+    """mrf_kernel with conv_post + tanh + peak fused into the last stage (overlapping windows, stride N - 6) against the
+    same kernel followed by conv_post_kernel, for two window widths incl. the 4-units-per-wave one: bit-identical float
+    waveform and PCM on a ragged batch (one-frame utterance, windows hanging over both ends)."""
+    cfg = W.preset("tiny")
+    w = W.synthetic_weights(cfg, 1234)
+    Ts = (7, 3, 1)
+    ids = [W.synthetic_phoneme_ids(T, i, id_max=cfg.n_vocab - 1) for i, T in enumerate(Ts)]
+    nw, nz = _noise(cfg, len(Ts), max(Ts), 31)
+    monkeypatch.setenv("PIPER_HIP_MRF", "2")
+    res = {}
+    for tail, ou in (("0", "2"), ("1", "2"), ("1", "4")):
+        monkeypatch.setenv("PIPER_HIP_MRF_TAIL", tail)
+        monkeypatch.setenv("PIPER_HIP_MRF_OU", ou)
+        eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
+        eng.profile_enable(2)
+        r = eng.synthesize_batch(ids, (0.5, 1.0, 0.8), noise_w=nw, noise_z=nz)
+        names = {row["name"] for row in eng.profile()}
+        assert f"mrf_kernel<32,{ou},1>" in names and ("conv_post_kernel" in names) == (tail == "0"), names
+        res[(tail, ou)] = r
+        eng.close()
+    ref = res[("0", "2")]
+    o = O.synthesize(w, cfg, ids[0], (0.5, 1.0, 0.8), nw[0][:, :Ts[0]], nz[0])
+    assert np.max(np.abs(ref.audio[0] - o["audio"])) < 1e-4
+    for key in (("1", "2"), ("1", "4")):
+        for i in range(len(Ts)):
+            assert np.array_equal(res[key].audio[i], ref.audio[i]) and np.array_equal(res[key].pcm[i], ref.pcm[i]), (key, i)

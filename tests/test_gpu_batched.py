@@ -44,7 +44,7 @@ def make_engine(monkeypatch, cfg, w, env=None):
     for k in ("PIPER_HIP_SPLITK_MAX", "PIPER_HIP_SMALL", "PIPER_HIP_WIDE_MIN", "PIPER_HIP_TPB", "PIPER_HIP_SPLITK16",
               "PIPER_HIP_WIDE_SPLITK", "PIPER_HIP_DEBUG_KEEP", "PIPER_HIP_MRF", "PIPER_HIP_FUSE_DP",
               "PIPER_HIP_MRF_MAXF", "PIPER_HIP_SPEC", "PIPER_HIP_COLCHAIN", "PIPER_HIP_GROUP_MRF", 
-              "PIPER_HIP_MRF_OU", "PIPER_HIP_MATRIX", "PIPER_HIP_BF3_MINF"):
+              "PIPER_HIP_MRF_OU", "PIPER_HIP_MATRIX", "PIPER_HIP_BF3_MINF", "PIPER_HIP_MRF_TAIL"):
         monkeypatch.delenv(k, raising=False)
     for k, v in (env or {}).items():
         monkeypatch.setenv(k, str(v))
@@ -391,7 +391,7 @@ def test_randomised_stress_sweep(monkeypatch):
 
 
 @pytest.mark.parametrize("preset,lens,ou", [("medium", [128, 37], 0), ("medium", [100] * 12, 0), ("medium", [77, 128], 1),
-                                            ("medium", [128], 2), ("medium", [90, 31], 3), ("high", [64, 9], 0),
+                                            ("medium", [128], 2), ("medium", [90, 31], 3), ("medium", [128, 60], 4), ("high", [64, 9], 0),
                                             ("high", [40], 1), ("high", [33, 20, 50], 3), ("x-low", [64], 0)])
 def test_fused_mrf_stage_kernel_matches_unfused_and_oracle(monkeypatch, preset, lens, ou):
     """mrf_kernel (one launch per <= 64-channel MRF stage: every resblock conv out of LDS, activated tensors, residuals
@@ -417,6 +417,31 @@ def test_fused_mrf_stage_kernel_matches_unfused_and_oracle(monkeypatch, preset, 
         assert a.audio[i].shape == b.audio[i].shape
         assert np.max(np.abs(a.audio[i] - b.audio[i])) < 2e-5
     print(preset, "fused stage kernels:", sorted(n for n in names if n.startswith("mrf")), "worst |d audio| %.2e" % worst)
+
+
+@pytest.mark.parametrize("preset,lens,ou", [("medium", [128, 45, 3], 0), ("medium", [128], 4), ("medium", [60] * 9, 3),
+                                            ("high", [50, 17], 0), ("x-low", [128, 64], 0)])
+def test_generator_tail_inside_the_last_stage_kernel_is_bit_identical(monkeypatch, preset, lens, ou):
+    """The last stage's mrf_kernel with the generator tail fused (leaky_relu(0.01) -> conv_post -> tanh, the utterance
+    peak; windows overlapping by the 6 conv_post taps) against the same stage kernel followed by conv_post_kernel
+    (PIPER_HIP_MRF_TAIL=0): float waveform and int16 PCM bit for bit (same channel-group partial sums, same order), on
+    windows that start before the utterance, end behind it, and on utterances shorter than one window."""
+    cfg, w = voice(preset)
+    ids, nw, nz = batch_inputs(cfg, lens, seed=57)
+    res = {}
+    for tail in (1, 0):
+        env = {"PIPER_HIP_MRF": 2, "PIPER_HIP_MRF_TAIL": tail}
+        if ou:
+            env["PIPER_HIP_MRF_OU"] = ou
+        eng = make_engine(monkeypatch, cfg, w, env)
+        names, worst = run_and_check(eng, cfg, w, ids, nw, nz, sample=[0, len(lens) - 1])
+        assert any(n.startswith("mrf_kernel<32") for n in names), names
+        assert ("conv_post_kernel" in names) == (tail == 0), names
+        res[tail] = eng.synthesize_batch(ids, SCALES, noise_w=nw, noise_z=nz)
+        eng.close()
+    for i in range(len(lens)):
+        assert np.array_equal(res[1].audio[i], res[0].audio[i]), f"utterance {i}: waveform differs"
+        assert np.array_equal(res[1].pcm[i], res[0].pcm[i]), f"utterance {i}: pcm differs"
 
 
 def test_speculative_stage_b_hits_and_misses(monkeypatch):
