@@ -18,6 +18,11 @@ run_pmc() {
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc_fetch_$n -- python $GRAFT_REPO_ROOT/bench.py --no-extra --no-cpu-baseline --no-roofline --min-seconds 0 "$@" > /dev/null 2>&1)
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/$O/pmc_write_$n -- python $GRAFT_REPO_ROOT/bench.py --no-extra --no-cpu-baseline --no-roofline --min-seconds 0 "$@" > /dev/null 2>&1)
 }
+# shader clock / power under sustained matrix load (configs[2], ~140 ms steps): sampled beside the run, ~2 samples / s
+( for i in $(seq 1 40); do rocm-smi -c -P --json 2>/dev/null | head -c 2000; echo; sleep 0.2; done > $O/clocks_high_b64.jsonl ) &
+SMI=$!
+timeout 300 python bench.py --no-extra --no-cpu-baseline --no-roofline --config 3 --steps 60 --warmup 2 --min-seconds 0 > $O/bench_high_b64_clk.json 2>> $O/err.log
+kill $SMI 2>/dev/null; wait $SMI 2>/dev/null
 run_stats b1 --steps 50
 run_stats b64 --config 4 --steps 5 --warmup 2
 run_stats high_b64 --config 3 --steps 2 --warmup 1 --min-seconds 0
@@ -28,4 +33,20 @@ python scripts/pmc_traffic.py medium/b64/t128 $O/pmc_fetch_b64 $O/pmc_write_b64 
 for n in b1 b64 high_b64; do f=$(find $O/st_$n -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/r03_${n}_kernel_stats.csv; done
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*counter_collection.csv" -delete
 cat $O/pytest_gpu.log $O/smoke.log; tail -3 $O/traffic.log; tail -3 $O/err.log $O/bench_default.err
+python - <<'PY'
+import json
+sc=[];pw=[]
+for ln in open("gpurun_out/r03/clocks_high_b64.jsonl"):
+    try: d=json.loads(ln)
+    except Exception: continue
+    for card,v in d.items():
+        for k,x in v.items():
+            if "sclk" in k.lower():
+                try: sc.append(float(str(x).strip("()Mhz ")))
+                except Exception: pass
+            if "power" in k.lower():
+                try: pw.append(float(x))
+                except Exception: pass
+print("sclk samples", len(sc), "min/median/max", (min(sc), sorted(sc)[len(sc)//2], max(sc)) if sc else None, "power max", max(pw) if pw else None)
+PY
 python scripts/_show_r03.py
