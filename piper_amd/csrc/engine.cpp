@@ -287,6 +287,24 @@ float* Engine::pack16(const std::vector<float>& W, int rows, int K) {
   return dev_alloc(np, skeleton_ ? nullptr : P.data());
 }
 
+// The same matrix in the A-operand order of the 4x4x1 MFMA used by dds_layer4_kernel (kernels/dds4.h):
+// [64-row tile][k quad][lane][4], lane -> row 64 * tile + lane, float4 element j of quad q = input channel 4q + j. Only
+// packed for the 192-channel shape the kernel is compiled for.
+float* Engine::pack4(const std::vector<float>& W, int rows, int K) {
+  if (K != 192 || rows > 192) return nullptr;
+  const int nq = K / 4, ntile = (rows + 63) / 64;
+  const size_t np = (size_t)ntile * nq * 256;
+  std::vector<float> P(skeleton_ ? 0 : np, 0.f);
+  for (int mt = 0; mt < (skeleton_ ? 0 : ntile); ++mt)
+    for (int q = 0; q < nq; ++q)
+      for (int lane = 0; lane < 64; ++lane)
+        for (int jj = 0; jj < 4; ++jj) {
+          const int row = mt * 64 + lane;
+          if (row < rows) P[(((size_t)mt * nq + q) * 64 + lane) * 4 + jj] = W[(size_t)row * K + 4 * q + jj];
+        }
+  return dev_alloc(np, skeleton_ ? nullptr : P.data());
+}
+
 // A 1x1 conv weight [Co][Ci][1] (optionally with reversed input / output channels: the Flip folded in) in pack16 order
 float* Engine::pack16_conv(const WeightSet& ws, const std::string& wname, int in_rev, int out_rev) {
   const HostTensor& w = ws.get(wname);
@@ -311,6 +329,7 @@ DdsW Engine::load_dds(const WeightSet& ws, const std::string& p) {
     {
       const HostTensor& w1 = ws.get(p + ".convs_1x1." + s + ".weight");
       d.w16.push_back(pack16(w1.data, (int)w1.dims[0], (int)w1.dims[1]));     // the same matrix for dds_layer16_kernel
+      d.w4.push_back(pack4(w1.data, (int)w1.dims[0], (int)w1.dims[1]));       // ... and for dds_layer4_kernel
     }
     d.g1.push_back(dev_tensor(ws, p + ".norms_1." + s + ".gamma"));
     d.b1.push_back(dev_tensor(ws, p + ".norms_1." + s + ".beta"));
@@ -397,6 +416,7 @@ void Engine::init(const WeightSet& ws) {
   {
     const HostTensor& w = ws.get("dp.proj.weight");
     dp_proj16_ = pack16(w.data, (int)w.dims[0], (int)w.dims[1]);
+    dp_proj4_ = pack4(w.data, (int)w.dims[0], (int)w.dims[1]);
   }
   for (int i = arch_[A_DPFLOWS] - 1; i >= 1; --i) {     // dp.flows.{7,5,3} (models.py:108-110)
     const std::string p = "dp.flows." + std::to_string(2 * i + 1);
@@ -410,6 +430,7 @@ void Engine::init(const WeightSet& ws) {
     {
       const HostTensor& w = ws.get(p + ".proj.weight");
       cf.proj16 = pack16(w.data, (int)w.dims[0], (int)w.dims[1]);
+      cf.proj4 = pack4(w.data, (int)w.dims[0], (int)w.dims[1]);
     }
     cflows_.push_back(cf);
   }
@@ -578,6 +599,8 @@ void Engine::init(const WeightSet& ws) {
   if (const char* t = getenv("PIPER_HIP_DEBUG_KEEP")) debug_keep_ = atoi(t) != 0;     // tests: keep z_p for debug_tensor
   if (const char* t = getenv("PIPER_HIP_COLCHAIN")) colchain_ = atoi(t);              // A/B knob, tests
   if (const char* t = getenv("PIPER_HIP_FUSE_DP")) fuse_dp_ = atoi(t) != 0;           // A/B knob, tests
+  if (const char* t = getenv("PIPER_HIP_COL4")) col4_ = atoi(t);                      // A/B knob, tests
+  if (const char* t = getenv("PIPER_HIP_COL4_MAXC")) col4_max_cols_ = atol(t);
   if (const char* t = getenv("PIPER_HIP_SPEC")) spec_enable_ = atoi(t) != 0;          // speculative stage B (A/B, tests)
 }
 
@@ -1174,7 +1197,7 @@ void Engine::dds_params(const DdsW& d, View in, View out, View tmp, const DdsOpt
     }
     p.z_scale = opt ? opt->z_scale : 1.f;
     if (opt && i == n - 1 && opt->post_w16) {
-      p.post_w16 = opt->post_w16; p.post_bias = opt->post_bias; p.post_rows = opt->post_rows;
+      p.post_w16 = opt->post_w16; p.post_w4 = opt->post_w4; p.post_bias = opt->post_bias; p.post_rows = opt->post_rows;
       p.post_out = opt->post_out.p; p.po_bs = opt->post_out.bs; p.po_cs = opt->post_out.cs;
       p.zin = opt->zin; p.zin_bs = opt->zin_bs; p.z_cs = opt->z_cs; p.c0 = opt->c0; p.c1 = opt->c1;
       p.zout = opt->zout; p.zout_bs = opt->zout_bs;
@@ -1186,6 +1209,7 @@ void Engine::dds_params(const DdsW& d, View in, View out, View tmp, const DdsOpt
     p.g1 = d.g1[i]; p.b1 = d.b1[i]; p.g2 = d.g2[i]; p.b2 = d.b2[i];
     p.bias = d.c1x1[i].bias;
     p.wp16 = d.w16[i];
+    p.wp4 = d.w4[i];
     p.nchunks = d.c1x1[i].nchunks;
     p.lens = d_tlens_; p.H = H_;
     list.push_back(p);
@@ -1197,7 +1221,18 @@ void Engine::dds_params(const DdsW& d, View in, View out, View tmp, const DdsOpt
 void Engine::dds(const DdsW& d, View in, View out, View tmp, const DdsOpt* opt) {
   std::vector<DdsP> list;
   dds_params(d, in, out, tmp, opt, list);
+  // Small calls of the 192-channel voices: 4-column workgroups on 4x the CUs (kernels/dds4.h). Every layer of the chain
+  // needs its matrices in the 4x4x1 order; the form reads 4x the weight bytes, hence the column limit.
+  bool four = col4_ && H_ == 192 && ksz_ <= 3 && (col4_ == 2 || (long)B_ * Tg_ <= col4_max_cols_);
+  for (const DdsP& p : list) four = four && p.wp4 && (!p.post_w16 || p.post_w4);
   for (const DdsP& p : list) {
+    if (four) {
+      const int kh4 = kbegin(prof_level_ >= 2 ? krow("dds_layer4_kernel") : 0, 0.0);
+      const size_t smem4 = ((size_t)4 * 196 + 4 * 192 * 4 + 32 + 64 * 4) * sizeof(float);
+      launch::dds_layer4(dim3((Tg_ + 3) / 4, B_), smem4, stream_, p);
+      kend(kh4);
+      continue;
+    }
     const int kh = kbegin(prof_level_ >= 2 ? krow(p.nchunks == 3 ? "dds_layer16_kernel<3>" : p.nchunks == 6 ? "dds_layer16_kernel<6>"
                                                                                        : "dds_layer16_kernel<8>") : 0, 0.0);
     const dim3 grid16((Tg_ + 15) / 16, B_);
@@ -1453,7 +1488,7 @@ void Engine::issue_stage_a() {
   conv(dp_pre_, x, dy, d_tlens_, 1, T, EPI_STORE, 1.f, ACT_NONE, none, none, 0, 1.f, cb_dp, cond_bs_);
   if (fuse_dp_) {
     DdsOpt o;                      // dp.proj fused after the last DDSConv layer (models.py:65)
-    o.post_w16 = dp_proj16_; o.post_bias = dp_proj_.bias; o.post_rows = dp_proj_.rows; o.post_out = xg;
+    o.post_w16 = dp_proj16_; o.post_w4 = dp_proj4_; o.post_bias = dp_proj_.bias; o.post_rows = dp_proj_.rows; o.post_out = xg;
     dds(dp_dds_, dy, dh, dy2, &o);
   } else {
     dds(dp_dds_, dy, dh, dy2);
@@ -1483,7 +1518,7 @@ void Engine::issue_stage_a() {
       DdsOpt o;
       o.pre_z = zin + (long)c0 * Ts; o.pre_z_bs = (long)2 * Ts; o.pre_w = cf.pre_w; o.pre_b = cf.pre_b;
       o.z_scale = fi == 0 ? scales_[2] : 1.f;
-      o.post_w16 = cf.proj16; o.post_bias = cf.proj.bias; o.post_rows = cf.proj.rows;
+      o.post_w16 = cf.proj16; o.post_w4 = cf.proj4; o.post_bias = cf.proj.bias; o.post_rows = cf.proj.rows;
       o.zin = zin; o.zin_bs = (long)2 * Ts; o.z_cs = Ts; o.c0 = c0; o.c1 = c1; o.zout = z2_; o.zout_bs = (long)2 * Ts;
       dds(cf.dds, xg, dh, dy2, &o);
     } else {
@@ -2101,19 +2136,36 @@ void Engine::debug_tensor(const std::string& name, int b, std::vector<float>& ou
 }  // namespace pe
 
 #ifdef PE_STAMPS
-// tuning build only (`make stamps`): the phase timestamps of pe_rt.h's PE_STAMP, [PE_NSTAMP_K][PE_NSTAMP_I] 100 MHz ticks
+// tuning build only (`make stamps`): the kernels live in four launch translation units, each with its own copy of the
+// stamp / trace arrays (pe_rt.h PE_TRACE_FETCHER); these two entry points merge them.
+extern "C" int pe_trace_fetch_conv(long long*, long long*, unsigned*);
+extern "C" int pe_trace_fetch_bf3(long long*, long long*, unsigned*);
+extern "C" int pe_trace_fetch_front(long long*, long long*, unsigned*);
+extern "C" int pe_trace_fetch_tail(long long*, long long*, unsigned*);
+static int pe_trace_merge(long long* stamps, long long* trace, unsigned* count) {
+  int (*const fetch[4])(long long*, long long*, unsigned*) = {pe_trace_fetch_conv, pe_trace_fetch_bf3, pe_trace_fetch_front,
+                                                               pe_trace_fetch_tail};
+  std::vector<long long> st(PE_NSTAMP_K * PE_NSTAMP_I), tr((size_t)PE_NTRACE * 5);
+  unsigned total = 0;
+  for (auto f : fetch) {
+    unsigned n = 0;
+    const int rc = f(st.data(), tr.data(), &n);
+    if (rc) return rc;
+    if (stamps)
+      for (size_t i = 0; i < st.size(); ++i)
+        if (st[i]) stamps[i] = st[i];
+    if (trace)
+      for (unsigned r = 0; r < (n < PE_NTRACE ? n : PE_NTRACE) && total < PE_NTRACE; ++r, ++total)
+        memcpy(trace + (size_t)total * 5, tr.data() + (size_t)r * 5, 5 * sizeof(long long));
+  }
+  if (count) *count = total;
+  return 0;
+}
+// phase timestamps of pe_rt.h's PE_STAMP, [PE_NSTAMP_K][PE_NSTAMP_I] 100 MHz ticks
 extern "C" int pe_debug_stamps(long long* out) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pe_stamps), sizeof(long long) * PE_NSTAMP_K * PE_NSTAMP_I);
+  memset(out, 0, sizeof(long long) * PE_NSTAMP_K * PE_NSTAMP_I);
+  return pe_trace_merge(out, nullptr, nullptr);
 }
-// per-launch trace: copies [PE_NTRACE][5] records (id, wall in, wall out, clock in, clock out) and the launch counter,
-// then resets the counter
-extern "C" int pe_debug_trace(long long* out, unsigned* count) {
-  hipDeviceSynchronize();
-  int rc = (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(pe_trace), sizeof(long long) * PE_NTRACE * 5);
-  if (rc) return rc;
-  rc = (int)hipMemcpyFromSymbol(count, HIP_SYMBOL(pe_trace_seq), sizeof(unsigned));
-  if (rc) return rc;
-  const unsigned zero = 0;
-  return (int)hipMemcpyToSymbol(HIP_SYMBOL(pe_trace_seq), &zero, sizeof(unsigned));
-}
+// per-launch trace: up to PE_NTRACE records (id, wall in, wall out, clock in, clock out) and their count; resets the counters
+extern "C" int pe_debug_trace(long long* out, unsigned* count) { return pe_trace_merge(nullptr, out, count); }
 #endif

@@ -32,6 +32,7 @@ struct DdsW {               // one DDSConv (modules.py:81-129)
   std::vector<float*> dw_w, dw_b, g1, b1, g2, b2;
   std::vector<PackedConv> c1x1;
   std::vector<float*> w16;           // 1x1 weights in the 16x16x4 fragment order (dds_layer16_kernel)
+  std::vector<float*> w4;            // ... in the 4x4x1 fragment order (dds_layer4_kernel; 192-channel voices only, else null)
 };
 
 struct ProfileRow {
@@ -160,14 +161,16 @@ class Engine {
   struct DdsOpt {
     const float* pre_z = nullptr; long pre_z_bs = 0; const float* pre_w = nullptr; const float* pre_b = nullptr;
     float z_scale = 1.f;
-    const float* post_w16 = nullptr; const float* post_bias = nullptr; int post_rows = 0;
+    const float* post_w16 = nullptr; const float* post_w4 = nullptr; const float* post_bias = nullptr; int post_rows = 0;
     View post_out{nullptr, 0, 0};
     const float* zin = nullptr; long zin_bs = 0; int z_cs = 0, c0 = 0, c1 = 1; float* zout = nullptr; long zout_bs = 0;
   };
   void dds(const DdsW& d, View in, View out, View tmp, const DdsOpt* opt = nullptr);
   void dds_params(const DdsW& d, View in, View out, View tmp, const DdsOpt* opt, std::vector<struct DdsP>& list);
   float* pack16(const std::vector<float>& W, int rows, int K);    // [16-row tile][q][lane][4] (dds_layer16_kernel)
+  float* pack4(const std::vector<float>& W, int rows, int K);     // [64-row tile][k quad][lane][4] (dds_layer4_kernel); null unless K == 192
   float* dp_proj16_ = nullptr;
+  float* dp_proj4_ = nullptr;                    // pack4 order (dds_layer4_kernel)
   int colchain_ = 1;                        // PIPER_HIP_COLCHAIN: 0 off, 1 by batch size, 2 always (A/B, tests)
   // batch columns up to which colchain_kernel / lngemm_kernel replace conv + LayerNorm pairs: ids for the encoder,
   // frames for the flow. Measured (profiles/r02_notes.md): -3.5 % at B=1, -2.5 % at B=16, neutral at B=32, +1 % at B=64.
@@ -180,6 +183,8 @@ class Engine {
   void lngemm(View y, const float* g, const float* b, View x, const float* w16, const float* bias, int rows, View out,
               int T, double flops);
   float* pack16_conv(const WeightSet& ws, const std::string& wname, int in_rev, int out_rev);
+  int col4_ = 1;                            // PIPER_HIP_COL4: 4-column workgroups for the DDSConv layers: 0 off, 1 up to col4_max_cols_ columns per call, 2 always (A/B, tests)
+  long col4_max_cols_ = 1024;
   bool fuse_dp_ = true;                     // PIPER_HIP_FUSE_DP=0: cf_pre / proj / spline as separate launches (A/B, tests)
   void issue_stage_a();
   void issue_stage_b();
@@ -235,6 +240,7 @@ class Engine {
     DdsW dds;
     PackedConv proj;
     float* proj16 = nullptr;             // proj in the 16x16x4 fragment order (fused after the last DDSConv layer)
+    float* proj4 = nullptr;              // ... in the 4x4x1 fragment order (dds_layer4_kernel)
   };
   std::vector<CFlow> cflows_;
   float ea_m0_ = 0, ea_es0_ = 1;

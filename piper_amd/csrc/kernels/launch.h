@@ -32,6 +32,7 @@ void embed(dim3 grid, hipStream_t stream, const int* ids, int ids_bs, const int*
 void attention(int dk, dim3 grid, size_t smem, hipStream_t stream, const AttnP& p);
 void layer_norm(dim3 grid, hipStream_t stream, const LnP& p);
 void dds_layer(int nchunks, dim3 grid, size_t smem, hipStream_t stream, const DdsP& p);
+void dds_layer4(dim3 grid, size_t smem, hipStream_t stream, const DdsP& p);      // 4-column form, 192 channels (dds4.h)
 void colchain(dim3 grid, size_t smem, hipStream_t stream, const ColP& p);
 void lngemm(dim3 grid, size_t smem, hipStream_t stream, const LnGemmP& p);
 void cf_pre(dim3 grid, hipStream_t stream, const float* z0, long z_bs, const float* w, const float* bias, const float* xg,

@@ -39,3 +39,7 @@ void conv_bf3(int cfg, bool gate, int halo, dim3 grid, size_t smem, hipStream_t 
 
 }  // namespace launch
 }  // namespace pe
+
+#ifdef PE_STAMPS
+PE_TRACE_FETCHER(bf3)
+#endif

@@ -81,3 +81,7 @@ void conv_group_sum(dim3 grid, size_t smem, hipStream_t stream, const ConvP& p) 
 
 }  // namespace launch
 }  // namespace pe
+
+#ifdef PE_STAMPS
+PE_TRACE_FETCHER(conv)
+#endif

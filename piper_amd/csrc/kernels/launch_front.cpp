@@ -4,6 +4,7 @@
 #include "attention.h"
 #include "colchain.h"
 #include "dds.h"
+#include "dds4.h"
 #include "duration.h"
 #include "layernorm.h"
 #include "glue.h"
@@ -39,6 +40,10 @@ void dds_layer(int nchunks, dim3 grid, size_t smem, hipStream_t stream, const Dd
   if (nchunks == 3) PE_LAUNCH(dds_layer16_kernel<3>, grid, dim3(512), smem, stream, p);
   else if (nchunks == 6) PE_LAUNCH(dds_layer16_kernel<6>, grid, dim3(512), smem, stream, p);
   else PE_LAUNCH(dds_layer16_kernel<8>, grid, dim3(512), smem, stream, p);
+}
+
+void dds_layer4(dim3 grid, size_t smem, hipStream_t stream, const DdsP& p) {
+  PE_LAUNCH(dds_layer4_kernel, grid, dim3(256), smem, stream, p);
 }
 
 void colchain(dim3 grid, size_t smem, hipStream_t stream, const ColP& p) {
@@ -79,3 +84,7 @@ void cond(dim3 grid, hipStream_t stream, const float* emb_g, int gin, const int*
 
 }  // namespace launch
 }  // namespace pe
+
+#ifdef PE_STAMPS
+PE_TRACE_FETCHER(front)
+#endif

@@ -50,3 +50,7 @@ void window_copy(dim3 grid, hipStream_t stream, const float* z, int zs, const in
 
 }  // namespace launch
 }  // namespace pe
+
+#ifdef PE_STAMPS
+PE_TRACE_FETCHER(tail)
+#endif

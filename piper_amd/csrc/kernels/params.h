@@ -84,6 +84,7 @@ struct DdsP {
   const float* g1; const float* b1; const float* g2; const float* b2;
   const float* bias;                        // 1x1 conv bias
   const float* wp16;                        // 1x1 conv weights in the 16x16x4 fragment order (engine.cpp)
+  const float* wp4;                         // the same in the 4x4x1 fragment order (dds_layer4_kernel; null: not packed)
   int nchunks;                              // ceil(H / 32)
   const int* lens;
   int H;
@@ -94,7 +95,7 @@ struct DdsP {
   float z_scale;                            // noise_scale_w on the first flow (z is still the raw N(0,1) draw), else 1
   // Optional second 1x1 conv on the layer's output columns (last layer of a DDSConv: dp.proj / ConvFlow.proj,
   // models.py:65, modules.py:507), weights in the 16x16x4 fragment order; the layer output itself is then not stored.
-  const float* post_w16; const float* post_bias; int post_rows;
+  const float* post_w16; const float* post_w4; const float* post_bias; int post_rows;
   float* post_out; long po_bs; int po_cs;   // plain store of the post conv (dp.proj), or null
   // Optional spline epilogue (ConvFlow, modules.py:508-526): the post conv's 29 rows are the per-position parameters;
   // z1 <- rq_spline_inverse(z1 * z_scale), z0 <- z0 * z_scale (pass-through), both [2][Ts] tensors may alias.

@@ -13,6 +13,7 @@ namespace pe { extern thread_local long g_launches; }   // kernel launches issue
 #define PE_KTRACE(id) ((void)0)
 #define pe_mfma_32x32x2(a, b, c) emu_mfma_32x32x2((a), (b), (c))
 #define pe_mfma_16x16x4(a, b, c) emu_mfma_16x16x4((a), (b), (c))
+#define pe_mfma_4x4x1(a, b, c) emu_mfma_4x4x1((a), (b), (c))
 #define PE_WAVE_SYNC() emu::wave_sync()
 #define PE_OPAQUE(x) ((void)0)
 #define PE_UNIFORM(x) (emu::uniform_check((long long)(x)), (x))     // checked: readfirstlane on the GPU
@@ -75,6 +76,21 @@ struct PeTrace {
   }
 };
 #define PE_KTRACE(id) PeTrace pe_ktrace_obj(id)
+// The stamp / trace arrays are one copy per translation unit (static __device__): every launch unit defines a fetcher of
+// ITS copy with this macro, and engine.cpp's pe_debug_stamps / pe_debug_trace merge them (stamps: non-zero slots; trace:
+// records appended, counters summed and reset).
+#define PE_TRACE_FETCHER(tag) \
+  extern "C" int pe_trace_fetch_##tag(long long* stamps, long long* trace, unsigned* count) { \
+    hipDeviceSynchronize(); \
+    int rc = (int)hipMemcpyFromSymbol(stamps, HIP_SYMBOL(pe_stamps), sizeof(long long) * PE_NSTAMP_K * PE_NSTAMP_I); \
+    if (rc) return rc; \
+    rc = (int)hipMemcpyFromSymbol(trace, HIP_SYMBOL(pe_trace), sizeof(long long) * PE_NTRACE * 5); \
+    if (rc) return rc; \
+    rc = (int)hipMemcpyFromSymbol(count, HIP_SYMBOL(pe_trace_seq), sizeof(unsigned)); \
+    if (rc) return rc; \
+    const unsigned zero = 0; \
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(pe_trace_seq), &zero, sizeof(unsigned)); \
+  }
 #else
 #define PE_STAMP(k, i) do {} while (0)
 #define PE_KTRACE(id) do {} while (0)
@@ -83,6 +99,9 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define pe_mfma_32x32x2(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 #define pe_mfma_16x16x4(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+// 16 independent 4x4 outer products (blocks): lane l gives A[block l/4][row l%4] and B[block l/4][col l%4], VGPR r of lane l
+// holds D[block l/4][row r][col l%4] (checked on the hardware: scripts/microbench/mfma4x4.hip)
+#define pe_mfma_4x4x1(a, b, c) __builtin_amdgcn_mfma_f32_4x4x1f32((a), (b), (c), 0, 0, 0)
 // lanes of a wave run in lockstep and LDS accesses of one wave complete in order: only the compiler
 // must not reorder across this point
 #define PE_WAVE_SYNC() __builtin_amdgcn_wave_barrier()

@@ -56,8 +56,8 @@ def main():
 
 
 NAMES = {0: "attn", 1: "conv_splitk", 2: "dds_layer16", 3: "colchain", 4: "conv_splitk16", 5: "ln", 10: "embed",
-         11: "conv_mfma", 12: "cf_pre", 13: "duration", 6: "conv_splitk_group", 7: "lngemm", 8: "conv_splitk_sum", 14: "dp_persist", 15: "randn", 16: "regulate", 17: "conv_post",
-         18: "pcm16", 19: "mrf2", 20: "mrf_fused", 21: "spline_inverse"}
+         11: "conv_mfma", 13: "duration", 6: "conv_splitk_group", 7: "lngemm", 8: "conv_splitk_sum", 14: "dp_persist", 15: "randn", 16: "regulate", 17: "conv_post",
+         18: "pcm16", 20: "mrf", 12: "conv_bf3", 21: "spline_inverse"}
 
 
 def trace(lib, eng):

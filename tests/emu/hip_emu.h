@@ -120,6 +120,20 @@ inline f32x4 emu_mfma_16x16x4(float a, float b, f32x4 c) {
   emu::wave_sync();
   return c;
 }
+// v_mfma_f32_4x4x1_16B_f32: 16 blocks of a 4x4 outer product; lane l: A[block l/4][row l%4], B[block l/4][col l%4];
+// D VGPR r = D[block l/4][row r][col l%4].
+inline f32x4 emu_mfma_4x4x1(float a, float b, f32x4 c) {
+  float* sa = emu::wave_f(1);
+  float* sb = emu::wave_f(2);
+  const int l = emu::lane();
+  sa[l] = a;
+  sb[l] = b;
+  emu::wave_sync();
+  const int blk = l >> 2;
+  for (int r = 0; r < 4; ++r) c[r] = fmaf(sa[4 * blk + r], sb[l], c[r]);
+  emu::wave_sync();
+  return c;
+}
 
 // v_mfma_f32_32x32x16_bf16: lane l gives A[i=l&31][k = 8*(l>>5) + e], B[k = 8*(l>>5) + e][j=l&31], e = 0..7 (four dwords
 // of two bf16 each); D as the f32 32x32 form. Products of bf16 values are exact in f32; f32 accumulation.

@@ -351,3 +351,32 @@ def test_emulated_generator_tail_inside_the_last_stage_kernel(emu_lib, monkeypat
     for key in (("1", "2"), ("1", "4")):
         for i in range(len(Ts)):
             assert np.array_equal(res[key].audio[i], ref.audio[i]) and np.array_equal(res[key].pcm[i], ref.pcm[i]), (key, i)
+
+
+@pytest.mark.parametrize("col4", ["0", "1"])
+def test_emulated_192_channel_small_call_kernels(emu_lib, monkeypatch, col4):
+    """The kernels compiled for exactly 192 hidden channels (the reference's medium / high qualities) on a voice that
+    is tiny everywhere else: colchain_kernel, lngemm_kernel, attn_kernel<96> and the duration predictor's DDSConv layers
+    in both forms -- dds_layer16_kernel (PIPER_HIP_COL4=0) and the 4-column dds_layer4_kernel on the 4x4x1 MFMA
+    (kernels/dds4.h) -- against the oracle: equal integer durations, logw and waveform."""
+    monkeypatch.setenv("PIPER_HIP_COL4", col4)
+    cfg = W.preset("tiny", hidden=192, inter=192, filter=64, n_layers=1)
+    w = W.synthetic_weights(cfg, 1234)
+    lens = [9, 5]
+    ids = [W.synthetic_phoneme_ids(T, i, id_max=cfg.n_vocab - 1) for i, T in enumerate(lens)]
+    nw = np.random.default_rng(5).standard_normal((len(lens), 2, max(lens))).astype(np.float32)
+    eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
+    eng.profile_enable(2)
+    r = eng.synthesize_batch(ids, (0.0, 1.0, 0.8), noise_w=nw)
+    names = {row["name"] for row in eng.profile()[5:] if row["launches"]}
+    assert {"colchain_kernel<6>", "lngemm_kernel<6>", "attn_kernel<96>"} <= names
+    assert ("dds_layer4_kernel" in names) == (col4 == "1") and ("dds_layer16_kernel<6>" in names) == (col4 == "0")
+    durs = eng.durations()
+    off = np.concatenate([[0], np.cumsum(lens)])
+    for i, T in enumerate(lens):
+        o = O.synthesize(w, cfg, ids[i], (0.0, 1.0, 0.8), nw[i], keep=True)
+        assert np.array_equal(durs[off[i]:off[i + 1]], o["durations"])
+        lw = eng.debug_tensor("logw", i).ravel()[:T]
+        assert np.max(np.abs(lw - np.asarray(o["logw"]).ravel()[:T])) < 1e-5
+        assert np.max(np.abs(r.audio[i] - o["audio"])) < 1e-5
+    eng.close()

@@ -44,7 +44,8 @@ def make_engine(monkeypatch, cfg, w, env=None):
     for k in ("PIPER_HIP_SPLITK_MAX", "PIPER_HIP_SMALL", "PIPER_HIP_WIDE_MIN", "PIPER_HIP_TPB", "PIPER_HIP_SPLITK16",
               "PIPER_HIP_WIDE_SPLITK", "PIPER_HIP_DEBUG_KEEP", "PIPER_HIP_MRF", "PIPER_HIP_FUSE_DP",
               "PIPER_HIP_MRF_MAXF", "PIPER_HIP_SPEC", "PIPER_HIP_COLCHAIN", "PIPER_HIP_GROUP_MRF", 
-              "PIPER_HIP_MRF_OU", "PIPER_HIP_MATRIX", "PIPER_HIP_BF3_MINF", "PIPER_HIP_MRF_TAIL"):
+              "PIPER_HIP_MRF_OU", "PIPER_HIP_MATRIX", "PIPER_HIP_BF3_MINF", "PIPER_HIP_MRF_TAIL", "PIPER_HIP_COL4",
+              "PIPER_HIP_COL4_MAXC"):
         monkeypatch.delenv(k, raising=False)
     for k, v in (env or {}).items():
         monkeypatch.setenv(k, str(v))
@@ -199,6 +200,10 @@ FORCED = [
     ("medium", [128, 17], {"PIPER_HIP_SPLITK16": 3},
      {"conv_splitk16_kernel<true,12,2>", "conv_splitk16_kernel<false,8,4>"}),
     ("high", [48], {"PIPER_HIP_SPLITK_MAX": 0}, {"conv_mfma_kernel<2,2,2,1,16,true,64>"}),
+    # DDSConv layers of the duration predictor: the 4-column form on the 4x4x1 MFMA (default for small calls) forced
+    # on for a ragged batch beyond its column limit, and off (the 16-column form)
+    ("medium", [128, 77, 16, 33, 3, 1, 128, 90, 128, 128], {"PIPER_HIP_COL4": 2}, {"dds_layer4_kernel"}),
+    ("medium", [128, 31], {"PIPER_HIP_COL4": 0}, {"dds_layer16_kernel<6>"}),
 ]
 
 
