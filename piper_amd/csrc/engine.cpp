@@ -284,14 +284,16 @@ float* Engine::pack16(const std::vector<float>& W, int rows, int K) {
           const int row = mt * 16 + (lane & 15), ci = 4 * (4 * q + jj) + (lane >> 4);
           if (row < rows && ci < K) P[(((size_t)mt * nq + q) * 64 + lane) * 4 + jj] = W[(size_t)row * K + ci];
         }
-  return dev_alloc(np, skeleton_ ? nullptr : P.data());
+  float* d16 = dev_alloc(np, skeleton_ ? nullptr : P.data());
+  if (const float* d4 = pack4(W, rows, K)) w4_of_[d16] = d4;
+  return d16;
 }
 
 // The same matrix in the A-operand order of the 4x4x1 MFMA used by dds_layer4_kernel (kernels/dds4.h):
 // [64-row tile][k quad][lane][4], lane -> row 64 * tile + lane, float4 element j of quad q = input channel 4q + j. Only
-// packed for the 192-channel shape the kernel is compiled for.
+// packed for the K = 192 / 96 shapes the 4-column kernels are compiled for (kernels/col4.h).
 float* Engine::pack4(const std::vector<float>& W, int rows, int K) {
-  if (K != 192 || rows > 192) return nullptr;
+  if (K != 192 && K != 96) return nullptr;
   const int nq = K / 4, ntile = (rows + 63) / 64;
   const size_t np = (size_t)ntile * nq * 256;
   std::vector<float> P(skeleton_ ? 0 : np, 0.f);
@@ -329,7 +331,6 @@ DdsW Engine::load_dds(const WeightSet& ws, const std::string& p) {
     {
       const HostTensor& w1 = ws.get(p + ".convs_1x1." + s + ".weight");
       d.w16.push_back(pack16(w1.data, (int)w1.dims[0], (int)w1.dims[1]));     // the same matrix for dds_layer16_kernel
-      d.w4.push_back(pack4(w1.data, (int)w1.dims[0], (int)w1.dims[1]));       // ... and for dds_layer4_kernel
     }
     d.g1.push_back(dev_tensor(ws, p + ".norms_1." + s + ".gamma"));
     d.b1.push_back(dev_tensor(ws, p + ".norms_1." + s + ".beta"));
@@ -416,7 +417,6 @@ void Engine::init(const WeightSet& ws) {
   {
     const HostTensor& w = ws.get("dp.proj.weight");
     dp_proj16_ = pack16(w.data, (int)w.dims[0], (int)w.dims[1]);
-    dp_proj4_ = pack4(w.data, (int)w.dims[0], (int)w.dims[1]);
   }
   for (int i = arch_[A_DPFLOWS] - 1; i >= 1; --i) {     // dp.flows.{7,5,3} (models.py:108-110)
     const std::string p = "dp.flows." + std::to_string(2 * i + 1);
@@ -430,7 +430,6 @@ void Engine::init(const WeightSet& ws) {
     {
       const HostTensor& w = ws.get(p + ".proj.weight");
       cf.proj16 = pack16(w.data, (int)w.dims[0], (int)w.dims[1]);
-      cf.proj4 = pack4(w.data, (int)w.dims[0], (int)w.dims[1]);
     }
     cflows_.push_back(cf);
   }
@@ -1197,7 +1196,7 @@ void Engine::dds_params(const DdsW& d, View in, View out, View tmp, const DdsOpt
     }
     p.z_scale = opt ? opt->z_scale : 1.f;
     if (opt && i == n - 1 && opt->post_w16) {
-      p.post_w16 = opt->post_w16; p.post_w4 = opt->post_w4; p.post_bias = opt->post_bias; p.post_rows = opt->post_rows;
+      p.post_w16 = opt->post_w16; p.post_w4 = w4_of(opt->post_w16); p.post_bias = opt->post_bias; p.post_rows = opt->post_rows;
       p.post_out = opt->post_out.p; p.po_bs = opt->post_out.bs; p.po_cs = opt->post_out.cs;
       p.zin = opt->zin; p.zin_bs = opt->zin_bs; p.z_cs = opt->z_cs; p.c0 = opt->c0; p.c1 = opt->c1;
       p.zout = opt->zout; p.zout_bs = opt->zout_bs;
@@ -1209,7 +1208,7 @@ void Engine::dds_params(const DdsW& d, View in, View out, View tmp, const DdsOpt
     p.g1 = d.g1[i]; p.b1 = d.b1[i]; p.g2 = d.g2[i]; p.b2 = d.b2[i];
     p.bias = d.c1x1[i].bias;
     p.wp16 = d.w16[i];
-    p.wp4 = d.w4[i];
+    p.wp4 = w4_of(d.w16[i]);
     p.nchunks = d.c1x1[i].nchunks;
     p.lens = d_tlens_; p.H = H_;
     list.push_back(p);
@@ -1223,13 +1222,12 @@ void Engine::dds(const DdsW& d, View in, View out, View tmp, const DdsOpt* opt) 
   dds_params(d, in, out, tmp, opt, list);
   // Small calls of the 192-channel voices: 4-column workgroups on 4x the CUs (kernels/dds4.h). Every layer of the chain
   // needs its matrices in the 4x4x1 order; the form reads 4x the weight bytes, hence the column limit.
-  bool four = col4_ && H_ == 192 && ksz_ <= 3 && (col4_ == 2 || (long)B_ * Tg_ <= col4_max_cols_);
+  bool four = H_ == 192 && ksz_ <= 3 && use_col4((long)B_ * Tg_);
   for (const DdsP& p : list) four = four && p.wp4 && (!p.post_w16 || p.post_w4);
   for (const DdsP& p : list) {
     if (four) {
       const int kh4 = kbegin(prof_level_ >= 2 ? krow("dds_layer4_kernel") : 0, 0.0);
-      const size_t smem4 = ((size_t)4 * 196 + 4 * 192 * 4 + 32 + 64 * 4) * sizeof(float);
-      launch::dds_layer4(dim3((Tg_ + 3) / 4, B_), smem4, stream_, p);
+      launch::dds_layer4(dim3((Tg_ + 3) / 4, B_), col4_smem(), stream_, p);
       kend(kh4);
       continue;
     }
@@ -1269,6 +1267,14 @@ void Engine::lngemm(View y, const float* g, const float* b, View x, const float*
   p.w16 = w16; p.bias = bias; p.rows = rows;
   p.out = out.p; p.o_bs = out.bs; p.o_cs = out.cs;
   p.lens = d_tlens_;
+  // small calls: 4-column workgroups on the 4x4x1 MFMA (kernels/col4.h), like Engine::dds
+  if (const float* w4 = use_col4((long)B_ * T) ? w4_of(w16) : nullptr) {
+    p.w16 = w4;
+    const int kh4 = kbegin(prof_level_ >= 2 ? krow("lngemm4_kernel") : 0, flops);
+    launch::lngemm4(dim3((T + 3) / 4, B_, (rows + 191) / 192), col4_smem(), stream_, p);
+    kend(kh4);
+    return;
+  }
   const int kh = kbegin(prof_level_ >= 2 ? krow("lngemm_kernel<6>") : 0, flops);
   const size_t smem = ((size_t)192 * 16 + 16 * 16) * sizeof(float);
   launch::lngemm(dim3((T + 15) / 16, B_, (rows + 191) / 192), smem, stream_, p);
@@ -1276,6 +1282,18 @@ void Engine::lngemm(View y, const float* g, const float* b, View x, const float*
 }
 
 void Engine::colchain(const ColP& p, int B, int Lmax, double flops) {
+  if (use_col4((long)B * Lmax) && p.K1 == 192 && (p.mode == 0 ? p.rows1 == 192 : (p.rows1 == 96 && (!p.w2 || p.rows2 <= 192)))) {
+    const float* w1 = w4_of(p.w1);
+    const float* w2 = p.w2 ? w4_of(p.w2) : nullptr;
+    if (w1 && (!p.w2 || w2)) {
+      ColP q = p;
+      q.w1 = w1; q.w2 = w2;
+      const int kh4 = kbegin(prof_level_ >= 2 ? krow("colchain4_kernel") : 0, flops);
+      launch::colchain4(dim3((Lmax + 3) / 4, B), col4_smem(), stream_, q);
+      kend(kh4);
+      return;
+    }
+  }
   const int kh = kbegin(prof_level_ >= 2 ? krow("colchain_kernel<6>") : 0, flops);
   const size_t smem = ((size_t)2 * 6 * 32 * 16 + 16 * 16) * sizeof(float);
   launch::colchain(dim3((Lmax + 15) / 16, B), smem, stream_, p);
@@ -1488,7 +1506,7 @@ void Engine::issue_stage_a() {
   conv(dp_pre_, x, dy, d_tlens_, 1, T, EPI_STORE, 1.f, ACT_NONE, none, none, 0, 1.f, cb_dp, cond_bs_);
   if (fuse_dp_) {
     DdsOpt o;                      // dp.proj fused after the last DDSConv layer (models.py:65)
-    o.post_w16 = dp_proj16_; o.post_w4 = dp_proj4_; o.post_bias = dp_proj_.bias; o.post_rows = dp_proj_.rows; o.post_out = xg;
+    o.post_w16 = dp_proj16_; o.post_bias = dp_proj_.bias; o.post_rows = dp_proj_.rows; o.post_out = xg;
     dds(dp_dds_, dy, dh, dy2, &o);
   } else {
     dds(dp_dds_, dy, dh, dy2);
@@ -1518,7 +1536,7 @@ void Engine::issue_stage_a() {
       DdsOpt o;
       o.pre_z = zin + (long)c0 * Ts; o.pre_z_bs = (long)2 * Ts; o.pre_w = cf.pre_w; o.pre_b = cf.pre_b;
       o.z_scale = fi == 0 ? scales_[2] : 1.f;
-      o.post_w16 = cf.proj16; o.post_w4 = cf.proj4; o.post_bias = cf.proj.bias; o.post_rows = cf.proj.rows;
+      o.post_w16 = cf.proj16; o.post_bias = cf.proj.bias; o.post_rows = cf.proj.rows;
       o.zin = zin; o.zin_bs = (long)2 * Ts; o.z_cs = Ts; o.c0 = c0; o.c1 = c1; o.zout = z2_; o.zout_bs = (long)2 * Ts;
       dds(cf.dds, xg, dh, dy2, &o);
     } else {

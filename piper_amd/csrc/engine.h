@@ -6,6 +6,7 @@
 #include <deque>
 #include <map>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "pe_rt.h"
@@ -32,7 +33,6 @@ struct DdsW {               // one DDSConv (modules.py:81-129)
   std::vector<float*> dw_w, dw_b, g1, b1, g2, b2;
   std::vector<PackedConv> c1x1;
   std::vector<float*> w16;           // 1x1 weights in the 16x16x4 fragment order (dds_layer16_kernel)
-  std::vector<float*> w4;            // ... in the 4x4x1 fragment order (dds_layer4_kernel; 192-channel voices only, else null)
 };
 
 struct ProfileRow {
@@ -161,16 +161,19 @@ class Engine {
   struct DdsOpt {
     const float* pre_z = nullptr; long pre_z_bs = 0; const float* pre_w = nullptr; const float* pre_b = nullptr;
     float z_scale = 1.f;
-    const float* post_w16 = nullptr; const float* post_w4 = nullptr; const float* post_bias = nullptr; int post_rows = 0;
+    const float* post_w16 = nullptr; const float* post_bias = nullptr; int post_rows = 0;
     View post_out{nullptr, 0, 0};
     const float* zin = nullptr; long zin_bs = 0; int z_cs = 0, c0 = 0, c1 = 1; float* zout = nullptr; long zout_bs = 0;
   };
   void dds(const DdsW& d, View in, View out, View tmp, const DdsOpt* opt = nullptr);
   void dds_params(const DdsW& d, View in, View out, View tmp, const DdsOpt* opt, std::vector<struct DdsP>& list);
   float* pack16(const std::vector<float>& W, int rows, int K);    // [16-row tile][q][lane][4] (dds_layer16_kernel)
-  float* pack4(const std::vector<float>& W, int rows, int K);     // [64-row tile][k quad][lane][4] (dds_layer4_kernel); null unless K == 192
+  // every pack16 matrix with K = 96 / 192 is also packed for the 4x4x1 MFMA of the 4-column kernels (kernels/col4.h):
+  // [64-row tile][k quad][lane][4]; looked up by its pack16 pointer (null: not packed)
+  float* pack4(const std::vector<float>& W, int rows, int K);
+  std::unordered_map<const float*, const float*> w4_of_;
+  const float* w4_of(const float* w16) const { auto it = w4_of_.find(w16); return it == w4_of_.end() ? nullptr : it->second; }
   float* dp_proj16_ = nullptr;
-  float* dp_proj4_ = nullptr;                    // pack4 order (dds_layer4_kernel)
   int colchain_ = 1;                        // PIPER_HIP_COLCHAIN: 0 off, 1 by batch size, 2 always (A/B, tests)
   // batch columns up to which colchain_kernel / lngemm_kernel replace conv + LayerNorm pairs: ids for the encoder,
   // frames for the flow. Measured (profiles/r02_notes.md): -3.5 % at B=1, -2.5 % at B=16, neutral at B=32, +1 % at B=64.
@@ -185,6 +188,8 @@ class Engine {
   float* pack16_conv(const WeightSet& ws, const std::string& wname, int in_rev, int out_rev);
   int col4_ = 1;                            // PIPER_HIP_COL4: 4-column workgroups for the DDSConv layers: 0 off, 1 up to col4_max_cols_ columns per call, 2 always (A/B, tests)
   long col4_max_cols_ = 1024;
+  bool use_col4(long cols) const { return col4_ && (col4_ == 2 || cols <= col4_max_cols_); }
+  static size_t col4_smem() { return ((size_t)4 * 196 + 4 * 192 * 4 + 32 + 64 * 4) * sizeof(float); }   // YT | P | red | ZL (kernels/col4.h, dds4.h)
   bool fuse_dp_ = true;                     // PIPER_HIP_FUSE_DP=0: cf_pre / proj / spline as separate launches (A/B, tests)
   void issue_stage_a();
   void issue_stage_b();
@@ -240,7 +245,6 @@ class Engine {
     DdsW dds;
     PackedConv proj;
     float* proj16 = nullptr;             // proj in the 16x16x4 fragment order (fused after the last DDSConv layer)
-    float* proj4 = nullptr;              // ... in the 4x4x1 fragment order (dds_layer4_kernel)
   };
   std::vector<CFlow> cflows_;
   float ea_m0_ = 0, ea_es0_ = 1;

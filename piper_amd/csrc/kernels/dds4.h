@@ -3,6 +3,7 @@
 // /root/reference/src/python/piper_train/vits/.)
 #pragma once
 #include "dds.h"
+#include "col4.h"
 
 namespace pe {
 
@@ -22,74 +23,13 @@ namespace pe {
 // Weights: engine.cpp pack4 -- [64-row tile][k quad = K/4][lane][4]: lane l <-> row 64 * tile + l, element j <-> input
 // channel 4 * quad + j. Each workgroup streams the layer's 147 KB of weights from L2, so the form is for small calls
 // only (engine.cpp: Engine::dds; 4x the workgroups of the 16-column form read 4x the weight bytes).
-constexpr int C4_H = 192, C4_NT = C4_H / 64, C4_NQ = C4_H / 16;      // channels, 64-row tiles, k quads per wave
-constexpr int C4_KS = C4_H + 4;                                      // LDS row stride of the B operand ([column][KS])
-
-struct Col4W {
-  f32x4 w[C4_NT][C4_NQ];
-};
-// this wave's weight fragments: tiles [0, nt) of a [rows <= 192][192] matrix in pack4 order (missing tiles: zeros)
-__device__ __forceinline__ void col_gemm4_fetch(Col4W& W, const float* wp4, int nt, int wv, int lane) {
-  constexpr int tile_floats = (C4_H / 4) * 256;
-#pragma unroll
-  for (int m = 0; m < C4_NT; ++m) {
-    const bool live = PE_UNIFORM(m < nt);
-    const pe_rowsrc ws = pe_make_row_u(wp4 + (long)(live ? m : 0) * tile_floats, live ? tile_floats : 0);
-#pragma unroll
-    for (int q = 0; q < C4_NQ; ++q) W.w[m][q] = pe_row_load4(ws, ((C4_NQ * wv + q) * 64 + lane) * 4);
-  }
-  PE_SCHED_FENCE();
-}
-// partial product of this wave's K range: P[wave][row][4 columns] <- W[:, K range] . Y[K range][4]; YT = [4][C4_KS]
-__device__ __forceinline__ void col_gemm4_run(const Col4W& W, int nt, const float* YT, float* P, int wv, int lane) {
-  f32x4 acc[C4_NT];
-#pragma unroll
-  for (int m = 0; m < C4_NT; ++m)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[m][r] = 0.f;
-  const float* yp = YT + (lane & 3) * C4_KS + 4 * C4_NQ * wv;
-#pragma unroll
-  for (int q = 0; q < C4_NQ; ++q) {
-    f32x4 yv;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) yv[j] = yp[4 * q + j];
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int m = 0; m < C4_NT; ++m) acc[m] = pe_mfma_4x4x1(W.w[m][q][j], yv[j], acc[m]);
-  }
-  (void)nt;
-#pragma unroll
-  for (int m = 0; m < C4_NT; ++m)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) P[((wv * C4_NT + m) * 64 + 4 * (lane >> 2) + r) * 4 + (lane & 3)] = acc[m][r];
-}
-// row `c` of the product at column `col`: the four waves' partials in wave order
-__device__ __forceinline__ float col_gemm4_get(const float* P, int c, int col) {
-  const int o = c * 4 + col;
-  return ((P[o] + P[C4_H * 4 + o]) + P[2 * C4_H * 4 + o]) + P[3 * C4_H * 4 + o];
-}
-// Sum over the 64 channel lanes x 3 slots that share a column (256-thread, 4-column workgroups): lanes by shuffle, the
-// four waves through `red` ([2][4][4] floats, halves alternating between calls like pe_col_sum16: one barrier per call)
-__device__ __forceinline__ float pe_col_sum4(float v, float* red, int& flip, int wv, int lane, int col) {
-  v += __shfl_xor(v, 4);
-  v += __shfl_xor(v, 8);
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 32);
-  float* r = red + flip * 16;
-  flip ^= 1;
-  if (lane < 4) r[wv * 4 + col] = v;
-  __syncthreads();
-  return ((r[col] + r[4 + col]) + r[8 + col]) + r[12 + col];
-}
-
 __global__ __launch_bounds__(256) void dds_layer4_kernel(DdsP p) {
   PE_KTRACE(2);
   PE_DYN_SMEM(float, sm);                       // YT[4][KS] | P[4 waves][192][4] | red[2][4][4] | ZL[64][4]
-  constexpr int NC = 4, NVT = 3, H = C4_H;
+  constexpr int NC = 4, NVT = 3, H = C4_H, C4_KS = Col4W<C4_H>::KS;
   const int b = blockIdx.y;
   const int L = p.lens[b];                      // first used after every operand load is in flight (dds.h)
-  const int t0 = blockIdx.x * NC;
+  const int t0 = c4_tile(blockIdx.x, gridDim.x) * NC;
   const int Lb = p.x_cs;
   float* YT = sm;
   float* P = YT + NC * C4_KS;
@@ -103,8 +43,8 @@ __global__ __launch_bounds__(256) void dds_layer4_kernel(DdsP p) {
   const int pad = (p.dw_k - 1) / 2 * p.dw_dil;
   const bool fold = p.pre_z != nullptr;
   // this wave's 1x1-conv weight fragments: in flight under phase 1
-  Col4W gw;
-  col_gemm4_fetch(gw, p.wp4, C4_NT, wv, lane);
+  Col4W<C4_H> gw;
+  col_gemm4_fetch<C4_H>(gw, p.wp4, C4_NT, wv, lane);
 
   int red_flip = 0;
   auto col_sum = [&](float x) -> float { return pe_col_sum4(x, red, red_flip, wv, lane, col); };
@@ -197,10 +137,10 @@ __global__ __launch_bounds__(256) void dds_layer4_kernel(DdsP p) {
   __syncthreads();
 
   // ---- phase 2: P <- per-wave partial products of W1x1 . Y
-  col_gemm4_run(gw, C4_NT, YT, P, wv, lane);
+  col_gemm4_run<C4_H>(gw, YT, P, wv, lane);
   // the following 1x1 conv's fragments (last layer of a DDSConv): requested now, in flight under phase 3
   const int post_nt = p.post_w4 ? (p.post_rows + 63) / 64 : 0;
-  if (p.post_w4) col_gemm4_fetch(gw, p.post_w4, post_nt, wv, lane);
+  if (p.post_w4) col_gemm4_fetch<C4_H>(gw, p.post_w4, post_nt, wv, lane);
   __syncthreads();
 
   // ---- phase 3: LN2, GELU, residual -> out
@@ -234,7 +174,7 @@ __global__ __launch_bounds__(256) void dds_layer4_kernel(DdsP p) {
 #pragma unroll
   for (int k = 0; k < NVT; ++k) pbv[k] = pe_row_load(pbd2, rl + 64 * k);      // rows >= post_rows: 0
   __syncthreads();                                // YT complete; every phase-3 read of P done
-  col_gemm4_run(gw, post_nt, YT, P, wv, lane);
+  col_gemm4_run<C4_H>(gw, YT, P, wv, lane);
   __syncthreads();
   if (p.post_out && ok) {
     float* po = p.post_out + (long)b * p.po_bs;

@@ -54,6 +54,14 @@ void lngemm(dim3 grid, size_t smem, hipStream_t stream, const LnGemmP& p) {
   PE_LAUNCH(lngemm_kernel<6>, grid, dim3(512), smem, stream, p);
 }
 
+void colchain4(dim3 grid, size_t smem, hipStream_t stream, const ColP& p) {
+  PE_LAUNCH(colchain4_kernel, grid, dim3(256), smem, stream, p);
+}
+
+void lngemm4(dim3 grid, size_t smem, hipStream_t stream, const LnGemmP& p) {
+  PE_LAUNCH(lngemm4_kernel, grid, dim3(256), smem, stream, p);
+}
+
 void cf_pre(dim3 grid, hipStream_t stream, const float* z0, long z_bs, const float* w, const float* bias, const float* xg,
             long g_bs, int g_cs, float* out, long o_bs, int o_cs, const int* lens, int H) {
   PE_LAUNCH(cf_pre_kernel, grid, dim3(64), 0, stream, z0, z_bs, w, bias, xg, g_bs, g_cs, out, o_bs, o_cs, lens, H);

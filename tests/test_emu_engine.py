@@ -356,11 +356,12 @@ def test_emulated_generator_tail_inside_the_last_stage_kernel(emu_lib, monkeypat
 @pytest.mark.parametrize("col4", ["0", "1"])
 def test_emulated_192_channel_small_call_kernels(emu_lib, monkeypatch, col4):
     """The kernels compiled for exactly 192 hidden channels (the reference's medium / high qualities) on a voice that
-    is tiny everywhere else: colchain_kernel, lngemm_kernel, attn_kernel<96> and the duration predictor's DDSConv layers
-    in both forms -- dds_layer16_kernel (PIPER_HIP_COL4=0) and the 4-column dds_layer4_kernel on the 4x4x1 MFMA
-    (kernels/dds4.h) -- against the oracle: equal integer durations, logw and waveform."""
+    is tiny everywhere else: attn_kernel<96> and the small-call chains in both forms -- colchain_kernel, lngemm_kernel,
+    dds_layer16_kernel on 16-column workgroups (PIPER_HIP_COL4=0) and colchain4_kernel, lngemm4_kernel,
+    dds_layer4_kernel on 4-column workgroups with the 4x4x1 MFMA (kernels/col4.h, dds4.h) -- against the oracle: equal
+    integer durations, logw and waveform."""
     monkeypatch.setenv("PIPER_HIP_COL4", col4)
-    cfg = W.preset("tiny", hidden=192, inter=192, filter=64, n_layers=1)
+    cfg = W.preset("tiny", hidden=192, inter=192, filter=64, n_layers=2)
     w = W.synthetic_weights(cfg, 1234)
     lens = [9, 5]
     ids = [W.synthetic_phoneme_ids(T, i, id_max=cfg.n_vocab - 1) for i, T in enumerate(lens)]
@@ -369,8 +370,11 @@ def test_emulated_192_channel_small_call_kernels(emu_lib, monkeypatch, col4):
     eng.profile_enable(2)
     r = eng.synthesize_batch(ids, (0.0, 1.0, 0.8), noise_w=nw)
     names = {row["name"] for row in eng.profile()[5:] if row["launches"]}
-    assert {"colchain_kernel<6>", "lngemm_kernel<6>", "attn_kernel<96>"} <= names
-    assert ("dds_layer4_kernel" in names) == (col4 == "1") and ("dds_layer16_kernel<6>" in names) == (col4 == "0")
+    assert "attn_kernel<96>" in names
+    assert ({"colchain4_kernel", "lngemm4_kernel", "dds_layer4_kernel"} if col4 == "1" else
+            {"colchain_kernel<6>", "lngemm_kernel<6>", "dds_layer16_kernel<6>"}) <= names
+    assert not ({"colchain_kernel<6>", "lngemm_kernel<6>", "dds_layer16_kernel<6>"} if col4 == "1" else
+                {"colchain4_kernel", "lngemm4_kernel", "dds_layer4_kernel"}) & names
     durs = eng.durations()
     off = np.concatenate([[0], np.cumsum(lens)])
     for i, T in enumerate(lens):

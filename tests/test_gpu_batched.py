@@ -183,7 +183,8 @@ FORCED = [
     # the duration predictor with ConvFlow.pre / proj / spline as separate launches (default: fused into the DDSConv layers)
     ("medium", [128, 31], {"PIPER_HIP_FUSE_DP": 0}, {"conv_splitk_kernel<1,false,8,4>"}),
     # conv_o + LN and coupling post + next pre as single launches (colchain_kernel): forced on for a batch, and off
-    ("medium", [128, 77, 16, 33], {"PIPER_HIP_COLCHAIN": 2}, {"colchain_kernel<6>", "lngemm_kernel<6>"}),
+    ("medium", [128, 77, 16, 33], {"PIPER_HIP_COLCHAIN": 2, "PIPER_HIP_COL4": 0}, {"colchain_kernel<6>", "lngemm_kernel<6>"}),
+    ("medium", [128, 77, 16, 33], {"PIPER_HIP_COLCHAIN": 2}, {"colchain4_kernel", "lngemm4_kernel", "dds_layer4_kernel"}),
     ("medium", [128, 31], {"PIPER_HIP_COLCHAIN": 0}, {"ln_kernel", "conv_splitk_kernel<1,false,4,4>"}),
     # sibling resblock convs of the 128-channel stage as grouped launches (64- and 128-column slabs), and one by one
     # (the last step, whose outputs the MRF only sums, is one GEMM over the concatenated K; GROUP_MRF=2: kept apart)
@@ -200,10 +201,11 @@ FORCED = [
     ("medium", [128, 17], {"PIPER_HIP_SPLITK16": 3},
      {"conv_splitk16_kernel<true,12,2>", "conv_splitk16_kernel<false,8,4>"}),
     ("high", [48], {"PIPER_HIP_SPLITK_MAX": 0}, {"conv_mfma_kernel<2,2,2,1,16,true,64>"}),
-    # DDSConv layers of the duration predictor: the 4-column form on the 4x4x1 MFMA (default for small calls) forced
+    # the 192-channel small-call chains (DDSConv layers, colchain, lngemm): the 4-column forms on the 4x4x1 MFMA (default for small calls) forced
     # on for a ragged batch beyond its column limit, and off (the 16-column form)
-    ("medium", [128, 77, 16, 33, 3, 1, 128, 90, 128, 128], {"PIPER_HIP_COL4": 2}, {"dds_layer4_kernel"}),
-    ("medium", [128, 31], {"PIPER_HIP_COL4": 0}, {"dds_layer16_kernel<6>"}),
+    ("medium", [128, 77, 16, 33, 3, 1, 128, 90, 128, 128], {"PIPER_HIP_COL4": 2},
+     {"dds_layer4_kernel", "colchain4_kernel", "lngemm4_kernel"}),
+    ("medium", [128, 31], {"PIPER_HIP_COL4": 0}, {"dds_layer16_kernel<6>", "colchain_kernel<6>", "lngemm_kernel<6>"}),
 ]
 
 
