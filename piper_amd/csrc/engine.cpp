@@ -465,6 +465,10 @@ void Engine::init(const WeightSet& ws) {
                                  1, -1, true, 0, 0));
         r.rs.push_back(pack_conv(ws, p + ".enc.res_skip_layers." + s + ".weight",
                                  p + ".enc.res_skip_layers." + s + ".bias", 1, -1, false, 0, 0));
+        {
+          const HostTensor& wrs = ws.get(p + ".enc.res_skip_layers." + s + ".weight");
+          r.rs4.push_back(wrs.dims.size() == 3 && wrs.dims[2] == 1 ? pack4(wrs.data, (int)wrs.dims[0], (int)wrs.dims[1]) : nullptr);
+        }
         (void)wnk;
       }
       r.post = pack_conv(ws, p + ".post.weight", p + ".post.bias", 1, -1, false, 0, odd);
@@ -1610,7 +1614,21 @@ void Engine::issue_flow() {
     for (int i = 0; i < nl; ++i) {
       const float* b2 = nspk_ > 1 ? cond_ + cond_off_wn_[ri] + (long)i * 2 * H_ : nullptr;
       conv(r.in[i], fh, facts, lens_b_, 1, Fmax, EPI_GATE, 1.f, ACT_NONE, none, none, 0, 1.f, b2, cond_bs_);
-      conv(r.rs[i], facts, fh, lens_b_, 1, Fmax, EPI_WNRS, 1.f, ACT_NONE, none, fskip, i == 0 ? 1 : 0);
+      if (r.rs4[i] && use_col4((long)B * Fmax) && H_ == 192 && r.rs[i].rows <= 2 * H_) {
+        // small calls: the res/skip 1x1 conv on 4-column workgroups (colchain4_kernel mode 2), one part per 192 rows
+        ColP cp{};
+        cp.in1 = facts.p; cp.in1_bs = facts.bs; cp.in1_cs = facts.cs; cp.K1 = H_;
+        cp.w1 = r.rs4[i]; cp.b1 = r.rs[i].bias; cp.rows1 = r.rs[i].rows;
+        cp.mode = 2; cp.first = i == 0 ? 1 : 0;
+        cp.x1 = fh.p; cp.x1_bs = fh.bs; cp.x1_cs = fh.cs;
+        cp.out = fskip.p; cp.out_bs = fskip.bs; cp.out_cs = fskip.cs;
+        cp.lens = lens_b_;
+        const int kh4 = kbegin(prof_level_ >= 2 ? krow("colchain4_kernel") : 0, 2.0 * fsum * r.rs[i].macs_per_col);
+        launch::colchain4(dim3((Fmax + 3) / 4, B, (cp.rows1 + 191) / 192), col4_smem(), stream_, cp);
+        kend(kh4);
+      } else {
+        conv(r.rs[i], facts, fh, lens_b_, 1, Fmax, EPI_WNRS, 1.f, ACT_NONE, none, fskip, i == 0 ? 1 : 0);
+      }
       fl += 2.0 * fsum * (r.in[i].macs_per_col + r.rs[i].macs_per_col);
     }
     if (chain) {

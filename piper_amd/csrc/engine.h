@@ -257,6 +257,7 @@ class Engine {
     PackedConv pre, post;
     float *pre16 = nullptr, *post16 = nullptr;   // the same two 1x1 convs in pack16 order (colchain_kernel)
     std::vector<PackedConv> in, rs;
+    std::vector<const float*> rs4;   // the res/skip 1x1 convs in pack4 order (colchain4_kernel mode 2; null: not packed)
     int in_off, out_off;             // channel offsets of x0 / x1 in the physical (unflipped) layout
   };
   std::vector<Rcl> rcls_;            // in execution order

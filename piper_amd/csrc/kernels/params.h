@@ -116,6 +116,7 @@ struct ColP {
   const float* w2; const float* b2; int rows2;          // w2 == null: no second GEMM (last coupling layer)
   float* out2; long o2_bs; int o2_cs;
   const int* lens;
+  int first;                                            // mode 2 (colchain4_kernel): first WN layer -- the skip sum is not read
 };
 struct LnGemmP {
   const float* in; long in_bs; int in_cs;        // y = x + ffn(x)
