@@ -307,6 +307,46 @@ float* Engine::pack4(const std::vector<float>& W, int rows, int K) {
   return dev_alloc(np, skeleton_ ? nullptr : P.data());
 }
 
+// FFN weights in ffn_kernel's per-slice orders (kernels/ffn.h). conv_1 [FC][192][3] ->
+// [slice][tile 3][wave 4][tap 3][quad 3][lane][4]: row 48 slice + 16 tile + (lane & 15), channel 48 wave + 4 (4 quad + j) + (lane >> 4).
+const float* Engine::pack_ffn1(const WeightSet& ws, const std::string& wname) {
+  const HostTensor& w = ws.get(wname);
+  if (w.dims.size() != 3 || w.dims[1] != 192 || w.dims[2] != 3 || w.dims[0] % 48 || w.dims[0] / 48 > 16) return nullptr;
+  const int FC = (int)w.dims[0], S = FC / 48;
+  const size_t np = (size_t)FC * 192 * 3;
+  std::vector<float> P(skeleton_ ? 0 : np, 0.f);
+  for (int s = 0; s < (skeleton_ ? 0 : S); ++s)
+    for (int m = 0; m < 3; ++m)
+      for (int wv = 0; wv < 4; ++wv)
+        for (int tp = 0; tp < 3; ++tp)
+          for (int q = 0; q < 3; ++q)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int j = 0; j < 4; ++j) {
+                const int row = 48 * s + 16 * m + (lane & 15), ch = 48 * wv + 4 * (4 * q + j) + (lane >> 4);
+                P[(((((size_t)(s * 3 + m) * 4 + wv) * 3 + tp) * 3 + q) * 64 + lane) * 4 + j] = w.data[((size_t)row * 192 + ch) * 3 + tp];
+              }
+  return dev_alloc(np, skeleton_ ? nullptr : P.data());
+}
+// conv_2 [192][FC][3] -> [slice][row tile 12][tap 3][quad 3][lane][4]: row 16 tile + (lane & 15), hidden channel
+// 48 slice + 4 (4 quad + j) + (lane >> 4).
+const float* Engine::pack_ffn2(const WeightSet& ws, const std::string& wname) {
+  const HostTensor& w = ws.get(wname);
+  if (w.dims.size() != 3 || w.dims[0] != 192 || w.dims[2] != 3 || w.dims[1] % 48 || w.dims[1] / 48 > 16) return nullptr;
+  const int FC = (int)w.dims[1], S = FC / 48;
+  const size_t np = (size_t)FC * 192 * 3;
+  std::vector<float> P(skeleton_ ? 0 : np, 0.f);
+  for (int s = 0; s < (skeleton_ ? 0 : S); ++s)
+    for (int rt = 0; rt < 12; ++rt)
+      for (int tp = 0; tp < 3; ++tp)
+        for (int q = 0; q < 3; ++q)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 4; ++j) {
+              const int row = 16 * rt + (lane & 15), hid = 48 * s + 4 * (4 * q + j) + (lane >> 4);
+              P[((((size_t)(s * 12 + rt) * 3 + tp) * 3 + q) * 64 + lane) * 4 + j] = w.data[((size_t)row * FC + hid) * 3 + tp];
+            }
+  return dev_alloc(np, skeleton_ ? nullptr : P.data());
+}
+
 // A 1x1 conv weight [Co][Ci][1] (optionally with reversed input / output channels: the Flip folded in) in pack16 order
 float* Engine::pack16_conv(const WeightSet& ws, const std::string& wname, int in_rev, int out_rev) {
   const HostTensor& w = ws.get(wname);
@@ -403,6 +443,10 @@ void Engine::init(const WeightSet& ws) {
     e.b1 = dev_tensor(ws, "enc_p.encoder.norm_layers_1." + s + ".beta");
     e.f1 = pack_conv(ws, f + ".conv_1.weight", f + ".conv_1.bias", 1, padl_ffn, false, 0, 0);
     e.f2 = pack_conv(ws, f + ".conv_2.weight", f + ".conv_2.bias", 1, padl_ffn, false, 0, 0);
+    if (H_ == 192 && ksz_ == 3 && padl_ffn == 1) {     // the fused small-call FFN (kernels/ffn.h)
+      e.f1p = pack_ffn1(ws, f + ".conv_1.weight");
+      e.f2p = pack_ffn2(ws, f + ".conv_2.weight");
+    }
     e.g2 = dev_tensor(ws, "enc_p.encoder.norm_layers_2." + s + ".gamma");
     e.b2 = dev_tensor(ws, "enc_p.encoder.norm_layers_2." + s + ".beta");
     enc_.push_back(e);
@@ -604,6 +648,7 @@ void Engine::init(const WeightSet& ws) {
   if (const char* t = getenv("PIPER_HIP_FUSE_DP")) fuse_dp_ = atoi(t) != 0;           // A/B knob, tests
   if (const char* t = getenv("PIPER_HIP_COL4")) col4_ = atoi(t);                      // A/B knob, tests
   if (const char* t = getenv("PIPER_HIP_COL4_MAXC")) col4_max_cols_ = atol(t);
+  if (const char* t = getenv("PIPER_HIP_FFN")) ffn_ = atoi(t);                        // A/B knob, tests
   if (const char* t = getenv("PIPER_HIP_SPEC")) spec_enable_ = atoi(t) != 0;          // speculative stage B (A/B, tests)
 }
 
@@ -641,6 +686,7 @@ void Engine::free_all() {
   for (hipEvent_t e : ev_pool_) hipEventDestroy(e);
   ev_pool_.clear();
   for (float*& p : side_) { if (p) hipFree(p); p = nullptr; }
+  if (ffn_parts_) { hipFree(ffn_parts_); ffn_parts_ = nullptr; }
   if (stream_) hipStreamDestroy(stream_);
   wsA_ = wsB_ = nullptr; h_audio_ = nullptr; h_pcm_ = nullptr; h_pcm_zc_ = nullptr; h_frames_ = nullptr;
   ev0_ = ev1_ = nullptr; stream_ = nullptr;
@@ -663,6 +709,11 @@ struct Carver {
 };
 
 void Engine::ensure_stage_a(int B, int Tmax) {
+  if (!ffn_parts_ && H_ == 192 && FC_ % 48 == 0 && FC_ / 48 <= 16 && !enc_.empty() && enc_[0].f1p) {
+    // partial outputs of the fused small-call FFN (kernels/ffn.h): [utterance][slice][192][columns], once
+    PE_HIP(hipStreamSynchronize(stream_));
+    PE_HIP(hipMalloc((void**)&ffn_parts_, (size_t)(FC_ / 48) * H_ * ffn_max_cols_ * sizeof(float)));
+  }
   const int Ts = rup(Tmax, 128);    // row strides are multiples of 128 columns (conv epilogue relies on it)
   bool grow = false;
   if ((size_t)B > capA_B_) { capA_B_ = B; grow = true; }
@@ -1263,7 +1314,7 @@ int Engine::krow(const std::string& name) {
   return (int)prof_.size() - 1;
 }
 void Engine::lngemm(View y, const float* g, const float* b, View x, const float* w16, const float* bias, int rows,
-                    View out, int T, double flops) {
+                    View out, int T, double flops, const float* parts, int nparts, const float* pbias) {
   LnGemmP p{};
   p.in = y.p; p.in_bs = y.bs; p.in_cs = y.cs;
   p.gamma = g; p.beta = b;
@@ -1272,6 +1323,12 @@ void Engine::lngemm(View y, const float* g, const float* b, View x, const float*
   p.out = out.p; p.o_bs = out.bs; p.o_cs = out.cs;
   p.lens = d_tlens_;
   // small calls: 4-column workgroups on the 4x4x1 MFMA (kernels/col4.h), like Engine::dds
+  if (parts) {        // y = (View y: the residual) + pbias + the fused FFN's partial outputs (ffn_kernel)
+    const int Tp = rup(T, 4);
+    p.parts = parts; p.nparts = nparts; p.pbias = pbias;
+    p.p_bs = (long)nparts * H_ * Tp;
+    if (!(use_col4((long)B_ * T) && w4_of(w16))) throw std::runtime_error("internal: FFN partials without the 4-column consumer");
+  }
   if (const float* w4 = use_col4((long)B_ * T) ? w4_of(w16) : nullptr) {
     p.w16 = w4;
     const int kh4 = kbegin(prof_level_ >= 2 ? krow("lngemm4_kernel") : 0, flops);
@@ -1426,7 +1483,8 @@ void Engine::issue_stage_a() {
   const int B = B_, Ts = Ts_, T = Tg_;
   const long bsH = (long)H_ * Ts;
   auto V = [&](float* p, int ch) { return View{p, (long)ch * Ts, Ts}; };
-  const View x = V(x_, H_), y = V(y_, H_), qkv = V(qkv_, 3 * H_), att = V(att_, H_), ffh = V(ffh_, FC_),
+  View x = V(x_, H_), y = V(y_, H_);
+  const View qkv = V(qkv_, 3 * H_), att = V(att_, H_), ffh = V(ffh_, FC_),
              stats = V(stats_, 2 * C_), xg = V(xg_, H_), dh = V(dh_, H_), dy = V(dy_, H_), dy2 = V(dy2_, H_),
              hproj = V(hproj_, 32);
   const View none{nullptr, 0, 0};
@@ -1455,10 +1513,22 @@ void Engine::issue_stage_a() {
   // conv_o + residual + norm_layers_1 as another (colchain_kernel); otherwise conv, then ln_kernel.
   const float *pg = nullptr, *pb = nullptr;        // pending norm_layers_2 of the previous layer (input still in y)
   const bool chain_q = use_colchain(tsum, colchain_max_ids_, H_, 96);
+  // Small calls: the FFN as ONE launch that leaves FC/48 partial outputs for lngemm4_kernel to sum (kernels/ffn.h). That
+  // consumer then reads the residual from x and writes LN(y) to the other buffer (its parts read x concurrently): x / y
+  // swap roles per layer.
+  bool ffn_fused = ffn_ && chain_q && use_col4((long)B * T) && ffn_parts_ && (long)B * rup(T, 4) <= ffn_max_cols_ &&
+                   FC_ % 48 == 0 && FC_ / 48 <= 16 && w4_of(enc_proj16_);
+  for (auto& e : enc_) ffn_fused = ffn_fused && e.f1p && e.f2p && w4_of(e.qkv16);
+  const int nsl = FC_ / 48;
+  const float* pend_bias = nullptr;                // conv_2 bias of the layer whose partial outputs are pending
   for (auto& e : enc_) {
-    if (pg) lngemm(y, pg, pb, x, e.qkv16, e.qkv.bias, 3 * H_, qkv, T, 2.0 * tsum * e.qkv.macs_per_col);
+    if (pg && pend_bias) {
+      lngemm(x, pg, pb, y, e.qkv16, e.qkv.bias, 3 * H_, qkv, T, 2.0 * tsum * e.qkv.macs_per_col, ffn_parts_, nsl, pend_bias);
+      std::swap(x, y);
+    } else if (pg) lngemm(y, pg, pb, x, e.qkv16, e.qkv.bias, 3 * H_, qkv, T, 2.0 * tsum * e.qkv.macs_per_col);
     else conv(e.qkv, x, qkv, d_tlens_, 1, T, EPI_STORE);
     pg = pb = nullptr;
+    pend_bias = nullptr;
     AttnP ap;
     ap.qkv = qkv_; ap.q_bs = (long)3 * H_ * Ts; ap.q_cs = Ts;
     ap.relk = e.relk; ap.relv = e.relv;
@@ -1492,15 +1562,33 @@ void Engine::issue_stage_a() {
       conv(e.o, att, y, d_tlens_, 1, T, EPI_RESADD, 1.f, ACT_NONE, x);
     }
     if (!chain_o) layer_norm(y, x, e.g1, e.b1, H_, d_tlens_, T);
-    conv(e.f1, x, ffh, d_tlens_, 1, T, EPI_STORE, 1.f, ACT_RELU);
-    conv(e.f2, ffh, y, d_tlens_, 1, T, EPI_RESADD, 1.f, ACT_NONE, x);
+    if (ffn_fused) {
+      FfnP fp{};
+      const int Tp = rup(T, 4);
+      fp.x = x.p; fp.x_bs = x.bs; fp.x_cs = x.cs;
+      fp.w1p = e.f1p; fp.b1 = e.f1.bias; fp.w2p = e.f2p;
+      fp.parts = ffn_parts_; fp.nslices = nsl; fp.p_bs = (long)nsl * H_ * Tp;
+      fp.lens = d_tlens_;
+      const int khf = kbegin(prof_level_ >= 2 ? krow("ffn_kernel") : 0, 2.0 * tsum * (e.f1.macs_per_col + e.f2.macs_per_col));
+      const size_t smemf = ((size_t)192 * 48 + 4 * 48 * 16 + 48 * 48) * sizeof(float);
+      launch::ffn(dim3((T + 11) / 12, nsl, B), smemf, stream_, fp);
+      kend(khf);
+      pend_bias = e.f2.bias;
+    } else {
+      conv(e.f1, x, ffh, d_tlens_, 1, T, EPI_STORE, 1.f, ACT_RELU);
+      conv(e.f2, ffh, y, d_tlens_, 1, T, EPI_RESADD, 1.f, ACT_NONE, x);
+    }
     if (chain_q) { pg = e.g2; pb = e.b2; }
     else layer_norm(y, x, e.g2, e.b2, H_, d_tlens_, T);
     fl += 2.0 * tsum * (e.qkv.macs_per_col + e.o.macs_per_col + e.f1.macs_per_col + e.f2.macs_per_col);
     for (int b = 0; b < B; ++b) fl += 2.0 * 2.0 * (double)tlens_h_[b] * tlens_h_[b] * H_;
   }
-  if (pg) lngemm(y, pg, pb, x, enc_proj16_, enc_proj_.bias, enc_proj_.rows, stats, T, 2.0 * tsum * enc_proj_.macs_per_col);
+  if (pg && pend_bias) {
+    lngemm(x, pg, pb, y, enc_proj16_, enc_proj_.bias, enc_proj_.rows, stats, T, 2.0 * tsum * enc_proj_.macs_per_col, ffn_parts_, nsl, pend_bias);
+    std::swap(x, y);
+  } else if (pg) lngemm(y, pg, pb, x, enc_proj16_, enc_proj_.bias, enc_proj_.rows, stats, T, 2.0 * tsum * enc_proj_.macs_per_col);
   else conv(enc_proj_, x, stats, d_tlens_, 1, T, EPI_STORE);
+  xenc_ = x.p;
   fl += 2.0 * tsum * enc_proj_.macs_per_col;
   prof_end(0, fl);
 
@@ -2149,7 +2237,7 @@ void Engine::debug_tensor(const std::string& name, int b, std::vector<float>& ou
   const float* src = nullptr;
   int R = 0, Cn = 0;
   long stride = 0;
-  if (name == "x_enc") { src = x_ + (size_t)b * H_ * Ts_; R = H_; Cn = tlens_h_[b]; stride = Ts_; }
+  if (name == "x_enc") { src = (xenc_ ? xenc_ : x_) + (size_t)b * H_ * Ts_; R = H_; Cn = tlens_h_[b]; stride = Ts_; }
   else if (name == "stats") { src = stats_ + (size_t)b * 2 * C_ * Ts_; R = 2 * C_; Cn = tlens_h_[b]; stride = Ts_; }
   else if (name == "xg") { src = xg_ + (size_t)b * H_ * Ts_; R = H_; Cn = tlens_h_[b]; stride = Ts_; }
   else if (name == "logw") { src = logw_ + (size_t)b * Ts_; R = 1; Cn = tlens_h_[b]; stride = Ts_; }

@@ -172,6 +172,15 @@ class Engine {
   // [64-row tile][k quad][lane][4]; looked up by its pack16 pointer (null: not packed)
   float* pack4(const std::vector<float>& W, int rows, int K);
   std::unordered_map<const float*, const float*> w4_of_;
+  // fused FFN for small calls (kernels/ffn.h): per-slice weight orders, the partial-output buffer [b][slice][192][Tp]
+  // (allocated once for ffn_max_cols_ columns), and the buffer that holds the encoder output after the last layer (the
+  // fused path ping-pongs x_ / y_: lngemm4_kernel must not write LN(y) over the residual other parts still read)
+  const float* pack_ffn1(const WeightSet& ws, const std::string& wname);
+  const float* pack_ffn2(const WeightSet& ws, const std::string& wname);
+  float* ffn_parts_ = nullptr;
+  static constexpr long ffn_max_cols_ = 2048;
+  int ffn_ = 1;                             // PIPER_HIP_FFN=0: conv by conv (A/B, tests)
+  float* xenc_ = nullptr;
   const float* w4_of(const float* w16) const { auto it = w4_of_.find(w16); return it == w4_of_.end() ? nullptr : it->second; }
   float* dp_proj16_ = nullptr;
   int colchain_ = 1;                        // PIPER_HIP_COLCHAIN: 0 off, 1 by batch size, 2 always (A/B, tests)
@@ -184,7 +193,7 @@ class Engine {
   }
   void colchain(const struct ColP& p, int B, int Lmax, double flops);
   void lngemm(View y, const float* g, const float* b, View x, const float* w16, const float* bias, int rows, View out,
-              int T, double flops);
+              int T, double flops, const float* parts = nullptr, int nparts = 0, const float* pbias = nullptr);
   float* pack16_conv(const WeightSet& ws, const std::string& wname, int in_rev, int out_rev);
   int col4_ = 1;                            // PIPER_HIP_COL4: 4-column workgroups for the DDSConv layers: 0 off, 1 up to col4_max_cols_ columns per call, 2 always (A/B, tests)
   long col4_max_cols_ = 1024;
@@ -233,6 +242,7 @@ class Engine {
     PackedConv qkv, o, f1, f2;
     float* o16 = nullptr;                        // conv_o in pack16 order (colchain_kernel)
     float* qkv16 = nullptr;                      // the fused q/k/v matrix in pack16 order (lngemm_kernel)
+    const float *f1p = nullptr, *f2p = nullptr;   // conv_1 / conv_2 in ffn_kernel's per-slice order (kernels/ffn.h; null: not packed)
     float *relk, *relv, *g1, *b1, *g2, *b2;
   };
   std::vector<EncLayer> enc_;

@@ -21,6 +21,7 @@ __device__ __forceinline__ int c4_tile(int bx, int nx) {
 }
 
 // ---- the 4-column GEMM: rows <= 192 x K (192 or 96) over the 4 columns in YT[4][K + 4] on the 4x4x1 MFMA
+constexpr int FFN_MAXS = 16;                          // slices of the fused FFN's hidden dimension (ffn.h): FC <= 768
 constexpr int C4_H = 192, C4_NT = C4_H / 64;          // output rows of one call, 64-row tiles
 template <int K>
 struct Col4W {
@@ -247,6 +248,28 @@ __global__ __launch_bounds__(256) void lngemm4_kernel(LnGemmP p) {
       gg[k] = pe_row_load(gd, c);
       bb[k] = pe_row_load(bd, c);
       cb[k] = pe_row_load(cbd, c);
+    }
+    if (p.parts) {
+      // y = x + (conv_2 bias + the FFN's partial outputs, summed in slice order): every load in flight at once
+      const pe_rowsrc pbd = pe_make_row(p.pbias, H);
+      float pv[NVT][FFN_MAXS];
+      float pbv[NVT];
+#pragma unroll
+      for (int k = 0; k < NVT; ++k) {
+        const int c = rl + 64 * k;
+        pbv[k] = pe_row_load(pbd, c);
+        // this workgroup's tile: one contiguous [slice][192][4] block
+        const pe_rowsrc pd = pe_make_row(p.parts + (long)b * p.p_bs + (long)(t0 >> 2) * p.nparts * (H * 4), p.nparts * (H * 4));
+#pragma unroll
+        for (int sl = 0; sl < FFN_MAXS; ++sl) pv[k][sl] = pe_row_load(pd, (ok && sl < p.nparts) ? sl * (H * 4) + c * 4 + col : -1);
+      }
+#pragma unroll
+      for (int k = 0; k < NVT; ++k) {
+        float a = pv[k][0];
+#pragma unroll
+        for (int sl = 1; sl < FFN_MAXS; ++sl) a += pv[k][sl];
+        v[k] = ok ? v[k] + (a + pbv[k]) : 0.f;
+      }
     }
   }
   int red_flip = 0;

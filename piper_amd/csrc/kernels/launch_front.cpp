@@ -5,6 +5,7 @@
 #include "colchain.h"
 #include "dds.h"
 #include "dds4.h"
+#include "ffn.h"
 #include "duration.h"
 #include "layernorm.h"
 #include "glue.h"
@@ -60,6 +61,10 @@ void colchain4(dim3 grid, size_t smem, hipStream_t stream, const ColP& p) {
 
 void lngemm4(dim3 grid, size_t smem, hipStream_t stream, const LnGemmP& p) {
   PE_LAUNCH(lngemm4_kernel, grid, dim3(256), smem, stream, p);
+}
+
+void ffn(dim3 grid, size_t smem, hipStream_t stream, const FfnP& p) {
+  PE_LAUNCH(ffn_kernel, grid, dim3(256), smem, stream, p);
 }
 
 void cf_pre(dim3 grid, hipStream_t stream, const float* z0, long z_bs, const float* w, const float* bias, const float* xg,

@@ -118,8 +118,19 @@ struct ColP {
   const int* lens;
   int first;                                            // mode 2 (colchain4_kernel): first WN layer -- the skip sum is not read
 };
+// ---- fused FFN (ffn.h): partial outputs per 48-row slice of the hidden dimension
+struct FfnP {
+  const float* x; long x_bs; int x_cs;           // norm_layers_1 output [192][T]
+  const float* w1p; const float* b1;             // conv_1: pack_ffn order per slice, bias [FC]
+  const float* w2p;                              // conv_2: pack_ffn order per slice (its bias is added by the consumer)
+  float* parts; long p_bs; int nslices;          // [utterance][4-column tile][slice][192][4], p_bs floats per utterance
+  const int* lens;
+};
 struct LnGemmP {
-  const float* in; long in_bs; int in_cs;        // y = x + ffn(x)
+  const float* in; long in_bs; int in_cs;        // y = x + ffn(x)  (parts != null: the residual x alone)
+  // lngemm4_kernel only: y = in + pbias + sum of the nparts partial FFN outputs (ffn_kernel), in slice order
+  const float* parts; long p_bs; int nparts;     // [utterance][4-column tile][slice][192][4]
+  const float* pbias;
   const float* gamma; const float* beta;
   float* xout; long x_bs; int x_cs;              // LN(y)
   const float* w16; const float* bias; int rows; // pack16 order, all parts; part z owns rows [32 NVT z, 32 NVT (z + 1))

@@ -358,12 +358,13 @@ def test_emulated_192_channel_small_call_kernels(emu_lib, monkeypatch, col4):
     """The kernels compiled for exactly 192 hidden channels (the reference's medium / high qualities) on a voice that
     is tiny everywhere else: attn_kernel<96> and the small-call chains in both forms -- colchain_kernel, lngemm_kernel,
     dds_layer16_kernel on 16-column workgroups (PIPER_HIP_COL4=0) and colchain4_kernel, lngemm4_kernel,
-    dds_layer4_kernel on 4-column workgroups with the 4x4x1 MFMA (kernels/col4.h, dds4.h) -- against the oracle: equal
-    integer durations, logw and waveform."""
+    dds_layer4_kernel on 4-column workgroups with the 4x4x1 MFMA (kernels/col4.h, dds4.h) plus the fused FFN (ffn_kernel:
+    two 48-row slices of the hidden dimension, three column tiles, partial outputs summed by lngemm4_kernel) -- against the
+    oracle: equal integer durations, logw and waveform."""
     monkeypatch.setenv("PIPER_HIP_COL4", col4)
-    cfg = W.preset("tiny", hidden=192, inter=192, filter=64, n_layers=2)
+    cfg = W.preset("tiny", hidden=192, inter=192, filter=96, n_layers=2)
     w = W.synthetic_weights(cfg, 1234)
-    lens = [9, 5]
+    lens = [9, 31]
     ids = [W.synthetic_phoneme_ids(T, i, id_max=cfg.n_vocab - 1) for i, T in enumerate(lens)]
     nw = np.random.default_rng(5).standard_normal((len(lens), 2, max(lens))).astype(np.float32)
     eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
@@ -371,10 +372,10 @@ def test_emulated_192_channel_small_call_kernels(emu_lib, monkeypatch, col4):
     r = eng.synthesize_batch(ids, (0.0, 1.0, 0.8), noise_w=nw)
     names = {row["name"] for row in eng.profile()[5:] if row["launches"]}
     assert "attn_kernel<96>" in names
-    assert ({"colchain4_kernel", "lngemm4_kernel", "dds_layer4_kernel"} if col4 == "1" else
+    assert ({"colchain4_kernel", "lngemm4_kernel", "dds_layer4_kernel", "ffn_kernel"} if col4 == "1" else
             {"colchain_kernel<6>", "lngemm_kernel<6>", "dds_layer16_kernel<6>"}) <= names
     assert not ({"colchain_kernel<6>", "lngemm_kernel<6>", "dds_layer16_kernel<6>"} if col4 == "1" else
-                {"colchain4_kernel", "lngemm4_kernel", "dds_layer4_kernel"}) & names
+                {"colchain4_kernel", "lngemm4_kernel", "dds_layer4_kernel", "ffn_kernel"}) & names
     durs = eng.durations()
     off = np.concatenate([[0], np.cumsum(lens)])
     for i, T in enumerate(lens):

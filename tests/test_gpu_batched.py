@@ -45,7 +45,7 @@ def make_engine(monkeypatch, cfg, w, env=None):
               "PIPER_HIP_WIDE_SPLITK", "PIPER_HIP_DEBUG_KEEP", "PIPER_HIP_MRF", "PIPER_HIP_FUSE_DP",
               "PIPER_HIP_MRF_MAXF", "PIPER_HIP_SPEC", "PIPER_HIP_COLCHAIN", "PIPER_HIP_GROUP_MRF", 
               "PIPER_HIP_MRF_OU", "PIPER_HIP_MATRIX", "PIPER_HIP_BF3_MINF", "PIPER_HIP_MRF_TAIL", "PIPER_HIP_COL4",
-              "PIPER_HIP_COL4_MAXC"):
+              "PIPER_HIP_COL4_MAXC", "PIPER_HIP_FFN"):
         monkeypatch.delenv(k, raising=False)
     for k, v in (env or {}).items():
         monkeypatch.setenv(k, str(v))
@@ -206,6 +206,10 @@ FORCED = [
     ("medium", [128, 77, 16, 33, 3, 1, 128, 90, 128, 128], {"PIPER_HIP_COL4": 2},
      {"dds_layer4_kernel", "colchain4_kernel", "lngemm4_kernel"}),
     ("medium", [128, 31], {"PIPER_HIP_COL4": 0}, {"dds_layer16_kernel<6>", "colchain_kernel<6>", "lngemm_kernel<6>"}),
+    # the encoder FFN as one launch with partial outputs per 48-row slice of the hidden dimension (default for small
+    # calls), and conv by conv behind the 4-column chains
+    ("medium", [128, 13, 14, 15, 29], {}, {"ffn_kernel", "lngemm4_kernel"}),
+    ("medium", [128, 31], {"PIPER_HIP_FFN": 0}, {"lngemm4_kernel", "conv_splitk16_kernel<false,8,4>"}),
 ]
 
 
