@@ -456,6 +456,7 @@ void Engine::init(const WeightSet& ws) {
 
   // ---- duration predictor (reverse path)
   dp_pre_ = pack_conv(ws, "dp.pre.weight", "dp.pre.bias", 1, -1, false, 0, 0);
+  dp_pre16_ = (H_ == 192) ? pack16_conv(ws, "dp.pre.weight", 0, 0) : nullptr;      // its pack4 twin: colchain4_kernel mode 3
   dp_dds_ = load_dds(ws, "dp.convs");
   dp_proj_ = pack_conv(ws, "dp.proj.weight", "dp.proj.bias", 1, -1, false, 0, 0);
   {
@@ -1342,8 +1343,28 @@ void Engine::lngemm(View y, const float* g, const float* b, View x, const float*
   kend(kh);
 }
 
+// A plain 1x1 conv over 192 input channels of a small call on 4-column workgroups (colchain4_kernel mode 3); false: the
+// caller launches the conv kernel instead. `w16`: the conv's pack16 matrix (its pack4 twin is looked up).
+bool Engine::conv1x1_col4(const float* w16, const float* bias, int rows, View in, View out, const int* lens, int B, int Lmax,
+                          double flops, const float* bias2, long bias2_bs) {
+  const float* w4 = (H_ == 192 && use_col4((long)B * Lmax)) ? w4_of(w16) : nullptr;
+  if (!w4) return false;
+  ColP cp{};
+  cp.in1 = in.p; cp.in1_bs = in.bs; cp.in1_cs = in.cs; cp.K1 = 192;
+  cp.w1 = w4; cp.b1 = bias; cp.rows1 = rows;
+  cp.mode = 3;
+  cp.res = bias2; cp.res_bs = bias2_bs;
+  cp.out = out.p; cp.out_bs = out.bs; cp.out_cs = out.cs;
+  cp.lens = lens;
+  const int kh4 = kbegin(prof_level_ >= 2 ? krow("colchain4_kernel") : 0, flops);
+  launch::colchain4(dim3((Lmax + 3) / 4, B, (rows + 191) / 192), col4_smem(), stream_, cp);
+  kend(kh4);
+  return true;
+}
+
 void Engine::colchain(const ColP& p, int B, int Lmax, double flops) {
-  if (use_col4((long)B * Lmax) && p.K1 == 192 && (p.mode == 0 ? p.rows1 == 192 : (p.rows1 == 96 && (!p.w2 || p.rows2 <= 192)))) {
+  // mode 1 runs on frames (coupling post + pre), mode 0 on ids: separate column limits (profiles/r03_notes.md)
+  if (col4_ && (col4_ == 2 || (long)B * Lmax <= (p.mode == 1 ? col4_max_frames_ : col4_max_cols_)) && p.K1 == 192 && (p.mode == 0 ? p.rows1 == 192 : (p.rows1 == 96 && (!p.w2 || p.rows2 <= 192)))) {
     const float* w1 = w4_of(p.w1);
     const float* w2 = p.w2 ? w4_of(p.w2) : nullptr;
     if (w1 && (!p.w2 || w2)) {
@@ -1526,7 +1547,8 @@ void Engine::issue_stage_a() {
       lngemm(x, pg, pb, y, e.qkv16, e.qkv.bias, 3 * H_, qkv, T, 2.0 * tsum * e.qkv.macs_per_col, ffn_parts_, nsl, pend_bias);
       std::swap(x, y);
     } else if (pg) lngemm(y, pg, pb, x, e.qkv16, e.qkv.bias, 3 * H_, qkv, T, 2.0 * tsum * e.qkv.macs_per_col);
-    else conv(e.qkv, x, qkv, d_tlens_, 1, T, EPI_STORE);
+    else if (!(chain_q && conv1x1_col4(e.qkv16, e.qkv.bias, 3 * H_, x, qkv, d_tlens_, B, T, 2.0 * tsum * e.qkv.macs_per_col)))
+      conv(e.qkv, x, qkv, d_tlens_, 1, T, EPI_STORE);
     pg = pb = nullptr;
     pend_bias = nullptr;
     AttnP ap;
@@ -1595,7 +1617,9 @@ void Engine::issue_stage_a() {
   // ================= stochastic duration predictor, reverse (models.py:63-71,108-117)
   prof_begin();
   fl = 0;
-  conv(dp_pre_, x, dy, d_tlens_, 1, T, EPI_STORE, 1.f, ACT_NONE, none, none, 0, 1.f, cb_dp, cond_bs_);
+  if (!(chain_q && dp_pre16_ && conv1x1_col4(dp_pre16_, dp_pre_.bias, dp_pre_.rows, x, dy, d_tlens_, B, T, 2.0 * tsum * dp_pre_.macs_per_col,
+                                             cb_dp, cond_bs_)))
+    conv(dp_pre_, x, dy, d_tlens_, 1, T, EPI_STORE, 1.f, ACT_NONE, none, none, 0, 1.f, cb_dp, cond_bs_);
   if (fuse_dp_) {
     DdsOpt o;                      // dp.proj fused after the last DDSConv layer (models.py:65)
     o.post_w16 = dp_proj16_; o.post_bias = dp_proj_.bias; o.post_rows = dp_proj_.rows; o.post_out = xg;
@@ -1702,7 +1726,7 @@ void Engine::issue_flow() {
     for (int i = 0; i < nl; ++i) {
       const float* b2 = nspk_ > 1 ? cond_ + cond_off_wn_[ri] + (long)i * 2 * H_ : nullptr;
       conv(r.in[i], fh, facts, lens_b_, 1, Fmax, EPI_GATE, 1.f, ACT_NONE, none, none, 0, 1.f, b2, cond_bs_);
-      if (r.rs4[i] && use_col4((long)B * Fmax) && H_ == 192 && r.rs[i].rows <= 2 * H_) {
+      if (r.rs4[i] && col4_ && (col4_ == 2 || (long)B * Fmax <= col4_max_frames_) && H_ == 192 && r.rs[i].rows <= 2 * H_) {
         // small calls: the res/skip 1x1 conv on 4-column workgroups (colchain4_kernel mode 2), one part per 192 rows
         ColP cp{};
         cp.in1 = facts.p; cp.in1_bs = facts.bs; cp.in1_cs = facts.cs; cp.K1 = H_;

@@ -183,6 +183,7 @@ class Engine {
   float* xenc_ = nullptr;
   const float* w4_of(const float* w16) const { auto it = w4_of_.find(w16); return it == w4_of_.end() ? nullptr : it->second; }
   float* dp_proj16_ = nullptr;
+  float* dp_pre16_ = nullptr;
   int colchain_ = 1;                        // PIPER_HIP_COLCHAIN: 0 off, 1 by batch size, 2 always (A/B, tests)
   // batch columns up to which colchain_kernel / lngemm_kernel replace conv + LayerNorm pairs: ids for the encoder,
   // frames for the flow. Measured (profiles/r02_notes.md): -3.5 % at B=1, -2.5 % at B=16, neutral at B=32, +1 % at B=64.
@@ -192,11 +193,14 @@ class Engine {
     return colchain_ && k1 == 192 && half == 96 && (colchain_ == 2 || cols <= (double)max_cols);
   }
   void colchain(const struct ColP& p, int B, int Lmax, double flops);
+  bool conv1x1_col4(const float* w16, const float* bias, int rows, View in, View out, const int* lens, int B, int Lmax,
+                    double flops, const float* bias2 = nullptr, long bias2_bs = 0);
   void lngemm(View y, const float* g, const float* b, View x, const float* w16, const float* bias, int rows, View out,
               int T, double flops, const float* parts = nullptr, int nparts = 0, const float* pbias = nullptr);
   float* pack16_conv(const WeightSet& ws, const std::string& wname, int in_rev, int out_rev);
   int col4_ = 1;                            // PIPER_HIP_COL4: 4-column workgroups for the DDSConv layers: 0 off, 1 up to col4_max_cols_ columns per call, 2 always (A/B, tests)
-  long col4_max_cols_ = 1024;
+  long col4_max_cols_ = 1024;               // ids per call (text encoder, duration predictor)
+  long col4_max_frames_ = 2048;             // frames per call (WN res/skip conv): the sweep in profiles/r03_notes.md
   bool use_col4(long cols) const { return col4_ && (col4_ == 2 || cols <= col4_max_cols_); }
   static size_t col4_smem() { return ((size_t)4 * 196 + 4 * 192 * 4 + 32 + 64 * 4) * sizeof(float); }   // YT | P | red | ZL (kernels/col4.h, dds4.h)
   bool fuse_dp_ = true;                     // PIPER_HIP_FUSE_DP=0: cf_pre / proj / spline as separate launches (A/B, tests)

@@ -94,6 +94,8 @@ __device__ __forceinline__ float pe_col_sum4(float v, float* red, int& flip, int
 //   mode 2   (4-column form only) WN res/skip conv (modules.py:200-208), grid.z = 192-row parts of W1:
 //            x1 += W1[res rows].in + b  (the WN hidden state, in place) ; out (+)= W1[skip rows].in + b  (the skip sum;
 //            `first`: not read). rows1 = 384: part 0 = res, part 1 = skip; rows1 = 192 (last WN layer): all skip.
+//   mode 3   (4-column form only) a plain 1x1 conv, grid.z = 192-row parts: out = W1.in + b1 (+ res[utterance][row], a
+//            per-utterance bias vector: the speaker conditioning of dp.pre) -- the first encoder layer's q/k/v, dp.pre.
 // 192 input channels, rows1 = 192 (mode 0) / 96 (mode 1), second GEMM 192 rows over the 96 updated channels.
 __global__ __launch_bounds__(256) void colchain4_kernel(ColP p) {
   PE_KTRACE(3);
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(256) void colchain4_kernel(ColP p) {
   const int tid = threadIdx.x, col = tid & 3, rl = tid >> 2, wv = PE_UNIFORM(tid >> 6), lane = tid & 63;
   const int t = t0 + col;
   const bool ok = t < L;
-  const int part = p.mode == 2 ? (int)blockIdx.z : 0, row0 = part * C4_H;
+  const int part = p.mode >= 2 ? (int)blockIdx.z : 0, row0 = part * C4_H;
   const int rows_here = p.rows1 - row0 < C4_H ? p.rows1 - row0 : C4_H;
   Col4W<K1> gw;                                  // first GEMM's fragments, in flight under the input staging
   col_gemm4_fetch<K1>(gw, p.w1 + (long)part * C4_NT * (K1 / 4) * 256, (rows_here + 63) / 64, wv, lane);
@@ -120,7 +122,8 @@ __global__ __launch_bounds__(256) void colchain4_kernel(ColP p) {
     const pe_rowsrc ind = pe_make_row(p.in1 + (long)b * p.in1_bs, K1 * p.in1_cs);
     const float* obp = p.mode == 0 ? p.res + (long)b * p.res_bs : (skip_part ? p.out + (long)b * p.out_bs : p.x1 + (long)b * p.x1_bs);
     const int ocs = p.mode == 0 ? p.res_cs : (skip_part ? p.out_cs : p.x1_cs);
-    const pe_rowsrc od = pe_make_row(obp, (skip_part && p.first) ? 0 : rows_here * ocs);
+    const pe_rowsrc od = p.mode == 3 ? pe_make_row(p.res ? p.res + (long)b * p.res_bs + row0 : p.w1, p.res ? rows_here : 0)
+                                     : pe_make_row(obp, (skip_part && p.first) ? 0 : rows_here * ocs);
     const pe_rowsrc gd = pe_make_row(p.mode == 0 ? p.gamma : p.w1, p.mode == 0 ? p.rows1 : 0);
     const pe_rowsrc bd = pe_make_row(p.mode == 0 ? p.beta : p.w1, p.mode == 0 ? p.rows1 : 0);
     const pe_rowsrc b1d = pe_make_row(p.b1 ? p.b1 + row0 : p.w1, p.b1 ? rows_here : 0);
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(256) void colchain4_kernel(ColP p) {
     for (int k = 0; k < NVT; ++k) {
       const int c = rl + 64 * k;
       xin[k] = pe_row_load(ind, ok ? c * p.in1_cs + t : -1);
-      ov[k] = pe_row_load(od, (ok && c < rows_here) ? c * ocs + t : -1);
+      ov[k] = pe_row_load(od, (ok && c < rows_here) ? (p.mode == 3 ? c : c * ocs + t) : -1);
       gg[k] = pe_row_load(gd, c < rows_here ? c : -1);
       bb[k] = pe_row_load(bd, c < rows_here ? c : -1);
       b1v[k] = pe_row_load(b1d, c < rows_here ? c : -1);
@@ -145,10 +148,10 @@ __global__ __launch_bounds__(256) void colchain4_kernel(ColP p) {
   if (second) col_gemm4_fetch<K2>(gw2, p.w2, (p.rows2 + 63) / 64, wv, lane);
   __syncthreads();
 
-  if (p.mode == 2) {
+  if (p.mode >= 2) {
     if (!ok) return;
-    float* tp = skip_part ? p.out + (long)b * p.out_bs : p.x1 + (long)b * p.x1_bs;
-    const int tcs = skip_part ? p.out_cs : p.x1_cs;
+    float* tp = (skip_part || p.mode == 3) ? p.out + (long)b * p.out_bs + (p.mode == 3 ? (long)row0 * p.out_cs : 0) : p.x1 + (long)b * p.x1_bs;
+    const int tcs = (skip_part || p.mode == 3) ? p.out_cs : p.x1_cs;
 #pragma unroll
     for (int k = 0; k < NVT; ++k) {
       const int c = rl + 64 * k;
