@@ -360,6 +360,20 @@ float* Engine::pack16_conv(const WeightSet& ws, const std::string& wname, int in
   return pack16(W, Co, Ci);
 }
 
+// A 1x1 conv weight [Co][Ci][1] with Ci < 192 in pack4 order with K zero-padded to 192, for colchain4_kernel mode 3 (whose
+// input descriptor ends after the Ci real rows, so the padded channels read as zeros too).
+const float* Engine::pack4_conv_pad192(const WeightSet& ws, const std::string& wname, int in_rev, int out_rev) {
+  const HostTensor& w = ws.get(wname);
+  if (w.dims.size() != 3 || w.dims[2] != 1 || w.dims[1] > 192) return nullptr;
+  const int Co = (int)w.dims[0], Ci = (int)w.dims[1];
+  std::vector<float> W(skeleton_ ? 0 : (size_t)Co * 192, 0.f);
+  if (!skeleton_)
+    for (int o = 0; o < Co; ++o)
+      for (int i = 0; i < Ci; ++i)
+        W[(size_t)o * 192 + i] = w.data[(size_t)(out_rev ? Co - 1 - o : o) * Ci + (in_rev ? Ci - 1 - i : i)];
+  return pack4(W, Co, 192);
+}
+
 DdsW Engine::load_dds(const WeightSet& ws, const std::string& p) {
   DdsW d;
   for (int i = 0; i < arch_[A_DDSLAYERS]; ++i) {
@@ -518,6 +532,7 @@ void Engine::init(const WeightSet& ws) {
       }
       r.post = pack_conv(ws, p + ".post.weight", p + ".post.bias", 1, -1, false, 0, odd);
       r.pre16 = pack16_conv(ws, p + ".pre.weight", odd, 0);
+      if (H_ == 192 && rcls_.empty()) r.pre4pad = pack4_conv_pad192(ws, p + ".pre.weight", odd, 0);   // first layer's pre: a launch of its own
       r.post16 = pack16_conv(ws, p + ".post.weight", 0, odd);
       rcls_.push_back(r);
       if (gin_) {
@@ -1346,11 +1361,12 @@ void Engine::lngemm(View y, const float* g, const float* b, View x, const float*
 // A plain 1x1 conv over 192 input channels of a small call on 4-column workgroups (colchain4_kernel mode 3); false: the
 // caller launches the conv kernel instead. `w16`: the conv's pack16 matrix (its pack4 twin is looked up).
 bool Engine::conv1x1_col4(const float* w16, const float* bias, int rows, View in, View out, const int* lens, int B, int Lmax,
-                          double flops, const float* bias2, long bias2_bs) {
-  const float* w4 = (H_ == 192 && use_col4((long)B * Lmax)) ? w4_of(w16) : nullptr;
+                          double flops, const float* bias2, long bias2_bs, const float* w4direct, int kin, long max_cols) {
+  const bool small = col4_ && (col4_ == 2 || (long)B * Lmax <= (max_cols ? max_cols : col4_max_cols_));
+  const float* w4 = (H_ == 192 && small) ? (w4direct ? w4direct : w4_of(w16)) : nullptr;
   if (!w4) return false;
   ColP cp{};
-  cp.in1 = in.p; cp.in1_bs = in.bs; cp.in1_cs = in.cs; cp.K1 = 192;
+  cp.in1 = in.p; cp.in1_bs = in.bs; cp.in1_cs = in.cs; cp.K1 = kin;
   cp.w1 = w4; cp.b1 = bias; cp.rows1 = rows;
   cp.mode = 3;
   cp.res = bias2; cp.res_bs = bias2_bs;
@@ -1721,7 +1737,11 @@ void Engine::issue_flow() {
     Rcl& r = rcls_[ri];
     const View x0{zp_ + (long)r.in_off * Fs, (long)C_ * Fs, Fs};
     const View x1{zp_ + (long)r.out_off * Fs, (long)C_ * Fs, Fs};
-    if (!(chain && ri > 0)) conv(r.pre, x0, fh, lens_b_, 1, Fmax, EPI_STORE);     // else: written by the previous layer's chain
+    if (!(chain && ri > 0)) {                                                     // else: written by the previous layer's chain
+      if (!(chain && r.pre4pad && conv1x1_col4(nullptr, r.pre.bias, r.pre.rows, x0, fh, lens_b_, B, Fmax, 2.0 * fsum * r.pre.macs_per_col,
+                                               nullptr, 0, r.pre4pad, half, col4_max_frames_)))
+        conv(r.pre, x0, fh, lens_b_, 1, Fmax, EPI_STORE);
+    }
     const int nl = (int)r.in.size();
     for (int i = 0; i < nl; ++i) {
       const float* b2 = nspk_ > 1 ? cond_ + cond_off_wn_[ri] + (long)i * 2 * H_ : nullptr;

@@ -194,7 +194,9 @@ class Engine {
   }
   void colchain(const struct ColP& p, int B, int Lmax, double flops);
   bool conv1x1_col4(const float* w16, const float* bias, int rows, View in, View out, const int* lens, int B, int Lmax,
-                    double flops, const float* bias2 = nullptr, long bias2_bs = 0);
+                    double flops, const float* bias2 = nullptr, long bias2_bs = 0, const float* w4direct = nullptr, int kin = 192,
+                    long max_cols = 0);
+  const float* pack4_conv_pad192(const WeightSet& ws, const std::string& wname, int in_rev, int out_rev);
   void lngemm(View y, const float* g, const float* b, View x, const float* w16, const float* bias, int rows, View out,
               int T, double flops, const float* parts = nullptr, int nparts = 0, const float* pbias = nullptr);
   float* pack16_conv(const WeightSet& ws, const std::string& wname, int in_rev, int out_rev);
@@ -270,6 +272,7 @@ class Engine {
   struct Rcl {
     PackedConv pre, post;
     float *pre16 = nullptr, *post16 = nullptr;   // the same two 1x1 convs in pack16 order (colchain_kernel)
+    const float* pre4pad = nullptr;               // the first layer's pre in pack4 order, K padded to 192 (colchain4_kernel mode 3)
     std::vector<PackedConv> in, rs;
     std::vector<const float*> rs4;   // the res/skip 1x1 convs in pack4 order (colchain4_kernel mode 2; null: not packed)
     int in_off, out_off;             // channel offsets of x0 / x1 in the physical (unflipped) layout

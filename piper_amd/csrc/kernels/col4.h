@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void colchain4_kernel(ColP p) {
   // operands of the step after the first GEMM are requested before it: residual / previous x1, LN gains, bias
   float ov[NVT], gg[NVT], bb[NVT], b1v[NVT];
   {
-    const pe_rowsrc ind = pe_make_row(p.in1 + (long)b * p.in1_bs, K1 * p.in1_cs);
+    const pe_rowsrc ind = pe_make_row(p.in1 + (long)b * p.in1_bs, p.K1 * p.in1_cs);      // K1 < 192 (mode 3): the missing channels read as zeros
     const float* obp = p.mode == 0 ? p.res + (long)b * p.res_bs : (skip_part ? p.out + (long)b * p.out_bs : p.x1 + (long)b * p.x1_bs);
     const int ocs = p.mode == 0 ? p.res_cs : (skip_part ? p.out_cs : p.x1_cs);
     const pe_rowsrc od = p.mode == 3 ? pe_make_row(p.res ? p.res + (long)b * p.res_bs + row0 : p.w1, p.res ? rows_here : 0)

@@ -193,7 +193,7 @@ FORCED = [
     ("high", [40], {}, {"conv_splitk_group_kernel<4,2,64>", "conv_splitk_sum_kernel<4,2>"}),
     ("medium", [128], {"PIPER_HIP_GROUP_MRF": 0}, {"conv_splitk_kernel<1,false,4,4>"}),
     # split-K variants: 4/8-wave only (no 16-column form), 12-wave everywhere, 16-column form everywhere
-    ("medium", [128], {"PIPER_HIP_SPLITK16": 0, "PIPER_HIP_WIDE_SPLITK": 0},
+    ("medium", [128], {"PIPER_HIP_SPLITK16": 0, "PIPER_HIP_WIDE_SPLITK": 0, "PIPER_HIP_COL4": 0},
      {"conv_splitk_kernel<2,true,8,3>", "conv_splitk_kernel<1,false,8,4>", "conv_splitk_kernel<1,false,4,4>"}),
     ("medium", [96], {"PIPER_HIP_SPLITK16": 0, "PIPER_HIP_WIDE_SPLITK": 2},
      {"conv_splitk_kernel<2,true,12,2>", "conv_splitk_kernel<1,false,12,4>"}),
