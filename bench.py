@@ -338,6 +338,7 @@ def main():
             "weight_broadcast_s": t_bcast,
             "weight_broadcast_bytes": bcast_bytes,
             "speculation": dict(zip(("runs", "misses"), eng.speculation_stats)),
+            "xcd_dispatch": dict(zip(("xcc_of_workgroups_0_63", "round_robin_period"), eng.xcc_pattern)),
         }
         if single_ref is not None:
             out["single_gpu_reference"] = single_ref

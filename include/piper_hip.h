@@ -153,6 +153,11 @@ int64_t pe_run_launches(pe_engine* e);
  * pe_create, misses = guesses that were too small (each cost one extra pass of the second half). */
 int pe_speculation_stats(pe_engine* e, int64_t* runs, int64_t* misses);
 
+/* Diagnostic: which XCD (accelerator complex of the MI355X) ran workgroups 0..63 of a 1-D probe launch at pe_create
+ * (xcc[64]), and *period = P when that was a round-robin over P XCDs (0 otherwise). The small-call kernels order their
+ * column tiles by it (piper_amd/csrc/kernels/col4.h); bench.py prints it so that a result line says what the box did. */
+int pe_xcc_pattern(pe_engine* e, int32_t xcc[64], int32_t* period);
+
 /* In-process multi-GPU synthesis for C / C++ callers (the reference runs the phrases of a text one
  * after the other on one session, src/cpp/piper.cpp:549-582 -- they are independent, so they shard). One engine, one
  * stream and one worker thread per device. The voice is parsed and packed ONCE, on devices[0]; every other device gets an

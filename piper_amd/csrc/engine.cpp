@@ -645,6 +645,7 @@ void Engine::init(const WeightSet& ws) {
   launch::init_bf3();
   launch::init_front();
   launch::init_tail();
+  probe_xcds();
   static const char* rows[] = {"text_encoder", "duration_predictor", "regulate+flow", "hifigan", "post+pcm"};
   for (auto n : rows) prof_.push_back(ProfileRow{n});
   PE_HIP(hipEventCreate(&ev0_));
@@ -706,6 +707,30 @@ void Engine::free_all() {
   if (stream_) hipStreamDestroy(stream_);
   wsA_ = wsB_ = nullptr; h_audio_ = nullptr; h_pcm_ = nullptr; h_pcm_zc_ = nullptr; h_frames_ = nullptr;
   ev0_ = ev1_ = nullptr; stream_ = nullptr;
+}
+
+// Which XCD runs which workgroup of a small 1-D launch (kernels/glue.h xcc_probe_kernel). The 4-column kernels hand out
+// column tiles so that one XCD owns a contiguous run of them (col4.h c4_tile); that needs the dispatch to be a
+// round-robin over P XCDs -- workgroup i on XCD pattern[i mod P], the first P all different -- which is what this checks.
+// Anything else (PIPER_HIP_XCD=0 forces it): period 0, tiles in workgroup order.
+void Engine::probe_xcds() {
+  int* d = nullptr;
+  PE_HIP(hipMalloc((void**)&d, 64 * sizeof(int)));
+  PE_HIP(hipMemsetAsync(d, 0xff, 64 * sizeof(int), stream_));
+  launch::xcc_probe(stream_, d);
+  PE_HIP(hipMemcpyAsync(xcc_of_, d, 64 * sizeof(int), hipMemcpyDeviceToHost, stream_));
+  PE_HIP(hipStreamSynchronize(stream_));
+  PE_HIP(hipFree(d));
+  int P = 0;
+  for (int c = 1; c <= 32 && !P; ++c) {           // smallest period with pairwise different ids inside it
+    bool ok = true;
+    for (int i = 0; i < c && ok; ++i)
+      for (int j = 0; j < i && ok; ++j) ok = xcc_of_[i] != xcc_of_[j];
+    for (int i = c; i < 64 && ok; ++i) ok = xcc_of_[i] == xcc_of_[i - c];
+    if (ok && c > 1 && xcc_of_[c] == xcc_of_[0]) P = c;
+  }
+  xcd_period_ = P;
+  if (const char* t = getenv("PIPER_HIP_XCD")) xcd_period_ = atoi(t);      // A/B knob: 0 = tiles in workgroup order
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1298,7 +1323,9 @@ void Engine::dds(const DdsW& d, View in, View out, View tmp, const DdsOpt* opt) 
   for (const DdsP& p : list) {
     if (four) {
       const int kh4 = kbegin(prof_level_ >= 2 ? krow("dds_layer4_kernel") : 0, 0.0);
-      launch::dds_layer4(dim3((Tg_ + 3) / 4, B_), col4_smem(), stream_, p);
+      DdsP p4 = p;
+      p4.xcd = xcd_period_;
+      launch::dds_layer4(dim3((Tg_ + 3) / 4, B_), col4_smem(), stream_, p4);
       kend(kh4);
       continue;
     }
@@ -1347,6 +1374,7 @@ void Engine::lngemm(View y, const float* g, const float* b, View x, const float*
   }
   if (const float* w4 = use_col4((long)B_ * T) ? w4_of(w16) : nullptr) {
     p.w16 = w4;
+    p.xcd = xcd_period_;
     const int kh4 = kbegin(prof_level_ >= 2 ? krow("lngemm4_kernel") : 0, flops);
     launch::lngemm4(dim3((T + 3) / 4, B_, (rows + 191) / 192), col4_smem(), stream_, p);
     kend(kh4);
@@ -1369,6 +1397,7 @@ bool Engine::conv1x1_col4(const float* w16, const float* bias, int rows, View in
   cp.in1 = in.p; cp.in1_bs = in.bs; cp.in1_cs = in.cs; cp.K1 = kin;
   cp.w1 = w4; cp.b1 = bias; cp.rows1 = rows;
   cp.mode = 3;
+  cp.xcd = xcd_period_;
   cp.res = bias2; cp.res_bs = bias2_bs;
   cp.out = out.p; cp.out_bs = out.bs; cp.out_cs = out.cs;
   cp.lens = lens;
@@ -1386,6 +1415,7 @@ void Engine::colchain(const ColP& p, int B, int Lmax, double flops) {
     if (w1 && (!p.w2 || w2)) {
       ColP q = p;
       q.w1 = w1; q.w2 = w2;
+      q.xcd = xcd_period_;
       const int kh4 = kbegin(prof_level_ >= 2 ? krow("colchain4_kernel") : 0, flops);
       launch::colchain4(dim3((Lmax + 3) / 4, B), col4_smem(), stream_, q);
       kend(kh4);
@@ -1752,6 +1782,7 @@ void Engine::issue_flow() {
         cp.in1 = facts.p; cp.in1_bs = facts.bs; cp.in1_cs = facts.cs; cp.K1 = H_;
         cp.w1 = r.rs4[i]; cp.b1 = r.rs[i].bias; cp.rows1 = r.rs[i].rows;
         cp.mode = 2; cp.first = i == 0 ? 1 : 0;
+        cp.xcd = xcd_period_;
         cp.x1 = fh.p; cp.x1_bs = fh.bs; cp.x1_cs = fh.cs;
         cp.out = fskip.p; cp.out_bs = fskip.bs; cp.out_cs = fskip.cs;
         cp.lens = lens_b_;

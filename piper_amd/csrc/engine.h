@@ -103,6 +103,8 @@ class Engine {
   // cost a second pass of stage B, since the engine was created
   long speculation_runs() const { return spec_runs_; }
   long speculation_misses() const { return spec_misses_; }
+  // XCC id of workgroups 0..63 of a 1-D launch as seen at engine creation, and the round-robin period (0: not a round-robin)
+  const int* xcc_pattern(int* period) const { if (period) *period = xcd_period_; return xcc_of_; }
 
   void set_seed(uint64_t s) { seed_ = s; }
   void set_use_graphs(bool on) { use_graphs_ = on; }
@@ -200,6 +202,11 @@ class Engine {
   void lngemm(View y, const float* g, const float* b, View x, const float* w16, const float* bias, int rows, View out,
               int T, double flops, const float* parts = nullptr, int nparts = 0, const float* pbias = nullptr);
   float* pack16_conv(const WeightSet& ws, const std::string& wname, int in_rev, int out_rev);
+  // XCD dispatch pattern of this device (xcc_probe_kernel at engine creation): XCC id of workgroups 0..63 of a 1-D launch,
+  // and the period P when it is a round-robin over P XCDs (0: anything else -- the 4-column kernels then use tile = id)
+  int xcc_of_[64] = {0};
+  int xcd_period_ = 0;
+  void probe_xcds();
   int col4_ = 1;                            // PIPER_HIP_COL4: 4-column workgroups for the DDSConv layers: 0 off, 1 up to col4_max_cols_ columns per call, 2 always (A/B, tests)
   long col4_max_cols_ = 1024;               // ids per call (text encoder, duration predictor)
   long col4_max_frames_ = 2048;             // frames per call (WN res/skip conv): the sweep in profiles/r03_notes.md

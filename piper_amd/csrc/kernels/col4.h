@@ -14,9 +14,12 @@ namespace pe {
 // Which 4-column tile a workgroup takes. Workgroups go to the 8 XCDs round-robin by linear id, so with tile = blockIdx.x
 // the eight 16-byte pieces of a 128-byte line of any [channel][time] tensor the launch writes would come from eight
 // different L2s (measured: the attention kernel behind such a launch ran 4.4 us slower). XCD j takes a contiguous run of
-// tiles instead: 64 bytes per row from one L2 for a 128-id utterance, what a 16-column workgroup writes.
-__device__ __forceinline__ int c4_tile(int bx, int nx) {
-  const int q = nx >> 3, r = nx & 7, j = bx & 7, i = bx >> 3;
+// tiles instead (when the probe at engine creation saw that round-robin): 64 bytes per row from one L2 for a 128-id utterance, what a 16-column workgroup writes.
+// `P` = the number of XCDs when the dispatch was seen to be round-robin over them at engine creation (xcc_probe_kernel),
+// 0 otherwise: then tile = blockIdx.x.
+__device__ __forceinline__ int c4_tile(int bx, int nx, int P) {
+  if (P <= 1) return bx;
+  const int q = nx / P, r = nx - q * P, i = bx / P, j = bx - i * P;
   return j * q + (j < r ? j : r) + i;
 }
 
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(256) void colchain4_kernel(ColP p) {
   constexpr int NC = 4, NVT = 3, K1 = C4_H, K2 = C4_H / 2, KS1 = Col4W<K1>::KS, KS2 = Col4W<K2>::KS;
   PE_DYN_SMEM(float, sm);                       // YT[4][KS1] | P[4 waves][192][4] | red[2][4][4]
   const int b = blockIdx.y, L = p.lens[b];
-  const int t0 = c4_tile(blockIdx.x, gridDim.x) * NC;
+  const int t0 = c4_tile(blockIdx.x, gridDim.x, p.xcd) * NC;
   if (t0 >= L) return;
   float* YT = sm;
   float* P = YT + NC * KS1;
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(256) void lngemm4_kernel(LnGemmP p) {
   constexpr int NC = 4, NVT = 3, H = C4_H, KS = Col4W<H>::KS;
   PE_DYN_SMEM(float, sm);                       // YT[4][KS] | P[4 waves][192][4] | red[2][4][4]
   const int b = blockIdx.y, L = p.lens[b];
-  const int t0 = c4_tile(blockIdx.x, gridDim.x) * NC;
+  const int t0 = c4_tile(blockIdx.x, gridDim.x, p.xcd) * NC;
   if (t0 >= L) return;
   float* YT = sm;
   float* P = YT + NC * KS;

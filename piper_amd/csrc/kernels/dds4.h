@@ -29,7 +29,7 @@ __global__ __launch_bounds__(256) void dds_layer4_kernel(DdsP p) {
   constexpr int NC = 4, NVT = 3, H = C4_H, C4_KS = Col4W<C4_H>::KS;
   const int b = blockIdx.y;
   const int L = p.lens[b];                      // first used after every operand load is in flight (dds.h)
-  const int t0 = c4_tile(blockIdx.x, gridDim.x) * NC;
+  const int t0 = c4_tile(blockIdx.x, gridDim.x, p.xcd) * NC;
   const int Lb = p.x_cs;
   float* YT = sm;
   float* P = YT + NC * C4_KS;

@@ -27,4 +27,16 @@ __global__ void cond_kernel(const float* emb_g, int gin, const int* sids, const 
   out[(long)b * o_bs + r] = s;
 }
 
+// Which XCD (accelerator complex) runs a workgroup: one wave per workgroup stores its XCC id. Engine creation launches 64
+// workgroups of this once per device and derives the order in which the 4-column kernels hand out column tiles
+// (col4.h c4_tile) from the observed dispatch pattern instead of assuming "linear workgroup id modulo 8".
+__global__ void xcc_probe_kernel(int* out) {
+#ifdef PE_EMU
+  out[blockIdx.x] = (int)(blockIdx.x % 8);
+#else
+  // s_getreg_b32 HW_REG_XCC_ID (hardware register 20 on gfx940+), field XCC_ID = bits 3:0: simm16 = (size-1) << 11 | offset << 6 | id
+  if (threadIdx.x == 0) out[blockIdx.x] = (int)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+#endif
+}
+
 }  // namespace pe

@@ -47,6 +47,7 @@ void duration(dim3 grid, hipStream_t stream, const DurP& p);
 void randn(hipStream_t stream, float* out, long rows, int cols, long stride, long row0, const unsigned long long* state,
            int site);
 void regulate(dim3 grid, hipStream_t stream, const RegP& p);
+void xcc_probe(hipStream_t stream, int* out64);       // 64 workgroups, out64[i] = XCC id of workgroup i
 void cond(dim3 grid, hipStream_t stream, const float* emb_g, int gin, const int* sids, const float* w, const float* bias,
           int rows, float* out, int o_bs);
 

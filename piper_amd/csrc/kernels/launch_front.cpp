@@ -67,6 +67,8 @@ void ffn(dim3 grid, size_t smem, hipStream_t stream, const FfnP& p) {
   PE_LAUNCH(ffn_kernel, grid, dim3(256), smem, stream, p);
 }
 
+void xcc_probe(hipStream_t stream, int* out64) { PE_LAUNCH(xcc_probe_kernel, dim3(64), dim3(64), 0, stream, out64); }
+
 void cf_pre(dim3 grid, hipStream_t stream, const float* z0, long z_bs, const float* w, const float* bias, const float* xg,
             long g_bs, int g_cs, float* out, long o_bs, int o_cs, const int* lens, int H) {
   PE_LAUNCH(cf_pre_kernel, grid, dim3(64), 0, stream, z0, z_bs, w, bias, xg, g_bs, g_cs, out, o_bs, o_cs, lens, H);

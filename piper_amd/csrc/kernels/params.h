@@ -102,6 +102,7 @@ struct DdsP {
   const float* zin; long zin_bs; int z_cs; int c0, c1;
   float* zout; long zout_bs;
   float inv_sqrt_h;
+  int xcd;                                  // dds_layer4_kernel: XCDs the dispatch round-robins over (0: unknown), col4.h c4_tile
 };
 
 // ---- 1x1 conv chains (colchain.h)
@@ -117,6 +118,7 @@ struct ColP {
   float* out2; long o2_bs; int o2_cs;
   const int* lens;
   int first;                                            // mode 2 (colchain4_kernel): first WN layer -- the skip sum is not read
+  int xcd;                                              // colchain4_kernel: XCDs the dispatch round-robins over (0: unknown)
 };
 // ---- fused FFN (ffn.h): partial outputs per 48-row slice of the hidden dimension
 struct FfnP {
@@ -131,6 +133,7 @@ struct LnGemmP {
   // lngemm4_kernel only: y = in + pbias + sum of the nparts partial FFN outputs (ffn_kernel), in slice order
   const float* parts; long p_bs; int nparts;     // [utterance][4-column tile][slice][192][4]
   const float* pbias;
+  int xcd;                                       // lngemm4_kernel: XCDs the dispatch round-robins over (0: unknown)
   const float* gamma; const float* beta;
   float* xout; long x_bs; int x_cs;              // LN(y)
   const float* w16; const float* bias; int rows; // pack16 order, all parts; part z owns rows [32 NVT z, 32 NVT (z + 1))

@@ -312,6 +312,16 @@ int pe_speculation_stats(pe_engine* e, int64_t* runs, int64_t* misses) {
   });
 }
 
+int pe_xcc_pattern(pe_engine* e, int32_t xcc[64], int32_t* period) {
+  return guard([&] {
+    if (!e) throw std::runtime_error("null engine");
+    int P = 0;
+    const int* x = e->eng->xcc_pattern(&P);
+    if (xcc) for (int i = 0; i < 64; ++i) xcc[i] = x[i];
+    if (period) *period = P;
+  });
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // pe_group_*: one engine / stream / worker thread per device in ONE process (include/piper_hip.h)
 // ---------------------------------------------------------------------------------------------------------------------

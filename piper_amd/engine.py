@@ -242,6 +242,14 @@ class Engine:
         return int(runs.value), int(miss.value)
 
     @property
+    def xcc_pattern(self):
+        """(XCC id of workgroups 0..63 of a probe launch at engine creation, round-robin period or 0) -- include/piper_hip.h."""
+        xs = (C.c_int32 * 64)()
+        per = C.c_int32()
+        self._check(self._lib.pe_xcc_pattern(self._h, xs, C.byref(per)))
+        return [int(v) for v in xs], int(per.value)
+
+    @property
     def rng_calls(self) -> int:
         return int(self._lib.pe_rng_calls(self._h))
 
