@@ -11,7 +11,7 @@ HDRS := include/piper.hpp $(CSRC)/engine.h $(wildcard $(CSRC)/kernels/*.h) $(CSR
 LIB := piper_amd/libpiper_hip.so
 EMULIB := tests/emu/libpiper_hip_emu.so
 HIPFLAGS := --offload-arch=gfx950 -O3 -std=c++17 -fPIC -x hip -Wno-unused-result -Wno-unused-value
-EMUFLAGS := -DPE_EMU -O2 -g -std=c++17 -Wno-psabi -fPIC -Itests/emu
+EMUFLAGS := -DPE_EMU -O2 -mfma -std=c++17 -Wno-psabi -fPIC -Itests/emu
 OBJ := $(patsubst $(CSRC)/%.cpp,build/gfx950/%.o,$(SRCS))
 OBJ_STAMPS := $(patsubst $(CSRC)/%.cpp,build/stamps/%.o,$(SRCS))
 OBJ_EMU := $(patsubst $(CSRC)/%.cpp,build/emu/%.o,$(SRCS)) build/emu/hip_emu.o

@@ -139,7 +139,8 @@ def test_cpp_piper_api_on_emulator(tmp_path):
     subprocess.check_call(["make", "-C", ROOT, "emu", "tests/cpp/test_piper_emu"], stdout=subprocess.DEVNULL)
     wav = str(tmp_path / "t.wav")
     out = subprocess.run([os.path.join(ROOT, "tests", "cpp", "test_piper_emu"),
-                          os.path.join(GOLD, "tiny_voice.onnx"), wav], capture_output=True, text=True, timeout=600)
+                          os.path.join(GOLD, "tiny_voice.onnx"), wav], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, PIPER_TEST_SHORT="1"))      # the GPU run of the same program uses the long text
     assert out.returncode == 0, out.stderr
     assert out.stdout.startswith("OK ") and "rate=16000" in out.stdout and "speakers=1" in out.stdout
     assert "pid=7 missing=1" in out.stdout          # a, b mapped (+PADs), the snowman counted as missing
@@ -201,6 +202,7 @@ def test_null_handles_are_errors_not_crashes(lib):
     assert lib.pe_debug_tensor(None, b"z", 0, buf, 4, C.byref(r), C.byref(c)) != 0
     assert lib.pe_debug_randn(None, 0, 1, 0, 4, buf) != 0
     assert lib.pe_speculation_stats(None, None, None) != 0
+    assert lib.pe_xcc_pattern(None, None, None) != 0
     assert lib.pe_rng_calls(None) == 0 and lib.pe_run_launches(None) == 0
     lib.pe_destroy(None)
 
