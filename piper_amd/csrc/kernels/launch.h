@@ -37,6 +37,7 @@ void colchain(dim3 grid, size_t smem, hipStream_t stream, const ColP& p);
 void colchain4(dim3 grid, size_t smem, hipStream_t stream, const ColP& p);     // 4-column forms (col4.h): weights in pack4 order
 void lngemm(dim3 grid, size_t smem, hipStream_t stream, const LnGemmP& p);
 void lngemm4(dim3 grid, size_t smem, hipStream_t stream, const LnGemmP& p);
+void wn(dim3 grid, size_t smem, hipStream_t stream, const WnP& p);              // fused WN layer (wn.h, opt-in)
 void ffn(dim3 grid, size_t smem, hipStream_t stream, const FfnP& p);            // fused small-call FFN (ffn.h)
 void cf_pre(dim3 grid, hipStream_t stream, const float* z0, long z_bs, const float* w, const float* bias, const float* xg,
             long g_bs, int g_cs, float* out, long o_bs, int o_cs, const int* lens, int H);

@@ -385,3 +385,33 @@ def test_emulated_192_channel_small_call_kernels(emu_lib, monkeypatch, col4):
         assert np.max(np.abs(lw - np.asarray(o["logw"]).ravel()[:T])) < 1e-5
         assert np.max(np.abs(r.audio[i] - o["audio"])) < 1e-5
     eng.close()
+
+
+@pytest.mark.parametrize("preset,sids", [("tiny-ms", [1, 3])])
+def test_emulated_fused_wn_layers(emu_lib, monkeypatch, preset, sids):
+    """Opt-in PIPER_HIP_WN=1: every WN layer of the coupling flow as ONE launch (kernels/wn.h: the gated channels dealt
+    to the workgroups; partial res products summed by the next layer's launch, partial skip products by the post conv in
+    colchain4_kernel) on a 192-channel multi-speaker voice (conditioning bias on the gate pre-activations), ragged batch
+    spanning several 16-frame tiles -- against the oracle and against the default schedule."""
+    cfg = W.preset(preset, hidden=192, inter=192, filter=96, n_layers=1)
+    w = W.synthetic_weights(cfg, 77)
+    lens = [9, 21]
+    ids = [W.synthetic_phoneme_ids(T, i, id_max=cfg.n_vocab - 1) for i, T in enumerate(lens)]
+    nw = np.random.default_rng(5).standard_normal((len(lens), 2, max(lens))).astype(np.float32)
+    outs = []
+    for wn in ("0", "1"):
+        monkeypatch.setenv("PIPER_HIP_WN", wn)
+        eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
+        eng.profile_enable(2)
+        r = eng.synthesize_batch(ids, (0.0, 1.0, 0.8), noise_w=nw, sids=sids)
+        names = {row["name"] for row in eng.profile()[5:] if row["launches"]}
+        assert ("wn_kernel" in names) == (wn == "1")
+        outs.append((r, eng.durations()))
+        eng.close()
+    off = np.concatenate([[0], np.cumsum(lens)])
+    for i, T in enumerate(lens):
+        o = O.synthesize(w, cfg, ids[i], (0.0, 1.0, 0.8), nw[i], sid=None if sids is None else sids[i])
+        for r, durs in outs:
+            assert np.array_equal(durs[off[i]:off[i + 1]], o["durations"])
+            assert np.max(np.abs(r.audio[i] - o["audio"])) < 1e-5
+        assert np.max(np.abs(outs[0][0].audio[i] - outs[1][0].audio[i])) < 1e-5

@@ -45,7 +45,7 @@ def make_engine(monkeypatch, cfg, w, env=None):
               "PIPER_HIP_WIDE_SPLITK", "PIPER_HIP_DEBUG_KEEP", "PIPER_HIP_MRF", "PIPER_HIP_FUSE_DP",
               "PIPER_HIP_MRF_MAXF", "PIPER_HIP_SPEC", "PIPER_HIP_COLCHAIN", "PIPER_HIP_GROUP_MRF", 
               "PIPER_HIP_MRF_OU", "PIPER_HIP_MATRIX", "PIPER_HIP_BF3_MINF", "PIPER_HIP_MRF_TAIL", "PIPER_HIP_COL4",
-              "PIPER_HIP_COL4_MAXC", "PIPER_HIP_FFN"):
+              "PIPER_HIP_COL4_MAXC", "PIPER_HIP_FFN", "PIPER_HIP_WN", "PIPER_HIP_XCD"):
         monkeypatch.delenv(k, raising=False)
     for k, v in (env or {}).items():
         monkeypatch.setenv(k, str(v))
@@ -210,6 +210,11 @@ FORCED = [
     # calls), and conv by conv behind the 4-column chains
     ("medium", [128, 13, 14, 15, 29], {}, {"ffn_kernel", "lngemm4_kernel"}),
     ("medium", [128, 31], {"PIPER_HIP_FFN": 0}, {"lngemm4_kernel", "conv_splitk16_kernel<false,8,4>"}),
+    # opt-in: every WN layer of the coupling flow as one launch (wn_kernel: gated channels dealt to the workgroups, partial
+    # res / skip products summed by the next layer's launch and by the post conv) -- emulator-verified, awaiting its A/B
+    ("medium", [128, 40, 7], {"PIPER_HIP_WN": 1}, {"wn_kernel", "colchain4_kernel"}),
+    # tiles of the 4-column kernels in workgroup order (no XCD-contiguous runs)
+    ("medium", [128, 31], {"PIPER_HIP_XCD": 0}, {"colchain4_kernel", "lngemm4_kernel", "dds_layer4_kernel"}),
 ]
 
 
