@@ -460,6 +460,7 @@ Engine::Engine(const WeightSet& ws, int device, ArenaSpec arena) : device_(devic
 
 void Engine::init(const WeightSet& ws) {
   if (const char* t = getenv("PIPER_HIP_MRF")) mrf_mode_ = atoi(t);       // A/B knob: 0 = conv-by-conv MRF stages, 2 = always fused
+  if (const char* t = getenv("PIPER_HIP_WN")) wn_ = atoi(t);              // opt-in: fused WN layers (kernels/wn.h); read before the weights are packed
   if (const char* t = getenv("PIPER_HIP_MRF_MAXF")) mrf_rb1_max_frames_ = atol(t);
   if (const char* t = getenv("PIPER_HIP_MRF_OU")) mrf_ou_ = atoi(t);
   if (const char* t = getenv("PIPER_HIP_MRF_TAIL")) mrf_tail_ = atoi(t) != 0;   // A/B knob, tests: conv_post inside the last mrf_kernel
@@ -569,14 +570,14 @@ void Engine::init(const WeightSet& ws) {
           const HostTensor& wrs = ws.get(p + ".enc.res_skip_layers." + s + ".weight");
           r.rs4.push_back(wrs.dims.size() == 3 && wrs.dims[2] == 1 ? pack4(wrs.data, (int)wrs.dims[0], (int)wrs.dims[1]) : nullptr);
         }
-        if (H_ == 192 && wnk == 5) {      // fused WN layer (kernels/wn.h)
+        if (wn_ && H_ == 192 && wnk == 5) {      // fused WN layer (kernels/wn.h): packed only when the mode is on (30 MB for the medium voice)
           r.wn_g.push_back(pack_wn_gate(ws, p + ".enc.in_layers." + s + ".weight"));
           r.wn_r.push_back(pack_wn_rs(ws, p + ".enc.res_skip_layers." + s + ".weight"));
         }
         (void)wnk;
       }
       r.post = pack_conv(ws, p + ".post.weight", p + ".post.bias", 1, -1, false, 0, odd);
-      if ((int)r.wn_g.size() == wnl) {      // sum of the layers' skip biases: rows [192, 384) of res_skip_i, all rows of the last
+      if (wn_ && (int)r.wn_g.size() == wnl) {      // sum of the layers' skip biases: rows [192, 384) of res_skip_i, all rows of the last
         std::vector<float> sb(skeleton_ ? 0 : 192, 0.f);
         for (int i = 0; i < (skeleton_ ? 0 : wnl); ++i) {
           const HostTensor& bb = ws.get(p + ".enc.res_skip_layers." + std::to_string(i) + ".bias");
@@ -720,7 +721,6 @@ void Engine::init(const WeightSet& ws) {
   if (const char* t = getenv("PIPER_HIP_COL4")) col4_ = atoi(t);                      // A/B knob, tests
   if (const char* t = getenv("PIPER_HIP_COL4_MAXC")) col4_max_cols_ = atol(t);
   if (const char* t = getenv("PIPER_HIP_FFN")) ffn_ = atoi(t);                        // A/B knob, tests
-  if (const char* t = getenv("PIPER_HIP_WN")) wn_ = atoi(t);                          // opt-in: fused WN layers (kernels/wn.h)
   if (const char* t = getenv("PIPER_HIP_SPEC")) spec_enable_ = atoi(t) != 0;          // speculative stage B (A/B, tests)
 }
 
