@@ -210,9 +210,6 @@ FORCED = [
     # calls), and conv by conv behind the 4-column chains
     ("medium", [128, 13, 14, 15, 29], {}, {"ffn_kernel", "lngemm4_kernel"}),
     ("medium", [128, 31], {"PIPER_HIP_FFN": 0}, {"lngemm4_kernel", "conv_splitk16_kernel<false,8,4>"}),
-    # opt-in: every WN layer of the coupling flow as one launch (wn_kernel: gated channels dealt to the workgroups, partial
-    # res / skip products summed by the next layer's launch and by the post conv) -- emulator-verified, awaiting its A/B
-    ("medium", [128, 40, 7], {"PIPER_HIP_WN": 1}, {"wn_kernel", "colchain4_kernel"}),
     # tiles of the 4-column kernels in workgroup order (no XCD-contiguous runs)
     ("medium", [128, 31], {"PIPER_HIP_XCD": 0}, {"colchain4_kernel", "lngemm4_kernel", "dds_layer4_kernel"}),
 ]
