@@ -1,6 +1,7 @@
 // TEST INFRASTRUCTURE ONLY -- see hip_emu.h. Fiber scheduler for the HIP functional emulator.
 #include "hip_emu.h"
 
+#include <cstring>
 #include <algorithm>
 #include <vector>
 
@@ -131,9 +132,24 @@ static void run_blocks(unsigned nthreads, int nblocks) {
     const unsigned l = (unsigned)i % nthreads, bx = blockDim.x, by = blockDim.y;
     g_f[i].tid = emu_idx3{l % bx, (l / bx) % by, l / (bx * by)};
   }
+  // EMU_ORDER=reverse | shuffle: the order in which runnable fibers get their turn. On the GPU the waves of a workgroup
+  // advance in no particular order between barriers; a kernel with a missing barrier (one wave reading LDS another has not
+  // written yet) gives the same answer here on every run of the default ascending order, but not under another one --
+  // tests/test_emu_engine.py runs the small-call kernels under all three and compares.
+  static const int order = [] { const char* t = getenv("EMU_ORDER"); return !t ? 0 : (!strcmp(t, "reverse") ? 1 : (!strcmp(t, "shuffle") ? 2 : 0)); }();
+  unsigned sweep = 0;
   for (;;) {
     bool ran = false;
-    for (int i = 0; i < total; ++i) {
+    ++sweep;
+    for (int k = 0; k < total; ++k) {
+      int i = k;
+      if (order == 1) i = total - 1 - k;
+      else if (order == 2) {                       // a different wave-interleaved permutation every sweep (bijective for any total)
+        const int nwv = (total + 63) / 64, w = k % nwv, l = k / nwv;
+        const int wp = (int)((w * 7u + sweep * 5u) % (unsigned)nwv);       // 7 and nwv coprime unless nwv % 7 == 0: fall back below
+        i = ((nwv % 7) ? wp : w) * 64 + (int)((l + sweep) % 64u);
+        if (i >= total) continue;
+      }
       if (g_f[i].st != RUNNABLE) continue;
       g_cur = i;
       threadIdx = g_f[i].tid;

@@ -415,3 +415,24 @@ def test_emulated_fused_wn_layers(emu_lib, monkeypatch, preset, sids):
             assert np.array_equal(durs[off[i]:off[i + 1]], o["durations"])
             assert np.max(np.abs(r.audio[i] - o["audio"])) < 1e-5
         assert np.max(np.abs(outs[0][0].audio[i] - outs[1][0].audio[i])) < 1e-5
+
+
+def test_small_call_kernels_do_not_depend_on_wave_order(emu_lib):
+    """The fiber emulator runs the waves of a workgroup in ascending order between barriers; the GPU in no particular
+    order. A missing barrier (one wave reading LDS another has not written yet) can therefore pass every other emulator
+    test. hip_emu.cpp takes EMU_ORDER=reverse | shuffle (a different wave-interleaved order every scheduling sweep): the
+    small-call kernels of the 192-channel voices -- colchain4 / lngemm4 / dds_layer4 / ffn and the opt-in wn_kernel --
+    must give the oracle's answer, and bit for bit the same answer, under each order (tests/emu/order_check.py)."""
+    import json
+    import subprocess
+    import sys
+    outs = []
+    for order in ("reverse", "shuffle"):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "emu", "order_check.py")], capture_output=True, text=True,
+                           timeout=900, env=dict(os.environ, EMU_ORDER=order, PIPER_HIP_WN="1"))
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    for o in outs:
+        assert {"colchain4_kernel", "lngemm4_kernel", "dds_layer4_kernel", "ffn_kernel", "wn_kernel"} <= set(o["kernels"])
+        assert o["durations_equal"] and o["worst"] < 1e-5, o
+    assert outs[0]["checksum"] == outs[1]["checksum"]
