@@ -26,8 +26,8 @@ namespace pe {
 //   * skip rows: colchain4_kernel mode 1 (the coupling layer's post conv), which reads b_skip_sum + the 4 x 8 partials of
 //     all four layers where it used to read the skip sum; layout per ITS 4-column tile, [tile][layer * 8 + slice][192][4].
 // Gate GEMM: 48 rows (three 16-row tiles; tanh rows 0..23, sigmoid rows 24..47) on v_mfma_f32_16x16x4_f32, the 192
-// channels dealt to the four waves (48 each, five taps: 60 k-steps x 3 tiles), weights streamed tap by tap (9 float4 per
-// lane and tap, the next tap in flight), B operand = the x window [192][20 columns] in LDS; partial tiles meet in LDS in
+// channels dealt to the four waves (48 each, five taps: 60 k-steps x 3 tiles), all 45 weight float4 of a lane requested at
+// kernel entry, B operand = the x window [192][20 columns] in LDS; partial tiles meet in LDS in
 // wave order. Res/skip GEMM: K = 24 (padded to 32), wave w owns row tiles 6w .. 6w + 5 (waves 0, 1: res rows, 2, 3: skip
 // rows), no reduction. Weights: engine.cpp pack_wn_gate / pack_wn_rs.
 constexpr int WN_H = 192, WN_S = 24, WN_NS = WN_H / WN_S, WN_NC = 16, WN_XS = 48, WN_TAPS = 5;
@@ -42,16 +42,19 @@ __global__ __launch_bounds__(256) void wn_kernel(WnP p) {
   const int t0 = tile * WN_NC;
   const int tid = threadIdx.x, lane = tid & 63, wv = PE_UNIFORM(tid >> 6);
   const int l15 = lane & 15, lq = lane >> 4;
-  // ---- gate fragments of tap 0: [slice][tap][tile 3][wave 4][quad 3][lane][4]
+  // ---- gate fragments: [slice][tap][tile 3][wave 4][quad 3][lane][4]
   const pe_rowsrc gd = pe_make_row_u(p.wg + (long)s * (48 * WN_H * WN_TAPS), 48 * WN_H * WN_TAPS);
-  f32x4 ga[3][3], gb[3][3];
-  auto load_g = [&](int tp, f32x4 (&g)[3][3]) {
+  // all five taps' fragments (45 float4 per lane) are requested here, in front of the window staging: one memory latency
+  // for the whole gate GEMM, like ffn_kernel's (one wave per SIMD: the registers are there). The fence keeps the compiler
+  // from sinking each load next to its use (it did: 70 VGPRs, a wait in front of every few MFMAs).
+  f32x4 g[WN_TAPS][3][3];
+#pragma unroll
+  for (int tp = 0; tp < WN_TAPS; ++tp)
 #pragma unroll
     for (int m = 0; m < 3; ++m)
 #pragma unroll
-      for (int q = 0; q < 3; ++q) g[m][q] = pe_row_load4(gd, ((((tp * 3 + m) * 4 + wv) * 3 + q) * 64 + lane) * 4);
-  };
-  load_g(0, ga);
+      for (int q = 0; q < 3; ++q) g[tp][m][q] = pe_row_load4(gd, ((((tp * 3 + m) * 4 + wv) * 3 + q) * 64 + lane) * 4);
+  PE_SCHED_FENCE();
   const int L = p.lens[b];
   // ---- x window -> XS[ch][c], c = 0..19 <-> frame t0 - 2 + c; x = previous state (+ previous layer's res bias and its
   // partial products); zero outside [0, L). 192 x 20 values as 960 float4 along the frames: 4 rounds of 256 threads.
@@ -98,7 +101,7 @@ __global__ __launch_bounds__(256) void wn_kernel(WnP p) {
   }
   if (t0 >= L) return;
   __syncthreads();
-  // ---- gate GEMM: this wave's 48 channels x 5 taps into the three 16-row tiles; weights tap by tap (ping-pong)
+  // ---- gate GEMM: this wave's 48 channels x 5 taps into the three 16-row tiles
   {
     f32x4 acc[3];
 #pragma unroll
@@ -106,19 +109,14 @@ __global__ __launch_bounds__(256) void wn_kernel(WnP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc[m][r] = 0.f;
     const float* xp = XS + (48 * wv + lq) * WN_XS + l15;
-    auto taps = [&](int tp, const f32x4 (&g)[3][3]) {
+#pragma unroll
+    for (int tp = 0; tp < WN_TAPS; ++tp)
 #pragma unroll
       for (int st = 0; st < 12; ++st) {
         const float bv = xp[4 * st * WN_XS + tp];
 #pragma unroll
-        for (int m = 0; m < 3; ++m) acc[m] = pe_mfma_16x16x4(g[m][st >> 2][st & 3], bv, acc[m]);
+        for (int m = 0; m < 3; ++m) acc[m] = pe_mfma_16x16x4(g[tp][m][st >> 2][st & 3], bv, acc[m]);
       }
-    };
-    load_g(1, gb); taps(0, ga);
-    load_g(2, ga); taps(1, gb);
-    load_g(3, gb); taps(2, ga);
-    load_g(4, ga); taps(3, gb);
-    taps(4, ga);
 #pragma unroll
     for (int m = 0; m < 3; ++m)
 #pragma unroll
