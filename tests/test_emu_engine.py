@@ -436,3 +436,19 @@ def test_small_call_kernels_do_not_depend_on_wave_order(emu_lib):
         assert {"colchain4_kernel", "lngemm4_kernel", "dds_layer4_kernel", "ffn_kernel", "wn_kernel"} <= set(o["kernels"])
         assert o["durations_equal"] and o["worst"] < 1e-5, o
     assert outs[0]["checksum"] == outs[1]["checksum"]
+
+
+def test_xcd_dispatch_probe_and_override(emu_lib, monkeypatch):
+    """pe_xcc_pattern: the probe launch at engine creation (the emulator plays a round-robin over 8 XCDs) is recognised as
+    period 8; PIPER_HIP_XCD overrides the period the 4-column kernels order their tiles by (0 = workgroup order)."""
+    cfg = W.preset("tiny")
+    blob = W.pack_blob(cfg, W.synthetic_weights(cfg, 1234))
+    monkeypatch.delenv("PIPER_HIP_XCD", raising=False)
+    eng = Engine(blob=blob, lib=emu_lib)
+    xcc, period = eng.xcc_pattern
+    assert xcc == [i % 8 for i in range(64)] and period == 8
+    eng.close()
+    monkeypatch.setenv("PIPER_HIP_XCD", "0")
+    eng = Engine(blob=blob, lib=emu_lib)
+    assert eng.xcc_pattern[1] == 0
+    eng.close()
