@@ -460,6 +460,7 @@ Engine::Engine(const WeightSet& ws, int device, ArenaSpec arena) : device_(devic
 
 void Engine::init(const WeightSet& ws) {
   if (const char* t = getenv("PIPER_HIP_MRF")) mrf_mode_ = atoi(t);       // A/B knob: 0 = conv-by-conv MRF stages, 2 = always fused
+  if (const char* t = getenv("PIPER_HIP_UPPRE")) upre_ = atoi(t);        // opt-in: preloaded small-K up-convs (kernels/conv_small.h)
   if (const char* t = getenv("PIPER_HIP_WN")) wn_ = atoi(t);              // opt-in: fused WN layers (kernels/wn.h); read before the weights are packed
   if (const char* t = getenv("PIPER_HIP_MRF_MAXF")) mrf_rb1_max_frames_ = atol(t);
   if (const char* t = getenv("PIPER_HIP_MRF_OU")) mrf_ou_ = atoi(t);
@@ -1133,6 +1134,15 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     }
     launch::conv_bf3(bc, pc.gate, HALO, grid, smem, ls_, p);
     kend(kh);
+    return;
+  }
+  if (upre_ && epi == EPI_CONVT && !pc.gate && pc.nchunks <= 4 && pc.nchunks * pc.ntaps <= 8 && p.xhalo <= 64 &&
+      pc.mtiles % 2 == 0 && (long)((ncols + 63) / 64) * (pc.mtiles / 2) * B_ <= upre_max_blocks_) {
+    // opt-in: a small-K up-conv of a small call with everything prefetched (kernels/conv_small.h)
+    const dim3 gs((ncols + 63) / 64, pc.mtiles / 2, B_);
+    const int khs = kbegin(prof_level_ >= 2 ? krow("conv_small_kernel") : 0, kflops, kbytes);
+    launch::conv_small(gs, (size_t)pc.nchunks * KC * 128 * sizeof(float), ls_, p);
+    kend(khs);
     return;
   }
   if (blocks < 192 || small_tiles_) {   // medium-small: smaller tiles, more workgroups

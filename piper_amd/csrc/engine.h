@@ -183,6 +183,8 @@ class Engine {
   // fused WN layers (kernels/wn.h): PIPER_HIP_WN=1 (opt-in until measured); res partials (ping-pong) and skip partials,
   // allocated on first use for wn_max_frames_ frames per call
   int wn_ = 0;
+  int upre_ = 0;                            // PIPER_HIP_UPPRE=1 (opt-in until measured): conv_small_kernel for the late up-convs of small calls
+  long upre_max_blocks_ = 1024;
   static constexpr long wn_max_frames_ = 2048;
   float* wn_pr_[2] = {nullptr, nullptr};
   float* wn_ps_ = nullptr;

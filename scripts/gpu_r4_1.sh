@@ -6,12 +6,16 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 O=gpurun_out/r4a
 mkdir -p $O
-timeout 600 python -m pytest tests/test_gpu_zz_optin.py -m gpu -q 2>&1 | tail -4
+timeout 900 python -m pytest tests/test_gpu_zz_optin.py -m gpu -q 2>&1 | tail -4
 BQ="--no-extra --no-cpu-baseline --min-seconds 0.4"
 for b in 1 2 4; do
   for w in 0 1 0 1; do
     PIPER_HIP_WN=$w timeout 300 python bench.py $BQ --batch $b --steps 300 --warmup 10 > $O/b${b}_wn${w}_$RANDOM.json 2>> $O/err.log
   done
+done
+# the preloaded small-K up-convs (PIPER_HIP_UPPRE=1, kernels/conv_small.h), B=1
+for u in 0 1 0 1; do
+  PIPER_HIP_UPPRE=$u timeout 300 python bench.py $BQ --steps 300 --warmup 10 > $O/b1_upre${u}_$RANDOM.json 2>> $O/err.log
 done
 grep -v amdgpu.ids $O/err.log | tail -3
 python - <<'PY'
@@ -22,6 +26,6 @@ for f in sorted(glob.glob("gpurun_out/r4a/*.json")):
     r=d.get("roofline") or {}
     print("%-22s ms %8.4f launches %s stages %s" % (os.path.basename(f), d["ms_per_step"], d["config"].get("kernel_launches_per_step"), {k[:4]:round(v,3) for k,v in r.get("stage_ms",{}).items()}))
     for k,v in r.get("kernels",{}).items():
-        if any(x in k for x in ("wn_kernel","splitk16_kernel<true","colchain4")): print("     %-40s %5.1f x %7.2f us" % (k, v["launches_per_step"], v["avg_launch_us"]))
+        if any(x in k for x in ("wn_kernel","splitk16_kernel<true","colchain4","conv_small","conv_mfma")): print("     %-40s %5.1f x %7.2f us" % (k, v["launches_per_step"], v["avg_launch_us"]))
 print(d.get("xcd_dispatch"))
 PY

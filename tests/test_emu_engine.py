@@ -452,3 +452,28 @@ def test_xcd_dispatch_probe_and_override(emu_lib, monkeypatch):
     eng = Engine(blob=blob, lib=emu_lib)
     assert eng.xcc_pattern[1] == 0
     eng.close()
+
+
+def test_emulated_preloaded_small_k_upconv(emu_lib, monkeypatch):
+    """Opt-in PIPER_HIP_UPPRE=1: conv_small_kernel (kernels/conv_small.h: a polyphase up-conv with <= 8 chunk-tap units,
+    every weight fragment and x slab requested before the first MFMA) against the tiled kernel it replaces and the oracle;
+    PIPER_HIP_SPLITK_MAX=0 sends the tiny voice's convs to the tiled kernels at all."""
+    monkeypatch.setenv("PIPER_HIP_SPLITK_MAX", "0")
+    cfg = W.preset("tiny-high")
+    w = W.synthetic_weights(cfg, 1234)
+    lens = [12, 5]
+    ids = [W.synthetic_phoneme_ids(T, i, id_max=cfg.n_vocab - 1) for i, T in enumerate(lens)]
+    outs = []
+    for on in ("0", "1"):
+        monkeypatch.setenv("PIPER_HIP_UPPRE", on)
+        eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
+        eng.profile_enable(2)
+        r = eng.synthesize_batch(ids, (0.0, 1.0, 0.0))
+        names = {row["name"] for row in eng.profile()[5:] if row["launches"]}
+        assert ("conv_small_kernel" in names) == (on == "1")
+        outs.append(r)
+        eng.close()
+    for i in range(len(lens)):
+        o = O.synthesize(w, cfg, ids[i], (0.0, 1.0, 0.0))
+        assert np.array_equal(outs[0].audio[i], outs[1].audio[i])        # the same fmaf chain: bit-identical
+        assert np.max(np.abs(outs[1].audio[i] - o["audio"])) < 1e-5

@@ -20,3 +20,17 @@ def test_fused_wn_layers_match_oracle(monkeypatch, lens):
     eng.close()
     assert {"wn_kernel", "colchain4_kernel"} <= names, sorted(names)
     print("fused WN layers, kernels:", sorted(names), "worst |d audio| %.2e" % worst)
+
+
+@pytest.mark.parametrize("preset,lens", [("medium", [128]), ("high", [64, 17])])
+def test_preloaded_small_k_upconvs_match_oracle(monkeypatch, preset, lens):
+    """PIPER_HIP_UPPRE=1: the late polyphase up-convs of a small call through conv_small_kernel (kernels/conv_small.h:
+    every weight fragment and x slab requested before the first MFMA). Bit-identical to the tiled kernel on the emulator;
+    this is its first run on the hardware."""
+    cfg, w = voice(preset)
+    eng = make_engine(monkeypatch, cfg, w, {"PIPER_HIP_UPPRE": 1})
+    ids, nw, nz = batch_inputs(cfg, lens, seed=131 + len(lens))
+    names, worst = run_and_check(eng, cfg, w, ids, nw, nz, sample=sorted({0, len(lens) - 1}))
+    eng.close()
+    assert "conv_small_kernel" in names, sorted(names)
+    print("preloaded up-convs, kernels:", sorted(names), "worst |d audio| %.2e" % worst)
