@@ -460,6 +460,7 @@ Engine::Engine(const WeightSet& ws, int device, ArenaSpec arena) : device_(devic
 
 void Engine::init(const WeightSet& ws) {
   if (const char* t = getenv("PIPER_HIP_MRF")) mrf_mode_ = atoi(t);       // A/B knob: 0 = conv-by-conv MRF stages, 2 = always fused
+  if (const char* t = getenv("PIPER_HIP_SUMD")) sum_deep_ = atoi(t) >= 16;   // opt-in: 16-deep weight ring of conv_splitk_sum_kernel
   if (const char* t = getenv("PIPER_HIP_UPPRE")) upre_ = atoi(t);        // opt-in: preloaded small-K up-convs (kernels/conv_small.h)
   if (const char* t = getenv("PIPER_HIP_WN")) wn_ = atoi(t);              // opt-in: fused WN layers (kernels/wn.h); read before the weights are packed
   if (const char* t = getenv("PIPER_HIP_MRF_MAXF")) mrf_rb1_max_frames_ = atol(t);
@@ -1004,8 +1005,12 @@ void Engine::group_end_sum(View out, const float* bias_sum, float alpha) {
   const size_t smem = std::max<size_t>((size_t)NW * KC * 128, (size_t)NW * 16 * 64) * sizeof(float);
   const dim3 grid((group_ncols_ + 31) / 32, (q.rows + 31) / 32, B_);
   // (a 4-deep weight ring measured slower than 2: hifigan stage 0.345 vs 0.338 ms)
-  const int kh = kbegin(prof_level_ >= 2 ? krow("conv_splitk_sum_kernel<4,2>") : 0, group_flops_, group_bytes_);
-  launch::conv_group_sum(grid, smem, ls_, q);
+  // (a 16-deep ring -- the whole K range of a wave in flight at entry, one workgroup per CU -- is opt-in: PIPER_HIP_SUMD=16)
+  int maxsteps = 0;
+  for (int i = 0; i < q.nseg; ++i) maxsteps += q.seg_ntaps[i];          // steps of a wave that holds one chunk of every segment
+  const bool deep = sum_deep_ && q.nchunks <= NW && maxsteps <= 16;
+  const int kh = kbegin(prof_level_ >= 2 ? krow(deep ? "conv_splitk_sum_kernel<4,16>" : "conv_splitk_sum_kernel<4,2>") : 0, group_flops_, group_bytes_);
+  launch::conv_group_sum(grid, smem, ls_, q, deep);
   kend(kh);
   group_.clear();
 }

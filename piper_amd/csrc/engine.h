@@ -185,6 +185,7 @@ class Engine {
   int wn_ = 0;
   int upre_ = 0;                            // PIPER_HIP_UPPRE=1 (opt-in until measured): conv_small_kernel for the late up-convs of small calls
   long upre_max_blocks_ = 1024;
+  bool sum_deep_ = false;                   // PIPER_HIP_SUMD=16 (opt-in until measured): conv_splitk_sum_kernel<4,16>
   static constexpr long wn_max_frames_ = 2048;
   float* wn_pr_[2] = {nullptr, nullptr};
   float* wn_ps_ = nullptr;

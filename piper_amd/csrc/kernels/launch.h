@@ -18,7 +18,7 @@ void conv_tile(int cfg, bool gate, int halo, dim3 grid, size_t smem, hipStream_t
 void conv_splitk(bool gate, int nw, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p);
 void conv_splitk16(bool gate, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p);
 void conv_group(bool wide, dim3 grid, size_t smem, hipStream_t stream, const ConvG& g);
-void conv_group_sum(dim3 grid, size_t smem, hipStream_t stream, const ConvP& p);
+void conv_group_sum(dim3 grid, size_t smem, hipStream_t stream, const ConvP& p, bool deep = false);      // deep: the 16-step weight ring (opt-in)
 void conv_small(dim3 grid, size_t smem, hipStream_t stream, const ConvP& p);      // small-K conv, everything prefetched (conv_small.h, opt-in)
 
 // ---- split-bf16 tiled conv GEMM (launch_bf3.cpp; opt-in matrix mode PIPER_HIP_MATRIX=bf16x3)

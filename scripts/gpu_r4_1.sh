@@ -17,6 +17,10 @@ done
 for u in 0 1 0 1; do
   PIPER_HIP_UPPRE=$u timeout 300 python bench.py $BQ --steps 300 --warmup 10 > $O/b1_upre${u}_$RANDOM.json 2>> $O/err.log
 done
+# the 16-deep weight ring of the K-concatenated stage-1 launch (PIPER_HIP_SUMD=16), B=1
+for d in 2 16 2 16; do
+  PIPER_HIP_SUMD=$d timeout 300 python bench.py $BQ --steps 300 --warmup 10 > $O/b1_sumd${d}_$RANDOM.json 2>> $O/err.log
+done
 grep -v amdgpu.ids $O/err.log | tail -3
 python - <<'PY'
 import json,glob,os
@@ -26,6 +30,6 @@ for f in sorted(glob.glob("gpurun_out/r4a/*.json")):
     r=d.get("roofline") or {}
     print("%-22s ms %8.4f launches %s stages %s" % (os.path.basename(f), d["ms_per_step"], d["config"].get("kernel_launches_per_step"), {k[:4]:round(v,3) for k,v in r.get("stage_ms",{}).items()}))
     for k,v in r.get("kernels",{}).items():
-        if any(x in k for x in ("wn_kernel","splitk16_kernel<true","colchain4","conv_small","conv_mfma")): print("     %-40s %5.1f x %7.2f us" % (k, v["launches_per_step"], v["avg_launch_us"]))
+        if any(x in k for x in ("wn_kernel","splitk16_kernel<true","colchain4","conv_small","conv_mfma","conv_splitk_sum")): print("     %-40s %5.1f x %7.2f us" % (k, v["launches_per_step"], v["avg_launch_us"]))
 print(d.get("xcd_dispatch"))
 PY

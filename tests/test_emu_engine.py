@@ -477,3 +477,25 @@ def test_emulated_preloaded_small_k_upconv(emu_lib, monkeypatch):
         o = O.synthesize(w, cfg, ids[i], (0.0, 1.0, 0.0))
         assert np.array_equal(outs[0].audio[i], outs[1].audio[i])        # the same fmaf chain: bit-identical
         assert np.max(np.abs(outs[1].audio[i] - o["audio"])) < 1e-5
+
+
+def test_emulated_deep_ring_sum_kernel(emu_lib, monkeypatch):
+    """Opt-in PIPER_HIP_SUMD=16: conv_splitk_sum_kernel<4,16> (a wave's whole K range of the K-concatenated sibling convs in
+    flight at kernel entry) gives bit for bit what the 2-deep ring gives -- the ring depth does not enter the fmaf chain."""
+    monkeypatch.setenv("PIPER_HIP_MRF", "0")          # the tiny voice's stages would otherwise run as fused stage kernels
+    cfg = W.preset("tiny")
+    w = W.synthetic_weights(cfg, 1234)
+    ids = [W.synthetic_phoneme_ids(12, 0, id_max=cfg.n_vocab - 1)]
+    outs = []
+    for d in ("2", "16"):
+        monkeypatch.setenv("PIPER_HIP_SUMD", d)
+        eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
+        eng.profile_enable(2)
+        r = eng.synthesize_batch(ids, (0.0, 1.0, 0.0))
+        names = {row["name"] for row in eng.profile()[5:] if row["launches"]}
+        assert ("conv_splitk_sum_kernel<4,16>" if d == "16" else "conv_splitk_sum_kernel<4,2>") in names
+        outs.append(r.audio[0])
+        eng.close()
+    assert np.array_equal(outs[0], outs[1])
+    o = O.synthesize(w, cfg, ids[0], (0.0, 1.0, 0.0))
+    assert np.max(np.abs(outs[1] - o["audio"])) < 1e-5

@@ -45,7 +45,7 @@ def make_engine(monkeypatch, cfg, w, env=None):
               "PIPER_HIP_WIDE_SPLITK", "PIPER_HIP_DEBUG_KEEP", "PIPER_HIP_MRF", "PIPER_HIP_FUSE_DP",
               "PIPER_HIP_MRF_MAXF", "PIPER_HIP_SPEC", "PIPER_HIP_COLCHAIN", "PIPER_HIP_GROUP_MRF", 
               "PIPER_HIP_MRF_OU", "PIPER_HIP_MATRIX", "PIPER_HIP_BF3_MINF", "PIPER_HIP_MRF_TAIL", "PIPER_HIP_COL4",
-              "PIPER_HIP_COL4_MAXC", "PIPER_HIP_FFN", "PIPER_HIP_WN", "PIPER_HIP_XCD", "PIPER_HIP_UPPRE"):
+              "PIPER_HIP_COL4_MAXC", "PIPER_HIP_FFN", "PIPER_HIP_WN", "PIPER_HIP_XCD", "PIPER_HIP_UPPRE", "PIPER_HIP_SUMD"):
         monkeypatch.delenv(k, raising=False)
     for k, v in (env or {}).items():
         monkeypatch.setenv(k, str(v))

@@ -34,3 +34,14 @@ def test_preloaded_small_k_upconvs_match_oracle(monkeypatch, preset, lens):
     eng.close()
     assert "conv_small_kernel" in names, sorted(names)
     print("preloaded up-convs, kernels:", sorted(names), "worst |d audio| %.2e" % worst)
+
+
+def test_deep_ring_sum_kernel_matches_oracle(monkeypatch):
+    """PIPER_HIP_SUMD=16: the K-concatenated last convs of the 128-channel stage's sibling resblocks with a wave's whole K
+    range in flight at kernel entry (conv_splitk_sum_kernel<4,16>); bit-identical to the 2-deep ring on the emulator."""
+    cfg, w = voice("medium")
+    eng = make_engine(monkeypatch, cfg, w, {"PIPER_HIP_SUMD": 16})
+    ids, nw, nz = batch_inputs(cfg, [117], seed=151)
+    names, worst = run_and_check(eng, cfg, w, ids, nw, nz, sample=[0])
+    eng.close()
+    assert "conv_splitk_sum_kernel<4,16>" in names, sorted(names)
