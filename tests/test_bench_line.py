@@ -1,0 +1,76 @@
+"""The driver parses the LAST stdout line of bench.py from a size-capped tail: it must be one small JSON object
+(round 3 lost its measurement to a 47 KB line). Canned input: the full result object of a real run."""
+import copy
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+CANNED = os.path.join(ROOT, "profiles", "r03_bench_default.json")
+
+
+def _full():
+    return json.load(open(CANNED))
+
+
+def _check(line, n_gpus):
+    assert "\n" not in line
+    assert len(line) < bench.COMPACT_LIMIT, len(line)
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["n_gpus"] == n_gpus and d["unit"] == "samples/s" and d["dtype"] == "f32"
+    assert "model" not in d["config"] and d["config"]["workload"]
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+        assert k in r, k
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    return d
+
+
+def test_single_gpu_line_is_compact_and_complete():
+    full = _full()
+    assert len(json.dumps(full)) > 40000                 # the canned object really is the oversized one
+    d = _check(bench.compact_line(full, "bench_full.json"), 1)
+    cb = d["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert abs(d["value"] - full["value"]) / full["value"] < 1e-5
+    assert abs(d["ms_per_step"] - full["ms_per_step"]) / full["ms_per_step"] < 1e-4
+    legs = d["extra_configs"]
+    assert len(legs) == len(full["extra_configs"])
+    assert all(len(json.dumps(l, separators=(",", ":"))) <= 250 for l in legs)
+    assert d["full"] == "bench_full.json"
+
+
+def test_multi_gpu_line_is_compact():
+    full = _full()
+    full.pop("extra_configs")
+    full.pop("cpu_baseline")
+    full["n_gpus"] = 8
+    full["per_rank_samples_per_s"] = [3.4e8 + i for i in range(8)]
+    full["single_gpu_reference"] = {"value": 3.45e8, "ms_per_step": 18.8, "steps": 10, "what": "x" * 300}
+    full["b1_per_gpu"] = {"config": {"workload": "y" * 300}, "value": 8.8e8, "unit": "samples/s", "x_realtime": 4e4,
+                          "ms_per_step": 0.95, "steps": 100, "per_rank_samples_per_s": [1.1e8] * 8}
+    full["weight_broadcast_bytes"] = 139000000
+    full["weight_broadcast_s"] = 0.0021
+    d = _check(bench.compact_line(full, None), 8)
+    assert len(d["per_rank_samples_per_s"]) == 8 and d["b1_per_gpu"]["value"] == 8.8e8
+    assert d["weight_broadcast"]["bytes"] == 139000000
+
+
+def test_line_sheds_optional_parts_rather_than_overflow():
+    full = _full()
+    leg = copy.deepcopy(full["extra_configs"][0])
+    full["extra_configs"] = [dict(leg, leg=f"leg {i} " + "z" * 40) for i in range(40)]
+    line = bench.compact_line(full, "bench_full.json")
+    d = _check(line, 1)
+    assert "extra_configs" not in d and "cpu_baseline" in d and "roofline" in d
+
+
+def test_failed_leg_is_reported_short():
+    e = bench.compact_leg({"leg": "configs[2]", "error": "RuntimeError: " + "q" * 1000})
+    assert len(json.dumps(e)) < 250 and e["error"].startswith("RuntimeError")
