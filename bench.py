@@ -830,7 +830,9 @@ def cpu_baseline(cfg, wts, ids, scales, noise_w, budget_s, preset="medium"):
     single = {"value": samples / dt, "cores": cores, "x_realtime": samples / dt / cfg.sample_rate}
     # ---- all host cores: P independent copies of that sequential program side by side (P * threads <= cores), the way
     # a CPU server would use the box; this is `value` when it beats the single program (it does on a 256-core host)
-    allc = cpu_all_cores(preset, len(ids), ncpu, budget_s)
+    ucores = usable_cores()
+    allc = cpu_all_cores(preset, len(ids), ucores, budget_s)
+    single["usable_cores"] = ucores
     if allc and allc["value"] > single["value"]:
         return {"value": allc["value"], "unit": "samples/s", "cores": allc["cores"], "kind": "port",
                 "onnxruntime_probe": ort_probe, "x_realtime": allc["value"] / cfg.sample_rate,
@@ -838,41 +840,67 @@ def cpu_baseline(cfg, wts, ids, scales, noise_w, budget_s, preset="medium"):
                 "note": "torch-CPU port of the reference graph (the oracle), not onnxruntime: the reference's own CPU "
                         "path cannot be built or imported on this box",
                 "sample": f"{allc['syntheses']} B=1 syntheses of the same {len(ids)}-id utterance in {allc['seconds']:.1f} s by "
-                          f"{allc['processes']} processes x {allc['threads_each']} threads (torch CPU fp32, {ncpu}-core host); one "
+                          f"{allc['processes']} processes x {allc['threads_each']} thread (torch CPU fp32, {ucores} usable of {ncpu} cores); one "
                           f"program alone on {cores} threads: {single['value'] / 1e6:.2f} M samples/s"}
     return {"value": samples / dt, "unit": "samples/s", "cores": cores, "kind": "port", "onnxruntime_probe": ort_probe,
-            "x_realtime": samples / dt / cfg.sample_rate,
+            "x_realtime": samples / dt / cfg.sample_rate, "usable_cores": ucores, "all_cores_attempt": allc,
             "note": "torch-CPU port of the reference graph (the oracle), not onnxruntime: the reference's own CPU path "
                     "cannot be built or imported on this box",
             "sample": f"{n} sequential B=1 syntheses of the same {len(ids)}-id utterance in {dt:.1f} s "
                       f"(torch CPU fp32, {cores} threads chosen by a probe over 1..64 on a {ncpu}-core host)"}
 
 
+def usable_cores():
+    """Cores this process may actually use: the affinity mask, capped by the cgroup CPU quota (a container on a 256-core
+    host can be limited to a few of them; os.cpu_count() does not say)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                if q > 0:
+                    n = min(n, max(1, q // per))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def cpu_all_cores(preset, T, ncpu, budget_s):
-    """P worker processes (oracle/cpu_worker.py) x a small thread count each over a shared window of ~budget_s/2 seconds."""
-    threads = 4 if ncpu >= 16 else 1
-    procs = max(1, min(64, ncpu // threads))
+    """P single-threaded worker processes (oracle/cpu_worker.py; one thread each, so nothing spins when the box has fewer
+    usable cores than it reports) over a shared window of ~budget_s/2 seconds."""
+    threads = 1
+    procs = max(1, min(64, ncpu))
     if procs < 2:
         return None
     seconds = max(4.0, min(10.0, budget_s / 2))
     start_at = time.time() + 25.0                     # imports + voice generation + one warm-up synthesis per worker
     env = dict(os.environ, OMP_NUM_THREADS=str(threads), MKL_NUM_THREADS=str(threads))
     cmd = [sys.executable, os.path.join(ROOT, "oracle", "cpu_worker.py"), preset, str(T), str(threads), str(seconds)]
-    ps = [subprocess.Popen(cmd + [str(start_at)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, text=True)
+    ps = [subprocess.Popen(cmd + [str(start_at)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, text=True)
           for _ in range(procs)]
-    rows = []
+    rows, err = [], None
     for p in ps:
         try:
-            o, _ = p.communicate(timeout=120)
+            o, e = p.communicate(timeout=120)
             rows.append(json.loads(o.strip().splitlines()[-1]))
-        except Exception:          # noqa: BLE001 -- a worker that failed simply does not count
+        except Exception as ex:          # noqa: BLE001 -- a worker that failed simply does not count
             p.kill()
+            err = err or f"{type(ex).__name__}: {ex}"
     if not rows:
-        return None
+        return {"value": 0.0, "error": err}
     t0, t1 = min(r["t0"] for r in rows), max(r["t1"] for r in rows)
     samples = sum(r["samples"] for r in rows)
     return {"value": samples / (t1 - t0), "cores": len(rows) * threads, "processes": len(rows), "threads_each": threads,
-            "syntheses": sum(r["n"] for r in rows), "seconds": t1 - t0}
+            "syntheses": sum(r["n"] for r in rows), "seconds": t1 - t0, "error": err}
 
 
 if __name__ == "__main__":

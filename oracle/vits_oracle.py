@@ -353,6 +353,51 @@ def generate_path(duration, mask):
     return path.unsqueeze(1).transpose(2, 3) * mask
 
 
+@torch.no_grad()
+def stream_chunks(w, cfg, z, chunk_frames: int, pad_frames: int, sid: Optional[int] = None):
+    """The reference's chunked decode (infer_onnx_streaming.py:76-124): the latent z [inter, F] is cut into chunks of
+    `chunk_frames` frames, every chunk is decoded together with `pad_frames` frames of its neighbours (as many as exist)
+    and the padding's samples are trimmed; each chunk is converted to int16 on its own peak (:122). Restated without the
+    script's end-pad bug (`audio[start:-wav_end_pad]` reuses the previous chunk's end pad on the LAST chunk, :107-110)
+    and without its "too short to stream" shortcut, so that every chunk goes through the same path.
+    Returns [(float chunk, int16 chunk), ...]."""
+    if not isinstance(next(iter(w.values())), torch.Tensor):
+        w = to_torch(w)
+    zt = torch.as_tensor(np.asarray(z), dtype=w["enc_p.emb.weight"].dtype)[None]
+    g = None
+    if cfg.n_speakers > 1:
+        g = F.embedding(torch.tensor([int(sid or 0)]), w["emb_g.weight"]).unsqueeze(-1)
+    Fr = zt.shape[2]
+    hop = int(np.prod(cfg.up_rates))
+    out = []
+    for s in range(0, Fr, chunk_frames):
+        e = min(Fr, s + chunk_frames)
+        ps, pe = min(pad_frames, s), min(pad_frames, Fr - e)
+        a = generator(w, cfg, zt[:, :, s - ps:e + pe], g=g)[0, 0].numpy()
+        a = a[ps * hop:a.size - pe * hop]
+        out.append((a, audio_float_to_int16(a)))
+    return out
+
+
+@torch.no_grad()
+def durations_only(w, cfg, ids, scales, noise_w=None, sid: Optional[int] = None) -> np.ndarray:
+    """The integer durations ceil(exp(logw) * length_scale) of one utterance (models.py:688-703): text encoder +
+    stochastic duration predictor only -- cheap enough to check EVERY utterance of a large batch."""
+    if not isinstance(next(iter(w.values())), torch.Tensor):
+        w = to_torch(w)
+    dtype = w["enc_p.emb.weight"].dtype
+    ids_t = torch.as_tensor(np.asarray(ids), dtype=torch.long).view(1, -1)
+    T = ids_t.shape[1]
+    x, _, _, x_mask = text_encoder(w, cfg, ids_t, torch.tensor([T], dtype=torch.long))
+    g = None
+    if cfg.n_speakers > 1:
+        g = F.embedding(torch.tensor([int(sid or 0)]), w["emb_g.weight"]).unsqueeze(-1)
+    nw = torch.zeros(1, 2, T, dtype=dtype) if noise_w is None else \
+        torch.as_tensor(np.asarray(noise_w), dtype=dtype).view(1, 2, -1)[:, :, :T]
+    logw = sdp_reverse(w, cfg, x, x_mask, nw, float(scales[2]), g=g)
+    return torch.ceil(torch.exp(logw) * x_mask * float(scales[1]))[0, 0].to(torch.int64).numpy()
+
+
 def infer_one(w, cfg, ids, scales, noise_w=None, noise_z=None, sid: Optional[int] = None,
               keep=False) -> Dict[str, torch.Tensor]:
     """One utterance through SynthesizerTrn.infer as wrapped by export_onnx.py:56-69 (B=1, like

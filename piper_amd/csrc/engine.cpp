@@ -360,47 +360,6 @@ float* Engine::pack16_conv(const WeightSet& ws, const std::string& wname, int in
   return pack16(W, Co, Ci);
 }
 
-// WN weights in wn_kernel's per-slice orders (kernels/wn.h). Gate conv [384][192][5] -> [slice 8][tap 5][tile 3][wave 4]
-// [quad 3][lane][4]: slice row 16 tile + (lane & 15) = tanh row 24 slice + r for r < 24, sigmoid row 192 + 24 slice + r - 24
-// otherwise; channel 48 wave + 4 (4 quad + j) + (lane >> 4).
-const float* Engine::pack_wn_gate(const WeightSet& ws, const std::string& wname) {
-  const HostTensor& w = ws.get(wname);
-  if (w.dims.size() != 3 || w.dims[0] != 384 || w.dims[1] != 192 || w.dims[2] != 5) return nullptr;
-  const size_t np = (size_t)384 * 192 * 5;
-  std::vector<float> P(skeleton_ ? 0 : np, 0.f);
-  for (int s = 0; s < (skeleton_ ? 0 : 8); ++s)
-    for (int tp = 0; tp < 5; ++tp)
-      for (int m = 0; m < 3; ++m)
-        for (int wv = 0; wv < 4; ++wv)
-          for (int q = 0; q < 3; ++q)
-            for (int lane = 0; lane < 64; ++lane)
-              for (int j = 0; j < 4; ++j) {
-                const int r = 16 * m + (lane & 15);
-                const int row = r < 24 ? 24 * s + r : 192 + 24 * s + (r - 24);
-                const int ch = 48 * wv + 4 * (4 * q + j) + (lane >> 4);
-                P[((((((size_t)s * 5 + tp) * 3 + m) * 4 + wv) * 3 + q) * 64 + lane) * 4 + j] = w.data[((size_t)row * 192 + ch) * 5 + tp];
-              }
-  return dev_alloc(np, skeleton_ ? nullptr : P.data());
-}
-// Res/skip conv [rows = 384 | 192][192][1] -> [slice 8][row tile rows/16][quad 2][lane][4]: row 16 tile + (lane & 15),
-// slice channel k = 4 (4 quad + j) + (lane >> 4) < 24 (K padded to 32 with zeros) = input channel 24 slice + k.
-const float* Engine::pack_wn_rs(const WeightSet& ws, const std::string& wname) {
-  const HostTensor& w = ws.get(wname);
-  if (w.dims.size() != 3 || (w.dims[0] != 384 && w.dims[0] != 192) || w.dims[1] != 192 || w.dims[2] != 1) return nullptr;
-  const int rows = (int)w.dims[0];
-  const size_t np = (size_t)8 * rows * 32;
-  std::vector<float> P(skeleton_ ? 0 : np, 0.f);
-  for (int s = 0; s < (skeleton_ ? 0 : 8); ++s)
-    for (int rt = 0; rt < rows / 16; ++rt)
-      for (int q = 0; q < 2; ++q)
-        for (int lane = 0; lane < 64; ++lane)
-          for (int j = 0; j < 4; ++j) {
-            const int row = 16 * rt + (lane & 15), k = 4 * (4 * q + j) + (lane >> 4);
-            if (k < 24) P[((((size_t)s * (rows / 16) + rt) * 2 + q) * 64 + lane) * 4 + j] = w.data[(size_t)row * 192 + 24 * s + k];
-          }
-  return dev_alloc(np, skeleton_ ? nullptr : P.data());
-}
-
 // A 1x1 conv weight [Co][Ci][1] with Ci < 192 in pack4 order with K zero-padded to 192, for colchain4_kernel mode 3 (whose
 // input descriptor ends after the Ci real rows, so the padded channels read as zeros too).
 const float* Engine::pack4_conv_pad192(const WeightSet& ws, const std::string& wname, int in_rev, int out_rev) {
@@ -460,9 +419,6 @@ Engine::Engine(const WeightSet& ws, int device, ArenaSpec arena) : device_(devic
 
 void Engine::init(const WeightSet& ws) {
   if (const char* t = getenv("PIPER_HIP_MRF")) mrf_mode_ = atoi(t);       // A/B knob: 0 = conv-by-conv MRF stages, 2 = always fused
-  if (const char* t = getenv("PIPER_HIP_SUMD")) sum_deep_ = atoi(t) >= 16;   // opt-in: 16-deep weight ring of conv_splitk_sum_kernel
-  if (const char* t = getenv("PIPER_HIP_UPPRE")) upre_ = atoi(t);        // opt-in: preloaded small-K up-convs (kernels/conv_small.h)
-  if (const char* t = getenv("PIPER_HIP_WN")) wn_ = atoi(t);              // opt-in: fused WN layers (kernels/wn.h); read before the weights are packed
   if (const char* t = getenv("PIPER_HIP_MRF_MAXF")) mrf_rb1_max_frames_ = atol(t);
   if (const char* t = getenv("PIPER_HIP_MRF_OU")) mrf_ou_ = atoi(t);
   if (const char* t = getenv("PIPER_HIP_MRF_TAIL")) mrf_tail_ = atoi(t) != 0;   // A/B knob, tests: conv_post inside the last mrf_kernel
@@ -572,22 +528,9 @@ void Engine::init(const WeightSet& ws) {
           const HostTensor& wrs = ws.get(p + ".enc.res_skip_layers." + s + ".weight");
           r.rs4.push_back(wrs.dims.size() == 3 && wrs.dims[2] == 1 ? pack4(wrs.data, (int)wrs.dims[0], (int)wrs.dims[1]) : nullptr);
         }
-        if (wn_ && H_ == 192 && wnk == 5) {      // fused WN layer (kernels/wn.h): packed only when the mode is on (30 MB for the medium voice)
-          r.wn_g.push_back(pack_wn_gate(ws, p + ".enc.in_layers." + s + ".weight"));
-          r.wn_r.push_back(pack_wn_rs(ws, p + ".enc.res_skip_layers." + s + ".weight"));
-        }
         (void)wnk;
       }
       r.post = pack_conv(ws, p + ".post.weight", p + ".post.bias", 1, -1, false, 0, odd);
-      if (wn_ && (int)r.wn_g.size() == wnl) {      // sum of the layers' skip biases: rows [192, 384) of res_skip_i, all rows of the last
-        std::vector<float> sb(skeleton_ ? 0 : 192, 0.f);
-        for (int i = 0; i < (skeleton_ ? 0 : wnl); ++i) {
-          const HostTensor& bb = ws.get(p + ".enc.res_skip_layers." + std::to_string(i) + ".bias");
-          const int off = bb.numel() > 192 ? 192 : 0;
-          for (int c = 0; c < 192; ++c) sb[c] += bb.data[off + c];
-        }
-        r.skip_bias_sum = dev_alloc(192, skeleton_ ? nullptr : sb.data());
-      }
       r.pre16 = pack16_conv(ws, p + ".pre.weight", odd, 0);
       if (H_ == 192 && rcls_.empty()) r.pre4pad = pack4_conv_pad192(ws, p + ".pre.weight", odd, 0);   // first layer's pre: a launch of its own
       r.post16 = pack16_conv(ws, p + ".post.weight", 0, odd);
@@ -761,8 +704,6 @@ void Engine::free_all() {
   ev_pool_.clear();
   for (float*& p : side_) { if (p) hipFree(p); p = nullptr; }
   if (ffn_parts_) { hipFree(ffn_parts_); ffn_parts_ = nullptr; }
-  for (float*& q : wn_pr_) { if (q) hipFree(q); q = nullptr; }
-  if (wn_ps_) { hipFree(wn_ps_); wn_ps_ = nullptr; }
   if (stream_) hipStreamDestroy(stream_);
   wsA_ = wsB_ = nullptr; h_audio_ = nullptr; h_pcm_ = nullptr; h_pcm_zc_ = nullptr; h_frames_ = nullptr;
   ev0_ = ev1_ = nullptr; stream_ = nullptr;
@@ -789,7 +730,7 @@ void Engine::probe_xcds() {
     if (ok && c > 1 && xcc_of_[c] == xcc_of_[0]) P = c;
   }
   xcd_period_ = P;
-  if (const char* t = getenv("PIPER_HIP_XCD")) xcd_period_ = atoi(t);      // A/B knob: 0 = tiles in workgroup order
+  if (const char* t = getenv("PIPER_HIP_XCD")) xcd_period_ = std::min(32, std::max(0, atoi(t)));      // A/B knob: 0 = tiles in workgroup order
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -862,14 +803,6 @@ void Engine::ensure_stage_a(int B, int Tmax) {
 }
 
 void Engine::ensure_stage_b(int Fmax) {
-  if (wn_ && !wn_ps_ && H_ == 192 && !rcls_.empty() && !rcls_[0].wn_g.empty()) {
-    // partial products of the fused WN layers (kernels/wn.h), once: res partials [tile16][8][192][16] x 2 (ping-pong), skip
-    // partials [tile4][<= 32][192][4], for wn_max_frames_ frames per call (+ tile padding of up to 128 utterances)
-    PE_HIP(hipStreamSynchronize(stream_));
-    const size_t cols = (size_t)wn_max_frames_ + 2048;
-    for (float*& q : wn_pr_) PE_HIP(hipMalloc((void**)&q, cols * 8 * H_ * sizeof(float)));
-    PE_HIP(hipMalloc((void**)&wn_ps_, (cols / 4 + 128) * 32 * H_ * 4 * sizeof(float)));
-  }
   const int Fs = rup(Fmax, 128);
   bool grow = false;
   if ((size_t)Fs > capB_F_) { capB_F_ = Fs; grow = true; }
@@ -1005,12 +938,10 @@ void Engine::group_end_sum(View out, const float* bias_sum, float alpha) {
   const size_t smem = std::max<size_t>((size_t)NW * KC * 128, (size_t)NW * 16 * 64) * sizeof(float);
   const dim3 grid((group_ncols_ + 31) / 32, (q.rows + 31) / 32, B_);
   // (a 4-deep weight ring measured slower than 2: hifigan stage 0.345 vs 0.338 ms)
-  // (a 16-deep ring -- the whole K range of a wave in flight at entry, one workgroup per CU -- is opt-in: PIPER_HIP_SUMD=16)
-  int maxsteps = 0;
-  for (int i = 0; i < q.nseg; ++i) maxsteps += q.seg_ntaps[i];          // steps of a wave that holds one chunk of every segment
-  const bool deep = sum_deep_ && q.nchunks <= NW && maxsteps <= 16;
-  const int kh = kbegin(prof_level_ >= 2 ? krow(deep ? "conv_splitk_sum_kernel<4,16>" : "conv_splitk_sum_kernel<4,2>") : 0, group_flops_, group_bytes_);
-  launch::conv_group_sum(grid, smem, ls_, q, deep);
+  // (a 16-deep ring -- a wave's whole K range in flight at entry, 256 registers, one workgroup per CU -- measured 59 us
+  // against 30: profiles/r04_notes.md)
+  const int kh = kbegin(prof_level_ >= 2 ? krow("conv_splitk_sum_kernel<4,2>") : 0, group_flops_, group_bytes_);
+  launch::conv_group_sum(grid, smem, ls_, q);
   kend(kh);
   group_.clear();
 }
@@ -1139,15 +1070,6 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     }
     launch::conv_bf3(bc, pc.gate, HALO, grid, smem, ls_, p);
     kend(kh);
-    return;
-  }
-  if (upre_ && epi == EPI_CONVT && !pc.gate && pc.nchunks <= 4 && pc.nchunks * pc.ntaps <= 8 && p.xhalo <= 64 &&
-      pc.mtiles % 2 == 0 && (long)((ncols + 63) / 64) * (pc.mtiles / 2) * B_ <= upre_max_blocks_) {
-    // opt-in: a small-K up-conv of a small call with everything prefetched (kernels/conv_small.h)
-    const dim3 gs((ncols + 63) / 64, pc.mtiles / 2, B_);
-    const int khs = kbegin(prof_level_ >= 2 ? krow("conv_small_kernel") : 0, kflops, kbytes);
-    launch::conv_small(gs, (size_t)pc.nchunks * KC * 128 * sizeof(float), ls_, p);
-    kend(khs);
     return;
   }
   if (blocks < 192 || small_tiles_) {   // medium-small: smaller tiles, more workgroups
@@ -1853,38 +1775,7 @@ void Engine::issue_flow() {
         conv(r.pre, x0, fh, lens_b_, 1, Fmax, EPI_STORE);
     }
     const int nl = (int)r.in.size();
-    // Opt-in (PIPER_HIP_WN=1): every WN layer as ONE launch that leaves partial res / skip products for its consumers
-    // (kernels/wn.h) -- the next layer's launch and the coupling layer's post conv (colchain4_kernel mode 1).
-    const int nt16 = (Fmax + 15) / 16;
-    bool wnf = wn_ && chain && H_ == 192 && nl >= 2 && nl <= 4 && (int)r.wn_g.size() == nl && r.skip_bias_sum && wn_ps_ &&
-               col4_ && (col4_ == 2 || (long)B * Fmax <= col4_max_frames_) && B <= 128 && (long)B * nt16 * 16 <= wn_max_frames_ + 2048 &&
-               w4_of(r.post16) && (ri + 1 >= rcls_.size() || w4_of(rcls_[ri + 1].pre16));
-    for (int i = 0; i < nl && wnf; ++i) wnf = r.wn_g[i] && r.wn_r[i] && r.rs[i].rows == (i + 1 < nl ? 2 * H_ : H_);
-    if (wnf) {
-      float* xa = facts.p;
-      float* xb = fskip.p;
-      for (int i = 0; i < nl; ++i) {
-        WnP q{};
-        q.xprev = i <= 1 ? fh.p : ((i & 1) ? xb : xa);
-        q.x_bs = fh.bs; q.x_cs = fh.cs;
-        q.prev_parts = i ? wn_pr_[(i - 1) & 1] : nullptr;
-        q.prev_bias = i ? r.rs[i - 1].bias : nullptr;
-        q.xout = (i == 0 || i == nl - 1) ? nullptr : ((i & 1) ? xa : xb);
-        q.wg = r.wn_g[i]; q.bg = r.in[i].bias;
-        q.bias2 = nspk_ > 1 ? cond_ + cond_off_wn_[ri] + (long)i * 2 * H_ : nullptr;
-        q.bias2_bs = cond_bs_;
-        q.wr = r.wn_r[i]; q.rs_rows = r.rs[i].rows;
-        q.pr_out = i + 1 < nl ? wn_pr_[i & 1] : nullptr;
-        q.pr_bs = (long)nt16 * 8 * H_ * 16; q.ntiles = nt16;
-        q.ps_out = wn_ps_; q.ps_bs = (long)((Fmax + 3) / 4) * (nl * 8) * H_ * 4; q.ps_n = nl * 8; q.layer = i;
-        q.lens = lens_b_;
-        const int khw = kbegin(prof_level_ >= 2 ? krow("wn_kernel") : 0, 2.0 * fsum * (r.in[i].macs_per_col + r.rs[i].macs_per_col));
-        launch::wn(dim3(nt16, 8, B), ((size_t)192 * 48 + 4 * 48 * 16 + 32 * 16) * sizeof(float), stream_, q);
-        kend(khw);
-        fl += 2.0 * fsum * (r.in[i].macs_per_col + r.rs[i].macs_per_col);
-      }
-    }
-    for (int i = 0; i < nl && !wnf; ++i) {
+    for (int i = 0; i < nl; ++i) {
       const float* b2 = nspk_ > 1 ? cond_ + cond_off_wn_[ri] + (long)i * 2 * H_ : nullptr;
       conv(r.in[i], fh, facts, lens_b_, 1, Fmax, EPI_GATE, 1.f, ACT_NONE, none, none, 0, 1.f, b2, cond_bs_);
       if (r.rs4[i] && col4_ && (col4_ == 2 || (long)B * Fmax <= col4_max_frames_) && H_ == 192 && r.rs[i].rows <= 2 * H_) {
@@ -1909,10 +1800,6 @@ void Engine::issue_flow() {
       // post + "x1 -= m" + the next coupling layer's pre over the updated half, one launch
       ColP cp{};
       cp.in1 = fskip.p; cp.in1_bs = fskip.bs; cp.in1_cs = fskip.cs; cp.K1 = H_;
-      if (wnf) {      // the skip sum is still in pieces: bias sum + nl x 8 partial products per 4-column tile
-        cp.in1 = nullptr;
-        cp.parts = wn_ps_; cp.p_bs = (long)((Fmax + 3) / 4) * (nl * 8) * H_ * 4; cp.nparts = nl * 8; cp.pbias = r.skip_bias_sum;
-      }
       cp.w1 = r.post16; cp.b1 = r.post.bias; cp.rows1 = half;
       cp.mode = 1;
       cp.x1 = x1.p; cp.x1_bs = x1.bs; cp.x1_cs = x1.cs;

@@ -180,17 +180,6 @@ class Engine {
   const float* pack_ffn1(const WeightSet& ws, const std::string& wname);
   const float* pack_ffn2(const WeightSet& ws, const std::string& wname);
   float* ffn_parts_ = nullptr;
-  // fused WN layers (kernels/wn.h): PIPER_HIP_WN=1 (opt-in until measured); res partials (ping-pong) and skip partials,
-  // allocated on first use for wn_max_frames_ frames per call
-  int wn_ = 0;
-  int upre_ = 0;                            // PIPER_HIP_UPPRE=1 (opt-in until measured): conv_small_kernel for the late up-convs of small calls
-  long upre_max_blocks_ = 1024;
-  bool sum_deep_ = false;                   // PIPER_HIP_SUMD=16 (opt-in until measured): conv_splitk_sum_kernel<4,16>
-  static constexpr long wn_max_frames_ = 2048;
-  float* wn_pr_[2] = {nullptr, nullptr};
-  float* wn_ps_ = nullptr;
-  const float* pack_wn_gate(const WeightSet& ws, const std::string& wname);
-  const float* pack_wn_rs(const WeightSet& ws, const std::string& wname);
   static constexpr long ffn_max_cols_ = 2048;
   int ffn_ = 1;                             // PIPER_HIP_FFN=0: conv by conv (A/B, tests)
   float* xenc_ = nullptr;
@@ -290,10 +279,6 @@ class Engine {
   struct Rcl {
     PackedConv pre, post;
     float *pre16 = nullptr, *post16 = nullptr;   // the same two 1x1 convs in pack16 order (colchain_kernel)
-    // fused WN layers (kernels/wn.h, opt-in): per layer the gate conv / res-skip conv in wn_kernel's per-slice orders,
-    // and the sum of the layers' skip biases (added once by the consumer of the skip partials); empty: not packed
-    std::vector<const float*> wn_g, wn_r;
-    const float* skip_bias_sum = nullptr;
     const float* pre4pad = nullptr;               // the first layer's pre in pack4 order, K padded to 192 (colchain4_kernel mode 3)
     std::vector<PackedConv> in, rs;
     std::vector<const float*> rs4;   // the res/skip 1x1 convs in pack4 order (colchain4_kernel mode 2; null: not packed)

@@ -16,7 +16,9 @@ namespace pe {
 // different L2s (measured: the attention kernel behind such a launch ran 4.4 us slower). XCD j takes a contiguous run of
 // tiles instead (when the probe at engine creation saw that round-robin): 64 bytes per row from one L2 for a 128-id utterance, what a 16-column workgroup writes.
 // `P` = the number of XCDs when the dispatch was seen to be round-robin over them at engine creation (xcc_probe_kernel),
-// 0 otherwise: then tile = blockIdx.x.
+// 0 otherwise: then tile = blockIdx.x. (The round-robin runs over the LINEAR workgroup id, so in row (y, z) of the grid
+// workgroup x sits on XCD (base(y, z) + x) mod P: which XCD owns residue class x mod P changes from row to row, but a
+// class always sits on ONE XCD -- all the map needs.)
 __device__ __forceinline__ int c4_tile(int bx, int nx, int P) {
   if (P <= 1) return bx;
   const int q = nx / P, r = nx - q * P, i = bx / P, j = bx - i * P;
@@ -134,29 +136,11 @@ __global__ __launch_bounds__(256) void colchain4_kernel(ColP p) {
 #pragma unroll
     for (int k = 0; k < NVT; ++k) {
       const int c = rl + 64 * k;
-      xin[k] = pe_row_load(ind, (ok && !p.parts) ? c * p.in1_cs + t : -1);
+      xin[k] = pe_row_load(ind, ok ? c * p.in1_cs + t : -1);
       ov[k] = pe_row_load(od, (ok && c < rows_here) ? (p.mode == 3 ? c : c * ocs + t) : -1);
       gg[k] = pe_row_load(gd, c < rows_here ? c : -1);
       bb[k] = pe_row_load(bd, c < rows_here ? c : -1);
       b1v[k] = pe_row_load(b1d, c < rows_here ? c : -1);
-    }
-    if (p.parts) {
-      // mode 1 behind the fused WN layers: the skip sum = its bias sum + every layer's / slice's partial product, in order
-      const pe_rowsrc pd = pe_make_row(p.parts + (long)b * p.p_bs + (long)(t0 >> 2) * p.nparts * (K1 * 4), p.nparts * (K1 * 4));
-      const pe_rowsrc pbd = pe_make_row(p.pbias, K1);
-#pragma unroll
-      for (int k = 0; k < NVT; ++k) {
-        const int c = rl + 64 * k;
-        float a = 0.f;
-        for (int q0 = 0; q0 < p.nparts; q0 += 8) {          // 8 loads in flight at a time
-          float pv[8];
-#pragma unroll
-          for (int e = 0; e < 8; ++e) pv[e] = pe_row_load(pd, (ok && q0 + e < p.nparts) ? (q0 + e) * (K1 * 4) + c * 4 + col : -1);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) a += pv[e];
-        }
-        xin[k] = ok ? a + pe_row_load(pbd, c) : 0.f;
-      }
     }
 #pragma unroll
     for (int k = 0; k < NVT; ++k) YT[col * KS1 + rl + 64 * k] = xin[k];

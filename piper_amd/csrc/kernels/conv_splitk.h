@@ -282,11 +282,10 @@ __global__ __launch_bounds__(64 * NW, XW == 64 ? 4 : 2) void conv_splitk_group_k
 }
 // The siblings' LAST convs, whose outputs the MRF sums: one GEMM over the concatenated K (MS form of the body), one
 // output tensor -- no per-sibling outputs, no summing pass.
-// D = 16 (opt-in, PIPER_HIP_SUMD=16; not yet measured): a wave's whole K range -- 15 weight steps for the medium voice's
-// 128-channel stage -- in flight at kernel entry (256 registers: one workgroup per SIMD set instead of two). The device
-// trace shows the 2-deep ring of the default spending 1.8 us per step for 0.43 us of MFMAs with 1-2 workgroups per CU.
+// (D = 16 -- a wave's whole K range in flight at kernel entry, 256 registers, one workgroup per CU -- measured 59 us against
+// the 2-deep ring's 30 on the medium voice's 128-channel stage and was removed: profiles/r04_notes.md.)
 template <int NW, int D>
-__global__ __launch_bounds__(64 * NW, (D > 4 ? 1 : 2)) void conv_splitk_sum_kernel(ConvP p) {
+__global__ __launch_bounds__(64 * NW, 2) void conv_splitk_sum_kernel(ConvP p) {
   PE_KTRACE(8);
   PE_DYN_SMEM(float, sm);
   conv_splitk_body<1, false, NW, D, 128, true>(p, blockIdx.z, sm);

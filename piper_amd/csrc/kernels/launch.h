@@ -18,8 +18,7 @@ void conv_tile(int cfg, bool gate, int halo, dim3 grid, size_t smem, hipStream_t
 void conv_splitk(bool gate, int nw, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p);
 void conv_splitk16(bool gate, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p);
 void conv_group(bool wide, dim3 grid, size_t smem, hipStream_t stream, const ConvG& g);
-void conv_group_sum(dim3 grid, size_t smem, hipStream_t stream, const ConvP& p, bool deep = false);      // deep: the 16-step weight ring (opt-in)
-void conv_small(dim3 grid, size_t smem, hipStream_t stream, const ConvP& p);      // small-K conv, everything prefetched (conv_small.h, opt-in)
+void conv_group_sum(dim3 grid, size_t smem, hipStream_t stream, const ConvP& p);
 
 // ---- split-bf16 tiled conv GEMM (launch_bf3.cpp; opt-in matrix mode PIPER_HIP_MATRIX=bf16x3)
 void init_bf3();
@@ -38,7 +37,6 @@ void colchain(dim3 grid, size_t smem, hipStream_t stream, const ColP& p);
 void colchain4(dim3 grid, size_t smem, hipStream_t stream, const ColP& p);     // 4-column forms (col4.h): weights in pack4 order
 void lngemm(dim3 grid, size_t smem, hipStream_t stream, const LnGemmP& p);
 void lngemm4(dim3 grid, size_t smem, hipStream_t stream, const LnGemmP& p);
-void wn(dim3 grid, size_t smem, hipStream_t stream, const WnP& p);              // fused WN layer (wn.h, opt-in)
 void ffn(dim3 grid, size_t smem, hipStream_t stream, const FfnP& p);            // fused small-call FFN (ffn.h)
 void cf_pre(dim3 grid, hipStream_t stream, const float* z0, long z_bs, const float* w, const float* bias, const float* xg,
             long g_bs, int g_cs, float* out, long o_bs, int o_cs, const int* lens, int H);

@@ -3,7 +3,6 @@
 
 #include "conv_mfma.h"
 #include "conv_splitk.h"
-#include "conv_small.h"
 
 namespace pe {
 namespace launch {
@@ -21,8 +20,7 @@ void init_conv() {
                       (const void*)conv_splitk_kernel<2, true, 12, 2>, (const void*)conv_splitk_kernel<1, false, 12, 4>,
                       (const void*)conv_splitk16_kernel<true, 12, 2>, (const void*)conv_splitk16_kernel<false, 8, 4>,
                       (const void*)conv_splitk_group_kernel<4, 2, 64>, (const void*)conv_splitk_group_kernel<4, 2, 128>,
-                      (const void*)conv_splitk_sum_kernel<4, 2>, (const void*)conv_splitk_sum_kernel<4, 16>,
-                      (const void*)conv_small_kernel};
+                      (const void*)conv_splitk_sum_kernel<4, 2>};
 #undef PE_K2
   for (const void* k : ks) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
 #endif
@@ -77,13 +75,8 @@ void conv_group(bool wide, dim3 grid, size_t smem, hipStream_t stream, const Con
   else PE_LAUNCH((conv_splitk_group_kernel<4, 2, 64>), grid, dim3(256), smem, stream, g);
 }
 
-void conv_group_sum(dim3 grid, size_t smem, hipStream_t stream, const ConvP& p, bool deep) {
-  if (deep) PE_LAUNCH((conv_splitk_sum_kernel<4, 16>), grid, dim3(256), smem, stream, p);
-  else PE_LAUNCH((conv_splitk_sum_kernel<4, 2>), grid, dim3(256), smem, stream, p);
-}
-
-void conv_small(dim3 grid, size_t smem, hipStream_t stream, const ConvP& p) {
-  PE_LAUNCH(conv_small_kernel, grid, dim3(256), smem, stream, p);
+void conv_group_sum(dim3 grid, size_t smem, hipStream_t stream, const ConvP& p) {
+  PE_LAUNCH((conv_splitk_sum_kernel<4, 2>), grid, dim3(256), smem, stream, p);
 }
 
 }  // namespace launch

@@ -6,7 +6,6 @@
 #include "dds.h"
 #include "dds4.h"
 #include "ffn.h"
-#include "wn.h"
 #include "duration.h"
 #include "layernorm.h"
 #include "glue.h"
@@ -69,10 +68,6 @@ void ffn(dim3 grid, size_t smem, hipStream_t stream, const FfnP& p) {
 }
 
 void xcc_probe(hipStream_t stream, int* out64) { PE_LAUNCH(xcc_probe_kernel, dim3(64), dim3(64), 0, stream, out64); }
-
-void wn(dim3 grid, size_t smem, hipStream_t stream, const WnP& p) {
-  PE_LAUNCH(wn_kernel, grid, dim3(256), smem, stream, p);
-}
 
 void cf_pre(dim3 grid, hipStream_t stream, const float* z0, long z_bs, const float* w, const float* bias, const float* xg,
             long g_bs, int g_cs, float* out, long o_bs, int o_cs, const int* lens, int H) {

@@ -119,20 +119,6 @@ struct ColP {
   const int* lens;
   int first;                                            // mode 2 (colchain4_kernel): first WN layer -- the skip sum is not read
   int xcd;                                              // colchain4_kernel: XCDs the dispatch round-robins over (0: unknown)
-  // colchain4_kernel mode 1 with the fused WN layers (wn.h): in1 = pbias + the sum of nparts skip partials [tile4][nparts][192][4]
-  const float* parts; long p_bs; int nparts; const float* pbias;
-};
-// ---- fused WN layer (wn.h, opt-in): partial res / skip products per 24-channel slice
-struct WnP {
-  const float* xprev; long x_bs; int x_cs;       // the hidden state the PREVIOUS layer started from ([192][F]); layer 0: the state itself
-  const float* prev_parts; const float* prev_bias;   // previous layer's res partials [tile16][8][192][16] + its res bias (null: layer 0)
-  float* xout;                                   // this layer's input state, written back by the slice-0 workgroups (null: not needed)
-  const float* wg; const float* bg;              // gate conv: pack_wn_gate order per slice, bias [384]
-  const float* bias2; long bias2_bs;             // per-utterance conditioning added to the gate pre-activations (null: none)
-  const float* wr; int rs_rows;                  // res/skip conv: pack_wn_rs order per slice; 384 rows, or 192 (last layer: skip only)
-  float* pr_out; long pr_bs; int ntiles;         // res partials of this layer (null on the last layer), floats per utterance, 16-column tiles per utterance
-  float* ps_out; long ps_bs; int ps_n; int layer;   // skip partials [tile4][ps_n][192][4], this layer's index
-  const int* lens;
 };
 // ---- fused FFN (ffn.h): partial outputs per 48-row slice of the hidden dimension
 struct FfnP {

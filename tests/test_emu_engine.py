@@ -41,6 +41,7 @@ def test_emulated_pipeline_matches_golden(emu_lib):
     r = eng.synthesize(g["ids"], tuple(g["scales"]), noise_w=nw[0], noise_z=nz[0])
     assert np.array_equal(eng.durations(), g["durations"])
     assert np.max(np.abs(r.audio[0] - g["audio"])) < 1e-4
+    assert np.array_equal(O.audio_float_to_int16(r.audio[0]), r.pcm[0])      # integer work: 0 LSB on its own waveform
     ref = O.audio_float_to_int16(g["audio"])
     assert np.max(np.abs(r.pcm[0].astype(np.int32) - ref.astype(np.int32))) <= 4
 
@@ -58,6 +59,7 @@ def test_emulated_ragged_batch_and_errors(emu_lib):
         o = O.synthesize(w, cfg, ids[i], scales, nw[i], nz[i])
         assert rb.audio[i].shape == o["audio"].shape
         assert np.max(np.abs(rb.audio[i] - o["audio"])) < 1e-4
+        assert np.array_equal(O.audio_float_to_int16(rb.audio[i]), rb.pcm[i])
     with pytest.raises(EngineError):
         eng.synthesize([1, 0, 999, 2])
     with pytest.raises(EngineError):
@@ -94,6 +96,15 @@ def test_emulated_streaming_equals_unchunked(emu_lib):
     assert cat.shape == full.shape
     assert np.max(np.abs(cat - full)) < 1e-5
     assert all(c[1].dtype == np.int16 and np.max(np.abs(c[1].astype(np.int32))) <= 32767 for c in chunks)
+    # against the oracle's restatement of the reference's chunked decode (infer_onnx_streaming.py:76-124) on the oracle's z
+    o = O.synthesize(w, cfg, ids, (0.0, 1.0, 0.0), keep=True)
+    ref = O.stream_chunks(w, cfg, o["z"], 4, eng.stream_halo)
+    assert len(ref) == len(chunks)
+    for (a, p), (ra, rp) in zip(chunks, ref):
+        assert a.shape == ra.shape and np.max(np.abs(a - ra)) < 1e-4
+        assert np.array_equal(O.audio_float_to_int16(a), p)
+        assert np.sqrt(np.mean(((p.astype(np.float64) - rp) / 32767.0) ** 2)) <= 1e-3
+    assert np.max(np.abs(np.concatenate([c[0] for c in ref]) - o["audio"])) < 1e-5
 
 
 def test_emulated_wide_splitk_matches(emu_lib, monkeypatch):
@@ -387,41 +398,11 @@ def test_emulated_192_channel_small_call_kernels(emu_lib, monkeypatch, col4):
     eng.close()
 
 
-@pytest.mark.parametrize("preset,sids", [("tiny-ms", [1, 3])])
-def test_emulated_fused_wn_layers(emu_lib, monkeypatch, preset, sids):
-    """Opt-in PIPER_HIP_WN=1: every WN layer of the coupling flow as ONE launch (kernels/wn.h: the gated channels dealt
-    to the workgroups; partial res products summed by the next layer's launch, partial skip products by the post conv in
-    colchain4_kernel) on a 192-channel multi-speaker voice (conditioning bias on the gate pre-activations), ragged batch
-    spanning several 16-frame tiles -- against the oracle and against the default schedule."""
-    cfg = W.preset(preset, hidden=192, inter=192, filter=96, n_layers=1)
-    w = W.synthetic_weights(cfg, 77)
-    lens = [9, 21]
-    ids = [W.synthetic_phoneme_ids(T, i, id_max=cfg.n_vocab - 1) for i, T in enumerate(lens)]
-    nw = np.random.default_rng(5).standard_normal((len(lens), 2, max(lens))).astype(np.float32)
-    outs = []
-    for wn in ("0", "1"):
-        monkeypatch.setenv("PIPER_HIP_WN", wn)
-        eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
-        eng.profile_enable(2)
-        r = eng.synthesize_batch(ids, (0.0, 1.0, 0.8), noise_w=nw, sids=sids)
-        names = {row["name"] for row in eng.profile()[5:] if row["launches"]}
-        assert ("wn_kernel" in names) == (wn == "1")
-        outs.append((r, eng.durations()))
-        eng.close()
-    off = np.concatenate([[0], np.cumsum(lens)])
-    for i, T in enumerate(lens):
-        o = O.synthesize(w, cfg, ids[i], (0.0, 1.0, 0.8), nw[i], sid=None if sids is None else sids[i])
-        for r, durs in outs:
-            assert np.array_equal(durs[off[i]:off[i + 1]], o["durations"])
-            assert np.max(np.abs(r.audio[i] - o["audio"])) < 1e-5
-        assert np.max(np.abs(outs[0][0].audio[i] - outs[1][0].audio[i])) < 1e-5
-
-
 def test_small_call_kernels_do_not_depend_on_wave_order(emu_lib):
     """The fiber emulator runs the waves of a workgroup in ascending order between barriers; the GPU in no particular
     order. A missing barrier (one wave reading LDS another has not written yet) can therefore pass every other emulator
     test. hip_emu.cpp takes EMU_ORDER=reverse | shuffle (a different wave-interleaved order every scheduling sweep): the
-    small-call kernels of the 192-channel voices -- colchain4 / lngemm4 / dds_layer4 / ffn and the opt-in wn_kernel --
+    small-call kernels of the 192-channel voices -- colchain4 / lngemm4 / dds_layer4 / ffn --
     must give the oracle's answer, and bit for bit the same answer, under each order (tests/emu/order_check.py)."""
     import json
     import subprocess
@@ -429,11 +410,11 @@ def test_small_call_kernels_do_not_depend_on_wave_order(emu_lib):
     outs = []
     for order in ("reverse", "shuffle"):
         p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "emu", "order_check.py")], capture_output=True, text=True,
-                           timeout=900, env=dict(os.environ, EMU_ORDER=order, PIPER_HIP_WN="1"))
+                           timeout=900, env=dict(os.environ, EMU_ORDER=order))
         assert p.returncode == 0, p.stderr[-2000:]
         outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
     for o in outs:
-        assert {"colchain4_kernel", "lngemm4_kernel", "dds_layer4_kernel", "ffn_kernel", "wn_kernel"} <= set(o["kernels"])
+        assert {"colchain4_kernel", "lngemm4_kernel", "dds_layer4_kernel", "ffn_kernel"} <= set(o["kernels"])
         assert o["durations_equal"] and o["worst"] < 1e-5, o
     assert outs[0]["checksum"] == outs[1]["checksum"]
 
@@ -452,50 +433,3 @@ def test_xcd_dispatch_probe_and_override(emu_lib, monkeypatch):
     eng = Engine(blob=blob, lib=emu_lib)
     assert eng.xcc_pattern[1] == 0
     eng.close()
-
-
-def test_emulated_preloaded_small_k_upconv(emu_lib, monkeypatch):
-    """Opt-in PIPER_HIP_UPPRE=1: conv_small_kernel (kernels/conv_small.h: a polyphase up-conv with <= 8 chunk-tap units,
-    every weight fragment and x slab requested before the first MFMA) against the tiled kernel it replaces and the oracle;
-    PIPER_HIP_SPLITK_MAX=0 sends the tiny voice's convs to the tiled kernels at all."""
-    monkeypatch.setenv("PIPER_HIP_SPLITK_MAX", "0")
-    cfg = W.preset("tiny-high")
-    w = W.synthetic_weights(cfg, 1234)
-    lens = [12, 5]
-    ids = [W.synthetic_phoneme_ids(T, i, id_max=cfg.n_vocab - 1) for i, T in enumerate(lens)]
-    outs = []
-    for on in ("0", "1"):
-        monkeypatch.setenv("PIPER_HIP_UPPRE", on)
-        eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
-        eng.profile_enable(2)
-        r = eng.synthesize_batch(ids, (0.0, 1.0, 0.0))
-        names = {row["name"] for row in eng.profile()[5:] if row["launches"]}
-        assert ("conv_small_kernel" in names) == (on == "1")
-        outs.append(r)
-        eng.close()
-    for i in range(len(lens)):
-        o = O.synthesize(w, cfg, ids[i], (0.0, 1.0, 0.0))
-        assert np.array_equal(outs[0].audio[i], outs[1].audio[i])        # the same fmaf chain: bit-identical
-        assert np.max(np.abs(outs[1].audio[i] - o["audio"])) < 1e-5
-
-
-def test_emulated_deep_ring_sum_kernel(emu_lib, monkeypatch):
-    """Opt-in PIPER_HIP_SUMD=16: conv_splitk_sum_kernel<4,16> (a wave's whole K range of the K-concatenated sibling convs in
-    flight at kernel entry) gives bit for bit what the 2-deep ring gives -- the ring depth does not enter the fmaf chain."""
-    monkeypatch.setenv("PIPER_HIP_MRF", "0")          # the tiny voice's stages would otherwise run as fused stage kernels
-    cfg = W.preset("tiny")
-    w = W.synthetic_weights(cfg, 1234)
-    ids = [W.synthetic_phoneme_ids(12, 0, id_max=cfg.n_vocab - 1)]
-    outs = []
-    for d in ("2", "16"):
-        monkeypatch.setenv("PIPER_HIP_SUMD", d)
-        eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
-        eng.profile_enable(2)
-        r = eng.synthesize_batch(ids, (0.0, 1.0, 0.0))
-        names = {row["name"] for row in eng.profile()[5:] if row["launches"]}
-        assert ("conv_splitk_sum_kernel<4,16>" if d == "16" else "conv_splitk_sum_kernel<4,2>") in names
-        outs.append(r.audio[0])
-        eng.close()
-    assert np.array_equal(outs[0], outs[1])
-    o = O.synthesize(w, cfg, ids[0], (0.0, 1.0, 0.0))
-    assert np.max(np.abs(outs[1] - o["audio"])) < 1e-5

@@ -45,7 +45,7 @@ def make_engine(monkeypatch, cfg, w, env=None):
               "PIPER_HIP_WIDE_SPLITK", "PIPER_HIP_DEBUG_KEEP", "PIPER_HIP_MRF", "PIPER_HIP_FUSE_DP",
               "PIPER_HIP_MRF_MAXF", "PIPER_HIP_SPEC", "PIPER_HIP_COLCHAIN", "PIPER_HIP_GROUP_MRF", 
               "PIPER_HIP_MRF_OU", "PIPER_HIP_MATRIX", "PIPER_HIP_BF3_MINF", "PIPER_HIP_MRF_TAIL", "PIPER_HIP_COL4",
-              "PIPER_HIP_COL4_MAXC", "PIPER_HIP_FFN", "PIPER_HIP_WN", "PIPER_HIP_XCD", "PIPER_HIP_UPPRE", "PIPER_HIP_SUMD"):
+              "PIPER_HIP_COL4_MAXC", "PIPER_HIP_FFN", "PIPER_HIP_XCD"):
         monkeypatch.delenv(k, raising=False)
     for k, v in (env or {}).items():
         monkeypatch.setenv(k, str(v))
@@ -84,6 +84,12 @@ def run_and_check(eng, cfg, w, ids, nw, nz, sample, scales=SCALES, sids=None, au
         d = durs[off[i]:off[i + 1]]
         assert int(r.frames[i]) == max(int(d.sum()), 1)
         assert r.pcm[i].size == int(r.frames[i]) * eng.hop == r.audio[i].size
+        # integer work is bit-exact, for EVERY utterance: the durations against the oracle's encoder + duration predictor
+        # (f32 there and here, also in matrix mode bf16x3), and the int16 conversion of the engine's own float waveform
+        # against the oracle's restatement of piper.cpp:410-431 -- 0 LSB
+        assert np.array_equal(d, O.durations_only(wt, cfg, ids[i], scales, nw[i], None if sids is None else sids[i])), \
+            f"utterance {i}: durations differ from the oracle"
+        assert np.array_equal(O.audio_float_to_int16(r.audio[i]), r.pcm[i]), f"utterance {i}: int16 conversion not bit-exact"
         # peak-normalised (piper.cpp:410-431): the loudest sample maps to 32767 (32766 when peak * (32767 / peak)
         # rounds just below 32767 before the truncating cast)
         assert np.max(np.abs(r.pcm[i].astype(np.int32))) >= 32766 or np.max(np.abs(r.audio[i])) < 0.01
