@@ -41,6 +41,8 @@ typedef int64_t SpeakerId;
 // piper.cpp:470-479 calls it (text, eSpeakPhonemeConfig{voice}, phonemes)
 typedef std::function<void(const std::string &text, const std::string &espeakVoice,
                            std::vector<std::vector<Phoneme>> &sentencePhonemes)> PhonemizeFn;
+// text -> diacritized text: the signature of libtashkeel's tashkeel_run minus its state argument (piper.cpp:463)
+typedef std::function<std::string(const std::string &text)> TashkeelFn;
 // where missing-phoneme warnings go (the reference logs them with spdlog::warn, piper.cpp:600-610); default: stderr
 typedef std::function<void(const std::string &message)> WarnFn;
 
@@ -53,6 +55,15 @@ struct PiperConfig {
   // throws for eSpeak voices, exactly where the reference would call phonemize_eSpeak.
   PhonemizeFn phonemizer;
   WarnFn warn;
+  // Host-side diacritizer for Arabic voices: the slot for libtashkeel's tashkeel_run (piper.cpp:457-464), which stays on
+  // the host like espeak-ng. With useTashkeel set and no function here textToAudio throws "Tashkeel model is not
+  // loaded", as the reference does without a tashkeelState.
+  TashkeelFn tashkeel;
+  // textToAudio runs the phrases of a text as batched engine calls; a call takes at most this many PADDED phoneme ids
+  // (utterances x the longest one), so that device and pinned host memory stay bounded by a budget instead of growing
+  // with sentences x the longest sentence (the reference's memory is bounded by one phrase: one session.Run per phrase,
+  // piper.cpp:549-582). 8192 = the 64 x 128-id configuration the engine is tuned for.
+  std::size_t maxBatchIds = 8192;
 };
 
 enum PhonemeType { eSpeakPhonemes, TextPhonemes };

@@ -419,6 +419,11 @@ void textToAudio(PiperConfig& config, Voice& voice, std::string text, std::vecto
   if (sc.sentenceSilenceSeconds > 0)
     sentenceSilenceSamples = (std::size_t)(sc.sentenceSilenceSeconds * sc.sampleRate * sc.channels);
 
+  if (config.useTashkeel) {     // piper.cpp:457-464: diacritize first; the model lives on the host, behind the slot
+    if (!config.tashkeel) throw std::runtime_error("Tashkeel model is not loaded");
+    text = config.tashkeel(text);
+  }
+
   std::vector<std::vector<Phoneme>> sentences;
   if (voice.phonemizeConfig.phonemeType == eSpeakPhonemes) {
     // piper.cpp:470-479: phonemize_eSpeak(text, {voice}, phonemes) -- espeak-ng lives on the host, behind the slot
@@ -477,15 +482,25 @@ void textToAudio(PiperConfig& config, Voice& voice, std::string text, std::vecto
   //     group g + 1 (its upload + launch are enqueued first; the PCM of g was copied out of the engine's buffer before).
   // Either way the caller sees the reference's sequence: per sentence its phrases + silences appended to audioBuffer,
   // then audioCallback(), then the buffer cleared (piper.cpp:577-595).
-  struct Group { std::size_t p0 = 0, p1 = 0; };       // phrases [p0, p1): whole sentences, except beyond 4096 phrases
+  // A group is bounded by a PADDED-size budget (config.maxBatchIds: utterances x the longest one -- what the engine's
+  // workspaces are sized by), so that a long document with one long sentence costs a bounded amount of device and pinned
+  // host memory; a phrase longer than the budget goes alone, as in the reference.
+  struct Group { std::size_t p0 = 0, p1 = 0; };       // phrases [p0, p1): whole sentences, except where a limit cuts in
   std::vector<Group> groups;
   {
+    const std::size_t budget = std::max<std::size_t>(config.maxBatchIds, 1);
     std::size_t p = 0, s = 0, want = audioCallback ? 1 : sentences.size();
     while (s < sentences.size()) {
       Group g;
       g.p0 = p;
       const std::size_t s1 = std::min(sentences.size(), s + std::max<std::size_t>(want, 1));
-      while (p < phrases.size() && phrases[p].sentence < s1 && p - g.p0 < 4096) ++p;      // 4096 = the engine's batch limit
+      std::size_t longest = 0;
+      while (p < phrases.size() && phrases[p].sentence < s1 && p - g.p0 < 4096) {      // 4096 = the engine's batch limit
+        const std::size_t l = std::max(longest, phrases[p].ids.size());
+        if (p > g.p0 && l * (p - g.p0 + 1) > budget) break;
+        longest = l;
+        ++p;
+      }
       g.p1 = p;
       groups.push_back(g);
       s = (p < phrases.size() && phrases[p].sentence < s1) ? phrases[p].sentence : s1;   // limit hit: go on from there

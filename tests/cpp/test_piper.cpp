@@ -212,6 +212,49 @@ int main(int argc, char** argv) {
           return 1;
         }
       }
+      // ---- the padded-size budget of a batched call (PiperConfig::maxBatchIds): a text with many short sentences and one
+      // long one, cut into several engine calls -- also in the middle of the text and with a phrase longer than the
+      // budget -- gives exactly what the unbounded grouping gives
+      {
+        const std::string text = "ab. cd. ef. abcdefgh abcdefgh abcdefgh abcdefgh. gh. ab. cd. a. b";
+        std::vector<int16_t> one, cut, tiny, cb_parts, buf2;
+        piper::SynthesisResult ra, rb, rc, rd;
+        ec.maxBatchIds = 1 << 20;
+        piper::textToAudio(ec, ev, text, one, ra, nullptr);
+        ec.maxBatchIds = 40;                       // 2-3 short sentences per call; the long one (> 40 padded ids) alone
+        piper::textToAudio(ec, ev, text, cut, rb, nullptr);
+        int ncb = 0;
+        piper::textToAudio(ec, ev, text, buf2, rd, [&] { ++ncb; cb_parts.insert(cb_parts.end(), buf2.begin(), buf2.end()); });
+        ec.maxBatchIds = 1;                        // every phrase alone: the reference's own schedule
+        piper::textToAudio(ec, ev, text, tiny, rc, nullptr);
+        ec.maxBatchIds = 8192;
+        auto maxdiff2 = [](const std::vector<int16_t>& a, const std::vector<int16_t>& b) {
+          long m = a.size() == b.size() ? 0 : 1 << 20;
+          for (std::size_t i = 0; i < a.size() && i < b.size(); ++i) m = std::max(m, std::labs((long)a[i] - (long)b[i]));
+          return m;
+        };
+        if (one.empty() || maxdiff2(one, cut) > 2 || maxdiff2(one, tiny) > 2 || maxdiff2(one, cb_parts) > 2 || ncb != 9) {
+          std::cerr << "ERROR: maxBatchIds changes the audio: |unbounded - 40| = " << maxdiff2(one, cut) << ", |unbounded - 1| = "
+                    << maxdiff2(one, tiny) << ", |unbounded - callbacks| = " << maxdiff2(one, cb_parts) << " (" << ncb << " callbacks)\n";
+          return 1;
+        }
+      }
+      // ---- Arabic diacritization slot (piper.cpp:457-464): useTashkeel without a function throws like the reference does
+      // without a tashkeelState; with one the text passes through it before phonemization
+      {
+        std::vector<int16_t> a1, a2;
+        piper::SynthesisResult r7;
+        ec.useTashkeel = true;
+        bool threw2 = false;
+        try { piper::textToAudio(ec, ev, "ab", a1, r7, nullptr); }
+        catch (const std::runtime_error& e) { threw2 = std::string(e.what()) == "Tashkeel model is not loaded"; }
+        if (!threw2) { std::cerr << "ERROR: useTashkeel without a tashkeel function must throw\n"; return 1; }
+        ec.tashkeel = [](const std::string& t) { return t + "cd"; };
+        piper::textToAudio(ec, ev, "ab", a1, r7, nullptr);
+        ec.useTashkeel = false;
+        piper::textToAudio(ec, ev, "abcd", a2, r7, nullptr);
+        if (a1.empty() || a1 != a2) { std::cerr << "ERROR: tashkeel slot not applied before phonemization\n"; return 1; }
+      }
       // single-speaker voice: no speaker id is fed (reference omits the "sid" input)
       if (ev.synthesisConfig.speakerId) { std::cerr << "ERROR: speakerId set on a single-speaker voice\n"; return 1; }
     }
