@@ -161,14 +161,20 @@ int pe_xcc_pattern(pe_engine* e, int32_t xcc[64], int32_t* period);
 /* In-process multi-GPU synthesis for C / C++ callers (the reference runs the phrases of a text one
  * after the other on one session, src/cpp/piper.cpp:549-582 -- they are independent, so they shard). One engine, one
  * stream and one worker thread per device. The voice is parsed and packed ONCE, on devices[0]; every other device gets an
- * identically laid out arena (pe_create_in_arena, skeleton) and receives the packed weights by ONE device-to-device copy
- * (hipMemcpyPeer, xGMI) -- the in-process counterpart of the RCCL broadcast in piper_amd/dist.py. A call deals its
+ * identically laid out arena (pe_create_in_arena, skeleton) and receives the packed weights by ONE RCCL broadcast over
+ * xGMI (ncclBroadcast on a communicator of the group's distinct devices; peer copies when librccl cannot be loaded) -- the
+ * in-process counterpart of the torch.distributed broadcast in piper_amd/dist.py. A call deals its
  * utterances to the devices in longest-first order onto the least-loaded device (load = phoneme ids), runs the shards
  * concurrently and returns group-owned host views in the CALLER's order: sample_offsets / pcm / frames as in pe_result,
  * `audio` is NULL (fetch floats per engine if needed), infer_seconds = wall time of the whole call. The same device may
  * be listed more than once (two engines sharing a GPU). Not thread-safe: one call at a time per group. */
 typedef struct pe_group pe_group;
 int pe_group_create(const void* blob, size_t nbytes, const int32_t* devices, int32_t n_devices, pe_group** out);
+/* How the last pe_group_create on this thread moved the packed weights between devices: "rccl" (one ncclBroadcast on a
+ * communicator of the group's distinct devices -- librccl is dlopen'ed on first use), "peer-copy (<why RCCL was not used>)",
+ * "same-device" (all engines share one GPU) or "none" (one engine). PIPER_HIP_GROUP_BCAST=peer forces the copies, =rccl
+ * takes the collective even for a single device (self-test on a one-GPU box). */
+const char* pe_group_broadcast_path(void);
 int32_t pe_group_size(pe_group* g);
 pe_engine* pe_group_engine(pe_group* g, int32_t i);           /* e.g. pe_set_seed / pe_get_info / pe_profile_* per device */
 int pe_group_synthesize_batch(pe_group* g, const int64_t* ids, const int64_t* offsets, int32_t batch,

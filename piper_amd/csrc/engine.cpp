@@ -1545,6 +1545,20 @@ void Engine::upload(const int64_t* ids, const int64_t* offsets, int B, const flo
   PE_HIP(hipStreamSynchronize(stream_));   // host staging buffers go out of scope
 }
 
+// Whether stage A of the CURRENT call (B_, Tg_, tlens_h_) runs the encoder FFNs as ffn_kernel launches, and which of the
+// two ping-pong buffers then holds the encoder output: functions of the call alone, so that a replayed graph and the code
+// that captured it agree (the fused path swaps x / y once per layer; debug_tensor("x_enc") reads the result).
+bool Engine::stage_a_ffn_fused() const {
+  double tsum = 0;
+  for (int b = 0; b < B_; ++b) tsum += tlens_h_[b];
+  const bool chain_q = use_colchain(tsum, colchain_max_ids_, H_, 96);
+  bool f = ffn_ && chain_q && use_col4((long)B_ * Tg_) && ffn_parts_ && (long)B_ * rup(Tg_, 4) <= ffn_max_cols_ &&
+           FC_ % 48 == 0 && FC_ / 48 <= 16 && w4_of(enc_proj16_);
+  for (auto& e : enc_) f = f && e.f1p && e.f2p && w4_of(e.qkv16);
+  return f;
+}
+float* Engine::stage_a_enc_out() const { return (stage_a_ffn_fused() && (enc_.size() & 1)) ? y_ : x_; }
+
 // Everything up to the frame counts: speaker vectors, text encoder, duration predictor, durations.
 // Grids are sized by the bucketed maximum length Tg_; kernels bound themselves by the device-side
 // per-utterance lengths, so the same captured graph serves every batch of that bucket.
@@ -1585,9 +1599,7 @@ void Engine::issue_stage_a() {
   // Small calls: the FFN as ONE launch that leaves FC/48 partial outputs for lngemm4_kernel to sum (kernels/ffn.h). That
   // consumer then reads the residual from x and writes LN(y) to the other buffer (its parts read x concurrently): x / y
   // swap roles per layer.
-  bool ffn_fused = ffn_ && chain_q && use_col4((long)B * T) && ffn_parts_ && (long)B * rup(T, 4) <= ffn_max_cols_ &&
-                   FC_ % 48 == 0 && FC_ / 48 <= 16 && w4_of(enc_proj16_);
-  for (auto& e : enc_) ffn_fused = ffn_fused && e.f1p && e.f2p && w4_of(e.qkv16);
+  const bool ffn_fused = stage_a_ffn_fused();
   const int nsl = FC_ / 48;
   const float* pend_bias = nullptr;                // conv_2 bias of the layer whose partial outputs are pending
   for (auto& e : enc_) {
@@ -1658,7 +1670,7 @@ void Engine::issue_stage_a() {
     std::swap(x, y);
   } else if (pg) lngemm(y, pg, pb, x, enc_proj16_, enc_proj_.bias, enc_proj_.rows, stats, T, 2.0 * tsum * enc_proj_.macs_per_col);
   else conv(enc_proj_, x, stats, d_tlens_, 1, T, EPI_STORE);
-  xenc_ = x.p;
+  if (x.p != stage_a_enc_out()) throw std::runtime_error("internal: encoder output buffer bookkeeping");
   fl += 2.0 * tsum * enc_proj_.macs_per_col;
   prof_end(0, fl);
 
@@ -2314,7 +2326,7 @@ void Engine::debug_tensor(const std::string& name, int b, std::vector<float>& ou
   const float* src = nullptr;
   int R = 0, Cn = 0;
   long stride = 0;
-  if (name == "x_enc") { src = (xenc_ ? xenc_ : x_) + (size_t)b * H_ * Ts_; R = H_; Cn = tlens_h_[b]; stride = Ts_; }
+  if (name == "x_enc") { src = stage_a_enc_out() + (size_t)b * H_ * Ts_; R = H_; Cn = tlens_h_[b]; stride = Ts_; }
   else if (name == "stats") { src = stats_ + (size_t)b * 2 * C_ * Ts_; R = 2 * C_; Cn = tlens_h_[b]; stride = Ts_; }
   else if (name == "xg") { src = xg_ + (size_t)b * H_ * Ts_; R = H_; Cn = tlens_h_[b]; stride = Ts_; }
   else if (name == "logw") { src = logw_ + (size_t)b * Ts_; R = 1; Cn = tlens_h_[b]; stride = Ts_; }

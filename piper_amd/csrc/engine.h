@@ -182,7 +182,8 @@ class Engine {
   float* ffn_parts_ = nullptr;
   static constexpr long ffn_max_cols_ = 2048;
   int ffn_ = 1;                             // PIPER_HIP_FFN=0: conv by conv (A/B, tests)
-  float* xenc_ = nullptr;
+  bool stage_a_ffn_fused() const;
+  float* stage_a_enc_out() const;
   const float* w4_of(const float* w16) const { auto it = w4_of_.find(w16); return it == w4_of_.end() ? nullptr : it->second; }
   float* dp_proj16_ = nullptr;
   float* dp_pre16_ = nullptr;

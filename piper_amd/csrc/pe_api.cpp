@@ -361,9 +361,12 @@ std::vector<std::vector<int>> lpt(const int64_t* offsets, int batch, int n) {
   std::vector<std::vector<int>> shard(n);
   std::vector<int64_t> load(n, 0);
   for (int u : order) {
-    int best = 0;
-    for (int i = 1; i < n; ++i)
-      if (load[i] < load[best]) best = i;
+    // least-loaded engine that still has room: an engine call takes at most 4096 utterances (Engine::upload), so many
+    // short utterances beside a few long ones spill to the next-least-loaded engine instead of overfilling one
+    int best = -1;
+    for (int i = 0; i < n; ++i)
+      if (shard[i].size() < 4096 && (best < 0 || load[i] < load[best])) best = i;
+    if (best < 0) throw std::runtime_error("batch size must be in [1, 4096 per engine]");
     shard[best].push_back(u);
     load[best] += offsets[u + 1] - offsets[u];
   }
@@ -372,7 +375,86 @@ std::vector<std::vector<int>> lpt(const int64_t* offsets, int batch, int n) {
 }
 }  // namespace
 
+// ---- the weight broadcast of pe_group_create over RCCL (north_star: "RCCL broadcast of the shared voice weights over xGMI").
+// librccl is loaded on first use (a process that drives one GPU never pays for it); one communicator over the DISTINCT
+// devices of the group, one ncclBroadcast of the packed arena's used prefix from devices[0]. Returns false (with the
+// reason in `why`) when the library or a call is unavailable: the caller then copies peer to peer.
+#ifndef PE_EMU
+#include <dlfcn.h>
+namespace {
+struct Rccl {
+  typedef int (*InitAll)(void**, int, const int*);
+  typedef int (*Bcast)(const void*, void*, size_t, int, int, void*, hipStream_t);
+  typedef int (*Void0)();
+  typedef int (*Destroy)(void*);
+  typedef const char* (*ErrStr)(int);
+  InitAll init_all = nullptr; Bcast bcast = nullptr; Void0 group_start = nullptr, group_end = nullptr;
+  Destroy destroy = nullptr; ErrStr err = nullptr;
+  bool ok = false;
+  Rccl() {
+    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return;
+    init_all = (InitAll)dlsym(h, "ncclCommInitAll");
+    bcast = (Bcast)dlsym(h, "ncclBroadcast");
+    group_start = (Void0)dlsym(h, "ncclGroupStart");
+    group_end = (Void0)dlsym(h, "ncclGroupEnd");
+    destroy = (Destroy)dlsym(h, "ncclCommDestroy");
+    err = (ErrStr)dlsym(h, "ncclGetErrorString");
+    ok = init_all && bcast && group_start && group_end && destroy;
+  }
+};
+// arenas[i] lives on devs[i] (distinct devices, devs[0] = the packing device); `used` bytes travel
+bool rccl_broadcast(const std::vector<int>& devs, const std::vector<void*>& arenas, size_t used, std::string& why) {
+  static Rccl r;
+  if (!r.ok) { why = "librccl not loadable"; return false; }
+  const int n = (int)devs.size();
+  std::vector<void*> comms(n, nullptr);
+  std::vector<hipStream_t> streams(n, nullptr);
+  auto fail = [&](const char* what, int rc) {
+    why = std::string(what) + ": " + (r.err ? r.err(rc) : "error") + " (" + std::to_string(rc) + ")";
+    for (int i = 0; i < n; ++i) {
+      if (streams[i]) { hipSetDevice(devs[i]); hipStreamDestroy(streams[i]); }
+      if (comms[i]) r.destroy(comms[i]);
+    }
+    return false;
+  };
+  int rc = r.init_all(comms.data(), n, devs.data());
+  if (rc) return fail("ncclCommInitAll", rc);
+  for (int i = 0; i < n; ++i) {
+    if (hipSetDevice(devs[i]) != hipSuccess || hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking) != hipSuccess)
+      return fail("stream creation", 1);
+  }
+  if ((rc = r.group_start())) return fail("ncclGroupStart", rc);
+  for (int i = 0; i < n; ++i) {
+    hipSetDevice(devs[i]);
+    if ((rc = r.bcast(arenas[0], arenas[i], used, /*ncclUint8*/ 1, /*root*/ 0, comms[i], streams[i]))) {
+      r.group_end();
+      return fail("ncclBroadcast", rc);
+    }
+  }
+  if ((rc = r.group_end())) return fail("ncclGroupEnd", rc);
+  for (int i = 0; i < n; ++i) {
+    hipSetDevice(devs[i]);
+    if (hipStreamSynchronize(streams[i]) != hipSuccess) return fail("stream synchronisation", 1);
+  }
+  for (int i = 0; i < n; ++i) {
+    hipSetDevice(devs[i]);
+    hipStreamDestroy(streams[i]);
+    r.destroy(comms[i]);
+  }
+  return true;
+}
+}  // namespace
+#endif
+
+static thread_local std::string g_group_bcast = "none";
+
 extern "C" {
+
+// how the last pe_group_create on this thread moved the packed weights between devices: "rccl", "peer-copy (<reason>)",
+// "same-device" or "none" (one engine)
+const char* pe_group_broadcast_path(void) { return g_group_bcast.c_str(); }
 
 int pe_group_create(const void* blob, size_t nbytes, const int32_t* devices, int32_t n_devices, pe_group** out) {
   pe_group* g = nullptr;
@@ -402,20 +484,63 @@ int pe_group_create(const void* blob, size_t nbytes, const int32_t* devices, int
       size_t u = 0;
       if (pe_weights_used(g->eng[i], &u)) throw std::runtime_error(g_err);
       if (u != used) throw std::runtime_error("internal: arena layouts differ between devices");
-      if (devices[i] != devices[0]) {
-        int can = 0;
-        PE_HIP(hipDeviceCanAccessPeer(&can, devices[i], devices[0]));
-        if (can) {
-          PE_HIP(hipSetDevice(devices[i]));
-          hipDeviceEnablePeerAccess(devices[0], 0);       // "already enabled" is fine
-          (void)hipGetLastError();
-        }
-        PE_HIP(hipMemcpyPeer(g->arena[i], devices[i], g->arena[0], devices[0], used));   // staged by the runtime without P2P
+    }
+    g_group_bcast = n_devices > 1 ? "same-device" : "none";
+    // ---- one engine per DISTINCT device receives the packed arena from devices[0]: ONE RCCL broadcast over xGMI on a
+    // communicator made of the distinct devices (PIPER_HIP_GROUP_BCAST=peer skips it; =rccl also takes it for a group on
+    // ONE device -- the only way to exercise the collective on a single-GPU box); if RCCL is unavailable: peer copies
+    std::vector<int> first;                       // index of the first engine on each distinct device, devices[0] first
+    for (int i = 0; i < n_devices; ++i) {
+      bool seen = false;
+      for (int j : first) seen = seen || devices[j] == devices[i];
+      if (!seen) first.push_back(i);
+    }
+    std::vector<bool> have(n_devices, false);
+    have[0] = true;
+    const char* mode = getenv("PIPER_HIP_GROUP_BCAST");
+    const bool want_rccl = !(mode && std::string(mode) == "peer") && (first.size() > 1 || (mode && std::string(mode) == "rccl"));
+#ifndef PE_EMU
+    if (want_rccl) {
+      std::vector<int> devs;
+      std::vector<void*> arenas;
+      for (int j : first) { devs.push_back(devices[j]); arenas.push_back(g->arena[j]); }
+      std::string why;
+      PE_HIP(hipSetDevice(devices[0]));
+      PE_HIP(hipDeviceSynchronize());             // engine 0's uploads into its arena are complete
+      if (rccl_broadcast(devs, arenas, used, why)) {
+        for (int j : first) have[j] = true;
+        g_group_bcast = "rccl";
       } else {
-        PE_HIP(hipSetDevice(devices[i]));
-        PE_HIP(hipMemcpy(g->arena[i], g->arena[0], used, hipMemcpyDeviceToDevice));
+        g_group_bcast = "peer-copy (" + why + ")";
       }
-      PE_HIP(hipDeviceSynchronize());
+    }
+#else
+    (void)want_rccl;
+#endif
+    for (int i = 1; i < n_devices; ++i) {
+      if (!have[i]) {
+        // source: the first engine on the same device if it already has the weights, else engine 0 (peer copy)
+        int src = 0;
+        for (int j : first)
+          if (devices[j] == devices[i] && have[j]) src = j;
+        if (devices[i] != devices[src]) {
+          int can = 0;
+          PE_HIP(hipDeviceCanAccessPeer(&can, devices[i], devices[src]));
+          if (can) {
+            PE_HIP(hipSetDevice(devices[i]));
+            hipDeviceEnablePeerAccess(devices[src], 0);       // "already enabled" is fine
+            (void)hipGetLastError();
+          }
+          PE_HIP(hipMemcpyPeer(g->arena[i], devices[i], g->arena[src], devices[src], used));   // staged by the runtime without P2P
+          if (g_group_bcast == "same-device") g_group_bcast = "peer-copy (PIPER_HIP_GROUP_BCAST=peer)";
+        } else {
+          PE_HIP(hipSetDevice(devices[i]));
+          PE_HIP(hipMemcpy(g->arena[i], g->arena[src], used, hipMemcpyDeviceToDevice));
+        }
+        PE_HIP(hipSetDevice(devices[i]));
+        PE_HIP(hipDeviceSynchronize());
+        have[i] = true;
+      }
       if (pe_arena_ready(g->eng[i])) throw std::runtime_error(g_err);
     }
     *out = g;

@@ -14,6 +14,9 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 
+MAX_PER_RANK = 4096     # utterances per engine call (Engine::upload)
+
+
 def shard_indices(costs: Sequence[int], world: int) -> List[List[int]]:
     """Deterministic longest-processing-time assignment of utterances to ranks by cost (phoneme-id
     count, a proxy for frames): every rank computes the same table. Returns per-rank index lists,
@@ -22,7 +25,12 @@ def shard_indices(costs: Sequence[int], world: int) -> List[List[int]]:
     load = [0] * world
     out: List[List[int]] = [[] for _ in range(world)]
     for i in order:
-        r = min(range(world), key=lambda k: (load[k], k))
+        # least-loaded rank that still has room: an engine call takes at most 4096 utterances (same rule as lpt() in
+        # piper_amd/csrc/pe_api.cpp)
+        room = [k for k in range(world) if len(out[k]) < MAX_PER_RANK]
+        if not room:
+            raise ValueError(f"more than {MAX_PER_RANK} utterances per rank")
+        r = min(room, key=lambda k: (load[k], k))
         out[r].append(i)
         load[r] += int(costs[i])
     return [sorted(x) for x in out]

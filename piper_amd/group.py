@@ -1,7 +1,7 @@
 """In-process multi-GPU synthesis (``pe_group_*`` of include/piper_hip.h): one engine, stream and worker thread per
 device inside ONE process -- what a C++ caller of the library uses to reach the GPUs of a node without
 ``torch.distributed`` (for the one-process-per-GPU form see ``piper_amd.dist``). The voice is packed once on the first
-device and copied device to device into identically laid out arenas on the others.
+device and reaches identically laid out arenas on the others by one RCCL broadcast (peer copies without librccl).
 """
 from __future__ import annotations
 
@@ -24,6 +24,8 @@ class EngineGroup:
                                        C.byref(self._h))
         self._check(rc)
         self.devices = [int(d) for d in dev]
+        # "rccl" | "peer-copy (<why>)" | "same-device" | "none": how the packed weights reached the other devices
+        self.broadcast_path = self._lib.pe_group_broadcast_path().decode()
 
     def _check(self, rc):
         if rc:

@@ -47,6 +47,18 @@ def test_shard_indices_partition_and_balance():
     assert shard_indices(costs, 2) == shard_indices(costs, 2)      # deterministic on every rank
 
 
+def test_shard_indices_respect_the_engine_batch_limit():
+    """many short utterances beside a few long ones must not put more than 4096 on one rank (an engine call
+    takes at most 4096); the deal spills to the next-least-loaded rank, and a batch that cannot fit raises."""
+    from piper_amd import dist
+    costs = [4000] * 3 + [1] * 8000            # by load alone rank 1 would get ~all of the short ones
+    table = dist.shard_indices(costs, 2)
+    assert sorted(i for t in table for i in t) == list(range(len(costs)))
+    assert max(len(t) for t in table) <= dist.MAX_PER_RANK
+    with pytest.raises(ValueError):
+        dist.shard_indices([1] * (2 * dist.MAX_PER_RANK + 1), 2)
+
+
 def test_two_rank_gloo_matches_single_process(tmp_path):
     if not os.path.exists(EMU):
         subprocess.check_call(["make", "-C", ROOT, "emu"])

@@ -542,6 +542,7 @@ def test_engine_group_two_engines(monkeypatch, devices):
     ids = [W.synthetic_phoneme_ids(T, 300 + i, id_max=129) for i, T in enumerate(lens)]
     scales = (0.0, 1.0, 0.0)
     grp = EngineGroup(blob, devices)
+    assert grp.broadcast_path == ("same-device" if devices[0] == devices[1] else "rccl"), grp.broadcast_path
     rg = grp.synthesize_batch(ids, scales)
     assign = grp.assignment(len(ids))
     table = dist.shard_indices(lens, 2)
@@ -557,3 +558,46 @@ def test_engine_group_two_engines(monkeypatch, devices):
         assert np.max(np.abs(r2.pcm[0].astype(np.int32) - rs.pcm[5].astype(np.int32))) <= 2
     eng.close()
     grp.close()
+
+
+def test_engine_group_weight_broadcast_through_rccl(monkeypatch):
+    """pe_group_create's collective path on a one-GPU box: PIPER_HIP_GROUP_BCAST=rccl takes the ncclBroadcast (librccl
+    dlopen'ed, a communicator over the group's distinct devices -- here one -- and one broadcast of the packed arena from
+    devices[0]) where two engines on one GPU would otherwise be filled by a device-to-device copy; =peer forces the copies.
+    Either way the second engine, whose weights only ever arrived that way, gives the single engine's PCM."""
+    from piper_amd.group import EngineGroup
+    cfg, w = voice("medium")
+    blob = W.pack_blob(cfg, w)
+    ids = [W.synthetic_phoneme_ids(T, 400 + i, id_max=129) for i, T in enumerate([96, 64])]
+    scales = (0.0, 1.0, 0.0)
+    eng = make_engine(monkeypatch, cfg, w)
+    rs = eng.synthesize_batch(ids, scales)
+    eng.close()
+    for mode, want in (("rccl", "rccl"), ("peer", "same-device")):
+        monkeypatch.setenv("PIPER_HIP_GROUP_BCAST", mode)
+        grp = EngineGroup(blob, [0, 0])
+        assert grp.broadcast_path == want, grp.broadcast_path
+        rg = grp.synthesize_batch(ids, scales)
+        assert sorted(grp.assignment(2)) == [0, 1]
+        for a, b in zip(rg.pcm, rs.pcm):
+            assert a.shape == b.shape and np.max(np.abs(a.astype(np.int32) - b.astype(np.int32))) <= 2
+        grp.close()
+
+
+def test_bench_two_ranks_on_one_gpu_prints_a_compact_line():
+    """`bench.py --gpus 2` end to end on ONE GPU (PIPER_BENCH_BACKEND=gloo: both ranks share device 0, the process group
+    and load_sharded's broadcast run over gloo): the N > 1 plumbing -- self-launch, barriers, max-over-ranks timing, the
+    per-rank gather -- must produce a driver-parsable last line before the first real multi-GPU run exists."""
+    import subprocess
+    import sys
+    env = dict(os.environ, PIPER_BENCH_BACKEND="gloo", PIPER_BENCH_FULL=os.path.join(ROOT, "gpurun_out", "bench_full_2rank.json"))
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--min-seconds", "0", "--no-roofline"], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0, p.stderr[-3000:]
+    line = p.stdout.strip().splitlines()[-1]
+    assert len(line) < 4096
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"
+    assert len(d["per_rank_samples_per_s"]) == 2 and d["weight_broadcast"]["bytes"] > 1e8
+    assert "64 utterance(s) x 128" in d["config"]["workload"]
