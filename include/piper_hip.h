@@ -153,6 +153,20 @@ int64_t pe_run_launches(pe_engine* e);
  * pe_create, misses = guesses that were too small (each cost one extra pass of the second half). */
 int pe_speculation_stats(pe_engine* e, int64_t* runs, int64_t* misses);
 
+/* Session warm-up -- what loadModel's session creation does for ORT (piper.cpp:262-306: graph optimisation at load), here
+ * for the hipGraphs: the kernel sequence of a call is captured once per shape bucket (ids in steps of 32 up to 512, then
+ * 8 steps per octave; frames in steps of 64 up to 1024, then 16 per octave) and replayed afterwards; the cache keeps the
+ * 64 most recently used graphs (PIPER_HIP_GRAPHS) and evicts one at a time. pe_warmup
+ *   - sizes the workspaces for calls of up to max_batch utterances x max_ids ids and frames_per_id * max_ids frames
+ *     (<= 0: 8), so that no later call grows them (growth re-creates every graph), and
+ *   - if sample_ids is given (a representative utterance of the voice: its frames-per-id ratio seeds the speculative
+ *     sizing), synthesises it cut / tiled to every id bucket up to max_ids with `scales` (NULL: 0.667 / 1 / 0.8), so that
+ *     the single-utterance graphs exist before the first real call.
+ * pe_graph_stats: graphs currently cached / captures since pe_create (a steady server stops capturing). */
+int pe_warmup(pe_engine* e, int32_t max_batch, int32_t max_ids, float frames_per_id, const float scales[3],
+              const int64_t* sample_ids, int64_t n_sample);
+int pe_graph_stats(pe_engine* e, int64_t* cached, int64_t* captures);
+
 /* Diagnostic: which XCD (accelerator complex of the MI355X) ran workgroups 0..63 of a 1-D probe launch at pe_create
  * (xcc[64]), and *period = P when that was a round-robin over P XCDs (0 otherwise). The small-call kernels order their
  * column tiles by it (piper_amd/csrc/kernels/col4.h); bench.py prints it so that a result line says what the box did. */

@@ -14,12 +14,13 @@ thread_local long g_launches = 0;
 
 // a launch with a level-2 profile row of its own (the element-wise / integer glue kernels; the conv / attention /
 // fused-stage launchers bracket themselves and also carry FLOP and byte counts)
-#define PE_LAUNCH_K(kname, call)                                                 \
+#define PE_LAUNCH_KB(kname, bytes, call)                                         \
   do {                                                                           \
-    const int kh_ = kbegin(prof_level_ >= 2 ? krow(kname) : 0, 0.0);             \
+    const int kh_ = kbegin(prof_level_ >= 2 ? krow(kname) : 0, 0.0, (bytes));    \
     call;                                                                        \
     kend(kh_);                                                                   \
   } while (0)
+#define PE_LAUNCH_K(kname, call) PE_LAUNCH_KB(kname, 0.0, call)
 
 // Engines that share a process (pe_group_*: one per device, each on its own thread) must not be inside a HIP call while
 // another one CAPTURES a graph: allocations / synchronising copies on a second thread invalidate a capture in progress on
@@ -652,6 +653,7 @@ void Engine::init(const WeightSet& ws) {
   PE_HIP(hipEventCreate(&ev1_));
   PE_HIP(hipHostMalloc((void**)&h_frames_, 4096 * sizeof(int)));
   if (const char* ng = getenv("PIPER_HIP_NO_GRAPH")) use_graphs_ = !(ng[0] && ng[0] != '0');
+  if (const char* t = getenv("PIPER_HIP_GRAPHS")) graph_cap_ = (size_t)std::min(4096, std::max(1, atoi(t)));
   if (const char* t = getenv("PIPER_HIP_TPB")) tpb_override_ = atoi(t);     // tuning / test knob
   if (const char* t = getenv("PIPER_HIP_WIDE_MIN")) wide_min_blocks_ = atol(t);
   if (const char* t = getenv("PIPER_HIP_SMALL")) small_tiles_ = atoi(t) != 0;
@@ -696,6 +698,8 @@ void Engine::free_all() {
   if (h_pcm_) hipHostFree(h_pcm_);
   if (h_pcm_zc_) hipHostFree(h_pcm_zc_);
   if (h_frames_) hipHostFree(h_frames_);
+  if (h_in_) hipHostFree(h_in_);
+  h_in_ = nullptr; h_in_cap_ = 0;
   if (ev0_) hipEventDestroy(ev0_);
   if (ev1_) hipEventDestroy(ev1_);
   for (auto& k : kev_) { hipEventDestroy(k.a); hipEventDestroy(k.b); }
@@ -758,14 +762,20 @@ void Engine::ensure_stage_a(int B, int Tmax) {
   const int Ts = rup(Tmax, 128);    // row strides are multiples of 128 columns (conv epilogue relies on it)
   bool grow = false;
   if ((size_t)B > capA_B_) { capA_B_ = B; grow = true; }
-  if ((size_t)Ts > capA_T_) { capA_T_ = Ts; grow = true; }
+  // (growth re-creates every graph: grow the id capacity by at least half, so that texts of slowly increasing length
+  // cost a few re-creations, not one per 128 ids)
+  if ((size_t)Ts > capA_T_) { capA_T_ = std::max<size_t>(Ts, capA_T_ ? rup((int)(capA_T_ + capA_T_ / 2), 128) : 0); grow = true; }
   Ts_ = (int)capA_T_;
   const size_t Bc = capA_B_, T = capA_T_;
   auto carve = [&](char* base) -> size_t {
     Carver c(base);
-    d_ids_ = c.take<int>(Bc * T);
-    d_tlens_ = c.take<int>(Bc);
-    d_sids_ = c.take<int>(Bc);
+    // input block: [rng 4 x u64 | lengths Bc | speaker ids Bc | ids Bc x T] (contiguous, copied as one piece by upload())
+    d_in_ = c.take<char>(32 + (2 * Bc + Bc * T) * sizeof(int));
+    d_rng_ = reinterpret_cast<unsigned long long*>(d_in_);
+    d_tlens_ = reinterpret_cast<int*>(d_in_ + 32);
+    d_sids_ = d_tlens_ + Bc;
+    d_ids_ = d_sids_ + Bc;
+    in_bytes_ = 32 + (2 * Bc + Bc * T) * sizeof(int);
     d_dur_ = c.take<int>(Bc * T);
     d_cum_ = c.take<int>(Bc * T);
     d_frames_ = c.take<int>(Bc);
@@ -786,7 +796,6 @@ void Engine::ensure_stage_a(int B, int Tmax) {
     logw_ = c.take<float>(Bc * T);
     noise_w_ = c.take<float>(Bc * 2 * T);
     cond_ = c.take<float>(Bc * (size_t)std::max(cond_bs_, 1));
-    d_rng_ = c.take<unsigned long long>(4);
     return c.off + 256;
   };
   if (grow || !wsA_) {
@@ -798,6 +807,11 @@ void Engine::ensure_stage_a(int B, int Tmax) {
     wsA_bytes_ = carve(nullptr);
     PE_HIP(hipMalloc((void**)&wsA_, wsA_bytes_));
     carve(wsA_);
+    if (h_in_cap_ < in_bytes_) {
+      if (h_in_) PE_HIP(hipHostFree(h_in_));
+      h_in_cap_ = in_bytes_;
+      PE_HIP(hipHostMalloc((void**)&h_in_, h_in_cap_));
+    }
   }
   carve(wsA_);
 }
@@ -805,7 +819,7 @@ void Engine::ensure_stage_a(int B, int Tmax) {
 void Engine::ensure_stage_b(int Fmax) {
   const int Fs = rup(Fmax, 128);
   bool grow = false;
-  if ((size_t)Fs > capB_F_) { capB_F_ = Fs; grow = true; }
+  if ((size_t)Fs > capB_F_) { capB_F_ = std::max<size_t>(Fs, capB_F_ ? rup((int)(capB_F_ + capB_F_ / 2), 128) : 0); grow = true; }
   Fs_ = (int)capB_F_;
   const size_t Bc = capA_B_, F = capB_F_;
   // largest [channels x length] activation of the generator
@@ -1274,7 +1288,7 @@ void Engine::layer_norm(View in, View out, const float* g, const float* b, int C
   p.lens = lens; p.C = C;
   if (C > LN_COLS * 32) throw std::runtime_error("LayerNorm over more than 256 channels is not supported");
   dim3 grid((Lmax + LN_COLS - 1) / LN_COLS, B_);
-  const int kh = kbegin(prof_level_ >= 2 ? krow("ln_kernel") : 0, 0.0);
+  const int kh = kbegin(prof_level_ >= 2 ? krow("ln_kernel") : 0, 0.0, 4.0 * 2.0 * C * (lens == d_tlens_ ? cols_ids_ : cols_frames_));
   launch::layer_norm(grid, stream_, p);
   kend(kh);
 }
@@ -1315,6 +1329,11 @@ void Engine::dds_params(const DdsW& d, View in, View out, View tmp, const DdsOpt
   }
 }
 
+// algorithmic bytes of one DDSConv layer launch: x in, out (+ the fused 1x1 conv's rows), the 1x1 matrix (+ the fused one)
+double Engine::dds_bytes(const DdsP& p) const {
+  return 4.0 * (cols_ids_ * (2.0 * H_ + p.post_rows) + (double)H_ * H_ + (double)p.post_rows * H_);
+}
+
 void Engine::dds(const DdsW& d, View in, View out, View tmp, const DdsOpt* opt) {
   std::vector<DdsP> list;
   dds_params(d, in, out, tmp, opt, list);
@@ -1324,7 +1343,7 @@ void Engine::dds(const DdsW& d, View in, View out, View tmp, const DdsOpt* opt) 
   for (const DdsP& p : list) four = four && p.wp4 && (!p.post_w16 || p.post_w4);
   for (const DdsP& p : list) {
     if (four) {
-      const int kh4 = kbegin(prof_level_ >= 2 ? krow("dds_layer4_kernel") : 0, 0.0);
+      const int kh4 = kbegin(prof_level_ >= 2 ? krow("dds_layer4_kernel") : 0, 0.0, dds_bytes(p));
       DdsP p4 = p;
       p4.xcd = xcd_period_;
       launch::dds_layer4(dim3((Tg_ + 3) / 4, B_), col4_smem(), stream_, p4);
@@ -1332,7 +1351,7 @@ void Engine::dds(const DdsW& d, View in, View out, View tmp, const DdsOpt* opt) 
       continue;
     }
     const int kh = kbegin(prof_level_ >= 2 ? krow(p.nchunks == 3 ? "dds_layer16_kernel<3>" : p.nchunks == 6 ? "dds_layer16_kernel<6>"
-                                                                                       : "dds_layer16_kernel<8>") : 0, 0.0);
+                                                                                       : "dds_layer16_kernel<8>") : 0, 0.0, dds_bytes(p));
     const dim3 grid16((Tg_ + 15) / 16, B_);
     const size_t smem16 = ((size_t)2 * p.nchunks * 32 * 16 + 16 * 16) * sizeof(float);
     // <3> / <6> are compiled for exactly 96 / 192 padded channels; <8> takes any width up to 256
@@ -1360,6 +1379,8 @@ int Engine::krow(const std::string& name) {
 }
 void Engine::lngemm(View y, const float* g, const float* b, View x, const float* w16, const float* bias, int rows,
                     View out, int T, double flops, const float* parts, int nparts, const float* pbias) {
+  // algorithmic bytes: y in, LN(y) out, the conv's rows out, the FFN's partial outputs in; weights once
+  const double kbytes = 4.0 * (cols_ids_ * (2.0 * H_ + rows + (parts ? (double)nparts * H_ : 0.0)) + (double)rows * H_);
   LnGemmP p{};
   p.in = y.p; p.in_bs = y.bs; p.in_cs = y.cs;
   p.gamma = g; p.beta = b;
@@ -1377,12 +1398,12 @@ void Engine::lngemm(View y, const float* g, const float* b, View x, const float*
   if (const float* w4 = use_col4((long)B_ * T) ? w4_of(w16) : nullptr) {
     p.w16 = w4;
     p.xcd = xcd_period_;
-    const int kh4 = kbegin(prof_level_ >= 2 ? krow("lngemm4_kernel") : 0, flops);
+    const int kh4 = kbegin(prof_level_ >= 2 ? krow("lngemm4_kernel") : 0, flops, kbytes);
     launch::lngemm4(dim3((T + 3) / 4, B_, (rows + 191) / 192), col4_smem(), stream_, p);
     kend(kh4);
     return;
   }
-  const int kh = kbegin(prof_level_ >= 2 ? krow("lngemm_kernel<6>") : 0, flops);
+  const int kh = kbegin(prof_level_ >= 2 ? krow("lngemm_kernel<6>") : 0, flops, kbytes);
   const size_t smem = ((size_t)192 * 16 + 16 * 16) * sizeof(float);
   launch::lngemm(dim3((T + 15) / 16, B_, (rows + 191) / 192), smem, stream_, p);
   kend(kh);
@@ -1403,13 +1424,18 @@ bool Engine::conv1x1_col4(const float* w16, const float* bias, int rows, View in
   cp.res = bias2; cp.res_bs = bias2_bs;
   cp.out = out.p; cp.out_bs = out.bs; cp.out_cs = out.cs;
   cp.lens = lens;
-  const int kh4 = kbegin(prof_level_ >= 2 ? krow("colchain4_kernel") : 0, flops);
+  const double cols = lens == d_tlens_ ? cols_ids_ : cols_frames_;
+  const int kh4 = kbegin(prof_level_ >= 2 ? krow("colchain4_kernel") : 0, flops, 4.0 * (cols * (kin + rows) + (double)rows * kin));
   launch::colchain4(dim3((Lmax + 3) / 4, B, (rows + 191) / 192), col4_smem(), stream_, cp);
   kend(kh4);
   return true;
 }
 
 void Engine::colchain(const ColP& p, int B, int Lmax, double flops) {
+  // algorithmic bytes: GEMM input, the residual / x1 read and written, the second GEMM's output; weights once
+  const double cols = p.lens == d_tlens_ ? cols_ids_ : cols_frames_;
+  const double kbytes = 4.0 * (cols * (p.K1 + 2.0 * p.rows1 + (p.w2 ? p.rows2 : 0)) + (double)p.rows1 * p.K1 +
+                               (p.w2 ? (double)p.rows2 * p.rows1 : 0.0));
   // mode 1 runs on frames (coupling post + pre), mode 0 on ids: separate column limits (profiles/r03_notes.md)
   if (col4_ && (col4_ == 2 || (long)B * Lmax <= (p.mode == 1 ? col4_max_frames_ : col4_max_cols_)) && p.K1 == 192 && (p.mode == 0 ? p.rows1 == 192 : (p.rows1 == 96 && (!p.w2 || p.rows2 <= 192)))) {
     const float* w1 = w4_of(p.w1);
@@ -1418,13 +1444,13 @@ void Engine::colchain(const ColP& p, int B, int Lmax, double flops) {
       ColP q = p;
       q.w1 = w1; q.w2 = w2;
       q.xcd = xcd_period_;
-      const int kh4 = kbegin(prof_level_ >= 2 ? krow("colchain4_kernel") : 0, flops);
+      const int kh4 = kbegin(prof_level_ >= 2 ? krow("colchain4_kernel") : 0, flops, kbytes);
       launch::colchain4(dim3((Lmax + 3) / 4, B), col4_smem(), stream_, q);
       kend(kh4);
       return;
     }
   }
-  const int kh = kbegin(prof_level_ >= 2 ? krow("colchain_kernel<6>") : 0, flops);
+  const int kh = kbegin(prof_level_ >= 2 ? krow("colchain_kernel<6>") : 0, flops, kbytes);
   const size_t smem = ((size_t)2 * 6 * 32 * 16 + 16 * 16) * sizeof(float);
   launch::colchain(dim3((Lmax + 15) / 16, B), smem, stream_, p);
   kend(kh);
@@ -1505,30 +1531,42 @@ void Engine::upload(const int64_t* ids, const int64_t* offsets, int B, const flo
   Tmax_ = Tmax;
   ensure_stage_a(B, Tmax);
   const int Ts = Ts_;
-  std::vector<int> idbuf((size_t)B * Ts, 0);
-  for (int b = 0; b < B; ++b)
-    for (int t = 0; t < tlens_h_[b]; ++t) {
-      const int64_t id = ids[offsets[b] + t];
+  // the pinned mirror of the input block; a copy of the previous call that might still read it ended with that call's
+  // final synchronisation (an abandoned upload is simply overwritten)
+  const size_t Bc = capA_B_;
+  unsigned long long* hr = reinterpret_cast<unsigned long long*>(h_in_);
+  int* htl = reinterpret_cast<int*>(h_in_ + 32);
+  int* hsid = htl + Bc;
+  int* hid = hsid + Bc;
+  for (int b = 0; b < B; ++b) {
+    int* row = hid + (size_t)b * Ts;
+    const int64_t* src = ids + offsets[b];
+    const int T = tlens_h_[b];
+    for (int t = 0; t < T; ++t) {
+      const int64_t id = src[t];
       if (id < 0 || id >= arch_[A_NVOCAB])
         throw std::runtime_error("phoneme id " + std::to_string(id) + " outside [0, num_symbols)");
-      idbuf[(size_t)b * Ts + t] = (int)id;
+      row[t] = (int)id;
     }
-  PE_HIP(hipMemcpyAsync(d_ids_, idbuf.data(), idbuf.size() * sizeof(int), hipMemcpyHostToDevice, stream_));
-  PE_HIP(hipMemcpyAsync(d_tlens_, tlens_h_.data(), B * sizeof(int), hipMemcpyHostToDevice, stream_));
-  std::vector<int> sidbuf(B, 0);
+    memset(row + T, 0, (size_t)(Ts - T) * sizeof(int));
+    htl[b] = T;
+    hsid[b] = 0;
+  }
   if (nspk_ > 1)
     for (int b = 0; b < B; ++b) {
-      const int64_t s = sids ? sids[b] : 0;
-      if (s < 0 || s >= nspk_) throw std::runtime_error("speaker id outside [0, num_speakers)");
-      sidbuf[b] = (int)s;
+      const int64_t sp = sids ? sids[b] : 0;
+      if (sp < 0 || sp >= nspk_) throw std::runtime_error("speaker id outside [0, num_speakers)");
+      hsid[b] = (int)sp;
     }
-  PE_HIP(hipMemcpyAsync(d_sids_, sidbuf.data(), B * sizeof(int), hipMemcpyHostToDevice, stream_));
+  // {seed, runs so far}: the first kernel of every run() advances the counter on the device (embed_kernel)
+  hr[0] = seed_; hr[1] = call_; hr[2] = hr[3] = 0;
+  PE_HIP(hipMemcpyAsync(d_in_, h_in_, 32 + (2 * Bc + (size_t)B * Ts) * sizeof(int), hipMemcpyHostToDevice, stream_));
   scales_[0] = scales[0]; scales_[1] = scales[1]; scales_[2] = scales[2];
   have_noise_w_ = noise && noise->noise_w;
   have_noise_z_ = noise && noise->noise_z;
   h_noise_z_ = have_noise_z_ ? noise->noise_z : nullptr;
   h_noise_z_stride_ = have_noise_z_ ? noise->z_stride : 0;
-  if (have_noise_w_) {
+  if (have_noise_w_) {      // injected duration noise (parity tests): pageable staging, so wait for the copy
     if (noise->w_stride < Tmax) throw std::runtime_error("noise_w stride shorter than the longest utterance");
     std::vector<float> nb((size_t)B * 2 * Ts, 0.f);
     for (int b = 0; b < B; ++b)
@@ -1536,13 +1574,8 @@ void Engine::upload(const int64_t* ids, const int64_t* offsets, int B, const flo
         memcpy(&nb[((size_t)b * 2 + c) * Ts], noise->noise_w + ((size_t)b * 2 + c) * noise->w_stride,
                tlens_h_[b] * sizeof(float));
     PE_HIP(hipMemcpyAsync(noise_w_, nb.data(), nb.size() * sizeof(float), hipMemcpyHostToDevice, stream_));
+    PE_HIP(hipStreamSynchronize(stream_));
   }
-  {
-    // {seed, runs so far}: the first kernel of every run() advances the counter on the device (embed_kernel)
-    const unsigned long long st[2] = {seed_, call_};
-    PE_HIP(hipMemcpyAsync(d_rng_, st, sizeof(st), hipMemcpyHostToDevice, stream_));
-  }
-  PE_HIP(hipStreamSynchronize(stream_));   // host staging buffers go out of scope
 }
 
 // Whether stage A of the CURRENT call (B_, Tg_, tlens_h_) runs the encoder FFNs as ffn_kernel launches, and which of the
@@ -1574,6 +1607,7 @@ void Engine::issue_stage_a() {
   (void)bsH;
   double tsum = 0;
   for (int b = 0; b < B; ++b) tsum += tlens_h_[b];
+  cols_ids_ = tsum;
 
   // ================= speaker conditioning vectors
   const float* cb_dp = nullptr;
@@ -1590,7 +1624,7 @@ void Engine::issue_stage_a() {
   // ================= text encoder (models.py:198-209, attentions.py:60-74)
   prof_begin();
   double fl = 0;
-  PE_LAUNCH_K("embed_kernel", launch::embed(dim3((T + 63) / 64, (H_ + 15) / 16, B), stream_, d_ids_, Ts, d_tlens_, emb_, H_, std::sqrt((float)H_), x_, (long)H_ * Ts, Ts, d_rng_));
+  PE_LAUNCH_KB("embed_kernel", 4.0 * tsum * (1.0 + H_), launch::embed(dim3((T + 63) / 64, (H_ + 15) / 16, B), stream_, d_ids_, Ts, d_tlens_, emb_, H_, std::sqrt((float)H_), x_, (long)H_ * Ts, Ts, d_rng_));
   // norm_layers_2 of a layer feeds only the next layer's q/k/v conv (or, after the last layer, proj) + the residual of
   // conv_o. Small batches with the 192-channel encoder run norm_layers_2 + that conv as one launch (lngemm_kernel), and
   // conv_o + residual + norm_layers_1 as another (colchain_kernel); otherwise conv, then ln_kernel.
@@ -1624,7 +1658,7 @@ void Engine::issue_stage_a() {
     if (smem > 160 * 1024) throw std::runtime_error("utterance too long for the attention score tile");
     double afl = 0;
     for (int b = 0; b < B; ++b) afl += 4.0 * (double)tlens_h_[b] * tlens_h_[b] * H_;
-    const int kh = kbegin(prof_level_ >= 2 ? krow(ap.dk == 96 ? "attn_kernel<96>" : ap.dk == 48 ? "attn_kernel<48>" : "attn_kernel<0>") : 0, afl);
+    const int kh = kbegin(prof_level_ >= 2 ? krow(ap.dk == 96 ? "attn_kernel<96>" : ap.dk == 48 ? "attn_kernel<48>" : "attn_kernel<0>") : 0, afl, 4.0 * 4.0 * H_ * tsum);
     const dim3 agrid((T + ATT_QB - 1) / ATT_QB, nh_, B);
     launch::attention(ap.dk, agrid, smem, stream_, ap);
     kend(kh);
@@ -1651,7 +1685,8 @@ void Engine::issue_stage_a() {
       fp.w1p = e.f1p; fp.b1 = e.f1.bias; fp.w2p = e.f2p;
       fp.parts = ffn_parts_; fp.nslices = nsl; fp.p_bs = (long)nsl * H_ * Tp;
       fp.lens = d_tlens_;
-      const int khf = kbegin(prof_level_ >= 2 ? krow("ffn_kernel") : 0, 2.0 * tsum * (e.f1.macs_per_col + e.f2.macs_per_col));
+      const int khf = kbegin(prof_level_ >= 2 ? krow("ffn_kernel") : 0, 2.0 * tsum * (e.f1.macs_per_col + e.f2.macs_per_col),
+                             4.0 * (tsum * (1.0 + nsl) * H_ + e.f1.macs_per_col + e.f2.macs_per_col));
       const size_t smemf = ((size_t)192 * 48 + 4 * 48 * 16 + 48 * 48) * sizeof(float);
       launch::ffn(dim3((T + 11) / 12, nsl, B), smemf, stream_, fp);
       kend(khf);
@@ -1691,7 +1726,7 @@ void Engine::issue_stage_a() {
   fl += 2.0 * tsum * (2 + arch_[A_DDSLAYERS]) * dp_pre_.macs_per_col;
   // z = noise * noise_scale_w   [B][2][Ts]
   if (!have_noise_w_)
-    PE_LAUNCH_K("randn_kernel", launch::randn(stream_, noise_w_, (long)B * 2, T, (long)Ts, 0L, d_rng_, 0));
+    PE_LAUNCH_KB("randn_kernel", 4.0 * 2.0 * tsum, launch::randn(stream_, noise_w_, (long)B * 2, T, (long)Ts, 0L, d_rng_, 0));
   if (!fuse_dp_) {
     const long n = (long)B * 2 * Ts;
     PE_LAUNCH_K("scale_kernel", launch::scale(dim3((unsigned)((n + 255) / 256)), stream_, noise_w_, z2_, n, scales_[2]));
@@ -1731,7 +1766,7 @@ void Engine::issue_stage_a() {
     dp.lens = d_tlens_; dp.dur = d_dur_; dp.cum = d_cum_; dp.d_bs = Ts; dp.frames = d_frames_; dp.logw_out = logw_;
     dp.frames_host = h_frames_; dp.frames_clamped = d_framesc_; dp.frame_cap = std::max(Fs_, 1);
     {
-      PE_LAUNCH_K("duration_kernel", launch::duration(dim3(B), stream_, dp));
+      PE_LAUNCH_KB("duration_kernel", 4.0 * 4.0 * tsum, launch::duration(dim3(B), stream_, dp));
     }
   }
   prof_end(1, fl);
@@ -1744,6 +1779,7 @@ void Engine::issue_flow() {
   const View none{nullptr, 0, 0};
   double fsum = 0;
   for (int b = 0; b < B; ++b) fsum += frames_h_[b];
+  cols_frames_ = fsum;
   double fl = 0;
 
   // ================= length regulator + prior noise + coupling flow (models.py:705-719)
@@ -1759,7 +1795,7 @@ void Engine::issue_flow() {
   } else {
     // (drawing the noise inside regulate_kernel was tried: one launch fewer, but a Philox block + Box-Muller per element
     // in its 16-channels-per-thread loop cost 21 us against this launch's 5, profiles/r02_notes.md)
-    PE_LAUNCH_K("randn_kernel", launch::randn(stream_, noise_z_, (long)B * C_, Fmax, (long)Fs, 0L, d_rng_, 1));
+    PE_LAUNCH_KB("randn_kernel", 4.0 * C_ * fsum, launch::randn(stream_, noise_z_, (long)B * C_, Fmax, (long)Fs, 0L, d_rng_, 1));
   }
   {
     RegP rp;
@@ -1769,7 +1805,7 @@ void Engine::issue_flow() {
     rp.noise_scale = scales_[0];
     rp.out = zp_; rp.o_bs = (long)C_ * Fs; rp.o_cs = Fs; rp.C = C_;
     rp.absmax = absmax_;
-    PE_LAUNCH_K("regulate_kernel", launch::regulate(dim3((Fmax + 63) / 64, (C_ + 15) / 16, B), stream_, rp));
+    PE_LAUNCH_KB("regulate_kernel", 4.0 * (2.0 * C_ * cols_ids_ + 2.0 * C_ * fsum), launch::regulate(dim3((Fmax + 63) / 64, (C_ + 15) / 16, B), stream_, rp));
     if (zp_keep_)     // tests: z_p, the flow's input (the flow transforms zp_ in place)
       PE_HIP(hipMemcpyAsync(zp_keep_, zp_, (size_t)B * C_ * Fs * sizeof(float), hipMemcpyDeviceToDevice, stream_));
   }
@@ -1800,7 +1836,8 @@ void Engine::issue_flow() {
         cp.x1 = fh.p; cp.x1_bs = fh.bs; cp.x1_cs = fh.cs;
         cp.out = fskip.p; cp.out_bs = fskip.bs; cp.out_cs = fskip.cs;
         cp.lens = lens_b_;
-        const int kh4 = kbegin(prof_level_ >= 2 ? krow("colchain4_kernel") : 0, 2.0 * fsum * r.rs[i].macs_per_col);
+        const int kh4 = kbegin(prof_level_ >= 2 ? krow("colchain4_kernel") : 0, 2.0 * fsum * r.rs[i].macs_per_col,
+                               4.0 * (fsum * (H_ + 2.0 * cp.rows1) + (double)cp.rows1 * H_));
         launch::colchain4(dim3((Fmax + 3) / 4, B, (cp.rows1 + 191) / 192), col4_smem(), stream_, cp);
         kend(kh4);
       } else {
@@ -1991,10 +2028,10 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
     prof_begin();
     const int K = 7, Lmax = Fmax * hop_;
     if (!tail_done)
-      PE_LAUNCH_K("conv_post_kernel", launch::conv_post(dim3((Lmax + POST_SPB - 1) / POST_SPB, B), stream_, cur.p, cur.bs, cur.cs, post_w_, post_cin_, 0.01f, lens, hop_, audio_, Ss_, absmax_));
+      PE_LAUNCH_KB("conv_post_kernel", 4.0 * fsum * hop_ * (post_cin_ + 1.0), launch::conv_post(dim3((Lmax + POST_SPB - 1) / POST_SPB, B), stream_, cur.p, cur.bs, cur.cs, post_w_, post_cin_, 0.01f, lens, hop_, audio_, Ss_, absmax_));
     // (the streaming window path delivers per chunk from the device buffer)
     int16_t* zc = (pcm_zc_ && !zero_absmax && h_pcm_zc_cap_ >= (size_t)B * (size_t)Ss_) ? h_pcm_zc_ : nullptr;
-    PE_LAUNCH_K("pcm16_kernel", launch::pcm16(dim3((Lmax + 255) / 256, B), stream_, audio_, Ss_, absmax_, lens, hop_, pcm_, Ss_, zc));
+    PE_LAUNCH_KB("pcm16_kernel", fsum * hop_ * (4.0 + 2.0 + (zc ? 2.0 : 0.0)), launch::pcm16(dim3((Lmax + 255) / 256, B), stream_, audio_, Ss_, absmax_, lens, hop_, pcm_, Ss_, zc));
     prof_end(4, tail_done ? 0.0 : 2.0 * fsum * hop_ * post_cin_ * K);
   }
 }
@@ -2005,8 +2042,8 @@ void Engine::run_stage(char which, const std::string& key) {
   const long l0 = g_launches;
 #ifndef PE_EMU
   if (use_graphs_ && !prof_on_) {
-    auto it = graphs_.find(key);
-    if (it == graphs_.end()) {
+    auto hit = graph_of_.find(key);
+    if (hit == graph_of_.end()) {
       hipGraph_t g = nullptr;
       hipGraphExec_t ex = nullptr;
       // exclusive: no other engine of this process is inside a HIP call while this one captures (see g_capture_mu)
@@ -2031,12 +2068,22 @@ void Engine::run_stage(char which, const std::string& key) {
       }
       g_capture_mu.unlock();
       g_capture_mu.lock_shared();
-      if (graphs_.size() > 64) drop_graphs();
-      it = graphs_.emplace(key, ex).first;
-      graph_launches_[key] = g_launches - l0;
+      ++graph_captures_;
+      if (graphs_.size() >= graph_cap_) {          // evict the least recently used graph only
+        // (it may still be executing: destroying the exec object of a launched graph is deferred by the runtime until
+        // the launch completes; the stream is in order, so nothing of this engine runs concurrently with it anyway)
+        PE_HIP(hipStreamSynchronize(stream_));
+        hipGraphExecDestroy((hipGraphExec_t)graphs_.front().exec);
+        graph_of_.erase(graphs_.front().key);
+        graphs_.pop_front();
+      }
+      graphs_.push_back(GraphEntry{key, (void*)ex, g_launches - l0});
+      hit = graph_of_.emplace(key, std::prev(graphs_.end())).first;
+    } else if (std::next(hit->second) != graphs_.end()) {
+      graphs_.splice(graphs_.end(), graphs_, hit->second);      // most recently used last; iterators stay valid
     }
-    PE_HIP(hipGraphLaunch((hipGraphExec_t)it->second, stream_));
-    run_launches_ += graph_launches_[key];
+    PE_HIP(hipGraphLaunch((hipGraphExec_t)hit->second->exec, stream_));
+    run_launches_ += hit->second->launches;
     return;
   }
 #endif
@@ -2057,10 +2104,61 @@ void Engine::dispatch_stage(char which) {
 
 void Engine::drop_graphs() {
 #ifndef PE_EMU
-  for (auto& kv : graphs_) hipGraphExecDestroy((hipGraphExec_t)kv.second);
+  for (auto& e : graphs_) hipGraphExecDestroy((hipGraphExec_t)e.exec);
 #endif
   graphs_.clear();
-  graph_launches_.clear();
+  graph_of_.clear();
+}
+
+// Shape buckets (engine.h). Steps of 32 ids up to 512, then 8 per octave; steps of 64 frames up to 1024, then 16 per octave.
+int Engine::id_bucket(int T) {
+  int g = rup(std::max(T, 1), 32);
+  if (g > 512) {
+    int step = 64;
+    while (step * 16 <= g) step *= 2;             // step = (largest power of two <= g) / 8
+    g = rup(T, step);
+  }
+  return g;
+}
+int Engine::frame_bucket(int F) {
+  int g = rup(std::max(F, 1), 64);
+  if (g > 1024) {
+    int step = 64;
+    while (step * 32 <= g) step *= 2;             // step = (largest power of two <= g) / 16
+    g = rup(F, step);
+  }
+  return g;
+}
+
+void Engine::warmup(int max_batch, int max_ids, float frames_per_id, const float* scales_in, const int64_t* sample, int64_t n_sample) {
+  EntryLock entry_lock;
+  if (max_batch < 1 || max_batch > 4096) throw std::runtime_error("batch size must be in [1, 4096]");
+  if (max_ids < 1 || max_ids > 8192) throw std::runtime_error("phoneme id sequence longer than 8192");
+  PE_HIP(hipSetDevice(device_));
+  if (!(frames_per_id > 0.f)) frames_per_id = 8.f;
+  const long fmax = std::min<long>(MAX_FRAMES, (long)std::ceil((double)frames_per_id * max_ids) + 1);
+  ensure_stage_a(max_batch, max_ids);
+  ensure_stage_b(frame_bucket((int)fmax));
+  if (!sample || n_sample < 1) return;
+  // the single-utterance graphs of every id bucket up to max_ids: the sample cut / tiled to the bucket length, twice --
+  // the first call of a bucket runs as two graphs around the frame-count read-back, the second as the one speculative
+  // graph later calls replay (engine.h)
+  const float scales[3] = {scales_in ? scales_in[0] : scales_[0], scales_in ? scales_in[1] : scales_[1], scales_in ? scales_in[2] : scales_[2]};
+  std::vector<int64_t> ids;
+  int prev = 0;
+  for (int T = 32; prev < max_ids; T = id_bucket(T + 1)) {
+    const int len = std::min(T, max_ids);
+    ids.resize(len);
+    for (int t = 0; t < len; ++t) ids[t] = sample[t % n_sample];
+    const int64_t off[2] = {0, len};
+    for (int rep = 0; rep < 2; ++rep) {
+      upload(ids.data(), off, 1, scales, nullptr, nullptr);
+      run();
+      finish_run();
+    }
+    prev = len;
+  }
+  PE_HIP(hipStreamSynchronize(stream_));
 }
 
 void Engine::run() {
@@ -2068,14 +2166,14 @@ void Engine::run() {
   PE_HIP(hipSetDevice(device_));
   const int B = B_;
   spec_pending_ = false;
-  Tg_ = std::min(rup(Tmax_, 32), Ts_);
+  Tg_ = std::min(id_bucket(Tmax_), Ts_);
   run_launches_ = 0;
   // speculative sizing of stage B from the previous run's frames-per-id ratio (see engine.h)
   bool spec = spec_enable_ && B <= spec_max_batch_ && last_ratio_ > 0.f && !have_noise_z_ && use_graphs_ && !prof_on_;
   if (spec && spec_cooldown_ > 0) { --spec_cooldown_; spec = false; }
   int fguess = 0;
   if (spec) {
-    fguess = rup((int)std::ceil(last_ratio_ * spec_margin_ * (float)Tmax_) + 1, 32);
+    fguess = frame_bucket((int)std::ceil(last_ratio_ * spec_margin_ * (float)Tmax_) + 1);
     if (fguess > MAX_FRAMES) spec = false;
   }
   if (spec) ensure_stage_b(fguess);              // before stage A is enqueued: growing the workspace drops every graph
@@ -2100,8 +2198,8 @@ void Engine::run() {
   ++call_;                                    // mirrors the device-side counter bump of this run
   PE_HIP(hipStreamSynchronize(stream_));      // the only data-dependent shape: F
   finish_stage_b_sizes();
-  ensure_stage_b(rup(Fmax_, 32));
-  Fg_ = std::min(rup(Fmax_, 32), Fs_);
+  ensure_stage_b(frame_bucket(Fmax_));
+  Fg_ = std::min(frame_bucket(Fmax_), Fs_);
   lens_b_ = d_frames_;
   if (have_noise_z_) {
     const long l0 = g_launches;
@@ -2154,8 +2252,8 @@ bool Engine::finish_run() {
   spec_hit_streak_ = 0;
   spec_margin_ = std::min(1.5f, spec_margin_ * 1.15f);
   if (++spec_recent_misses_ >= 4) { spec_recent_misses_ = 0; spec_recent_runs_ = 0; spec_cooldown_ = 64; }
-  ensure_stage_b(rup(Fmax_, 32));
-  Fg_ = std::min(rup(Fmax_, 32), Fs_);
+  ensure_stage_b(frame_bucket(Fmax_));
+  Fg_ = std::min(frame_bucket(Fmax_), Fs_);
   lens_b_ = d_frames_;
   char key[160];
   snprintf(key, sizeof(key), "B|%d|%d|%d|%d|%a", B_, Fg_, Fs_, Ts_, scales_[0]);
@@ -2218,15 +2316,15 @@ int Engine::stream_begin(const int64_t* ids, int64_t n, const float scales[3], i
   upload(ids, offs, 1, scales, sids, noise);
   PE_HIP(hipSetDevice(device_));
   spec_pending_ = false;
-  Tg_ = std::min(rup(Tmax_, 32), Ts_);
+  Tg_ = std::min(id_bucket(Tmax_), Ts_);
   char key[160];
   snprintf(key, sizeof(key), "A|%d|%d|%d|%a|%a|%d|%d", 1, Tg_, Ts_, scales_[1], scales_[2], (int)have_noise_w_, Fs_);
   run_stage('A', key);
   ++call_;
   PE_HIP(hipStreamSynchronize(stream_));
   finish_stage_b_sizes();
-  ensure_stage_b(rup(Fmax_, 32));
-  Fg_ = std::min(rup(Fmax_, 32), Fs_);
+  ensure_stage_b(frame_bucket(Fmax_));
+  Fg_ = std::min(frame_bucket(Fmax_), Fs_);
   lens_b_ = d_frames_;
   if (have_noise_z_) {
     issue_flow();

@@ -4,6 +4,7 @@
 #pragma once
 #include <cstdint>
 #include <deque>
+#include <list>
 #include <map>
 #include <string>
 #include <unordered_map>
@@ -168,6 +169,8 @@ class Engine {
     const float* zin = nullptr; long zin_bs = 0; int z_cs = 0, c0 = 0, c1 = 1; float* zout = nullptr; long zout_bs = 0;
   };
   void dds(const DdsW& d, View in, View out, View tmp, const DdsOpt* opt = nullptr);
+  double dds_bytes(const struct DdsP& p) const;
+  double cols_ids_ = 0, cols_frames_ = 0;     // ids / frames of the call being issued (algorithmic byte counts of the profile rows)
   void dds_params(const DdsW& d, View in, View out, View tmp, const DdsOpt* opt, std::vector<struct DdsP>& list);
   float* pack16(const std::vector<float>& W, int rows, int K);    // [16-row tile][q][lane][4] (dds_layer16_kernel)
   // every pack16 matrix with K = 96 / 192 is also packed for the 4x4x1 MFMA of the 4-column kernels (kernels/col4.h):
@@ -335,8 +338,25 @@ class Engine {
   int tpb_override_ = 0;
   bool small_tiles_ = true;                 // 32x32 wave tiles everywhere: occupancy beats register reuse here (profiles/)
   long wide_min_blocks_ = 1L << 40;        // 256-column tiles measured slower than 128 (profiles/): off unless PIPER_HIP_WIDE_MIN is set
-  std::map<std::string, void*> graphs_;       // hipGraphExec_t per (stage, shape bucket, scales)
-  std::map<std::string, long> graph_launches_;
+  // hipGraphExec_t per (stage, shape bucket, scales), least recently used first: a new key beyond graph_cap_ entries
+  // evicts ONE graph (the coldest), never the whole cache
+  struct GraphEntry { std::string key; void* exec; long launches; };
+  std::list<GraphEntry> graphs_;
+  std::unordered_map<std::string, std::list<GraphEntry>::iterator> graph_of_;
+  size_t graph_cap_ = 64;                     // PIPER_HIP_GRAPHS
+  long graph_captures_ = 0;                   // captures since the engine was created (pe_graph_stats)
+ public:
+  long graph_captures() const { return graph_captures_; }
+  size_t graphs_cached() const { return graphs_.size(); }
+  // Shape buckets of the captured graphs: ids in steps of 32 up to 512, beyond that 8 steps per octave; frames in steps
+  // of 64 up to 1024, then 16 per octave. A text of any length maps onto a bounded set of graphs.
+  static int id_bucket(int T);
+  static int frame_bucket(int F);
+  // Pre-size the workspaces (so that no later call grows them -- growth re-creates every graph) and, given a sample
+  // utterance, capture the single-utterance graphs of every id bucket up to max_ids by synthesising the sample cut /
+  // tiled to each bucket length
+  void warmup(int max_batch, int max_ids, float frames_per_id, const float* scales, const int64_t* sample, int64_t n_sample);
+ private:
   long run_launches_ = 0;
   unsigned long long* d_rng_ = nullptr;       // {seed, call counter} read by randn_kernel
   float scales_[3] = {0.667f, 1.0f, 0.8f};
@@ -354,6 +374,10 @@ class Engine {
   char* wsB_ = nullptr; size_t wsB_bytes_ = 0;
   int *d_ids_ = nullptr, *d_tlens_ = nullptr, *d_sids_ = nullptr, *d_dur_ = nullptr, *d_cum_ = nullptr,
       *d_frames_ = nullptr;
+  // The small inputs of a call -- {seed, call}, lengths, speaker ids, phoneme ids -- are one contiguous block in the stage-A
+  // workspace (d_in_) mirrored by a pinned host block (h_in_): upload() fills the host block and enqueues ONE copy, no
+  // synchronisation (the pinned block outlives the copy; the call's final synchronisation covers it)
+  char* d_in_ = nullptr; char* h_in_ = nullptr; size_t in_bytes_ = 0, h_in_cap_ = 0;
   float *x_ = nullptr, *y_ = nullptr, *qkv_ = nullptr, *att_ = nullptr, *ffh_ = nullptr, *stats_ = nullptr,
         *xg_ = nullptr, *dh_ = nullptr, *dy_ = nullptr, *dy2_ = nullptr, *hproj_ = nullptr, *z2_ = nullptr,
         *logw_ = nullptr, *noise_w_ = nullptr, *cond_ = nullptr;

@@ -312,6 +312,22 @@ int pe_speculation_stats(pe_engine* e, int64_t* runs, int64_t* misses) {
   });
 }
 
+int pe_warmup(pe_engine* e, int32_t max_batch, int32_t max_ids, float frames_per_id, const float scales[3],
+              const int64_t* sample_ids, int64_t n_sample) {
+  return guard([&] {
+    if (!e) throw std::runtime_error("null engine");
+    e->eng->warmup(max_batch, max_ids, frames_per_id, scales, sample_ids, n_sample);
+  });
+}
+
+int pe_graph_stats(pe_engine* e, int64_t* cached, int64_t* captures) {
+  return guard([&] {
+    if (!e) throw std::runtime_error("null engine");
+    if (cached) *cached = (int64_t)e->eng->graphs_cached();
+    if (captures) *captures = (int64_t)e->eng->graph_captures();
+  });
+}
+
 int pe_xcc_pattern(pe_engine* e, int32_t xcc[64], int32_t* period) {
   return guard([&] {
     if (!e) throw std::runtime_error("null engine");

@@ -241,6 +241,24 @@ class Engine:
         self._check(self._lib.pe_speculation_stats(self._h, C.byref(runs), C.byref(miss)))
         return int(runs.value), int(miss.value)
 
+    def warmup(self, max_batch: int = 1, max_ids: int = 256, frames_per_id: float = 0.0, scales=None, sample_ids=None):
+        """Pre-size the workspaces and (given a sample utterance) capture the single-utterance graphs of every id bucket
+        up to max_ids -- include/piper_hip.h: pe_warmup."""
+        sc = None if scales is None else (C.c_float * 3)(*[float(v) for v in scales])
+        if sample_ids is None:
+            self._check(self._lib.pe_warmup(self._h, int(max_batch), int(max_ids), float(frames_per_id), sc, None, 0))
+            return
+        ids = np.ascontiguousarray(sample_ids, np.int64)
+        self._check(self._lib.pe_warmup(self._h, int(max_batch), int(max_ids), float(frames_per_id), sc,
+                                        ids.ctypes.data_as(C.POINTER(C.c_int64)), ids.size))
+
+    @property
+    def graph_stats(self):
+        """(graphs cached, captures since the engine was created) -- include/piper_hip.h: pe_graph_stats."""
+        a, b = C.c_int64(), C.c_int64()
+        self._check(self._lib.pe_graph_stats(self._h, C.byref(a), C.byref(b)))
+        return int(a.value), int(b.value)
+
     @property
     def xcc_pattern(self):
         """(XCC id of workgroups 0..63 of a probe launch at engine creation, round-robin period or 0) -- include/piper_hip.h."""

@@ -433,3 +433,26 @@ def test_xcd_dispatch_probe_and_override(emu_lib, monkeypatch):
     eng = Engine(blob=blob, lib=emu_lib)
     assert eng.xcc_pattern[1] == 0
     eng.close()
+
+
+def test_warmup_presizes_and_leaves_results_unchanged(emu_lib):
+    """pe_warmup on the emulator (no hipGraphs there: the sizing + the sample runs): a warmed engine gives the waveform of
+    a fresh one (noise off), for lengths below and beyond the warmed range; argument errors are errors."""
+    cfg = W.preset("tiny")
+    blob = W.pack_blob(cfg, W.synthetic_weights(cfg, 1234))
+    sample = W.synthetic_phoneme_ids(20, 3, id_max=cfg.n_vocab - 1)
+    warm = Engine(blob=blob, lib=emu_lib)
+    warm.warmup(max_batch=2, max_ids=70, frames_per_id=6.0, scales=(0.0, 1.0, 0.0), sample_ids=sample)
+    assert warm.graph_stats == (0, 0)                  # the emulator launches directly
+    cold = Engine(blob=blob, lib=emu_lib)
+    for T in (5, 33, 64, 90):
+        ids = W.synthetic_phoneme_ids(T, T, id_max=cfg.n_vocab - 1)
+        a = warm.synthesize(ids, (0.0, 1.0, 0.0))
+        b = cold.synthesize(ids, (0.0, 1.0, 0.0))
+        assert np.array_equal(a.audio[0], b.audio[0]) and np.array_equal(a.pcm[0], b.pcm[0]), T
+    for bad in (dict(max_batch=0), dict(max_ids=0), dict(max_ids=9000), dict(max_batch=5000)):
+        with pytest.raises(EngineError):
+            warm.warmup(**bad)
+    warm.warmup(max_batch=1, max_ids=16)               # sizing only
+    warm.close()
+    cold.close()

@@ -45,7 +45,7 @@ def make_engine(monkeypatch, cfg, w, env=None):
               "PIPER_HIP_WIDE_SPLITK", "PIPER_HIP_DEBUG_KEEP", "PIPER_HIP_MRF", "PIPER_HIP_FUSE_DP",
               "PIPER_HIP_MRF_MAXF", "PIPER_HIP_SPEC", "PIPER_HIP_COLCHAIN", "PIPER_HIP_GROUP_MRF", 
               "PIPER_HIP_MRF_OU", "PIPER_HIP_MATRIX", "PIPER_HIP_BF3_MINF", "PIPER_HIP_MRF_TAIL", "PIPER_HIP_COL4",
-              "PIPER_HIP_COL4_MAXC", "PIPER_HIP_FFN", "PIPER_HIP_XCD"):
+              "PIPER_HIP_COL4_MAXC", "PIPER_HIP_FFN", "PIPER_HIP_XCD", "PIPER_HIP_GRAPHS"):
         monkeypatch.delenv(k, raising=False)
     for k, v in (env or {}).items():
         monkeypatch.setenv(k, str(v))
@@ -601,3 +601,39 @@ def test_bench_two_ranks_on_one_gpu_prints_a_compact_line():
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"
     assert len(d["per_rank_samples_per_s"]) == 2 and d["weight_broadcast"]["bytes"] > 1e8
     assert "64 utterance(s) x 128" in d["config"]["workload"]
+
+
+def test_graph_cache_is_lru_and_warmup_stops_captures(monkeypatch):
+    """The hipGraph cache: shape buckets bound the number of graphs a stream of texts needs, the cache evicts ONE graph
+    (the least recently used) when full -- never all of them -- and after pe_warmup with a representative utterance a
+    second pass over the same texts captures nothing. Results under eviction and replay equal a fresh engine's."""
+    cfg, w = voice("medium")
+    texts = [W.synthetic_phoneme_ids(T, 700 + i, id_max=129) for i, T in enumerate([40, 70, 100, 130, 170, 200, 90, 150])]
+    scales = (0.0, 1.0, 0.0)
+    ref_eng = make_engine(monkeypatch, cfg, w)
+    want = [ref_eng.synthesize(t, scales).pcm[0] for t in texts]
+    ref_eng.close()
+    # ---- a 3-entry cache cycling through 8 buckets: every call evicts, every result is still right
+    eng = make_engine(monkeypatch, cfg, w, {"PIPER_HIP_GRAPHS": 3})
+    for rep in range(2):
+        for t, wpcm in zip(texts, want):
+            got = eng.synthesize(t, scales).pcm[0]
+            assert got.shape == wpcm.shape and np.max(np.abs(got.astype(np.int32) - wpcm.astype(np.int32))) <= 2
+            assert eng.graph_stats[0] <= 3
+    assert eng.graph_stats[1] >= 8
+    eng.close()
+    # ---- the default cache after a warm-up: the second pass over the texts captures nothing
+    eng = make_engine(monkeypatch, cfg, w)
+    eng.warmup(max_batch=1, max_ids=224, frames_per_id=6.0, scales=scales, sample_ids=texts[3])
+    c0 = eng.graph_stats[1]
+    assert c0 >= 7                                      # seven id buckets up to 224
+    for t in texts:
+        eng.synthesize(t, scales)
+    c1 = eng.graph_stats[1]
+    for t, wpcm in zip(texts, want):
+        got = eng.synthesize(t, scales).pcm[0]
+        assert got.shape == wpcm.shape and np.max(np.abs(got.astype(np.int32) - wpcm.astype(np.int32))) <= 2
+    assert eng.graph_stats[1] == c1, (c0, c1, eng.graph_stats)
+    assert c1 - c0 <= len(texts)                        # at most one frame bucket the warm-up did not meet, per text
+    print("graph captures: warm-up", c0, "first pass", c1 - c0, "second pass 0; cached", eng.graph_stats[0])
+    eng.close()
