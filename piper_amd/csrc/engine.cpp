@@ -271,6 +271,36 @@ PackedConv Engine::pack_convT(const WeightSet& ws, const std::string& prefix, in
   return pc;
 }
 
+// The ConvTranspose1d of a stage whose MRF runs as mrf_kernel, once more in the order that kernel's fused up-conv reads
+// (mrf.h UPF): polyphase rows (co * stride + phase) as in pack_convT, A fragments of the 16x16x4 MFMA
+// [16-row tile][chunk of 32 input channels][tap][q = 0..1][lane][4]: lane -> (row = lane & 15, k = lane >> 4), element j of
+// group q = k-step 4q + j = input channel 32 chunk + 4 (4q + j) + k; tap 0 = W[ci][co][phase + stride] (reads x[j - 1]),
+// tap 1 = W[ci][co][phase] (reads x[j]). Only for the shape the kernel is compiled for: Cin = 2 * padded channels, a
+// power-of-two stride >= 2 with kernel = 2 * stride.
+void Engine::pack_up16(const WeightSet& ws, const std::string& prefix, UpStage& st) {
+  if (!st.mrf_ok) return;
+  const HostTensor& w = ws.get(prefix + ".weight");
+  const int Ci = (int)w.dims[0], Co = (int)w.dims[1], K = (int)w.dims[2], S = st.rate, CP = st.mrf_cp;
+  if (Ci != 2 * CP || Co > CP || K != 2 * S || S < 2 || (S & (S - 1)) || (CP * S) % 16) return;
+  const int nrt = CP * S / 16, nch = Ci / KC;
+  const size_t np = (size_t)nrt * nch * 2 * 512;
+  std::vector<float> P(skeleton_ ? 0 : np, 0.f);
+  for (int mt = 0; mt < (skeleton_ ? 0 : nrt); ++mt)
+    for (int c = 0; c < nch; ++c)
+      for (int tap = 0; tap < 2; ++tap)
+        for (int q = 0; q < 2; ++q)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int jj = 0; jj < 4; ++jj) {
+              const int row = mt * 16 + (lane & 15), co = row / S, ph = row % S;
+              const int ci = c * KC + 4 * (4 * q + jj) + (lane >> 4);
+              if (co < Co)
+                P[((((size_t)mt * nch + c) * 2 + tap) * 2 + q) * 256 + lane * 4 + jj] =
+                    w.data[((size_t)ci * Co + co) * K + ph + (tap == 0 ? S : 0)];
+            }
+  st.up16 = dev_alloc(np, skeleton_ ? nullptr : P.data());
+  st.up16_floats = (int)np;
+}
+
 // A dense [rows][K] matrix in the A-operand order of the 16x16x4 MFMA used by dds_layer16_kernel:
 // [16-row tile][q][lane][4], lane -> (row = lane & 15, k = lane >> 4), float4 element j of group q = k-step 4q + j, i.e.
 // input channel 4 * (4q + j) + k. K is padded to a multiple of 32 (the kernel's Hp).
@@ -595,6 +625,7 @@ void Engine::init(const WeightSet& ws) {
       }
       build_mrf(st);
       st.rb_host.clear();
+      pack_up16(ws, "dec.ups." + std::to_string(i), st);
       ups_.push_back(st);
     }
     const HostTensor& pw = ws.get("dec.conv_post.weight");
@@ -653,6 +684,7 @@ void Engine::init(const WeightSet& ws) {
   PE_HIP(hipEventCreate(&ev1_));
   PE_HIP(hipHostMalloc((void**)&h_frames_, 4096 * sizeof(int)));
   if (const char* ng = getenv("PIPER_HIP_NO_GRAPH")) use_graphs_ = !(ng[0] && ng[0] != '0');
+  if (const char* t = getenv("PIPER_HIP_UPF")) upf_ = std::min(2, std::max(0, atoi(t)));      // fused up-conv: 0 off, 1 small calls, 2 always (tests)
   if (const char* t = getenv("PIPER_HIP_GRAPHS")) graph_cap_ = (size_t)std::min(4096, std::max(1, atoi(t)));
   if (const char* t = getenv("PIPER_HIP_TPB")) tpb_override_ = atoi(t);     // tuning / test knob
   if (const char* t = getenv("PIPER_HIP_WIDE_MIN")) wide_min_blocks_ = atol(t);
@@ -700,6 +732,8 @@ void Engine::free_all() {
   if (h_frames_) hipHostFree(h_frames_);
   if (h_in_) hipHostFree(h_in_);
   h_in_ = nullptr; h_in_cap_ = 0;
+  if (upf_scratch_) hipFree(upf_scratch_);
+  upf_scratch_ = nullptr; upf_scratch_bytes_ = 0;
   if (ev0_) hipEventDestroy(ev0_);
   if (ev1_) hipEventDestroy(ev1_);
   for (auto& k : kev_) { hipEventDestroy(k.a); hipEventDestroy(k.b); }
@@ -863,6 +897,28 @@ void Engine::ensure_stage_b(int Fmax) {
     if (h_pcm_zc_) PE_HIP(hipHostFree(h_pcm_zc_));
     h_pcm_zc_cap_ = zc_want;
     PE_HIP(hipHostMalloc((void**)&h_pcm_zc_, h_pcm_zc_cap_ * sizeof(int16_t)));
+  }
+  // scratch of the fused up-conv (mrf.h UPF): the raw stage input of every workgroup's window, for the small calls the
+  // fusion is used on (sized for the 2-units-per-wave geometry at this frame capacity; a launch that needs more, or more
+  // than the cap, runs its up-conv as a separate launch -- Engine::upf_plan)
+  if (upf_) {
+    size_t want = 0;
+    const size_t nb = upf_ == 2 ? Bc : std::min<size_t>(Bc, (size_t)upf_max_batch_);
+    size_t L = F;
+    for (auto& st : ups_) {
+      L *= st.rate;
+      if (!st.up16) continue;
+      const int CP = st.mrf_cp, N2 = 16 * (CP == 32 ? 8 : 4) * 2;
+      want = std::max(want, nb * (L / (N2 - (POST_K - 1)) + 2) * CP * mrf_ws(CP, 2) * sizeof(float));
+    }
+    want = std::min(want, upf_scratch_cap_);
+    if (want > upf_scratch_bytes_) {
+      PE_HIP(hipStreamSynchronize(stream_));
+      drop_graphs();                                     // the pointer is a kernel argument inside the graphs
+      if (upf_scratch_) PE_HIP(hipFree(upf_scratch_));
+      upf_scratch_bytes_ = want;
+      PE_HIP(hipMalloc((void**)&upf_scratch_, upf_scratch_bytes_));
+    }
   }
   // per-resblock buffers of the grouped sibling schedule (one-utterance calls, first generator stage): allocated
   // here, outside any graph capture; the schedule only applies below 700 64x64 blocks per stage
@@ -1206,24 +1262,23 @@ void Engine::build_mrf(UpStage& st) {
 // utterances: the launch is one or two rounds of workgroups over the 256 CUs, so the workgroup count should sit just under
 // a multiple of 256 and a workgroup should be short; batches: many rounds, so large N (less halo recompute, fewer
 // prologues) wins. Cost model: rounds x (MFMA columns of one workgroup incl. recompute + a fixed prologue / epilogue).
-void Engine::mrf(const UpStage& st, View x, View out, const int* lens, int len_mul, int Lmax, bool tail) {
+bool Engine::mrf_geo(const UpStage& st, int len_mul, bool tail, MrfGeo& best) const {
   const int CP = st.mrf_cp, NCG = CP == 32 ? 8 : 4, HU = CP == 32 ? 1 : 2;
   const int OUMAX = CP == 32 ? 4 : 3;      // 32 channels: 4 units per wave (N = 512) fill the 160 KB of LDS
   const int hx = st.mrf_hx, hxa = rup(hx, 16);
-  struct Geo { int ou, N, cu_lo, cu_hi, nleft, nhalo; };
-  auto geo = [&](int ou, Geo& g) {
+  auto geo = [&](int ou, MrfGeo& g) {
     g.ou = ou; g.N = 16 * NCG * ou;
     if (hxa + g.N + hx > mrf_ws(CP, ou)) return false;
     g.cu_lo = (hxa - hx) / 16; g.cu_hi = (hxa + g.N + hx + 15) / 16;
     g.nleft = hxa / 16 - g.cu_lo; g.nhalo = g.cu_hi - g.cu_lo - g.N / 16;
     return g.nhalo <= NCG * HU;
   };
-  Geo best{};
+  best = MrfGeo{};
   double best_cost = 0;
-  Geo forced;
+  MrfGeo forced;
   const int force = (mrf_ou_ >= 1 && mrf_ou_ <= OUMAX && geo(mrf_ou_, forced)) ? mrf_ou_ : 0;     // (tests / A-B; ignored when it does not fit)
   for (int ou = 1; ou <= OUMAX; ++ou) {
-    Geo g;
+    MrfGeo g;
     if ((force && ou != force) || !geo(ou, g)) continue;
     double wgs = 0;
     const int stride = tail ? g.N - (POST_K - 1) : g.N;
@@ -1241,8 +1296,42 @@ void Engine::mrf(const UpStage& st, View x, View out, const int* lens, int len_m
     if (ou == 4) cost *= 1.06;
     if (!best.ou || cost < best_cost) { best = g; best_cost = cost; }
   }
-  if (!best.ou) throw std::runtime_error("internal: no mrf_kernel geometry for this stage");
-  MrfP p;
+  return best.ou != 0;
+}
+
+// The fused up-conv's window geometry for the stage's chosen mrf geometry (mrf.h UPF), or false: the stage's
+// ConvTranspose1d then runs as its own launch. Checks what the kernel is compiled for (staged input window <= 64 x 3 /
+// 64 x 2 columns per row, inside LDS buffer 1) and that the scratch buffer holds every workgroup's raw window.
+bool Engine::upf_plan(const UpStage& st, int len_mul, int Lmax, bool tail, MrfP* o) {
+  if (!upf_ || !st.up16 || !(upf_ == 2 || B_ <= upf_max_batch_)) return false;
+  MrfGeo g;
+  if (!mrf_geo(st, len_mul, tail, g)) return false;
+  const int CP = st.mrf_cp, S = st.rate, hx = st.mrf_hx, hxa = rup(hx, 16), WS = mrf_ws(CP, g.ou);
+  const int wcols = hxa + g.N + hx;
+  const int njt = (wcols + S + 16 * S - 1) / (16 * S);
+  int xs = 16 * (njt + (njt & 1)) + 1;
+  xs = xs + ((16 - xs % 32) + 32) % 32;                        // == 16 (mod 32): the k rows of a half-wave hit disjoint banks
+  if (xs > 64 * (CP == 32 ? 3 : 2) || (size_t)2 * CP * xs > (size_t)CP * WS) return false;
+  const int stride = tail ? g.N - (POST_K - 1) : g.N;
+  const long nwg = (Lmax + stride - 1) / stride;
+  if ((size_t)B_ * nwg * CP * WS * sizeof(float) > upf_scratch_bytes_) return false;
+  if (o) {
+    int sh = 0;
+    while ((1 << sh) < S) ++sh;
+    o->up_w = st.up16; o->up_wfloats = st.up16_floats; o->up_bias = st.up.bias;
+    o->up_stride = S; o->up_shift = sh; o->up_pad = st.up.padT;
+    o->up_njt = njt; o->up_xs = xs; o->up_slope = 0.1f;
+    o->up_scratch = upf_scratch_; o->up_sc_bs = nwg * CP * WS;
+  }
+  return true;
+}
+
+void Engine::mrf(const UpStage& st, View x, View out, const int* lens, int len_mul, int Lmax, bool tail, bool up) {
+  const int CP = st.mrf_cp, HU = CP == 32 ? 1 : 2;
+  const int hx = st.mrf_hx, hxa = rup(hx, 16);
+  MrfGeo best;
+  if (!mrf_geo(st, len_mul, tail, best)) throw std::runtime_error("internal: no mrf_kernel geometry for this stage");
+  MrfP p{};
   p.x = x.p; p.x_bs = x.bs; p.x_cs = x.cs;
   p.out = out.p; p.o_bs = out.bs; p.o_cs = out.cs;
   p.lens = lens; p.len_mul = len_mul;
@@ -1258,6 +1347,11 @@ void Engine::mrf(const UpStage& st, View x, View out, const int* lens, int len_m
     p.stride = best.N - (POST_K - 1); p.n0off = (POST_K - 1) / 2;
     p.post_w = post_w_; p.audio = audio_; p.a_bs = Ss_; p.absmax = absmax_;
   }
+  if (up) {        // the stage's up-conv inside the kernel: `x` is the previous stage's output
+    if (!upf_plan(st, len_mul, Lmax, tail, &p)) throw std::runtime_error("internal: fused up-conv does not fit");
+    p.up_x = x.p; p.up_x_bs = x.bs; p.up_x_cs = x.cs; p.up_lmul = len_mul / st.rate;
+    p.x = nullptr; p.x_bs = 0; p.x_cs = 0;
+  }
   double kflops = 0, kbytes = 0;
   if (prof_level_ >= 2) {
     double cols = 0;
@@ -1271,10 +1365,14 @@ void Engine::mrf(const UpStage& st, View x, View out, const int* lens, int len_m
       kflops += 2.0 * cols * st.ch * POST_K;
       kbytes = 4.0 * (st.ch + 1) * cols + 4.0 * st.mrf_wfloats;   // one read of x, one write of the waveform
     }
+    if (up) {      // + the up-conv's work; x is its (shorter, wider) input instead of its output
+      kflops += 2.0 * st.up.macs_per_col * cols / st.rate;
+      kbytes += 4.0 * (2.0 * CP / st.rate - st.ch) * cols + 4.0 * st.up16_floats;
+    }
   }
   dim3 grid((Lmax + p.stride - 1) / p.stride, B_);
   char nm[64];
-  snprintf(nm, sizeof(nm), "mrf_kernel<%d,%d,%d>", CP, best.ou, HU);
+  snprintf(nm, sizeof(nm), "mrf_kernel<%d,%d,%d,%s>", CP, best.ou, HU, up ? "true" : "false");
   const int kh = prof_level_ >= 2 ? kbegin(krow(std::string(nm)), kflops, kbytes) : -1;
   launch::mrf(CP, best.ou, grid, ls_, p);
   kend(kh);
@@ -1914,12 +2012,24 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
       const long Ls = (long)Fs * mult;
       auto VS = [&](int bi) { return View{hb_[bi], (long)st.ch * Ls, (int)Ls}; };
       const View u = VS(ids[0]), ta = VS(ids[1]), tb = VS(ids[2]), tc = VS(ids[3]);
-      // leaky_relu(0.1) -> ConvTranspose1d
-      conv(st.up, cur, u, lens, Lin, Fmax * Lin, EPI_CONVT, 0.1f);
-      fl += 2.0 * fsum * Lin * st.up.macs_per_col;
-      // xs accumulates into the buffer that held the stage input (free once the up-conv is done)
-      const View xs{hb_[cur_buf], (long)st.ch * Ls, (int)Ls};
       const int Lmax = Fmax * mult;
+      // One launch per stage (mrf_kernel). Measured (profiles/r03_notes.md): ResBlock2 stages (medium / x-low) win at every
+      // batch size (B=1 -3 %, B=16 / 64 +4.5 % end to end over the conv-by-conv schedule); ResBlock1 stages (high) tie at
+      // one utterance and lose at batch (its 64-channel stage: 86 vs ~110 TFLOP/s for the conv GEMM kernel on K = 64 * 11
+      // convs), so those are fused for one or two utterances and on 32 channels only.
+      // (matrix mode bf16x3: the fused kernel is f32; from a few utterances up the conv-by-conv schedule on the bf16 pipe is faster)
+      const bool fuse = mrf_mode_ && st.mrf_ok && !(matrix_bf3_ && mrf_mode_ != 2 && fsum >= (double)bf3_min_frames_) &&
+                        (mrf_mode_ == 2 || !st.mrf_rb1 || (st.mrf_cp == 32 && fsum <= (double)mrf_rb1_max_frames_));
+      // the last stage also runs the generator tail (conv_post, tanh, peak) on its MRF mean while it is still on chip
+      const bool tail = fuse && mrf_tail_ && &st == &ups_.back() && st.mrf_cp == 32 && st.ch == post_cin_ && mult == hop_;
+      // small calls: the stage kernel computes the up-conv of its own window too (mrf.h UPF) -- no launch, no u tensor
+      const bool upfuse = fuse && upf_plan(st, mult, Lmax, tail, nullptr);
+      // leaky_relu(0.1) -> ConvTranspose1d
+      if (!upfuse) conv(st.up, cur, u, lens, Lin, Fmax * Lin, EPI_CONVT, 0.1f);
+      fl += 2.0 * fsum * Lin * st.up.macs_per_col;
+      // xs accumulates into the buffer that held the stage input (free once the up-conv is done); with the fused up-conv
+      // the stage kernel reads that buffer itself, so the MRF mean goes where u would have been
+      const View xs{hb_[upfuse ? ids[0] : cur_buf], (long)st.ch * Ls, (int)Ls};
       // One resblock chain, accumulated into xs with the MRF mode. `t` = {c1 output, ping, pong}.
       auto chain = [&](int j, const View (&t)[3], View dst, int accmode) {
         auto& cv = st.rb[j];
@@ -1963,17 +2073,8 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
         if (cv.size() != st.rb[0].size()) grp = false;
         for (auto& c : cv) grp = grp && can_group(c, Lmax);
       }
-      // One launch per stage (mrf_kernel). Measured (profiles/r03_notes.md): ResBlock2 stages (medium / x-low) win at every
-      // batch size (B=1 -3 %, B=16 / 64 +4.5 % end to end over the conv-by-conv schedule); ResBlock1 stages (high) tie at
-      // one utterance and lose at batch (its 64-channel stage: 86 vs ~110 TFLOP/s for the conv GEMM kernel on K = 64 * 11
-      // convs), so those are fused for one or two utterances and on 32 channels only.
-      // (matrix mode bf16x3: the fused kernel is f32; from a few utterances up the conv-by-conv schedule on the bf16 pipe is faster)
-      const bool fuse = mrf_mode_ && st.mrf_ok && !(matrix_bf3_ && mrf_mode_ != 2 && fsum >= (double)bf3_min_frames_) &&
-                        (mrf_mode_ == 2 || !st.mrf_rb1 || (st.mrf_cp == 32 && fsum <= (double)mrf_rb1_max_frames_));
       if (fuse) {
-        // the last stage also runs the generator tail (conv_post, tanh, peak) on its MRF mean while it is still on chip
-        const bool tail = mrf_tail_ && &st == &ups_.back() && st.mrf_cp == 32 && st.ch == post_cin_ && mult == hop_;
-        mrf(st, u, xs, lens, mult, Lmax, tail);
+        mrf(st, upfuse ? cur : u, xs, lens, mult, Lmax, tail, upfuse);
         for (auto& cv : st.rb)
           for (auto& c : cv) fl += 2.0 * fsum * mult * c.macs_per_col;
         if (tail) {
@@ -2020,7 +2121,8 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
           chain(j, t, xs, accmode);
         }
       }
-      cur = xs;      // same buffer index cur_buf, new shape
+      cur = xs;      // new shape; the buffer that held the stage input, or (fused up-conv) the one u would have used
+      if (upfuse) cur_buf = ids[0];
     }
     prof_end(3, fl);
 
@@ -2156,6 +2258,22 @@ void Engine::warmup(int max_batch, int max_ids, float frames_per_id, const float
       run();
       finish_run();
     }
+    // ... and the frame buckets next to the one the sample landed in: other texts of this length differ by a few per cent
+    // in frames per id (each call below replays or captures the whole-utterance graph for a forced guess; a guess that
+    // is too small for the sample costs one re-run of the second half, like any miss -- not counted)
+    const int fg = frame_bucket(Fmax_);
+    const long runs0 = spec_runs_, miss0 = spec_misses_;
+    const float margin0 = spec_margin_;
+    const int streak0 = spec_hit_streak_, rm0 = spec_recent_misses_, rr0 = spec_recent_runs_, cd0 = spec_cooldown_;
+    for (int d = -1; d <= 1; ++d) {
+      spec_fg_force_ = frame_bucket(std::max(1, fg + d * 64));
+      upload(ids.data(), off, 1, scales, nullptr, nullptr);
+      run();
+      finish_run();
+    }
+    spec_fg_force_ = 0;
+    spec_runs_ = runs0; spec_misses_ = miss0; spec_margin_ = margin0;
+    spec_hit_streak_ = streak0; spec_recent_misses_ = rm0; spec_recent_runs_ = rr0; spec_cooldown_ = cd0;
     prev = len;
   }
   PE_HIP(hipStreamSynchronize(stream_));
@@ -2173,7 +2291,7 @@ void Engine::run() {
   if (spec && spec_cooldown_ > 0) { --spec_cooldown_; spec = false; }
   int fguess = 0;
   if (spec) {
-    fguess = frame_bucket((int)std::ceil(last_ratio_ * spec_margin_ * (float)Tmax_) + 1);
+    fguess = spec_fg_force_ ? spec_fg_force_ : frame_bucket((int)std::ceil(last_ratio_ * spec_margin_ * (float)Tmax_) + 1);
     if (fguess > MAX_FRAMES) spec = false;
   }
   if (spec) ensure_stage_b(fguess);              // before stage A is enqueued: growing the workspace drops every graph

@@ -234,6 +234,7 @@ class Engine {
   void finish_stage_b_sizes();
   bool spec_enable_ = true, spec_pending_ = false;
   int spec_max_batch_ = 4, spec_fg_ = 0;
+  int spec_fg_force_ = 0;            // warm-up only: the frame bucket the next speculative run is issued for
   // The guess = (slowly decaying maximum of the frames-per-id ratios seen so far) x margin. The margin adapts: a miss
   // widens it (x 1.15, up to 1.5), 32 hits in a row narrow it again (down to 1.10); four misses within 16 speculative
   // runs switch speculation off for the next 64 calls (texts whose lengths vary too much for the estimate to hold).
@@ -302,9 +303,21 @@ class Engine {
     int mrf_wfloats = 0, mrf_cp = 0, mrf_hx = 0;  // padded channels (32 / 64), halo of the stage (widest resblock chain)
     std::vector<struct MrfPhase> mrf_ph;          // host copy of the phases (cost model of the geometry choice)
     bool mrf_ok = false, mrf_rb1 = false;
+    float* up16 = nullptr; int up16_floats = 0;   // the stage's ConvTranspose1d in the fused up-conv's fragment order (pack_up16; null: not fusable)
   };
+  struct MrfGeo { int ou = 0, N = 0, cu_lo = 0, cu_hi = 0, nleft = 0, nhalo = 0; };
+  bool mrf_geo(const UpStage& st, int len_mul, bool tail, MrfGeo& best) const;      // window geometry by the cost model
   void build_mrf(UpStage& st);
-  void mrf(const UpStage& st, View x, View out, const int* lens, int len_mul, int Lmax, bool tail = false);
+  void pack_up16(const WeightSet& ws, const std::string& prefix, UpStage& st);
+  // `xin` (with `up` set): the previous stage's output -- the kernel computes the stage's up-conv itself (mrf.h UPF)
+  void mrf(const UpStage& st, View x, View out, const int* lens, int len_mul, int Lmax, bool tail = false, bool up = false);
+  // Fused up-conv policy (PIPER_HIP_UPF: 0 off, 1 calls of up to upf_max_batch_ utterances, 2 wherever it applies): the
+  // workgroups keep the raw stage input of their windows in a scratch buffer ([utterance][workgroup][CP][row stride],
+  // grown on demand up to upf_scratch_cap_ bytes; beyond: the separate up-conv launch)
+  int upf_ = 1, upf_max_batch_ = 4;
+  float* upf_scratch_ = nullptr; size_t upf_scratch_bytes_ = 0;
+  static constexpr size_t upf_scratch_cap_ = (size_t)512 << 20;
+  bool upf_plan(const UpStage& st, int len_mul, int Lmax, bool tail, struct MrfP* out_geo);
   int mrf_mode_ = 1;                        // PIPER_HIP_MRF: 0 off (conv by conv), 1 by the measured policy, 2 wherever it applies
   long mrf_rb1_max_frames_ = 1100;          // ResBlock1 stages: batch frames up to which the fused kernel is used in mode 1
   bool mrf_tail_ = true;                    // PIPER_HIP_MRF_TAIL=0: conv_post_kernel as its own launch behind a fused last stage

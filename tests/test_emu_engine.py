@@ -353,7 +353,7 @@ def test_emulated_generator_tail_inside_the_last_stage_kernel(emu_lib, monkeypat
         eng.profile_enable(2)
         r = eng.synthesize_batch(ids, (0.5, 1.0, 0.8), noise_w=nw, noise_z=nz)
         names = {row["name"] for row in eng.profile()}
-        assert f"mrf_kernel<32,{ou},1>" in names and ("conv_post_kernel" in names) == (tail == "0"), names
+        assert any(n.startswith(f"mrf_kernel<32,{ou},1,") for n in names) and ("conv_post_kernel" in names) == (tail == "0"), names
         res[(tail, ou)] = r
         eng.close()
     ref = res[("0", "2")]
@@ -442,17 +442,51 @@ def test_warmup_presizes_and_leaves_results_unchanged(emu_lib):
     blob = W.pack_blob(cfg, W.synthetic_weights(cfg, 1234))
     sample = W.synthetic_phoneme_ids(20, 3, id_max=cfg.n_vocab - 1)
     warm = Engine(blob=blob, lib=emu_lib)
-    warm.warmup(max_batch=2, max_ids=70, frames_per_id=6.0, scales=(0.0, 1.0, 0.0), sample_ids=sample)
+    warm.warmup(max_batch=2, max_ids=40, frames_per_id=6.0, scales=(0.0, 1.0, 0.0), sample_ids=sample)
     assert warm.graph_stats == (0, 0)                  # the emulator launches directly
     cold = Engine(blob=blob, lib=emu_lib)
-    for T in (5, 33, 64, 90):
+    for T in (5, 40, 90):
         ids = W.synthetic_phoneme_ids(T, T, id_max=cfg.n_vocab - 1)
         a = warm.synthesize(ids, (0.0, 1.0, 0.0))
         b = cold.synthesize(ids, (0.0, 1.0, 0.0))
-        assert np.array_equal(a.audio[0], b.audio[0]) and np.array_equal(a.pcm[0], b.pcm[0]), T
+        # (the warmed engine sizes its second half speculatively: another frame bucket, possibly another conv route --
+        # identical up to the float summation order)
+        assert a.audio[0].shape == b.audio[0].shape and np.max(np.abs(a.audio[0] - b.audio[0])) < 1e-6, T
     for bad in (dict(max_batch=0), dict(max_ids=0), dict(max_ids=9000), dict(max_batch=5000)):
         with pytest.raises(EngineError):
             warm.warmup(**bad)
     warm.warmup(max_batch=1, max_ids=16)               # sizing only
     warm.close()
     cold.close()
+
+
+@pytest.mark.parametrize("preset,over,lens,ou", [("tiny", {}, [7, 3, 1], 1), ("tiny", {"up_initial": 256}, [4], 2),
+                                                 ("tiny", {"up_initial": 256}, [3, 2], 3), ("tiny-high", {}, [5], 2),
+                                                 ("tiny", {}, [9], 4)])
+def test_emulated_fused_upconv_is_bit_identical(emu_lib, monkeypatch, preset, over, lens, ou):
+    """mrf_kernel<..., UPF = true>: the stage kernel computes the ConvTranspose1d of its own window (polyphase GEMM on the
+    16x16x4 MFMA out of an activated input window in LDS, raw window to a scratch slice) instead of reading the output of
+    a separate up-conv launch. Against that launch through the TILED conv kernel (same k order: chunk-major, tap-minor,
+    ascending channel) the waveform must be bit-identical -- for strides 8 and 4, 32 and 64 padded channels, every window
+    width, the fused generator tail, ResBlock1 re-staging from the scratch, ragged batches with one-frame utterances."""
+    monkeypatch.setenv("PIPER_HIP_SPLITK_MAX", "0")        # the unfused up-conv through conv_mfma_kernel, not split-K
+    monkeypatch.setenv("PIPER_HIP_MRF", "2")
+    monkeypatch.setenv("PIPER_HIP_MRF_OU", str(ou))
+    cfg = W.preset(preset, **over)
+    w = W.synthetic_weights(cfg, 1234)
+    ids = [W.synthetic_phoneme_ids(T, i, id_max=cfg.n_vocab - 1) for i, T in enumerate(lens)]
+    nw, nz = _noise(cfg, len(lens), max(lens), 77)
+    res = {}
+    for upf in ("0", "2"):
+        monkeypatch.setenv("PIPER_HIP_UPF", upf)
+        eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
+        eng.profile_enable(2)
+        res[upf] = eng.synthesize_batch(ids, (0.5, 1.0, 0.8), noise_w=nw, noise_z=nz)
+        names = {row["name"] for row in eng.profile()[5:] if row["launches"]}
+        assert any(n.startswith("mrf_kernel<") and n.endswith(",true>") for n in names) == (upf == "2"), names
+        eng.close()
+    for i in range(len(lens)):
+        assert np.array_equal(res["0"].audio[i], res["2"].audio[i]), i
+        assert np.array_equal(res["0"].pcm[i], res["2"].pcm[i]), i
+    o = O.synthesize(w, cfg, ids[0], (0.5, 1.0, 0.8), nw[0][:, :lens[0]], nz[0])
+    assert np.max(np.abs(res["2"].audio[0] - o["audio"])) < 1e-4
