@@ -271,36 +271,6 @@ PackedConv Engine::pack_convT(const WeightSet& ws, const std::string& prefix, in
   return pc;
 }
 
-// The ConvTranspose1d of a stage whose MRF runs as mrf_kernel, once more in the order that kernel's fused up-conv reads
-// (mrf.h UPF): polyphase rows (co * stride + phase) as in pack_convT, A fragments of the 16x16x4 MFMA
-// [16-row tile][chunk of 32 input channels][tap][q = 0..1][lane][4]: lane -> (row = lane & 15, k = lane >> 4), element j of
-// group q = k-step 4q + j = input channel 32 chunk + 4 (4q + j) + k; tap 0 = W[ci][co][phase + stride] (reads x[j - 1]),
-// tap 1 = W[ci][co][phase] (reads x[j]). Only for the shape the kernel is compiled for: Cin = 2 * padded channels, a
-// power-of-two stride >= 2 with kernel = 2 * stride.
-void Engine::pack_up16(const WeightSet& ws, const std::string& prefix, UpStage& st) {
-  if (!st.mrf_ok) return;
-  const HostTensor& w = ws.get(prefix + ".weight");
-  const int Ci = (int)w.dims[0], Co = (int)w.dims[1], K = (int)w.dims[2], S = st.rate, CP = st.mrf_cp;
-  if (Ci != 2 * CP || Co > CP || K != 2 * S || S < 2 || (S & (S - 1)) || (CP * S) % 16) return;
-  const int nrt = CP * S / 16, nch = Ci / KC;
-  const size_t np = (size_t)nrt * nch * 2 * 512;
-  std::vector<float> P(skeleton_ ? 0 : np, 0.f);
-  for (int mt = 0; mt < (skeleton_ ? 0 : nrt); ++mt)
-    for (int c = 0; c < nch; ++c)
-      for (int tap = 0; tap < 2; ++tap)
-        for (int q = 0; q < 2; ++q)
-          for (int lane = 0; lane < 64; ++lane)
-            for (int jj = 0; jj < 4; ++jj) {
-              const int row = mt * 16 + (lane & 15), co = row / S, ph = row % S;
-              const int ci = c * KC + 4 * (4 * q + jj) + (lane >> 4);
-              if (co < Co)
-                P[((((size_t)mt * nch + c) * 2 + tap) * 2 + q) * 256 + lane * 4 + jj] =
-                    w.data[((size_t)ci * Co + co) * K + ph + (tap == 0 ? S : 0)];
-            }
-  st.up16 = dev_alloc(np, skeleton_ ? nullptr : P.data());
-  st.up16_floats = (int)np;
-}
-
 // A dense [rows][K] matrix in the A-operand order of the 16x16x4 MFMA used by dds_layer16_kernel:
 // [16-row tile][q][lane][4], lane -> (row = lane & 15, k = lane >> 4), float4 element j of group q = k-step 4q + j, i.e.
 // input channel 4 * (4q + j) + k. K is padded to a multiple of 32 (the kernel's Hp).
@@ -625,7 +595,6 @@ void Engine::init(const WeightSet& ws) {
       }
       build_mrf(st);
       st.rb_host.clear();
-      pack_up16(ws, "dec.ups." + std::to_string(i), st);
       ups_.push_back(st);
     }
     const HostTensor& pw = ws.get("dec.conv_post.weight");
@@ -684,7 +653,7 @@ void Engine::init(const WeightSet& ws) {
   PE_HIP(hipEventCreate(&ev1_));
   PE_HIP(hipHostMalloc((void**)&h_frames_, 4096 * sizeof(int)));
   if (const char* ng = getenv("PIPER_HIP_NO_GRAPH")) use_graphs_ = !(ng[0] && ng[0] != '0');
-  if (const char* t = getenv("PIPER_HIP_UPF")) upf_ = std::min(2, std::max(0, atoi(t)));      // fused up-conv: 0 off, 1 small calls, 2 always (tests)
+  if (const char* t = getenv("PIPER_HIP_ATTNO")) attno_ = atoi(t) != 0;          // attention + conv_o + LN as one launch (small calls): 0 = two launches
   if (const char* t = getenv("PIPER_HIP_GRAPHS")) graph_cap_ = (size_t)std::min(4096, std::max(1, atoi(t)));
   if (const char* t = getenv("PIPER_HIP_TPB")) tpb_override_ = atoi(t);     // tuning / test knob
   if (const char* t = getenv("PIPER_HIP_WIDE_MIN")) wide_min_blocks_ = atol(t);
@@ -732,8 +701,6 @@ void Engine::free_all() {
   if (h_frames_) hipHostFree(h_frames_);
   if (h_in_) hipHostFree(h_in_);
   h_in_ = nullptr; h_in_cap_ = 0;
-  if (upf_scratch_) hipFree(upf_scratch_);
-  upf_scratch_ = nullptr; upf_scratch_bytes_ = 0;
   if (ev0_) hipEventDestroy(ev0_);
   if (ev1_) hipEventDestroy(ev1_);
   for (auto& k : kev_) { hipEventDestroy(k.a); hipEventDestroy(k.b); }
@@ -897,28 +864,6 @@ void Engine::ensure_stage_b(int Fmax) {
     if (h_pcm_zc_) PE_HIP(hipHostFree(h_pcm_zc_));
     h_pcm_zc_cap_ = zc_want;
     PE_HIP(hipHostMalloc((void**)&h_pcm_zc_, h_pcm_zc_cap_ * sizeof(int16_t)));
-  }
-  // scratch of the fused up-conv (mrf.h UPF): the raw stage input of every workgroup's window, for the small calls the
-  // fusion is used on (sized for the 2-units-per-wave geometry at this frame capacity; a launch that needs more, or more
-  // than the cap, runs its up-conv as a separate launch -- Engine::upf_plan)
-  if (upf_) {
-    size_t want = 0;
-    const size_t nb = upf_ == 2 ? Bc : std::min<size_t>(Bc, (size_t)upf_max_batch_);
-    size_t L = F;
-    for (auto& st : ups_) {
-      L *= st.rate;
-      if (!st.up16) continue;
-      const int CP = st.mrf_cp, N2 = 16 * (CP == 32 ? 8 : 4) * 2;
-      want = std::max(want, nb * (L / (N2 - (POST_K - 1)) + 2) * CP * mrf_ws(CP, 2) * sizeof(float));
-    }
-    want = std::min(want, upf_scratch_cap_);
-    if (want > upf_scratch_bytes_) {
-      PE_HIP(hipStreamSynchronize(stream_));
-      drop_graphs();                                     // the pointer is a kernel argument inside the graphs
-      if (upf_scratch_) PE_HIP(hipFree(upf_scratch_));
-      upf_scratch_bytes_ = want;
-      PE_HIP(hipMalloc((void**)&upf_scratch_, upf_scratch_bytes_));
-    }
   }
   // per-resblock buffers of the grouped sibling schedule (one-utterance calls, first generator stage): allocated
   // here, outside any graph capture; the schedule only applies below 700 64x64 blocks per stage
@@ -1299,34 +1244,7 @@ bool Engine::mrf_geo(const UpStage& st, int len_mul, bool tail, MrfGeo& best) co
   return best.ou != 0;
 }
 
-// The fused up-conv's window geometry for the stage's chosen mrf geometry (mrf.h UPF), or false: the stage's
-// ConvTranspose1d then runs as its own launch. Checks what the kernel is compiled for (staged input window <= 64 x 3 /
-// 64 x 2 columns per row, inside LDS buffer 1) and that the scratch buffer holds every workgroup's raw window.
-bool Engine::upf_plan(const UpStage& st, int len_mul, int Lmax, bool tail, MrfP* o) {
-  if (!upf_ || !st.up16 || !(upf_ == 2 || B_ <= upf_max_batch_)) return false;
-  MrfGeo g;
-  if (!mrf_geo(st, len_mul, tail, g)) return false;
-  const int CP = st.mrf_cp, S = st.rate, hx = st.mrf_hx, hxa = rup(hx, 16), WS = mrf_ws(CP, g.ou);
-  const int wcols = hxa + g.N + hx;
-  const int njt = (wcols + S + 16 * S - 1) / (16 * S);
-  int xs = 16 * (njt + (njt & 1)) + 1;
-  xs = xs + ((16 - xs % 32) + 32) % 32;                        // == 16 (mod 32): the k rows of a half-wave hit disjoint banks
-  if (xs > 64 * (CP == 32 ? 3 : 2) || (size_t)2 * CP * xs > (size_t)CP * WS) return false;
-  const int stride = tail ? g.N - (POST_K - 1) : g.N;
-  const long nwg = (Lmax + stride - 1) / stride;
-  if ((size_t)B_ * nwg * CP * WS * sizeof(float) > upf_scratch_bytes_) return false;
-  if (o) {
-    int sh = 0;
-    while ((1 << sh) < S) ++sh;
-    o->up_w = st.up16; o->up_wfloats = st.up16_floats; o->up_bias = st.up.bias;
-    o->up_stride = S; o->up_shift = sh; o->up_pad = st.up.padT;
-    o->up_njt = njt; o->up_xs = xs; o->up_slope = 0.1f;
-    o->up_scratch = upf_scratch_; o->up_sc_bs = nwg * CP * WS;
-  }
-  return true;
-}
-
-void Engine::mrf(const UpStage& st, View x, View out, const int* lens, int len_mul, int Lmax, bool tail, bool up) {
+void Engine::mrf(const UpStage& st, View x, View out, const int* lens, int len_mul, int Lmax, bool tail) {
   const int CP = st.mrf_cp, HU = CP == 32 ? 1 : 2;
   const int hx = st.mrf_hx, hxa = rup(hx, 16);
   MrfGeo best;
@@ -1347,11 +1265,6 @@ void Engine::mrf(const UpStage& st, View x, View out, const int* lens, int len_m
     p.stride = best.N - (POST_K - 1); p.n0off = (POST_K - 1) / 2;
     p.post_w = post_w_; p.audio = audio_; p.a_bs = Ss_; p.absmax = absmax_;
   }
-  if (up) {        // the stage's up-conv inside the kernel: `x` is the previous stage's output
-    if (!upf_plan(st, len_mul, Lmax, tail, &p)) throw std::runtime_error("internal: fused up-conv does not fit");
-    p.up_x = x.p; p.up_x_bs = x.bs; p.up_x_cs = x.cs; p.up_lmul = len_mul / st.rate;
-    p.x = nullptr; p.x_bs = 0; p.x_cs = 0;
-  }
   double kflops = 0, kbytes = 0;
   if (prof_level_ >= 2) {
     double cols = 0;
@@ -1365,14 +1278,10 @@ void Engine::mrf(const UpStage& st, View x, View out, const int* lens, int len_m
       kflops += 2.0 * cols * st.ch * POST_K;
       kbytes = 4.0 * (st.ch + 1) * cols + 4.0 * st.mrf_wfloats;   // one read of x, one write of the waveform
     }
-    if (up) {      // + the up-conv's work; x is its (shorter, wider) input instead of its output
-      kflops += 2.0 * st.up.macs_per_col * cols / st.rate;
-      kbytes += 4.0 * (2.0 * CP / st.rate - st.ch) * cols + 4.0 * st.up16_floats;
-    }
   }
   dim3 grid((Lmax + p.stride - 1) / p.stride, B_);
   char nm[64];
-  snprintf(nm, sizeof(nm), "mrf_kernel<%d,%d,%d,%s>", CP, best.ou, HU, up ? "true" : "false");
+  snprintf(nm, sizeof(nm), "mrf_kernel<%d,%d,%d>", CP, best.ou, HU);
   const int kh = prof_level_ >= 2 ? kbegin(krow(std::string(nm)), kflops, kbytes) : -1;
   launch::mrf(CP, best.ou, grid, ls_, p);
   kend(kh);
@@ -1743,6 +1652,27 @@ void Engine::issue_stage_a() {
       conv(e.qkv, x, qkv, d_tlens_, 1, T, EPI_STORE);
     pg = pb = nullptr;
     pend_bias = nullptr;
+    // Small calls of the 192-channel voices: attention + conv_o + residual + norm_layers_1 as ONE launch (kernels/attno.h:
+    // 16 queries of both heads per workgroup)
+    const int ao_sp = rup(T, 64) + 2;
+    const size_t ao_smem = ((size_t)2 * 16 * ao_sp + 2 * 64 * (dk_ + 1) + 2 * dk_ * 16 + (size_t)2 * (2 * window_ + 1) * dk_ + 8 * 256 + 256) * sizeof(float);
+    const bool attno = attno_ && chain_q && use_col4((long)B * T) && H_ == 192 && nh_ == 2 && dk_ == 96 && window_ <= 4 && e.o16 &&
+                       ao_smem <= (size_t)160 * 1024;
+    if (attno) {
+      AttnOP ap{};
+      ap.qkv = qkv_; ap.q_bs = (long)3 * H_ * Ts; ap.q_cs = Ts;
+      ap.relk = e.relk; ap.relv = e.relv;
+      ap.lens = d_tlens_; ap.window = window_; ap.SP = ao_sp;
+      ap.qscale = 1.0f / std::sqrt((float)dk_);
+      ap.wo16 = e.o16; ap.bo = e.o.bias; ap.gamma = e.g1; ap.beta = e.b1;
+      ap.x = x.p; ap.x_bs = x.bs; ap.x_cs = x.cs;
+      double afl = 0;
+      for (int b = 0; b < B; ++b) afl += 4.0 * (double)tlens_h_[b] * tlens_h_[b] * H_;
+      const int kh = kbegin(prof_level_ >= 2 ? krow("attno_kernel<96>") : 0, afl + 2.0 * tsum * e.o.macs_per_col,
+                            4.0 * (tsum * 5.0 * H_ + e.o.macs_per_col));
+      launch::attno(dim3((T + 15) / 16, B), ao_smem, stream_, ap);
+      kend(kh);
+    } else {
     AttnP ap;
     ap.qkv = qkv_; ap.q_bs = (long)3 * H_ * Ts; ap.q_cs = Ts;
     ap.relk = e.relk; ap.relv = e.relv;
@@ -1776,6 +1706,7 @@ void Engine::issue_stage_a() {
       conv(e.o, att, y, d_tlens_, 1, T, EPI_RESADD, 1.f, ACT_NONE, x);
     }
     if (!chain_o) layer_norm(y, x, e.g1, e.b1, H_, d_tlens_, T);
+    }      // !attno
     if (ffn_fused) {
       FfnP fp{};
       const int Tp = rup(T, 4);
@@ -2022,14 +1953,13 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
                         (mrf_mode_ == 2 || !st.mrf_rb1 || (st.mrf_cp == 32 && fsum <= (double)mrf_rb1_max_frames_));
       // the last stage also runs the generator tail (conv_post, tanh, peak) on its MRF mean while it is still on chip
       const bool tail = fuse && mrf_tail_ && &st == &ups_.back() && st.mrf_cp == 32 && st.ch == post_cin_ && mult == hop_;
-      // small calls: the stage kernel computes the up-conv of its own window too (mrf.h UPF) -- no launch, no u tensor
-      const bool upfuse = fuse && upf_plan(st, mult, Lmax, tail, nullptr);
       // leaky_relu(0.1) -> ConvTranspose1d
-      if (!upfuse) conv(st.up, cur, u, lens, Lin, Fmax * Lin, EPI_CONVT, 0.1f);
+      // (folding the up-conv into the stage kernel's prologue was built and measured: the window GEMM with its halo
+      // recompute on the 209 workgroups of a single round costs what the launch costs -- profiles/r04_notes.md)
+      conv(st.up, cur, u, lens, Lin, Fmax * Lin, EPI_CONVT, 0.1f);
       fl += 2.0 * fsum * Lin * st.up.macs_per_col;
-      // xs accumulates into the buffer that held the stage input (free once the up-conv is done); with the fused up-conv
-      // the stage kernel reads that buffer itself, so the MRF mean goes where u would have been
-      const View xs{hb_[upfuse ? ids[0] : cur_buf], (long)st.ch * Ls, (int)Ls};
+      // xs accumulates into the buffer that held the stage input (free once the up-conv is done)
+      const View xs{hb_[cur_buf], (long)st.ch * Ls, (int)Ls};
       // One resblock chain, accumulated into xs with the MRF mode. `t` = {c1 output, ping, pong}.
       auto chain = [&](int j, const View (&t)[3], View dst, int accmode) {
         auto& cv = st.rb[j];
@@ -2074,7 +2004,7 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
         for (auto& c : cv) grp = grp && can_group(c, Lmax);
       }
       if (fuse) {
-        mrf(st, upfuse ? cur : u, xs, lens, mult, Lmax, tail, upfuse);
+        mrf(st, u, xs, lens, mult, Lmax, tail);
         for (auto& cv : st.rb)
           for (auto& c : cv) fl += 2.0 * fsum * mult * c.macs_per_col;
         if (tail) {
@@ -2121,8 +2051,7 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
           chain(j, t, xs, accmode);
         }
       }
-      cur = xs;      // new shape; the buffer that held the stage input, or (fused up-conv) the one u would have used
-      if (upfuse) cur_buf = ids[0];
+      cur = xs;      // same buffer index cur_buf, new shape
     }
     prof_end(3, fl);
 

@@ -185,6 +185,7 @@ class Engine {
   float* ffn_parts_ = nullptr;
   static constexpr long ffn_max_cols_ = 2048;
   int ffn_ = 1;                             // PIPER_HIP_FFN=0: conv by conv (A/B, tests)
+  bool attno_ = true;                       // PIPER_HIP_ATTNO=0: attention and conv_o + LN as two launches (A/B, tests)
   bool stage_a_ffn_fused() const;
   float* stage_a_enc_out() const;
   const float* w4_of(const float* w16) const { auto it = w4_of_.find(w16); return it == w4_of_.end() ? nullptr : it->second; }
@@ -303,21 +304,11 @@ class Engine {
     int mrf_wfloats = 0, mrf_cp = 0, mrf_hx = 0;  // padded channels (32 / 64), halo of the stage (widest resblock chain)
     std::vector<struct MrfPhase> mrf_ph;          // host copy of the phases (cost model of the geometry choice)
     bool mrf_ok = false, mrf_rb1 = false;
-    float* up16 = nullptr; int up16_floats = 0;   // the stage's ConvTranspose1d in the fused up-conv's fragment order (pack_up16; null: not fusable)
   };
   struct MrfGeo { int ou = 0, N = 0, cu_lo = 0, cu_hi = 0, nleft = 0, nhalo = 0; };
   bool mrf_geo(const UpStage& st, int len_mul, bool tail, MrfGeo& best) const;      // window geometry by the cost model
   void build_mrf(UpStage& st);
-  void pack_up16(const WeightSet& ws, const std::string& prefix, UpStage& st);
-  // `xin` (with `up` set): the previous stage's output -- the kernel computes the stage's up-conv itself (mrf.h UPF)
-  void mrf(const UpStage& st, View x, View out, const int* lens, int len_mul, int Lmax, bool tail = false, bool up = false);
-  // Fused up-conv policy (PIPER_HIP_UPF: 0 off, 1 calls of up to upf_max_batch_ utterances, 2 wherever it applies): the
-  // workgroups keep the raw stage input of their windows in a scratch buffer ([utterance][workgroup][CP][row stride],
-  // grown on demand up to upf_scratch_cap_ bytes; beyond: the separate up-conv launch)
-  int upf_ = 1, upf_max_batch_ = 4;
-  float* upf_scratch_ = nullptr; size_t upf_scratch_bytes_ = 0;
-  static constexpr size_t upf_scratch_cap_ = (size_t)512 << 20;
-  bool upf_plan(const UpStage& st, int len_mul, int Lmax, bool tail, struct MrfP* out_geo);
+  void mrf(const UpStage& st, View x, View out, const int* lens, int len_mul, int Lmax, bool tail = false);
   int mrf_mode_ = 1;                        // PIPER_HIP_MRF: 0 off (conv by conv), 1 by the measured policy, 2 wherever it applies
   long mrf_rb1_max_frames_ = 1100;          // ResBlock1 stages: batch frames up to which the fused kernel is used in mode 1
   bool mrf_tail_ = true;                    // PIPER_HIP_MRF_TAIL=0: conv_post_kernel as its own launch behind a fused last stage

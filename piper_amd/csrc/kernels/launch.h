@@ -30,6 +30,7 @@ void init_front();
 void embed(dim3 grid, hipStream_t stream, const int* ids, int ids_bs, const int* lens, const float* emb, int H, float scale,
            float* out, long o_bs, int o_cs, unsigned long long* rng);
 void attention(int dk, dim3 grid, size_t smem, hipStream_t stream, const AttnP& p);
+void attno(dim3 grid, size_t smem, hipStream_t stream, const AttnOP& p);        // attention + conv_o + LN, dk = 96 x 2 heads (attno.h)
 void layer_norm(dim3 grid, hipStream_t stream, const LnP& p);
 void dds_layer(int nchunks, dim3 grid, size_t smem, hipStream_t stream, const DdsP& p);
 void dds_layer4(dim3 grid, size_t smem, hipStream_t stream, const DdsP& p);      // 4-column form, 192 channels (dds4.h)

@@ -2,6 +2,7 @@
 #include "launch.h"
 
 #include "attention.h"
+#include "attno.h"
 #include "colchain.h"
 #include "dds.h"
 #include "dds4.h"
@@ -17,7 +18,8 @@ namespace launch {
 void init_front() {
 #ifndef PE_EMU
   const int lim = 160 * 1024;
-  const void* ks[] = {(const void*)attn_kernel<0>, (const void*)attn_kernel<48>, (const void*)attn_kernel<96>};
+  const void* ks[] = {(const void*)attn_kernel<0>, (const void*)attn_kernel<48>, (const void*)attn_kernel<96>,
+                      (const void*)attno_kernel<96>};
   for (const void* k : ks) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
 #endif
 }
@@ -32,6 +34,10 @@ void attention(int dk, dim3 grid, size_t smem, hipStream_t stream, const AttnP& 
   if (dk == 96) PE_LAUNCH(attn_kernel<96>, grid, dim3(256), smem, stream, p);
   else if (dk == 48) PE_LAUNCH(attn_kernel<48>, grid, dim3(256), smem, stream, p);
   else PE_LAUNCH(attn_kernel<0>, grid, dim3(256), smem, stream, p);
+}
+
+void attno(dim3 grid, size_t smem, hipStream_t stream, const AttnOP& p) {
+  PE_LAUNCH(attno_kernel<96>, grid, dim3(512), smem, stream, p);
 }
 
 void layer_norm(dim3 grid, hipStream_t stream, const LnP& p) { PE_LAUNCH(ln_kernel, grid, dim3(256), 0, stream, p); }

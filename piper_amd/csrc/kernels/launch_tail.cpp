@@ -10,24 +10,17 @@ namespace launch {
 void init_tail() {
 #ifndef PE_EMU
   const int lim = 160 * 1024;
-#define PE_MRF2(CP_, OU_, HU_) (const void*)mrf_kernel<CP_, OU_, HU_, false>, (const void*)mrf_kernel<CP_, OU_, HU_, true>
-  const void* ks[] = {PE_MRF2(32, 1, 1), PE_MRF2(32, 2, 1), PE_MRF2(32, 3, 1), PE_MRF2(32, 4, 1),
-                      PE_MRF2(64, 1, 2), PE_MRF2(64, 2, 2), PE_MRF2(64, 3, 2)};
-#undef PE_MRF2
+  const void* ks[] = {(const void*)mrf_kernel<32, 1, 1>, (const void*)mrf_kernel<32, 2, 1>, (const void*)mrf_kernel<32, 3, 1>, (const void*)mrf_kernel<32, 4, 1>,
+                      (const void*)mrf_kernel<64, 1, 2>, (const void*)mrf_kernel<64, 2, 2>, (const void*)mrf_kernel<64, 3, 2>};
   for (const void* k : ks) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
 #endif
 }
 
 // cp = padded channels (32: one row group of 8 column groups, 1 halo unit per wave; 64: two row groups of 4 column
-// groups, 2 halo units per wave); ou = output units per wave (N = 16 * column groups * ou); p.up_w != null: the form
-// that computes the stage's up-conv itself (mrf.h UPF)
+// groups, 2 halo units per wave); ou = output units per wave (N = 16 * column groups * ou)
 void mrf(int cp, int ou, dim3 grid, hipStream_t stream, const MrfP& p) {
   const size_t smem = mrf_smem_bytes(cp, ou);
-#define PE_MRF(CP_, OU_, HU_)                                                                                  \
-  do {                                                                                                        \
-    if (p.up_w) PE_LAUNCH((mrf_kernel<CP_, OU_, HU_, true>), grid, dim3(64 * MRF_NW), smem, stream, p);       \
-    else PE_LAUNCH((mrf_kernel<CP_, OU_, HU_, false>), grid, dim3(64 * MRF_NW), smem, stream, p);             \
-  } while (0)
+#define PE_MRF(CP_, OU_, HU_) PE_LAUNCH((mrf_kernel<CP_, OU_, HU_>), grid, dim3(64 * MRF_NW), smem, stream, p)
   if (cp == 32) {
     if (ou == 1) PE_MRF(32, 1, 1); else if (ou == 2) PE_MRF(32, 2, 1); else if (ou == 3) PE_MRF(32, 3, 1); else PE_MRF(32, 4, 1);
   } else {

@@ -64,14 +64,7 @@ __device__ __forceinline__ void mrf_interleave() {
 }
 
 
-// UPF: the stage's ConvTranspose1d is computed by the workgroup for its own window (MrfP: up_*) instead of being a launch
-// of its own in front of this one. The window of u is a small GEMM: rows (co, phase) x 16-position tiles over K = 2 taps x
-// 2 CP input channels; a wave owns row tiles (its A fragments stay in registers), walks the position tiles two at a
-// time (independent accumulators) with the B operand read from the activated input window in LDS (buffer 1, free until
-// the first phase writes it), and stores lrelu(u) into buffer 0 -- where stage_x would have put it -- and raw u into the
-// workgroup's scratch slice. Same k order as the conv kernels' polyphase form (chunk-major, tap-minor, ascending
-// channel): bit-identical to the separate launch.
-template <int CP, int OU, int HU, bool UPF>
+template <int CP, int OU, int HU>
 __global__ __launch_bounds__(64 * MRF_NW) void mrf_kernel(MrfP p) {
   PE_KTRACE(20);
   constexpr int NW = MRF_NW, WS = mrf_ws(CP, OU), MS = CP / 16, MSW = 2, NRG = MS / MSW, NCG = NW / NRG, NT = 64 * NW;
@@ -161,94 +154,7 @@ __global__ __launch_bounds__(64 * MRF_NW) void mrf_kernel(MrfP p) {
     }
   }
   const pe_rowsrc xd = pe_make_row(xb, C * p.x_cs);
-  float* scr = nullptr;                               // UPF: raw u of this workgroup's window, [CP][WS]
-  if constexpr (UPF) {
-    scr = p.up_scratch + ((long)b * p.up_sc_bs + (long)blockIdx.x * bufsz);
-    constexpr int CIN = 2 * CP, NCHI = CIN / KC, NST = NCHI * 2;     // input channels, their 32-chunks, (chunk, tap) steps
-    constexpr int RPW = CIN / NW, NCC = CP == 32 ? 3 : 2;            // staging: rows per wave, 64-column groups per row (XS <= 64 NCC)
-    const int S = p.up_stride, sh = p.up_shift, pad = p.up_pad, XS = p.up_xs, njt = p.up_njt;
-    const int j0 = (g0 + pad) >> sh;                   // position of window column 0 (arithmetic shift = floor for g0 < 0)
-    float* xin = bufs + bufsz;                         // buffer 1: [CIN][XS] = lrelu(xin[ci][j0 - 1 + c])
-    {
-      const float* uxb = p.up_x + (long)b * p.up_x_bs;
-      const int Lin = p.lens[b] * p.up_lmul;
-      float v[RPW][NCC];
-#pragma unroll
-      for (int i = 0; i < RPW; ++i) {
-        const int row = wv + NW * i;
-        const pe_rowsrc rd = pe_make_row(uxb + (long)row * p.up_x_cs, Lin);
-#pragma unroll
-        for (int j = 0; j < NCC; ++j) v[i][j] = pe_row_load(rd, (lane + 64 * j < XS) ? j0 - 1 + lane + 64 * j : -1);
-      }
-#pragma unroll
-      for (int i = 0; i < RPW; ++i)
-#pragma unroll
-        for (int j = 0; j < NCC; ++j)
-          if (lane + 64 * j < XS) xin[(wv + NW * i) * XS + lane + 64 * j] = pe_lrelu(v[i][j], p.up_slope);
-    }
-    // window columns behind the last position tile (never read by a needed output; stage_x leaves zeros there)
-    const int cend = j0 * S - pad - g0 + njt * 16 * S;
-    if (cend < WS) {
-      const int nz = WS - cend;
-      for (int i = tid; i < CP * nz; i += NT) bufs[(i / nz) * WS + cend + i % nz] = 0.f;
-    }
-    __syncthreads();
-    const pe_rowsrc uwd = pe_make_row(p.up_w, p.up_wfloats);
-    const pe_rowsrc ubd = pe_make_row(p.up_bias, C);
-    const int nrt = (CP << sh) / 16;                   // 16-row tiles of the polyphase GEMM
-    for (int mt = wv; mt < nrt; mt += NW) {
-      f32x4 a[NST][2];
-#pragma unroll
-      for (int st = 0; st < NST; ++st)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) a[st][q] = pe_row_load4_so(uwd, lane * 4 + q * 256, PE_UNIFORM((mt * NST + st) * 512));
-      // rows 4 lq + r of the tile: one output channel, four consecutive phases (stride is a multiple of 4) -- or, for
-      // stride 2, two channels x two phases
-      int co[4], phs[4];
-      float bz4[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = mt * 16 + 4 * lq + r;
-        co[r] = row >> sh;
-        phs[r] = (row & (S - 1)) - pad;
-        bz4[r] = pe_row_load(ubd, co[r]);
-      }
-      for (int jt = 0; jt < njt; jt += 2) {
-        f32x4 acc0, acc1;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
-#pragma unroll
-        for (int st = 0; st < NST; ++st) {
-          const float* bp = xin + ((st >> 1) * KC + lq) * XS + jt * 16 + l15 + (st & 1);
-          float b0[8], b1[8];
-#pragma unroll
-          for (int s8 = 0; s8 < 8; ++s8) { b0[s8] = bp[4 * s8 * XS]; b1[s8] = bp[4 * s8 * XS + 16]; }
-#pragma unroll
-          for (int s8 = 0; s8 < 8; ++s8) {
-            acc0 = pe_mfma_16x16x4(a[st][s8 >> 2][s8 & 3], b0[s8], acc0);
-            acc1 = pe_mfma_16x16x4(a[st][s8 >> 2][s8 & 3], b1[s8], acc1);
-          }
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          if (h == 1 && jt + 1 >= njt) break;
-          const f32x4& acc = h ? acc1 : acc0;
-          const int tb = (j0 + (jt + h) * 16 + l15) * S;           // first output sample of this lane's position (+ phase - pad)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int t = tb + phs[r], c = t - g0;
-            if (c >= 0 && c < WS && co[r] < CP) {
-              const float raw = (t >= 0 && t < L && co[r] < C) ? acc[r] + bz4[r] : 0.f;
-              bufs[co[r] * WS + c] = pe_lrelu(raw, slope);
-              scr[co[r] * WS + c] = raw;
-            }
-          }
-        }
-      }
-    }
-  } else {
-    stage_x();
-  }
+  stage_x();
 
   for (int ph = 0; ph < p.nphases; ++ph) {
     __syncthreads();            // table + window (first phase) / the previous phase's activations are in LDS
@@ -261,29 +167,12 @@ __global__ __launch_bounds__(64 * MRF_NW) void mrf_kernel(MrfP p) {
       P.src = PE_UNIFORM(t[5]); P.dst = PE_UNIFORM(t[6]); P.flags = PE_UNIFORM(t[7]);
     }
     if (P.flags & MRF_RESTAGE) {       // ResBlock1 rewrites buffer 0 in place: a new chain starts from the stage input
-      if constexpr (UPF) {
-        for (int i = tid; i < bufsz; i += NT) bufs[i] = pe_lrelu(scr[i], slope);      // (this workgroup's own stores: visible)
-      } else {
-        stage_x();
-      }
+      stage_x();
       __syncthreads();
     }
     if (P.flags & MRF_INIT) {          // running x of the chain <- raw stage input of the owned units (L2-hot; used in the
                                         // epilogue, so the loads fly under the K loop). One lane offset per unit + an SGPR
                                         // row offset: no per-element address registers (rows >= C: beyond the descriptor)
-      if constexpr (UPF) {
-        // (raw u of the window: written by this workgroup's waves before the barrier above, zero outside [0, L))
-        const pe_rowsrc sd = pe_make_row(scr, bufsz);
-#pragma unroll
-        for (int u = 0; u < UPW; ++u) {
-          int voff = cu[u] >= 0 ? 4 * lq * WS + 16 * cu[u] + l15 : 0x3fffffff;
-          PE_OPAQUE(voff);
-#pragma unroll
-          for (int m = 0; m < MSW; ++m)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) rawc[m][u][r] = pe_row_load_so(sd, voff, ((ms0 + m) * 16 + r) * WS);
-        }
-      } else {
 #pragma unroll
       for (int u = 0; u < UPW; ++u) {
         const int g = g0 + 16 * cu[u] + l15;
@@ -293,7 +182,6 @@ __global__ __launch_bounds__(64 * MRF_NW) void mrf_kernel(MrfP p) {
         for (int m = 0; m < MSW; ++m)
 #pragma unroll
           for (int r = 0; r < 4; ++r) rawc[m][u][r] = pe_row_load_so(xd, voff, ((ms0 + m) * 16 + r) * p.x_cs);
-      }
       }
     }
     const pe_rowsrc bd = pe_make_row(P.bias, P.bias ? C : 0);

@@ -59,6 +59,18 @@ struct AttnP {
   int SP;                                   // score row stride in LDS: odd, >= round_up(max len, 64)
   float qscale;
 };
+// attno_kernel (attno.h): attention + conv_o + residual + norm_layers_1 of an encoder layer in one launch
+struct AttnOP {
+  const float* qkv; long q_bs; int q_cs;
+  const float* relk; const float* relv;     // [2w+1][dk]
+  const int* lens;
+  int window;
+  int SP;                                   // score row stride in LDS: round_up(max len, 64) + 2 (== 2 mod 32)
+  float qscale;
+  const float* wo16; const float* bo;       // conv_o in pack16 order, bias [H]
+  const float* gamma; const float* beta;    // norm_layers_1
+  float* x; long x_bs; int x_cs;            // residual in, LayerNorm output (in place)
+};
 static constexpr int ATT_QB = 32;           // queries per workgroup (one MFMA tile)
 static constexpr int ATT_KCH = 64;          // keys staged per V chunk
 static constexpr int ATT_MAXDK = 128;
@@ -194,19 +206,6 @@ struct MrfP {
   // generator tail fused into the last stage (post_w != nullptr; out is not written): conv_post weights [C][7], waveform,
   // per-utterance peak (post.h: conv_post_kernel); stride = N - 6, n0off = 3
   const float* post_w; float* audio; long a_bs; unsigned* absmax; float post_slope;
-  // Fused up-conv (mrf_kernel<..., UPF = true>): the stage input u = ConvTranspose1d(lrelu(xin)) (models.py:353-355; k = 2 *
-  // stride, polyphase rows (co, phase) as in Engine::pack_convT) is computed per window by the workgroup itself instead of
-  // being read from `x`: one launch and one tensor round trip fewer per stage. `up_x` = the previous stage's output
-  // [2 CP][lens * up_lmul]; `up_w` = A fragments [16-row tile][chunk][tap][2][lane][4] (16x16x4 order, rows = co * stride +
-  // phase); raw u of the window goes to the workgroup's slice of `up_scratch` ([utterance][workgroup][CP][row stride]),
-  // from which the resblock chains take their raw stage input (registers cannot hold it, LDS holds the activated copy).
-  const float* up_x; long up_x_bs; int up_x_cs; int up_lmul;
-  const float* up_w; int up_wfloats; const float* up_bias;
-  int up_stride, up_shift, up_pad;     // stride = 1 << shift; pad = (k - stride) / 2
-  int up_njt;                          // 16-position tiles that cover the window: ceil((wcols + stride) / (16 stride))
-  int up_xs;                           // LDS row stride of the staged input window (== 16 mod 32, >= 16 * (njt + (njt & 1)) + 1)
-  float up_slope;
-  float* up_scratch; long up_sc_bs;    // floats per utterance = gridDim.x * CP * row stride
 };
 static constexpr int MRF_NW = 8, MRF_PAD = 128, MRF_MAXPH = 24;
 // row stride of the LDS window (== 16 mod 32). 32 channels with 4 output units per wave (N = 512, one utterance's last

@@ -353,7 +353,7 @@ def test_emulated_generator_tail_inside_the_last_stage_kernel(emu_lib, monkeypat
         eng.profile_enable(2)
         r = eng.synthesize_batch(ids, (0.5, 1.0, 0.8), noise_w=nw, noise_z=nz)
         names = {row["name"] for row in eng.profile()}
-        assert any(n.startswith(f"mrf_kernel<32,{ou},1,") for n in names) and ("conv_post_kernel" in names) == (tail == "0"), names
+        assert f"mrf_kernel<32,{ou},1>" in names and ("conv_post_kernel" in names) == (tail == "0"), names
         res[(tail, ou)] = r
         eng.close()
     ref = res[("0", "2")]
@@ -382,7 +382,9 @@ def test_emulated_192_channel_small_call_kernels(emu_lib, monkeypatch, col4):
     eng.profile_enable(2)
     r = eng.synthesize_batch(ids, (0.0, 1.0, 0.8), noise_w=nw)
     names = {row["name"] for row in eng.profile()[5:] if row["launches"]}
-    assert "attn_kernel<96>" in names
+    # small calls: attention + conv_o + norm_layers_1 as one launch (attno_kernel); the 16-column forms keep two
+    assert ("attno_kernel<96>" if col4 == "1" else "attn_kernel<96>") in names
+    assert ("attn_kernel<96>" if col4 == "1" else "attno_kernel<96>") not in names
     assert ({"colchain4_kernel", "lngemm4_kernel", "dds_layer4_kernel", "ffn_kernel"} if col4 == "1" else
             {"colchain_kernel<6>", "lngemm_kernel<6>", "dds_layer16_kernel<6>"}) <= names
     assert not ({"colchain_kernel<6>", "lngemm_kernel<6>", "dds_layer16_kernel<6>"} if col4 == "1" else
@@ -460,33 +462,33 @@ def test_warmup_presizes_and_leaves_results_unchanged(emu_lib):
     cold.close()
 
 
-@pytest.mark.parametrize("preset,over,lens,ou", [("tiny", {}, [7, 3, 1], 1), ("tiny", {"up_initial": 256}, [4], 2),
-                                                 ("tiny", {"up_initial": 256}, [3, 2], 3), ("tiny-high", {}, [5], 2),
-                                                 ("tiny", {}, [9], 4)])
-def test_emulated_fused_upconv_is_bit_identical(emu_lib, monkeypatch, preset, over, lens, ou):
-    """mrf_kernel<..., UPF = true>: the stage kernel computes the ConvTranspose1d of its own window (polyphase GEMM on the
-    16x16x4 MFMA out of an activated input window in LDS, raw window to a scratch slice) instead of reading the output of
-    a separate up-conv launch. Against that launch through the TILED conv kernel (same k order: chunk-major, tap-minor,
-    ascending channel) the waveform must be bit-identical -- for strides 8 and 4, 32 and 64 padded channels, every window
-    width, the fused generator tail, ResBlock1 re-staging from the scratch, ragged batches with one-frame utterances."""
-    monkeypatch.setenv("PIPER_HIP_SPLITK_MAX", "0")        # the unfused up-conv through conv_mfma_kernel, not split-K
-    monkeypatch.setenv("PIPER_HIP_MRF", "2")
-    monkeypatch.setenv("PIPER_HIP_MRF_OU", str(ou))
-    cfg = W.preset(preset, **over)
+@pytest.mark.parametrize("lens,sids", [([9, 31], None), ([1, 17, 130], None), ([70, 5], [2, 0])])
+def test_emulated_attention_conv_o_layernorm_in_one_launch(emu_lib, monkeypatch, lens, sids):
+    """attno_kernel (kernels/attno.h): an encoder layer's windowed relative-position attention, conv_o, the residual and
+    norm_layers_1 in ONE launch -- 16 queries of both heads per workgroup on the 16x16x4 MFMA -- against the two launches
+    it replaces (PIPER_HIP_ATTNO=0: attn_kernel + colchain4_kernel) and the oracle: the encoder output, the integer
+    durations, the waveform. Lengths on both softmax paths (<= 128 keys in registers, longer through LDS), a one-id
+    utterance, ragged batches, a multi-speaker voice."""
+    cfg = W.preset("tiny-ms" if sids else "tiny", hidden=192, inter=192, filter=96, n_layers=2)
     w = W.synthetic_weights(cfg, 1234)
     ids = [W.synthetic_phoneme_ids(T, i, id_max=cfg.n_vocab - 1) for i, T in enumerate(lens)]
-    nw, nz = _noise(cfg, len(lens), max(lens), 77)
+    nw = np.random.default_rng(5).standard_normal((len(lens), 2, max(lens))).astype(np.float32)
     res = {}
-    for upf in ("0", "2"):
-        monkeypatch.setenv("PIPER_HIP_UPF", upf)
+    for on in ("0", "1"):
+        monkeypatch.setenv("PIPER_HIP_ATTNO", on)
         eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
         eng.profile_enable(2)
-        res[upf] = eng.synthesize_batch(ids, (0.5, 1.0, 0.8), noise_w=nw, noise_z=nz)
+        r = eng.synthesize_batch(ids, (0.0, 1.0, 0.8), noise_w=nw, sids=sids)
         names = {row["name"] for row in eng.profile()[5:] if row["launches"]}
-        assert any(n.startswith("mrf_kernel<") and n.endswith(",true>") for n in names) == (upf == "2"), names
+        assert ("attno_kernel<96>" in names) == (on == "1") and ("attn_kernel<96>" in names) == (on == "0"), names
+        res[on] = (r, eng.durations(), [eng.debug_tensor("x_enc", i) for i in range(len(lens))])
         eng.close()
-    for i in range(len(lens)):
-        assert np.array_equal(res["0"].audio[i], res["2"].audio[i]), i
-        assert np.array_equal(res["0"].pcm[i], res["2"].pcm[i]), i
-    o = O.synthesize(w, cfg, ids[0], (0.5, 1.0, 0.8), nw[0][:, :lens[0]], nz[0])
-    assert np.max(np.abs(res["2"].audio[0] - o["audio"])) < 1e-4
+    off = np.concatenate([[0], np.cumsum(lens)])
+    for i, T in enumerate(lens):
+        o = O.synthesize(w, cfg, ids[i], (0.0, 1.0, 0.8), nw[i], sid=None if sids is None else sids[i], keep=True)
+        for on in ("0", "1"):
+            r, durs, xenc = res[on]
+            assert np.array_equal(durs[off[i]:off[i + 1]], o["durations"]), (on, i)
+            assert np.max(np.abs(xenc[i] - np.asarray(o["x_enc"]).reshape(xenc[i].shape))) < 1e-5, (on, i)
+            assert np.max(np.abs(r.audio[i] - o["audio"])) < 1e-5, (on, i)
+        assert np.max(np.abs(res["0"][2][i] - res["1"][2][i])) < 1e-5

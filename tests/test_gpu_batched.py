@@ -45,7 +45,7 @@ def make_engine(monkeypatch, cfg, w, env=None):
               "PIPER_HIP_WIDE_SPLITK", "PIPER_HIP_DEBUG_KEEP", "PIPER_HIP_MRF", "PIPER_HIP_FUSE_DP",
               "PIPER_HIP_MRF_MAXF", "PIPER_HIP_SPEC", "PIPER_HIP_COLCHAIN", "PIPER_HIP_GROUP_MRF", 
               "PIPER_HIP_MRF_OU", "PIPER_HIP_MATRIX", "PIPER_HIP_BF3_MINF", "PIPER_HIP_MRF_TAIL", "PIPER_HIP_COL4",
-              "PIPER_HIP_COL4_MAXC", "PIPER_HIP_FFN", "PIPER_HIP_XCD", "PIPER_HIP_GRAPHS", "PIPER_HIP_UPF"):
+              "PIPER_HIP_COL4_MAXC", "PIPER_HIP_FFN", "PIPER_HIP_XCD", "PIPER_HIP_GRAPHS", "PIPER_HIP_ATTNO"):
         monkeypatch.delenv(k, raising=False)
     for k, v in (env or {}).items():
         monkeypatch.setenv(k, str(v))
@@ -216,12 +216,11 @@ FORCED = [
     # calls), and conv by conv behind the 4-column chains
     ("medium", [128, 13, 14, 15, 29], {}, {"ffn_kernel", "lngemm4_kernel"}),
     ("medium", [128, 31], {"PIPER_HIP_FFN": 0}, {"lngemm4_kernel", "conv_splitk16_kernel<false,8,4>"}),
-    # the stage kernels with the up-conv of their own window inside (default for calls of <= 4 utterances), forced on for
-    # a batch (the 3-units-per-wave geometries), and off (the up-convs as launches of the tiled kernel)
-    ("medium", [128], {}, {"mrf_kernel<64,2,2,true>", "mrf_kernel<32,4,1,true>"}),
-    ("medium", [128, 77, 16, 33, 3, 1, 128, 90, 128, 128, 60, 128], {"PIPER_HIP_UPF": 2}, {"mrf_kernel<64,3,2,true>", "mrf_kernel<32,3,1,true>"}),
-    ("medium", [128, 40], {"PIPER_HIP_UPF": 0}, {"mrf_kernel<64,2,2,false>", "conv_mfma_kernel<2,2,1,1,16,false,64>"}),
-    ("high", [48], {"PIPER_HIP_UPF": 2, "PIPER_HIP_MRF": 2}, set()),
+    # attention + conv_o + norm_layers_1 as one launch (default for small calls): on for a ragged batch incl. lengths on
+    # both softmax paths, and off (attn_kernel + colchain4_kernel)
+    ("medium", [128, 13, 1, 129, 77, 200], {}, {"attno_kernel<96>", "lngemm4_kernel", "ffn_kernel"}),
+    ("high", [96, 40], {}, {"attno_kernel<96>"}),
+    ("medium", [128, 31], {"PIPER_HIP_ATTNO": 0}, {"attn_kernel<96>", "colchain4_kernel"}),
     # tiles of the 4-column kernels in workgroup order (no XCD-contiguous runs)
     ("medium", [128, 31], {"PIPER_HIP_XCD": 0}, {"colchain4_kernel", "lngemm4_kernel", "dds_layer4_kernel"}),
 ]
@@ -643,26 +642,3 @@ def test_graph_cache_is_lru_and_warmup_stops_captures(monkeypatch):
     assert c1 - c0 <= len(texts)                        # at most one frame bucket the warm-up did not meet, per text
     print("graph captures: warm-up", c0, "first pass", c1 - c0, "second pass 0; cached", eng.graph_stats[0])
     eng.close()
-
-
-@pytest.mark.parametrize("preset,lens,ou", [("medium", [128], 0), ("medium", [128, 45, 3], 2), ("medium", [60] * 5, 3),
-                                            ("x-low", [128, 64], 0), ("medium", [200], 4)])
-def test_fused_upconv_is_bit_identical_to_the_separate_launch(monkeypatch, preset, lens, ou):
-    """mrf_kernel<..., UPF = true> on the hardware: the stage kernel computing the ConvTranspose1d of its own window against
-    the same kernel behind a separate up-conv launch of the TILED conv kernel (PIPER_HIP_SPLITK_MAX=0: same k order) --
-    float waveform and int16 PCM bit for bit; and against the oracle (run_and_check)."""
-    cfg, w = voice(preset)
-    ids, nw, nz = batch_inputs(cfg, lens, seed=91)
-    res = {}
-    for upf in (2, 0):
-        env = {"PIPER_HIP_MRF": 2, "PIPER_HIP_UPF": upf, "PIPER_HIP_SPLITK_MAX": 0}
-        if ou:
-            env["PIPER_HIP_MRF_OU"] = ou
-        eng = make_engine(monkeypatch, cfg, w, env)
-        names, worst = run_and_check(eng, cfg, w, ids, nw, nz, sample=[0, len(lens) - 1])
-        assert any(n.startswith("mrf_kernel<") and n.endswith(",true>") for n in names) == (upf == 2), names
-        res[upf] = eng.synthesize_batch(ids, SCALES, noise_w=nw, noise_z=nz)
-        eng.close()
-    for i in range(len(lens)):
-        assert np.array_equal(res[2].audio[i], res[0].audio[i]), f"utterance {i}: waveform differs"
-        assert np.array_equal(res[2].pcm[i], res[0].pcm[i]), f"utterance {i}: pcm differs"
