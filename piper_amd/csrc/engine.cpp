@@ -653,6 +653,7 @@ void Engine::init(const WeightSet& ws) {
   PE_HIP(hipEventCreate(&ev1_));
   PE_HIP(hipHostMalloc((void**)&h_frames_, 4096 * sizeof(int)));
   if (const char* ng = getenv("PIPER_HIP_NO_GRAPH")) use_graphs_ = !(ng[0] && ng[0] != '0');
+  if (const char* t = getenv("PIPER_HIP_WS_MEM")) ws_mem_ = std::min(2, std::max(0, atoi(t)));
   if (const char* t = getenv("PIPER_HIP_ATTNO")) attno_ = atoi(t) != 0;          // attention + conv_o + LN as one launch (small calls): 0 = two launches
   if (const char* t = getenv("PIPER_HIP_GRAPHS")) graph_cap_ = (size_t)std::min(4096, std::max(1, atoi(t)));
   if (const char* t = getenv("PIPER_HIP_TPB")) tpb_override_ = atoi(t);     // tuning / test knob
@@ -742,6 +743,17 @@ void Engine::probe_xcds() {
 // workspaces
 // ------------------------------------------------------------------------------------------------
 
+// Activation workspaces. PIPER_HIP_WS_MEM (experiment, profiles/r04_notes.md): 1 = uncached device memory, 2 = fine-grained
+// -- a dependent launch costs ~4 us in the pipeline against 1.6 us for an empty one, the difference being the L2 write-back
+// / invalidate between kernels whose data crosses XCDs; memory the L2s do not hold dirty has nothing to write back.
+hipError_t Engine::ws_malloc(void** p, size_t bytes) {
+#ifndef PE_EMU
+  if (ws_mem_ == 1) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocUncached);
+  if (ws_mem_ == 2) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained);
+#endif
+  return hipMalloc(p, bytes);
+}
+
 struct Carver {
   char* base;
   size_t off = 0;
@@ -758,7 +770,7 @@ void Engine::ensure_stage_a(int B, int Tmax) {
   if (!ffn_parts_ && H_ == 192 && FC_ % 48 == 0 && FC_ / 48 <= 16 && !enc_.empty() && enc_[0].f1p) {
     // partial outputs of the fused small-call FFN (kernels/ffn.h): [utterance][slice][192][columns], once
     PE_HIP(hipStreamSynchronize(stream_));
-    PE_HIP(hipMalloc((void**)&ffn_parts_, (size_t)(FC_ / 48) * H_ * ffn_max_cols_ * sizeof(float)));
+    PE_HIP(ws_malloc((void**)&ffn_parts_, (size_t)(FC_ / 48) * H_ * ffn_max_cols_ * sizeof(float)));
   }
   const int Ts = rup(Tmax, 128);    // row strides are multiples of 128 columns (conv epilogue relies on it)
   bool grow = false;
@@ -806,7 +818,7 @@ void Engine::ensure_stage_a(int B, int Tmax) {
     if (wsB_) { PE_HIP(hipFree(wsB_)); wsB_ = nullptr; }   // stage-B sizes depend on the batch capacity
     capB_F_ = 0;
     wsA_bytes_ = carve(nullptr);
-    PE_HIP(hipMalloc((void**)&wsA_, wsA_bytes_));
+    PE_HIP(ws_malloc((void**)&wsA_, wsA_bytes_));
     carve(wsA_);
     if (h_in_cap_ < in_bytes_) {
       if (h_in_) PE_HIP(hipHostFree(h_in_));
@@ -853,7 +865,7 @@ void Engine::ensure_stage_b(int Fmax) {
     drop_graphs();
     if (wsB_) PE_HIP(hipFree(wsB_));
     wsB_bytes_ = carve(nullptr);
-    PE_HIP(hipMalloc((void**)&wsB_, wsB_bytes_));
+    PE_HIP(ws_malloc((void**)&wsB_, wsB_bytes_));
   }
   carve(wsB_);
   // zero-copy PCM: room for every utterance of the batch capacity, up to 256 MiB of pinned memory (beyond: copies)
@@ -873,7 +885,7 @@ void Engine::ensure_stage_b(int Fmax) {
     drop_graphs();
     for (float*& sp : side_) { if (sp) PE_HIP(hipFree(sp)); sp = nullptr; }
     side_floats_ = want;
-    for (float*& sp : side_) PE_HIP(hipMalloc((void**)&sp, side_floats_ * sizeof(float)));
+    for (float*& sp : side_) PE_HIP(ws_malloc((void**)&sp, side_floats_ * sizeof(float)));
   }
 }
 

@@ -135,6 +135,8 @@ class Engine {
   PackedConv pack_matrix(const std::vector<float>& W, int rows, int Cin, int ntaps,
                          const std::vector<float>* bias, int nbias, int dil, int padl, bool gate, int split);
   DdsW load_dds(const WeightSet& ws, const std::string& prefix);
+  hipError_t ws_malloc(void** p, size_t bytes);
+  int ws_mem_ = 0;                          // PIPER_HIP_WS_MEM: 0 default device memory, 1 uncached, 2 fine-grained (experiment)
   void ensure_stage_a(int B, int Tmax);
   void ensure_stage_b(int Fmax);
 

@@ -408,7 +408,16 @@ struct Rccl {
   Destroy destroy = nullptr; ErrStr err = nullptr;
   bool ok = false;
   Rccl() {
-    void* h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+    // the RCCL that belongs to THIS library's HIP runtime: next to the libamdhip64 this library is linked against (a host
+    // process may carry another ROCm copy -- PyTorch bundles one -- whose RCCL cannot take this runtime's device pointers)
+    void* h = nullptr;
+    Dl_info di;
+    if (dladdr((void*)&hipGetDeviceCount, &di) && di.dli_fname) {
+      std::string dir(di.dli_fname);
+      const size_t slash = dir.rfind('/');
+      if (slash != std::string::npos) h = dlopen((dir.substr(0, slash) + "/librccl.so.1").c_str(), RTLD_NOW | RTLD_LOCAL);
+    }
+    if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
     if (!h) return;
     init_all = (InitAll)dlsym(h, "ncclCommInitAll");
