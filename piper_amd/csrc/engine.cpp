@@ -653,12 +653,9 @@ void Engine::init(const WeightSet& ws) {
   PE_HIP(hipEventCreate(&ev1_));
   PE_HIP(hipHostMalloc((void**)&h_frames_, 4096 * sizeof(int)));
   if (const char* ng = getenv("PIPER_HIP_NO_GRAPH")) use_graphs_ = !(ng[0] && ng[0] != '0');
-  if (const char* t = getenv("PIPER_HIP_WS_MEM")) ws_mem_ = std::min(2, std::max(0, atoi(t)));
   if (const char* t = getenv("PIPER_HIP_ATTNO")) attno_ = atoi(t) != 0;          // attention + conv_o + LN as one launch (small calls): 0 = two launches
   if (const char* t = getenv("PIPER_HIP_GRAPHS")) graph_cap_ = (size_t)std::min(4096, std::max(1, atoi(t)));
   if (const char* t = getenv("PIPER_HIP_TPB")) tpb_override_ = atoi(t);     // tuning / test knob
-  if (const char* t = getenv("PIPER_HIP_WIDE_MIN")) wide_min_blocks_ = atol(t);
-  if (const char* t = getenv("PIPER_HIP_SMALL")) small_tiles_ = atoi(t) != 0;
   if (const char* t = getenv("PIPER_HIP_GROUP_MRF")) group_mrf_ = atoi(t);
   if (const char* t = getenv("PIPER_HIP_PCM_ZC")) pcm_zc_ = atoi(t) != 0;
   if (const char* t = getenv("PIPER_HIP_SPLITK_MAX")) splitk_max_blocks_ = atol(t);   // tuning knob
@@ -743,34 +740,11 @@ void Engine::probe_xcds() {
 // workspaces
 // ------------------------------------------------------------------------------------------------
 
-// Activation workspaces. PIPER_HIP_WS_MEM (experiment, profiles/r04_notes.md): 1 = uncached device memory, 2 = fine-grained
-// -- a dependent launch costs ~4 us in the pipeline against 1.6 us for an empty one, the difference being the L2 write-back
-// / invalidate between kernels whose data crosses XCDs; memory the L2s do not hold dirty has nothing to write back.
-hipError_t Engine::ws_malloc(void** p, size_t bytes) {
-#ifndef PE_EMU
-  if (ws_mem_ == 1) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocUncached);
-  if (ws_mem_ == 2) return hipExtMallocWithFlags(p, bytes, hipDeviceMallocFinegrained);
-#endif
-  return hipMalloc(p, bytes);
-}
-
-struct Carver {
-  char* base;
-  size_t off = 0;
-  explicit Carver(char* b) : base(b) {}
-  template <class T> T* take(size_t n) {
-    off = (off + 255) / 256 * 256;
-    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
-    off += n * sizeof(T);
-    return p;
-  }
-};
-
 void Engine::ensure_stage_a(int B, int Tmax) {
   if (!ffn_parts_ && H_ == 192 && FC_ % 48 == 0 && FC_ / 48 <= 16 && !enc_.empty() && enc_[0].f1p) {
     // partial outputs of the fused small-call FFN (kernels/ffn.h): [utterance][slice][192][columns], once
     PE_HIP(hipStreamSynchronize(stream_));
-    PE_HIP(ws_malloc((void**)&ffn_parts_, (size_t)(FC_ / 48) * H_ * ffn_max_cols_ * sizeof(float)));
+    PE_HIP(hipMalloc((void**)&ffn_parts_, (size_t)(FC_ / 48) * H_ * ffn_max_cols_ * sizeof(float)));
   }
   const int Ts = rup(Tmax, 128);    // row strides are multiples of 128 columns (conv epilogue relies on it)
   bool grow = false;
@@ -818,7 +792,7 @@ void Engine::ensure_stage_a(int B, int Tmax) {
     if (wsB_) { PE_HIP(hipFree(wsB_)); wsB_ = nullptr; }   // stage-B sizes depend on the batch capacity
     capB_F_ = 0;
     wsA_bytes_ = carve(nullptr);
-    PE_HIP(ws_malloc((void**)&wsA_, wsA_bytes_));
+    PE_HIP(hipMalloc((void**)&wsA_, wsA_bytes_));
     carve(wsA_);
     if (h_in_cap_ < in_bytes_) {
       if (h_in_) PE_HIP(hipHostFree(h_in_));
@@ -865,7 +839,7 @@ void Engine::ensure_stage_b(int Fmax) {
     drop_graphs();
     if (wsB_) PE_HIP(hipFree(wsB_));
     wsB_bytes_ = carve(nullptr);
-    PE_HIP(ws_malloc((void**)&wsB_, wsB_bytes_));
+    PE_HIP(hipMalloc((void**)&wsB_, wsB_bytes_));
   }
   carve(wsB_);
   // zero-copy PCM: room for every utterance of the batch capacity, up to 256 MiB of pinned memory (beyond: copies)
@@ -885,7 +859,7 @@ void Engine::ensure_stage_b(int Fmax) {
     drop_graphs();
     for (float*& sp : side_) { if (sp) PE_HIP(hipFree(sp)); sp = nullptr; }
     side_floats_ = want;
-    for (float*& sp : side_) PE_HIP(ws_malloc((void**)&sp, side_floats_ * sizeof(float)));
+    for (float*& sp : side_) PE_HIP(hipMalloc((void**)&sp, side_floats_ * sizeof(float)));
   }
 }
 
@@ -1099,15 +1073,11 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     kend(kh);
     return;
   }
-  if (blocks < 192 || small_tiles_) {   // medium-small: smaller tiles, more workgroups
-    if (cfg == CFG_A) cfg = pc.gate ? CFG_G : CFG_S;
-    else if (cfg == CFG_B && !pc.gate) cfg = CFG_S;
-  } else if (!pc.gate && blocks >= wide_min_blocks_ && out.cs % 256 == 0) {
-    // plenty of columns (late generator stages): twice the columns per wave halves the weight-fragment
-    // loads and the per-workgroup prologue/epilogue overhead per MFMA
-    if (cfg == CFG_C) cfg = CFG_C2;
-    else if (cfg == CFG_B) cfg = CFG_B2;
-  }
+  // 32x32 wave tiles everywhere (64x64 / 32x128 workgroup tiles; the gate form pairs two row tiles per wave): measured in
+  // rounds 1-3 against 128x128, 64x128 and 256-column tiles at every batch size -- latency here is hidden across
+  // workgroups, occupancy beats register reuse (profiles/r01_ablation.txt, r02_notes.md); the larger instantiations are gone
+  if (cfg == CFG_A) cfg = pc.gate ? CFG_G : CFG_S;
+  else if (cfg == CFG_B && !pc.gate) cfg = CFG_S;
   const int BM = CFG_BM[cfg], BN = CFG_BN[cfg];
   const int ntile = (ncols + BN - 1) / BN, mblocks = pc.mtiles * 32 / BM;
   // Column tiles walked by one workgroup. Measured on MI355X (profiles/r01_tpb_sweep.txt): with 2-3

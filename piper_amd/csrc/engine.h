@@ -135,8 +135,6 @@ class Engine {
   PackedConv pack_matrix(const std::vector<float>& W, int rows, int Cin, int ntaps,
                          const std::vector<float>* bias, int nbias, int dil, int padl, bool gate, int split);
   DdsW load_dds(const WeightSet& ws, const std::string& prefix);
-  hipError_t ws_malloc(void** p, size_t bytes);
-  int ws_mem_ = 0;                          // PIPER_HIP_WS_MEM: 0 default device memory, 1 uncached, 2 fine-grained (experiment)
   void ensure_stage_a(int B, int Tmax);
   void ensure_stage_b(int Fmax);
 
@@ -342,8 +340,6 @@ class Engine {
   int B_ = 0, Tmax_ = 0, Ts_ = 0, Fmax_ = 0, Fs_ = 0, Tg_ = 0, Fg_ = 0;
   bool use_graphs_ = true;
   int tpb_override_ = 0;
-  bool small_tiles_ = true;                 // 32x32 wave tiles everywhere: occupancy beats register reuse here (profiles/)
-  long wide_min_blocks_ = 1L << 40;        // 256-column tiles measured slower than 128 (profiles/): off unless PIPER_HIP_WIDE_MIN is set
   // hipGraphExec_t per (stage, shape bucket, scales), least recently used first: a new key beyond graph_cap_ entries
   // evicts ONE graph (the coldest), never the whole cache
   struct GraphEntry { std::string key; void* exec; long launches; };

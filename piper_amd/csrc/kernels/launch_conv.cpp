@@ -11,9 +11,7 @@ void init_conv() {
 #ifndef PE_EMU
   const int lim = 160 * 1024;       // > 64 KiB of dynamic LDS needs the attribute (gfx950: 160 KiB per workgroup)
 #define PE_K2(WM, WN, MT, NT, KS, G) (const void*)conv_mfma_kernel<WM, WN, MT, NT, KS, G, 64>, (const void*)conv_mfma_kernel<WM, WN, MT, NT, KS, G, 128>
-  const void* ks[] = {PE_K2(2, 2, 2, 2, 8, false), PE_K2(1, 4, 2, 1, 16, false), PE_K2(1, 4, 1, 1, 16, false),
-                      PE_K2(2, 2, 1, 1, 16, false), PE_K2(2, 2, 2, 1, 16, false), PE_K2(1, 4, 1, 2, 16, false),
-                      PE_K2(1, 4, 2, 2, 8, false), PE_K2(2, 2, 2, 2, 8, true), PE_K2(1, 4, 2, 1, 16, true),
+  const void* ks[] = {PE_K2(1, 4, 1, 1, 16, false), PE_K2(2, 2, 1, 1, 16, false), PE_K2(1, 4, 2, 1, 16, true),
                       PE_K2(2, 2, 2, 1, 16, true),
                       (const void*)conv_splitk_kernel<2, true, 8, 3>, (const void*)conv_splitk_kernel<2, true, 4, 3>,
                       (const void*)conv_splitk_kernel<1, false, 8, 4>, (const void*)conv_splitk_kernel<1, false, 4, 4>,
@@ -26,29 +24,20 @@ void init_conv() {
 #endif
 }
 
-// tile configurations {WM, WN, MT, NT, KS}: ids as engine.cpp's CFG_* (A, B, C, S, G, C2, B2)
+// tile configurations {WM, WN, MT, NT, KS}: ids as engine.cpp's CFG_* -- B (gate: 64 x 128), C (32 x 128), S (64 x 64), G (gate: 128 x 64)
 void conv_tile(int cfg, bool gate, int halo, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p) {
 #define PE_CONV_LAUNCH(WM, WN, MT, NT, KS, G)                                                                  \
   do {                                                                                                         \
     if (halo == 64) PE_LAUNCH((conv_mfma_kernel<WM, WN, MT, NT, KS, G, 64>), grid, dim3(256), smem, stream, p); \
     else PE_LAUNCH((conv_mfma_kernel<WM, WN, MT, NT, KS, G, 128>), grid, dim3(256), smem, stream, p);          \
   } while (0)
+  // (the 128x128, 64x128 non-gate and 256-column configurations lost every A/B of rounds 1-3 and are no longer compiled)
   if (gate) {
-    switch (cfg) {
-      case 0: PE_CONV_LAUNCH(2, 2, 2, 2, 8, true); break;
-      case 1: PE_CONV_LAUNCH(1, 4, 2, 1, 16, true); break;
-      default: PE_CONV_LAUNCH(2, 2, 2, 1, 16, true); break;
-    }
+    if (cfg == 1) PE_CONV_LAUNCH(1, 4, 2, 1, 16, true);
+    else PE_CONV_LAUNCH(2, 2, 2, 1, 16, true);
   } else {
-    switch (cfg) {
-      case 0: PE_CONV_LAUNCH(2, 2, 2, 2, 8, false); break;
-      case 1: PE_CONV_LAUNCH(1, 4, 2, 1, 16, false); break;
-      case 2: PE_CONV_LAUNCH(1, 4, 1, 1, 16, false); break;
-      case 3: PE_CONV_LAUNCH(2, 2, 1, 1, 16, false); break;
-      case 5: PE_CONV_LAUNCH(1, 4, 1, 2, 16, false); break;
-      case 6: PE_CONV_LAUNCH(1, 4, 2, 2, 8, false); break;
-      default: PE_CONV_LAUNCH(2, 2, 2, 1, 16, false); break;
-    }
+    if (cfg == 2) PE_CONV_LAUNCH(1, 4, 1, 1, 16, false);
+    else PE_CONV_LAUNCH(2, 2, 1, 1, 16, false);
   }
 #undef PE_CONV_LAUNCH
 }
