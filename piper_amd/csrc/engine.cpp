@@ -740,6 +740,18 @@ void Engine::probe_xcds() {
 // workspaces
 // ------------------------------------------------------------------------------------------------
 
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(char* b) : base(b) {}
+  template <class T> T* take(size_t n) {
+    off = (off + 255) / 256 * 256;
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
 void Engine::ensure_stage_a(int B, int Tmax) {
   if (!ffn_parts_ && H_ == 192 && FC_ % 48 == 0 && FC_ / 48 <= 16 && !enc_.empty() && enc_[0].f1p) {
     // partial outputs of the fused small-call FFN (kernels/ffn.h): [utterance][slice][192][columns], once
