@@ -653,6 +653,8 @@ void Engine::init(const WeightSet& ws) {
   PE_HIP(hipEventCreate(&ev1_));
   PE_HIP(hipHostMalloc((void**)&h_frames_, 4096 * sizeof(int)));
   if (const char* ng = getenv("PIPER_HIP_NO_GRAPH")) use_graphs_ = !(ng[0] && ng[0] != '0');
+  if (const char* t = getenv("PIPER_HIP_CONVT_LDS")) convt_lds_ = atoi(t) != 0;      // up-conv tiles through LDS: 0 = element-wise stores (A/B, tests)
+  if (const char* t = getenv("PIPER_HIP_PROF_SITES")) prof_sites_ = atoi(t) != 0;
   if (const char* t = getenv("PIPER_HIP_ATTNO")) attno_ = atoi(t) != 0;          // attention + conv_o + LN as one launch (small calls): 0 = two launches
   if (const char* t = getenv("PIPER_HIP_GRAPHS")) graph_cap_ = (size_t)std::min(4096, std::max(1, atoi(t)));
   if (const char* t = getenv("PIPER_HIP_TPB")) tpb_override_ = atoi(t);     // tuning / test knob
@@ -988,6 +990,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
   p.split = (epi == EPI_GATE) ? pc.split : (epi == EPI_WNRS ? (pc.rows > H_ ? H_ : 0) : 0);
   p.up = pc.up; p.padT = pc.padT;
   p.up_magic = pc.up ? (unsigned)((0x100000000ULL + pc.up - 1) / pc.up) : 0u;
+  p.up_shift = -1;
   p.mode = mode; p.alpha = alpha;
   p.tpb = 1;
   p.tgroups = 1;
@@ -1105,11 +1108,22 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
   const int nbuf = (tpb == 1 && pc.nchunks == 1) ? 1 : 2;
   const int HALO = p.xhalo <= 64 ? 64 : 128;
   const size_t smem = (size_t)nbuf * KC * ((BN + HALO + 63) / 64 * 64) * sizeof(float);
+  // polyphase up-conv: the tile leaves through LDS as rows of consecutive output samples (conv_mfma.h) when the stride is
+  // a power of two that divides the tile's rows, one tile per workgroup, and the slab area holds BM x BN + padding
+  p.up_shift = -1;
+  if (epi == EPI_CONVT && convt_lds_ && tpb == 1 && pc.up >= 2 && (pc.up & (pc.up - 1)) == 0 && BM % pc.up == 0 &&
+      ((size_t)BM * BN + (size_t)(BM / pc.up) * 4) * sizeof(float) <= smem) {
+    int sh = 0;
+    while ((1 << sh) < pc.up) ++sh;
+    p.up_shift = sh;
+  }
   static const char* knames[] = {"2,2,2,2,8", "1,4,2,1,16", "1,4,1,1,16", "2,2,1,1,16", "2,2,2,1,16", "1,4,1,2,16", "1,4,2,2,8"};
   int kh = -1;
   if (prof_level_ >= 2) {
     char nm[96];
-    snprintf(nm, sizeof(nm), "conv_mfma_kernel<%s,%s,%d>", knames[cfg], pc.gate ? "true" : "false", HALO);
+    int n = snprintf(nm, sizeof(nm), "conv_mfma_kernel<%s,%s,%d>", knames[cfg], pc.gate ? "true" : "false", HALO);
+    // tuning aid (PIPER_HIP_PROF_SITES=1): one profile row per conv SHAPE instead of per instantiation
+    if (prof_sites_) snprintf(nm + n, sizeof(nm) - n, "|%dx%dx%d d%d e%d L%d", pc.rows, pc.Cin, pc.ntaps, pc.dil, epi, len_mul);
     kh = kbegin(krow(std::string(nm)), kflops, kbytes);
   }
   launch::conv_tile(cfg, pc.gate, HALO, grid, smem, ls_, p);

@@ -31,6 +31,8 @@ struct ConvP {
   int split;                                    // GATE: H ; WNRS: rows < split go to h, rest to skip
   int up, padT;                                 // CONVT: stride and padding
   unsigned up_magic;                            // CONVT: ceil(2^32 / up): row / up == (row * up_magic) >> 32 for row < 2^16
+  int up_shift;                                 // CONVT, conv_mfma_kernel: log2(up) when the tile leaves through LDS (coalesced rows of
+                                                // output samples instead of one strided store per phase), -1: element-wise stores
   int mode;                                     // ACCUM: 0 first,1 middle,2 last,3 only ; WNRS: 1 = first layer
   float alpha;                                  // ACCUM last/only: scale
   int tpb;                                      // conv_mfma_kernel: column tiles walked by one workgroup

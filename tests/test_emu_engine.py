@@ -492,3 +492,26 @@ def test_emulated_attention_conv_o_layernorm_in_one_launch(emu_lib, monkeypatch,
             assert np.max(np.abs(xenc[i] - np.asarray(o["x_enc"]).reshape(xenc[i].shape))) < 1e-5, (on, i)
             assert np.max(np.abs(r.audio[i] - o["audio"])) < 1e-5, (on, i)
         assert np.max(np.abs(res["0"][2][i] - res["1"][2][i])) < 1e-5
+
+
+@pytest.mark.parametrize("preset,lens", [("tiny", [7, 3, 1]), ("tiny-high", [5, 2])])
+def test_emulated_upconv_tile_through_lds_is_bit_identical(emu_lib, monkeypatch, preset, lens):
+    """conv_mfma_kernel's polyphase ConvTranspose1d epilogue: the tile transposed through LDS and stored as rows of
+    consecutive output samples (default) against one strided element-wise store per phase (PIPER_HIP_CONVT_LDS=0) -- the
+    same values to the same addresses: bit-identical waveforms for strides 8, 4 and 2, both tile shapes, ragged lengths
+    (first tile starting before sample 0, last tile hanging over the end). PIPER_HIP_SPLITK_MAX=0 sends the tiny voices'
+    up-convs to the tiled kernel at all."""
+    monkeypatch.setenv("PIPER_HIP_SPLITK_MAX", "0")
+    cfg = W.preset(preset)
+    w = W.synthetic_weights(cfg, 1234)
+    ids = [W.synthetic_phoneme_ids(T, i, id_max=cfg.n_vocab - 1) for i, T in enumerate(lens)]
+    res = {}
+    for on in ("0", "1"):
+        monkeypatch.setenv("PIPER_HIP_CONVT_LDS", on)
+        eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
+        res[on] = eng.synthesize_batch(ids, (0.0, 1.0, 0.0))
+        eng.close()
+    for i in range(len(lens)):
+        assert np.array_equal(res["0"].audio[i], res["1"].audio[i]) and np.array_equal(res["0"].pcm[i], res["1"].pcm[i]), i
+    o = O.synthesize(w, cfg, ids[0], (0.0, 1.0, 0.0))
+    assert np.max(np.abs(res["1"].audio[0] - o["audio"])) < 1e-4
