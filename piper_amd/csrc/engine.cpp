@@ -653,7 +653,7 @@ void Engine::init(const WeightSet& ws) {
   PE_HIP(hipEventCreate(&ev1_));
   PE_HIP(hipHostMalloc((void**)&h_frames_, 4096 * sizeof(int)));
   if (const char* ng = getenv("PIPER_HIP_NO_GRAPH")) use_graphs_ = !(ng[0] && ng[0] != '0');
-  if (const char* t = getenv("PIPER_HIP_CONVT_LDS")) convt_lds_ = atoi(t) != 0;      // up-conv tiles through LDS: 0 = element-wise stores (A/B, tests)
+  if (const char* t = getenv("PIPER_HIP_CONVT_LDS")) convt_lds_ = std::min(2, std::max(0, atoi(t)));      // up-conv tiles through LDS: 0 = never, 1 = stride >= 8, 2 = every stride (tests)
   if (const char* t = getenv("PIPER_HIP_PROF_SITES")) prof_sites_ = atoi(t) != 0;
   if (const char* t = getenv("PIPER_HIP_ATTNO")) attno_ = atoi(t) != 0;          // attention + conv_o + LN as one launch (small calls): 0 = two launches
   if (const char* t = getenv("PIPER_HIP_GRAPHS")) graph_cap_ = (size_t)std::min(4096, std::max(1, atoi(t)));
@@ -1111,7 +1111,9 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
   // polyphase up-conv: the tile leaves through LDS as rows of consecutive output samples (conv_mfma.h) when the stride is
   // a power of two that divides the tile's rows, one tile per workgroup, and the slab area holds BM x BN + padding
   p.up_shift = -1;
-  if (epi == EPI_CONVT && convt_lds_ && tpb == 1 && pc.up >= 2 && (pc.up & (pc.up - 1)) == 0 && BM % pc.up == 0 &&
+  // (measured, profiles/r04_notes.md: stride 8 -6 % per launch at batch; strides 4 and 2 gain nothing or lose -- their
+  // LDS writes are 4- / 2-way bank conflicts for a store pattern the L2 was already merging; convt_lds_ == 2 forces it)
+  if (epi == EPI_CONVT && convt_lds_ && (pc.up >= 8 || convt_lds_ == 2) && tpb == 1 && pc.up >= 2 && (pc.up & (pc.up - 1)) == 0 && BM % pc.up == 0 &&
       ((size_t)BM * BN + (size_t)(BM / pc.up) * 4) * sizeof(float) <= smem) {
     int sh = 0;
     while ((1 << sh) < pc.up) ++sh;

@@ -185,7 +185,7 @@ class Engine {
   float* ffn_parts_ = nullptr;
   static constexpr long ffn_max_cols_ = 2048;
   int ffn_ = 1;                             // PIPER_HIP_FFN=0: conv by conv (A/B, tests)
-  bool convt_lds_ = true;                   // PIPER_HIP_CONVT_LDS=0: up-conv tiles stored element-wise (A/B, tests)
+  int convt_lds_ = 1;                       // PIPER_HIP_CONVT_LDS: up-conv tiles through LDS: 0 never, 1 stride >= 8 (measured), 2 every stride (tests)
   bool prof_sites_ = false;                 // PIPER_HIP_PROF_SITES=1: level-2 profile rows of the tiled conv kernel per conv shape (tuning aid)
   bool attno_ = true;                       // PIPER_HIP_ATTNO=0: attention and conv_o + LN as two launches (A/B, tests)
   bool stage_a_ffn_fused() const;

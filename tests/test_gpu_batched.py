@@ -218,7 +218,7 @@ FORCED = [
     ("medium", [128, 31], {"PIPER_HIP_ATTNO": 0}, {"attn_kernel<96>", "colchain4_kernel"}),
     # the up-convs' tiles stored element-wise (default: transposed through LDS, rows of consecutive samples), B = 1 and batch
     ("medium", [128], {"PIPER_HIP_CONVT_LDS": 0}, {"conv_mfma_kernel<2,2,1,1,16,false,64>"}),
-    ("high", [70, 128, 9, 128, 128, 33], {"PIPER_HIP_CONVT_LDS": 0}, set()),
+    ("high", [70, 128, 9, 128, 128, 33], {"PIPER_HIP_CONVT_LDS": 2}, set()),
     # tiles of the 4-column kernels in workgroup order (no XCD-contiguous runs)
     ("medium", [128, 31], {"PIPER_HIP_XCD": 0}, {"colchain4_kernel", "lngemm4_kernel", "dds_layer4_kernel"}),
 ]
