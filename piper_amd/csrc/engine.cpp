@@ -2239,7 +2239,14 @@ void Engine::run() {
     // the whole utterance -- text encoder to int16 -- as ONE graph: stage B is issued right behind stage A for the
     // guessed frame bucket (the kernels read the real frame counts from device memory, clamped to the bucket)
     Fg_ = std::min(fguess, Fs_);
-    frames_h_.assign(B, Fg_);                 // placeholder for FLOP accounting while issuing; real counts in finish_run()
+    // What the cost models see while the graph is issued (window geometry of the stage kernels, column thresholds): the
+    // EXPECTED frame counts -- ratio x ids, without the safety margin and the bucket rounding that size the grids. With
+    // the bucket capacity here a 417-frame utterance in the 512-frame bucket got the last stage's two-round geometry
+    // (mrf_kernel<32,3,1>: 125.6 us per replay) instead of the one-round one its real length takes (<32,4,1>: 85.7 us;
+    // profiles/r04_notes.md). Grids and clamps are sized by Fg_; the real counts arrive in finish_run().
+    frames_h_.resize(B);
+    for (int b = 0; b < B; ++b)
+      frames_h_[b] = std::min(Fg_, std::max(1, (int)std::ceil(last_ratio_ * (float)tlens_h_[b])));
     lens_b_ = d_framesc_;
     snprintf(key, sizeof(key), "C|%d|%d|%d|%a|%a|%d|%d|%d|%a", B, Tg_, Ts_, scales_[1], scales_[2], (int)have_noise_w_,
              Fs_, Fg_, scales_[0]);
