@@ -655,6 +655,9 @@ void Engine::init(const WeightSet& ws) {
   if (const char* ng = getenv("PIPER_HIP_NO_GRAPH")) use_graphs_ = !(ng[0] && ng[0] != '0');
   if (const char* t = getenv("PIPER_HIP_CONVT_LDS")) convt_lds_ = std::min(2, std::max(0, atoi(t)));      // up-conv tiles through LDS: 0 = never, 1 = stride >= 8, 2 = every stride (tests)
   if (const char* t = getenv("PIPER_HIP_PROF_SITES")) prof_sites_ = atoi(t) != 0;
+  if (const char* t = getenv("PIPER_HIP_XCD_TILE")) xcd_tile_ = atoi(t) != 0;    // A/B knob: 0 = tiled conv workgroups take (blockIdx.x, blockIdx.y)
+  if (const char* t = getenv("PIPER_HIP_SPEC_EXPECT")) spec_expect_ = atoi(t) != 0;   // A/B knob: 0 = speculative graphs are planned for the bucket capacity
+  if (const char* t = getenv("PIPER_HIP_XCD_ROWS")) xcd_rows_ = atoi(t) != 0;    // A/B knob: 0 = split-K / FFN workgroups take (blockIdx.x, blockIdx.y)
   if (const char* t = getenv("PIPER_HIP_ATTNO")) attno_ = atoi(t) != 0;          // attention + conv_o + LN as one launch (small calls): 0 = two launches
   if (const char* t = getenv("PIPER_HIP_GRAPHS")) graph_cap_ = (size_t)std::min(4096, std::max(1, atoi(t)));
   if (const char* t = getenv("PIPER_HIP_TPB")) tpb_override_ = atoi(t);     // tuning / test knob
@@ -994,6 +997,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
   p.mode = mode; p.alpha = alpha;
   p.tpb = 1;
   p.tgroups = 1;
+  p.xcd = xcd_rows_ ? xcd_period_ : 0;          // split-K kernels: (column tile, row part) dealt to the XCDs row part-major
   if ((epi == EPI_GATE) != pc.gate) throw std::runtime_error("internal: gate epilogue/packing mismatch");
 
   const int ncols = (epi == EPI_CONVT) ? Lmax + 1 : Lmax;
@@ -1128,6 +1132,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     if (prof_sites_) snprintf(nm + n, sizeof(nm) - n, "|%dx%dx%d d%d e%d L%d", pc.rows, pc.Cin, pc.ntaps, pc.dil, epi, len_mul);
     kh = kbegin(krow(std::string(nm)), kflops, kbytes);
   }
+  p.xcd = xcd_tile_ ? xcd_period_ : 0;          // (column tile, row block) dealt to the XCDs column tile-major
   launch::conv_tile(cfg, pc.gate, HALO, grid, smem, ls_, p);
   kend(kh);
 }
@@ -1719,6 +1724,7 @@ void Engine::issue_stage_a() {
     }      // !attno
     if (ffn_fused) {
       FfnP fp{};
+      fp.xcd = xcd_rows_ ? xcd_period_ : 0;
       const int Tp = rup(T, 4);
       fp.x = x.p; fp.x_bs = x.bs; fp.x_cs = x.cs;
       fp.w1p = e.f1p; fp.b1 = e.f1.bias; fp.w2p = e.f2p;
@@ -2246,7 +2252,7 @@ void Engine::run() {
     // profiles/r04_notes.md). Grids and clamps are sized by Fg_; the real counts arrive in finish_run().
     frames_h_.resize(B);
     for (int b = 0; b < B; ++b)
-      frames_h_[b] = std::min(Fg_, std::max(1, (int)std::ceil(last_ratio_ * (float)tlens_h_[b])));
+      frames_h_[b] = spec_expect_ ? std::min(Fg_, std::max(1, (int)std::ceil(last_ratio_ * (float)tlens_h_[b]))) : Fg_;
     lens_b_ = d_framesc_;
     snprintf(key, sizeof(key), "C|%d|%d|%d|%a|%a|%d|%d|%d|%a", B, Tg_, Ts_, scales_[1], scales_[2], (int)have_noise_w_,
              Fs_, Fg_, scales_[0]);

@@ -213,6 +213,9 @@ class Engine {
   // and the period P when it is a round-robin over P XCDs (0: anything else -- the 4-column kernels then use tile = id)
   int xcc_of_[64] = {0};
   int xcd_period_ = 0;
+  bool xcd_tile_ = true;                    // PIPER_HIP_XCD_TILE=0: the tiled conv kernel takes (column tile, row block) = blockIdx (A/B)
+  bool spec_expect_ = true;                 // PIPER_HIP_SPEC_EXPECT=0: speculative graphs planned for the bucket capacity instead of the expected frames (A/B)
+  bool xcd_rows_ = true;                    // PIPER_HIP_XCD_ROWS=0: split-K convs and the fused FFN take (column tile, row part) = blockIdx (A/B)
   void probe_xcds();
   int col4_ = 1;                            // PIPER_HIP_COL4: 4-column workgroups for the DDSConv layers: 0 off, 1 up to col4_max_cols_ columns per call, 2 always (A/B, tests)
   long col4_max_cols_ = 1024;               // ids per call (text encoder, duration predictor)

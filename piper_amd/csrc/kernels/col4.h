@@ -19,11 +19,7 @@ namespace pe {
 // 0 otherwise: then tile = blockIdx.x. (The round-robin runs over the LINEAR workgroup id, so in row (y, z) of the grid
 // workgroup x sits on XCD (base(y, z) + x) mod P: which XCD owns residue class x mod P changes from row to row, but a
 // class always sits on ONE XCD -- all the map needs.)
-__device__ __forceinline__ int c4_tile(int bx, int nx, int P) {
-  if (P <= 1) return bx;
-  const int q = nx / P, r = nx - q * P, i = bx / P, j = bx - i * P;
-  return j * q + (j < r ? j : r) + i;
-}
+__device__ __forceinline__ int c4_tile(int bx, int nx, int P) { return pe_xcd_tile(bx, nx, P); }
 
 // ---- the 4-column GEMM: rows <= 192 x K (192 or 96) over the 4 columns in YT[4][K + 4] on the 4x4x1 MFMA
 constexpr int FFN_MAXS = 16;                          // slices of the fused FFN's hidden dimension (ffn.h): FC <= 768

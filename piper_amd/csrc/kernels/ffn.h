@@ -38,8 +38,11 @@ __global__ __launch_bounds__(256) void ffn_kernel(FfnP p) {
   float* XS = sm;
   float* PA = XS + FFN_H * FFN_XS;
   float* HS = PA + 4 * FFN_SL * FFN_NC;
-  const int b = blockIdx.z, s = blockIdx.y;
-  const int o0 = blockIdx.x * FFN_NO;             // first output column of the tile; hidden columns o0 - 1 .. o0 + 14, x columns o0 - 2 .. o0 + 15
+  // (column tile, slice), slice-major over the XCDs: an XCD's workgroups share one or two slices' weights (pe_rt.h)
+  int bx = blockIdx.x, by = blockIdx.y;
+  pe_xcd_xy(p.xcd, bx, by);
+  const int b = blockIdx.z, s = PE_UNIFORM(by);
+  const int o0 = PE_UNIFORM(bx) * FFN_NO;             // first output column of the tile; hidden columns o0 - 1 .. o0 + 14, x columns o0 - 2 .. o0 + 15
                                                   // (outputs o0 .. o0 + 11 are kept)
   const int tid = threadIdx.x, lane = tid & 63, wv = PE_UNIFORM(tid >> 6);
   const int l15 = lane & 15, lq = lane >> 4;

@@ -37,6 +37,8 @@ struct ConvP {
   float alpha;                                  // ACCUM last/only: scale
   int tpb;                                      // conv_mfma_kernel: column tiles walked by one workgroup
   int tgroups;                                  // conv_splitk_kernel: 1, or 2 = two halves of the waves split the taps
+  int xcd;                                      // split-K kernels: XCDs the dispatch round-robins over -> (column tile, row part) by
+                                                // pe_xcd_xy (pe_rt.h); 0 / 1: (blockIdx.x, blockIdx.y)
   // conv_splitk_body<..., MS = true> only: K = the concatenation of nseg convs of one shape whose outputs are summed
   // (segment 0 repeats x / wp / ntaps / dil / padl); res2 / res3 = the residual tensors of segments 1 / 2
   int nseg;
@@ -141,6 +143,7 @@ struct FfnP {
   const float* w2p;                              // conv_2: pack_ffn order per slice (its bias is added by the consumer)
   float* parts; long p_bs; int nslices;          // [utterance][4-column tile][slice][192][4], p_bs floats per utterance
   const int* lens;
+  int xcd;                                       // XCDs the dispatch round-robins over -> (column tile, slice) by pe_xcd_xy; 0 / 1: blockIdx
 };
 struct LnGemmP {
   const float* in; long in_bs; int in_cs;        // y = x + ffn(x)  (parts != null: the residual x alone)

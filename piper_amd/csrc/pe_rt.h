@@ -154,6 +154,37 @@ __device__ __forceinline__ float pe_lrelu(float v, float slope) {
 }
 #endif
 
+// ---- XCD-aware tile order. Workgroups go to the P XCDs (each with its own L2) round-robin by LINEAR workgroup id, so
+// the workgroups of one residue class mod P share an L2. pe_xcd_tile maps workgroup `id` of `n` onto a tile such that
+// every XCD owns one contiguous run of tiles (a bijection on [0, n); P <= 1: the identity).
+__device__ __forceinline__ int pe_xcd_tile(int id, int n, int P) {
+  if (P <= 1) return id;
+  const int q = n / P, r = n - q * P, i = id / P, j = id - i * P;
+  return j * q + (j < r ? j : r) + i;
+}
+// The same for a (column tile x, row part y) grid plane whose row parts read DIFFERENT weights (split-K convs, the fused
+// FFN's slices): tiles are numbered row part-major, so an XCD's run covers one or two row parts and its L2 fetches only
+// their weights -- with (x, y) = blockIdx every L2 pulled the whole layer through the fabric (the gate conv of a
+// one-utterance call: 14.5 MB of traffic per launch for 2.1 MB of operands, profiles/r04_pmc_traffic.json). The planes
+// of a 3-D grid are mapped one by one: within a plane a residue class still sits on ONE XCD.
+__device__ __forceinline__ void pe_xcd_xy(int P, int& bx, int& by) {
+  if (P <= 1) return;
+  const int nx = (int)gridDim.x;
+  const int t = pe_xcd_tile(by * nx + bx, nx * (int)gridDim.y, P);
+  by = t / nx;
+  bx = t - by * nx;
+}
+// Column tile-major, for the tiled conv kernel whose row blocks of one column tile read the SAME x slab: an XCD's run
+// holds all row blocks of a column tile back to back, so the slab comes through the fabric once instead of once per row
+// block (up to 16 for the first up-conv) and the later row blocks hit in that XCD's L2.
+__device__ __forceinline__ void pe_xcd_yx(int P, int& bx, int& by) {
+  if (P <= 1) return;
+  const int ny = (int)gridDim.y;
+  const int t = pe_xcd_tile(by * (int)gridDim.x + bx, (int)gridDim.x * ny, P);
+  bx = t / ny;
+  by = t - bx * ny;
+}
+
 #include <stdexcept>
 #include <string>
 
