@@ -172,6 +172,12 @@ int pe_graph_stats(pe_engine* e, int64_t* cached, int64_t* captures);
  * column tiles by it (piper_amd/csrc/kernels/col4.h); bench.py prints it so that a result line says what the box did. */
 int pe_xcc_pattern(pe_engine* e, int32_t xcc[64], int32_t* period);
 
+/* Diagnostic: the engine's launch-policy knobs -- every environment variable that picks a kernel form, with its default,
+ * range and meaning -- as a JSON array of {"env", "default", "lo", "hi", "doc"} objects (piper_amd/csrc/policy.h; a
+ * static string, valid for the life of the process). The knobs are read once per engine, at pe_create; the product needs
+ * none of them (onnxruntime's session options are the reference's counterpart, src/cpp/piper.cpp:262-306). */
+const char* pe_policy_describe(void);
+
 /* In-process multi-GPU synthesis for C / C++ callers (the reference runs the phrases of a text one
  * after the other on one session, src/cpp/piper.cpp:549-582 -- they are independent, so they shard). One engine, one
  * stream and one worker thread per device. The voice is parsed and packed ONCE, on devices[0]; every other device gets an

@@ -17,7 +17,7 @@ SYMBOLS = [
     "pe_synthesize_batch", "pe_upload", "pe_run", "pe_fetch", "pe_stream_begin", "pe_stream_next",
     "pe_get_durations", "pe_get_info",
     "pe_set_seed", "pe_profile_enable", "pe_profile_reset", "pe_profile_rows", "pe_profile_get", "pe_profile_bytes",
-    "pe_stream", "pe_debug_tensor", "pe_debug_randn", "pe_rng_calls", "pe_run_launches", "pe_speculation_stats", "pe_warmup", "pe_graph_stats", "pe_xcc_pattern", "pe_last_error", "pe_destroy",
+    "pe_stream", "pe_debug_tensor", "pe_debug_randn", "pe_rng_calls", "pe_run_launches", "pe_speculation_stats", "pe_warmup", "pe_graph_stats", "pe_xcc_pattern", "pe_policy_describe", "pe_last_error", "pe_destroy",
     "pe_group_create", "pe_group_broadcast_path", "pe_group_size", "pe_group_engine", "pe_group_synthesize_batch", "pe_group_assignment",
     "pe_group_destroy",
 ]
@@ -81,6 +81,8 @@ def bind(path: str) -> C.CDLL:
     lib.pe_run_launches.restype = C.c_int64
     lib.pe_speculation_stats.argtypes = [vp, i64p, i64p]
     lib.pe_xcc_pattern.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    lib.pe_policy_describe.argtypes = []
+    lib.pe_policy_describe.restype = C.c_char_p
     lib.pe_warmup.argtypes = [vp, C.c_int32, C.c_int32, C.c_float, f32p, i64p, C.c_int64]
     lib.pe_graph_stats.argtypes = [vp, i64p, i64p]
     lib.pe_group_create.argtypes = [vp, C.c_size_t, i32p, C.c_int32, C.POINTER(vp)]

@@ -72,12 +72,7 @@ size_t Engine::arena_bound(const WeightSet& ws) {
   // matrix mode bf16x3: the flow / generator conv weights once more as split bf16 fragments (same size as the f32 packing)
   return (n * (env_bf3() ? 10 : 7) / 2 + (4u << 20)) * sizeof(float);
 }
-bool Engine::env_bf3() {
-  const char* t = getenv("PIPER_HIP_MATRIX");
-  if (!t || !t[0] || !strcmp(t, "f32")) return false;
-  if (!strcmp(t, "bf16x3")) return true;
-  throw std::runtime_error("PIPER_HIP_MATRIX: expected f32 or bf16x3");
-}
+bool Engine::env_bf3() { return LaunchPolicy::matrix_bf3_env(); }
 
 static inline uint16_t bf16_rne(float v) {
   uint32_t u;
@@ -135,8 +130,7 @@ PackedConv Engine::pack_matrix(const std::vector<float>& W, int rows, int Cin, i
             P[(((size_t)mt * pc.nchunks + c) * ntaps + tap) * (KC / 2) * 64 + (kk >> 2) * 256 + lane * 4 + (kk & 3)] = v;
           }
   pc.wp = dev_alloc(np, skeleton_ ? nullptr : P.data());
-  const char* f16 = getenv("PIPER_HIP_SPLITK16");          // 3 = every conv (tests)
-  if (pc.nchunks * ntaps >= 24 || (f16 && atoi(f16) >= 3)) {
+  if (pc.nchunks * ntaps >= 24 || pol_.splitk16 >= 3) {          // 3 = every conv (tests)
     // long-K convs may run through conv_splitk16_kernel: [16-row sub-tile][chunk][tap][q][lane][4], lane ->
     // (row = lane & 15, k = lane >> 4), float4 element j of group q = k-step 4q + j = input channel chunk*32 + 4s + k
     const size_t nq = (size_t)pc.mtiles * 2 * pc.nchunks * ntaps * (KC / 4) * 64;
@@ -419,12 +413,9 @@ Engine::Engine(const WeightSet& ws, int device, ArenaSpec arena) : device_(devic
 }
 
 void Engine::init(const WeightSet& ws) {
-  if (const char* t = getenv("PIPER_HIP_MRF")) mrf_mode_ = atoi(t);       // A/B knob: 0 = conv-by-conv MRF stages, 2 = always fused
-  if (const char* t = getenv("PIPER_HIP_MRF_MAXF")) mrf_rb1_max_frames_ = atol(t);
-  if (const char* t = getenv("PIPER_HIP_MRF_OU")) mrf_ou_ = atoi(t);
-  if (const char* t = getenv("PIPER_HIP_MRF_TAIL")) mrf_tail_ = atoi(t) != 0;   // A/B knob, tests: conv_post inside the last mrf_kernel
+  pol_.read_env();
+  use_graphs_ = !pol_.no_graph;
   matrix_bf3_ = env_bf3();
-  if (const char* t = getenv("PIPER_HIP_BF3_MINF")) bf3_min_frames_ = atol(t);
   memcpy(arch_, ws.arch, sizeof(arch_));
   PE_HIP(hipSetDevice(device_));
   PE_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));
@@ -652,27 +643,6 @@ void Engine::init(const WeightSet& ws) {
   PE_HIP(hipEventCreate(&ev0_));
   PE_HIP(hipEventCreate(&ev1_));
   PE_HIP(hipHostMalloc((void**)&h_frames_, 4096 * sizeof(int)));
-  if (const char* ng = getenv("PIPER_HIP_NO_GRAPH")) use_graphs_ = !(ng[0] && ng[0] != '0');
-  if (const char* t = getenv("PIPER_HIP_CONVT_LDS")) convt_lds_ = std::min(2, std::max(0, atoi(t)));      // up-conv tiles through LDS: 0 = never, 1 = stride >= 8, 2 = every stride (tests)
-  if (const char* t = getenv("PIPER_HIP_PROF_SITES")) prof_sites_ = atoi(t) != 0;
-  if (const char* t = getenv("PIPER_HIP_XCD_TILE")) xcd_tile_ = atoi(t) != 0;    // A/B knob: 0 = tiled conv workgroups take (blockIdx.x, blockIdx.y)
-  if (const char* t = getenv("PIPER_HIP_SPEC_EXPECT")) spec_expect_ = atoi(t) != 0;   // A/B knob: 0 = speculative graphs are planned for the bucket capacity
-  if (const char* t = getenv("PIPER_HIP_XCD_ROWS")) xcd_rows_ = atoi(t) != 0;    // A/B knob: 0 = split-K / FFN workgroups take (blockIdx.x, blockIdx.y)
-  if (const char* t = getenv("PIPER_HIP_ATTNO")) attno_ = atoi(t) != 0;          // attention + conv_o + LN as one launch (small calls): 0 = two launches
-  if (const char* t = getenv("PIPER_HIP_GRAPHS")) graph_cap_ = (size_t)std::min(4096, std::max(1, atoi(t)));
-  if (const char* t = getenv("PIPER_HIP_TPB")) tpb_override_ = atoi(t);     // tuning / test knob
-  if (const char* t = getenv("PIPER_HIP_GROUP_MRF")) group_mrf_ = atoi(t);
-  if (const char* t = getenv("PIPER_HIP_PCM_ZC")) pcm_zc_ = atoi(t) != 0;
-  if (const char* t = getenv("PIPER_HIP_SPLITK_MAX")) splitk_max_blocks_ = atol(t);   // tuning knob
-  if (const char* t = getenv("PIPER_HIP_SPLITK16")) splitk16_ = atoi(t);              // A/B knob
-  if (const char* t = getenv("PIPER_HIP_WIDE_SPLITK")) wide_splitk_ = atoi(t);        // 0 off, 1 auto, 2 always (tests)
-  if (const char* t = getenv("PIPER_HIP_DEBUG_KEEP")) debug_keep_ = atoi(t) != 0;     // tests: keep z_p for debug_tensor
-  if (const char* t = getenv("PIPER_HIP_COLCHAIN")) colchain_ = atoi(t);              // A/B knob, tests
-  if (const char* t = getenv("PIPER_HIP_FUSE_DP")) fuse_dp_ = atoi(t) != 0;           // A/B knob, tests
-  if (const char* t = getenv("PIPER_HIP_COL4")) col4_ = atoi(t);                      // A/B knob, tests
-  if (const char* t = getenv("PIPER_HIP_COL4_MAXC")) col4_max_cols_ = atol(t);
-  if (const char* t = getenv("PIPER_HIP_FFN")) ffn_ = atoi(t);                        // A/B knob, tests
-  if (const char* t = getenv("PIPER_HIP_SPEC")) spec_enable_ = atoi(t) != 0;          // speculative stage B (A/B, tests)
 }
 
 Engine::~Engine() { free_all(); }
@@ -738,7 +708,7 @@ void Engine::probe_xcds() {
     if (ok && c > 1 && xcc_of_[c] == xcc_of_[0]) P = c;
   }
   xcd_period_ = P;
-  if (const char* t = getenv("PIPER_HIP_XCD")) xcd_period_ = std::min(32, std::max(0, atoi(t)));      // A/B knob: 0 = tiles in workgroup order
+  if (pol_.xcd >= 0) xcd_period_ = (int)pol_.xcd;       // PIPER_HIP_XCD (A/B, tests): 0 = tiles in workgroup order
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -761,7 +731,7 @@ void Engine::ensure_stage_a(int B, int Tmax) {
   if (!ffn_parts_ && H_ == 192 && FC_ % 48 == 0 && FC_ / 48 <= 16 && !enc_.empty() && enc_[0].f1p) {
     // partial outputs of the fused small-call FFN (kernels/ffn.h): [utterance][slice][192][columns], once
     PE_HIP(hipStreamSynchronize(stream_));
-    PE_HIP(hipMalloc((void**)&ffn_parts_, (size_t)(FC_ / 48) * H_ * ffn_max_cols_ * sizeof(float)));
+    PE_HIP(hipMalloc((void**)&ffn_parts_, (size_t)(FC_ / 48) * H_ * LaunchPolicy::ffn_max_cols * sizeof(float)));
   }
   const int Ts = rup(Tmax, 128);    // row strides are multiples of 128 columns (conv epilogue relies on it)
   bool grow = false;
@@ -845,7 +815,7 @@ void Engine::ensure_stage_b(int Fmax) {
     noise_z_ = c.take<float>(Bc * C_ * F);
     for (int i = 0; i < 5; ++i) hb_[i] = c.take<float>(Bc * hmax);
     zwin_ = c.take<float>((size_t)C_ * F);
-    zp_keep_ = debug_keep_ ? c.take<float>(Bc * C_ * F) : nullptr;
+    zp_keep_ = pol_.debug_keep ? c.take<float>(Bc * C_ * F) : nullptr;
     d_win_ = c.take<int>(4);
     audio_ = c.take<float>(Bc * (size_t)Ss_);
     pcm_ = c.take<int16_t>(Bc * (size_t)Ss_);
@@ -861,7 +831,7 @@ void Engine::ensure_stage_b(int Fmax) {
   carve(wsB_);
   // zero-copy PCM: room for every utterance of the batch capacity, up to 256 MiB of pinned memory (beyond: copies)
   const size_t zc_want = Bc * (size_t)Ss_;
-  if (pcm_zc_ && zc_want * sizeof(int16_t) <= ((size_t)256 << 20) && h_pcm_zc_cap_ < zc_want) {
+  if (pol_.pcm_zc && zc_want * sizeof(int16_t) <= ((size_t)256 << 20) && h_pcm_zc_cap_ < zc_want) {
     PE_HIP(hipStreamSynchronize(stream_));
     drop_graphs();                                     // the pointer is a kernel argument inside the graphs
     if (h_pcm_zc_) PE_HIP(hipHostFree(h_pcm_zc_));
@@ -871,7 +841,7 @@ void Engine::ensure_stage_b(int Fmax) {
   // per-resblock buffers of the grouped sibling schedule (one-utterance calls, first generator stage): allocated
   // here, outside any graph capture; the schedule only applies below 700 64x64 blocks per stage
   const size_t want = std::min<size_t>(Bc * hmax, (size_t)700 * 4096);
-  if (group_mrf_ && side_floats_ < want) {
+  if (pol_.group_mrf && side_floats_ < want) {
     PE_HIP(hipStreamSynchronize(stream_));
     drop_graphs();
     for (float*& sp : side_) { if (sp) PE_HIP(hipFree(sp)); sp = nullptr; }
@@ -888,7 +858,7 @@ void Engine::ensure_stage_b(int Fmax) {
 // throughput-bound, and a halo the 128-column slab covers.
 bool Engine::can_group(const PackedConv& pc, int ncols) const {
   const long blocks = (long)((ncols + CFG_BN[pc.cfg] - 1) / CFG_BN[pc.cfg]) * (pc.mtiles * 32 / CFG_BM[pc.cfg]) * B_;
-  return !pc.gate && !pc.up && blocks < splitk_max_blocks_ && (pc.ntaps - 1) * pc.dil <= 96;
+  return pol_.groupable(pc.gate, pc.up != 0, blocks, (pc.ntaps - 1) * pc.dil);
 }
 void Engine::group_begin() {
   grouping_ = true;
@@ -968,11 +938,8 @@ void Engine::group_end_sum(View out, const float* bias_sum, float alpha) {
 int Engine::route(const PackedConv& pc, int ncols, int epi) const {
   const int cfg = pc.cfg;
   const long blocks = (long)((ncols + CFG_BN[cfg] - 1) / CFG_BN[cfg]) * (pc.mtiles * 32 / CFG_BM[cfg]) * B_;
-  if (!(blocks < splitk_max_blocks_ && (pc.ntaps - 1) * pc.dil <= 32)) return ROUTE_TILE;
-  const int units = pc.nchunks * pc.ntaps;
-  const bool k16 = pc.wp16 && epi != EPI_CONVT && ((pc.gate && splitk16_ >= 1) || (!pc.gate && splitk16_ >= 2)) &&
-                   (units >= 24 || splitk16_ >= 3);
-  return k16 ? ROUTE_SPLITK16 : ROUTE_SPLITK;
+  if (!pol_.splitk(blocks, (pc.ntaps - 1) * pc.dil)) return ROUTE_TILE;
+  return pol_.splitk_16col(pc.wp16 != nullptr, epi == EPI_CONVT, pc.gate, pc.nchunks * pc.ntaps) ? ROUTE_SPLITK16 : ROUTE_SPLITK;
 }
 void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int len_mul, int Lmax, int epi,
                   float in_slope, int act, View res, View out2, int mode, float alpha, const float* bias2,
@@ -997,7 +964,6 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
   p.mode = mode; p.alpha = alpha;
   p.tpb = 1;
   p.tgroups = 1;
-  p.xcd = xcd_rows_ ? xcd_period_ : 0;          // split-K kernels: (column tile, row part) dealt to the XCDs row part-major
   if ((epi == EPI_GATE) != pc.gate) throw std::runtime_error("internal: gate epilogue/packing mismatch");
 
   const int ncols = (epi == EPI_CONVT) ? Lmax + 1 : Lmax;
@@ -1029,7 +995,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     group_bytes_ += kbytes;
     return;
   }
-  if (blocks < splitk_max_blocks_ && p.xhalo <= 32) {
+  if (pol_.splitk(blocks, p.xhalo)) {
     // few columns (one utterance through encoder / duration predictor / flow): split K across the waves
     const int MT = pc.gate ? 2 : 1;
     // waves per workgroup: 4 / 8 take whole chunks; the WN gate conv (6 chunks x 5 taps, two M tiles per wave)
@@ -1038,15 +1004,13 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     const int units = pc.nchunks * pc.ntaps;
     int NW = pc.nchunks >= 5 ? 8 : 4;
     p.tgroups = 1;
-    if ((wide_splitk_ == 1 && pc.gate && units >= 24 && pc.nchunks <= 6 && pc.ntaps >= 4) ||
-        wide_splitk_ == 2) {          // 2 = always (tests)
+    if (pol_.splitk_12wave(pc.gate, units, pc.nchunks, pc.ntaps)) {
       NW = 12;
       p.tgroups = pc.nchunks <= 6 ? 2 : 1;
     }
     dim3 grid((ncols + 31) / 32, pc.mtiles / MT, B_);
     const size_t smem = std::max<size_t>((size_t)NW * KC * 64, (size_t)NW * MT * 16 * 64) * sizeof(float);
-    const bool k16 = pc.wp16 && epi != EPI_CONVT && ((pc.gate && splitk16_ >= 1) || (!pc.gate && splitk16_ >= 2)) &&
-                     (units >= 24 || splitk16_ >= 3);
+    const bool k16 = pol_.splitk_16col(pc.wp16 != nullptr, epi == EPI_CONVT, pc.gate, units);
     // profile rows carry the instantiation exactly as rocprofv3 prints it (minus spaces)
     int kh = -1;
     if (prof_level_ >= 2) {
@@ -1103,8 +1067,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
   // workgroups resident per CU, one tile per workgroup (latency hidden across workgroups) beats walking
   // several tiles with the in-kernel prefetch pipeline at every batch size, so the default is 1; the
   // multi-tile path stays available through PIPER_HIP_TPB.
-  int tpb = 1;
-  if (tpb_override_ > 0) tpb = tpb_override_;
+  const int tpb = pol_.tiles_per_workgroup();
   p.tpb = tpb;
   dim3 grid((ntile + tpb - 1) / tpb, mblocks, B_);
   if (p.xhalo > 128) throw std::runtime_error("conv halo (kernel-1)*dilation > 128 is not supported");
@@ -1116,9 +1079,9 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
   // a power of two that divides the tile's rows, one tile per workgroup, and the slab area holds BM x BN + padding
   p.up_shift = -1;
   // (measured, profiles/r04_notes.md: stride 8 -6 % per launch at batch; strides 4 and 2 gain nothing or lose -- their
-  // LDS writes are 4- / 2-way bank conflicts for a store pattern the L2 was already merging; convt_lds_ == 2 forces it)
-  if (epi == EPI_CONVT && convt_lds_ && (pc.up >= 8 || convt_lds_ == 2) && tpb == 1 && pc.up >= 2 && (pc.up & (pc.up - 1)) == 0 && BM % pc.up == 0 &&
-      ((size_t)BM * BN + (size_t)(BM / pc.up) * 4) * sizeof(float) <= smem) {
+  // LDS writes are 4- / 2-way bank conflicts for a store pattern the L2 was already merging; PIPER_HIP_CONVT_LDS=2 forces it)
+  if (epi == EPI_CONVT && pc.up >= 2 &&
+      pol_.convt_through_lds(pc.up, tpb, BM, ((size_t)BM * BN + (size_t)(BM / pc.up) * 4) * sizeof(float), smem)) {
     int sh = 0;
     while ((1 << sh) < pc.up) ++sh;
     p.up_shift = sh;
@@ -1129,10 +1092,9 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     char nm[96];
     int n = snprintf(nm, sizeof(nm), "conv_mfma_kernel<%s,%s,%d>", knames[cfg], pc.gate ? "true" : "false", HALO);
     // tuning aid (PIPER_HIP_PROF_SITES=1): one profile row per conv SHAPE instead of per instantiation
-    if (prof_sites_) snprintf(nm + n, sizeof(nm) - n, "|%dx%dx%d d%d e%d L%d", pc.rows, pc.Cin, pc.ntaps, pc.dil, epi, len_mul);
+    if (pol_.prof_sites) snprintf(nm + n, sizeof(nm) - n, "|%dx%dx%d d%d e%d L%d", pc.rows, pc.Cin, pc.ntaps, pc.dil, epi, len_mul);
     kh = kbegin(krow(std::string(nm)), kflops, kbytes);
   }
-  p.xcd = xcd_tile_ ? xcd_period_ : 0;          // (column tile, row block) dealt to the XCDs column tile-major
   launch::conv_tile(cfg, pc.gate, HALO, grid, smem, ls_, p);
   kend(kh);
 }
@@ -1144,7 +1106,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
 // x <- x + c2_d(lrelu(c1_d(lrelu(x)))).
 void Engine::build_mrf(UpStage& st) {
   const int ch = st.ch;
-  if (!mrf_mode_ || ch > 64 || st.rb_host.empty()) return;
+  if (!pol_.mrf_build(ch) || st.rb_host.empty()) return;
   const int CP = ch <= 32 ? 32 : 64, MS = CP / 16, NCH = CP / KC, STEPF = MS * 512;
   const bool rb1 = arch_[A_RESBLOCK] == 1;
   int hx = 0;                              // halo of the stage = the widest resblock chain
@@ -1236,7 +1198,7 @@ bool Engine::mrf_geo(const UpStage& st, int len_mul, bool tail, MrfGeo& best) co
   best = MrfGeo{};
   double best_cost = 0;
   MrfGeo forced;
-  const int force = (mrf_ou_ >= 1 && mrf_ou_ <= OUMAX && geo(mrf_ou_, forced)) ? mrf_ou_ : 0;     // (tests / A-B; ignored when it does not fit)
+  const int force = (pol_.mrf_ou >= 1 && pol_.mrf_ou <= OUMAX && geo((int)pol_.mrf_ou, forced)) ? (int)pol_.mrf_ou : 0;     // (tests / A-B; ignored when it does not fit)
   for (int ou = 1; ou <= OUMAX; ++ou) {
     MrfGeo g;
     if ((force && ou != force) || !geo(ou, g)) continue;
@@ -1361,7 +1323,7 @@ void Engine::dds(const DdsW& d, View in, View out, View tmp, const DdsOpt* opt) 
   dds_params(d, in, out, tmp, opt, list);
   // Small calls of the 192-channel voices: 4-column workgroups on 4x the CUs (kernels/dds4.h). Every layer of the chain
   // needs its matrices in the 4x4x1 order; the form reads 4x the weight bytes, hence the column limit.
-  bool four = H_ == 192 && ksz_ <= 3 && use_col4((long)B_ * Tg_);
+  bool four = H_ == 192 && ksz_ <= 3 && pol_.chain4((long)B_ * Tg_);
   for (const DdsP& p : list) four = four && p.wp4 && (!p.post_w16 || p.post_w4);
   for (const DdsP& p : list) {
     if (four) {
@@ -1415,9 +1377,9 @@ void Engine::lngemm(View y, const float* g, const float* b, View x, const float*
     const int Tp = rup(T, 4);
     p.parts = parts; p.nparts = nparts; p.pbias = pbias;
     p.p_bs = (long)nparts * H_ * Tp;
-    if (!(use_col4((long)B_ * T) && w4_of(w16))) throw std::runtime_error("internal: FFN partials without the 4-column consumer");
+    if (!(pol_.chain4((long)B_ * T) && w4_of(w16))) throw std::runtime_error("internal: FFN partials without the 4-column consumer");
   }
-  if (const float* w4 = use_col4((long)B_ * T) ? w4_of(w16) : nullptr) {
+  if (const float* w4 = pol_.chain4((long)B_ * T) ? w4_of(w16) : nullptr) {
     p.w16 = w4;
     p.xcd = xcd_period_;
     const int kh4 = kbegin(prof_level_ >= 2 ? krow("lngemm4_kernel") : 0, flops, kbytes);
@@ -1435,7 +1397,7 @@ void Engine::lngemm(View y, const float* g, const float* b, View x, const float*
 // caller launches the conv kernel instead. `w16`: the conv's pack16 matrix (its pack4 twin is looked up).
 bool Engine::conv1x1_col4(const float* w16, const float* bias, int rows, View in, View out, const int* lens, int B, int Lmax,
                           double flops, const float* bias2, long bias2_bs, const float* w4direct, int kin, long max_cols) {
-  const bool small = col4_ && (col4_ == 2 || (long)B * Lmax <= (max_cols ? max_cols : col4_max_cols_));
+  const bool small = pol_.chain4((long)B * Lmax, max_cols);
   const float* w4 = (H_ == 192 && small) ? (w4direct ? w4direct : w4_of(w16)) : nullptr;
   if (!w4) return false;
   ColP cp{};
@@ -1459,7 +1421,7 @@ void Engine::colchain(const ColP& p, int B, int Lmax, double flops) {
   const double kbytes = 4.0 * (cols * (p.K1 + 2.0 * p.rows1 + (p.w2 ? p.rows2 : 0)) + (double)p.rows1 * p.K1 +
                                (p.w2 ? (double)p.rows2 * p.rows1 : 0.0));
   // mode 1 runs on frames (coupling post + pre), mode 0 on ids: separate column limits (profiles/r03_notes.md)
-  if (col4_ && (col4_ == 2 || (long)B * Lmax <= (p.mode == 1 ? col4_max_frames_ : col4_max_cols_)) && p.K1 == 192 && (p.mode == 0 ? p.rows1 == 192 : (p.rows1 == 96 && (!p.w2 || p.rows2 <= 192)))) {
+  if ((p.mode == 1 ? pol_.chain4_frames((long)B * Lmax) : pol_.chain4((long)B * Lmax)) && p.K1 == 192 && (p.mode == 0 ? p.rows1 == 192 : (p.rows1 == 96 && (!p.w2 || p.rows2 <= 192)))) {
     const float* w1 = w4_of(p.w1);
     const float* w2 = p.w2 ? w4_of(p.w2) : nullptr;
     if (w1 && (!p.w2 || w2)) {
@@ -1606,8 +1568,8 @@ void Engine::upload(const int64_t* ids, const int64_t* offsets, int B, const flo
 bool Engine::stage_a_ffn_fused() const {
   double tsum = 0;
   for (int b = 0; b < B_; ++b) tsum += tlens_h_[b];
-  const bool chain_q = use_colchain(tsum, colchain_max_ids_, H_, 96);
-  bool f = ffn_ && chain_q && use_col4((long)B_ * Tg_) && ffn_parts_ && (long)B_ * rup(Tg_, 4) <= ffn_max_cols_ &&
+  const bool chain_q = pol_.chain16(tsum, false, H_, 96);
+  bool f = pol_.ffn && chain_q && pol_.chain4((long)B_ * Tg_) && ffn_parts_ && (long)B_ * rup(Tg_, 4) <= LaunchPolicy::ffn_max_cols &&
            FC_ % 48 == 0 && FC_ / 48 <= 16 && w4_of(enc_proj16_);
   for (auto& e : enc_) f = f && e.f1p && e.f2p && w4_of(e.qkv16);
   return f;
@@ -1651,7 +1613,7 @@ void Engine::issue_stage_a() {
   // conv_o. Small batches with the 192-channel encoder run norm_layers_2 + that conv as one launch (lngemm_kernel), and
   // conv_o + residual + norm_layers_1 as another (colchain_kernel); otherwise conv, then ln_kernel.
   const float *pg = nullptr, *pb = nullptr;        // pending norm_layers_2 of the previous layer (input still in y)
-  const bool chain_q = use_colchain(tsum, colchain_max_ids_, H_, 96);
+  const bool chain_q = pol_.chain16(tsum, false, H_, 96);
   // Small calls: the FFN as ONE launch that leaves FC/48 partial outputs for lngemm4_kernel to sum (kernels/ffn.h). That
   // consumer then reads the residual from x and writes LN(y) to the other buffer (its parts read x concurrently): x / y
   // swap roles per layer.
@@ -1671,7 +1633,7 @@ void Engine::issue_stage_a() {
     // 16 queries of both heads per workgroup)
     const int ao_sp = rup(T, 64) + 2;
     const size_t ao_smem = ((size_t)2 * 16 * ao_sp + 2 * 64 * (dk_ + 1) + 2 * dk_ * 16 + (size_t)2 * (2 * window_ + 1) * dk_ + 8 * 256 + 256) * sizeof(float);
-    const bool attno = attno_ && chain_q && use_col4((long)B * T) && H_ == 192 && nh_ == 2 && dk_ == 96 && window_ <= 4 && e.o16 &&
+    const bool attno = pol_.attno && chain_q && pol_.chain4((long)B * T) && H_ == 192 && nh_ == 2 && dk_ == 96 && window_ <= 4 && e.o16 &&
                        ao_smem <= (size_t)160 * 1024;
     if (attno) {
       AttnOP ap{};
@@ -1724,7 +1686,7 @@ void Engine::issue_stage_a() {
     }      // !attno
     if (ffn_fused) {
       FfnP fp{};
-      fp.xcd = xcd_rows_ ? xcd_period_ : 0;
+      fp.xcd = pol_.xcd_ffn ? xcd_period_ : 0;          // (column tile, slice) dealt to the XCDs slice-major
       const int Tp = rup(T, 4);
       fp.x = x.p; fp.x_bs = x.bs; fp.x_cs = x.cs;
       fp.w1p = e.f1p; fp.b1 = e.f1.bias; fp.w2p = e.f2p;
@@ -1760,7 +1722,7 @@ void Engine::issue_stage_a() {
   if (!(chain_q && dp_pre16_ && conv1x1_col4(dp_pre16_, dp_pre_.bias, dp_pre_.rows, x, dy, d_tlens_, B, T, 2.0 * tsum * dp_pre_.macs_per_col,
                                              cb_dp, cond_bs_)))
     conv(dp_pre_, x, dy, d_tlens_, 1, T, EPI_STORE, 1.f, ACT_NONE, none, none, 0, 1.f, cb_dp, cond_bs_);
-  if (fuse_dp_) {
+  if (pol_.fuse_dp) {
     DdsOpt o;                      // dp.proj fused after the last DDSConv layer (models.py:65)
     o.post_w16 = dp_proj16_; o.post_bias = dp_proj_.bias; o.post_rows = dp_proj_.rows; o.post_out = xg;
     dds(dp_dds_, dy, dh, dy2, &o);
@@ -1772,7 +1734,7 @@ void Engine::issue_stage_a() {
   // z = noise * noise_scale_w   [B][2][Ts]
   if (!have_noise_w_)
     PE_LAUNCH_KB("randn_kernel", 4.0 * 2.0 * tsum, launch::randn(stream_, noise_w_, (long)B * 2, T, (long)Ts, 0L, d_rng_, 0));
-  if (!fuse_dp_) {
+  if (!pol_.fuse_dp) {
     const long n = (long)B * 2 * Ts;
     PE_LAUNCH_K("scale_kernel", launch::scale(dim3((unsigned)((n + 255) / 256)), stream_, noise_w_, z2_, n, scales_[2]));
   }
@@ -1784,7 +1746,7 @@ void Engine::issue_stage_a() {
     ++flips;
     const int c0 = (flips & 1) ? 1 : 0;     // physical channel holding logical x0
     const int c1 = 1 - c0;
-    if (fuse_dp_) {
+    if (pol_.fuse_dp) {
       // One launch per DDSConv layer and nothing else: ConvFlow.pre (+ g) is folded into the first layer's input,
       // proj and the spline run on the last layer's columns. The first flow reads the raw N(0,1) draw and applies
       // noise_scale_w itself; its spline epilogue also moves the pass-through channel into z2_.
@@ -1857,21 +1819,21 @@ void Engine::issue_flow() {
   auto VF = [&](float* p, int ch) { return View{p, (long)ch * Fs, Fs}; };
   const View fh = VF(fh_, H_), facts = VF(facts_, H_), fskip = VF(fskip_, H_);
   const int half = C_ / 2;
-  const bool chain = use_colchain(fsum, colchain_max_frames_, H_, half);
+  const bool chain = pol_.chain16(fsum, true, H_, half);
   for (size_t ri = 0; ri < rcls_.size(); ++ri) {
     Rcl& r = rcls_[ri];
     const View x0{zp_ + (long)r.in_off * Fs, (long)C_ * Fs, Fs};
     const View x1{zp_ + (long)r.out_off * Fs, (long)C_ * Fs, Fs};
     if (!(chain && ri > 0)) {                                                     // else: written by the previous layer's chain
       if (!(chain && r.pre4pad && conv1x1_col4(nullptr, r.pre.bias, r.pre.rows, x0, fh, lens_b_, B, Fmax, 2.0 * fsum * r.pre.macs_per_col,
-                                               nullptr, 0, r.pre4pad, half, col4_max_frames_)))
+                                               nullptr, 0, r.pre4pad, half, LaunchPolicy::col4_max_frames)))
         conv(r.pre, x0, fh, lens_b_, 1, Fmax, EPI_STORE);
     }
     const int nl = (int)r.in.size();
     for (int i = 0; i < nl; ++i) {
       const float* b2 = nspk_ > 1 ? cond_ + cond_off_wn_[ri] + (long)i * 2 * H_ : nullptr;
       conv(r.in[i], fh, facts, lens_b_, 1, Fmax, EPI_GATE, 1.f, ACT_NONE, none, none, 0, 1.f, b2, cond_bs_);
-      if (r.rs4[i] && col4_ && (col4_ == 2 || (long)B * Fmax <= col4_max_frames_) && H_ == 192 && r.rs[i].rows <= 2 * H_) {
+      if (r.rs4[i] && pol_.chain4_frames((long)B * Fmax) && H_ == 192 && r.rs[i].rows <= 2 * H_) {
         // small calls: the res/skip 1x1 conv on 4-column workgroups (colchain4_kernel mode 2), one part per 192 rows
         ColP cp{};
         cp.in1 = facts.p; cp.in1_bs = facts.bs; cp.in1_cs = facts.cs; cp.K1 = H_;
@@ -1965,10 +1927,9 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
       // one utterance and lose at batch (its 64-channel stage: 86 vs ~110 TFLOP/s for the conv GEMM kernel on K = 64 * 11
       // convs), so those are fused for one or two utterances and on 32 channels only.
       // (matrix mode bf16x3: the fused kernel is f32; from a few utterances up the conv-by-conv schedule on the bf16 pipe is faster)
-      const bool fuse = mrf_mode_ && st.mrf_ok && !(matrix_bf3_ && mrf_mode_ != 2 && fsum >= (double)bf3_min_frames_) &&
-                        (mrf_mode_ == 2 || !st.mrf_rb1 || (st.mrf_cp == 32 && fsum <= (double)mrf_rb1_max_frames_));
+      const bool fuse = pol_.mrf_stage(st.mrf_ok, st.mrf_rb1, st.mrf_cp, fsum, matrix_bf3_);
       // the last stage also runs the generator tail (conv_post, tanh, peak) on its MRF mean while it is still on chip
-      const bool tail = fuse && mrf_tail_ && &st == &ups_.back() && st.mrf_cp == 32 && st.ch == post_cin_ && mult == hop_;
+      const bool tail = fuse && pol_.mrf_tail && &st == &ups_.back() && st.mrf_cp == 32 && st.ch == post_cin_ && mult == hop_;
       // leaky_relu(0.1) -> ConvTranspose1d
       // (folding the up-conv into the stage kernel's prologue was built and measured: the window GEMM with its halo
       // recompute on the 209 workgroups of a single round costs what the launch costs -- profiles/r04_notes.md)
@@ -2014,7 +1975,7 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
       const long blocks64 = (long)((Lmax + 63) / 64) * ((st.ch + 63) / 64) * B;
       // grouped sibling launches are a single-utterance latency measure: measured -24 us (medium) / -4 % (high) at
       // B=1, but +1..2 % at B=2 and B=4, where every conv already fills the chip on its own
-      bool grp = group_mrf_ && B == 1 && nk >= 2 && nk <= 3 && blocks64 < 700 && need <= side_floats_;
+      bool grp = pol_.group_stage(B, nk, blocks64, need <= side_floats_);
       for (auto& cv : st.rb) {
         if (cv.size() != st.rb[0].size()) grp = false;
         for (auto& c : cv) grp = grp && can_group(c, Lmax);
@@ -2051,7 +2012,7 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
             fl += 2.0 * fsum * mult * cv[d].macs_per_col;
           }
           // the last step's outputs are only ever summed: one GEMM over the concatenated K writes the mean directly
-          if (d == nsteps - 1 && group_mrf_ != 2 && can_group_sum()) {
+          if (d == nsteps - 1 && pol_.group_sum() && can_group_sum()) {
             group_end_sum(xs, st.last_bias_sum, inv_nk);
             summed = true;
           } else {
@@ -2077,7 +2038,7 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
     if (!tail_done)
       PE_LAUNCH_KB("conv_post_kernel", 4.0 * fsum * hop_ * (post_cin_ + 1.0), launch::conv_post(dim3((Lmax + POST_SPB - 1) / POST_SPB, B), stream_, cur.p, cur.bs, cur.cs, post_w_, post_cin_, 0.01f, lens, hop_, audio_, Ss_, absmax_));
     // (the streaming window path delivers per chunk from the device buffer)
-    int16_t* zc = (pcm_zc_ && !zero_absmax && h_pcm_zc_cap_ >= (size_t)B * (size_t)Ss_) ? h_pcm_zc_ : nullptr;
+    int16_t* zc = (pol_.pcm_zc && !zero_absmax && h_pcm_zc_cap_ >= (size_t)B * (size_t)Ss_) ? h_pcm_zc_ : nullptr;
     PE_LAUNCH_KB("pcm16_kernel", fsum * hop_ * (4.0 + 2.0 + (zc ? 2.0 : 0.0)), launch::pcm16(dim3((Lmax + 255) / 256, B), stream_, audio_, Ss_, absmax_, lens, hop_, pcm_, Ss_, zc));
     prof_end(4, tail_done ? 0.0 : 2.0 * fsum * hop_ * post_cin_ * K);
   }
@@ -2116,7 +2077,7 @@ void Engine::run_stage(char which, const std::string& key) {
       g_capture_mu.unlock();
       g_capture_mu.lock_shared();
       ++graph_captures_;
-      if (graphs_.size() >= graph_cap_) {          // evict the least recently used graph only
+      if (graphs_.size() >= (size_t)pol_.graphs) {          // evict the least recently used graph only
         // (it may still be executing: destroying the exec object of a launched graph is deferred by the runtime until
         // the launch completes; the stream is in order, so nothing of this engine runs concurrently with it anyway)
         PE_HIP(hipStreamSynchronize(stream_));
@@ -2232,7 +2193,7 @@ void Engine::run() {
   Tg_ = std::min(id_bucket(Tmax_), Ts_);
   run_launches_ = 0;
   // speculative sizing of stage B from the previous run's frames-per-id ratio (see engine.h)
-  bool spec = spec_enable_ && B <= spec_max_batch_ && last_ratio_ > 0.f && !have_noise_z_ && use_graphs_ && !prof_on_;
+  bool spec = pol_.speculate(B) && last_ratio_ > 0.f && !have_noise_z_ && use_graphs_ && !prof_on_;
   if (spec && spec_cooldown_ > 0) { --spec_cooldown_; spec = false; }
   int fguess = 0;
   if (spec) {
@@ -2252,7 +2213,7 @@ void Engine::run() {
     // profiles/r04_notes.md). Grids and clamps are sized by Fg_; the real counts arrive in finish_run().
     frames_h_.resize(B);
     for (int b = 0; b < B; ++b)
-      frames_h_[b] = spec_expect_ ? std::min(Fg_, std::max(1, (int)std::ceil(last_ratio_ * (float)tlens_h_[b]))) : Fg_;
+      frames_h_[b] = pol_.spec_expect ? std::min(Fg_, std::max(1, (int)std::ceil(last_ratio_ * (float)tlens_h_[b]))) : Fg_;
     lens_b_ = d_framesc_;
     snprintf(key, sizeof(key), "C|%d|%d|%d|%a|%a|%d|%d|%d|%a", B, Tg_, Ts_, scales_[1], scales_[2], (int)have_noise_w_,
              Fs_, Fg_, scales_[0]);
@@ -2346,7 +2307,7 @@ void Engine::download(bool want_audio, bool want_pcm) {
     }
   };
   // pcm16_kernel already wrote the samples into pinned host memory (zero-copy), packed back to back: nothing to enqueue
-  const bool zc = pcm_zc_ && h_pcm_zc_ != nullptr && h_pcm_zc_cap_ >= (size_t)B_ * (size_t)Ss_;
+  const bool zc = pol_.pcm_zc && h_pcm_zc_ != nullptr && h_pcm_zc_cap_ >= (size_t)B_ * (size_t)Ss_;
   pcm_zc_live_ = false;
   if (spec_pending_ && B_ == 1 && (want_audio || want_pcm)) {
     // one utterance, speculative run: the copies are enqueued for the guessed length (>= the real one when the guess

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "pe_rt.h"
+#include "policy.h"
 #include "weights.h"
 
 namespace pe {
@@ -121,6 +122,8 @@ class Engine {
   size_t weight_bytes() const { return weight_bytes_; }
 
  private:
+  // every threshold and A/B knob that picks a kernel form (policy.h; read from the environment at engine creation)
+  LaunchPolicy pol_;
   // ---- setup
   void init(const WeightSet& ws);
   float* dev_copy(const std::vector<float>& v);
@@ -156,7 +159,6 @@ class Engine {
   // the recorded convs as ONE GEMM over their concatenated K, summed: out = (sum_j (res_j + conv_j)) * alpha
   bool can_group_sum() const;
   void group_end_sum(View out, const float* bias_sum, float alpha);
-  int group_mrf_ = 1;                        // PIPER_HIP_GROUP_MRF=0: sibling resblock convs one launch each (A/B, tests)
   enum { ROUTE_TILE = 0, ROUTE_SPLITK = 1, ROUTE_SPLITK16 = 2 };
   int route(const PackedConv& pc, int ncols, int epi) const;
   void layer_norm(View in, View out, const float* g, const float* b, int C, const int* lens, int Lmax);
@@ -178,29 +180,16 @@ class Engine {
   float* pack4(const std::vector<float>& W, int rows, int K);
   std::unordered_map<const float*, const float*> w4_of_;
   // fused FFN for small calls (kernels/ffn.h): per-slice weight orders, the partial-output buffer [b][slice][192][Tp]
-  // (allocated once for ffn_max_cols_ columns), and the buffer that holds the encoder output after the last layer (the
+  // (allocated once for LaunchPolicy::ffn_max_cols columns), and the buffer that holds the encoder output after the last layer (the
   // fused path ping-pongs x_ / y_: lngemm4_kernel must not write LN(y) over the residual other parts still read)
   const float* pack_ffn1(const WeightSet& ws, const std::string& wname);
   const float* pack_ffn2(const WeightSet& ws, const std::string& wname);
   float* ffn_parts_ = nullptr;
-  static constexpr long ffn_max_cols_ = 2048;
-  int ffn_ = 1;                             // PIPER_HIP_FFN=0: conv by conv (A/B, tests)
-  int convt_lds_ = 1;                       // PIPER_HIP_CONVT_LDS: up-conv tiles through LDS: 0 never, 1 stride >= 8 (measured), 2 every stride (tests)
-  bool prof_sites_ = false;                 // PIPER_HIP_PROF_SITES=1: level-2 profile rows of the tiled conv kernel per conv shape (tuning aid)
-  bool attno_ = true;                       // PIPER_HIP_ATTNO=0: attention and conv_o + LN as two launches (A/B, tests)
   bool stage_a_ffn_fused() const;
   float* stage_a_enc_out() const;
   const float* w4_of(const float* w16) const { auto it = w4_of_.find(w16); return it == w4_of_.end() ? nullptr : it->second; }
   float* dp_proj16_ = nullptr;
   float* dp_pre16_ = nullptr;
-  int colchain_ = 1;                        // PIPER_HIP_COLCHAIN: 0 off, 1 by batch size, 2 always (A/B, tests)
-  // batch columns up to which colchain_kernel / lngemm_kernel replace conv + LayerNorm pairs: ids for the encoder,
-  // frames for the flow. Measured (profiles/r02_notes.md): -3.5 % at B=1, -2.5 % at B=16, neutral at B=32, +1 % at B=64.
-  long colchain_max_ids_ = 4096, colchain_max_frames_ = 8192;
-  // colchain_kernel<6> is compiled for exactly 192 input channels (and 96 = half of them in the coupling layers)
-  bool use_colchain(double cols, long max_cols, int k1, int half) const {
-    return colchain_ && k1 == 192 && half == 96 && (colchain_ == 2 || cols <= (double)max_cols);
-  }
   void colchain(const struct ColP& p, int B, int Lmax, double flops);
   bool conv1x1_col4(const float* w16, const float* bias, int rows, View in, View out, const int* lens, int B, int Lmax,
                     double flops, const float* bias2 = nullptr, long bias2_bs = 0, const float* w4direct = nullptr, int kin = 192,
@@ -213,16 +202,8 @@ class Engine {
   // and the period P when it is a round-robin over P XCDs (0: anything else -- the 4-column kernels then use tile = id)
   int xcc_of_[64] = {0};
   int xcd_period_ = 0;
-  bool xcd_tile_ = true;                    // PIPER_HIP_XCD_TILE=0: the tiled conv kernel takes (column tile, row block) = blockIdx (A/B)
-  bool spec_expect_ = true;                 // PIPER_HIP_SPEC_EXPECT=0: speculative graphs planned for the bucket capacity instead of the expected frames (A/B)
-  bool xcd_rows_ = true;                    // PIPER_HIP_XCD_ROWS=0: split-K convs and the fused FFN take (column tile, row part) = blockIdx (A/B)
   void probe_xcds();
-  int col4_ = 1;                            // PIPER_HIP_COL4: 4-column workgroups for the DDSConv layers: 0 off, 1 up to col4_max_cols_ columns per call, 2 always (A/B, tests)
-  long col4_max_cols_ = 1024;               // ids per call (text encoder, duration predictor)
-  long col4_max_frames_ = 2048;             // frames per call (WN res/skip conv): the sweep in profiles/r03_notes.md
-  bool use_col4(long cols) const { return col4_ && (col4_ == 2 || cols <= col4_max_cols_); }
   static size_t col4_smem() { return ((size_t)4 * 196 + 4 * 192 * 4 + 32 + 64 * 4) * sizeof(float); }   // YT | P | red | ZL (kernels/col4.h, dds4.h)
-  bool fuse_dp_ = true;                     // PIPER_HIP_FUSE_DP=0: cf_pre / proj / spline as separate launches (A/B, tests)
   void issue_stage_a();
   void issue_stage_b();
   void issue_flow();
@@ -231,15 +212,15 @@ class Engine {
   void run_stage(char which, const std::string& key);
   void dispatch_stage(char which);
   void drop_graphs();
-  // Speculative stage B (one to spec_max_batch_ utterances): the frame count F is the path's only data-dependent
+  // Speculative stage B (one to LaunchPolicy::spec_max_batch utterances): the frame count F is the path's only data-dependent
   // shape and normally costs a host round trip in the middle of the pipeline. When a previous run of this engine gives
   // a frames-per-id estimate, stage B is launched right behind stage A for a guessed bucket (kernels read the true
   // lengths from device memory, clamped to the allocated capacity), and the guess is verified when the results are
   // fetched; a wrong guess re-runs stage B with the right size.
   bool finish_run();                 // completes a speculative run; false if stage B had to be re-run
   void finish_stage_b_sizes();
-  bool spec_enable_ = true, spec_pending_ = false;
-  int spec_max_batch_ = 4, spec_fg_ = 0;
+  bool spec_pending_ = false;
+  int spec_fg_ = 0;
   int spec_fg_force_ = 0;            // warm-up only: the frame bucket the next speculative run is issued for
   // The guess = (slowly decaying maximum of the frames-per-id ratios seen so far) x margin. The margin adapts: a miss
   // widens it (x 1.15, up to 1.5), 32 hits in a row narrow it again (down to 1.10); four misses within 16 speculative
@@ -314,24 +295,15 @@ class Engine {
   bool mrf_geo(const UpStage& st, int len_mul, bool tail, MrfGeo& best) const;      // window geometry by the cost model
   void build_mrf(UpStage& st);
   void mrf(const UpStage& st, View x, View out, const int* lens, int len_mul, int Lmax, bool tail = false);
-  int mrf_mode_ = 1;                        // PIPER_HIP_MRF: 0 off (conv by conv), 1 by the measured policy, 2 wherever it applies
-  long mrf_rb1_max_frames_ = 1100;          // ResBlock1 stages: batch frames up to which the fused kernel is used in mode 1
-  bool mrf_tail_ = true;                    // PIPER_HIP_MRF_TAIL=0: conv_post_kernel as its own launch behind a fused last stage
-  int mrf_ou_ = 0;                          // PIPER_HIP_MRF_OU=1..4 forces the output units per wave (tests); 0 = cost model
   // Opt-in matrix mode PIPER_HIP_MATRIX=bf16x3 (read at engine creation): the tiled conv GEMMs of the coupling flow and
   // the generator run on the bf16 matrix pipe with split operands (kernels/conv_bf3.h; ~16 mantissa bits per operand,
   // f32 accumulate, 3 MFMAs at 16x the f32 rate). The text encoder and the duration predictor stay f32 (the integer
   // durations are those of the f32 path), and so does every latency-bound split-K launch. Default: off, all f32.
   bool matrix_bf3_ = false, pack_bf3_now_ = false;
-  long bf3_min_frames_ = 1100;              // batch frames from which the <= 64-channel MRF stages run conv by conv on
-                                            // the bf16 pipe instead of the fused f32 stage kernel (PIPER_HIP_BF3_MINF)
   static bool env_bf3();
  public:
   bool matrix_bf3() const { return matrix_bf3_; }
  private:
-  int splitk16_ = 2;                        // 16-column split-K: 0 off, 1 WN gate conv, 2 also long-K plain convs, 3 all (tests)
-  int wide_splitk_ = 1;                     // 12-wave split-K workgroups for long-K launches
-  long splitk_max_blocks_ = 96;             // launches with fewer tile-kernel workgroups use conv_splitk_kernel
   std::vector<UpStage> ups_;
   float* post_w_ = nullptr;
   int post_cin_ = 0;
@@ -344,13 +316,11 @@ class Engine {
   // per-call state
   int B_ = 0, Tmax_ = 0, Ts_ = 0, Fmax_ = 0, Fs_ = 0, Tg_ = 0, Fg_ = 0;
   bool use_graphs_ = true;
-  int tpb_override_ = 0;
   // hipGraphExec_t per (stage, shape bucket, scales), least recently used first: a new key beyond graph_cap_ entries
   // evicts ONE graph (the coldest), never the whole cache
   struct GraphEntry { std::string key; void* exec; long launches; };
   std::list<GraphEntry> graphs_;
   std::unordered_map<std::string, std::list<GraphEntry>::iterator> graph_of_;
-  size_t graph_cap_ = 64;                     // PIPER_HIP_GRAPHS
   long graph_captures_ = 0;                   // captures since the engine was created (pe_graph_stats)
  public:
   long graph_captures() const { return graph_captures_; }
@@ -414,7 +384,6 @@ class Engine {
   // call ends with one stream synchronisation.
   int16_t* h_pcm_zc_ = nullptr; size_t h_pcm_zc_cap_ = 0;
   bool pcm_zc_live_ = false;                // the last run's PCM is in h_pcm_zc_
-  bool pcm_zc_ = true;                      // PIPER_HIP_PCM_ZC=0: always copy (A/B, tests)
   int* h_frames_ = nullptr;
 
   // profiling
@@ -431,7 +400,6 @@ class Engine {
   int krow(const char* name);
   int krow(const std::string& name);
   std::deque<std::string> names_;            // storage of generated profile row names (stable pointers)
-  bool debug_keep_ = false;                   // PIPER_HIP_DEBUG_KEEP=1: keep z_p (the flow's input) for debug_tensor
   float* zp_keep_ = nullptr;
   void free_all();
 };

@@ -41,14 +41,11 @@ void conv_mfma_kernel(ConvP p) {
   const int L = p.lens[b] * p.len_mul;
   const int ncols = (p.epi == EPI_CONVT) ? L + 1 : L;
   // a workgroup walks p.tpb consecutive column tiles (1 by default, profiles/r01_tpb_sweep.txt)
-  int bx = blockIdx.x, by = blockIdx.y;           // (column tile, row block): column tile-major over the XCDs (pe_rt.h)
-  pe_xcd_yx(p.xcd, bx, by);
-  bx = PE_UNIFORM(bx); by = PE_UNIFORM(by);
-  const int tile0 = bx * p.tpb;
+  const int tile0 = blockIdx.x * p.tpb;
   const int ntile_all = (ncols + BN - 1) / BN;
   if (tile0 >= ntile_all) return;
   const int ntl = (ntile_all - tile0) < p.tpb ? (ntile_all - tile0) : p.tpb;
-  const int m0 = by * BM;
+  const int m0 = blockIdx.y * BM;
   const int tid = threadIdx.x, lane = tid & 63, wv = PE_UNIFORM(tid >> 6);
   const int wm = wv / WN, wn = wv % WN;
   const int l31 = lane & 31, lhi = lane >> 5;

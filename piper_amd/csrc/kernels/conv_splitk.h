@@ -26,10 +26,7 @@ namespace pe {
 // segment c / nchunks. With 4 chunk lanes and 4 chunks per segment every wave gets one chunk of each conv.
 template <int MT, bool GATE, int NW, int D, int XW, bool MS = false>
 __device__ __forceinline__ void conv_splitk_body(const ConvP& p, const int b, float* sm) {
-  // (column tile, row part): row part-major over the XCDs (pe_rt.h pe_xcd_xy; p.xcd <= 1: blockIdx as it is)
-  int bx = blockIdx.x, by = blockIdx.y;
-  pe_xcd_xy(p.xcd, bx, by);
-  bx = PE_UNIFORM(bx); by = PE_UNIFORM(by);
+
   constexpr int BN = 32, KH = KC / 2, XB = XW / 64;
   constexpr int NS = GATE ? (16 + NW - 1) / NW : (MT * 16 + NW - 1) / NW;    // epilogue slots per wave
   // sm: NW x [KC][XW] slabs, then NW x [MT*16][64] partial tiles
@@ -37,11 +34,10 @@ __device__ __forceinline__ void conv_splitk_body(const ConvP& p, const int b, fl
   // The utterance length lives in device memory (one graph per shape bucket). Nothing below touches it until the
   // x slab and the first weight fragments are requested, so its latency overlaps theirs instead of preceding them.
   const int L = p.lens[b] * p.len_mul;
-  const int n0 = bx * BN;
+  const int n0 = blockIdx.x * BN;
   const int tid = threadIdx.x, lane = tid & 63, wv = PE_UNIFORM(tid >> 6);
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int mtile0 = by * MT;
-  if (mtile0 * 32 >= p.rows) return;              // grouped launches: a sibling with fewer row tiles than the grid
+  const int mtile0 = blockIdx.y * MT;
   const int col = n0 + l31;
   const int ntaps = p.ntaps, nchunks = MS ? p.nchunks * p.nseg : p.nchunks;     // MS: chunks of the concatenated K
   const int wstride_mt = p.nchunks * ntaps * KH * 64;
@@ -282,7 +278,7 @@ __global__ __launch_bounds__(64 * NW, XW == 64 ? 4 : 2) void conv_splitk_group_k
   PE_DYN_SMEM(float, sm);
   const int gi = PE_UNIFORM((int)blockIdx.z / g.B);
   const ConvP& p = g.c[gi];
-  // (a sibling with fewer row tiles than the grid: its surplus workgroups leave inside the body, after the tile map)
+  if ((int)blockIdx.y * 32 >= p.rows) return;              // a sibling with fewer row tiles than the grid
   conv_splitk_body<1, false, NW, D, XW>(p, (int)blockIdx.z - gi * g.B, sm);
 }
 // The siblings' LAST convs, whose outputs the MRF sums: one GEMM over the concatenated K (MS form of the body), one
@@ -313,13 +309,10 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk16_kernel(ConvP p) {
   PE_DYN_SMEM(float, sm);                         // NW x [KC][XW] slabs, then NW x [MT16*4][64] partial tiles
   const int b = blockIdx.z;
   const int L = p.lens[b] * p.len_mul;            // first used after the loads below are in flight
-  int bx = blockIdx.x, by = blockIdx.y;           // (column tile, row part): row part-major over the XCDs (pe_rt.h)
-  pe_xcd_xy(p.xcd, bx, by);
-  bx = PE_UNIFORM(bx); by = PE_UNIFORM(by);
-  const int n0 = bx * BN;
+  const int n0 = blockIdx.x * BN;
   const int tid = threadIdx.x, lane = tid & 63, wv = PE_UNIFORM(tid >> 6);
   const int l15 = lane & 15, lq = lane >> 4;
-  const int st0 = by * MT16;                      // first 16-row sub-tile of this workgroup
+  const int st0 = blockIdx.y * MT16;              // first 16-row sub-tile of this workgroup
   const int col = n0 + l15;
   const int ntaps = p.ntaps, nchunks = p.nchunks;
   const int sub_stride = nchunks * ntaps * KS8 * 64;          // floats per 16-row sub-tile
@@ -394,7 +387,7 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk16_kernel(ConvP p) {
     const int s = wv + NW * i;
     e_b1[i] = 0.f; e_b2[i] = 0.f; e_o1[i] = 0.f; e_o2[i] = 0.f; e_dst[i] = nullptr;
     if constexpr (GATE) {
-      const int ch = by * 32 + (s >> 2) * 16 + 4 * lq + (s & 3);
+      const int ch = blockIdx.y * 32 + (s >> 2) * 16 + 4 * lq + (s & 3);
       if (s < NSLOT && ch < p.split && col < ncols) {
         e_b1[i] = p.bias[ch];
         e_o1[i] = p.bias[p.split + ch];

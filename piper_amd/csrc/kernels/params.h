@@ -37,8 +37,6 @@ struct ConvP {
   float alpha;                                  // ACCUM last/only: scale
   int tpb;                                      // conv_mfma_kernel: column tiles walked by one workgroup
   int tgroups;                                  // conv_splitk_kernel: 1, or 2 = two halves of the waves split the taps
-  int xcd;                                      // split-K kernels: XCDs the dispatch round-robins over -> (column tile, row part) by
-                                                // pe_xcd_xy (pe_rt.h); 0 / 1: (blockIdx.x, blockIdx.y)
   // conv_splitk_body<..., MS = true> only: K = the concatenation of nseg convs of one shape whose outputs are summed
   // (segment 0 repeats x / wp / ntaps / dil / padl); res2 / res3 = the residual tensors of segments 1 / 2
   int nseg;

@@ -328,6 +328,8 @@ int pe_graph_stats(pe_engine* e, int64_t* cached, int64_t* captures) {
   });
 }
 
+const char* pe_policy_describe(void) { return pe::LaunchPolicy::describe(); }
+
 int pe_xcc_pattern(pe_engine* e, int32_t xcc[64], int32_t* period) {
   return guard([&] {
     if (!e) throw std::runtime_error("null engine");

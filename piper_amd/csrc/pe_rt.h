@@ -162,11 +162,14 @@ __device__ __forceinline__ int pe_xcd_tile(int id, int n, int P) {
   const int q = n / P, r = n - q * P, i = id / P, j = id - i * P;
   return j * q + (j < r ? j : r) + i;
 }
-// The same for a (column tile x, row part y) grid plane whose row parts read DIFFERENT weights (split-K convs, the fused
-// FFN's slices): tiles are numbered row part-major, so an XCD's run covers one or two row parts and its L2 fetches only
-// their weights -- with (x, y) = blockIdx every L2 pulled the whole layer through the fabric (the gate conv of a
-// one-utterance call: 14.5 MB of traffic per launch for 2.1 MB of operands, profiles/r04_pmc_traffic.json). The planes
-// of a 3-D grid are mapped one by one: within a plane a residue class still sits on ONE XCD.
+// The same for a (column tile x, row part y) grid plane whose row parts read DIFFERENT weights: tiles are numbered row
+// part-major, so an XCD's run covers one or two row parts and its L2 fetches only their weights. Used by ffn_kernel (16
+// slices of the hidden dimension: 30.8 MB of fabric traffic per launch for 5.2 MB of operands with (x, y) = blockIdx,
+// profiles/r04_pmc_traffic.json; 9.98 -> 8.81 us per launch with the map). Measured and NOT used (profiles/r04_notes.md):
+// the split-K convs (the gate conv 10.03 -> 10.26 us: 27 workgroups asking ONE L2 for the same weight lines at the same
+// moment cost more than eight L2s fetching them once each), and a column tile-major order for the tiled conv kernel
+// (+1 % at one utterance, +0.5 % / +6.5 % on the medium / high voice at 64). The planes of a 3-D grid are mapped one by
+// one: within a plane a residue class still sits on ONE XCD.
 __device__ __forceinline__ void pe_xcd_xy(int P, int& bx, int& by) {
   if (P <= 1) return;
   const int nx = (int)gridDim.x;
@@ -174,17 +177,6 @@ __device__ __forceinline__ void pe_xcd_xy(int P, int& bx, int& by) {
   by = t / nx;
   bx = t - by * nx;
 }
-// Column tile-major, for the tiled conv kernel whose row blocks of one column tile read the SAME x slab: an XCD's run
-// holds all row blocks of a column tile back to back, so the slab comes through the fabric once instead of once per row
-// block (up to 16 for the first up-conv) and the later row blocks hit in that XCD's L2.
-__device__ __forceinline__ void pe_xcd_yx(int P, int& bx, int& by) {
-  if (P <= 1) return;
-  const int ny = (int)gridDim.y;
-  const int t = pe_xcd_tile(by * (int)gridDim.x + bx, (int)gridDim.x * ny, P);
-  bx = t / ny;
-  by = t - bx * ny;
-}
-
 #include <stdexcept>
 #include <string>
 

@@ -1,0 +1,90 @@
+// The knob table of the launch policy (policy.h): one row per environment variable.
+#include "policy.h"
+
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+
+namespace pe {
+
+static const LaunchPolicy::Knob kKnobs[] = {
+    {"PIPER_HIP_MRF", &LaunchPolicy::mrf, 0, 2, "fused MRF stage kernel: 0 off (conv by conv), 1 by the measured policy (ResBlock2 stages always; ResBlock1 stages on 32 channels up to PIPER_HIP_MRF_MAXF frames per call), 2 wherever it applies"},
+    {"PIPER_HIP_MRF_MAXF", &LaunchPolicy::mrf_maxf, 0, 1L << 40, "batch frames up to which a 32-channel ResBlock1 stage runs in the fused kernel (mode 1)"},
+    {"PIPER_HIP_MRF_OU", &LaunchPolicy::mrf_ou, 0, 4, "force the output units per wave of mrf_kernel (1..4) instead of the cost model; ignored when the width does not fit"},
+    {"PIPER_HIP_MRF_TAIL", &LaunchPolicy::mrf_tail, 0, 1, "generator tail inside the last stage's mrf_kernel (0: separate conv_post_kernel)"},
+    {"PIPER_HIP_BF3_MINF", &LaunchPolicy::bf3_minf, 0, 1L << 40, "matrix mode bf16x3: batch frames from which the <= 64-channel MRF stages run conv by conv on the bf16 pipe"},
+    {"PIPER_HIP_SPLITK_MAX", &LaunchPolicy::splitk_max, 0, 1L << 40, "tile-workgroup count below which a conv goes to the split-K kernels (0: always the tiled kernel)"},
+    {"PIPER_HIP_SPLITK16", &LaunchPolicy::splitk16, 0, 3, "16-column split-K form: 0 off, 1 gate convs, 2 + long-K plain convs, 3 everywhere"},
+    {"PIPER_HIP_WIDE_SPLITK", &LaunchPolicy::wide_splitk, 0, 2, "12-wave split-K: 0 off, 1 WN gate conv, 2 always"},
+    {"PIPER_HIP_TPB", &LaunchPolicy::tpb, 0, 64, "tiled kernel: column tiles walked by one workgroup (0 = 1)"},
+    {"PIPER_HIP_GROUP_MRF", &LaunchPolicy::group_mrf, 0, 2, "sibling resblock convs of a wider small stage as grouped launches (one-utterance calls): 0 off, 2 without the K-concatenated last step"},
+    {"PIPER_HIP_COLCHAIN", &LaunchPolicy::colchain, 0, 2, "colchain_kernel / lngemm_kernel: 0 off, 1 up to 4096 ids / 8192 frames per call, 2 always"},
+    {"PIPER_HIP_COL4", &LaunchPolicy::col4, 0, 2, "4-column forms of the 192-channel chains: 0 off, 1 up to PIPER_HIP_COL4_MAXC ids (2048 frames for the flow's launches) per call, 2 always"},
+    {"PIPER_HIP_COL4_MAXC", &LaunchPolicy::col4_maxc, 0, 1L << 40, "ids per call up to which the 4-column chains are used"},
+    {"PIPER_HIP_FFN", &LaunchPolicy::ffn, 0, 1, "the encoder FFN as one launch (ffn_kernel) wherever the 4-column chains run: 0 = conv by conv"},
+    {"PIPER_HIP_ATTNO", &LaunchPolicy::attno, 0, 1, "attention + conv_o + norm_layers_1 as one launch (attno_kernel) wherever the 4-column chains run: 0 = attn_kernel + colchain4_kernel"},
+    {"PIPER_HIP_FUSE_DP", &LaunchPolicy::fuse_dp, 0, 1, "ConvFlow.pre / proj / spline fused into the DDSConv layer launches"},
+    {"PIPER_HIP_SPEC", &LaunchPolicy::spec, 0, 1, "speculative stage-B sizing / whole utterance as one graph for <= 4 utterances per call"},
+    {"PIPER_HIP_SPEC_EXPECT", &LaunchPolicy::spec_expect, 0, 1, "speculative graphs planned for the expected frame counts (0: for the bucket capacity)"},
+    {"PIPER_HIP_PCM_ZC", &LaunchPolicy::pcm_zc, 0, 1, "PCM written straight into pinned host memory by pcm16_kernel (0: one copy per utterance behind the graph)"},
+    {"PIPER_HIP_NO_GRAPH", &LaunchPolicy::no_graph, 0, 1, "launch kernels directly instead of replaying hipGraphs"},
+    {"PIPER_HIP_GRAPHS", &LaunchPolicy::graphs, 1, 4096, "hipGraphs kept per engine (least recently used evicted one at a time)"},
+    {"PIPER_HIP_CONVT_LDS", &LaunchPolicy::convt_lds, 0, 2, "polyphase up-conv tiles leave through LDS as rows of consecutive samples: 0 never, 1 stride >= 8, 2 every stride"},
+    {"PIPER_HIP_XCD", &LaunchPolicy::xcd, -1, 32, "XCDs the dispatch round-robins over, for the XCD-aware tile orders (-1 = probed at engine creation, 0 = tiles in workgroup order)"},
+    {"PIPER_HIP_XCD_FFN", &LaunchPolicy::xcd_ffn, 0, 1, "ffn_kernel deals (column tile, slice) to the XCDs slice-major, so an XCD's L2 holds two slices' weights instead of all sixteen (0: blockIdx order)"},
+    {"PIPER_HIP_PROF_SITES", &LaunchPolicy::prof_sites, 0, 1, "level-2 profile rows of the tiled conv kernel per conv shape (tuning aid)"},
+    {"PIPER_HIP_DEBUG_KEEP", &LaunchPolicy::debug_keep, 0, 1, "test hook: keep z_p for pe_debug_tensor"},
+};
+
+const LaunchPolicy::Knob* LaunchPolicy::knobs(int* n) {
+  if (n) *n = (int)(sizeof(kKnobs) / sizeof(kKnobs[0]));
+  return kKnobs;
+}
+
+void LaunchPolicy::read_env() {
+  for (const Knob& k : kKnobs) {
+    const char* t = getenv(k.env);
+    if (!t || !*t) continue;
+    errno = 0;
+    char* end = nullptr;
+    const long v = strtol(t, &end, 10);
+    if (errno || end == t || *end)
+      throw std::runtime_error(std::string(k.env) + "=" + t + ": not an integer (" + k.doc + ")");
+    this->*k.field = v < k.lo ? k.lo : (v > k.hi ? k.hi : v);
+  }
+}
+
+bool LaunchPolicy::matrix_bf3_env() {
+  const char* t = getenv("PIPER_HIP_MATRIX");
+  if (!t || !t[0] || !strcmp(t, "f32")) return false;
+  if (!strcmp(t, "bf16x3")) return true;
+  throw std::runtime_error("PIPER_HIP_MATRIX: expected f32 or bf16x3");
+}
+
+const char* LaunchPolicy::describe() {
+  static std::string out;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    const LaunchPolicy d;
+    out = "[";
+    for (const Knob& k : kKnobs) {
+      char head[160];
+      snprintf(head, sizeof(head), "%s{\"env\":\"%s\",\"default\":%ld,\"lo\":%ld,\"hi\":%ld,\"doc\":\"", out.size() > 1 ? "," : "", k.env,
+               d.*k.field, k.lo, k.hi);
+      out += head;
+      for (const char* c = k.doc; *c; ++c) {
+        if (*c == '"' || *c == '\\') out += '\\';
+        out += *c;
+      }
+      out += "\"}";
+    }
+    out += "]";
+  });
+  return out.c_str();
+}
+
+}  // namespace pe

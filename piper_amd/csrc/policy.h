@@ -1,0 +1,96 @@
+// Launch policy of the engine: every threshold and A/B knob that decides WHICH kernel form a launch takes, in ONE place.
+//
+// The engine (engine*.cpp) asks the questions below with plain numbers -- workgroup counts, columns per call, halo
+// widths -- and never reads the environment or compares against a tuning constant itself. The knobs are one table
+// (environment variable, field, range, meaning), read once at engine creation; their defaults are the measured choices
+// (profiles/r01..r04_notes.md carry the A/B behind each one). They exist so that every kernel variant can be forced on any
+// shape by the parity tests and A/B-ed on one box: the product needs none of them. A value that is not an integer is an
+// error (engine creation fails with the variable's name); a value outside the range is clamped to it.
+#pragma once
+#include <cstddef>
+
+namespace pe {
+
+struct LaunchPolicy {
+  // ---- knobs (field = default)
+  long mrf = 1;               // fused MRF stage kernel: 0 off (conv by conv), 1 by the measured policy, 2 wherever it applies
+  long mrf_maxf = 1100;       // ResBlock1 stages on 32 channels: batch frames up to which the fused kernel is used in mode 1
+  long mrf_ou = 0;            // force the output units per wave of mrf_kernel (1..4); 0 = cost model
+  long mrf_tail = 1;          // generator tail (conv_post, tanh, peak) inside the last stage's mrf_kernel
+  long bf3_minf = 1100;       // matrix mode bf16x3: batch frames from which the <= 64-channel stages run conv by conv on the bf16 pipe
+  long splitk_max = 96;       // tile-kernel workgroups below which a conv goes to the split-K kernels (0: always the tiled kernel)
+  long splitk16 = 2;          // 16-column split-K: 0 off, 1 WN gate conv, 2 + long-K plain convs, 3 everywhere (tests)
+  long wide_splitk = 1;       // 12-wave split-K workgroups: 0 off, 1 WN gate conv, 2 always (tests)
+  long tpb = 0;               // tiled kernel: column tiles walked by one workgroup (0 = 1, the measured choice)
+  long group_mrf = 1;         // sibling resblock convs of a wider one-utterance stage as grouped launches: 0 off, 2 without the K-concatenated last step
+  long colchain = 1;          // colchain_kernel / lngemm_kernel: 0 off, 1 by batch size, 2 always
+  long col4 = 1;              // 4-column forms of the 192-channel chains: 0 off, 1 by batch size, 2 always
+  long col4_maxc = 1024;      // ... up to this many ids per call (text encoder, duration predictor)
+  long ffn = 1;               // encoder FFN as one launch (ffn_kernel) wherever the 4-column chains run
+  long attno = 1;             // attention + conv_o + norm_layers_1 as one launch wherever the 4-column chains run
+  long fuse_dp = 1;           // ConvFlow.pre / proj / spline fused into the DDSConv layer launches
+  long spec = 1;              // speculative stage-B sizing: the whole utterance as one graph for <= spec_max_batch utterances
+  long spec_expect = 1;       // speculative graphs planned for the expected frame counts (0: for the bucket capacity)
+  long pcm_zc = 1;            // int16 PCM written straight into pinned host memory by pcm16_kernel
+  long no_graph = 0;          // launch kernels directly instead of replaying hipGraphs
+  long graphs = 64;           // hipGraphs kept per engine (least recently used evicted one at a time)
+  long convt_lds = 1;         // polyphase up-conv tiles through LDS: 0 never, 1 stride >= 8 (measured), 2 every stride (tests)
+  long xcd = -1;              // XCDs the dispatch round-robins over: -1 = probed at engine creation, 0 = tiles in workgroup order
+  long xcd_ffn = 1;           // fused FFN: (column tile, slice) dealt to the XCDs slice-major (0: blockIdx order)
+  long prof_sites = 0;        // level-2 profile rows of the tiled conv kernel per conv SHAPE (tuning aid)
+  long debug_keep = 0;        // test hook: keep z_p for pe_debug_tensor
+
+  // ---- thresholds without a knob (measured once, profiles/r02_notes.md / r03_notes.md)
+  static constexpr long colchain_max_ids = 4096, colchain_max_frames = 8192;   // colchain / lngemm replace conv + LN pairs up to here
+  static constexpr long col4_max_frames = 2048;   // 4-column WN res/skip conv and coupling pre: frames per call
+  static constexpr long ffn_max_cols = 2048;      // ffn_kernel's partial-output buffer is allocated for this many columns
+  static constexpr int spec_max_batch = 4;        // utterances per call up to which stage B is sized speculatively
+  static constexpr long group_max_blocks64 = 700; // grouped sibling launches: 64-column tiles of the stage up to which they pay
+
+  struct Knob { const char* env; long LaunchPolicy::*field; long lo, hi; const char* doc; };
+  static const Knob* knobs(int* n);
+  // reads every knob that is set; throws std::runtime_error naming the variable when its value is not an integer
+  void read_env();
+  // the table as a JSON array (name, default, lo, hi, doc): pe_policy_describe() of the C ABI, DESIGN.md section 4.1
+  static const char* describe();
+  // the one string-valued knob: PIPER_HIP_MATRIX = f32 (default) | bf16x3 (opt-in matrix mode, kernels/conv_bf3.h); anything
+  // else throws
+  static bool matrix_bf3_env();
+
+  // ---- decisions ------------------------------------------------------------------------------------------------
+  // conv routing (engine_launch.cpp Engine::conv): `blocks` = workgroups the tiled kernel would launch, `halo` =
+  // (taps - 1) * dilation, `units` = 32-channel chunks x taps of the K loop
+  bool splitk(long blocks, int halo) const { return blocks < splitk_max && halo <= 32; }
+  bool groupable(bool gate, bool convt, long blocks, int halo) const { return !gate && !convt && blocks < splitk_max && halo <= 96; }
+  bool splitk_16col(bool packed16, bool convt, bool gate, int units) const {
+    return packed16 && !convt && ((gate && splitk16 >= 1) || (!gate && splitk16 >= 2)) && (units >= 24 || splitk16 >= 3);
+  }
+  bool splitk_12wave(bool gate, int units, int nchunks, int ntaps) const {
+    return (wide_splitk == 1 && gate && units >= 24 && nchunks <= 6 && ntaps >= 4) || wide_splitk == 2;
+  }
+  int tiles_per_workgroup() const { return tpb > 0 ? (int)tpb : 1; }
+  // polyphase up-conv tile through LDS (stride a power of two that divides the tile's rows, one tile per workgroup)
+  bool convt_through_lds(int stride, int tiles_per_wg, int BM, size_t tile_bytes, size_t smem_bytes) const {
+    return convt_lds && (stride >= 8 || convt_lds == 2) && tiles_per_wg == 1 && stride >= 2 && (stride & (stride - 1)) == 0 &&
+           BM % stride == 0 && tile_bytes <= smem_bytes;
+  }
+  // 192-channel chains
+  bool chain16(double cols, bool frames, int k1, int half) const {     // colchain_kernel<6> / lngemm_kernel<6>
+    return colchain && k1 == 192 && half == 96 && (colchain == 2 || cols <= (double)(frames ? colchain_max_frames : colchain_max_ids));
+  }
+  bool chain4(long cols, long limit = 0) const { return col4 && (col4 == 2 || cols <= (limit ? limit : col4_maxc)); }
+  bool chain4_frames(long cols) const { return chain4(cols, col4_max_frames); }
+  // fused MRF stage
+  bool mrf_build(int channels) const { return mrf != 0 && channels <= 64; }
+  bool mrf_stage(bool built, bool resblock1, int padded_channels, double frames, bool matrix_bf3) const {
+    return mrf && built && !(matrix_bf3 && mrf != 2 && frames >= (double)bf3_minf) &&
+           (mrf == 2 || !resblock1 || (padded_channels == 32 && frames <= (double)mrf_maxf));
+  }
+  bool group_stage(int B, int nk, long blocks64, bool buffers_fit) const {
+    return group_mrf && B == 1 && nk >= 2 && nk <= 3 && blocks64 < group_max_blocks64 && buffers_fit;
+  }
+  bool group_sum() const { return group_mrf != 2; }
+  bool speculate(int B) const { return spec && !no_graph && B <= spec_max_batch; }
+};
+
+}  // namespace pe

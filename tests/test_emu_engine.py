@@ -517,35 +517,40 @@ def test_emulated_upconv_tile_through_lds_is_bit_identical(emu_lib, monkeypatch,
     assert np.max(np.abs(res["2"].audio[0] - o["audio"])) < 1e-4
 
 
-@pytest.mark.parametrize("knob,extra", [("PIPER_HIP_XCD_ROWS", {}), ("PIPER_HIP_XCD_TILE", {"PIPER_HIP_SPLITK_MAX": "0"})])
 @pytest.mark.parametrize("lens", [[31], [9, 31]])
-def test_xcd_aware_tile_orders_are_bit_identical(emu_lib, monkeypatch, lens, knob, extra):
-    """Split-K convs and the fused FFN deal (column tile, row part) to the XCDs row part-major, the tiled conv kernel
-    (column tile, row block) column tile-major (pe_rt.h pe_xcd_xy / pe_xcd_yx; the emulator plays a round-robin over 8
-    XCDs): permutations of which workgroup computes which tile, so the results with the knob at 0 (tile = blockIdx) and
-    the default are the same bits -- on a 192-channel voice whose one-utterance calls take conv_splitk_kernel,
-    conv_splitk16_kernel, the grouped / K-concatenated stage launches and ffn_kernel, and with every conv forced onto
-    the tiled kernel (PIPER_HIP_SPLITK_MAX=0)."""
+def test_xcd_aware_ffn_slice_order_is_bit_identical(emu_lib, monkeypatch, lens):
+    """ffn_kernel deals (column tile, slice) to the XCDs slice-major (pe_rt.h pe_xcd_xy; the emulator plays a round-robin
+    over 8 XCDs): a permutation of which workgroup computes which tile, so PIPER_HIP_XCD_FFN=0 (tile = blockIdx) and the
+    default give the same bits, and the oracle's answer."""
     cfg = W.preset("tiny", hidden=192, inter=192, filter=96, n_layers=2)
     w = W.synthetic_weights(cfg, 1234)
     ids = [W.synthetic_phoneme_ids(T, i, id_max=cfg.n_vocab - 1) for i, T in enumerate(lens)]
     nw = np.random.default_rng(5).standard_normal((len(lens), 2, max(lens))).astype(np.float32)
-    for k, v in extra.items():
-        monkeypatch.setenv(k, v)
     res, names = {}, {}
     for mode in ("0", "1"):
-        monkeypatch.setenv(knob, mode)
+        monkeypatch.setenv("PIPER_HIP_XCD_FFN", mode)
         eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
         eng.profile_enable(2)
         res[mode] = eng.synthesize_batch(ids, (0.0, 1.0, 0.8), noise_w=nw)
         names[mode] = {row["name"] for row in eng.profile()[5:] if row["launches"]}
         eng.close()
-    assert names["0"] == names["1"]
-    if knob == "PIPER_HIP_XCD_ROWS":
-        assert any(n.startswith("conv_splitk") for n in names["1"]) and "ffn_kernel" in names["1"]
-    else:
-        assert any(n.startswith("conv_mfma_kernel") for n in names["1"])
+    assert names["0"] == names["1"] and "ffn_kernel" in names["1"]
     for i in range(len(lens)):
         assert np.array_equal(res["0"].audio[i], res["1"].audio[i]) and np.array_equal(res["0"].pcm[i], res["1"].pcm[i])
     o = O.synthesize(w, cfg, ids[-1], (0.0, 1.0, 0.8), nw[-1])
     assert np.max(np.abs(res["1"].audio[-1] - o["audio"])) < 1e-5
+
+
+def test_policy_knob_values_are_validated(emu_lib, monkeypatch):
+    """A knob that is not an integer fails engine creation with the variable's name (policy.cpp read_env); a value outside
+    the range is clamped (PIPER_HIP_XCD=99 -> 32)."""
+    cfg = W.preset("tiny")
+    blob = W.pack_blob(cfg, W.synthetic_weights(cfg, 1234))
+    monkeypatch.setenv("PIPER_HIP_COL4", "yes")
+    with pytest.raises(EngineError, match="PIPER_HIP_COL4"):
+        Engine(blob=blob, lib=emu_lib)
+    monkeypatch.delenv("PIPER_HIP_COL4")
+    monkeypatch.setenv("PIPER_HIP_XCD", "99")
+    eng = Engine(blob=blob, lib=emu_lib)
+    assert eng.xcc_pattern[1] == 32
+    eng.close()
