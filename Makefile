@@ -4,9 +4,9 @@ ROCM ?= /opt/rocm
 HIPCC ?= $(ROCM)/bin/hipcc
 CXX_EMU ?= $(ROCM)/lib/llvm/bin/clang++
 CSRC := piper_amd/csrc
-SRCS := $(CSRC)/engine.cpp $(CSRC)/kernels/launch_conv.cpp $(CSRC)/kernels/launch_bf3.cpp $(CSRC)/kernels/launch_front.cpp $(CSRC)/kernels/launch_tail.cpp \
+SRCS := $(CSRC)/engine.cpp $(CSRC)/engine_pack.cpp $(CSRC)/engine_launch.cpp $(CSRC)/engine_issue.cpp $(CSRC)/kernels/launch_conv.cpp $(CSRC)/kernels/launch_bf3.cpp $(CSRC)/kernels/launch_front.cpp $(CSRC)/kernels/launch_tail.cpp \
         $(CSRC)/pe_api.cpp $(CSRC)/policy.cpp $(CSRC)/weights.cpp $(CSRC)/onnx_reader.cpp $(CSRC)/piper_shim.cpp
-HDRS := include/piper.hpp $(CSRC)/engine.h $(wildcard $(CSRC)/kernels/*.h) $(CSRC)/pe_rt.h $(CSRC)/policy.h $(CSRC)/weights.h \
+HDRS := include/piper.hpp $(CSRC)/engine.h $(CSRC)/engine_internal.h $(wildcard $(CSRC)/kernels/*.h) $(CSRC)/pe_rt.h $(CSRC)/policy.h $(CSRC)/weights.h \
         $(CSRC)/unicode_tables.h include/piper_hip.h
 LIB := piper_amd/libpiper_hip.so
 EMULIB := tests/emu/libpiper_hip_emu.so

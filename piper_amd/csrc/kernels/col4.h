@@ -9,7 +9,7 @@ namespace pe {
 
 // Why 4 columns: see dds4.h -- a 16-column workgroup of the 192-channel chains is bound inside its ONE CU (element-wise
 // phases on 8 waves + three 16-row GEMM tiles per SIMD) while a 128-id utterance occupies 8 of 256 CUs; 4-column
-// workgroups put a quarter of that work on each of 4x the CUs. Weights: engine.cpp pack4 -- [64-row tile][k quad = K/4]
+// workgroups put a quarter of that work on each of 4x the CUs. Weights: engine_pack.cpp pack4 -- [64-row tile][k quad = K/4]
 // [lane][4]: lane l <-> row 64 * tile + l, element j <-> input channel 4 * quad + j.
 // Which 4-column tile a workgroup takes. Workgroups go to the 8 XCDs round-robin by linear id, so with tile = blockIdx.x
 // the eight 16-byte pieces of a 128-byte line of any [channel][time] tensor the launch writes would come from eight

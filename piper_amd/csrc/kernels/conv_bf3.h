@@ -17,7 +17,7 @@ namespace pe {
 //   * B operand (activations): staged per 32-channel chunk through registers, pre-activation and the split applied
 //     ONCE per element there, written to LDS as [part hi|lo][k group of 8 channels][column][8 bf16]: a lane's B
 //     fragment of one k-step (8 consecutive channels of its column) is one ds_read_b128, a dilated tap a shifted column.
-//   * A operand (weights): split and packed at load time (engine.cpp pack_bf3) as
+//   * A operand (weights): split and packed at load time (engine_pack.cpp pack_matrix) as
 //     [m tile][chunk][tap][part][k-step 0|1][lane][8 bf16]: 1024 floats per step like the f32 packing, four 16-byte
 //     loads per lane and (m tile, chunk, tap), prefetched one unit ahead (ping-pong).
 //   * accumulator layout == v_mfma_f32_32x32x2_f32's: the epilogues of conv_common.h are shared.

@@ -8,7 +8,7 @@
 namespace pe {
 
 
-// A-operand fragments (engine.cpp: pack_matrix). One (m tile, chunk, tap) step is 1024 floats:
+// A-operand fragments (engine_pack.cpp: pack_matrix). One (m tile, chunk, tap) step is 1024 floats:
 // [q = 0..3][lane][j = 0..3] holds fragment kk = 4q + j of `lane`, so NK fragments are NK/4 float4 loads.
 template <int NK>
 __device__ __forceinline__ void load_frags(const float* step_base, int lane, int kk0, float (&a)[NK]) {

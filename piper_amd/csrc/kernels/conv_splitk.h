@@ -296,7 +296,7 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_splitk_sum_kernel(ConvP p) {
 // workgroup although most CUs idle (one utterance through the WN gate conv: 84 workgroups of 960 MFMAs): half the
 // columns per workgroup = half the matrix time per CU and twice the workgroups. One workgroup = MT16 sixteen-row
 // sub-tiles (4 for the gate: tanh a, tanh b, sigmoid a, sigmoid b of one 32-channel group; 2 otherwise) x 16 columns;
-// K is dealt to the waves exactly as in conv_splitk_kernel. Weights: engine.cpp pack16 --
+// K is dealt to the waves exactly as in conv_splitk_kernel. Weights: engine_pack.cpp pack16 --
 // [16-row sub-tile][chunk][tap][q = 0..1][lane][4] with lane -> (row = lane & 15, k = lane >> 4), float4 element j of
 // group q = k-step s = 4q + j, input channel chunk*32 + 4s + k; ascending k inside and across instructions, i.e. the
 // same fmaf chain as the 32x32x2 form.

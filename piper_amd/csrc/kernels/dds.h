@@ -122,7 +122,7 @@ __device__ __forceinline__ void col_gemm16(const float* wp16, const float* bias,
 // N matches the column count, its 16-row tiles (Hp/16 = 12 for H = 192) spread evenly over the four SIMDs of the 8
 // waves (three each), and a 128-id utterance still gives 8 workgroups. (A first version used 32 columns and the
 // 32x32x2 MFMA: six row tiles on eight waves put two tiles on two of the SIMDs; 17.3 vs 11.0 us per launch.) k runs
-// over the input channels in ascending order inside and across the instructions: the same fmaf chain. Weights: packed by engine.cpp pack_dds16 as
+// over the input channels in ascending order inside and across the instructions: the same fmaf chain. Weights: packed by engine_pack.cpp pack16 as
 // [16-row tile][q][lane][4] with lane -> (row = lane & 15, k = lane >> 4) and step s = 4q + j covering ci = 4s + k.
 template <int NVT>                              // NVT = channel slots per thread: ceil(Hp / 32)
 __device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b, float* sm) {

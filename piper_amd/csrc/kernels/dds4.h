@@ -20,9 +20,9 @@ namespace pe {
 //     partial tiles meet in LDS in a fixed order (deterministic; within a wave k ascends like the fmaf chain of dds.h);
 //   * everything else -- ConvFlow.pre folded into the first layer's input, the second 1x1 conv (dp.proj / ConvFlow.proj)
 //     and the rational-quadratic spline behind the last layer -- as in dds_layer16_kernel.
-// Weights: engine.cpp pack4 -- [64-row tile][k quad = K/4][lane][4]: lane l <-> row 64 * tile + l, element j <-> input
+// Weights: engine_pack.cpp pack4 -- [64-row tile][k quad = K/4][lane][4]: lane l <-> row 64 * tile + l, element j <-> input
 // channel 4 * quad + j. Each workgroup streams the layer's 147 KB of weights from L2, so the form is for small calls
-// only (engine.cpp: Engine::dds; 4x the workgroups of the 16-column form read 4x the weight bytes).
+// only (engine_launch.cpp: Engine::dds; 4x the workgroups of the 16-column form read 4x the weight bytes).
 __global__ __launch_bounds__(256) void dds_layer4_kernel(DdsP p) {
   PE_KTRACE(2);
   PE_DYN_SMEM(float, sm);                       // YT[4][KS] | P[4 waves][192][4] | red[2][4][4] | ZL[64][4]

@@ -26,7 +26,7 @@ namespace pe {
 //   * h = relu(sum + b1), zero outside [0, L) (conv_2's zero padding and the mask), [48][18] in LDS (columns 16, 17 zero).
 //   * conv_2 partial: [192 rows] x [K = 48 hidden x 3 taps] x [16 cols]: wave w owns row tiles 3w .. 3w + 2 over the
 //     whole K (108 MFMAs), no reduction; columns 0..11 are stored.
-// Both weight slices (27 float4 per lane each) are requested at kernel entry / under the first GEMM. Weights: engine.cpp
+// Both weight slices (27 float4 per lane each) are requested at kernel entry / under the first GEMM. Weights: engine_pack.cpp
 // pack_ffn -- conv_1 [slice][tile 3][wave 4][tap 3][step quad 3][lane][4], lane -> (row = lane & 15, k = lane >> 4),
 // element j of quad Q = channel 48 wave + 4 (4Q + j) + k; conv_2 [slice][row tile 12][tap 3][step quad 3][lane][4] with
 // hidden channel 48 slice + 4 (4Q + j) + k.

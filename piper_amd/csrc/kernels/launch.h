@@ -1,5 +1,5 @@
 // Host-side launchers of the kernels, one translation unit per kernel family (launch_conv.cpp, launch_front.cpp,
-// launch_tail.cpp) so that the library builds in parallel: engine.cpp sees only the parameter structs (params.h) and
+// launch_tail.cpp) so that the library builds in parallel: the engine (engine_launch.cpp) sees only the parameter structs (params.h) and
 // these prototypes. A launcher picks the template instantiation for its runtime arguments and issues ONE launch on
 // `stream` (counted in pe::g_launches). `init()` of a family raises the dynamic-LDS limit of its kernels (160 KiB per
 // workgroup on gfx950) and must run once per process before the first launch.
@@ -12,7 +12,7 @@ namespace launch {
 
 // ---- conv GEMM family (launch_conv.cpp)
 void init_conv();
-// tiled implicit GEMM: cfg = tile configuration id (engine.cpp CFG_*), halo = 64 | 128 columns of staging slack
+// tiled implicit GEMM: cfg = tile configuration id (engine_internal.h CFG_*), halo = 64 | 128 columns of staging slack
 void conv_tile(int cfg, bool gate, int halo, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p);
 // split-K forms: nw = 4 | 8 | 12 waves
 void conv_splitk(bool gate, int nw, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p);
@@ -22,7 +22,7 @@ void conv_group_sum(dim3 grid, size_t smem, hipStream_t stream, const ConvP& p);
 
 // ---- split-bf16 tiled conv GEMM (launch_bf3.cpp; opt-in matrix mode PIPER_HIP_MATRIX=bf16x3)
 void init_bf3();
-// cfg: 0 = 128 x 128 tile, 1 = 64 x 128, 2 = 32 x 256 (engine.cpp BF3_BM / BF3_BN); gate needs cfg 0 or 1
+// cfg: 0 = 128 x 128 tile, 1 = 64 x 128, 2 = 32 x 256 (engine_launch.cpp BF3_BM / BF3_BN); gate needs cfg 0 or 1
 void conv_bf3(int cfg, bool gate, int halo, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p);
 
 // ---- text encoder / duration predictor / flow glue (launch_front.cpp)

@@ -24,7 +24,7 @@ void init_conv() {
 #endif
 }
 
-// tile configurations {WM, WN, MT, NT, KS}: ids as engine.cpp's CFG_* -- B (gate: 64 x 128), C (32 x 128), S (64 x 64), G (gate: 128 x 64)
+// tile configurations {WM, WN, MT, NT, KS}: ids as engine_internal.h's CFG_* -- B (gate: 64 x 128), C (32 x 128), S (64 x 64), G (gate: 128 x 64)
 void conv_tile(int cfg, bool gate, int halo, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p) {
 #define PE_CONV_LAUNCH(WM, WN, MT, NT, KS, G)                                                                  \
   do {                                                                                                         \

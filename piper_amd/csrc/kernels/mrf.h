@@ -20,7 +20,7 @@
 //     step loop (exact wait counts); the fragments of the next PHASE's first step are fetched during the last step.
 //   * The K loop is specialised at compile time on which halo units take part in a phase; (chunk, tap) are counters.
 //   * The row stride WS is a per-width constant (immediates for the 8 k-rows of a step); the number of output units per
-//     wave (OU = 1..3 -> N = 16 * NCG * OU columns per workgroup) is picked per launch (engine.cpp: Engine::mrf).
+//     wave (OU = 1..3 -> N = 16 * NCG * OU columns per workgroup) is picked per launch (engine_launch.cpp: Engine::mrf).
 // Every step is the same k-ordered f32 fmaf chain as the conv kernels (chunk-major, tap-minor, ascending channel).
 // History (profiles/r02_notes.md, r03_notes.md): generation 1 applied the leaky-relu on the read side (3 VALU per MFMA);
 // generation 2 staged the weights through a double-buffered LDS ring with one workgroup barrier per segment (16 waves,

@@ -1,4 +1,4 @@
-// Launch parameters and host-visible constants of every kernel (what engine.cpp fills in and the launch translation
+// Launch parameters and host-visible constants of every kernel (what engine_launch.cpp fills in and the launch translation
 // units kernels/launch_*.cpp pass on). Device code lives in the per-kernel headers next to this file; each struct's
 // fields are documented there where the kernel uses them.
 #pragma once
@@ -13,9 +13,9 @@ enum Epi { EPI_STORE = 0, EPI_RESADD = 1, EPI_GATE = 2, EPI_WNRS = 3, EPI_SUBFRO
 enum Act { ACT_NONE = 0, ACT_RELU = 1 };
 struct ConvP {
   const float* x; long x_bs; int x_cs;          // input  x[b][ci][t]
-  const float* wp;                              // packed weights (engine.cpp: pack_conv)
+  const float* wp;                              // packed weights (engine_pack.cpp: pack_conv)
   const float* wp16;                            // conv_splitk16_kernel: the same in 16x16x4 fragment order, or null
-  const float* wpb;                             // conv_bf3_kernel: bf16 hi/lo split fragments (engine.cpp pack_bf3), or null
+  const float* wpb;                             // conv_bf3_kernel: bf16 hi/lo split fragments (engine_pack.cpp pack_matrix), or null
   const float* bias;                            // per output channel or null
   const float* bias2; int bias2_bs;             // per-utterance extra bias (speaker cond) or null
   float* out; long o_bs; int o_cs;
@@ -97,7 +97,7 @@ struct DdsP {
   const float* dw_w; const float* dw_b; int dw_k, dw_dil;
   const float* g1; const float* b1; const float* g2; const float* b2;
   const float* bias;                        // 1x1 conv bias
-  const float* wp16;                        // 1x1 conv weights in the 16x16x4 fragment order (engine.cpp)
+  const float* wp16;                        // 1x1 conv weights in the 16x16x4 fragment order (engine_pack.cpp)
   const float* wp4;                         // the same in the 4x4x1 fragment order (dds_layer4_kernel; null: not packed)
   int nchunks;                              // ceil(H / 32)
   const int* lens;
