@@ -7,7 +7,7 @@ with every ``weight_norm`` folded into a plain ``.weight`` (the exporter does th
 
 Numpy only: this module travels to the GPU box and must not need the reference or torch.
 
-Blob layout (little endian), parsed by ``piper_amd/csrc/blob.cpp``::
+Blob layout (little endian), parsed by ``piper_amd/csrc/weights.cpp``::
 
     char     magic[8] = "PEBLOB01"
     int32    arch[64]                 (ARCH_* indices below)

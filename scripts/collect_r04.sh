@@ -42,6 +42,10 @@ python scripts/pmc_traffic.py high/b64/t128 $O/pmc_fetch_high_b64 $O/pmc_write_h
   python scripts/pmc_summary.py $O/pmc_sq_b1 $O/pmc_sq_b64 $O/pmc_sq_high_b64
 } > $O/r04_pmc_summary.txt 2>> $O/err.log
 for n in b1 b64 high_b64; do f=$(find $O/st_$n -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f $O/r04_${n}_kernel_stats.csv; done
+# MFMA pipe utilisation per kernel: executed matrix FLOPs (SQ pass) / launch duration (kernel stats of the same command) / peak
+{ echo; python scripts/pmc_util.py $O/r04_pmc_summary.txt pmc_sq_b1=$O/r04_b1_kernel_stats.csv pmc_sq_b64=$O/r04_b64_kernel_stats.csv pmc_sq_high_b64=$O/r04_high_b64_kernel_stats.csv; } >> $O/r04_pmc_summary.txt 2>> $O/err.log
+# randomised parity sweep against the oracle (random lengths, ragged batches, scales, speakers; four voices)
+timeout 600 python scripts/stress_parity.py 24 > $O/r04_stress_parity.log 2>&1; tail -1 $O/r04_stress_parity.log
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*counter_collection.csv" -delete
 cat $O/smoke.log; tail -3 $O/traffic.log; grep -v amdgpu.ids $O/err.log | tail -3; tail -2 $O/bench_default.err
 echo "last line bytes: $(tail -n 1 $O/bench_default.stdout | wc -c)"; tail -n 1 $O/bench_default.stdout
