@@ -31,6 +31,16 @@ inline void pe_row_store_so(const pe_rowsrc& r, int vidx, int sidx, float v) {
   const long i = (long)vidx + sidx;
   if (i >= 0 && i < r.n) const_cast<float*>(r.p)[i] = v;
 }
+// two / four consecutive floats starting at element idx (all of them inside the row, or none is written)
+inline void pe_row_store2(const pe_rowsrc& r, int idx, float a, float b) {
+  if (idx >= 0 && idx + 1 < r.n) { const_cast<float*>(r.p)[idx] = a; const_cast<float*>(r.p)[idx + 1] = b; }
+}
+inline void pe_row_store4(const pe_rowsrc& r, int idx, float a, float b, float c, float d) {
+  if (idx >= 0 && idx + 3 < r.n) {
+    float* q = const_cast<float*>(r.p) + idx;
+    q[0] = a; q[1] = b; q[2] = c; q[3] = d;
+  }
+}
 inline f32x4 pe_row_load4(const pe_rowsrc& r, int idx) {
   f32x4 v;
   for (int j = 0; j < 4; ++j) v[j] = (idx + j >= 0 && idx + j < r.n) ? r.p[idx + j] : 0.f;
@@ -143,6 +153,17 @@ __device__ __forceinline__ float pe_row_load_so(pe_rowsrc r, int vidx, int sidx)
 }
 __device__ __forceinline__ void pe_row_store_so(pe_rowsrc r, int vidx, int sidx, float v) {
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, (int)((unsigned)vidx * 4u), sidx * 4, 0);
+}
+// two / four consecutive floats in one store instruction; idx must be a multiple of 2 / 4 elements past an aligned base
+// (the callers check) and the whole group inside the row (a group that straddles the end is the caller's business)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void pe_row_store2(pe_rowsrc r, int idx, float a, float b) {
+  f32x2 v = {a, b};
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(__attribute__((ext_vector_type(2))) unsigned, v), r, (int)((unsigned)idx * 4u), 0, 0);
+}
+__device__ __forceinline__ void pe_row_store4(pe_rowsrc r, int idx, float a, float b, float c, float d) {
+  f32x4 v = {a, b, c, d};
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, v), r, (int)((unsigned)idx * 4u), 0, 0);
 }
 // four consecutive floats (16-byte aligned index) in one instruction
 __device__ __forceinline__ f32x4 pe_row_load4(pe_rowsrc r, int idx) {

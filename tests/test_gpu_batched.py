@@ -41,11 +41,10 @@ def voice(preset, seed=1234, **over):
 
 def make_engine(monkeypatch, cfg, w, env=None):
     from piper_amd.engine import Engine
-    for k in ("PIPER_HIP_SPLITK_MAX", "PIPER_HIP_TPB", "PIPER_HIP_SPLITK16",
-              "PIPER_HIP_WIDE_SPLITK", "PIPER_HIP_DEBUG_KEEP", "PIPER_HIP_MRF", "PIPER_HIP_FUSE_DP",
-              "PIPER_HIP_MRF_MAXF", "PIPER_HIP_SPEC", "PIPER_HIP_COLCHAIN", "PIPER_HIP_GROUP_MRF", 
-              "PIPER_HIP_MRF_OU", "PIPER_HIP_MATRIX", "PIPER_HIP_BF3_MINF", "PIPER_HIP_MRF_TAIL", "PIPER_HIP_COL4",
-              "PIPER_HIP_COL4_MAXC", "PIPER_HIP_FFN", "PIPER_HIP_XCD", "PIPER_HIP_GRAPHS", "PIPER_HIP_ATTNO", "PIPER_HIP_CONVT_LDS"):
+    import json
+    from piper_amd import _lib as L
+    # every launch-policy knob the engine reads (piper_amd/csrc/policy.h) + the string-valued matrix mode
+    for k in [x["env"] for x in json.loads(L.get_lib().pe_policy_describe().decode())] + ["PIPER_HIP_MATRIX"]:
         monkeypatch.delenv(k, raising=False)
     for k, v in (env or {}).items():
         monkeypatch.setenv(k, str(v))
@@ -216,9 +215,11 @@ FORCED = [
     ("medium", [128, 13, 1, 129], {}, {"attno_kernel<96>", "lngemm4_kernel", "ffn_kernel"}),
     ("high", [96, 40], {}, {"attno_kernel<96>"}),
     ("medium", [128, 31], {"PIPER_HIP_ATTNO": 0}, {"attn_kernel<96>", "colchain4_kernel"}),
-    # the up-convs' tiles stored element-wise (default: transposed through LDS, rows of consecutive samples), B = 1 and batch
-    ("medium", [128], {"PIPER_HIP_CONVT_LDS": 0}, {"conv_mfma_kernel<2,2,1,1,16,false,64>"}),
-    ("high", [70, 128, 9, 128, 128, 33], {"PIPER_HIP_CONVT_LDS": 2}, set()),
+    # the up-convs' tiles stored element-wise, and transposed through LDS as rows of consecutive samples at every stride
+    # (default: 16- / 8-byte pieces straight from the accumulators where the stride is a multiple of 4), B = 1 and batch
+    ("medium", [128], {"PIPER_HIP_CONVT_VEC": 0, "PIPER_HIP_CONVT_LDS": 0}, {"conv_mfma_kernel<2,2,1,1,16,false,64>"}),
+    ("medium", [128, 40, 77], {"PIPER_HIP_CONVT_VEC": 0, "PIPER_HIP_CONVT_LDS": 2}, set()),
+    ("high", [70, 128, 9, 128, 128, 33], {"PIPER_HIP_CONVT_VEC": 0, "PIPER_HIP_CONVT_LDS": 2}, set()),
     # tiles of the 4-column kernels in workgroup order (no XCD-contiguous runs)
     ("medium", [128, 31], {"PIPER_HIP_XCD": 0}, {"colchain4_kernel", "lngemm4_kernel", "dds_layer4_kernel"}),
 ]
