@@ -114,7 +114,6 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
   p.split = (epi == EPI_GATE) ? pc.split : (epi == EPI_WNRS ? (pc.rows > H_ ? H_ : 0) : 0);
   p.up = pc.up; p.padT = pc.padT;
   p.up_magic = pc.up ? (unsigned)((0x100000000ULL + pc.up - 1) / pc.up) : 0u;
-  p.up_shift = -1;
   p.up_vec = 0;
   p.mode = mode; p.alpha = alpha;
   p.tpb = 1;
@@ -230,24 +229,10 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
   const int nbuf = (tpb == 1 && pc.nchunks == 1) ? 1 : 2;
   const int HALO = p.xhalo <= 64 ? 64 : 128;
   const size_t smem = (size_t)nbuf * KC * ((BN + HALO + 63) / 64 * 64) * sizeof(float);
-  // polyphase up-conv: the tile leaves through LDS as rows of consecutive output samples (conv_mfma.h) when the stride is
-  // a power of two that divides the tile's rows, one tile per workgroup, and the slab area holds BM x BN + padding
-  p.up_shift = -1;
-  // ... or, when the stride is a multiple of 4, straight from the accumulators: a lane's four rows are four consecutive
-  // samples of one channel -- one 16-byte store (stride 8, padding 4) or two 8-byte ones (stride 4, padding 2)
-  p.up_vec = 0;
-  if (epi == EPI_CONVT && pol_.convt_vec && pc.up % 4 == 0 && (((uintptr_t)out.p) & 15) == 0) {
-    if (out.cs % 4 == 0 && out.bs % 4 == 0 && pc.padT % 4 == 0) p.up_vec = 4;
-    else if (out.cs % 2 == 0 && out.bs % 2 == 0 && pc.padT % 2 == 0) p.up_vec = 2;
-  }
-  // (measured, profiles/r04_notes.md: stride 8 -6 % per launch at batch; strides 4 and 2 gain nothing or lose -- their
-  // LDS writes are 4- / 2-way bank conflicts for a store pattern the L2 was already merging; PIPER_HIP_CONVT_LDS=2 forces it)
-  if (epi == EPI_CONVT && pc.up >= 2 && !p.up_vec &&
-      pol_.convt_through_lds(pc.up, tpb, BM, ((size_t)BM * BN + (size_t)(BM / pc.up) * 4) * sizeof(float), smem)) {
-    int sh = 0;
-    while ((1 << sh) < pc.up) ++sh;
-    p.up_shift = sh;
-  }
+  // polyphase up-conv: a lane's four accumulator rows are consecutive output samples of one channel (stride a multiple of
+  // 4) or both phases of two channels (stride 2): stored as 16- / 8-byte pieces straight from the accumulators. Measured
+  // against one 4-byte store per phase and against the tile transposed through LDS (profiles/r04_notes.md, calls 7 / 11).
+  p.up_vec = (epi == EPI_CONVT && pol_.convt_vec) ? (pc.up % 4 == 0 ? 4 : (pc.up == 2 ? 2 : 0)) : 0;
   static const char* knames[] = {"2,2,2,2,8", "1,4,2,1,16", "1,4,1,1,16", "2,2,1,1,16", "2,2,2,1,16", "1,4,1,2,16", "1,4,2,2,8"};
   int kh = -1;
   if (prof_level_ >= 2) {

@@ -98,11 +98,13 @@ __device__ __forceinline__ void conv_store_tile(const ConvP& p, const EpiFlags& 
     const pe_rowsrc od = pe_make_row_u(p.out + (long)b * p.o_bs, (p.rows / p.up) * p.o_cs);
     const pe_rowsrc bd = pe_make_row_u(p.bias, p.bias ? p.rows / p.up : 0);
     const int tmax = L * p.up;
-    if (p.up_vec) {
+    if (p.up_vec == 4) {
       // up % 4 == 0: rows rb + 8g .. + 3 (rb = row0 + 4 lhi) are four consecutive phases of ONE output channel, i.e. the
-      // lane's accumulators 4g .. 4g + 3 are four consecutive output samples: one 16-byte store (or two 8-byte ones when
-      // t is only 8-byte aligned: stride 4 with padding 2) instead of four 4-byte stores `up` samples apart from the
-      // next lane's. Groups that straddle the ends of the utterance go element by element.
+      // lane's accumulators 4g .. 4g + 3 are four consecutive output samples: one 16-byte store instead of four 4-byte
+      // stores `up` samples apart from the next lane's (any dword alignment: stride 4 with padding 2 lands on 8-byte
+      // boundaries). Medium voice at 64 utterances: the three up-convs 349 / 643 / 790 -> 316 / 544 / 674 us, against
+      // both the element-wise stores and the tile transposed through LDS (profiles/r04_notes.md, call 11). Groups that
+      // straddle the ends of the utterance go element by element.
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int row = rb + 8 * g;
@@ -113,8 +115,7 @@ __device__ __forceinline__ void conv_store_tile(const ConvP& p, const EpiFlags& 
         const float v0 = acc[4 * g] + bz, v1 = acc[4 * g + 1] + bz, v2 = acc[4 * g + 2] + bz, v3 = acc[4 * g + 3] + bz;
         const int o0 = co * p.o_cs + t0;
         if (ok && t0 >= 0 && t0 + 3 < tmax) {
-          if (p.up_vec == 4) pe_row_store4(od, o0, v0, v1, v2, v3);
-          else { pe_row_store2(od, o0, v0, v1); pe_row_store2(od, o0 + 2, v2, v3); }
+          pe_row_store4(od, o0, v0, v1, v2, v3);
         } else if (ok) {
           if (t0 >= 0 && t0 < tmax) pe_row_store_so(od, o0, 0, v0);
           if (t0 + 1 >= 0 && t0 + 1 < tmax) pe_row_store_so(od, o0 + 1, 0, v1);
@@ -122,6 +123,27 @@ __device__ __forceinline__ void conv_store_tile(const ConvP& p, const EpiFlags& 
           if (t0 + 3 >= 0 && t0 + 3 < tmax) pe_row_store_so(od, o0 + 3, 0, v3);
         }
       }
+      return;
+    }
+    if (p.up_vec == 2) {
+      // up == 2: rows rb + 8g .. + 3 are both phases of TWO channels: two 8-byte stores
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int row = rb + 8 * g + 2 * h, co = row >> 1;
+          const int t0 = 2 * col - p.padT;
+          const bool ok = row < p.rows && col < ncols;
+          const float bz = pe_row_load(bd, ok ? co : OOB);
+          const float v0 = acc[4 * g + 2 * h] + bz, v1 = acc[4 * g + 2 * h + 1] + bz;
+          const int o0 = co * p.o_cs + t0;
+          if (ok && t0 >= 0 && t0 + 1 < tmax) {
+            pe_row_store2(od, o0, v0, v1);
+          } else if (ok) {
+            if (t0 >= 0 && t0 < tmax) pe_row_store_so(od, o0, 0, v0);
+            if (t0 + 1 >= 0 && t0 + 1 < tmax) pe_row_store_so(od, o0 + 1, 0, v1);
+          }
+        }
       return;
     }
     float bv[16];

@@ -172,38 +172,6 @@ void conv_mfma_kernel(ConvP p) {
           if (ch < p.split && col < ncols) conv_store_gate(p, b, ch, col, acc[0][j][r], acc[MT - 1][j][r]);
         }
       }
-    } else if (p.epi == EPI_CONVT && p.up_shift >= 0) {
-      // Polyphase ConvTranspose1d: row = co * up + phase, column j -> output sample t = j * up + phase - padT. Stored from
-      // the accumulators, a wave-store hits 32 samples `up` apart (one 4-byte piece per 16- or 32-byte stride, once per
-      // phase): the up-convs of a batch ran at 65-78 TFLOP/s behind 1.3 GB of such stores (profiles/r04_notes.md). The
-      // tile goes through LDS instead -- [channel][BN * up samples], the slabs are dead by now -- and leaves as whole rows:
-      // 64 consecutive samples per wave-store. (The launcher sets up_shift only with one tile per workgroup and two slab
-      // buffers: BM x BN floats + row padding fit.)
-      const int sh = p.up_shift, S = 1 << sh;
-      const int RS = BN * S + 4;                               // LDS row stride of one output channel of the tile
-      __syncthreads();                                         // every wave is done with the slabs
-      float* ot = xs;
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-          const int cl = (wn * NT + j) * 32 + l31;             // column inside the tile
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int rl = (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;     // row inside the tile
-            ot[(rl >> sh) * RS + (cl << sh) + (rl & (S - 1))] = acc[i][j][r];
-          }
-        }
-      __syncthreads();
-      const int nco = BM >> sh, per = BN << sh;                // channels of the tile, samples per channel
-      const int co0 = m0 >> sh, Cout = p.rows >> sh, tmax = L << sh;
-      const int tb = (n0 << sh) - p.padT;                      // output sample of tile sample 0
-      float* ob = p.out + (long)b * p.o_bs;
-      for (int f = tid; f < nco * per; f += 256) {
-        const int c = f / per, idx = f - c * per;              // (per is a multiple of 64: a wave stays inside one channel)
-        const int co = co0 + c, t = tb + idx;
-        if (co < Cout && t >= 0 && t < tmax) ob[(long)co * p.o_cs + t] = ot[c * RS + idx] + (p.bias ? p.bias[co] : 0.f);
-      }
     } else {
 #pragma unroll
       for (int i = 0; i < MT; ++i)

@@ -31,11 +31,9 @@ struct ConvP {
   int split;                                    // GATE: H ; WNRS: rows < split go to h, rest to skip
   int up, padT;                                 // CONVT: stride and padding
   unsigned up_magic;                            // CONVT: ceil(2^32 / up): row / up == (row * up_magic) >> 32 for row < 2^16
-  int up_shift;                                 // CONVT, conv_mfma_kernel: log2(up) when the tile leaves through LDS (coalesced rows of
-                                                // output samples instead of one strided store per phase), -1: element-wise stores
-  int up_vec;                                   // CONVT, conv_mfma_kernel: a lane's four accumulator rows (co * up + 4i .. + 3) are consecutive
-                                                // output samples of ONE channel when up is a multiple of 4: stored as one 16-byte (4) or two
-                                                // 8-byte (2) pieces, as the alignment of t = col * up + phase - padT allows; 0: one by one
+  int up_vec;                                   // CONVT, conv_mfma_kernel: a lane's four accumulator rows are consecutive output samples of ONE
+                                                // channel when up is a multiple of 4 (4: one 16-byte store) or both phases of two channels when
+                                                // up == 2 (2: two 8-byte stores); 0: one by one
   int mode;                                     // ACCUM: 0 first,1 middle,2 last,3 only ; WNRS: 1 = first layer
   float alpha;                                  // ACCUM last/only: scale
   int tpb;                                      // conv_mfma_kernel: column tiles walked by one workgroup

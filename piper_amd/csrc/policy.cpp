@@ -33,8 +33,7 @@ static const LaunchPolicy::Knob kKnobs[] = {
     {"PIPER_HIP_PCM_ZC", &LaunchPolicy::pcm_zc, 0, 1, "PCM written straight into pinned host memory by pcm16_kernel (0: one copy per utterance behind the graph)"},
     {"PIPER_HIP_NO_GRAPH", &LaunchPolicy::no_graph, 0, 1, "launch kernels directly instead of replaying hipGraphs"},
     {"PIPER_HIP_GRAPHS", &LaunchPolicy::graphs, 1, 4096, "hipGraphs kept per engine (least recently used evicted one at a time)"},
-    {"PIPER_HIP_CONVT_VEC", &LaunchPolicy::convt_vec, 0, 1, "polyphase up-conv with a stride that is a multiple of 4: a lane's four accumulator rows are consecutive samples of one channel and leave as one 16-byte (or two 8-byte) stores; 0: through LDS (PIPER_HIP_CONVT_LDS) or one by one"},
-    {"PIPER_HIP_CONVT_LDS", &LaunchPolicy::convt_lds, 0, 2, "polyphase up-conv tiles leave through LDS as rows of consecutive samples: 0 never, 1 stride >= 8, 2 every stride"},
+    {"PIPER_HIP_CONVT_VEC", &LaunchPolicy::convt_vec, 0, 1, "polyphase up-conv: a lane's four accumulator rows leave as one 16-byte store (stride a multiple of 4) or two 8-byte stores (stride 2) of consecutive output samples; 0: one 4-byte store per phase"},
     {"PIPER_HIP_XCD", &LaunchPolicy::xcd, -1, 32, "XCDs the dispatch round-robins over, for the XCD-aware tile orders (-1 = probed at engine creation, 0 = tiles in workgroup order)"},
     {"PIPER_HIP_XCD_FFN", &LaunchPolicy::xcd_ffn, 0, 1, "ffn_kernel deals (column tile, slice) to the XCDs slice-major, so an XCD's L2 holds two slices' weights instead of all sixteen (0: blockIdx order)"},
     {"PIPER_HIP_PROF_SITES", &LaunchPolicy::prof_sites, 0, 1, "level-2 profile rows of the tiled conv kernel per conv shape (tuning aid)"},

@@ -34,8 +34,7 @@ struct LaunchPolicy {
   long pcm_zc = 1;            // int16 PCM written straight into pinned host memory by pcm16_kernel
   long no_graph = 0;          // launch kernels directly instead of replaying hipGraphs
   long graphs = 64;           // hipGraphs kept per engine (least recently used evicted one at a time)
-  long convt_vec = 1;         // polyphase up-conv tiles stored as 16- / 8-byte pieces straight from the accumulators (stride % 4 == 0)
-  long convt_lds = 1;         // polyphase up-conv tiles through LDS: 0 never, 1 stride >= 8 (measured), 2 every stride (tests)
+  long convt_vec = 1;         // polyphase up-conv tiles stored as 16- / 8-byte pieces straight from the accumulators (0: one 4-byte store per phase)
   long xcd = -1;              // XCDs the dispatch round-robins over: -1 = probed at engine creation, 0 = tiles in workgroup order
   long xcd_ffn = 1;           // fused FFN: (column tile, slice) dealt to the XCDs slice-major (0: blockIdx order)
   long prof_sites = 0;        // level-2 profile rows of the tiled conv kernel per conv SHAPE (tuning aid)
@@ -70,11 +69,6 @@ struct LaunchPolicy {
     return (wide_splitk == 1 && gate && units >= 24 && nchunks <= 6 && ntaps >= 4) || wide_splitk == 2;
   }
   int tiles_per_workgroup() const { return tpb > 0 ? (int)tpb : 1; }
-  // polyphase up-conv tile through LDS (stride a power of two that divides the tile's rows, one tile per workgroup)
-  bool convt_through_lds(int stride, int tiles_per_wg, int BM, size_t tile_bytes, size_t smem_bytes) const {
-    return convt_lds && (stride >= 8 || convt_lds == 2) && tiles_per_wg == 1 && stride >= 2 && (stride & (stride - 1)) == 0 &&
-           BM % stride == 0 && tile_bytes <= smem_bytes;
-  }
   // 192-channel chains
   bool chain16(double cols, bool frames, int k1, int half) const {     // colchain_kernel<6> / lngemm_kernel<6>
     return colchain && k1 == 192 && half == 96 && (colchain == 2 || cols <= (double)(frames ? colchain_max_frames : colchain_max_ids));

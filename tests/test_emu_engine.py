@@ -496,29 +496,25 @@ def test_emulated_attention_conv_o_layernorm_in_one_launch(emu_lib, monkeypatch,
 
 @pytest.mark.parametrize("preset,lens", [("tiny", [7, 3, 1]), ("tiny-high", [5, 2])])
 def test_emulated_upconv_epilogues_are_bit_identical(emu_lib, monkeypatch, preset, lens):
-    """conv_mfma_kernel's polyphase ConvTranspose1d epilogues: (a) one strided element-wise store per phase
-    (PIPER_HIP_CONVT_VEC=0, PIPER_HIP_CONVT_LDS=0), (b) the tile transposed through LDS and stored as rows of consecutive
-    output samples (CONVT_VEC=0, CONVT_LDS=2 = every stride), (c) the default: a lane's four accumulator rows stored as one
-    16-byte / two 8-byte pieces where the stride is a multiple of 4 (CONVT_VEC=1; the other strides as in (b) / (a)) -- the
-    same values to the same addresses: bit-identical waveforms for strides 8, 4 and 2, both tile shapes, ragged lengths
-    (first tile starting before sample 0, last tile hanging over the end). PIPER_HIP_SPLITK_MAX=0 sends the tiny voices'
-    up-convs to the tiled kernel at all."""
+    """conv_mfma_kernel's polyphase ConvTranspose1d epilogues: one 4-byte store per phase (PIPER_HIP_CONVT_VEC=0) against
+    the default -- a lane's four accumulator rows stored as one 16-byte piece (stride a multiple of 4) or two 8-byte pieces
+    (stride 2) of consecutive output samples: the same values to the same addresses, bit-identical waveforms for strides
+    8, 4 and 2, both tile shapes, ragged lengths (first tile starting before sample 0, last tile hanging over the end:
+    those groups go element by element). PIPER_HIP_SPLITK_MAX=0 sends the tiny voices' up-convs to the tiled kernel at all."""
     monkeypatch.setenv("PIPER_HIP_SPLITK_MAX", "0")
     cfg = W.preset(preset)
     w = W.synthetic_weights(cfg, 1234)
     ids = [W.synthetic_phoneme_ids(T, i, id_max=cfg.n_vocab - 1) for i, T in enumerate(lens)]
     res = {}
-    for name, vec, lds in (("elem", "0", "0"), ("lds", "0", "2"), ("vec", "1", "1")):
+    for vec in ("0", "1"):
         monkeypatch.setenv("PIPER_HIP_CONVT_VEC", vec)
-        monkeypatch.setenv("PIPER_HIP_CONVT_LDS", lds)
         eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
-        res[name] = eng.synthesize_batch(ids, (0.0, 1.0, 0.0))
+        res[vec] = eng.synthesize_batch(ids, (0.0, 1.0, 0.0))
         eng.close()
     for i in range(len(lens)):
-        for name in ("lds", "vec"):
-            assert np.array_equal(res["elem"].audio[i], res[name].audio[i]) and np.array_equal(res["elem"].pcm[i], res[name].pcm[i]), (name, i)
+        assert np.array_equal(res["0"].audio[i], res["1"].audio[i]) and np.array_equal(res["0"].pcm[i], res["1"].pcm[i]), i
     o = O.synthesize(w, cfg, ids[0], (0.0, 1.0, 0.0))
-    assert np.max(np.abs(res["vec"].audio[0] - o["audio"])) < 1e-4
+    assert np.max(np.abs(res["1"].audio[0] - o["audio"])) < 1e-4
 
 
 @pytest.mark.parametrize("lens", [[31], [9, 31]])

@@ -215,11 +215,12 @@ FORCED = [
     ("medium", [128, 13, 1, 129], {}, {"attno_kernel<96>", "lngemm4_kernel", "ffn_kernel"}),
     ("high", [96, 40], {}, {"attno_kernel<96>"}),
     ("medium", [128, 31], {"PIPER_HIP_ATTNO": 0}, {"attn_kernel<96>", "colchain4_kernel"}),
-    # the up-convs' tiles stored element-wise, and transposed through LDS as rows of consecutive samples at every stride
-    # (default: 16- / 8-byte pieces straight from the accumulators where the stride is a multiple of 4), B = 1 and batch
-    ("medium", [128], {"PIPER_HIP_CONVT_VEC": 0, "PIPER_HIP_CONVT_LDS": 0}, {"conv_mfma_kernel<2,2,1,1,16,false,64>"}),
-    ("medium", [128, 40, 77], {"PIPER_HIP_CONVT_VEC": 0, "PIPER_HIP_CONVT_LDS": 2}, set()),
-    ("high", [70, 128, 9, 128, 128, 33], {"PIPER_HIP_CONVT_VEC": 0, "PIPER_HIP_CONVT_LDS": 2}, set()),
+    # the up-convs' tiles stored one 4-byte piece per phase (default: 16- / 8-byte pieces of consecutive samples straight
+    # from the accumulators: strides 8 and 4 on the medium voice, 8 and 2 on the high one), B = 1 and ragged batches
+    ("medium", [128], {"PIPER_HIP_CONVT_VEC": 0}, {"conv_mfma_kernel<2,2,1,1,16,false,64>"}),
+    ("medium", [128, 40, 77], {"PIPER_HIP_CONVT_VEC": 0}, set()),
+    ("high", [70, 128, 9, 128, 128, 33], {"PIPER_HIP_CONVT_VEC": 0}, set()),
+    ("high", [70, 128, 9, 128, 128, 33], {}, set()),
     # tiles of the 4-column kernels in workgroup order (no XCD-contiguous runs)
     ("medium", [128, 31], {"PIPER_HIP_XCD": 0}, {"colchain4_kernel", "lngemm4_kernel", "dds_layer4_kernel"}),
 ]
