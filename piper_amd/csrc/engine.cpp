@@ -481,7 +481,14 @@ void Engine::run() {
     lens_b_ = d_framesc_;
     snprintf(key, sizeof(key), "C|%d|%d|%d|%a|%a|%d|%d|%d|%a", B, Tg_, Ts_, scales_[1], scales_[2], (int)have_noise_w_,
              Fs_, Fg_, scales_[0]);
-    run_stage('C', key);
+    fold_dur_ = Tg_ <= REG_MAXT;              // (part of what graph 'C' is: a fixed function of its key)
+    try {
+      run_stage('C', key);
+    } catch (...) {
+      fold_dur_ = false;
+      throw;
+    }
+    fold_dur_ = false;
     ++call_;                                  // mirrors the device-side counter bump of this run
     spec_pending_ = true;
     spec_fg_ = Fg_;

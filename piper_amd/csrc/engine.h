@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "pe_rt.h"
+#include "kernels/params.h"
 #include "policy.h"
 #include "weights.h"
 
@@ -338,6 +339,8 @@ class Engine {
   unsigned long long* d_rng_ = nullptr;       // {seed, call counter} read by randn_kernel
   float scales_[3] = {0.667f, 1.0f, 0.8f};
   bool have_noise_w_ = false, have_noise_z_ = false;
+  bool fold_dur_ = false;                  // the stage being issued is the one-graph form: regulate_kernel computes the durations
+  DurP fold_dp_{};                         // ... from these fields (filled by issue_stage_a)
   std::vector<int64_t> id_off_;
   std::vector<int32_t> tlens_h_, frames_h_, dur_h_;
   std::vector<int64_t> sample_off_;

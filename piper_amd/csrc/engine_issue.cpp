@@ -214,9 +214,9 @@ void Engine::issue_stage_a() {
     dp.z0 = z2_ + (long)c0 * Ts; dp.z_bs = (long)2 * Ts; dp.m0 = ea_m0_; dp.es0 = ea_es0_; dp.length_scale = scales_[1];
     dp.lens = d_tlens_; dp.dur = d_dur_; dp.cum = d_cum_; dp.d_bs = Ts; dp.frames = d_frames_; dp.logw_out = logw_;
     dp.frames_host = h_frames_; dp.frames_clamped = d_framesc_; dp.frame_cap = std::max(Fs_, 1);
-    {
-      PE_LAUNCH_KB("duration_kernel", 4.0 * 4.0 * tsum, launch::duration(dim3(B), stream_, dp));
-    }
+    // the whole utterance as one graph: regulate_kernel, first launch of stage B, computes the durations itself
+    fold_dp_ = dp;
+    if (!fold_dur_) PE_LAUNCH_KB("duration_kernel", 4.0 * 4.0 * tsum, launch::duration(dim3(B), stream_, dp));
   }
   prof_end(1, fl);
 }
@@ -241,20 +241,22 @@ void Engine::issue_flow() {
         PE_HIP(hipMemcpyAsync(noise_z_ + ((size_t)b * C_ + c) * Fs,
                               h_noise_z_ + ((size_t)b * C_ + c) * h_noise_z_stride_,
                               frames_h_[b] * sizeof(float), hipMemcpyHostToDevice, stream_));
-  } else {
-    // (drawing the noise inside regulate_kernel was tried: one launch fewer, but a Philox block + Box-Muller per element
-    // in its 16-channels-per-thread loop cost 21 us against this launch's 5, profiles/r02_notes.md)
-    PE_LAUNCH_KB("randn_kernel", 4.0 * C_ * fsum, launch::randn(stream_, noise_z_, (long)B * C_, Fmax, (long)Fs, 0L, d_rng_, 1));
   }
   {
-    RegP rp;
+    // The prior noise is drawn inside regulate_kernel: one thread = four frames of one channel = one Philox block, the
+    // mapping of randn_kernel (round 2 had tried it in a 16-channels-per-thread loop: 21 us against a 5 us launch). In the
+    // one-graph form the kernel also computes the durations (no duration_kernel in front of it): three launches -> one.
+    RegP rp{};
     rp.stats = stats_; rp.s_bs = (long)2 * C_ * Ts; rp.s_cs = Ts;
     rp.cum = d_cum_; rp.d_bs = Ts; rp.tlens = d_tlens_; rp.frames = lens_b_;
     rp.noise = noise_z_; rp.n_bs = (long)C_ * Fs; rp.n_cs = Fs;
     rp.noise_scale = scales_[0];
     rp.out = zp_; rp.o_bs = (long)C_ * Fs; rp.o_cs = Fs; rp.C = C_;
     rp.absmax = absmax_;
-    PE_LAUNCH_KB("regulate_kernel", 4.0 * (2.0 * C_ * cols_ids_ + 2.0 * C_ * fsum), launch::regulate(dim3((Fmax + 63) / 64, (C_ + 15) / 16, B), stream_, rp));
+    rp.rng = d_rng_; rp.gen = have_noise_z_ ? 0 : 1;
+    rp.fold = fold_dur_ ? 1 : 0;
+    if (fold_dur_) rp.dur = fold_dp_;
+    PE_LAUNCH_KB("regulate_kernel", 4.0 * (2.0 * C_ * cols_ids_ + 3.0 * C_ * fsum), launch::regulate(dim3((Fmax + 255) / 256, (C_ + 3) / 4, B), stream_, rp));
     if (zp_keep_)     // tests: z_p, the flow's input (the flow transforms zp_ in place)
       PE_HIP(hipMemcpyAsync(zp_keep_, zp_, (size_t)B * C_ * Fs * sizeof(float), hipMemcpyDeviceToDevice, stream_));
   }

@@ -81,9 +81,12 @@ __device__ __forceinline__ void randn4(long q, const unsigned long long* state, 
   for (int h = 0; h < 2; ++h) {
     const float u1 = ((float)r[2 * h] + 1.0f) * 2.3283064365386963e-10f;   // (0,1]
     const float u2 = (float)r[2 * h + 1] * 2.3283064365386963e-10f;
-    const float rad = sqrtf(-2.f * logf(u1));
-    g[2 * h] = rad * cosf(6.283185307179586f * u2);
-    g[2 * h + 1] = rad * sinf(6.283185307179586f * u2);
+    // Box-Muller on the hardware's transcendental units: v_log_f32 (log2), v_sin_f32 / v_cos_f32 (argument in turns, i.e.
+    // sin(2 pi u2) without a range reduction) -- a draw is a latency chain inside the kernels that consume it, and the
+    // library forms of logf / sinf / cosf were 2/3 of it
+    const float rad = sqrtf(-1.3862943611198906f * pe_log2(u1));           // -2 ln(u1) = -2 ln2 log2(u1)
+    g[2 * h] = rad * pe_cos_turns(u2);
+    g[2 * h + 1] = rad * pe_sin_turns(u2);
   }
 }
 // A site's stream is a logical 2-D array [row][RNG_PITCH] (row = utterance * channels + channel, column = phoneme id /
@@ -107,52 +110,119 @@ __global__ void randn_kernel(float* out, long rows, int cols, long stride, long 
 // Length regulator + prior sample (models.py:705-718, commons.py:116-129). The reference multiplies
 // by a one-hot path matrix; the same result is a gather: frame f takes id i with cum[i-1] <= f < cum[i].
 //   z_p[c][f] = m_p[c][i] + noise[c][f] * exp(logs_p[c][i]) * noise_scale
-// At batch 1 this launch is a latency chain, so: `cum` is copied to LDS once (the 7-step binary search then never
-// leaves the CU) and the 3 x 16 operands of a thread's channels are requested together through row descriptors.
-__global__ __launch_bounds__(64) void regulate_kernel(RegP p) {
+// One thread = four consecutive frames of one channel = one Philox block of the prior-noise stream (site 1): with
+// p.gen the N(0,1) draws are made here -- exactly the values randn_kernel would have written, which are stored to
+// `noise` as well (pe_debug_tensor, tests) -- instead of by a launch of their own in front of this one. With p.fold
+// (the whole utterance as one graph: no host read-back between the duration predictor and this kernel) every
+// workgroup first computes the durations and their running sum itself -- duration_kernel's arithmetic, T <= REG_MAXT
+// ids, integer results, so every workgroup gets the same table -- and workgroup (0, 0, b) publishes them (dur, cum,
+// logw, the frame counts for the host and for the kernels behind this one): one launch instead of three at the only
+// data-dependent point of the pipeline. `cum` lives in LDS, so the four 7-step searches never leave the CU.
+__global__ __launch_bounds__(256) void regulate_kernel(RegP p) {
   PE_KTRACE(16);
   __shared__ int scum[REG_MAXT];
-  const int b = blockIdx.z;
-  if (p.absmax && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) p.absmax[b] = 0u;
-  const int f = blockIdx.x * blockDim.x + threadIdx.x;
-  const int F = p.frames[b], T = p.tlens[b];
-  if ((int)(blockIdx.x * blockDim.x) >= F) return;
-  const int* cum = p.cum + b * p.d_bs;
-  const bool in_lds = T <= REG_MAXT;
-  if (in_lds) {
-    for (int i = threadIdx.x; i < T; i += 64) scum[i] = cum[i];
+  __shared__ long long part[256];
+  __shared__ int sF;
+  const int b = blockIdx.z, tid = threadIdx.x;
+  const bool lead = blockIdx.x == 0 && blockIdx.y == 0;
+  if (p.absmax && lead && tid == 0) p.absmax[b] = 0u;
+  const int T = p.tlens[b];
+  int F;
+  bool in_lds = T <= REG_MAXT;
+  if (p.fold) {
+    // ---- duration_kernel's arithmetic (modules.py:407-409; models.py:702-704), ids [lo, hi) per thread
+    const DurP& d = p.dur;
+    const int per = (T + 255) / 256;
+    const int lo = tid * per < T ? tid * per : T, hi = (lo + per < T) ? lo + per : T;
+    long long s = 0;
+    for (int t = lo; t < hi; ++t) {
+      const float zv = d.z0[(long)b * d.z_bs + t];
+      const float logw = (zv - d.m0) * d.es0;
+      const float w = expf(logw) * d.length_scale;
+      float c = ceilf(w);
+      c = c < 0.f ? 0.f : (c > 1.0e6f ? 1.0e6f : c);
+      const int dv = (int)c;
+      scum[t] = dv;
+      if (lead) {
+        d.dur[b * d.d_bs + t] = dv;
+        if (d.logw_out) d.logw_out[(long)b * d.d_bs + t] = logw;
+      }
+      s += dv;
+    }
+    part[tid] = s;
     __syncthreads();
-  }
-  if (f >= F) return;
-  int lo = 0, hi = T;                      // first i with cum[i] > f
-  if (in_lds) {
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (scum[mid] > f) hi = mid; else lo = mid + 1;
+    long long run = 0;                       // exclusive prefix of this thread's ids (LDS broadcast reads)
+    for (int i = 0; i < tid; ++i) run += part[i];
+    if (tid == 255) {
+      const long long tot = run + s;
+      const int f = tot < 1 ? 1 : (tot > MAX_FRAMES ? MAX_FRAMES + 1 : (int)tot);
+      sF = f < d.frame_cap ? f : d.frame_cap;
+      if (lead) {
+        d.frames[b] = f;
+        if (d.frames_host) d.frames_host[b] = f;
+        d.frames_clamped[b] = sF;
+      }
     }
+    for (int t = lo; t < hi; ++t) {
+      run += scum[t];
+      const int cv = run > MAX_FRAMES ? MAX_FRAMES + 1 : (int)run;
+      scum[t] = cv;
+      if (lead) d.cum[b * d.d_bs + t] = cv;
+    }
+    __syncthreads();
+    F = sF;
   } else {
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (cum[mid] > f) hi = mid; else lo = mid + 1;
+    F = p.frames[b];
+    if ((int)(blockIdx.x * 256) >= F) return;
+    if (in_lds) {
+      const int* cum = p.cum + b * p.d_bs;
+      for (int i = tid; i < T; i += 256) scum[i] = cum[i];
+      __syncthreads();
     }
   }
-  const bool hit = lo < T;                 // false only when every duration is 0 (frames clamped to 1)
-  const int c0 = blockIdx.y * 16;
-  const pe_rowsrc sd = pe_make_row(p.stats + (long)b * p.s_bs, 2 * p.C * p.s_cs);
-  const pe_rowsrc nd = pe_make_row(p.noise ? p.noise + (long)b * p.n_bs : p.stats, p.noise ? p.C * p.n_cs : 0);
-  float m[16], lg[16], nz[16];
+  const int f0 = ((int)blockIdx.x * 64 + (tid & 63)) * 4;
+  const int c = (int)blockIdx.y * 4 + (tid >> 6);
+  if (f0 >= F || c >= p.C) return;
+  const int* cum = p.cum + b * p.d_bs;
+  int id[4];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) {
-    const int c = c0 + k;
-    const bool cv = c < p.C;
-    m[k] = pe_row_load(sd, (hit && cv) ? c * p.s_cs + lo : -1);
-    lg[k] = pe_row_load(sd, (hit && cv) ? (p.C + c) * p.s_cs + lo : -1);
-    nz[k] = pe_row_load(nd, cv ? c * p.n_cs + f : -1);
+  for (int k = 0; k < 4; ++k) {
+    const int f = f0 + k;
+    int lo = 0, hi = T;                      // first i with cum[i] > f
+    if (in_lds) {
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (scum[mid] > f) hi = mid; else lo = mid + 1;
+      }
+    } else {
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (cum[mid] > f) hi = mid; else lo = mid + 1;
+      }
+    }
+    id[k] = (lo < T && f < F) ? lo : -1;     // -1: beyond the utterance, or every duration is 0 (frames clamped to 1)
   }
-  float* ob = p.out + (long)b * p.o_bs + f;
+  const pe_rowsrc sd = pe_make_row(p.stats + (long)b * p.s_bs, 2 * p.C * p.s_cs);
+  float m[4], lg[4], nz[4];
 #pragma unroll
-  for (int k = 0; k < 16; ++k)
-    if (c0 + k < p.C) ob[(long)(c0 + k) * p.o_cs] = m[k] + nz[k] * expf(lg[k]) * p.noise_scale;
+  for (int k = 0; k < 4; ++k) {
+    m[k] = pe_row_load(sd, id[k] >= 0 ? c * p.s_cs + id[k] : -1);
+    lg[k] = pe_row_load(sd, id[k] >= 0 ? (p.C + c) * p.s_cs + id[k] : -1);
+  }
+  float* nrow = p.noise ? p.noise + (long)b * p.n_bs + (long)c * p.n_cs + f0 : nullptr;
+  if (p.gen) {
+    randn4((((long)b * p.C + c) * RNG_PITCH + f0) >> 2, p.rng, 1, nz);
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (f0 + k < p.n_cs) nrow[k] = nz[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) nz[k] = (nrow && f0 + k < F) ? nrow[k] : 0.f;
+  }
+  float* ob = p.out + (long)b * p.o_bs + (long)c * p.o_cs + f0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    if (f0 + k < F) ob[k] = m[k] + nz[k] * expf(lg[k]) * p.noise_scale;
 }
 
 }  // namespace pe

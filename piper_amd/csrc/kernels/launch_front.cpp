@@ -96,7 +96,7 @@ void randn(hipStream_t stream, float* out, long rows, int cols, long stride, lon
   PE_LAUNCH(randn_kernel, dim3(randn_blocks(rows, cols)), dim3(256), 0, stream, out, rows, cols, stride, row0, state, site);
 }
 
-void regulate(dim3 grid, hipStream_t stream, const RegP& p) { PE_LAUNCH(regulate_kernel, grid, dim3(64), 0, stream, p); }
+void regulate(dim3 grid, hipStream_t stream, const RegP& p) { PE_LAUNCH(regulate_kernel, grid, dim3(256), 0, stream, p); }
 
 void cond(dim3 grid, hipStream_t stream, const float* emb_g, int gin, const int* sids, const float* w, const float* bias,
           int rows, float* out, int o_bs) {

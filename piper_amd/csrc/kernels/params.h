@@ -170,11 +170,13 @@ struct RegP {
   const float* stats; long s_bs; int s_cs;     // [B][2C][Ts]: m_p rows [0,C), logs_p rows [C,2C)
   const int* cum; int d_bs;
   const int* tlens; const int* frames;
-  const float* noise; long n_bs; int n_cs;     // [B][C][>=F] or null
+  float* noise; long n_bs; int n_cs;           // [B][C][>=F]: read (injected noise), or written by the kernel's own draws (gen)
   float noise_scale;
   float* out; long o_bs; int o_cs;
   int C;
   unsigned* absmax;                            // per-utterance peak accumulator of conv_post_kernel: zeroed here
+  const unsigned long long* rng; int gen;      // gen: the prior noise (site 1) is drawn here and stored to `noise`
+  DurP dur; int fold;                          // fold: the durations are computed here too (duration_kernel's fields)
 };
 static constexpr int REG_MAXT = 4096;          // ids whose cumulative durations fit the LDS copy; longer: search in global memory
 

@@ -47,6 +47,9 @@ inline f32x4 pe_row_load4(const pe_rowsrc& r, int idx) {
   return v;
 }
 inline float pe_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
+inline float pe_log2(float x) { return log2f(x); }
+inline float pe_sin_turns(float x) { return sinf(6.283185307179586f * x); }
+inline float pe_cos_turns(float x) { return cosf(6.283185307179586f * x); }
 #else
 #include <hip/hip_runtime.h>
 #define PE_LAUNCH(kernel, grid, block, smem, stream, ...) \
@@ -169,6 +172,10 @@ __device__ __forceinline__ void pe_row_store4(pe_rowsrc r, int idx, float a, flo
 __device__ __forceinline__ f32x4 pe_row_load4(pe_rowsrc r, int idx) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, idx * 4, 0, 0));
 }
+// the hardware's transcendental units: log2, and sine / cosine of an angle given in turns (x = 1 is a full circle)
+__device__ __forceinline__ float pe_log2(float x) { return __builtin_amdgcn_logf(x); }
+__device__ __forceinline__ float pe_sin_turns(float x) { return __builtin_amdgcn_sinf(x); }
+__device__ __forceinline__ float pe_cos_turns(float x) { return __builtin_amdgcn_cosf(x); }
 // leaky-relu for 0 < slope < 1 in two VALU ops: median(v, v*slope, +inf) = max(v, v*slope)
 __device__ __forceinline__ float pe_lrelu(float v, float slope) {
   return __builtin_amdgcn_fmed3f(v, v * slope, __builtin_inff());
