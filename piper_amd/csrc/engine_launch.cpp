@@ -210,6 +210,20 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     kend(kh);
     return;
   }
+  if (pol_.one_tap_direct(pc.gate, epi == EPI_CONVT, pc.ntaps)) {
+    // one tap: nothing to share between the MFMA's k rows, so the B operand skips LDS (kernels/conv1x1.h)
+    const dim3 grid((ncols + 63) / 64, (pc.mtiles + 1) / 2, B_);
+    int kh = -1;
+    if (prof_level_ >= 2) {
+      char nm[96];
+      int n = snprintf(nm, sizeof(nm), "conv1x1_kernel<1>");
+      if (pol_.prof_sites) snprintf(nm + n, sizeof(nm) - n, "|%dx%dx%d e%d L%d", pc.rows, pc.Cin, pc.ntaps, epi, len_mul);
+      kh = kbegin(krow(std::string(nm)), kflops, kbytes);
+    }
+    launch::conv1x1(grid, ls_, p);
+    kend(kh);
+    return;
+  }
   // 32x32 wave tiles everywhere (64x64 / 32x128 workgroup tiles; the gate form pairs two row tiles per wave): measured in
   // rounds 1-3 against 128x128, 64x128 and 256-column tiles at every batch size -- latency here is hidden across
   // workgroups, occupancy beats register reuse (profiles/r01_ablation.txt, r02_notes.md); the larger instantiations are gone

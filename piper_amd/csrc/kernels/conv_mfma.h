@@ -76,16 +76,21 @@ void conv_mfma_kernel(ConvP p) {
       for (int cc = 0; cc < NCOL; ++cc) xr[rr][cc] = pe_row_load(row, tbase + 64 * cc);
     }
   };
+  // (the pre-activation costs matrix-pipe time -- a VALU op takes 5-7 cycles out of the MFMA stream, profiles/r04_mfma_mix.txt --
+  // so it is two ops per element, max(v, v * slope), and none at all for inputs that take no activation: slope == 1)
   auto store_x = [&](int buf) {
     float* dst = xs + buf * KC * XS + wv * XS + lane;
+    if (slope != 1.f) {
 #pragma unroll
-    for (int rr = 0; rr < KC / 4; ++rr)
+      for (int rr = 0; rr < KC / 4; ++rr)
 #pragma unroll
-      for (int cc = 0; cc < NCOL; ++cc) {
-        float v = xr[rr][cc];
-        v = v > 0.f ? v : v * slope;
-        dst[4 * rr * XS + 64 * cc] = v;
-      }
+        for (int cc = 0; cc < NCOL; ++cc) dst[4 * rr * XS + 64 * cc] = pe_lrelu(xr[rr][cc], slope);
+    } else {
+#pragma unroll
+      for (int rr = 0; rr < KC / 4; ++rr)
+#pragma unroll
+        for (int cc = 0; cc < NCOL; ++cc) dst[4 * rr * XS + 64 * cc] = xr[rr][cc];
+    }
   };
   // unit u of a tile = (chunk, tap, sub): KS fragments per M tile
   auto load_a = [&](int u, float (&a)[MT][KS]) {

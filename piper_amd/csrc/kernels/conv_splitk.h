@@ -43,6 +43,7 @@ __device__ __forceinline__ void conv_splitk_body(const ConvP& p, const int b, fl
   const int wstride_mt = p.nchunks * ntaps * KH * 64;
   const float* xb = p.x + (long)b * p.x_bs;
   const float slope = p.in_slope;
+  const bool act_in = slope != 1.f;               // inputs without a pre-activation skip its two VALU ops per element
   const pe_rowsrc wsrc = pe_make_row(p.wp + (long)mtile0 * wstride_mt, MT * wstride_mt);
   // per-segment views (MS): taps, dilation, left padding, weights, input of the segment that owns global chunk c
   // (no integer division on the step path: nseg <= 3, two compares)
@@ -94,11 +95,12 @@ __device__ __forceinline__ void conv_splitk_body(const ConvP& p, const int b, fl
 #pragma unroll
     for (int h = 0; h < XB; ++h) {
       const bool live = xcol + 64 * h < L;
+      if (act_in) {
 #pragma unroll
-      for (int r = 0; r < KC; ++r) {
-        float v = live ? xr[h][r] : 0.f;
-        v = v > 0.f ? v : v * slope;
-        xw[r * XW + 64 * h + lane] = v;
+        for (int r = 0; r < KC; ++r) xw[r * XW + 64 * h + lane] = pe_lrelu(live ? xr[h][r] : 0.f, slope);
+      } else {
+#pragma unroll
+        for (int r = 0; r < KC; ++r) xw[r * XW + 64 * h + lane] = live ? xr[h][r] : 0.f;
       }
     }
   };
@@ -318,6 +320,7 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk16_kernel(ConvP p) {
   const int sub_stride = nchunks * ntaps * KS8 * 64;          // floats per 16-row sub-tile
   const float* xb = p.x + (long)b * p.x_bs;
   const float slope = p.in_slope;
+  const bool act_in = slope != 1.f;
   const pe_rowsrc wsrc = pe_make_row(p.wp16 + (long)st0 * sub_stride, MT16 * sub_stride);
   float* xw = sm + wv * KC * XW;
   const int CL = NW / p.tgroups;
@@ -338,11 +341,12 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk16_kernel(ConvP p) {
   };
   auto store_x = [&]() {
     const bool live = xcol < L;
+    if (act_in) {
 #pragma unroll
-    for (int r = 0; r < KC; ++r) {
-      float v = live ? xr[r] : 0.f;
-      v = v > 0.f ? v : v * slope;
-      xw[r * XW + lane] = v;
+      for (int r = 0; r < KC; ++r) xw[r * XW + lane] = pe_lrelu(live ? xr[r] : 0.f, slope);
+    } else {
+#pragma unroll
+      for (int r = 0; r < KC; ++r) xw[r * XW + lane] = live ? xr[r] : 0.f;
     }
   };
   float a[D][MT16][KS8];

@@ -14,6 +14,9 @@ namespace launch {
 void init_conv();
 // tiled implicit GEMM: cfg = tile configuration id (engine_internal.h CFG_*), halo = 64 | 128 columns of staging slack
 void conv_tile(int cfg, bool gate, int halo, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p);
+// one-tap convs of a batched call, B operand straight from global memory (conv1x1.h):
+// grid = (64-column tiles, blocks of 64 rows, utterances)
+void conv1x1(dim3 grid, hipStream_t stream, const ConvP& p);
 // split-K forms: nw = 4 | 8 | 12 waves
 void conv_splitk(bool gate, int nw, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p);
 void conv_splitk16(bool gate, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p);

@@ -2,6 +2,7 @@
 #include "launch.h"
 
 #include "conv_mfma.h"
+#include "conv1x1.h"
 #include "conv_splitk.h"
 
 namespace pe {
@@ -41,6 +42,8 @@ void conv_tile(int cfg, bool gate, int halo, dim3 grid, size_t smem, hipStream_t
   }
 #undef PE_CONV_LAUNCH
 }
+
+void conv1x1(dim3 grid, hipStream_t stream, const ConvP& p) { PE_LAUNCH((conv1x1_kernel<1>), grid, dim3(256), 0, stream, p); }
 
 void conv_splitk(bool gate, int nw, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p) {
   if (gate) {

@@ -554,3 +554,39 @@ def test_policy_knob_values_are_validated(emu_lib, monkeypatch):
     eng = Engine(blob=blob, lib=emu_lib)
     assert eng.xcc_pattern[1] == 32
     eng.close()
+
+
+def test_emulated_one_tap_convs_without_lds_are_bit_identical(emu_lib, monkeypatch):
+    """conv1x1_kernel (kernels/conv1x1.h): the batched one-tap convs -- q/k/v, conv_o, WN res/skip, coupling pre / post,
+    proj, dp.pre / proj -- with the B operand loaded from global memory straight into the MFMA's registers, against the tiled kernel they replace (PIPER_HIP_CONV1X1=0): the same fmaf chain, so the waveform
+    and the durations are bit-identical. Every conv is forced onto the batched route (PIPER_HIP_SPLITK_MAX=0, chains off);
+    a ragged batch whose frame counts straddle the 64-column tiles, row counts below one 32-row tile (post: 16 rows) and
+    input channels below one 32-channel chunk (pre: 16 channels); single- and multi-speaker."""
+    for preset, sids in (("tiny", None), ("tiny-ms", [3, 0, 1])):
+        cfg = W.preset(preset)
+        w = W.synthetic_weights(cfg, 1234)
+        lens = [5, 41, 23]
+        ids = [W.synthetic_phoneme_ids(T, i, id_max=cfg.n_vocab - 1) for i, T in enumerate(lens)]
+        nw = np.random.default_rng(11).standard_normal((len(lens), 2, max(lens))).astype(np.float32)
+        monkeypatch.setenv("PIPER_HIP_SPLITK_MAX", "0")
+        monkeypatch.setenv("PIPER_HIP_COLCHAIN", "0")
+        res = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("PIPER_HIP_CONV1X1", mode)
+            eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
+            eng.profile_enable(2)
+            r = eng.synthesize_batch(ids, (0.0, 1.1, 0.8), noise_w=nw, sids=sids)
+            names = {row["name"] for row in eng.profile()[5:] if row["launches"]}
+            assert (f"conv1x1_kernel<{mode}>" in names) == (mode != "0"), names
+            res[mode] = (r, eng.durations())
+            eng.close()
+        assert max(int(f) for f in res["0"][0].frames) > 64
+        for mode in ("1",):
+            assert np.array_equal(res[mode][1], res["0"][1])
+            for a, b in zip(res[mode][0].audio, res["0"][0].audio):
+                assert np.array_equal(a, b), mode
+        off = np.concatenate([[0], np.cumsum(lens)])
+        for i in range(len(lens)):
+            o = O.synthesize(w, cfg, ids[i], (0.0, 1.1, 0.8), nw[i][:, :lens[i]], sid=None if sids is None else sids[i])
+            assert np.array_equal(res["1"][1][off[i]:off[i + 1]], o["durations"])
+            assert np.max(np.abs(res["1"][0].audio[i] - o["audio"])) < 1e-5

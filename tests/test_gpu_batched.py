@@ -176,6 +176,11 @@ FORCED = [
      {"conv_mfma_kernel<2,2,2,1,16,true,64>", "conv_mfma_kernel<2,2,1,1,16,false,64>",
       "conv_mfma_kernel<1,4,1,1,16,false,64>", "conv_mfma_kernel<2,2,1,1,16,false,128>",
       "conv_mfma_kernel<1,4,1,1,16,false,128>"}),
+    # the one-tap convs (q/k/v, conv_o, res/skip, pre / post, proj) on the batched route: B operand straight from global
+    # memory (conv1x1_kernel, the default), and through the tiled kernel's LDS slabs
+    ("medium", [128, 70], {"PIPER_HIP_SPLITK_MAX": 0, "PIPER_HIP_MRF": 0, "PIPER_HIP_COLCHAIN": 0}, {"conv1x1_kernel<1>"}),
+    ("medium", [128, 70], {"PIPER_HIP_SPLITK_MAX": 0, "PIPER_HIP_MRF": 0, "PIPER_HIP_COLCHAIN": 0, "PIPER_HIP_CONV1X1": 0},
+     {"conv_mfma_kernel<1,4,1,1,16,false,64>"}),
     # the x-low voice's gate conv at batch: the 64 x 128 gate tile
     ("x-low", [64] * 32, {"PIPER_HIP_MRF": 0}, {"conv_mfma_kernel<1,4,2,1,16,true,64>"}),
     # several column tiles per workgroup (in-kernel slab pipeline across tiles)
