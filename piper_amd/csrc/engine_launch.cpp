@@ -417,7 +417,7 @@ void Engine::dds(const DdsW& d, View in, View out, View tmp, const DdsOpt* opt) 
     const int kh = kbegin(prof_level_ >= 2 ? krow(p.nchunks == 3 ? "dds_layer16_kernel<3>" : p.nchunks == 6 ? "dds_layer16_kernel<6>"
                                                                                        : "dds_layer16_kernel<8>") : 0, 0.0, dds_bytes(p));
     const dim3 grid16((Tg_ + 15) / 16, B_);
-    const size_t smem16 = ((size_t)2 * p.nchunks * 32 * 16 + 16 * 16) * sizeof(float);
+    const size_t smem16 = ((size_t)2 * p.nchunks * 32 * 16 + 16 * 16 + 16 * 3 * 16) * sizeof(float);     // Y, Z, red, the spline tail's S
     // <3> / <6> are compiled for exactly 96 / 192 padded channels; <8> takes any width up to 256
     launch::dds_layer(p.nchunks, grid16, smem16, stream_, p);
     kend(kh);

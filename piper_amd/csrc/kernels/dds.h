@@ -126,7 +126,7 @@ __device__ __forceinline__ void col_gemm16(const float* wp16, const float* bias,
 // [16-row tile][q][lane][4] with lane -> (row = lane & 15, k = lane >> 4) and step s = 4q + j covering ci = 4s + k.
 template <int NVT>                              // NVT = channel slots per thread: ceil(Hp / 32)
 __device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b, float* sm) {
-  constexpr int NC = 16;                        // sm: Y[Hp][16] | Z[Hp][16] | red[2][8][16]
+  constexpr int NC = 16;                        // sm: Y[Hp][16] | Z[Hp][16] | red[2][8][16] | S[16][3][16] (spline tail)
   PE_STAMP(2, 0);
   // The utterance length lives in device memory. Nothing below uses it until every operand load has been issued
   // against the row stride instead (Lb): its latency overlaps theirs, and the taps beyond the length are zeroed
@@ -304,7 +304,10 @@ __device__ __forceinline__ void dds_layer16_body(const DdsP& p, int ctile, int b
     // ConvFlow's spline on z1 (z0 passes through, scaled). The ~40 transcendentals of one position are spread over 16
     // lanes (lane j: softmax terms of bin j, derivative j), the order-sensitive sums run in one lane afterwards.
     constexpr int NB = SPL_NB;
-    float* S = Y;                                      // Y is free: [16 cols][3][16]
+    // (a region of its own: it used to alias Y, which is smaller than the 768 floats below 48 padded channels -- the tail of
+    // S then ran into the rows of Z that other waves were still reading. No reference quality is that narrow, the tiny test
+    // voices are; the emulator's wave-by-wave schedule found it, tests/emu/hip_emu.cpp)
+    float* S = red + 2 * 8 * NC;                       // [16 cols][3][16]
     const int scol = tid >> 4, j = tid & 15;           // first 256 threads: 16 consecutive lanes per column
     const int st = t0 + scol;
     if (tid < 256) {

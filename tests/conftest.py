@@ -47,7 +47,8 @@ _LONGEST_FIRST = [
     "test_xcd_aware_ffn_slice_order_is_bit_identical", "test_emulated_attention_conv_o_layernorm_in_one_launch[lens0",
     "test_jsonl_drivers_on_emulator", "test_small_call_kernels_do_not_depend_on_wave_order",
     "test_emulated_192_channel_small_call_kernels", "test_engine_group_matches_single_engine",
-    "test_emulated_multi_tile_conv_pipeline", "test_emulated_upconv_epilogues_are_bit_identical",
+    "test_emulated_one_tap_convs_without_lds_are_bit_identical", "test_emulated_multi_tile_conv_pipeline",
+    "test_emulated_upconv_epilogues_are_bit_identical",
 ]
 
 

@@ -42,6 +42,7 @@ struct Fiber {
   State st;
   emu_idx3 tid;
   unsigned useq;                  // PE_UNIFORM calls made so far (uniform_check)
+  unsigned cseq;                  // wave collectives entered so far (collective_parity)
 };
 
 // Fibers of ALL blocks that are live at once: one block (ordinary launches) or the whole grid (launch_coop).
@@ -54,7 +55,7 @@ static void* g_sched_sp;
 static int g_cur = -1;            // global fiber index = block slot * nthreads + thread
 static int g_nthreads = 0;
 static const std::function<void()>* g_body = nullptr;
-static std::vector<float> g_wave_scratch;      // [block slot][wave][4][64]
+static std::vector<float> g_wave_scratch;      // [block slot][wave][8][64]
 static std::vector<char> g_smem;
 static size_t g_smem_stride = 0;
 static std::vector<emu_idx3> g_block_of;       // block index of each live block slot
@@ -64,8 +65,9 @@ int lane() { return (g_cur % g_nthreads) & 63; }
 int wave() { return (g_cur % g_nthreads) >> 6; }
 float* wave_f(int slot) {
   const int nw = (g_nthreads + 63) / 64;
-  return &g_wave_scratch[(((size_t)(g_cur / g_nthreads) * nw + wave()) * 4 + slot) * 64];
+  return &g_wave_scratch[(((size_t)(g_cur / g_nthreads) * nw + wave()) * 8 + slot) * 64];
 }
+int collective_parity() { return (int)(g_f[g_cur].cseq++ & 1u); }
 
 static void yield_to_sched() { emu_switch(&g_f[g_cur].sp, g_sched_sp); }
 
@@ -125,7 +127,7 @@ static void run_blocks(unsigned nthreads, int nblocks) {
   }
   g_f.assign(total, Fiber{});
   const int nw = ((int)nthreads + 63) / 64;
-  g_wave_scratch.assign((size_t)nblocks * nw * 4 * 64, 0.f);
+  g_wave_scratch.assign((size_t)nblocks * nw * 8 * 64, 0.f);
   g_uniform.assign((size_t)nblocks * nw, std::vector<long long>());
   for (int i = 0; i < total; ++i) {
     init_fiber(i);
@@ -137,39 +139,39 @@ static void run_blocks(unsigned nthreads, int nblocks) {
   // written yet) gives the same answer here on every run of the default ascending order, but not under another one --
   // tests/test_emu_engine.py runs the small-call kernels under all three and compares.
   static const int order = [] { const char* t = getenv("EMU_ORDER"); return !t ? 0 : (!strcmp(t, "reverse") ? 1 : (!strcmp(t, "shuffle") ? 2 : 0)); }();
+  // Wave by wave: the 64 lanes of a wave take their turn back to back, and a wave whose live lanes have all reached a wave
+  // collective is released on the spot and runs on -- until it parks at a block barrier or ends -- before the next wave
+  // gets its turn (a wave's 64 stacks stay in cache; most rendezvous in the kernels are wave collectives). Between two
+  // block barriers one wave may therefore run arbitrarily far ahead of another: a legal order on the GPU, and the order
+  // in which the waves go (ascending, EMU_ORDER=reverse, =shuffle: another permutation every round) is what the
+  // wave-order tests vary.
   unsigned sweep = 0;
+  const int nwv_all = nblocks * nw;
+  auto run_fiber = [&](int i) {
+    g_cur = i;
+    threadIdx = g_f[i].tid;
+    blockIdx = g_block_of[i / (int)nthreads];
+    dyn_smem = (char*)(((uintptr_t)g_smem.data() + 63) & ~(uintptr_t)63) + (size_t)(i / (int)nthreads) * g_smem_stride;
+    emu_switch(&g_sched_sp, g_f[i].sp);
+  };
   for (;;) {
-    bool ran = false;
+    bool ran = false, released = false;
     ++sweep;
-    for (int k = 0; k < total; ++k) {
-      int i = k;
-      if (order == 1) i = total - 1 - k;
-      else if (order == 2) {                       // a different wave-interleaved permutation every sweep (bijective for any total)
-        const int nwv = (total + 63) / 64, w = k % nwv, l = k / nwv;
-        const int wp = (int)((w * 7u + sweep * 5u) % (unsigned)nwv);       // 7 and nwv coprime unless nwv % 7 == 0: fall back below
-        i = ((nwv % 7) ? wp : w) * 64 + (int)((l + sweep) % 64u);
-        if (i >= total) continue;
-      }
-      if (g_f[i].st != RUNNABLE) continue;
-      g_cur = i;
-      threadIdx = g_f[i].tid;
-      blockIdx = g_block_of[i / (int)nthreads];
-      dyn_smem = (char*)(((uintptr_t)g_smem.data() + 63) & ~(uintptr_t)63) + (size_t)(i / (int)nthreads) * g_smem_stride;
-      emu_switch(&g_sched_sp, g_f[i].sp);
-      ran = true;
-    }
-    int alive_all = 0;
-    bool released = false;
-    for (int blk = 0; blk < nblocks; ++blk) {
-      const int base = blk * (int)nthreads;
-      int alive = 0, at_block = 0;
-      for (int i = base; i < base + (int)nthreads; ++i) {
-        if (g_f[i].st != DONE) ++alive;
-        if (g_f[i].st == WAIT_BLOCK) ++at_block;
-      }
-      alive_all += alive;
-      for (int w = 0; w < nw; ++w) {
-        const int lo = base + w * 64, hi = std::min(lo + 64, base + (int)nthreads);
+    for (int k = 0; k < nwv_all; ++k) {
+      int wq = k;
+      if (order == 1) wq = nwv_all - 1 - k;
+      else if (order == 2) wq = (int)(((unsigned)k * 7u + sweep * 5u) % (unsigned)nwv_all), wq = (nwv_all % 7) ? wq : (int)((k + sweep) % (unsigned)nwv_all);
+      const int blk = wq / nw, w = wq % nw;
+      const int lo = blk * (int)nthreads + w * 64, hi = std::min(lo + 64, (blk + 1) * (int)nthreads);
+      for (;;) {
+        bool any = false;
+        for (int j = 0; j < hi - lo; ++j) {
+          const int i = order == 1 ? hi - 1 - j : (order == 2 ? lo + (int)((j + sweep) % (unsigned)(hi - lo)) : lo + j);
+          if (g_f[i].st != RUNNABLE) continue;
+          run_fiber(i);
+          any = true;
+        }
+        ran = ran || any;
         int live = 0, ww = 0;
         for (int i = lo; i < hi; ++i) {
           if (g_f[i].st != DONE) ++live;
@@ -182,8 +184,23 @@ static void run_blocks(unsigned nthreads, int nblocks) {
           }
           for (int i = lo; i < hi; ++i) g_f[i].st = RUNNABLE;
           released = true;
+          continue;                      // the wave runs on
         }
+        if (!any) break;                 // parked (block barrier, partial collective) or done
+        bool runnable = false;
+        for (int i = lo; i < hi; ++i) runnable = runnable || g_f[i].st == RUNNABLE;
+        if (!runnable) break;
       }
+    }
+    int alive_all = 0;
+    for (int blk = 0; blk < nblocks; ++blk) {
+      const int base = blk * (int)nthreads;
+      int alive = 0, at_block = 0;
+      for (int i = base; i < base + (int)nthreads; ++i) {
+        if (g_f[i].st != DONE) ++alive;
+        if (g_f[i].st == WAIT_BLOCK) ++at_block;
+      }
+      alive_all += alive;
       if (at_block > 0 && at_block == alive) {
         for (int i = base; i < base + (int)nthreads; ++i)
           if (g_f[i].st == WAIT_BLOCK) g_f[i].st = RUNNABLE;

@@ -55,7 +55,11 @@ void uniform_check(long long v);   // PE_UNIFORM: aborts when the lanes of a wav
 void block_sync();
 int lane();
 int wave();
-float* wave_f(int slot);   // 64-float scratch rows owned by the calling wave (slots 0..3)
+float* wave_f(int slot);   // 64-float scratch rows owned by the calling wave (slots 0..7)
+// Parity of the calling fiber's n-th wave collective (0 / 1 alternating): collectives exchange their operands through
+// TWO sets of scratch rows used in turn, so ONE rendezvous per collective is enough -- a lane that runs ahead writes the
+// other set, and it cannot get two collectives ahead because the next rendezvous waits for everybody.
+int collective_parity();
 }  // namespace emu
 
 inline void __syncthreads() { emu::block_sync(); }
@@ -64,12 +68,11 @@ inline void __syncthreads() { emu::block_sync(); }
 template <class T>
 inline T emu_exchange(T v, int src_lane) {
   static_assert(sizeof(T) == 4, "emu shuffles are 32-bit");
-  float* s = emu::wave_f(0);
+  float* s = emu::wave_f(emu::collective_parity());
   memcpy(&s[emu::lane()], &v, 4);
   emu::wave_sync();
   T r;
   memcpy(&r, &s[src_lane & 63], 4);
-  emu::wave_sync();
   return r;
 }
 template <class T> inline T __shfl_xor(T v, int m, int = 64) { return emu_exchange(v, emu::lane() ^ m); }
@@ -85,8 +88,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // v_mfma_f32_32x32x2_f32: lane l gives A[i=l&31][k=l>>5], B[k=l>>5][j=l&31];
 // D col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5); k-ordered fmaf chain.
 inline f32x16 emu_mfma_32x32x2(float a, float b, f32x16 c) {
-  float* sa = emu::wave_f(1);
-  float* sb = emu::wave_f(2);
+  const int par = emu::collective_parity();
+  float* sa = emu::wave_f(2 + par);
+  float* sb = emu::wave_f(4 + par);
   int l = emu::lane();
   sa[l] = a;
   sb[l] = b;
@@ -99,13 +103,13 @@ inline f32x16 emu_mfma_32x32x2(float a, float b, f32x16 c) {
     acc = fmaf(sa[32 + i], sb[32 + j], acc);
     c[r] = acc;
   }
-  emu::wave_sync();
   return c;
 }
 // v_mfma_f32_16x16x4_f32: A[l&15][k=l>>4], B[k=l>>4][l&15]; D col = l&15, row = (l>>4)*4 + r.
 inline f32x4 emu_mfma_16x16x4(float a, float b, f32x4 c) {
-  float* sa = emu::wave_f(1);
-  float* sb = emu::wave_f(2);
+  const int par = emu::collective_parity();
+  float* sa = emu::wave_f(2 + par);
+  float* sb = emu::wave_f(4 + par);
   int l = emu::lane();
   sa[l] = a;
   sb[l] = b;
@@ -117,21 +121,20 @@ inline f32x4 emu_mfma_16x16x4(float a, float b, f32x4 c) {
     for (int k = 0; k < 4; ++k) acc = fmaf(sa[k * 16 + i], sb[k * 16 + j], acc);
     c[r] = acc;
   }
-  emu::wave_sync();
   return c;
 }
 // v_mfma_f32_4x4x1_16B_f32: 16 blocks of a 4x4 outer product; lane l: A[block l/4][row l%4], B[block l/4][col l%4];
 // D VGPR r = D[block l/4][row r][col l%4].
 inline f32x4 emu_mfma_4x4x1(float a, float b, f32x4 c) {
-  float* sa = emu::wave_f(1);
-  float* sb = emu::wave_f(2);
+  const int par = emu::collective_parity();
+  float* sa = emu::wave_f(2 + par);
+  float* sb = emu::wave_f(4 + par);
   const int l = emu::lane();
   sa[l] = a;
   sb[l] = b;
   emu::wave_sync();
   const int blk = l >> 2;
   for (int r = 0; r < 4; ++r) c[r] = fmaf(sa[4 * blk + r], sb[l], c[r]);
-  emu::wave_sync();
   return c;
 }
 
@@ -139,13 +142,14 @@ inline f32x4 emu_mfma_4x4x1(float a, float b, f32x4 c) {
 // of two bf16 each); D as the f32 32x32 form. Products of bf16 values are exact in f32; f32 accumulation.
 typedef __bf16 emu_bf16x8 __attribute__((ext_vector_type(8)));
 inline f32x16 emu_mfma_bf16_32x32x16(emu_bf16x8 a, emu_bf16x8 b, f32x16 c) {
-  float* sa = emu::wave_f(1);
-  float* sb = emu::wave_f(2);
   const int l = emu::lane(), j = l & 31;
   float au[4], bu[4];
   memcpy(au, &a, 16);
   memcpy(bu, &b, 16);
   for (int d = 0; d < 4; ++d) {
+    const int par = emu::collective_parity();
+    float* sa = emu::wave_f(2 + par);
+    float* sb = emu::wave_f(4 + par);
     sa[l] = au[d];
     sb[l] = bu[d];
     emu::wave_sync();
@@ -166,7 +170,6 @@ inline f32x16 emu_mfma_bf16_32x32x16(emu_bf16x8 a, emu_bf16x8 b, f32x16 c) {
       }
       c[r] = acc;
     }
-    emu::wave_sync();
   }
   return c;
 }

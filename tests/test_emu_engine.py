@@ -561,8 +561,8 @@ def test_emulated_one_tap_convs_without_lds_are_bit_identical(emu_lib, monkeypat
     proj, dp.pre / proj -- with the B operand loaded from global memory straight into the MFMA's registers, against the tiled kernel they replace (PIPER_HIP_CONV1X1=0): the same fmaf chain, so the waveform
     and the durations are bit-identical. Every conv is forced onto the batched route (PIPER_HIP_SPLITK_MAX=0, chains off);
     a ragged batch whose frame counts straddle the 64-column tiles, row counts below one 32-row tile (post: 16 rows) and
-    input channels below one 32-channel chunk (pre: 16 channels); single- and multi-speaker."""
-    for preset, sids in (("tiny", None), ("tiny-ms", [3, 0, 1])):
+    input channels below one 32-channel chunk (pre: 16 channels); a multi-speaker voice (per-utterance bias streams)."""
+    for preset, sids in (("tiny-ms", [3, 0, 1]),):
         cfg = W.preset(preset)
         w = W.synthetic_weights(cfg, 1234)
         lens = [5, 41, 23]
