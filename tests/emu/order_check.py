@@ -16,9 +16,14 @@ from piper_amd.engine import Engine                      # noqa: E402
 
 def main():
     elib = L.bind(os.path.join(ROOT, "tests", "emu", "libpiper_hip_emu.so"))
-    cfg = W.preset("tiny-ms", hidden=192, inter=192, filter=96, n_layers=2)
+    case = sys.argv[1] if len(sys.argv) > 1 else "small192"
+    if case == "small192":        # the 4-column small-call kernels of the 192-channel voices
+        cfg = W.preset("tiny-ms", hidden=192, inter=192, filter=96, n_layers=2)
+        lens, sids = [9, 21], [1, 3]
+    else:                         # a tiny preset as it is: the general kernels (16-column DDSConv layers with the fused
+        cfg = W.preset(case)      # pre / proj / spline, attention, split-K convs, the fused stage kernels)
+        lens, sids = [17, 6], ([2, 0] if cfg.n_speakers > 1 else None)
     w = W.synthetic_weights(cfg, 77)
-    lens, sids = [9, 21], [1, 3]
     ids = [W.synthetic_phoneme_ids(T, i, id_max=cfg.n_vocab - 1) for i, T in enumerate(lens)]
     nw = np.random.default_rng(5).standard_normal((len(lens), 2, max(lens))).astype(np.float32)
     eng = Engine(blob=W.pack_blob(cfg, w), lib=elib)
@@ -29,7 +34,7 @@ def main():
     off = np.concatenate([[0], np.cumsum(lens)])
     worst, same = 0.0, True
     for i in range(len(lens)):
-        o = O.synthesize(w, cfg, ids[i], (0.0, 1.0, 0.8), nw[i], sid=sids[i])
+        o = O.synthesize(w, cfg, ids[i], (0.0, 1.0, 0.8), nw[i][:, :lens[i]], sid=None if sids is None else sids[i])
         same = same and bool(np.array_equal(durs[off[i]:off[i + 1]], o["durations"])) and r.audio[i].shape == o["audio"].shape
         if r.audio[i].shape == o["audio"].shape:
             worst = max(worst, float(np.max(np.abs(r.audio[i] - o["audio"]))))

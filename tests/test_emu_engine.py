@@ -421,6 +421,28 @@ def test_small_call_kernels_do_not_depend_on_wave_order(emu_lib):
     assert outs[0]["checksum"] == outs[1]["checksum"]
 
 
+@pytest.mark.parametrize("preset", ["tiny", "tiny-high", "tiny-ms"])
+def test_pipeline_does_not_depend_on_wave_order(emu_lib, preset):
+    """The same check for the general kernels, on the tiny presets as they are: 16-column DDSConv layers with the fused
+    ConvFlow.pre / proj / spline, attention, split-K convs, the fused stage kernels (ResBlock1 and 2). The emulator runs a
+    wave as far as it can get before the next one takes its turn, so between two block barriers one wave is arbitrarily far
+    ahead of another -- ascending, descending or in another permutation every round: three schedules, one answer, the
+    oracle's. (This is the test that would have caught dds_layer16_kernel's spline scratch running into rows of Z that
+    other waves were still reading on voices below 48 channels, profiles/r04_notes.md.)"""
+    import json
+    import subprocess
+    import sys
+    outs = []
+    for order in ("", "reverse", "shuffle"):
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "emu", "order_check.py"), preset], capture_output=True,
+                           text=True, timeout=900, env=dict(os.environ, EMU_ORDER=order))
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    for o in outs:
+        assert o["durations_equal"] and o["worst"] < 1e-5, o
+    assert outs[0]["checksum"] == outs[1]["checksum"] == outs[2]["checksum"]
+
+
 def test_xcd_dispatch_probe_and_override(emu_lib, monkeypatch):
     """pe_xcc_pattern: the probe launch at engine creation (the emulator plays a round-robin over 8 XCDs) is recognised as
     period 8; PIPER_HIP_XCD overrides the period the 4-column kernels order their tiles by (0 = workgroup order)."""
