@@ -1,4 +1,4 @@
-# Round 4, call 24: staging without the pre-activation's VALU ops where the input takes none (slope == 1; two ops instead of
+# Round 4, calls 24 ...: A/B of the tree's build against build/ab/libpiper_hip_base.so (the previous commit) on B=1, 64 x 128 medium and high, one box, alternating twice
 # three elsewhere) in the tiled and split-K kernels + conv1x1_kernel<1> as the default, against the previous commit's build:
 # B=1, 64 x 128 medium, 64 x 128 high, one box, alternating twice.
 cd $GRAFT_REPO_ROOT
