@@ -129,6 +129,11 @@ __global__ __launch_bounds__(256) void regulate_kernel(RegP p) {
   const int T = p.tlens[b];
   int F;
   bool in_lds = T <= REG_MAXT;
+  // the draws depend on nothing this kernel computes: made first, under the latency of the loads below
+  const int f0 = ((int)blockIdx.x * 64 + (tid & 63)) * 4;
+  const int c = (int)blockIdx.y * 4 + (tid >> 6);
+  float nz[4] = {0.f, 0.f, 0.f, 0.f};
+  if (p.gen && c < p.C) randn4((((long)b * p.C + c) * RNG_PITCH + f0) >> 2, p.rng, 1, nz);
   if (p.fold) {
     // ---- duration_kernel's arithmetic (modules.py:407-409; models.py:702-704), ids [lo, hi) per thread
     const DurP& d = p.dur;
@@ -180,8 +185,6 @@ __global__ __launch_bounds__(256) void regulate_kernel(RegP p) {
       __syncthreads();
     }
   }
-  const int f0 = ((int)blockIdx.x * 64 + (tid & 63)) * 4;
-  const int c = (int)blockIdx.y * 4 + (tid >> 6);
   if (f0 >= F || c >= p.C) return;
   const int* cum = p.cum + b * p.d_bs;
   int id[4];
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(256) void regulate_kernel(RegP p) {
     id[k] = (lo < T && f < F) ? lo : -1;     // -1: beyond the utterance, or every duration is 0 (frames clamped to 1)
   }
   const pe_rowsrc sd = pe_make_row(p.stats + (long)b * p.s_bs, 2 * p.C * p.s_cs);
-  float m[4], lg[4], nz[4];
+  float m[4], lg[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     m[k] = pe_row_load(sd, id[k] >= 0 ? c * p.s_cs + id[k] : -1);
@@ -211,7 +214,6 @@ __global__ __launch_bounds__(256) void regulate_kernel(RegP p) {
   }
   float* nrow = p.noise ? p.noise + (long)b * p.n_bs + (long)c * p.n_cs + f0 : nullptr;
   if (p.gen) {
-    randn4((((long)b * p.C + c) * RNG_PITCH + f0) >> 2, p.rng, 1, nz);
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       if (f0 + k < p.n_cs) nrow[k] = nz[k];
