@@ -169,7 +169,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     int kh = -1;
     if (prof_level_ >= 2) {
       char nm[96];
-      if (k16) snprintf(nm, sizeof(nm), "conv_splitk16_kernel<%s>", pc.gate ? "true,12,2" : "false,8,4");
+      if (k16) snprintf(nm, sizeof(nm), "conv_splitk16_kernel<%s>", pc.gate ? (pol_.gate_half_groups(true, pc.nchunks, pc.ntaps, (long)((ncols + 15) / 16) * (pc.mtiles / MT) * B_) ? "true,6,5,2" : "true,12,2") : "false,8,4");
       else snprintf(nm, sizeof(nm), "conv_splitk_kernel<%d,%s,%d,%d>", MT, pc.gate ? "true" : "false", NW,
                     pc.gate ? (NW == 12 ? 2 : 3) : 4);
       kh = kbegin(krow(std::string(nm)), kflops, kbytes);
@@ -177,9 +177,15 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     // MFMA-pipe bound inside the workgroup (>= 24 chunk-tap units) although most CUs idle: 16 output columns
     if (k16) {
       dim3 grid16((ncols + 15) / 16, pc.mtiles / MT, B_);
-      const int nw = pc.gate ? 12 : 8;
-      p.tgroups = pc.gate ? (pc.nchunks <= 6 ? 2 : 1) : 1;
-      launch::conv_splitk16(pc.gate, grid16, (size_t)nw * KC * 64 * sizeof(float), ls_, p);
+      // the gate conv of a SHORT utterance (<= 128 workgroups of 12 waves: half the CUs idle): half a channel group per
+      // workgroup on 6 waves (one chunk and every tap each, all five weight steps in flight at entry) is twice the
+      // workgroups with half the matrix time each -- 64 ids: 9.64 -> 8.37 us per launch; beyond one workgroup per CU it
+      // loses (128 ids, 324 workgroups: 9.77 -> 12.6 us; profiles/r04_notes.md, call 32)
+      const bool half = pol_.gate_half_groups(pc.gate, pc.nchunks, pc.ntaps, (long)grid16.x * grid16.y * grid16.z);
+      if (half) grid16.y *= 2;
+      const int nw = pc.gate ? (half ? 6 : 12) : 8;
+      p.tgroups = pc.gate ? (half ? 1 : (pc.nchunks <= 6 ? 2 : 1)) : 1;
+      launch::conv_splitk16(pc.gate, grid16, (size_t)nw * KC * 64 * sizeof(float), ls_, p, half);
       kend(kh);
       return;
     }

@@ -302,11 +302,15 @@ __global__ __launch_bounds__(64 * NW, 2) void conv_splitk_sum_kernel(ConvP p) {
 // [16-row sub-tile][chunk][tap][q = 0..1][lane][4] with lane -> (row = lane & 15, k = lane >> 4), float4 element j of
 // group q = k-step s = 4q + j, input channel chunk*32 + 4s + k; ascending k inside and across instructions, i.e. the
 // same fmaf chain as the 32x32x2 form.
-template <bool GATE, int NW, int D>
+// GT (gate only): 16-row sub-tiles per workgroup -- 4 = a whole 32-channel group (tanh a, tanh b, sigmoid a, sigmoid b), 2 =
+// half of one (tanh h, sigmoid h; blockIdx.y = 2 * group + h): twice the workgroups with half the matrix time each, for
+// launches whose workgroups fit the chip either way (one utterance through the WN gate conv: 162 -> 324).
+template <bool GATE, int NW, int D, int GT = 4>
 __global__ __launch_bounds__(64 * NW) void conv_splitk16_kernel(ConvP p) {
   PE_KTRACE(4);
-  constexpr int BN = 16, XW = 64, KS8 = KC / 4, MT16 = GATE ? 4 : 2;
-  constexpr int NSLOT = GATE ? 8 : MT16 * 4;                  // result slots per lane position (gate: tanh/sigmoid pairs)
+  constexpr int BN = 16, XW = 64, KS8 = KC / 4, MT16 = GATE ? GT : 2;
+  constexpr int TSTR = (GATE && GT == 2) ? 2 : 1;             // sub-tile stride of a workgroup's tiles in the packed order
+  constexpr int NSLOT = GATE ? 2 * GT : MT16 * 4;             // result slots per lane position (gate: tanh/sigmoid pairs)
   constexpr int NS = (NSLOT + NW - 1) / NW;                   // epilogue slots per wave
   PE_DYN_SMEM(float, sm);                         // NW x [KC][XW] slabs, then NW x [MT16*4][64] partial tiles
   const int b = blockIdx.z;
@@ -314,14 +318,15 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk16_kernel(ConvP p) {
   const int n0 = blockIdx.x * BN;
   const int tid = threadIdx.x, lane = tid & 63, wv = PE_UNIFORM(tid >> 6);
   const int l15 = lane & 15, lq = lane >> 4;
-  const int st0 = blockIdx.y * MT16;              // first 16-row sub-tile of this workgroup
+  // first 16-row sub-tile of this workgroup (half-group gate form: group (y >> 1), tiles (tanh h, sigmoid h) two apart)
+  const int st0 = (GATE && GT == 2) ? ((int)blockIdx.y >> 1) * 4 + ((int)blockIdx.y & 1) : (int)blockIdx.y * MT16;
   const int col = n0 + l15;
   const int ntaps = p.ntaps, nchunks = p.nchunks;
   const int sub_stride = nchunks * ntaps * KS8 * 64;          // floats per 16-row sub-tile
   const float* xb = p.x + (long)b * p.x_bs;
   const float slope = p.in_slope;
   const bool act_in = slope != 1.f;
-  const pe_rowsrc wsrc = pe_make_row(p.wp16 + (long)st0 * sub_stride, MT16 * sub_stride);
+  const pe_rowsrc wsrc = pe_make_row(p.wp16 + (long)st0 * sub_stride, ((MT16 - 1) * TSTR + 1) * sub_stride);
   float* xw = sm + wv * KC * XW;
   const int CL = NW / p.tgroups;
   const int wi = wv % CL, wg = wv / CL;
@@ -357,7 +362,7 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk16_kernel(ConvP p) {
     for (int i = 0; i < MT16; ++i)
 #pragma unroll
       for (int q = 0; q < KS8 / 4; ++q) {
-        const f32x4 t = pe_row_load4(wsrc, off + i * sub_stride + q * 256 + lane * 4);
+        const f32x4 t = pe_row_load4(wsrc, off + i * TSTR * sub_stride + q * 256 + lane * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) dst[i][4 * q + j] = t[j];
       }
@@ -391,7 +396,8 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk16_kernel(ConvP p) {
     const int s = wv + NW * i;
     e_b1[i] = 0.f; e_b2[i] = 0.f; e_o1[i] = 0.f; e_o2[i] = 0.f; e_dst[i] = nullptr;
     if constexpr (GATE) {
-      const int ch = blockIdx.y * 32 + (s >> 2) * 16 + 4 * lq + (s & 3);
+      const int ch = GT == 2 ? ((int)blockIdx.y >> 1) * 32 + ((int)blockIdx.y & 1) * 16 + 4 * lq + (s & 3)
+                             : (int)blockIdx.y * 32 + (s >> 2) * 16 + 4 * lq + (s & 3);
       if (s < NSLOT && ch < p.split && col < ncols) {
         e_b1[i] = p.bias[ch];
         e_o1[i] = p.bias[p.split + ch];
@@ -459,7 +465,7 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk16_kernel(ConvP p) {
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
           ta += red[(w * MT16 * 4 + s) * 64 + lane];
-          sa += red[(w * MT16 * 4 + 8 + s) * 64 + lane];
+          sa += red[(w * MT16 * 4 + NSLOT + s) * 64 + lane];
         }
       }
       if (e_dst[i]) {

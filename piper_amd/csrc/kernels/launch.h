@@ -19,7 +19,8 @@ void conv_tile(int cfg, bool gate, int halo, dim3 grid, size_t smem, hipStream_t
 void conv1x1(dim3 grid, hipStream_t stream, const ConvP& p);
 // split-K forms: nw = 4 | 8 | 12 waves
 void conv_splitk(bool gate, int nw, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p);
-void conv_splitk16(bool gate, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p);
+// half (gate only): half a 32-channel group per workgroup on six waves with the whole K range in flight (conv_splitk.h GT = 2)
+void conv_splitk16(bool gate, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p, bool half = false);
 void conv_group(bool wide, dim3 grid, size_t smem, hipStream_t stream, const ConvG& g);
 void conv_group_sum(dim3 grid, size_t smem, hipStream_t stream, const ConvP& p);
 

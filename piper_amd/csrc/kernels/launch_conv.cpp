@@ -57,8 +57,9 @@ void conv_splitk(bool gate, int nw, dim3 grid, size_t smem, hipStream_t stream, 
   }
 }
 
-void conv_splitk16(bool gate, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p) {
-  if (gate) PE_LAUNCH((conv_splitk16_kernel<true, 12, 2>), grid, dim3(64 * 12), smem, stream, p);
+void conv_splitk16(bool gate, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p, bool half) {
+  if (gate && half) PE_LAUNCH((conv_splitk16_kernel<true, 6, 5, 2>), grid, dim3(64 * 6), smem, stream, p);
+  else if (gate) PE_LAUNCH((conv_splitk16_kernel<true, 12, 2>), grid, dim3(64 * 12), smem, stream, p);
   else PE_LAUNCH((conv_splitk16_kernel<false, 8, 4>), grid, dim3(64 * 8), smem, stream, p);
 }
 

@@ -37,6 +37,7 @@ struct LaunchPolicy {
   long convt_vec = 1;         // polyphase up-conv tiles stored as 16- / 8-byte pieces straight from the accumulators (0: one 4-byte store per phase)
   long xcd = -1;              // XCDs the dispatch round-robins over: -1 = probed at engine creation, 0 = tiles in workgroup order
   long xcd_ffn = 1;           // fused FFN: (column tile, slice) dealt to the XCDs slice-major (0: blockIdx order)
+  long gate_half = 1;         // short one-utterance calls: the WN gate conv on half a 32-channel group per workgroup (6 waves) while twice the workgroups still fit one per CU
   long conv1x1 = 1;           // batched one-tap convs through conv1x1_kernel (B operand straight from global memory): 0 = the tiled kernel
   long prof_sites = 0;        // level-2 profile rows of the tiled conv kernel per conv SHAPE (tuning aid)
   long debug_keep = 0;        // test hook: keep z_p for pe_debug_tensor
@@ -70,6 +71,9 @@ struct LaunchPolicy {
     return (wide_splitk == 1 && gate && units >= 24 && nchunks <= 6 && ntaps >= 4) || wide_splitk == 2;
   }
   bool one_tap_direct(bool gate, bool convt, int ntaps) const { return conv1x1 && !gate && !convt && ntaps == 1; }
+  bool gate_half_groups(bool gate, int nchunks, int ntaps, long workgroups_whole) const {
+    return gate_half && gate && nchunks == 6 && ntaps <= 5 && 2 * workgroups_whole <= 256;      // one workgroup per CU at most
+  }
   int tiles_per_workgroup() const { return tpb > 0 ? (int)tpb : 1; }
   // 192-channel chains
   bool chain16(double cols, bool frames, int k1, int half) const {     // colchain_kernel<6> / lngemm_kernel<6>
