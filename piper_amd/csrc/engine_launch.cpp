@@ -169,7 +169,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     int kh = -1;
     if (prof_level_ >= 2) {
       char nm[96];
-      if (k16) snprintf(nm, sizeof(nm), "conv_splitk16_kernel<%s>", pc.gate ? (pol_.gate_half_groups(true, pc.nchunks, pc.ntaps, (long)((ncols + 15) / 16) * (pc.mtiles / MT) * B_) ? "true,6,5,2" : "true,12,2") : "false,8,4");
+      if (k16) snprintf(nm, sizeof(nm), "conv_splitk16_kernel<%s>", pc.gate ? (pol_.gate_half_groups(true, pc.nchunks, pc.ntaps, (long)((ncols + 15) / 16) * (pc.mtiles / MT) * B_) ? "true,6,5,2" : "true,12,2,4") : "false,8,4,4");      // (as rocprofv3 prints them: the default GT = 4 included)
       else snprintf(nm, sizeof(nm), "conv_splitk_kernel<%d,%s,%d,%d>", MT, pc.gate ? "true" : "false", NW,
                     pc.gate ? (NW == 12 ? 2 : 3) : 4);
       kh = kbegin(krow(std::string(nm)), kflops, kbytes);

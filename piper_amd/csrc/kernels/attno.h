@@ -29,6 +29,7 @@ __global__ __launch_bounds__(512) void attno_kernel(AttnOP p) {
   static_assert(H == 192 && DK % 32 == 0, "compiled for the 192-channel voices (two heads of 96)");
   PE_DYN_SMEM(float, sm);
   const int b = blockIdx.y, i0 = blockIdx.x * AO_QB;
+  PE_STAMP(0, 0);
   const int T = p.lens[b];
   if (i0 >= T) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = PE_UNIFORM(tid >> 6), hh = PE_UNIFORM(wv >> 2), w4 = PE_UNIFORM(wv & 3);
@@ -103,6 +104,7 @@ __global__ __launch_bounds__(512) void attno_kernel(AttnOP p) {
     }
   }
   __syncthreads();
+  PE_STAMP(0, 1);
 
   // ---- 1. relative-key partial products R[q][r] = Q . rel_k^T (a quarter of the channel steps per wave of the head),
   // then the score tiles
@@ -142,6 +144,7 @@ __global__ __launch_bounds__(512) void attno_kernel(AttnOP p) {
     }
   }
   __syncthreads();
+  PE_STAMP(0, 2);
   // ---- 2a. relative-key band: S[i][i + r - w] += q_i . rel_k[r] (the head's four partial tiles, in wave order)
   for (int e = t4; e < AO_QB * nrel; e += 256) {
     const int i = e & 15, r = e >> 4;
@@ -152,6 +155,7 @@ __global__ __launch_bounds__(512) void attno_kernel(AttnOP p) {
     }
   }
   __syncthreads();
+  PE_STAMP(0, 3);
   // ---- 2b. softmax over the valid keys: row = t4 / 16, 16 adjacent lanes per row
   {
     const int i = t4 >> 4, sj = t4 & 15;
@@ -196,6 +200,7 @@ __global__ __launch_bounds__(512) void attno_kernel(AttnOP p) {
       for (int j = sj; j < Tpad; j += 16) Sr[j] = (j < T) ? Sr[j] * inv : 0.f;
     }
   }
+  PE_STAMP(0, 4);
   // conv_o's weight row blocks and the operands of the LayerNorm tail: in flight under phase 3
   const int col = tid & 15, rl = tid >> 4, t = i0 + col;
   const bool ok = t < T;
@@ -260,6 +265,7 @@ __global__ __launch_bounds__(512) void attno_kernel(AttnOP p) {
       }
     }
   }
+  PE_STAMP(0, 5);
   __syncthreads();                                             // every wave is done with the V chunks: IN may overwrite them
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
@@ -267,9 +273,11 @@ __global__ __launch_bounds__(512) void attno_kernel(AttnOP p) {
     if (two) IN[(hh * DK + (w4 + 4) * 16 + 4 * lq + r) * NC + l15] = o1[r];
   }
   __syncthreads();
+  PE_STAMP(0, 6);
   // ---- 4. conv_o + residual + norm_layers_1 (colchain_kernel mode 0)
   col_gemm16<2 * NVT, true, true>(p.wo16, p.bo, H, H, H, IN, wv, lane, [&](int row, int cc, float v) { Z[row * NC + cc] = v; }, &gw);
   __syncthreads();
+  PE_STAMP(0, 7);
   int red_flip = 0;
   auto col_sum = [&](float x) -> float { return pe_col_sum16(x, red, red_flip, wv, lane, col); };
   float v[NVT];
@@ -292,6 +300,7 @@ __global__ __launch_bounds__(512) void attno_kernel(AttnOP p) {
     const int c = rl + 32 * k;
     ob[(long)c * p.x_cs + t] = (v[k] - mean) * rstd * gg[k] + bb[k];
   }
+  PE_STAMP(0, 8);
 }
 
 }  // namespace pe

@@ -204,7 +204,10 @@ FORCED = [
      {"conv_splitk_kernel<2,true,12,2>", "conv_splitk_kernel<1,false,12,4>"}),
     ("x-low", [64], {"PIPER_HIP_SPLITK16": 0, "PIPER_HIP_WIDE_SPLITK": 0}, {"conv_splitk_kernel<2,true,4,3>"}),
     ("medium", [128, 17], {"PIPER_HIP_SPLITK16": 3},
-     {"conv_splitk16_kernel<true,12,2>", "conv_splitk16_kernel<false,8,4>"}),
+     {"conv_splitk16_kernel<true,12,2,4>", "conv_splitk16_kernel<false,8,4,4>"}),
+    # a short utterance: the gate conv on half channel groups (six waves, twice the workgroups), and forced back to whole groups
+    ("medium", [48], {}, {"conv_splitk16_kernel<true,6,5,2>"}),
+    ("medium", [48], {"PIPER_HIP_GATE_HALF": 0}, {"conv_splitk16_kernel<true,12,2,4>"}),
     ("high", [48], {"PIPER_HIP_SPLITK_MAX": 0}, {"conv_mfma_kernel<2,2,2,1,16,true,64>"}),
     # the 192-channel small-call chains (DDSConv layers, colchain, lngemm): the 4-column forms on the 4x4x1 MFMA (default for small calls) forced
     # on for a ragged batch beyond its column limit, and off (the 16-column form)
@@ -214,7 +217,7 @@ FORCED = [
     # the encoder FFN as one launch with partial outputs per 48-row slice of the hidden dimension (default for small
     # calls), and conv by conv behind the 4-column chains
     ("medium", [128, 13, 14, 15, 29], {}, {"ffn_kernel", "lngemm4_kernel"}),
-    ("medium", [128, 31], {"PIPER_HIP_FFN": 0}, {"lngemm4_kernel", "conv_splitk16_kernel<false,8,4>"}),
+    ("medium", [128, 31], {"PIPER_HIP_FFN": 0}, {"lngemm4_kernel", "conv_splitk16_kernel<false,8,4,4>"}),
     # attention + conv_o + norm_layers_1 as one launch (default for small calls): on for a ragged batch incl. lengths on
     # both softmax paths, and off (attn_kernel + colchain4_kernel)
     ("medium", [128, 13, 1, 129], {}, {"attno_kernel<96>", "lngemm4_kernel", "ffn_kernel"}),
