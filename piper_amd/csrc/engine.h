@@ -191,13 +191,20 @@ class Engine {
   const float* w4_of(const float* w16) const { auto it = w4_of_.find(w16); return it == w4_of_.end() ? nullptr : it->second; }
   float* dp_proj16_ = nullptr;
   float* dp_pre16_ = nullptr;
+  // enc_p.proj and dp.pre stacked for lngemm4_kernel (small calls): pack4 matrix, stacked bias, rows of proj
+  float* projpre4_ = nullptr; float* projpre_bias_ = nullptr; int projpre_split_ = 0;
   void colchain(const struct ColP& p, int B, int Lmax, double flops);
   bool conv1x1_col4(const float* w16, const float* bias, int rows, View in, View out, const int* lens, int B, int Lmax,
                     double flops, const float* bias2 = nullptr, long bias2_bs = 0, const float* w4direct = nullptr, int kin = 192,
                     long max_cols = 0);
   const float* pack4_conv_pad192(const WeightSet& ws, const std::string& wname, int in_rev, int out_rev);
+  // second: rows >= split of a STACKED pack4 matrix (w4) are another conv over the same LN(y), written to out2 with the
+  // per-utterance bias vector bias2 on top (enc_p.proj + dp.pre of a small call in one launch)
+  struct LnSecond { const float* w4 = nullptr; int split = 0; View out2{nullptr, 0, 0}; const float* bias2 = nullptr; long bias2_bs = 0; };
   void lngemm(View y, const float* g, const float* b, View x, const float* w16, const float* bias, int rows, View out,
-              int T, double flops, const float* parts = nullptr, int nparts = 0, const float* pbias = nullptr);
+              int T, double flops, const float* parts = nullptr, int nparts = 0, const float* pbias = nullptr,
+              const LnSecond* second = nullptr);
+  bool proj_pre_stacked() const;     // this call runs enc_p.proj and dp.pre as one lngemm4_kernel launch
   float* pack16_conv(const WeightSet& ws, const std::string& wname, int in_rev, int out_rev);
   // XCD dispatch pattern of this device (xcc_probe_kernel at engine creation): XCC id of workgroups 0..63 of a 1-D launch,
   // and the period P when it is a round-robin over P XCDs (0: anything else -- the 4-column kernels then use tile = id)

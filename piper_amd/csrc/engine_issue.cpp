@@ -16,6 +16,14 @@ bool Engine::stage_a_ffn_fused() const {
   for (auto& e : enc_) f = f && e.f1p && e.f2p && w4_of(e.qkv16);
   return f;
 }
+// Whether enc_p.proj and dp.pre of the current call go as ONE lngemm4_kernel launch over the stacked matrix (small calls of
+// the 192-channel voices, where both would take 4-column launches anyway): a function of the call alone.
+bool Engine::proj_pre_stacked() const {
+  double tsum = 0;
+  for (int b = 0; b < B_; ++b) tsum += tlens_h_[b];
+  return pol_.stack_pre && projpre4_ && projpre_split_ == enc_proj_.rows && dp_pre_.rows == 192 && H_ == 192 &&
+         pol_.chain16(tsum, false, H_, 96) && pol_.chain4((long)B_ * Tg_);
+}
 float* Engine::stage_a_enc_out() const { return (stage_a_ffn_fused() && (enc_.size() & 1)) ? y_ : x_; }
 
 // Everything up to the frame counts: speaker vectors, text encoder, duration predictor, durations.
@@ -149,10 +157,21 @@ void Engine::issue_stage_a() {
     fl += 2.0 * tsum * (e.qkv.macs_per_col + e.o.macs_per_col + e.f1.macs_per_col + e.f2.macs_per_col);
     for (int b = 0; b < B; ++b) fl += 2.0 * 2.0 * (double)tlens_h_[b] * tlens_h_[b] * H_;
   }
+  // small calls: the duration predictor's first conv reads the same LN(y) as proj -- one launch over the stacked matrix
+  // (three row parts of 192: m_p, logs_p, dp.pre) instead of two launches in a row
+  const bool stacked = pg && proj_pre_stacked();
+  LnSecond sec;
+  if (stacked) {
+    sec.w4 = projpre4_; sec.split = projpre_split_; sec.out2 = dy;
+    sec.bias2 = cb_dp; sec.bias2_bs = cond_bs_;
+  }
+  const float* pj_bias = stacked ? projpre_bias_ : enc_proj_.bias;
+  const int pj_rows = stacked ? projpre_split_ + dp_pre_.rows : enc_proj_.rows;
+  const double pj_flops = 2.0 * tsum * (enc_proj_.macs_per_col + (stacked ? dp_pre_.macs_per_col : 0));
   if (pg && pend_bias) {
-    lngemm(x, pg, pb, y, enc_proj16_, enc_proj_.bias, enc_proj_.rows, stats, T, 2.0 * tsum * enc_proj_.macs_per_col, ffn_parts_, nsl, pend_bias);
+    lngemm(x, pg, pb, y, enc_proj16_, pj_bias, pj_rows, stats, T, pj_flops, ffn_parts_, nsl, pend_bias, stacked ? &sec : nullptr);
     std::swap(x, y);
-  } else if (pg) lngemm(y, pg, pb, x, enc_proj16_, enc_proj_.bias, enc_proj_.rows, stats, T, 2.0 * tsum * enc_proj_.macs_per_col);
+  } else if (pg) lngemm(y, pg, pb, x, enc_proj16_, pj_bias, pj_rows, stats, T, pj_flops, nullptr, 0, nullptr, stacked ? &sec : nullptr);
   else conv(enc_proj_, x, stats, d_tlens_, 1, T, EPI_STORE);
   if (x.p != stage_a_enc_out()) throw std::runtime_error("internal: encoder output buffer bookkeeping");
   fl += 2.0 * tsum * enc_proj_.macs_per_col;
@@ -161,7 +180,8 @@ void Engine::issue_stage_a() {
   // ================= stochastic duration predictor, reverse (models.py:63-71,108-117)
   prof_begin();
   fl = 0;
-  if (!(chain_q && dp_pre16_ && conv1x1_col4(dp_pre16_, dp_pre_.bias, dp_pre_.rows, x, dy, d_tlens_, B, T, 2.0 * tsum * dp_pre_.macs_per_col,
+  if (!stacked &&
+      !(chain_q && dp_pre16_ && conv1x1_col4(dp_pre16_, dp_pre_.bias, dp_pre_.rows, x, dy, d_tlens_, B, T, 2.0 * tsum * dp_pre_.macs_per_col,
                                              cb_dp, cond_bs_)))
     conv(dp_pre_, x, dy, d_tlens_, 1, T, EPI_STORE, 1.f, ACT_NONE, none, none, 0, 1.f, cb_dp, cond_bs_);
   if (pol_.fuse_dp) {

@@ -448,7 +448,7 @@ int Engine::krow(const std::string& name) {
   return (int)prof_.size() - 1;
 }
 void Engine::lngemm(View y, const float* g, const float* b, View x, const float* w16, const float* bias, int rows,
-                    View out, int T, double flops, const float* parts, int nparts, const float* pbias) {
+                    View out, int T, double flops, const float* parts, int nparts, const float* pbias, const LnSecond* second) {
   // algorithmic bytes: y in, LN(y) out, the conv's rows out, the FFN's partial outputs in; weights once
   const double kbytes = 4.0 * (cols_ids_ * (2.0 * H_ + rows + (parts ? (double)nparts * H_ : 0.0)) + (double)rows * H_);
   LnGemmP p{};
@@ -465,9 +465,14 @@ void Engine::lngemm(View y, const float* g, const float* b, View x, const float*
     p.p_bs = (long)nparts * H_ * Tp;
     if (!(pol_.chain4((long)B_ * T) && w4_of(w16))) throw std::runtime_error("internal: FFN partials without the 4-column consumer");
   }
-  if (const float* w4 = pol_.chain4((long)B_ * T) ? w4_of(w16) : nullptr) {
+  if (second && !(pol_.chain4((long)B_ * T) && second->w4)) throw std::runtime_error("internal: stacked convs without the 4-column form");
+  if (const float* w4 = pol_.chain4((long)B_ * T) ? (second ? second->w4 : w4_of(w16)) : nullptr) {
     p.w16 = w4;
     p.xcd = xcd_period_;
+    if (second) {
+      p.split = second->split; p.out2 = second->out2.p; p.o2_bs = second->out2.bs; p.o2_cs = second->out2.cs;
+      p.bias2 = second->bias2; p.bias2_bs = second->bias2_bs;
+    }
     const int kh4 = kbegin(prof_level_ >= 2 ? krow("lngemm4_kernel") : 0, flops, kbytes);
     launch::lngemm4(dim3((T + 3) / 4, B_, (rows + 191) / 192), col4_smem(), stream_, p);
     kend(kh4);

@@ -404,6 +404,31 @@ void Engine::init(const WeightSet& ws) {
   // ---- duration predictor (reverse path)
   dp_pre_ = pack_conv(ws, "dp.pre.weight", "dp.pre.bias", 1, -1, false, 0, 0);
   dp_pre16_ = (H_ == 192) ? pack16_conv(ws, "dp.pre.weight", 0, 0) : nullptr;      // its pack4 twin: colchain4_kernel mode 3
+  // small calls: enc_p.proj (2 C rows) and dp.pre (H rows) read the same LN(y) -- stacked into ONE matrix for lngemm4_kernel
+  // (row parts 0 .. of 192 rows: the last ones are dp.pre's), pack4 order; biases stacked alike
+  projpre4_ = nullptr;
+  projpre_bias_ = nullptr;
+  projpre_split_ = 0;
+  if (H_ == 192) {
+    const HostTensor& wp = ws.get("enc_p.proj.weight");
+    const HostTensor& wd = ws.get("dp.pre.weight");
+    const HostTensor& bp = ws.get("enc_p.proj.bias");
+    const HostTensor& bd = ws.get("dp.pre.bias");
+    if (wp.dims.size() == 3 && wd.dims.size() == 3 && wp.dims[1] == 192 && wd.dims[1] == 192 && wp.dims[2] == 1 && wd.dims[2] == 1 &&
+        wp.dims[0] % 192 == 0 && wd.dims[0] == 192) {
+      const int rp = (int)wp.dims[0], rd = (int)wd.dims[0];
+      std::vector<float> Wst(skeleton_ ? 0 : (size_t)(rp + rd) * 192), Bst(skeleton_ ? 0 : (size_t)(rp + rd));
+      if (!skeleton_) {
+        std::copy(wp.data.begin(), wp.data.begin() + (size_t)rp * 192, Wst.begin());
+        std::copy(wd.data.begin(), wd.data.begin() + (size_t)rd * 192, Wst.begin() + (size_t)rp * 192);
+        std::copy(bp.data.begin(), bp.data.begin() + rp, Bst.begin());
+        std::copy(bd.data.begin(), bd.data.begin() + rd, Bst.begin() + rp);
+      }
+      projpre4_ = pack4(Wst, rp + rd, 192);
+      projpre_bias_ = dev_alloc((size_t)(rp + rd), skeleton_ ? nullptr : Bst.data());
+      projpre_split_ = rp;
+    }
+  }
   dp_dds_ = load_dds(ws, "dp.convs");
   dp_proj_ = pack_conv(ws, "dp.proj.weight", "dp.proj.bias", 1, -1, false, 0, 0);
   {

@@ -298,11 +298,14 @@ __global__ __launch_bounds__(256) void lngemm4_kernel(LnGemmP p) {
   col_gemm4_run<H>(gw, YT, P, wv, lane);
   __syncthreads();
   if (!ok) return;
-  float* ob = p.out + (long)b * p.o_bs + (long)row0 * p.o_cs;
+  const bool second = p.out2 != nullptr && row0 >= p.split;        // a row part of the stacked second conv (192-row parts: never mixed)
+  float* ob = second ? p.out2 + (long)b * p.o2_bs + (long)(row0 - p.split) * p.o2_cs : p.out + (long)b * p.o_bs + (long)row0 * p.o_cs;
+  const int ocs = second ? p.o2_cs : p.o_cs;
+  const pe_rowsrc c2d = pe_make_row((second && p.bias2) ? p.bias2 + (long)b * p.bias2_bs + (row0 - p.split) : p.gamma, (second && p.bias2) ? rows_here : 0);
 #pragma unroll
   for (int k = 0; k < NVT; ++k) {
     const int c = rl + 64 * k;
-    if (c < rows_here) ob[(long)c * p.o_cs + t] = col_gemm4_get(P, c, col) + cb[k];
+    if (c < rows_here) ob[(long)c * ocs + t] = (col_gemm4_get(P, c, col) + cb[k]) + pe_row_load(c2d, c);
   }
 }
 

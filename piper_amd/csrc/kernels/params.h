@@ -155,6 +155,9 @@ struct LnGemmP {
   const float* w16; const float* bias; int rows; // pack16 order, all parts; part z owns rows [32 NVT z, 32 NVT (z + 1))
   float* out; long o_bs; int o_cs;
   const int* lens;
+  // lngemm4_kernel, optional: rows >= split belong to a SECOND conv over the same LN(y) (enc_p.proj stacked with dp.pre):
+  // they go to out2 (row 0 = GEMM row split) and take the per-utterance bias vector bias2 (speaker conditioning) as well
+  int split; float* out2; long o2_bs; int o2_cs; const float* bias2; long bias2_bs;
 };
 
 // ---- durations, N(0,1) generator, length regulator (duration.h)

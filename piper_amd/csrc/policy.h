@@ -37,6 +37,7 @@ struct LaunchPolicy {
   long convt_vec = 1;         // polyphase up-conv tiles stored as 16- / 8-byte pieces straight from the accumulators (0: one 4-byte store per phase)
   long xcd = -1;              // XCDs the dispatch round-robins over: -1 = probed at engine creation, 0 = tiles in workgroup order
   long xcd_ffn = 1;           // fused FFN: (column tile, slice) dealt to the XCDs slice-major (0: blockIdx order)
+  long stack_pre = 1;         // small calls: enc_p.proj and dp.pre as one lngemm4_kernel launch over the stacked matrix (0: two launches)
   long gate_half = 1;         // short one-utterance calls: the WN gate conv on half a 32-channel group per workgroup (6 waves) while twice the workgroups still fit one per CU
   long conv1x1 = 1;           // batched one-tap convs through conv1x1_kernel (B operand straight from global memory): 0 = the tiled kernel
   long prof_sites = 0;        // level-2 profile rows of the tiled conv kernel per conv SHAPE (tuning aid)

@@ -40,9 +40,9 @@ def main():
     rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
     bad = 0
     for k in range(n):
-        hidden = int(rng.choice([32, 64, 96]))
-        heads = int(rng.choice([1, 2])) if hidden % 64 == 0 or hidden == 96 else 2
-        over = dict(hidden=hidden, inter=int(rng.choice([32, 64])), filter=int(rng.choice([32, 64, 96])),
+        hidden = int(rng.choice([32, 64, 96, 192], p=[0.3, 0.2, 0.2, 0.3]))      # 192: the small-call 4-column kernels
+        heads = 2 if hidden == 192 else (int(rng.choice([1, 2])) if hidden % 64 == 0 or hidden == 96 else 2)
+        over = dict(hidden=hidden, inter=(192 if hidden == 192 else int(rng.choice([32, 64]))), filter=int(rng.choice([48, 96]) if hidden == 192 else rng.choice([32, 64, 96])),
                     n_layers=int(rng.integers(1, 3)), n_heads=heads, window=int(rng.choice([2, 4])),
                     up_initial=int(rng.choice([32, 64, 128])))
         preset = str(rng.choice(["tiny", "tiny-high", "tiny-ms", "tiny-high-ms"]))
@@ -53,7 +53,9 @@ def main():
                 "wseed": int(rng.integers(1, 1 << 30)), "scales": [0.0, float(rng.choice([0.8, 1.0, 1.3])), 0.8]}
         env = dict(os.environ, EMU_ORDER=str(rng.choice(["", "reverse", "shuffle"])))
         for knob, vals in (("PIPER_HIP_SPLITK_MAX", ["", "0"]), ("PIPER_HIP_MRF", ["", "0", "2"]), ("PIPER_HIP_FUSE_DP", ["", "0"]),
-                           ("PIPER_HIP_COLCHAIN", ["", "0"]), ("PIPER_HIP_SPLITK16", ["", "3"])):
+                           ("PIPER_HIP_COLCHAIN", ["", "0"]), ("PIPER_HIP_SPLITK16", ["", "3"]), ("PIPER_HIP_COL4", ["", "0", "2"]),
+                           ("PIPER_HIP_ATTNO", ["", "0"]), ("PIPER_HIP_FFN", ["", "0"]), ("PIPER_HIP_GATE_HALF", ["", "0"]),
+                           ("PIPER_HIP_CONV1X1", ["", "0"])):
             v = str(rng.choice(vals))
             if v:
                 env[knob] = v

@@ -205,6 +205,9 @@ FORCED = [
     ("x-low", [64], {"PIPER_HIP_SPLITK16": 0, "PIPER_HIP_WIDE_SPLITK": 0}, {"conv_splitk_kernel<2,true,4,3>"}),
     ("medium", [128, 17], {"PIPER_HIP_SPLITK16": 3},
      {"conv_splitk16_kernel<true,12,2,4>", "conv_splitk16_kernel<false,8,4,4>"}),
+    # enc_p.proj + dp.pre as one launch over the stacked matrix is the default of small calls (every case above with the
+    # 4-column chains on; multi-speaker: test_full_size_multi_speaker_matches_oracle); here as two launches
+    ("medium", [128, 31], {"PIPER_HIP_STACK_PRE": 0}, {"colchain4_kernel", "lngemm4_kernel"}),
     # a short utterance: the gate conv on half channel groups (six waves, twice the workgroups), and forced back to whole groups
     ("medium", [48], {}, {"conv_splitk16_kernel<true,6,5,2>"}),
     ("medium", [48], {"PIPER_HIP_GATE_HALF": 0}, {"conv_splitk16_kernel<true,12,2,4>"}),
