@@ -20,6 +20,9 @@ def main():
     if case == "small192":        # the 4-column small-call kernels of the 192-channel voices
         cfg = W.preset("tiny-ms", hidden=192, inter=192, filter=96, n_layers=2)
         lens, sids = [9, 21], [1, 3]
+    elif case.endswith("+wide"):  # a first generator stage of 128 channels: the grouped / K-concatenated sibling launches of a
+        cfg = W.preset(case[:-5], up_initial=256)      # one-utterance call (conv_splitk_group_kernel, conv_splitk_sum_kernel)
+        lens, sids = [13], None
     else:                         # a tiny preset as it is: the general kernels (16-column DDSConv layers with the fused
         cfg = W.preset(case)      # pre / proj / spline, attention, split-K convs, the fused stage kernels)
         lens, sids = [17, 6], ([2, 0] if cfg.n_speakers > 1 else None)

@@ -421,7 +421,7 @@ def test_small_call_kernels_do_not_depend_on_wave_order(emu_lib):
     assert outs[0]["checksum"] == outs[1]["checksum"]
 
 
-@pytest.mark.parametrize("preset", ["tiny", "tiny-high", "tiny-ms"])
+@pytest.mark.parametrize("preset", ["tiny", "tiny-high", "tiny-ms", "tiny+wide", "tiny-high+wide"])
 def test_pipeline_does_not_depend_on_wave_order(emu_lib, preset):
     """The same check for the general kernels, on the tiny presets as they are: 16-column DDSConv layers with the fused
     ConvFlow.pre / proj / spline, attention, split-K convs, the fused stage kernels (ResBlock1 and 2). The emulator runs a
@@ -440,6 +440,8 @@ def test_pipeline_does_not_depend_on_wave_order(emu_lib, preset):
         outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
     for o in outs:
         assert o["durations_equal"] and o["worst"] < 1e-5, o
+        if preset.endswith("+wide"):       # the 128-channel first stage of ONE utterance: sibling resblock convs grouped
+            assert any(k.startswith("conv_splitk_group_kernel<") for k in o["kernels"]) and "conv_splitk_sum_kernel<4,2>" in o["kernels"], o["kernels"]
     assert outs[0]["checksum"] == outs[1]["checksum"] == outs[2]["checksum"]
 
 
