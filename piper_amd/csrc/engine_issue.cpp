@@ -294,9 +294,17 @@ void Engine::issue_flow() {
         conv(r.pre, x0, fh, lens_b_, 1, Fmax, EPI_STORE);
     }
     const int nl = (int)r.in.size();
+    // small calls: the LAST layer's res/skip conv (skip rows only) rides in front of the post + pre chain launch
+    const bool rs_front = chain && nl >= 1 && r.rs4[nl - 1] && r.rs[nl - 1].rows == H_ && H_ == 192 && half == 96 &&
+                          pol_.chain_rs_front((long)B * Fmax) && w4_of(r.post16) &&
+                          (ri + 1 >= rcls_.size() || (rcls_[ri + 1].pre.rows <= 192 && w4_of(rcls_[ri + 1].pre16)));
     for (int i = 0; i < nl; ++i) {
       const float* b2 = nspk_ > 1 ? cond_ + cond_off_wn_[ri] + (long)i * 2 * H_ : nullptr;
       conv(r.in[i], fh, facts, lens_b_, 1, Fmax, EPI_GATE, 1.f, ACT_NONE, none, none, 0, 1.f, b2, cond_bs_);
+      if (rs_front && i == nl - 1) {
+        fl += 2.0 * fsum * (r.in[i].macs_per_col + r.rs[i].macs_per_col);
+        continue;
+      }
       if (r.rs4[i] && pol_.chain4_frames((long)B * Fmax) && H_ == 192 && r.rs[i].rows <= 2 * H_) {
         // small calls: the res/skip 1x1 conv on 4-column workgroups (colchain4_kernel mode 2), one part per 192 rows
         ColP cp{};
@@ -307,7 +315,7 @@ void Engine::issue_flow() {
         cp.x1 = fh.p; cp.x1_bs = fh.bs; cp.x1_cs = fh.cs;
         cp.out = fskip.p; cp.out_bs = fskip.bs; cp.out_cs = fskip.cs;
         cp.lens = lens_b_;
-        const int kh4 = kbegin(prof_level_ >= 2 ? krow("colchain4_kernel") : 0, 2.0 * fsum * r.rs[i].macs_per_col,
+        const int kh4 = kbegin(prof_level_ >= 2 ? krow("colchain4_kernel<false>") : 0, 2.0 * fsum * r.rs[i].macs_per_col,
                                4.0 * (fsum * (H_ + 2.0 * cp.rows1) + (double)cp.rows1 * H_));
         launch::colchain4(dim3((Fmax + 3) / 4, B, (cp.rows1 + 191) / 192), col4_smem(), stream_, cp);
         kend(kh4);
@@ -330,7 +338,12 @@ void Engine::issue_flow() {
         cp.out2 = fh.p; cp.o2_bs = fh.bs; cp.o2_cs = fh.cs;
       }
       cp.lens = lens_b_;
-      colchain(cp, B, Fmax, 2.0 * fsum * (r.post.macs_per_col + (cp.w2 ? rcls_[ri + 1].pre.macs_per_col : 0)));
+      if (rs_front) {
+        cp.in0 = facts.p; cp.in0_bs = facts.bs; cp.in0_cs = facts.cs;
+        cp.w0 = r.rs4[nl - 1]; cp.b0 = r.rs[nl - 1].bias; cp.first = nl == 1 ? 1 : 0;
+      }
+      colchain(cp, B, Fmax, 2.0 * fsum * (r.post.macs_per_col + (cp.w2 ? rcls_[ri + 1].pre.macs_per_col : 0) +
+                                          (rs_front ? r.rs[nl - 1].macs_per_col : 0)));
     } else {
       conv(r.post, fskip, x1, lens_b_, 1, Fmax, EPI_SUBFROM);
     }

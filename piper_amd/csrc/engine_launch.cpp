@@ -500,7 +500,7 @@ bool Engine::conv1x1_col4(const float* w16, const float* bias, int rows, View in
   cp.out = out.p; cp.out_bs = out.bs; cp.out_cs = out.cs;
   cp.lens = lens;
   const double cols = lens == d_tlens_ ? cols_ids_ : cols_frames_;
-  const int kh4 = kbegin(prof_level_ >= 2 ? krow("colchain4_kernel") : 0, flops, 4.0 * (cols * (kin + rows) + (double)rows * kin));
+  const int kh4 = kbegin(prof_level_ >= 2 ? krow("colchain4_kernel<false>") : 0, flops, 4.0 * (cols * (kin + rows) + (double)rows * kin));
   launch::colchain4(dim3((Lmax + 3) / 4, B, (rows + 191) / 192), col4_smem(), stream_, cp);
   kend(kh4);
   return true;
@@ -519,12 +519,14 @@ void Engine::colchain(const ColP& p, int B, int Lmax, double flops) {
       ColP q = p;
       q.w1 = w1; q.w2 = w2;
       q.xcd = xcd_period_;
-      const int kh4 = kbegin(prof_level_ >= 2 ? krow("colchain4_kernel") : 0, flops, kbytes);
+      const double kb0 = q.w0 ? 4.0 * (cols * 192.0 + 192.0 * 192.0) : 0.0;      // the front conv: its input, its weights
+      const int kh4 = kbegin(prof_level_ >= 2 ? krow(q.w0 ? "colchain4_kernel<true>" : "colchain4_kernel<false>") : 0, flops, kbytes + kb0);
       launch::colchain4(dim3((Lmax + 3) / 4, B), col4_smem(), stream_, q);
       kend(kh4);
       return;
     }
   }
+  if (p.w0) throw std::runtime_error("internal: a res/skip conv in front of a chain that does not take the 4-column form");
   const int kh = kbegin(prof_level_ >= 2 ? krow("colchain_kernel<6>") : 0, flops, kbytes);
   const size_t smem = ((size_t)2 * 6 * 32 * 16 + 16 * 16) * sizeof(float);
   launch::colchain(dim3((Lmax + 15) / 16, B), smem, stream_, p);

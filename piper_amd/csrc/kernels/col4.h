@@ -98,6 +98,11 @@ __device__ __forceinline__ float pe_col_sum4(float v, float* red, int& flip, int
 //   mode 3   (4-column form only) a plain 1x1 conv, grid.z = 192-row parts: out = W1.in + b1 (+ res[utterance][row], a
 //            per-utterance bias vector: the speaker conditioning of dp.pre) -- the first encoder layer's q/k/v, dp.pre.
 // 192 input channels, rows1 = 192 (mode 0) / 96 (mode 1), second GEMM 192 rows over the 96 updated channels.
+// FRONT (mode 1 only): the LAST WN layer's res/skip conv -- 192 skip rows, no hidden-state update -- in front of the chain:
+// the post conv's input is (W0.in0 + b0) + in1 instead of in1 (in1 = the skip sum of the layers before; `first`: not
+// read). The same additions in the same order as the mode-2 launch it replaces, whose output is not written at all: the
+// skip sum of a coupling layer has no other reader.
+template <bool FRONT>
 __global__ __launch_bounds__(256) void colchain4_kernel(ColP p) {
   PE_KTRACE(3);
   constexpr int NC = 4, NVT = 3, K1 = C4_H, K2 = C4_H / 2, KS1 = Col4W<K1>::KS, KS2 = Col4W<K2>::KS;
@@ -113,9 +118,32 @@ __global__ __launch_bounds__(256) void colchain4_kernel(ColP p) {
   const bool ok = t < L;
   const int part = p.mode >= 2 ? (int)blockIdx.z : 0, row0 = part * C4_H;
   const int rows_here = p.rows1 - row0 < C4_H ? p.rows1 - row0 : C4_H;
+  Col4W<K1> gw0;                                 // FRONT: the res/skip conv's fragments
+  if constexpr (FRONT) col_gemm4_fetch<K1>(gw0, p.w0, C4_NT, wv, lane);
   Col4W<K1> gw;                                  // first GEMM's fragments, in flight under the input staging
   col_gemm4_fetch<K1>(gw, p.w1 + (long)part * C4_NT * (K1 / 4) * 256, (rows_here + 63) / 64, wv, lane);
   const bool skip_part = p.mode == 2 && (p.rows1 <= C4_H || part == 1);
+  float sk[NVT];                                 // FRONT: the completed skip sum of this thread's (channel, column) slots
+  if constexpr (FRONT) {
+    const pe_rowsrc a0 = pe_make_row(p.in0 + (long)b * p.in0_bs, K1 * p.in0_cs);
+    const pe_rowsrc s0 = pe_make_row(p.in1 + (long)b * p.in1_bs, p.first ? 0 : K1 * p.in1_cs);
+    const pe_rowsrc b0d = pe_make_row(p.b0 ? p.b0 : p.w0, p.b0 ? K1 : 0);
+    float av[NVT], b0v[NVT];
+#pragma unroll
+    for (int k = 0; k < NVT; ++k) {
+      const int c = rl + 64 * k;
+      av[k] = pe_row_load(a0, ok ? c * p.in0_cs + t : -1);
+      sk[k] = pe_row_load(s0, ok ? c * p.in1_cs + t : -1);
+      b0v[k] = pe_row_load(b0d, c);
+    }
+#pragma unroll
+    for (int k = 0; k < NVT; ++k) YT[col * KS1 + rl + 64 * k] = av[k];
+    __syncthreads();
+    col_gemm4_run<K1>(gw0, YT, P, wv, lane);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NVT; ++k) sk[k] = ok ? (col_gemm4_get(P, rl + 64 * k, col) + b0v[k]) + sk[k] : 0.f;
+  }
 
   // operands of the step after the first GEMM are requested before it: residual / previous x1, LN gains, bias
   float ov[NVT], gg[NVT], bb[NVT], b1v[NVT];
@@ -132,7 +160,7 @@ __global__ __launch_bounds__(256) void colchain4_kernel(ColP p) {
 #pragma unroll
     for (int k = 0; k < NVT; ++k) {
       const int c = rl + 64 * k;
-      xin[k] = pe_row_load(ind, ok ? c * p.in1_cs + t : -1);
+      xin[k] = FRONT ? sk[k] : pe_row_load(ind, ok ? c * p.in1_cs + t : -1);
       ov[k] = pe_row_load(od, (ok && c < rows_here) ? (p.mode == 3 ? c : c * ocs + t) : -1);
       gg[k] = pe_row_load(gd, c < rows_here ? c : -1);
       bb[k] = pe_row_load(bd, c < rows_here ? c : -1);

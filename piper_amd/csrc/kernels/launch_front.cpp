@@ -62,7 +62,8 @@ void lngemm(dim3 grid, size_t smem, hipStream_t stream, const LnGemmP& p) {
 }
 
 void colchain4(dim3 grid, size_t smem, hipStream_t stream, const ColP& p) {
-  PE_LAUNCH(colchain4_kernel, grid, dim3(256), smem, stream, p);
+  if (p.w0) PE_LAUNCH(colchain4_kernel<true>, grid, dim3(256), smem, stream, p);
+  else PE_LAUNCH(colchain4_kernel<false>, grid, dim3(256), smem, stream, p);
 }
 
 void lngemm4(dim3 grid, size_t smem, hipStream_t stream, const LnGemmP& p) {

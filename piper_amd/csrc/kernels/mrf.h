@@ -154,7 +154,10 @@ __global__ __launch_bounds__(64 * MRF_NW) void mrf_kernel(MrfP p) {
     }
   }
   const pe_rowsrc xd = pe_make_row(xb, C * p.x_cs);
+  constexpr int SK = CP == 64 ? 6 : 7;     // tuning build: stamps of the 64- / 32-channel stage (entry, window staged, then per phase: K loop starts, K loop done, epilogue done)
+  PE_STAMP(SK, 0);
   stage_x();
+  PE_STAMP(SK, 1);
 
   for (int ph = 0; ph < p.nphases; ++ph) {
     __syncthreads();            // table + window (first phase) / the previous phase's activations are in LDS
@@ -202,6 +205,7 @@ __global__ __launch_bounds__(64 * MRF_NW) void mrf_kernel(MrfP p) {
         for (int r = 0; r < 4; ++r) acc[m][u][r] = 0.f;
     }
     const float* src = bufs + P.src * bufsz;
+    if (ph < 7) PE_STAMP(SK, 2 + 3 * ph);
     // The K loop, specialised at compile time on WHICH halo units take part in this phase (bit v of MASK = halo unit
     // v; output units always do): the hot loop is straight-line code, the choice is one wave-uniform switch per phase.
     // Every variant issues the same weight fetches.
@@ -287,6 +291,7 @@ __global__ __launch_bounds__(64 * MRF_NW) void mrf_kernel(MrfP p) {
         }
       }
     }
+    if (ph < 7) PE_STAMP(SK, 3 + 3 * ph);
     // ---- epilogue of the phase
     float* dstb = bufs + (P.dst < 0 ? 0 : P.dst) * bufsz;
 #pragma unroll
@@ -315,6 +320,7 @@ __global__ __launch_bounds__(64 * MRF_NW) void mrf_kernel(MrfP p) {
           }
         }
       }
+    if (ph < 7) PE_STAMP(SK, 4 + 3 * ph);
   }
   if (p.post_w == nullptr) {
     // ---- MRF mean of the owned output units

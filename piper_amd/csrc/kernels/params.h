@@ -134,6 +134,9 @@ struct ColP {
   const int* lens;
   int first;                                            // mode 2 (colchain4_kernel): first WN layer -- the skip sum is not read
   int xcd;                                              // colchain4_kernel: XCDs the dispatch round-robins over (0: unknown)
+  // colchain4_kernel<true> (mode 1): the last WN layer's res/skip conv in front -- GEMM 1 reads (w0.in0 + b0) + in1
+  const float* in0; long in0_bs; int in0_cs;
+  const float* w0; const float* b0;
 };
 // ---- fused FFN (ffn.h): partial outputs per 48-row slice of the hidden dimension
 struct FfnP {

@@ -38,6 +38,7 @@ struct LaunchPolicy {
   long xcd = -1;              // XCDs the dispatch round-robins over: -1 = probed at engine creation, 0 = tiles in workgroup order
   long xcd_ffn = 1;           // fused FFN: (column tile, slice) dealt to the XCDs slice-major (0: blockIdx order)
   long stack_pre = 1;         // small calls: enc_p.proj and dp.pre as one lngemm4_kernel launch over the stacked matrix (0: two launches)
+  long chain_rs = 1;          // small calls: the last WN layer's res/skip conv in front of the post + pre chain launch (0: a launch of its own)
   long gate_half = 1;         // short one-utterance calls: the WN gate conv on half a 32-channel group per workgroup (6 waves) while twice the workgroups still fit one per CU
   long conv1x1 = 1;           // batched one-tap convs through conv1x1_kernel (B operand straight from global memory): 0 = the tiled kernel
   long prof_sites = 0;        // level-2 profile rows of the tiled conv kernel per conv SHAPE (tuning aid)
@@ -82,6 +83,7 @@ struct LaunchPolicy {
   }
   bool chain4(long cols, long limit = 0) const { return col4 && (col4 == 2 || cols <= (limit ? limit : col4_maxc)); }
   bool chain4_frames(long cols) const { return chain4(cols, col4_max_frames); }
+  bool chain_rs_front(long cols) const { return chain_rs && chain4_frames(cols); }
   // fused MRF stage
   bool mrf_build(int channels) const { return mrf != 0 && channels <= 64; }
   bool mrf_stage(bool built, bool resblock1, int padded_channels, double frames, bool matrix_bf3) const {

@@ -385,10 +385,10 @@ def test_emulated_192_channel_small_call_kernels(emu_lib, monkeypatch, col4):
     # small calls: attention + conv_o + norm_layers_1 as one launch (attno_kernel); the 16-column forms keep two
     assert ("attno_kernel<96>" if col4 == "1" else "attn_kernel<96>") in names
     assert ("attn_kernel<96>" if col4 == "1" else "attno_kernel<96>") not in names
-    assert ({"colchain4_kernel", "lngemm4_kernel", "dds_layer4_kernel", "ffn_kernel"} if col4 == "1" else
+    assert ({"colchain4_kernel<false>", "lngemm4_kernel", "dds_layer4_kernel", "ffn_kernel"} if col4 == "1" else
             {"colchain_kernel<6>", "lngemm_kernel<6>", "dds_layer16_kernel<6>"}) <= names
     assert not ({"colchain_kernel<6>", "lngemm_kernel<6>", "dds_layer16_kernel<6>"} if col4 == "1" else
-                {"colchain4_kernel", "lngemm4_kernel", "dds_layer4_kernel", "ffn_kernel"}) & names
+                {"colchain4_kernel<false>", "lngemm4_kernel", "dds_layer4_kernel", "ffn_kernel"}) & names
     durs = eng.durations()
     off = np.concatenate([[0], np.cumsum(lens)])
     for i, T in enumerate(lens):
@@ -416,7 +416,7 @@ def test_small_call_kernels_do_not_depend_on_wave_order(emu_lib):
         assert p.returncode == 0, p.stderr[-2000:]
         outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
     for o in outs:
-        assert {"colchain4_kernel", "lngemm4_kernel", "dds_layer4_kernel", "ffn_kernel"} <= set(o["kernels"])
+        assert {"colchain4_kernel<false>", "lngemm4_kernel", "dds_layer4_kernel", "ffn_kernel"} <= set(o["kernels"])
         assert o["durations_equal"] and o["worst"] < 1e-5, o
     assert outs[0]["checksum"] == outs[1]["checksum"]
 
@@ -614,3 +614,37 @@ def test_emulated_one_tap_convs_without_lds_are_bit_identical(emu_lib, monkeypat
             o = O.synthesize(w, cfg, ids[i], (0.0, 1.1, 0.8), nw[i][:, :lens[i]], sid=None if sids is None else sids[i])
             assert np.array_equal(res["1"][1][off[i]:off[i + 1]], o["durations"])
             assert np.max(np.abs(res["1"][0].audio[i] - o["audio"])) < 1e-5
+
+
+@pytest.mark.parametrize("lens,sids", [([31], None), ([9, 31, 14], [2, 0, 1])])
+def test_emulated_last_res_skip_conv_in_front_of_the_chain(emu_lib, monkeypatch, lens, sids):
+    """colchain4_kernel<true> (kernels/col4.h FRONT): the last WN layer of a coupling layer has skip rows only, and the skip
+    sum's one reader is the post conv -- so in small calls that res/skip conv rides in front of the post + pre chain launch
+    and the completed skip sum is never written. The same additions in the same order as the launch it replaces
+    (PIPER_HIP_CHAIN_RS=0): bit-identical waveform and durations, one launch fewer per coupling layer, and the oracle's
+    answer; ragged batch (a 4-column tile straddling an utterance's end), single- and multi-speaker."""
+    cfg = W.preset("tiny-ms" if sids else "tiny", hidden=192, inter=192, filter=96, n_layers=2)
+    w = W.synthetic_weights(cfg, 1234)
+    ids = [W.synthetic_phoneme_ids(T, i, id_max=cfg.n_vocab - 1) for i, T in enumerate(lens)]
+    nw = np.random.default_rng(5).standard_normal((len(lens), 2, max(lens))).astype(np.float32)
+    res, names, launches = {}, {}, {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PIPER_HIP_CHAIN_RS", mode)
+        eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
+        eng.profile_enable(2)
+        r = eng.synthesize_batch(ids, (0.0, 1.0, 0.8), noise_w=nw, sids=sids)
+        prof = [row for row in eng.profile()[5:] if row["launches"]]
+        names[mode] = {row["name"] for row in prof}
+        launches[mode] = sum(row["launches"] for row in prof if row["name"].startswith("colchain4_kernel"))
+        res[mode] = (r, eng.durations())
+        eng.close()
+    assert "colchain4_kernel<true>" in names["1"] and "colchain4_kernel<true>" not in names["0"]
+    assert launches["0"] - launches["1"] == cfg.flow_n
+    assert np.array_equal(res["0"][1], res["1"][1])
+    for a, b in zip(res["0"][0].audio, res["1"][0].audio):
+        assert np.array_equal(a, b)
+    for a, b in zip(res["0"][0].pcm, res["1"][0].pcm):
+        assert np.array_equal(a, b)
+    i = len(lens) - 1
+    o = O.synthesize(w, cfg, ids[i], (0.0, 1.0, 0.8), nw[i][:, :lens[i]], sid=None if sids is None else sids[i])
+    assert np.max(np.abs(res["1"][0].audio[i] - o["audio"])) < 1e-5

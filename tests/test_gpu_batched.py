@@ -189,7 +189,7 @@ FORCED = [
     ("medium", [128, 31], {"PIPER_HIP_FUSE_DP": 0}, {"conv_splitk_kernel<1,false,8,4>"}),
     # conv_o + LN and coupling post + next pre as single launches (colchain_kernel): forced on for a batch, and off
     ("medium", [128, 77, 16, 33], {"PIPER_HIP_COLCHAIN": 2, "PIPER_HIP_COL4": 0}, {"colchain_kernel<6>", "lngemm_kernel<6>"}),
-    ("medium", [128, 77, 16, 33], {"PIPER_HIP_COLCHAIN": 2}, {"colchain4_kernel", "lngemm4_kernel", "dds_layer4_kernel"}),
+    ("medium", [128, 77, 16, 33], {"PIPER_HIP_COLCHAIN": 2}, {"colchain4_kernel<false>", "lngemm4_kernel", "dds_layer4_kernel"}),
     ("medium", [128, 31], {"PIPER_HIP_COLCHAIN": 0}, {"ln_kernel", "conv_splitk_kernel<1,false,4,4>"}),
     # sibling resblock convs of the 128-channel stage as grouped launches (64- and 128-column slabs), and one by one
     # (the last step, whose outputs the MRF only sums, is one GEMM over the concatenated K; GROUP_MRF=2: kept apart)
@@ -207,7 +207,10 @@ FORCED = [
      {"conv_splitk16_kernel<true,12,2,4>", "conv_splitk16_kernel<false,8,4,4>"}),
     # enc_p.proj + dp.pre as one launch over the stacked matrix is the default of small calls (every case above with the
     # 4-column chains on; multi-speaker: test_full_size_multi_speaker_matches_oracle); here as two launches
-    ("medium", [128, 31], {"PIPER_HIP_STACK_PRE": 0}, {"colchain4_kernel", "lngemm4_kernel"}),
+    ("medium", [128, 31], {"PIPER_HIP_STACK_PRE": 0}, {"colchain4_kernel<false>", "lngemm4_kernel"}),
+    # the last WN layer's res/skip conv in front of the post + pre chain launch (default) and as a launch of its own
+    ("medium", [128, 31], {}, {"colchain4_kernel<true>", "colchain4_kernel<false>"}),
+    ("medium", [128, 31], {"PIPER_HIP_CHAIN_RS": 0}, {"colchain4_kernel<false>"}),
     # a short utterance: the gate conv on half channel groups (six waves, twice the workgroups), and forced back to whole groups
     ("medium", [48], {}, {"conv_splitk16_kernel<true,6,5,2>"}),
     ("medium", [48], {"PIPER_HIP_GATE_HALF": 0}, {"conv_splitk16_kernel<true,12,2,4>"}),
@@ -215,7 +218,7 @@ FORCED = [
     # the 192-channel small-call chains (DDSConv layers, colchain, lngemm): the 4-column forms on the 4x4x1 MFMA (default for small calls) forced
     # on for a ragged batch beyond its column limit, and off (the 16-column form)
     ("medium", [128, 77, 16, 33, 3, 1, 128, 90, 128, 128], {"PIPER_HIP_COL4": 2},
-     {"dds_layer4_kernel", "colchain4_kernel", "lngemm4_kernel"}),
+     {"dds_layer4_kernel", "colchain4_kernel<false>", "lngemm4_kernel"}),
     ("medium", [128, 31], {"PIPER_HIP_COL4": 0}, {"dds_layer16_kernel<6>", "colchain_kernel<6>", "lngemm_kernel<6>"}),
     # the encoder FFN as one launch with partial outputs per 48-row slice of the hidden dimension (default for small
     # calls), and conv by conv behind the 4-column chains
@@ -225,7 +228,7 @@ FORCED = [
     # both softmax paths, and off (attn_kernel + colchain4_kernel)
     ("medium", [128, 13, 1, 129], {}, {"attno_kernel<96>", "lngemm4_kernel", "ffn_kernel"}),
     ("high", [96, 40], {}, {"attno_kernel<96>"}),
-    ("medium", [128, 31], {"PIPER_HIP_ATTNO": 0}, {"attn_kernel<96>", "colchain4_kernel"}),
+    ("medium", [128, 31], {"PIPER_HIP_ATTNO": 0}, {"attn_kernel<96>", "colchain4_kernel<false>"}),
     # the up-convs' tiles stored one 4-byte piece per phase (default: 16- / 8-byte pieces of consecutive samples straight
     # from the accumulators: strides 8 and 4 on the medium voice, 8 and 2 on the high one), B = 1 and ragged batches
     ("medium", [128], {"PIPER_HIP_CONVT_VEC": 0}, {"conv_mfma_kernel<2,2,1,1,16,false,64>"}),
@@ -233,7 +236,7 @@ FORCED = [
     ("high", [70, 128, 9, 128, 128, 33], {"PIPER_HIP_CONVT_VEC": 0}, set()),
     ("high", [70, 128, 9, 128, 128, 33], {}, set()),
     # tiles of the 4-column kernels in workgroup order (no XCD-contiguous runs)
-    ("medium", [128, 31], {"PIPER_HIP_XCD": 0}, {"colchain4_kernel", "lngemm4_kernel", "dds_layer4_kernel"}),
+    ("medium", [128, 31], {"PIPER_HIP_XCD": 0}, {"colchain4_kernel<false>", "lngemm4_kernel", "dds_layer4_kernel"}),
 ]
 
 
