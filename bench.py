@@ -623,8 +623,8 @@ def concurrent_streams(ctx, cfg, counts=(2, 4, 8), T=128, calls=60):
 
 def varied_inputs(eng, cfg, n=64):
     """What real use looks like at batch 1: another text and fresh duration noise on every call, so the frame
-    count changes from call to call and the speculative sizing of stage B can miss. Whole C-ABI calls with host inputs
-    and outputs (pe_synthesize_batch)."""
+    count changes from call to call and the speculative sizing of stage B can miss. Whole calls with host inputs and
+    outputs as `piper::synthesize` makes them: pe_upload, pe_run, pe_fetch of the int16 PCM."""
     from piper_amd import weights as W
     id_max = min(cfg.n_vocab - 1, 129)
     rng = np.random.default_rng(4321)
@@ -635,22 +635,26 @@ def varied_inputs(eng, cfg, n=64):
     t_w = time.perf_counter()
     eng.warmup(max_batch=1, max_ids=256, frames_per_id=0.0, scales=SCALES, sample_ids=texts[0])
     warm_s = time.perf_counter() - t_w
+    def call(t):                                          # the C-ABI calls piper::synthesize makes (piper_shim.cpp:355-358):
+        eng.upload([t], SCALES)                           # ids H2D, the engine's own noise: durations differ every call
+        eng.run()
+        return eng.fetch(False, True)                     # the int16 PCM the reference's synthesize() returns, on the host
     for t in texts[:4]:
-        eng.synthesize_batch([t], SCALES)
+        call(t)
     r0, m0 = eng.speculation_stats
     g0 = eng.graph_stats
     ms, samples = [], 0
     for t in texts:
         t0 = time.perf_counter()
-        r = eng.synthesize_batch([t], SCALES)             # the engine's own noise: durations differ every call
+        r = call(t)
         ms.append((time.perf_counter() - t0) * 1e3)
         samples += r.pcm[0].size
     r1, m1 = eng.speculation_stats
     g1 = eng.graph_stats
     tot = sum(ms) * 1e-3
     ms.sort()
-    return {"config": {"workload": f"medium VITS voice, {n} pe_synthesize_batch calls of ONE utterance each, 60..200 ids, "
-                                   "another text and fresh duration + prior noise every call (host inputs and outputs), after one pe_warmup"},
+    return {"config": {"workload": f"medium VITS voice, {n} calls of ONE utterance each (pe_upload + pe_run + pe_fetch of the int16 PCM, "
+                                   "as piper::synthesize makes them), 60..200 ids, another text and fresh duration + prior noise every call, after one pe_warmup"},
             "metric": "audio samples/sec", "value": samples / tot, "unit": "samples/s", "dtype": "f32",
             "x_realtime": samples / tot / cfg.sample_rate, "ms_per_call_p50": ms[len(ms) // 2],
             "ms_per_call_mean": tot / n * 1e3, "ms_per_call_max": ms[-1], "calls": n,
