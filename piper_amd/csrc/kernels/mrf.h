@@ -64,6 +64,12 @@ __device__ __forceinline__ void mrf_interleave() {
 }
 
 
+// which instantiations buffer the B operand in half steps (see the K loop): the five-unit ones
+#ifndef PE_MRF_HALF
+#define PE_MRF_HALF 1          // 0: none, 2: all (A/B builds)
+#endif
+template <int CP, int OU, int HU> struct MRF_HALF_B { static constexpr bool value = PE_MRF_HALF == 2 || (PE_MRF_HALF == 1 && OU + HU >= 5); };
+
 template <int CP, int OU, int HU>
 __global__ __launch_bounds__(64 * MRF_NW) void mrf_kernel(MrfP p) {
   PE_KTRACE(20);
@@ -244,6 +250,75 @@ __global__ __launch_bounds__(64 * MRF_NW) void mrf_kernel(MrfP p) {
       };
       constexpr int NU = OU + ((MASK & 1) ? 1 : 0) + ((MASK & 2) ? 1 : 0);       // units taking part
       constexpr int NMF = 8 * MSW * NU, NVM = 2 * MSW, NDS = 4 * NU;             // MFMAs / weight fetches / ds_read2 per step
+      if constexpr (MRF_HALF_B<CP, OU, HU>::value) {
+        // B operands in HALF steps (four of a step's eight k-groups = the A fragment's q): two buffers of UPW x 4 registers
+        // instead of UPW x 8 -- 40 registers fewer with five units per wave, which is what takes the five-unit instantiations
+        // (<64,3,2>, <32,4,1>) from 23 / 12 spilled VGPRs to none: their spills were reloaded in every phase epilogue and in
+        // the prologue (profiles/r04_notes.md, call 48). Same MFMA order per accumulator.
+        auto read_bh = [&](int soff, int h, float (&bv)[UPW][4]) {
+#pragma unroll
+          for (int u = 0; u < UPW; ++u)
+            if (u < OU || ((MASK >> (u - OU)) & 1)) {
+              const float* bp = ub[u] + soff;
+#pragma unroll
+              for (int s4 = 0; s4 < 4; ++s4) bv[u][s4] = bp[4 * (4 * h + s4) * WS];
+            }
+        };
+        auto mma_h = [&](const f32x4 (&a)[MSW][2], int h, const float (&bv)[UPW][4]) {
+#pragma unroll
+          for (int s4 = 0; s4 < 4; ++s4)
+#pragma unroll
+            for (int u = 0; u < UPW; ++u)
+              if (u < OU || ((MASK >> (u - OU)) & 1)) {
+#pragma unroll
+                for (int m = 0; m < MSW; ++m) acc[m][u] = pe_mfma_16x16x4(a[m][h][s4], bv[u][s4], acc[m][u]);
+              }
+        };
+        constexpr int KH0 = (NMF / 2) / (NVM + NDS / 2 + 1), KH1 = (NMF / 2) / (NDS / 2 + 1);
+        float b0[UPW][4], b1[UPW][4];
+        int cur = 0;                                   // LDS offset of the step whose halves are being consumed
+        read_bh(0, 0, b0);
+        int st = 0;
+        for (; st + 1 < nsteps; st += 2) {
+          PE_SCHED_FENCE();
+          load_a(wnext, aB);
+          read_bh(cur, 1, b1);
+          wnext += STEPF;
+          mma_h(aA, 0, b0);
+          mrf_interleave<NVM, NDS / 2, KH0>();
+          PE_SCHED_FENCE();
+          cur = advance();
+          read_bh(cur, 0, b0);
+          mma_h(aA, 1, b1);
+          mrf_interleave<0, NDS / 2, KH1>();
+          PE_SCHED_FENCE();
+          load_a(wnext, aA);      // behind the phase's last step: the first step of the next phase
+          read_bh(cur, 1, b1);
+          wnext += STEPF;
+          mma_h(aB, 0, b0);
+          mrf_interleave<NVM, NDS / 2, KH0>();
+          PE_SCHED_FENCE();
+          cur = advance();
+          read_bh(cur, 0, b0);
+          mma_h(aB, 1, b1);
+          mrf_interleave<0, NDS / 2, KH1>();
+          PE_SCHED_FENCE();
+        }
+        if (st < nsteps) {        // odd step count: the last step, and the next phase's first fragments move to aA
+          load_a(wnext, aB);
+          read_bh(cur, 1, b1);
+          wnext += STEPF;
+          mma_h(aA, 0, b0);
+          mrf_interleave<NVM, NDS / 2, KH0>();
+          PE_SCHED_FENCE();
+          mma_h(aA, 1, b1);
+          PE_SCHED_FENCE();
+#pragma unroll
+          for (int m = 0; m < MSW; ++m)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) aA[m][q] = aB[m][q];
+        }
+      } else {
       constexpr int KI = NMF / (NVM + NDS + 1);
       float bA[UPW][8], bB[UPW][8];
       read_b(0, bA);
@@ -273,6 +348,7 @@ __global__ __launch_bounds__(64 * MRF_NW) void mrf_kernel(MrfP p) {
         for (int m = 0; m < MSW; ++m)
 #pragma unroll
           for (int q = 0; q < 2; ++q) aA[m][q] = aB[m][q];
+      }
       }
     };
     {
