@@ -298,7 +298,7 @@ bool Engine::mrf_geo(const UpStage& st, int len_mul, bool tail, MrfGeo& best) co
       taps += P.ntaps;
     }
     double cost = std::ceil(wgs / 256.0) * (work + 16.0 * taps);      // prologue + epilogue ~ 16 columns' worth
-    // 4 units per wave run at the register limit (a few spilled VGPRs): measured 3-5 % slower per column than 3 units at
+    // 4 units per wave ran at the register limit (12 spilled VGPRs until the half-step B buffers of call 48): measured 3-5 % slower per column than 3 units at
     // batch (B=16: 1108 vs 1082 us, B=64: 4.29 vs 4.25 ms), but one round instead of two for a single utterance's last
     // stage (B=1: 84.6 vs 93.4 us) -- profiles/r03_notes.md
     if (ou == 4) cost *= 1.06;
