@@ -55,7 +55,7 @@ def main():
         for knob, vals in (("PIPER_HIP_SPLITK_MAX", ["", "0"]), ("PIPER_HIP_MRF", ["", "0", "2"]), ("PIPER_HIP_FUSE_DP", ["", "0"]),
                            ("PIPER_HIP_COLCHAIN", ["", "0"]), ("PIPER_HIP_SPLITK16", ["", "3"]), ("PIPER_HIP_COL4", ["", "0", "2"]),
                            ("PIPER_HIP_ATTNO", ["", "0"]), ("PIPER_HIP_FFN", ["", "0"]), ("PIPER_HIP_GATE_HALF", ["", "0"]),
-                           ("PIPER_HIP_CONV1X1", ["", "0"])):
+                           ("PIPER_HIP_CONV1X1", ["", "0"]), ("PIPER_HIP_CHAIN_RS", ["", "0"]), ("PIPER_HIP_STACK_PRE", ["", "0"])):
             v = str(rng.choice(vals))
             if v:
                 env[knob] = v
