@@ -156,7 +156,7 @@ int pe_speculation_stats(pe_engine* e, int64_t* runs, int64_t* misses);
 /* Session warm-up -- what loadModel's session creation does for ORT (piper.cpp:262-306: graph optimisation at load), here
  * for the hipGraphs: the kernel sequence of a call is captured once per shape bucket (ids in steps of 32 up to 512, then
  * 8 steps per octave; frames in steps of 64 up to 1024, then 16 per octave) and replayed afterwards; the cache keeps the
- * 64 most recently used graphs (PIPER_HIP_GRAPHS) and evicts one at a time. pe_warmup
+ * 256 most recently used graphs (PIPER_HIP_GRAPHS) and evicts one at a time. pe_warmup
  *   - sizes the workspaces for calls of up to max_batch utterances x max_ids ids and frames_per_id * max_ids frames
  *     (<= 0: 8), so that no later call grows them (growth re-creates every graph), and
  *   - if sample_ids is given (a representative utterance of the voice: its frames-per-id ratio seeds the speculative

@@ -33,7 +33,7 @@ struct LaunchPolicy {
   long spec_expect = 1;       // speculative graphs planned for the expected frame counts (0: for the bucket capacity)
   long pcm_zc = 1;            // int16 PCM written straight into pinned host memory by pcm16_kernel
   long no_graph = 0;          // launch kernels directly instead of replaying hipGraphs
-  long graphs = 64;           // hipGraphs kept per engine (least recently used evicted one at a time)
+  long graphs = 256;          // hipGraphs kept per engine (least recently used evicted one at a time)
   long convt_vec = 1;         // polyphase up-conv tiles stored as 16- / 8-byte pieces straight from the accumulators (0: one 4-byte store per phase)
   long xcd = -1;              // XCDs the dispatch round-robins over: -1 = probed at engine creation, 0 = tiles in workgroup order
   long xcd_ffn = 1;           // fused FFN: (column tile, slice) dealt to the XCDs slice-major (0: blockIdx order)
