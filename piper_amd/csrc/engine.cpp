@@ -158,8 +158,13 @@ void Engine::ensure_stage_a(int B, int Tmax) {
     logw_ = c.take<float>(Bc * T);
     noise_w_ = c.take<float>(Bc * 2 * T);
     cond_ = c.take<float>(Bc * (size_t)std::max(cond_bs_, 1));
+    // utterances whose attention score slab does not fit LDS: [utterance][head][query block][32][SP] in global memory
+    att_s_ = attn_scores_global((int)T) ? c.take<float>(Bc * nh_ * (size_t)rup((int)T, ATT_QB) * (rup((int)T, 64) + 1)) : nullptr;
     return c.off + 256;
   };
+  if (carve(nullptr) >= (size_t)64 << 30)
+    throw std::runtime_error("batch too large: " + std::to_string(Bc) + " utterances padded to " + std::to_string(T) +
+                             " ids need more than 64 GiB of text-encoder workspace (attention scores of long utterances)");
   if (grow || !wsA_) {
     PE_HIP(hipStreamSynchronize(stream_));
     drop_graphs();

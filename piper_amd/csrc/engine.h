@@ -365,6 +365,9 @@ class Engine {
   // workspace (d_in_) mirrored by a pinned host block (h_in_): upload() fills the host block and enqueues ONE copy, no
   // synchronisation (the pinned block outlives the copy; the call's final synchronisation covers it)
   char* d_in_ = nullptr; char* h_in_ = nullptr; size_t in_bytes_ = 0, h_in_cap_ = 0;
+  float* att_s_ = nullptr;           // attention score slabs of long utterances (attn_long_kernel); null while every slab fits LDS
+  size_t attn_smem(int T, bool global_scores) const;
+  bool attn_scores_global(int T) const;
   float *x_ = nullptr, *y_ = nullptr, *qkv_ = nullptr, *att_ = nullptr, *ffh_ = nullptr, *stats_ = nullptr,
         *xg_ = nullptr, *dh_ = nullptr, *dy_ = nullptr, *dy2_ = nullptr, *hproj_ = nullptr, *z2_ = nullptr,
         *logw_ = nullptr, *noise_w_ = nullptr, *cond_ = nullptr;

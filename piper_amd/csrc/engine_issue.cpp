@@ -83,7 +83,7 @@ void Engine::issue_stage_a() {
     // 16 queries of both heads per workgroup)
     const int ao_sp = rup(T, 64) + 2;
     const size_t ao_smem = ((size_t)2 * 16 * ao_sp + 2 * 64 * (dk_ + 1) + 2 * dk_ * 16 + (size_t)2 * (2 * window_ + 1) * dk_ + 8 * 256 + 256) * sizeof(float);
-    const bool attno = pol_.attno && chain_q && pol_.chain4((long)B * T) && H_ == 192 && nh_ == 2 && dk_ == 96 && window_ <= 4 && e.o16 &&
+    const bool attno = pol_.attno && !pol_.attn_long && chain_q && pol_.chain4((long)B * T) && H_ == 192 && nh_ == 2 && dk_ == 96 && window_ <= 4 && e.o16 &&
                        ao_smem <= (size_t)160 * 1024;
     if (attno) {
       AttnOP ap{};
@@ -107,13 +107,14 @@ void Engine::issue_stage_a() {
     ap.lens = d_tlens_; ap.H = H_; ap.dk = dk_; ap.window = window_;
     ap.SP = rup(T, 64) + 1;
     ap.qscale = 1.0f / std::sqrt((float)dk_);
-    const int VS = dk_ + 1 + (dk_ & 1);
-    const size_t smem = ((size_t)ATT_QB * ap.SP + (size_t)ATT_KCH * VS + (size_t)dk_ * ATT_QB +
-                         (size_t)2 * (2 * window_ + 1) * dk_ + 4 * ATT_QB * 16) * sizeof(float);
-    if (smem > 160 * 1024) throw std::runtime_error("utterance too long for the attention score tile");
+    // the 32 x T score slab of a workgroup in LDS, or -- utterances of more than ~830 ids -- in global memory (same kernel body)
+    const bool sg = attn_scores_global(T);
+    if (sg && !att_s_) throw std::runtime_error("internal: attention score scratch not allocated");
+    ap.sglobal = sg ? att_s_ : nullptr;
+    const size_t smem = attn_smem(T, sg);
     double afl = 0;
     for (int b = 0; b < B; ++b) afl += 4.0 * (double)tlens_h_[b] * tlens_h_[b] * H_;
-    const int kh = kbegin(prof_level_ >= 2 ? krow(ap.dk == 96 ? "attn_kernel<96>" : ap.dk == 48 ? "attn_kernel<48>" : "attn_kernel<0>") : 0, afl, 4.0 * 4.0 * H_ * tsum);
+    const int kh = kbegin(prof_level_ >= 2 ? krow(std::string(sg ? "attn_long_kernel" : "attn_kernel") + (ap.dk == 96 ? "<96>" : ap.dk == 48 ? "<48>" : "<0>")) : 0, afl, 4.0 * 4.0 * H_ * tsum);
     const dim3 agrid((T + ATT_QB - 1) / ATT_QB, nh_, B);
     launch::attention(ap.dk, agrid, smem, stream_, ap);
     kend(kh);

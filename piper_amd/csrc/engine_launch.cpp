@@ -350,6 +350,14 @@ void Engine::mrf(const UpStage& st, View x, View out, const int* lens, int len_m
   kend(kh);
 }
 
+// LDS of attn_kernel / attn_long_kernel for utterances padded to T ids (kernels/attention.h: S | Vt | Qs | RK, RV | part)
+size_t Engine::attn_smem(int T, bool global_scores) const {
+  const int SP = rup(T, 64) + 1, VS = dk_ + 1 + (dk_ & 1);
+  return ((global_scores ? 0 : (size_t)ATT_QB * SP) + (size_t)ATT_KCH * VS + (size_t)dk_ * ATT_QB +
+          (size_t)2 * (2 * window_ + 1) * dk_ + 4 * ATT_QB * 16) * sizeof(float);
+}
+bool Engine::attn_scores_global(int T) const { return pol_.attn_long || attn_smem(T, false) > (size_t)160 * 1024; }
+
 void Engine::layer_norm(View in, View out, const float* g, const float* b, int C, const int* lens, int Lmax) {
   LnP p;
   p.in = in.p; p.i_bs = in.bs; p.i_cs = in.cs;

@@ -44,8 +44,13 @@ __global__ void embed_kernel(const int* ids, int ids_bs, const int* lens, const 
 // DKT: channels per head known at compile time (96 for the 192-channel voices, 48 for x-low): every unrolled loop has its
 // exact trip count. DKT = 0: any even dk <= ATT_MAXDK, loops sized for the maximum and guarded per step (on the common
 // shapes those guards were ~190 scalar branches per workgroup, a third of the kernel's time).
-template <int DKT>
-__global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
+// SG: the score slab [32][SP] of the workgroup lives in a global scratch buffer instead of LDS -- utterances whose slab
+// does not fit the 160 KB (more than ~830 ids; the reference has no such limit: attentions.py builds the full T x T
+// matrix). The same code on another address space: the waves of a workgroup share their CU's L1, so the workgroup
+// barriers publish the slab exactly as they do for LDS, and every sum runs in the same order (bit-identical results,
+// tests: forced on short utterances against the LDS form).
+template <int DKT, bool SG>
+__device__ __forceinline__ void attn_body(const AttnP& p) {
   constexpr int MAXDK = DKT ? DKT : ATT_MAXDK;
   PE_KTRACE(0);
   PE_DYN_SMEM(float, sm);
@@ -57,8 +62,15 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
   const int dk = DKT ? DKT : p.dk, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int l31 = lane & 31, lhi = lane >> 5;
   const int SP = p.SP, VS = dk + 1 + (dk & 1);       // odd strides -> conflict-free column reads
-  float* S = sm;                                      // [32][SP]
-  float* Vt = S + ATT_QB * SP;                        // [KCH][VS]
+  float* S;                                           // [32][SP]
+  float* Vt;                                          // [KCH][VS]
+  if constexpr (SG) {
+    S = p.sglobal + ((size_t)((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * ((size_t)ATT_QB * SP);
+    Vt = sm;
+  } else {
+    S = sm;
+    Vt = S + ATT_QB * SP;
+  }
   float* Qs = Vt + ATT_KCH * VS;                      // [dk][32], scaled by 1/sqrt(dk)
   const int nrel = 2 * p.window + 1;
   float* RK = Qs + dk * ATT_QB;                       // [nrel][dk] relative-key embeddings
@@ -299,5 +311,11 @@ __global__ __launch_bounds__(256) void attn_kernel(AttnP p) {
   }
   PE_STAMP(0, 20);
 }
+
+template <int DKT>
+__global__ __launch_bounds__(256) void attn_kernel(AttnP p) { attn_body<DKT, false>(p); }
+// long utterances: the score slab in global memory (AttnP::sglobal)
+template <int DKT>
+__global__ __launch_bounds__(256) void attn_long_kernel(AttnP p) { attn_body<DKT, true>(p); }
 
 }  // namespace pe

@@ -31,6 +31,12 @@ void embed(dim3 grid, hipStream_t stream, const int* ids, int ids_bs, const int*
 
 // compiled per head width (96 / 48); <0> = any even width <= 128 with guarded loops
 void attention(int dk, dim3 grid, size_t smem, hipStream_t stream, const AttnP& p) {
+  if (p.sglobal) {
+    if (dk == 96) PE_LAUNCH(attn_long_kernel<96>, grid, dim3(256), smem, stream, p);
+    else if (dk == 48) PE_LAUNCH(attn_long_kernel<48>, grid, dim3(256), smem, stream, p);
+    else PE_LAUNCH(attn_long_kernel<0>, grid, dim3(256), smem, stream, p);
+    return;
+  }
   if (dk == 96) PE_LAUNCH(attn_kernel<96>, grid, dim3(256), smem, stream, p);
   else if (dk == 48) PE_LAUNCH(attn_kernel<48>, grid, dim3(256), smem, stream, p);
   else PE_LAUNCH(attn_kernel<0>, grid, dim3(256), smem, stream, p);

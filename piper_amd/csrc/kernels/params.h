@@ -61,6 +61,7 @@ struct AttnP {
   int H, dk, window;
   int SP;                                   // score row stride in LDS: odd, >= round_up(max len, 64)
   float qscale;
+  float* sglobal;                           // attn_long_kernel: [utterance][head][query block][32][SP] score slabs (null: LDS)
 };
 // attno_kernel (attno.h): attention + conv_o + residual + norm_layers_1 of an encoder layer in one launch
 struct AttnOP {

@@ -648,3 +648,33 @@ def test_emulated_last_res_skip_conv_in_front_of_the_chain(emu_lib, monkeypatch,
     i = len(lens) - 1
     o = O.synthesize(w, cfg, ids[i], (0.0, 1.0, 0.8), nw[i][:, :lens[i]], sid=None if sids is None else sids[i])
     assert np.max(np.abs(res["1"][0].audio[i] - o["audio"])) < 1e-5
+
+
+@pytest.mark.parametrize("over,lens", [({}, [17, 40, 5]), (dict(hidden=192, inter=192, filter=96, n_layers=2), [9, 33])])
+def test_emulated_attention_with_global_score_slabs_is_bit_identical(emu_lib, monkeypatch, over, lens):
+    """attn_long_kernel (kernels/attention.h SG): the form of utterances whose 32 x T score slab does not fit LDS (more than
+    ~830 ids on the 192-channel voices) keeps the slab in a global scratch buffer and runs the same code on it. Forced on
+    short ragged batches (PIPER_HIP_ATTN_LONG=1) it must give the bits of the LDS form -- guarded head width (<0>) and the
+    compiled one (<96>, also in place of attno_kernel) -- and the oracle's answer."""
+    cfg = W.preset("tiny", **over)
+    w = W.synthetic_weights(cfg, 1234)
+    ids = [W.synthetic_phoneme_ids(T, i, id_max=cfg.n_vocab - 1) for i, T in enumerate(lens)]
+    nw = np.random.default_rng(5).standard_normal((len(lens), 2, max(lens))).astype(np.float32)
+    res, names = {}, {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("PIPER_HIP_ATTN_LONG", mode)
+        monkeypatch.setenv("PIPER_HIP_ATTNO", "0")          # the LDS form of the same kernel body on both sides
+        eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
+        eng.profile_enable(2)
+        r = eng.synthesize_batch(ids, (0.0, 1.0, 0.8), noise_w=nw)
+        names[mode] = {row["name"] for row in eng.profile()[5:] if row["launches"]}
+        res[mode] = (r, eng.durations(), eng.debug_tensor("x_enc", len(lens) - 1))
+        eng.close()
+    long_name = "attn_long_kernel<96>" if over else "attn_long_kernel<0>"
+    assert long_name in names["1"] and not any(n.startswith("attn_long") for n in names["0"]), names
+    assert np.array_equal(res["0"][1], res["1"][1]) and np.array_equal(res["0"][2], res["1"][2])
+    for a, b in zip(res["0"][0].audio, res["1"][0].audio):
+        assert np.array_equal(a, b)
+    i = len(lens) - 1
+    o = O.synthesize(w, cfg, ids[i], (0.0, 1.0, 0.8), nw[i][:, :lens[i]])
+    assert np.max(np.abs(res["1"][0].audio[i] - o["audio"])) < 1e-5

@@ -208,6 +208,12 @@ FORCED = [
     # enc_p.proj + dp.pre as one launch over the stacked matrix is the default of small calls (every case above with the
     # 4-column chains on; multi-speaker: test_full_size_multi_speaker_matches_oracle); here as two launches
     ("medium", [128, 31], {"PIPER_HIP_STACK_PRE": 0}, {"colchain4_kernel<false>", "lngemm4_kernel"}),
+    # attention with the score slabs in global memory (the form of utterances beyond ~830 ids) forced on short ragged batches
+    ("medium", [128, 31], {"PIPER_HIP_ATTN_LONG": 1}, {"attn_long_kernel<96>"}),
+    ("x-low", [64, 20, 33], {"PIPER_HIP_ATTN_LONG": 1}, {"attn_long_kernel<48>"}),
+    ("tiny", [50, 7], {"PIPER_HIP_ATTN_LONG": 1}, {"attn_long_kernel<0>"}),
+    # ... and chosen by the engine: a ragged batch padded to 900 ids
+    ("medium", [900, 40], {}, {"attn_long_kernel<96>"}),
     # the last WN layer's res/skip conv in front of the post + pre chain launch (default) and as a launch of its own
     ("medium", [128, 31], {}, {"colchain4_kernel<true>", "colchain4_kernel<false>"}),
     ("medium", [128, 31], {"PIPER_HIP_CHAIN_RS": 0}, {"colchain4_kernel<false>"}),

@@ -346,10 +346,11 @@ def test_streaming_chunks_match_the_oracle_chunked_decode(preset, T, chunk):
     assert np.max(np.abs(np.concatenate([c[0] for c in ref]) - o["audio"])) < 1e-5
 
 
-@pytest.mark.parametrize("T", [1, 2, 700])
+@pytest.mark.parametrize("T", [1, 2, 700, 1500])
 def test_extreme_lengths_match_oracle(T):
-    """Shortest possible inputs and one far longer than any test sentence (attention score slab, many
-    column tiles)."""
+    """Shortest possible inputs, one far longer than any test sentence (attention score slab, many column tiles) and
+    one whose 32 x T score slab no longer fits LDS (attn_long_kernel: the slab in global memory; the reference has no
+    length limit, attentions.py:225-272 builds the full T x T matrix)."""
     from oracle import vits_oracle as O
     cfg, w, eng = engine_for("tiny")
     ids = W.synthetic_phoneme_ids(T, 6, id_max=cfg.n_vocab - 1) if T > 2 else np.array([1, 2][:T], np.int64)
@@ -357,6 +358,30 @@ def test_extreme_lengths_match_oracle(T):
     o = O.synthesize(w, cfg, ids, (0.667, 1.0, 0.8), nw, nz)
     r = eng.synthesize(ids, (0.667, 1.0, 0.8), noise_w=nw, noise_z=nz)
     assert np.array_equal(eng.durations(), o["durations"])
+    assert r.audio[0].shape == o["audio"].shape
+    assert np.max(np.abs(r.audio[0] - o["audio"])) < TIGHT_AUDIO_TOL
+    assert pcm_rms(r.pcm[0], o["pcm"]) <= RMS_TOL
+
+
+def test_long_utterance_on_the_medium_voice_matches_oracle():
+    """1000 ids through the medium architecture: the attention score slabs of a 192-channel voice (two heads of 96) leave
+    LDS at ~830 ids, the text encoder runs attn_long_kernel<96> and the general kernels beyond the small-call limits; equal
+    integer durations, encoder output and waveform against the oracle."""
+    from oracle import vits_oracle as O
+    cfg, w, eng = engine_for("medium")
+    T = 1000
+    ids = W.synthetic_phoneme_ids(T, 9, id_max=min(cfg.n_vocab - 1, 129))
+    nw, nz = noise_for(cfg, T, 23)
+    scales = (0.667, 1.0, 0.8)
+    o = O.synthesize(w, cfg, ids, scales, nw, nz, keep=True)
+    eng.profile_enable(2)
+    r = eng.synthesize(ids, scales, noise_w=nw, noise_z=nz)
+    names = {row["name"] for row in eng.profile()[5:] if row["launches"]}
+    eng.profile_enable(0)
+    assert "attn_long_kernel<96>" in names and "attn_kernel<96>" not in names, names
+    assert np.array_equal(eng.durations(), o["durations"])
+    got = eng.debug_tensor("x_enc")
+    assert got.shape == o["x_enc"].shape and np.max(np.abs(got - o["x_enc"])) < 1e-3 * max(1.0, float(np.abs(o["x_enc"]).max()))
     assert r.audio[0].shape == o["audio"].shape
     assert np.max(np.abs(r.audio[0] - o["audio"])) < TIGHT_AUDIO_TOL
     assert pcm_rms(r.pcm[0], o["pcm"]) <= RMS_TOL
