@@ -115,6 +115,23 @@ struct Carver {
   }
 };
 
+// Workspace policy. Capacities only grow while the grown block fits the budget (a third of the device's memory per
+// stage): utterance count and padded length are separate capacities, so a huge batch of short texts followed by one long
+// text would otherwise ask for their product. A call whose grown capacities do not fit gets a block sized for exactly
+// that call (capacities may shrink); a call that does not fit by itself is an error, raised before anything changes.
+size_t Engine::ws_budget() {
+  if (!ws_budget_) {
+    if (pol_.ws_budget_mb > 0) {
+      ws_budget_ = (size_t)pol_.ws_budget_mb << 20;
+    } else {
+      size_t fr = 0, tot = 0;
+      PE_HIP(hipMemGetInfo(&fr, &tot));
+      ws_budget_ = std::max<size_t>(tot / 3, (size_t)1 << 30);
+    }
+  }
+  return ws_budget_;
+}
+
 void Engine::ensure_stage_a(int B, int Tmax) {
   if (!ffn_parts_ && H_ == 192 && FC_ % 48 == 0 && FC_ / 48 <= 16 && !enc_.empty() && enc_[0].f1p) {
     // partial outputs of the fused small-call FFN (kernels/ffn.h): [utterance][slice][192][columns], once
@@ -122,14 +139,7 @@ void Engine::ensure_stage_a(int B, int Tmax) {
     PE_HIP(hipMalloc((void**)&ffn_parts_, (size_t)(FC_ / 48) * H_ * LaunchPolicy::ffn_max_cols * sizeof(float)));
   }
   const int Ts = rup(Tmax, 128);    // row strides are multiples of 128 columns (conv epilogue relies on it)
-  bool grow = false;
-  if ((size_t)B > capA_B_) { capA_B_ = B; grow = true; }
-  // (growth re-creates every graph: grow the id capacity by at least half, so that texts of slowly increasing length
-  // cost a few re-creations, not one per 128 ids)
-  if ((size_t)Ts > capA_T_) { capA_T_ = std::max<size_t>(Ts, capA_T_ ? rup((int)(capA_T_ + capA_T_ / 2), 128) : 0); grow = true; }
-  Ts_ = (int)capA_T_;
-  const size_t Bc = capA_B_, T = capA_T_;
-  auto carve = [&](char* base) -> size_t {
+  auto carve = [&](char* base, size_t Bc, size_t T) -> size_t {
     Carver c(base);
     // input block: [rng 4 x u64 | lengths Bc | speaker ids Bc | ids Bc x T] (contiguous, copied as one piece by upload())
     d_in_ = c.take<char>(32 + (2 * Bc + Bc * T) * sizeof(int));
@@ -162,45 +172,62 @@ void Engine::ensure_stage_a(int B, int Tmax) {
     att_s_ = attn_scores_global((int)T) ? c.take<float>(Bc * nh_ * (size_t)rup((int)T, ATT_QB) * (rup((int)T, 64) + 1)) : nullptr;
     return c.off + 256;
   };
-  if (carve(nullptr) >= (size_t)64 << 30)
-    throw std::runtime_error("batch too large: " + std::to_string(Bc) + " utterances padded to " + std::to_string(T) +
-                             " ids need more than 64 GiB of text-encoder workspace (attention scores of long utterances)");
-  if (grow || !wsA_) {
+  // (growth re-creates every graph: grow the id capacity by at least half, so that texts of slowly increasing length
+  // cost a few re-creations, not one per 128 ids)
+  size_t nB = std::max<size_t>(B, capA_B_), nT = capA_T_;
+  if ((size_t)Ts > capA_T_) nT = std::max<size_t>(Ts, capA_T_ ? rup((int)(capA_T_ + capA_T_ / 2), 128) : 0);
+  if (nB != capA_B_ || nT != capA_T_ || !wsA_) {
+    const size_t budget = ws_budget();
+    if (carve(nullptr, nB, nT) > budget) { nB = B; nT = Ts; }          // exactly this call
+    const size_t exact = carve(nullptr, B, Ts);
+    if (exact > budget) {
+      carve(wsA_, capA_B_, capA_T_);                                      // (the probes above moved the pointers)
+      throw std::runtime_error("call too large: " + std::to_string(B) + " utterances padded to " + std::to_string(Ts) +
+                               " ids need " + std::to_string(exact >> 20) + " MiB of text-encoder workspace (budget " +
+                               std::to_string(budget >> 20) + " MiB)");
+    }
     PE_HIP(hipStreamSynchronize(stream_));
     drop_graphs();
-    if (wsA_) PE_HIP(hipFree(wsA_));
-    if (wsB_) { PE_HIP(hipFree(wsB_)); wsB_ = nullptr; }   // stage-B sizes depend on the batch capacity
-    capB_F_ = 0;
-    wsA_bytes_ = carve(nullptr);
-    PE_HIP(hipMalloc((void**)&wsA_, wsA_bytes_));
-    carve(wsA_);
+    if (wsA_) { PE_HIP(hipFree(wsA_)); wsA_ = nullptr; }
+    if (wsB_) { PE_HIP(hipFree(wsB_)); wsB_ = nullptr; }                  // stage-B pointers sit in the dropped graphs
+    capA_B_ = capA_T_ = 0; capB_B_ = capB_F_ = 0;
+    void* blk = nullptr;
+    size_t bytes = carve(nullptr, nB, nT);
+    if (hipMalloc(&blk, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      nB = B; nT = Ts; bytes = exact; blk = nullptr;
+      if (hipMalloc(&blk, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        carve(nullptr, 0, 0);
+        throw std::runtime_error("out of device memory: " + std::to_string(bytes >> 20) + " MiB of text-encoder workspace");
+      }
+    }
+    wsA_ = static_cast<char*>(blk); wsA_bytes_ = bytes; capA_B_ = nB; capA_T_ = nT;
+    carve(wsA_, capA_B_, capA_T_);
     if (h_in_cap_ < in_bytes_) {
       if (h_in_) PE_HIP(hipHostFree(h_in_));
       h_in_cap_ = in_bytes_;
       PE_HIP(hipHostMalloc((void**)&h_in_, h_in_cap_));
     }
   }
-  carve(wsA_);
+  Ts_ = (int)capA_T_;
+  carve(wsA_, capA_B_, capA_T_);
 }
 
 void Engine::ensure_stage_b(int Fmax) {
   const int Fs = rup(Fmax, 128);
-  bool grow = false;
-  if ((size_t)Fs > capB_F_) { capB_F_ = std::max<size_t>(Fs, capB_F_ ? rup((int)(capB_F_ + capB_F_ / 2), 128) : 0); grow = true; }
-  Fs_ = (int)capB_F_;
-  const size_t Bc = capA_B_, F = capB_F_;
-  // largest [channels x length] activation of the generator
-  size_t hmax = (size_t)U_ * F;
-  {
-    size_t L = F;
-    for (auto& st : ups_) { L *= st.rate; hmax = std::max(hmax, (size_t)st.ch * L); }
-  }
-  Ss_ = (long)F * hop_;
+  const size_t Bnow = (size_t)std::max(B_, 1);
+  auto hmax_of = [&](size_t F) {        // largest [channels x length] activation of the generator
+    size_t hm = (size_t)U_ * F, L = F;
+    for (auto& st : ups_) { L *= st.rate; hm = std::max(hm, (size_t)st.ch * L); }
+    return hm;
+  };
   // per-utterance activations are addressed with 32-bit byte offsets (buffer descriptors)
-  if (hmax * sizeof(float) >= (size_t)1 << 31 || (size_t)3 * H_ * F * sizeof(float) >= (size_t)1 << 31)
+  if (hmax_of(Fs) * sizeof(float) >= (size_t)1 << 31 || (size_t)3 * H_ * Fs * sizeof(float) >= (size_t)1 << 31)
     throw std::runtime_error("utterance too long: a per-utterance activation would exceed 2 GiB");
-  auto carve = [&](char* base) -> size_t {
+  auto carve = [&](char* base, size_t Bc, size_t F) -> size_t {
     Carver c(base);
+    const size_t hmax = hmax_of(F), S = F * (size_t)hop_;
     zp_ = c.take<float>(Bc * C_ * F);
     fh_ = c.take<float>(Bc * H_ * F);
     facts_ = c.take<float>(Bc * H_ * F);
@@ -210,18 +237,46 @@ void Engine::ensure_stage_b(int Fmax) {
     zwin_ = c.take<float>((size_t)C_ * F);
     zp_keep_ = pol_.debug_keep ? c.take<float>(Bc * C_ * F) : nullptr;
     d_win_ = c.take<int>(4);
-    audio_ = c.take<float>(Bc * (size_t)Ss_);
-    pcm_ = c.take<int16_t>(Bc * (size_t)Ss_);
+    audio_ = c.take<float>(Bc * S);
+    pcm_ = c.take<int16_t>(Bc * S);
     return c.off + 256;
   };
-  if (grow || !wsB_) {
+  // the batch capacity of this stage follows stage A's while that fits; under memory pressure it is this call's batch
+  size_t nB = std::max(capB_B_, std::max(Bnow, capA_B_)), nF = capB_F_;
+  if ((size_t)Fs > capB_F_) nF = std::max<size_t>(Fs, capB_F_ ? rup((int)(capB_F_ + capB_F_ / 2), 128) : 0);
+  // (a grown frame capacity past the 2 GiB descriptor range falls back to the exact one)
+  if (hmax_of(nF) * sizeof(float) >= (size_t)1 << 31 || (size_t)3 * H_ * nF * sizeof(float) >= (size_t)1 << 31) nF = Fs;
+  if (nB != capB_B_ || nF != capB_F_ || !wsB_) {
+    const size_t budget = ws_budget();
+    if (carve(nullptr, nB, nF) > budget) { nB = Bnow; nF = Fs; }
+    const size_t exact = carve(nullptr, Bnow, Fs);
+    if (exact > budget) {
+      carve(wsB_, capB_B_, capB_F_);
+      throw std::runtime_error("call too large: " + std::to_string(Bnow) + " utterances of up to " + std::to_string(Fs) +
+                               " frames need " + std::to_string(exact >> 20) + " MiB of vocoder workspace (budget " +
+                               std::to_string(budget >> 20) + " MiB)");
+    }
     PE_HIP(hipStreamSynchronize(stream_));
     drop_graphs();
-    if (wsB_) PE_HIP(hipFree(wsB_));
-    wsB_bytes_ = carve(nullptr);
-    PE_HIP(hipMalloc((void**)&wsB_, wsB_bytes_));
+    if (wsB_) { PE_HIP(hipFree(wsB_)); wsB_ = nullptr; }
+    capB_B_ = capB_F_ = 0;
+    void* blk = nullptr;
+    size_t bytes = carve(nullptr, nB, nF);
+    if (hipMalloc(&blk, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      nB = Bnow; nF = Fs; bytes = exact; blk = nullptr;
+      if (hipMalloc(&blk, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        carve(nullptr, 0, 0);
+        throw std::runtime_error("out of device memory: " + std::to_string(bytes >> 20) + " MiB of vocoder workspace");
+      }
+    }
+    wsB_ = static_cast<char*>(blk); wsB_bytes_ = bytes; capB_B_ = nB; capB_F_ = nF;
   }
-  carve(wsB_);
+  Fs_ = (int)capB_F_;
+  Ss_ = (long)capB_F_ * hop_;
+  carve(wsB_, capB_B_, capB_F_);
+  const size_t Bc = capB_B_, hmax = hmax_of(capB_F_);
   // zero-copy PCM: room for every utterance of the batch capacity, up to 256 MiB of pinned memory (beyond: copies)
   const size_t zc_want = Bc * (size_t)Ss_;
   if (pol_.pcm_zc && zc_want * sizeof(int16_t) <= ((size_t)256 << 20) && h_pcm_zc_cap_ < zc_want) {

@@ -356,7 +356,9 @@ class Engine {
   int64_t h_noise_z_stride_ = 0;
 
   // workspaces
-  size_t capA_B_ = 0, capA_T_ = 0, capB_F_ = 0;
+  size_t capA_B_ = 0, capA_T_ = 0, capB_B_ = 0, capB_F_ = 0;      // utterances / padded ids of stage A, utterances / frames of stage B
+  size_t ws_budget_ = 0;             // bytes a stage's workspace may take (a third of the device's memory)
+  size_t ws_budget();
   char* wsA_ = nullptr; size_t wsA_bytes_ = 0;
   char* wsB_ = nullptr; size_t wsB_bytes_ = 0;
   int *d_ids_ = nullptr, *d_tlens_ = nullptr, *d_sids_ = nullptr, *d_dur_ = nullptr, *d_cum_ = nullptr,

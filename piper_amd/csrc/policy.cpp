@@ -40,6 +40,7 @@ static const LaunchPolicy::Knob kKnobs[] = {
     {"PIPER_HIP_CHAIN_RS", &LaunchPolicy::chain_rs, 0, 1, "small calls of the 192-channel voices: the last WN layer's res/skip conv (skip rows only) in front of the coupling layer's post + pre chain launch, colchain4_kernel<true> (0: a launch of its own)"},
     {"PIPER_HIP_GATE_HALF", &LaunchPolicy::gate_half, 0, 1, "short one-utterance calls (up to 128 whole-group workgroups): the WN gate conv on half a 32-channel group per workgroup, six waves with the whole K range in flight, twice the workgroups (0: whole groups on twelve waves)"},
     {"PIPER_HIP_CONV1X1", &LaunchPolicy::conv1x1, 0, 1, "batched one-tap convs (q/k/v, WN res/skip, coupling pre/post, proj) through conv1x1_kernel, B operand straight from global memory (0: the tiled kernel)"},
+    {"PIPER_HIP_WS_BUDGET_MB", &LaunchPolicy::ws_budget_mb, 0, 1048576, "MiB of device memory the workspace of one pipeline half may take (0: a third of the device's memory): capacities grow only inside it, a call that does not fit by itself is an error"},
     {"PIPER_HIP_ATTN_LONG", &LaunchPolicy::attn_long, 0, 1, "attention score slabs in global memory (attn_long_kernel) at every length, also in place of attno_kernel (tests): by default only utterances whose 32 x T slab does not fit LDS (more than ~830 ids) take that form"},
     {"PIPER_HIP_PROF_SITES", &LaunchPolicy::prof_sites, 0, 1, "level-2 profile rows of the tiled conv kernel per conv shape (tuning aid)"},
     {"PIPER_HIP_DEBUG_KEEP", &LaunchPolicy::debug_keep, 0, 1, "test hook: keep z_p for pe_debug_tensor"},

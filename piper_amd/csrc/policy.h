@@ -41,6 +41,7 @@ struct LaunchPolicy {
   long chain_rs = 1;          // small calls: the last WN layer's res/skip conv in front of the post + pre chain launch (0: a launch of its own)
   long gate_half = 1;         // short one-utterance calls: the WN gate conv on half a 32-channel group per workgroup (6 waves) while twice the workgroups still fit one per CU
   long conv1x1 = 1;           // batched one-tap convs through conv1x1_kernel (B operand straight from global memory): 0 = the tiled kernel
+  long ws_budget_mb = 0;      // MiB a stage's workspace may take: 0 = a third of the device's memory
   long attn_long = 0;         // attention score slabs in global memory at every length (tests; by default only where they do not fit LDS)
   long prof_sites = 0;        // level-2 profile rows of the tiled conv kernel per conv SHAPE (tuning aid)
   long debug_keep = 0;        // test hook: keep z_p for pe_debug_tensor

@@ -48,7 +48,8 @@ _LONGEST_FIRST = [
     "test_jsonl_drivers_on_emulator", "test_small_call_kernels_do_not_depend_on_wave_order",
     "test_emulated_192_channel_small_call_kernels", "test_engine_group_matches_single_engine",
     "test_emulated_one_tap_convs_without_lds_are_bit_identical", "test_emulated_multi_tile_conv_pipeline",
-    "test_emulated_upconv_epilogues_are_bit_identical",
+    "test_emulated_upconv_epilogues_are_bit_identical", "test_workspace_capacities_stay_inside_the_budget",
+    "test_emulated_last_res_skip_conv_in_front_of_the_chain",
 ]
 
 

@@ -678,3 +678,46 @@ def test_emulated_attention_with_global_score_slabs_is_bit_identical(emu_lib, mo
     i = len(lens) - 1
     o = O.synthesize(w, cfg, ids[i], (0.0, 1.0, 0.8), nw[i][:, :lens[i]])
     assert np.max(np.abs(res["1"][0].audio[i] - o["audio"])) < 1e-5
+
+
+def test_workspace_capacities_stay_inside_the_budget(emu_lib, monkeypatch):
+    """Utterance count and padded length are separate workspace capacities; grown independently they would ask for their
+    product (a large batch of short texts, then one long text). With a budget (PIPER_HIP_WS_BUDGET_MB; by default a third of
+    the device's memory) the engine re-sizes for exactly the call at hand when the grown block does not fit, a call that
+    does not fit by itself is a clean error raised before anything changes, and the engine keeps working -- with the
+    results a fresh engine gives."""
+    cfg = W.preset("tiny")
+    w = W.synthetic_weights(cfg, 1234)
+    blob = W.pack_blob(cfg, w)
+    many = [W.synthetic_phoneme_ids(3 + (i % 5), i, id_max=cfg.n_vocab - 1) for i in range(24)]
+    long1 = [W.synthetic_phoneme_ids(200, 7, id_max=cfg.n_vocab - 1)]
+    short = [W.synthetic_phoneme_ids(9, 3, id_max=cfg.n_vocab - 1)]
+    huge = [W.synthetic_phoneme_ids(200, i, id_max=cfg.n_vocab - 1) for i in range(24)]
+    scales = (0.0, 1.0, 0.8)
+
+    def call(e, texts):
+        nw = np.random.default_rng(len(texts)).standard_normal((len(texts), 2, max(len(t) for t in texts))).astype(np.float32)
+        return e.synthesize_batch(texts, scales, noise_w=nw)
+
+    def fresh(texts):
+        e = Engine(blob=blob, lib=emu_lib)
+        r = call(e, texts)
+        e.close()
+        return r
+
+    monkeypatch.setenv("PIPER_HIP_WS_BUDGET_MB", "256")
+    eng = Engine(blob=blob, lib=emu_lib)
+    a = call(eng, many)                                 # 24 utterances x 128 frames: 126 MiB of vocoder workspace
+    b = call(eng, long1)                                # 24 x 384 frames would not fit: sized for 1 x 384
+    with pytest.raises(EngineError, match="call too large"):
+        call(eng, huge)                                 # 24 x 384 frames by itself
+    c = call(eng, short)                                # the engine is intact
+    d = call(eng, many)                                 # and grows back
+    eng.close()
+    monkeypatch.delenv("PIPER_HIP_WS_BUDGET_MB")
+    assert max(int(f) for f in b.frames) > 256
+    for got, texts in ((a, many), (b, long1), (c, short), (d, many)):
+        ref = fresh(texts)
+        assert len(got.audio) == len(ref.audio)
+        for x, y in zip(got.audio, ref.audio):
+            assert np.array_equal(x, y)
