@@ -12,9 +12,11 @@ ONE invocation covers every BASELINE.json configuration (the driver only ever ru
                                      # time-boxed legs for configs[2] (high, 64 x 128), configs[3]'s per-GPU share
                                      # (medium, 64 x 128), configs[4] (streaming p50 first chunk) and a B=1 leg with
                                      # changing text + noise every call (speculation misses), each with its own roofline
-    python bench.py --gpus N         # N>1: launches N ranks itself (torch.distributed.run). Headline = configs[3]:
-                                     # medium, 64 utterances per GPU (512 over 8), RCCL broadcast of the packed voice;
-                                     # the B=1-per-GPU line and rank 0's single-GPU rate on the same workload beside it
+    python bench.py --gpus N         # N>1: launches N ranks itself (torch.distributed.run). Headline = the SAME per-GPU
+                                     # workload as N=1 (configs[1]: one utterance per GPU per step, RCCL broadcast of the
+                                     # packed voice at load), so the per-N values are one weak-scaling curve;
+                                     # `batched_per_gpu` = configs[3] (medium, 64 utterances per GPU, 512 over 8) with
+                                     # rank 0's single-GPU rate on that share and the speed-up over it
     python bench.py --config 3       # any single configuration as the headline (2..5, 1-based like SURVEY.md 8d)
 
 The rate of the full C-ABI call with host inputs (`pe_synthesize_batch`: ids H2D, float + int16 D2H, the span the
@@ -163,10 +165,15 @@ def compact_line(full, full_path=None):
         out["device_pipeline_only_ms_per_step"] = _r(full["device_pipeline_only_ms_per_step"], 5)
     if full.get("per_rank_samples_per_s") and (full.get("n_gpus") or 1) > 1:
         out["per_rank_samples_per_s"] = [_r(v, 4) for v in full["per_rank_samples_per_s"]]
-    for k in ("single_gpu_reference", "b1_per_gpu"):
+    for k in ("single_gpu_reference", "batched_per_gpu"):
         v = full.get(k)
         if v:
             out[k] = {"value": _r(v.get("value")), "ms_per_step": _r(v.get("ms_per_step"), 5), "steps": v.get("steps")}
+            if v.get("config"):
+                out[k]["workload"] = _short(v["config"].get("workload", ""), 72)
+            for kk in ("single_gpu_value", "speedup_over_single_gpu"):
+                if v.get(kk) is not None:
+                    out[k][kk] = _r(v[kk])
     if full.get("weight_broadcast_bytes"):
         out["weight_broadcast"] = {"bytes": full["weight_broadcast_bytes"], "s": _r(full.get("weight_broadcast_s"), 3)}
     if full.get("speculation"):
@@ -177,7 +184,7 @@ def compact_line(full, full_path=None):
         out["full"] = full_path
     line = json.dumps(out, separators=(",", ":"))
     # belt and braces: shed the optional parts, largest first, until the line fits
-    for k in ("extra_configs", "api_inclusive", "speculation", "b1_per_gpu", "single_gpu_reference"):
+    for k in ("extra_configs", "api_inclusive", "speculation", "batched_per_gpu", "single_gpu_reference"):
         if len(line) <= COMPACT_LIMIT:
             break
         out.pop(k, None)
@@ -350,9 +357,11 @@ def main():
         self_launch(args)
     if args.gpus != ctx.world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={ctx.world}")
-    # headline: configs[1] (B=1) on one GPU -- the configuration BASELINE.json's metric is quoted on; with N>1 GPUs the
-    # split north_star names: configs[3], 64 utterances per GPU (512 over 8)
-    cfgno = args.config or (2 if ctx.world == 1 else 4)
+    # headline at EVERY N: configs[1] -- the configuration BASELINE.json's metric is quoted on -- one utterance per GPU
+    # per step, so the per-N `value`s of the driver's N = 1, 2, 4, 8 runs are one weak-scaling curve over a fixed
+    # per-GPU workload. The batched split north_star names (configs[3]: 64 utterances per GPU, 512 over 8) is timed in
+    # the same invocation and reported beside it (`batched_per_gpu`, with rank 0's single-GPU rate on the same share).
+    cfgno = args.config or 2
     preset, B, T = CONFIGS[cfgno]
     preset = args.preset or preset
     B = args.batch or B
@@ -449,13 +458,24 @@ def main():
     if ctx.rank == 0 and not args.no_roofline:
         roof = roofline(eng, preset, B, T, id_lists, noise_w, args.steps, leg["ms_per_step"], dev_ms)
 
-    # ---- N>1: the B=1-per-GPU line (configs[1] on every GPU at once) beside the batched headline
-    b1_line = None
-    if ctx.world > 1 and cfgno == 4 and not args.no_extra:
-        l1 = timed_leg(ctx, eng, cfg, preset, 1, T, max(10, min(args.steps, 100)), 3)
-        b1_line = {"config": {"workload": workload_text(2, preset, cfg, 1, T)}, "value": l1["value"], "unit": "samples/s",
-                   "x_realtime": l1["value"] / cfg.sample_rate, "ms_per_step": l1["ms_per_step"], "steps": l1["steps"],
-                   "per_rank_samples_per_s": l1["per_rank"]}
+    # ---- N>1: configs[3]'s per-GPU share (64 utterances x 128 ids on every GPU at once) beside the headline, after rank
+    # 0's rate on that share with the other GPUs idle: the 1 -> N scaling of BATCHED throughput from one invocation
+    batched_line = None
+    if ctx.world > 1 and cfgno == 2 and not args.no_extra and not (args.preset or args.batch or args.ids):
+        _, B4, T4 = CONFIGS[4]
+        n4 = max(3, min(args.steps, 10))
+        alone = None
+        if ctx.rank == 0:
+            alone = timed_leg(ctx, eng, cfg, preset, B4, T4, n4, 2, sync_ranks=False)
+        ctx.barrier()
+        l4 = timed_leg(ctx, eng, cfg, preset, B4, T4, n4, 2)
+        batched_line = {"config": {"workload": workload_text(4, preset, cfg, B4, T4)}, "value": l4["value"],
+                        "unit": "samples/s", "x_realtime": l4["value"] / cfg.sample_rate, "ms_per_step": l4["ms_per_step"],
+                        "steps": l4["steps"], "per_rank_samples_per_s": l4["per_rank"]}
+        if alone is not None:
+            batched_line["single_gpu_value"] = alone["value"]
+            batched_line["single_gpu_ms_per_step"] = alone["ms_per_step"]
+            batched_line["speedup_over_single_gpu"] = l4["value"] / alone["value"]
 
     out = None
     if ctx.rank == 0:
@@ -489,8 +509,8 @@ def main():
         }
         if single_ref is not None:
             out["single_gpu_reference"] = single_ref
-        if b1_line is not None:
-            out["b1_per_gpu"] = b1_line
+        if batched_line is not None:
+            out["batched_per_gpu"] = batched_line
         if roof is not None:
             out["roofline"] = roof
         if ctx.world == 1 and not args.no_cpu_baseline:

@@ -53,12 +53,14 @@ def test_multi_gpu_line_is_compact():
     full["n_gpus"] = 8
     full["per_rank_samples_per_s"] = [3.4e8 + i for i in range(8)]
     full["single_gpu_reference"] = {"value": 3.45e8, "ms_per_step": 18.8, "steps": 10, "what": "x" * 300}
-    full["b1_per_gpu"] = {"config": {"workload": "y" * 300}, "value": 8.8e8, "unit": "samples/s", "x_realtime": 4e4,
-                          "ms_per_step": 0.95, "steps": 100, "per_rank_samples_per_s": [1.1e8] * 8}
+    full["batched_per_gpu"] = {"config": {"workload": "y" * 300}, "value": 2.8e9, "unit": "samples/s", "x_realtime": 1.3e5,
+                               "ms_per_step": 18.6, "steps": 10, "per_rank_samples_per_s": [3.5e8] * 8,
+                               "single_gpu_value": 3.6e8, "single_gpu_ms_per_step": 18.1, "speedup_over_single_gpu": 7.78}
     full["weight_broadcast_bytes"] = 139000000
     full["weight_broadcast_s"] = 0.0021
     d = _check(bench.compact_line(full, None), 8)
-    assert len(d["per_rank_samples_per_s"]) == 8 and d["b1_per_gpu"]["value"] == 8.8e8
+    assert len(d["per_rank_samples_per_s"]) == 8 and d["batched_per_gpu"]["value"] == 2.8e9
+    assert d["batched_per_gpu"]["speedup_over_single_gpu"] == 7.78 and len(d["batched_per_gpu"]["workload"]) <= 72
     assert d["weight_broadcast"]["bytes"] == 139000000
 
 

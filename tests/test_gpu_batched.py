@@ -647,7 +647,10 @@ def test_bench_two_ranks_on_one_gpu_prints_a_compact_line():
     d = json.loads(line)
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"
     assert len(d["per_rank_samples_per_s"]) == 2 and d["weight_broadcast"]["bytes"] > 1e8
-    assert "64 utterance(s) x 128" in d["config"]["workload"]
+    # the same per-GPU workload as the N = 1 headline (one weak-scaling curve), the batched share beside it
+    assert "1 utterance(s) x 128" in d["config"]["workload"]
+    bp = d["batched_per_gpu"]
+    assert "64 utterance(s) x 128" in bp["workload"] and bp["value"] > 0 and bp["single_gpu_value"] > 0
 
 
 def test_graph_cache_is_lru_and_warmup_stops_captures(monkeypatch):
