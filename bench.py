@@ -170,7 +170,7 @@ def compact_line(full, full_path=None):
         if v:
             out[k] = {"value": _r(v.get("value")), "ms_per_step": _r(v.get("ms_per_step"), 5), "steps": v.get("steps")}
             if v.get("config"):
-                out[k]["workload"] = _short(v["config"].get("workload", ""), 72)
+                out[k]["workload"] = _short(v["config"].get("workload", "").split(";")[0], 120)
             for kk in ("single_gpu_value", "speedup_over_single_gpu"):
                 if v.get(kk) is not None:
                     out[k][kk] = _r(v[kk])
