@@ -15,12 +15,17 @@ namespace pe {
 //   1. S = (q / sqrt(dk)) k^T: a head's four waves take the 16-key tiles round-robin, K fragments straight from global
 //      (the next tile's in flight under the current tile's MFMAs); relative-key partial products next to them.
 //   2. band add, softmax (16 lanes per query row).
-//   3. O^T = V P^T: V chunks of 64 keys transposed through LDS, a wave owns channel tiles w and w + 4 of its head; the
-//      relative-value band as three more k-steps. conv_o's weight row blocks, the residual and the LayerNorm gains are
-//      requested before this phase and arrive under it.
+//   3. O^T = V P^T: a wave owns channel tiles w and w + 4 of its head and takes their V fragments straight from global
+//      memory into the MFMA's A registers -- lane (channel, lq) holds keys k0 + 16 c + 4 lq + e (e < 4) of a 64-key half as
+//      one 16-byte load per c, the first two halves requested at kernel entry, the matching P[q][key] read from the score
+//      rows in the same key order -- so the phase has no LDS transposition and no barrier per chunk (it was 6.5 of the
+//      workgroup's 15.8 us with V staged through LDS: profiles/r04_notes.md, calls 34 / 60); the relative-value band as
+//      three more k-steps. conv_o's weight row blocks, the residual and the LayerNorm gains are requested before this
+//      phase and arrive under it.
 //   4. O -> LDS as the [192][16] B operand of conv_o: colchain_kernel's mode 0 from here on (col_gemm16, pe_col_sum16).
 // Masked keys (>= len) get weight exactly 0, like the reference's -1e4 fill in fp32. k runs in ascending order inside and
-// across the MFMAs of every product: the same fmaf chains as attn_kernel + colchain_kernel.
+// across the MFMAs of the score and conv_o products (the same fmaf chains as attn_kernel + colchain_kernel); V P^T sums
+// the keys of a 16-key group in the order e-major (4 lq + e), a different rounding of the same sum.
 constexpr int AO_QB = 16, AO_KCH = 64;
 template <int DK>
 __global__ __launch_bounds__(512) void attno_kernel(AttnOP p) {
@@ -37,7 +42,7 @@ __global__ __launch_bounds__(512) void attno_kernel(AttnOP p) {
   const int SP = p.SP, nrel = 2 * p.window + 1;
   float* S = sm + hh * AO_QB * SP;                           // this head's scores / probabilities [16][SP]
   float* base = sm + NH * AO_QB * SP;
-  float* Vt = base + hh * AO_KCH * VS;                       // this head's V chunk, transposed [64][VS]
+  // (base .. base + NH * AO_KCH * VS: IN and Z of the conv_o / LayerNorm tail; nothing else lives there)
   float* Qs = base + NH * AO_KCH * VS + hh * DK * AO_QB;     // [DK][16], scaled by 1/sqrt(dk)
   float* RK = base + NH * AO_KCH * VS + NH * DK * AO_QB;     // [nrel][DK] relative-key embeddings (shared by the heads)
   float* RV = RK + nrel * DK;                                // [nrel][DK] relative-value embeddings
@@ -60,26 +65,22 @@ __global__ __launch_bounds__(512) void attno_kernel(AttnOP p) {
 #pragma unroll
     for (int s = 0; s < NKS; ++s) kf[s] = pe_row_load_so(kd, o, 4 * s * p.q_cs);
   };
-  float vv[DK / 32][8];
-  auto load_v = [&](int j0) {                                  // thread -> key t4 & 63, channel group t4 >> 6
-    const int jj = t4 & 63;
-    const int o = (j0 + jj < T) ? (t4 >> 6) * 8 * p.q_cs + j0 + jj : 0x3fffffff;
-#pragma unroll
-    for (int g = 0; g < DK / 32; ++g)
-#pragma unroll
-      for (int u = 0; u < 8; ++u) vv[g][u] = pe_row_load_so(vd, o, (32 * g + u) * p.q_cs);
-  };
-  auto store_v = [&]() {
-    const int jj = t4 & 63;
-#pragma unroll
-    for (int g = 0; g < DK / 32; ++g)
-#pragma unroll
-      for (int u = 0; u < 8; ++u) Vt[jj * VS + (t4 >> 6) * 8 + 32 * g + u] = vv[g][u];
-  };
+  // V fragments of this wave's channel tiles: slots [0, 4) = 64-key half A, [4, 8) = half B (a key group past the length
+  // is not read at all; a group that straddles it is masked element by element where it is used)
+  const bool two = PE_UNIFORM(w4 + 4 < NDT);
+  f32x4 va0[8], va1[8];
+  const int vrow0 = (w4 * 16 + l15) * p.q_cs + 4 * lq, vrow1 = ((w4 + 4) * 16 + l15) * p.q_cs + 4 * lq;
+#define AO_LOAD_HALF(S0, K0)                                                          \
+  _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                       \
+    const int kk = (K0) + 16 * c;                                                       \
+    va0[(S0) + c] = pe_row_load4(vd, (kk + 4 * lq < T) ? vrow0 + kk : -4);              \
+    va1[(S0) + c] = pe_row_load4(vd, (two && kk + 4 * lq < T) ? vrow1 + kk : -4);       \
+  }
   float kA[NKS], kB[NKS];
-  load_k(w4, kA);
-  load_v(0);
   {
+    // Q and the relative-position tables first: the first phase waits for them only (the memory counter retires in
+    // order), this wave's first two key tiles stay in flight behind them. (The V fragments are requested between the score
+    // tiles: 32 more 16-byte loads per lane in front of the LDS stores below cost the first phase 1.7 us of issue time.)
     constexpr int NQ = DK * AO_QB / 256;
     float qv[NQ];
 #pragma unroll
@@ -95,6 +96,10 @@ __global__ __launch_bounds__(512) void attno_kernel(AttnOP p) {
       rk[u] = pe_row_load(rkd, tid + 512 * u);
       rv[u] = pe_row_load(rvd, tid + 512 * u);
     }
+    PE_SCHED_FENCE();
+    load_k(w4, kA);
+    load_k(w4 + 4, kB);
+    PE_SCHED_FENCE();
 #pragma unroll
     for (int u = 0; u < NQ; ++u) Qs[t4 + 256 * u] = qv[u] * p.qscale;
 #pragma unroll
@@ -134,14 +139,16 @@ __global__ __launch_bounds__(512) void attno_kernel(AttnOP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) S[(4 * lq + r) * SP + kt * 16 + l15] = acc[r];
     };
-    for (int kt = w4; kt < nkt; kt += 8) {
-      load_k(kt + 4, kB);                                      // beyond the last tile: zero-length reads
+    AO_LOAD_HALF(0, 0)                                         // V: first 64 keys in front of the score tiles, the next 64 behind
+    for (int kt = w4; kt < nkt; kt += 8) {                     // (the first two tiles' fragments were requested at entry)
       tile(kt, kA);
       if (kt + 4 < nkt) {
-        load_k(kt + 8, kA);
+        load_k(kt + 8, kA);                                    // beyond the last tile: zero-length reads
         tile(kt + 4, kB);
+        load_k(kt + 12, kB);
       }
     }
+    AO_LOAD_HALF(4, AO_KCH)
   }
   __syncthreads();
   PE_STAMP(0, 2);
@@ -218,37 +225,33 @@ __global__ __launch_bounds__(512) void attno_kernel(AttnOP p) {
       bb[k] = pe_row_load(bd, c);
     }
   }
-  // ---- 3. O^T[d][q] = sum_key V[d][key] P[q][key]: channel tiles w4 and w4 + 4 of this head
-  const bool two = PE_UNIFORM(w4 + 4 < NDT);
+  // ---- 3. O^T[d][q] = sum_key V[d][key] P[q][key]: channel tiles w4 and w4 + 4 of this head, A operand from the registers
+  // loaded at entry, B operand P[q = l15][key] from the score rows (zeros from the length to the next multiple of 64)
   f32x4 o0, o1;
 #pragma unroll
   for (int r = 0; r < 4; ++r) o0[r] = o1[r] = 0.f;
-  for (int j0 = 0; j0 < T; j0 += AO_KCH) {
-    __syncthreads();                                           // softmax finished / previous chunk consumed
-    store_v();
-    if (j0 + AO_KCH < T) load_v(j0 + AO_KCH);
-    __syncthreads();
-    float a0[AO_KCH / 4], a1[AO_KCH / 4], pf[AO_KCH / 4];
-#pragma unroll
-    for (int s = 0; s < AO_KCH / 4; ++s) {
-      const int key = 4 * s + lq;
-      a0[s] = Vt[key * VS + w4 * 16 + l15];
-      a1[s] = two ? Vt[key * VS + (w4 + 4) * 16 + l15] : 0.f;
-      pf[s] = S[l15 * SP + j0 + key];
-    }
-    PE_SCHED_FENCE();
-    if (two) {
-#pragma unroll
-      for (int s = 0; s < AO_KCH / 4; ++s) {
-        o0 = pe_mfma_16x16x4(a0[s], pf[s], o0);
-        o1 = pe_mfma_16x16x4(a1[s], pf[s], o1);
-      }
-    } else {
-#pragma unroll
-      for (int s = 0; s < AO_KCH / 4; ++s) o0 = pe_mfma_16x16x4(a0[s], pf[s], o0);
-    }
-    PE_SCHED_FENCE();
+  __syncthreads();                                             // softmax finished
+#define AO_USE_HALF(S0, K0)                                                           \
+  _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                       \
+    const int key = (K0) + 16 * c + 4 * lq;                                             \
+    float pf[4];                                                                        \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) pf[e] = S[l15 * SP + key + e];        \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                     \
+      const bool in = key + e < T;                                                      \
+      o0 = pe_mfma_16x16x4(in ? va0[(S0) + c][e] : 0.f, pf[e], o0);                     \
+      if (two) o1 = pe_mfma_16x16x4(in ? va1[(S0) + c][e] : 0.f, pf[e], o1);            \
+    }                                                                                   \
   }
+  for (int j0 = 0; j0 < T; j0 += 2 * AO_KCH) {
+    AO_USE_HALF(0, j0)
+    if (j0 + 2 * AO_KCH < T) { AO_LOAD_HALF(0, j0 + 2 * AO_KCH) }
+    if (j0 + AO_KCH < T) {
+      AO_USE_HALF(4, j0 + AO_KCH)
+      if (j0 + 3 * AO_KCH < T) { AO_LOAD_HALF(4, j0 + 3 * AO_KCH) }
+    }
+  }
+#undef AO_USE_HALF
+#undef AO_LOAD_HALF
   {
     // relative-value band as three more k-steps: k index -> relative offset rr, A = rel_v[rr][d], B = p[q][q + rr - w]
     const int q = i0 + l15;
@@ -266,7 +269,7 @@ __global__ __launch_bounds__(512) void attno_kernel(AttnOP p) {
     }
   }
   PE_STAMP(0, 5);
-  __syncthreads();                                             // every wave is done with the V chunks: IN may overwrite them
+  // (IN overlaps nothing phase 3 reads: no barrier in front of these stores)
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
     IN[(hh * DK + w4 * 16 + 4 * lq + r) * NC + l15] = o0[r];

@@ -25,7 +25,7 @@ KERNELS = {0: "attn_kernel / attno_kernel (0 entry, 1 operands in LDS, 2 scores,
 def main():
     preset = sys.argv[1] if len(sys.argv) > 1 else "medium"
     T = int(sys.argv[2]) if len(sys.argv) > 2 else 128
-    lib = L.bind(os.path.join(ROOT, "piper_amd", "libpiper_hip_stamps.so"))
+    lib = L.bind(os.environ.get("PIPER_STAMPS_LIB") or os.path.join(ROOT, "piper_amd", "libpiper_hip_stamps.so"))
     lib.pe_debug_stamps.argtypes = [C.POINTER(C.c_longlong)]
     cfg = W.preset(preset)
     eng = Engine(blob=W.pack_blob(cfg, W.synthetic_weights(cfg, 1234)), lib=lib)
