@@ -67,9 +67,12 @@ __global__ __launch_bounds__(512) void attno_kernel(AttnOP p) {
   };
   // V fragments of this wave's channel tiles: slots [0, 4) = 64-key half A, [4, 8) = half B (a key group past the length
   // is not read at all; a group that straddles it is masked element by element where it is used)
-  const bool two = PE_UNIFORM(w4 + 4 < NDT);
+  // channel tiles wt and wt + 4 of this head: head 1 deals them in the opposite wave order, so the two waves that share a SIMD
+  // (w and w + 4) own three of the heads' twelve tiles between them instead of four or two
+  const int wt = PE_UNIFORM(hh ? 3 - w4 : w4);
+  const bool two = PE_UNIFORM(wt + 4 < NDT);
   f32x4 va0[8], va1[8];
-  const int vrow0 = (w4 * 16 + l15) * p.q_cs + 4 * lq, vrow1 = ((w4 + 4) * 16 + l15) * p.q_cs + 4 * lq;
+  const int vrow0 = (wt * 16 + l15) * p.q_cs + 4 * lq, vrow1 = ((wt + 4) * 16 + l15) * p.q_cs + 4 * lq;
 #define AO_LOAD_HALF(S0, K0)                                                          \
   _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                       \
     const int kk = (K0) + 16 * c;                                                       \
@@ -225,22 +228,31 @@ __global__ __launch_bounds__(512) void attno_kernel(AttnOP p) {
       bb[k] = pe_row_load(bd, c);
     }
   }
-  // ---- 3. O^T[d][q] = sum_key V[d][key] P[q][key]: channel tiles w4 and w4 + 4 of this head, A operand from the registers
+  // ---- 3. O^T[d][q] = sum_key V[d][key] P[q][key]: channel tiles wt and wt + 4 of this head, A operand from the registers
   // loaded at entry, B operand P[q = l15][key] from the score rows (zeros from the length to the next multiple of 64)
   f32x4 o0, o1;
 #pragma unroll
   for (int r = 0; r < 4; ++r) o0[r] = o1[r] = 0.f;
   __syncthreads();                                             // softmax finished
-#define AO_USE_HALF(S0, K0)                                                           \
+  // (a half that ends inside the utterance takes its fragments as they are; the one that straddles the length zeroes the
+  // stale columns behind it -- a select per element costs matrix-pipe issue slots, profiles/r04_mfma_mix.txt)
+#define AO_USE_HALF_(S0, K0, SEL, TWO)                                                \
   _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                       \
     const int key = (K0) + 16 * c + 4 * lq;                                             \
     float pf[4];                                                                        \
     _Pragma("unroll") for (int e = 0; e < 4; ++e) pf[e] = S[l15 * SP + key + e];        \
     _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                     \
-      const bool in = key + e < T;                                                      \
-      o0 = pe_mfma_16x16x4(in ? va0[(S0) + c][e] : 0.f, pf[e], o0);                     \
-      if (two) o1 = pe_mfma_16x16x4(in ? va1[(S0) + c][e] : 0.f, pf[e], o1);            \
+      o0 = pe_mfma_16x16x4(SEL(key + e, va0[(S0) + c][e]), pf[e], o0);                  \
+      if (TWO) o1 = pe_mfma_16x16x4(SEL(key + e, va1[(S0) + c][e]), pf[e], o1);         \
     }                                                                                   \
+  }
+#define AO_SEL_ALL(k, v) (v)
+#define AO_SEL_LEN(k, v) ((k) < T ? (v) : 0.f)
+#define AO_USE_HALF(S0, K0)                                                           \
+  if ((K0) + AO_KCH <= T) {                                                           \
+    if (two) { AO_USE_HALF_(S0, K0, AO_SEL_ALL, true) } else { AO_USE_HALF_(S0, K0, AO_SEL_ALL, false) }     \
+  } else {                                                                            \
+    if (two) { AO_USE_HALF_(S0, K0, AO_SEL_LEN, true) } else { AO_USE_HALF_(S0, K0, AO_SEL_LEN, false) }     \
   }
   for (int j0 = 0; j0 < T; j0 += 2 * AO_KCH) {
     AO_USE_HALF(0, j0)
@@ -251,6 +263,9 @@ __global__ __launch_bounds__(512) void attno_kernel(AttnOP p) {
     }
   }
 #undef AO_USE_HALF
+#undef AO_USE_HALF_
+#undef AO_SEL_ALL
+#undef AO_SEL_LEN
 #undef AO_LOAD_HALF
   {
     // relative-value band as three more k-steps: k index -> relative offset rr, A = rel_v[rr][d], B = p[q][q + rr - w]
@@ -260,10 +275,10 @@ __global__ __launch_bounds__(512) void attno_kernel(AttnOP p) {
       const int rr = 4 * s + lq;
       const int j = q + rr - p.window;
       const float bvv = (rr < nrel && q < T && j >= 0 && j < T) ? S[l15 * SP + j] : 0.f;
-      const float av0 = rr < nrel ? RV[rr * DK + w4 * 16 + l15] : 0.f;
+      const float av0 = rr < nrel ? RV[rr * DK + wt * 16 + l15] : 0.f;
       o0 = pe_mfma_16x16x4(av0, bvv, o0);
       if (two) {
-        const float av1 = rr < nrel ? RV[rr * DK + (w4 + 4) * 16 + l15] : 0.f;
+        const float av1 = rr < nrel ? RV[rr * DK + (wt + 4) * 16 + l15] : 0.f;
         o1 = pe_mfma_16x16x4(av1, bvv, o1);
       }
     }
@@ -272,8 +287,8 @@ __global__ __launch_bounds__(512) void attno_kernel(AttnOP p) {
   // (IN overlaps nothing phase 3 reads: no barrier in front of these stores)
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
-    IN[(hh * DK + w4 * 16 + 4 * lq + r) * NC + l15] = o0[r];
-    if (two) IN[(hh * DK + (w4 + 4) * 16 + 4 * lq + r) * NC + l15] = o1[r];
+    IN[(hh * DK + wt * 16 + 4 * lq + r) * NC + l15] = o0[r];
+    if (two) IN[(hh * DK + (wt + 4) * 16 + 4 * lq + r) * NC + l15] = o1[r];
   }
   __syncthreads();
   PE_STAMP(0, 6);

@@ -118,10 +118,12 @@ __global__ __launch_bounds__(256) void colchain4_kernel(ColP p) {
   const bool ok = t < L;
   const int part = p.mode >= 2 ? (int)blockIdx.z : 0, row0 = part * C4_H;
   const int rows_here = p.rows1 - row0 < C4_H ? p.rows1 - row0 : C4_H;
+  // Weight fragments are requested BEHIND the (few) input loads of the phase they belong to: a wave reaches its LDS stores
+  // only after the vector-memory pipe has taken every load in front of them, and the memory counter retires in order, so
+  // 36 16-byte loads per lane in front of the inputs put their whole fetch on the staging's critical path (profiles/r04_notes.md, calls 60-65)
   Col4W<K1> gw0;                                 // FRONT: the res/skip conv's fragments
-  if constexpr (FRONT) col_gemm4_fetch<K1>(gw0, p.w0, C4_NT, wv, lane);
-  Col4W<K1> gw;                                  // first GEMM's fragments, in flight under the input staging
-  col_gemm4_fetch<K1>(gw, p.w1 + (long)part * C4_NT * (K1 / 4) * 256, (rows_here + 63) / 64, wv, lane);
+  Col4W<K1> gw;                                  // first GEMM's fragments
+  auto fetch_gw = [&]() { col_gemm4_fetch<K1>(gw, p.w1 + (long)part * C4_NT * (K1 / 4) * 256, (rows_here + 63) / 64, wv, lane); };
   const bool skip_part = p.mode == 2 && (p.rows1 <= C4_H || part == 1);
   float sk[NVT];                                 // FRONT: the completed skip sum of this thread's (channel, column) slots
   if constexpr (FRONT) {
@@ -136,9 +138,12 @@ __global__ __launch_bounds__(256) void colchain4_kernel(ColP p) {
       sk[k] = pe_row_load(s0, ok ? c * p.in1_cs + t : -1);
       b0v[k] = pe_row_load(b0d, c);
     }
+    PE_SCHED_FENCE();
+    col_gemm4_fetch<K1>(gw0, p.w0, C4_NT, wv, lane);
 #pragma unroll
     for (int k = 0; k < NVT; ++k) YT[col * KS1 + rl + 64 * k] = av[k];
     __syncthreads();
+    fetch_gw();                                  // in flight under the res/skip GEMM
     col_gemm4_run<K1>(gw0, YT, P, wv, lane);
     __syncthreads();
 #pragma unroll
@@ -166,6 +171,8 @@ __global__ __launch_bounds__(256) void colchain4_kernel(ColP p) {
       bb[k] = pe_row_load(bd, c < rows_here ? c : -1);
       b1v[k] = pe_row_load(b1d, c < rows_here ? c : -1);
     }
+    PE_SCHED_FENCE();
+    if constexpr (!FRONT) fetch_gw();
 #pragma unroll
     for (int k = 0; k < NVT; ++k) YT[col * KS1 + rl + 64 * k] = xin[k];
   }
@@ -266,8 +273,8 @@ __global__ __launch_bounds__(256) void lngemm4_kernel(LnGemmP p) {
   const bool ok = t < L;
   const int part = blockIdx.z, row0 = part * H;
   const int rows_here = p.rows - row0 < H ? p.rows - row0 : H;
-  Col4W<H> gw;
-  col_gemm4_fetch<H>(gw, p.w16 + (long)part * C4_NT * (H / 4) * 256, (rows_here + 63) / 64, wv, lane);
+  Col4W<H> gw;                                   // requested behind the input loads (see colchain4_kernel)
+  auto fetch_gw = [&]() { col_gemm4_fetch<H>(gw, p.w16 + (long)part * C4_NT * (H / 4) * 256, (rows_here + 63) / 64, wv, lane); };
   float v[NVT], gg[NVT], bb[NVT], cb[NVT];
   {
     const pe_rowsrc ind = pe_make_row(p.in + (long)b * p.in_bs, H * p.in_cs);
@@ -295,6 +302,8 @@ __global__ __launch_bounds__(256) void lngemm4_kernel(LnGemmP p) {
 #pragma unroll
         for (int sl = 0; sl < FFN_MAXS; ++sl) pv[k][sl] = pe_row_load(pd, (ok && sl < p.nparts) ? sl * (H * 4) + c * 4 + col : -1);
       }
+      PE_SCHED_FENCE();
+      fetch_gw();
 #pragma unroll
       for (int k = 0; k < NVT; ++k) {
         float a = pv[k][0];
@@ -302,6 +311,9 @@ __global__ __launch_bounds__(256) void lngemm4_kernel(LnGemmP p) {
         for (int sl = 1; sl < FFN_MAXS; ++sl) a += pv[k][sl];
         v[k] = ok ? v[k] + (a + pbv[k]) : 0.f;
       }
+    } else {
+      PE_SCHED_FENCE();
+      fetch_gw();
     }
   }
   int red_flip = 0;

@@ -42,9 +42,9 @@ __global__ __launch_bounds__(256) void dds_layer4_kernel(DdsP p) {
   float* ob = p.out + (long)b * p.o_bs;
   const int pad = (p.dw_k - 1) / 2 * p.dw_dil;
   const bool fold = p.pre_z != nullptr;
-  // this wave's 1x1-conv weight fragments: in flight under phase 1
+  // this wave's 1x1-conv weight fragments: in flight under phase 1, requested BEHIND phase 1's own operands (the memory
+  // counter retires in order: in front of them their whole fetch sat on phase 1's critical path -- col4.h, r04_notes.md)
   Col4W<C4_H> gw;
-  col_gemm4_fetch<C4_H>(gw, p.wp4, C4_NT, wv, lane);
 
   int red_flip = 0;
   auto col_sum = [&](float x) -> float { return pe_col_sum4(x, red, red_flip, wv, lane, col); };
@@ -83,6 +83,8 @@ __global__ __launch_bounds__(256) void dds_layer4_kernel(DdsP p) {
       pw[k] = pe_row_load(pwd, okb ? c : -1);
       pb[k] = pe_row_load(pbd, okb ? c : -1);
     }
+    PE_SCHED_FENCE();
+    col_gemm4_fetch<C4_H>(gw, p.wp4, C4_NT, wv, lane);
     // first use of the length
     if (t0 >= L) return;
 #pragma unroll

@@ -46,17 +46,9 @@ __global__ __launch_bounds__(256) void ffn_kernel(FfnP p) {
                                                   // (outputs o0 .. o0 + 11 are kept)
   const int tid = threadIdx.x, lane = tid & 63, wv = PE_UNIFORM(tid >> 6);
   const int l15 = lane & 15, lq = lane >> 4;
-  // ---- conv_1 fragments of this wave: [tile][tap][quad]
+  // ---- conv_1 fragments of this wave: [tile][tap][quad], requested BEHIND the x window (the memory counter retires in
+  // order: in front of it the window's LDS stores waited for the whole fragment fetch -- col4.h, profiles/r04_notes.md)
   f32x4 a1[3][3][3];
-  {
-    const pe_rowsrc wd = pe_make_row_u(p.w1p + (long)s * (FFN_SL * FFN_H * 3), FFN_SL * FFN_H * 3);
-#pragma unroll
-    for (int m = 0; m < 3; ++m)
-#pragma unroll
-      for (int tp = 0; tp < 3; ++tp)
-#pragma unroll
-        for (int q = 0; q < 3; ++q) a1[m][tp][q] = pe_row_load4(wd, ((((m * 4 + wv) * 3 + tp) * 3 + q) * 64 + lane) * 4);
-  }
   // the utterance length lives in device memory: the window is requested against the row stride and the columns beyond
   // the length are zeroed when it is stored, so the length's latency overlaps the window's
   const int L = p.lens[b];
@@ -69,6 +61,17 @@ __global__ __launch_bounds__(256) void ffn_kernel(FfnP p) {
       const int idx = tid + 256 * i, ch = idx / 18, c = idx - ch * 18, t = o0 - 2 + c;
       xv[i] = pe_row_load(xd, (idx < FFN_H * 18 && t >= 0 && t < p.x_cs) ? ch * p.x_cs + t : -1);
     }
+    PE_SCHED_FENCE();
+    {
+      const pe_rowsrc wd = pe_make_row_u(p.w1p + (long)s * (FFN_SL * FFN_H * 3), FFN_SL * FFN_H * 3);
+#pragma unroll
+      for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int tp = 0; tp < 3; ++tp)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) a1[m][tp][q] = pe_row_load4(wd, ((((m * 4 + wv) * 3 + tp) * 3 + q) * 64 + lane) * 4);
+    }
+    PE_SCHED_FENCE();
     if (o0 >= L) return;
 #pragma unroll
     for (int i = 0; i < 14; ++i) {
