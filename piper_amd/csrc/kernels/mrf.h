@@ -395,6 +395,7 @@ __global__ __launch_bounds__(64 * MRF_NW) void mrf_kernel(MrfP p) {
             for (int r = 0; r < 4; ++r) dstb[((ms0 + m) * 16 + 4 * lq + r) * WS + col] = pe_lrelu(v[r], slope);
           }
         }
+        if (ph == 4 && u < 4) PE_STAMP(SK, 20 + u);
       }
     if (ph < 7) PE_STAMP(SK, 4 + 3 * ph);
   }

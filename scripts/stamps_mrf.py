@@ -22,7 +22,7 @@ def main():
     preset = sys.argv[1] if len(sys.argv) > 1 else "medium"
     B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
     T = int(sys.argv[3]) if len(sys.argv) > 3 else 128
-    lib = L.bind(os.path.join(ROOT, "piper_amd", "libpiper_hip_stamps.so"))
+    lib = L.bind(os.environ.get("PIPER_STAMPS_LIB") or os.path.join(ROOT, "piper_amd", "libpiper_hip_stamps.so"))
     lib.pe_debug_stamps.argtypes = [C.POINTER(C.c_longlong)]
     cfg = W.preset(preset)
     eng = Engine(blob=W.pack_blob(cfg, W.synthetic_weights(cfg, 1234)), lib=lib)
@@ -45,6 +45,7 @@ def main():
             if a == 0 or a < row[0]:
                 break
             print("  phase %d: K loop starts +%.2f  K loop %.2f us  epilogue %.2f us" % (ph, (a - row[0]) / 100.0, (b - a) / 100.0, (c - b) / 100.0))
+        print("  phase 4 epilogue, after unit 0..3: " + " ".join("+%.2f" % ((row[20 + u] - row[3 + 3 * 4]) / 100.0) if row[20 + u] else "-" for u in range(4)))
         last = max(row)
         print("  last stamp +%.2f us" % ((last - row[0]) / 100.0))
     eng.close()
