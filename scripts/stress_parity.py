@@ -1,5 +1,6 @@
 """Randomised parity sweep on a GPU box (not part of the pytest suite): random lengths / batches / scales on the
-medium, high and multi-speaker tiny voices, HIP path vs the CPU oracle. usage: python scripts/stress_parity.py [n]"""
+medium, high and multi-speaker tiny voices, HIP path vs the CPU oracle.
+usage: python scripts/stress_parity.py [n [seed [longest medium utterance]]]"""
 import sys
 import numpy as np
 sys.path.insert(0, ".")
@@ -8,9 +9,10 @@ from piper_amd import weights as W
 from piper_amd.engine import Engine
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
-rng = np.random.default_rng(2026)
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+tmax_medium = int(sys.argv[3]) if len(sys.argv) > 3 else 220
 worst = 0.0
-for preset, tmax, cases in (("medium", 220, n), ("high", 90, n // 3), ("tiny-high-ms", 60, n // 2), ("x-low", 120, n // 3)):
+for preset, tmax, cases in (("medium", tmax_medium, n), ("high", 90, n // 3), ("tiny-high-ms", 60, n // 2), ("x-low", 120, n // 3)):
     cfg = W.preset(preset)
     w = W.synthetic_weights(cfg, 99)
     eng = Engine(blob=W.pack_blob(cfg, w), device=0)
