@@ -136,7 +136,9 @@ void Engine::ensure_stage_a(int B, int Tmax) {
   if (!ffn_parts_ && H_ == 192 && FC_ % 48 == 0 && FC_ / 48 <= 16 && !enc_.empty() && enc_[0].f1p) {
     // partial outputs of the fused small-call FFN (kernels/ffn.h): [utterance][slice][192][columns], once
     PE_HIP(hipStreamSynchronize(stream_));
-    PE_HIP(hipMalloc((void**)&ffn_parts_, (size_t)(FC_ / 48) * H_ * LaunchPolicy::ffn_max_cols * sizeof(float)));
+    const size_t fbytes = (size_t)(FC_ / 48) * H_ * LaunchPolicy::ffn_max_cols * sizeof(float);
+    PE_HIP(hipMalloc((void**)&ffn_parts_, fbytes));
+    if (pol_.debug_poison) PE_HIP(hipMemset(ffn_parts_, 0xFF, fbytes));
   }
   const int Ts = rup(Tmax, 128);    // row strides are multiples of 128 columns (conv epilogue relies on it)
   auto carve = [&](char* base, size_t Bc, size_t T) -> size_t {
@@ -203,6 +205,7 @@ void Engine::ensure_stage_a(int B, int Tmax) {
       }
     }
     wsA_ = static_cast<char*>(blk); wsA_bytes_ = bytes; capA_B_ = nB; capA_T_ = nT;
+    if (pol_.debug_poison) PE_HIP(hipMemset(wsA_, 0xFF, bytes));
     carve(wsA_, capA_B_, capA_T_);
     if (h_in_cap_ < in_bytes_) {
       if (h_in_) PE_HIP(hipHostFree(h_in_));
@@ -272,6 +275,7 @@ void Engine::ensure_stage_b(int Fmax) {
       }
     }
     wsB_ = static_cast<char*>(blk); wsB_bytes_ = bytes; capB_B_ = nB; capB_F_ = nF;
+    if (pol_.debug_poison) PE_HIP(hipMemset(wsB_, 0xFF, bytes));
   }
   Fs_ = (int)capB_F_;
   Ss_ = (long)capB_F_ * hop_;
@@ -294,7 +298,10 @@ void Engine::ensure_stage_b(int Fmax) {
     drop_graphs();
     for (float*& sp : side_) { if (sp) PE_HIP(hipFree(sp)); sp = nullptr; }
     side_floats_ = want;
-    for (float*& sp : side_) PE_HIP(hipMalloc((void**)&sp, side_floats_ * sizeof(float)));
+    for (float*& sp : side_) {
+      PE_HIP(hipMalloc((void**)&sp, side_floats_ * sizeof(float)));
+      if (pol_.debug_poison) PE_HIP(hipMemset(sp, 0xFF, side_floats_ * sizeof(float)));
+    }
   }
 }
 

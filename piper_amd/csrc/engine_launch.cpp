@@ -12,7 +12,7 @@ namespace pe {
 // throughput-bound, and a halo the 128-column slab covers.
 bool Engine::can_group(const PackedConv& pc, int ncols) const {
   const long blocks = (long)((ncols + CFG_BN[pc.cfg] - 1) / CFG_BN[pc.cfg]) * (pc.mtiles * 32 / CFG_BM[pc.cfg]) * B_;
-  return pol_.groupable(pc.gate, pc.up != 0, blocks, (pc.ntaps - 1) * pc.dil);
+  return pol_.groupable(pc.gate, pc.up != 0, blocks, (pc.ntaps - 1) * pc.dil, pc.Cin);
 }
 void Engine::group_begin() {
   grouping_ = true;
@@ -92,7 +92,7 @@ void Engine::group_end_sum(View out, const float* bias_sum, float alpha) {
 int Engine::route(const PackedConv& pc, int ncols, int epi) const {
   const int cfg = pc.cfg;
   const long blocks = (long)((ncols + CFG_BN[cfg] - 1) / CFG_BN[cfg]) * (pc.mtiles * 32 / CFG_BM[cfg]) * B_;
-  if (!pol_.splitk(blocks, (pc.ntaps - 1) * pc.dil)) return ROUTE_TILE;
+  if (!pol_.splitk(blocks, (pc.ntaps - 1) * pc.dil, pc.Cin)) return ROUTE_TILE;
   return pol_.splitk_16col(pc.wp16 != nullptr, epi == EPI_CONVT, pc.gate, pc.nchunks * pc.ntaps) ? ROUTE_SPLITK16 : ROUTE_SPLITK;
 }
 void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int len_mul, int Lmax, int epi,
@@ -149,7 +149,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     group_bytes_ += kbytes;
     return;
   }
-  if (pol_.splitk(blocks, p.xhalo)) {
+  if (pol_.splitk(blocks, p.xhalo, pc.Cin)) {
     // few columns (one utterance through encoder / duration predictor / flow): split K across the waves
     const int MT = pc.gate ? 2 : 1;
     // waves per workgroup: 4 / 8 take whole chunks; the WN gate conv (6 chunks x 5 taps, two M tiles per wave)
@@ -216,7 +216,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     kend(kh);
     return;
   }
-  if (pol_.one_tap_direct(pc.gate, epi == EPI_CONVT, pc.ntaps)) {
+  if (pol_.one_tap_direct(pc.gate, epi == EPI_CONVT, pc.ntaps, pc.Cin)) {
     // one tap: nothing to share between the MFMA's k rows, so the B operand skips LDS (kernels/conv1x1.h)
     const dim3 grid((ncols + 63) / 64, (pc.mtiles + 1) / 2, B_);
     int kh = -1;

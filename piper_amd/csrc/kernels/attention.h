@@ -88,12 +88,12 @@ __device__ __forceinline__ void attn_body(const AttnP& p) {
   constexpr int NKF = MAXDK / 2;
   float kf[NKF];
   auto load_k = [&](int kt) {
-    // one per-lane base (channel parity, key) + a wave-uniform 2*u*stride in an SGPR: no VALU per load; rows
-    // beyond dk fall outside the descriptor and read 0
+    // one per-lane base (channel parity, key) + a wave-uniform 2*u*stride in an SGPR: no VALU per load
     const int j = kt * 32 + l31;
     const int base = (kt < nkt && j < T) ? lhi * p.q_cs + j : 0x3fffffff;
 #pragma unroll
-    for (int u = 0; u < NKF; ++u) kf[u] = pe_row_load_so(kd, base, 2 * u * p.q_cs);
+    for (int u = 0; u < NKF; ++u)          // (k-steps beyond dk exist only in the guarded <0> form: poisoned per step)
+      kf[u] = pe_row_load_so(kd, (DKT || 2 * u < dk) ? base : 0x3fffffff, 2 * u * p.q_cs);
   };
   // Every global operand of the kernel that does not depend on earlier phases is requested NOW, together: this wave's
   // first key tile, the first V chunk, then Q and the relative-position tables -- one memory latency instead of three
@@ -102,11 +102,12 @@ __device__ __forceinline__ void attn_body(const AttnP& p) {
   float vv[(MAXDK + 31) / 32][8];
   auto load_v = [&](int j0) {
     const int jj = tid & 63;
-    const int base = (j0 + jj < T) ? (tid >> 6) * 8 * p.q_cs + j0 + jj : 0x3fffffff;   // rows >= dk read 0
+    const int base = (j0 + jj < T) ? (tid >> 6) * 8 * p.q_cs + j0 + jj : 0x3fffffff;
 #pragma unroll
     for (int g = 0; g < (MAXDK + 31) / 32; ++g)
 #pragma unroll
-      for (int u = 0; u < 8; ++u) vv[g][u] = pe_row_load_so(vd, base, (32 * g + u) * p.q_cs);
+      for (int u = 0; u < 8; ++u)          // (the SGPR offset is outside the hardware's range check: rows >= dk are poisoned here)
+        vv[g][u] = pe_row_load_so(vd, ((int)(tid >> 6) * 8 + 32 * g + u < dk) ? base : 0x3fffffff, (32 * g + u) * p.q_cs);
   };
   auto store_v = [&]() {
     const int jj = tid & 63;

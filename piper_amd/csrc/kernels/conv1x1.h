@@ -15,8 +15,8 @@ namespace pe {
 // Without taps there is nothing to share between the MFMA's k rows: lane (n = l & 31, k = l >> 5) of v_mfma_f32_32x32x2
 // needs x[2 kk + k][col0 + n] -- for the 32 lanes of a k row that is ONE 128-byte piece of the channel's time row, so the
 // B operand is loaded straight into its register: one dword load per k-step through a descriptor over the utterance's
-// [Cin][stride] tensor (per-lane column offset, poisoned beyond the utterance's length; row offset in an SGPR; channels
-// beyond Cin are outside the descriptor), the same count as the staging loads and nothing else. No LDS, no barrier;
+// [Cin][stride] tensor (per-lane column offset, poisoned beyond the utterance's length; row offset in an SGPR, which the
+// hardware's range check does not see: the launcher sends only convs of whole 32-channel chunks here, policy.h), the same count as the staging loads and nothing else. No LDS, no barrier;
 // chunk c + 1's operands (A fragments as float4 descriptor loads, conv_mfma_kernel's packing; B as above) are in flight
 // while chunk c's MFMAs issue, at unconditional positions of a 2x unrolled ping-pong (exact wait counts; a chunk that
 // does not exist reads B through a zero-length descriptor, so its products are exact zeros).

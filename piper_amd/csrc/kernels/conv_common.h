@@ -37,6 +37,7 @@ __device__ __forceinline__ void load_frags(const pe_rowsrc& w, int step_off, int
 // with per-launch uniform flags, which keeps the unrolled epilogue small:
 //   STORE  : dst=out                         RESADD : +res            SUBFROM: old - v  (modules.py:464)
 //   ACCUM  : MRF sum/scale (models.py:356-363)       WNRS: rows<split h += v, else skip (+)= v (modules.py:201-208)
+template <bool V> struct pe_bool { static constexpr bool value = V; };
 struct EpiFlags {
   float sign, alpha;
   bool use_res, use_old, relu;
@@ -83,8 +84,8 @@ __device__ __forceinline__ void conv_store(const ConvP& p, const EpiFlags& f, in
 }
 // One 32x32 accumulator tile (16 values per lane) through the epilogue, branch-free: every operand stream
 // (bias, speaker bias, previous value, residual) is a buffer descriptor whose length is 0 when the stream
-// is not used and rows*stride otherwise, so unused operands and rows beyond the GEMM read as 0 and such
-// stores are dropped by the range check; invalid columns poison the lane offset. Addresses are one
+// is not used and rows*stride otherwise, so unused operands read as 0; invalid columns (and, in a matrix's partial last
+// row tile, invalid rows) poison the lane offset, so their loads give 0 and their stores are dropped. Addresses are one
 // per-lane offset (row base, column) shared by the 16 elements plus a wave-uniform k*stride that rides in
 // an SGPR: no per-element VALU address arithmetic. All loads are issued before the first store (out and
 // res may alias). WNRS relies on split % 32 == 0 (checked at load): a tile lies on one side of the split.
@@ -174,28 +175,40 @@ __device__ __forceinline__ void conv_store_tile(const ConvP& p, const EpiFlags& 
   const bool cok = col < ncols;
   const int ooff = cok ? (rb - orow0) * ocs + col : OOB;
   const int roff = cok ? rb * p.r_cs + col : OOB;
-  // two groups of eight elements (register budget of the 4-waves-per-SIMD instantiations); an element only
-  // ever reads its own location, so a group's stores cannot disturb the next group's loads
+  // A lane's 16 elements share ONE per-lane offset; the element's row rides in the SGPR offset, which the hardware's range
+  // check does not include (gfx9 / CDNA raw buffers: only the VGPR + immediate part is compared with num_records). Rows
+  // beyond the GEMM exist only in the LAST row tile of a matrix whose row count is not a multiple of 32: that tile
+  // (wave-uniform test) poisons the per-element lane offset instead; every other tile runs without per-element VALU.
+  const int row_end = to_skip ? p.rows : (p.epi == EPI_WNRS ? p.split : p.rows);      // first GEMM row NOT of this tensor
+  auto body = [&](auto partialc) {
+    constexpr bool PARTIAL = decltype(partialc)::value;
+    // two groups of eight elements (register budget of the 4-waves-per-SIMD instantiations); an element only
+    // ever reads its own location, so a group's stores cannot disturb the next group's loads
 #pragma unroll
-  for (int g = 0; g < 2; ++g) {
-    float b1[8], b2[8], o1[8], o2[8];
+    for (int g = 0; g < 2; ++g) {
+      float b1[8], b2[8], o1[8], o2[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int r = 8 * g + e, kr = (r & 3) + 8 * (r >> 2);
-      b1[e] = pe_row_load(bd, rb + kr);
-      b2[e] = pe_row_load(b2d, rb + kr);
-      o1[e] = pe_row_load_so(old, ooff, kr * ocs);
-      o2[e] = pe_row_load_so(rd, roff, kr * p.r_cs);
+      for (int e = 0; e < 8; ++e) {
+        const int r = 8 * g + e, kr = (r & 3) + 8 * (r >> 2);
+        const bool rok = !PARTIAL || rb + kr < row_end;
+        b1[e] = pe_row_load(bd, rb + kr);
+        b2[e] = pe_row_load(b2d, rb + kr);
+        o1[e] = pe_row_load_so(old, rok ? ooff : OOB, kr * ocs);
+        o2[e] = pe_row_load_so(rd, rok ? roff : OOB, kr * p.r_cs);
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int r = 8 * g + e, kr = (r & 3) + 8 * (r >> 2);
+        const bool rok = !PARTIAL || rb + kr < row_end;
+        float v = ((acc[r] + (b1[e] + b2[e])) * f.sign + (o1[e] + o2[e])) * f.alpha;
+        if (f.relu) v = v > 0.f ? v : 0.f;
+        pe_row_store_so(od, rok ? ooff : OOB, kr * ocs, v);
+      }
+      PE_SCHED_FENCE();
     }
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int r = 8 * g + e, kr = (r & 3) + 8 * (r >> 2);
-      float v = ((acc[r] + (b1[e] + b2[e])) * f.sign + (o1[e] + o2[e])) * f.alpha;
-      if (f.relu) v = v > 0.f ? v : 0.f;
-      pe_row_store_so(od, ooff, kr * ocs, v);
-    }
-    PE_SCHED_FENCE();
-  }
+  };
+  if (row0 + 32 <= row_end) body(pe_bool<false>{});
+  else body(pe_bool<true>{});
 }
 // commons.py:99-106 fused_add_tanh_sigmoid_multiply on a (tanh-tile, sigmoid-tile) accumulator pair
 __device__ __forceinline__ void conv_store_gate(const ConvP& p, int b, int ch, int col, float ta, float sa) {

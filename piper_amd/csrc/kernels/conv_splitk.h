@@ -67,8 +67,11 @@ __device__ __forceinline__ void conv_splitk_body(const ConvP& p, const int b, fl
 
   // x slab: one descriptor over the utterance's [Cin][stride] tensor, a per-lane column offset (poisoned outside
   // the row) and a wave-uniform row offset -- independent of L; columns >= L are zeroed when the slab is stored
+  // (the launcher sends only convs of whole 32-channel chunks here -- policy.h: the row offset of a load rides in the SGPR
+  // offset, which the hardware does not range-check; a chunk that does not exist reads through a zero-length descriptor)
   float xr[XB][KC];
   pe_rowsrc xd = pe_make_row(xb, p.Cin * p.x_cs);
+  const pe_rowsrc xz = pe_make_row(xb, 0);
   int xcol = n0 - p.padl + lane;
   int xoff[XB];
 #pragma unroll
@@ -78,17 +81,20 @@ __device__ __forceinline__ void conv_splitk_body(const ConvP& p, const int b, fl
     int cc = c;
     if (MS) {
       const int sgr = seg_of(c), sg = sgr < p.nseg ? sgr : 0;
-      cc = sgr < p.nseg ? c - sg * p.nchunks : p.nchunks;      // (a wave without work loads "chunk nchunks": zeros)
-      xd = pe_make_row(p.seg_x[sg] + (long)b * p.x_bs, p.Cin * p.x_cs);
+      cc = sgr < p.nseg ? c - sg * p.nchunks : 0;              // (a wave without work: zero-length descriptor, zeros)
+      xd = pe_make_row(p.seg_x[sg] + (long)b * p.x_bs, sgr < p.nseg ? p.Cin * p.x_cs : 0);
       xcol = n0 - p.seg_padl[sg] + lane;
       ld_dil = p.seg_dil[sg];
 #pragma unroll
       for (int h = 0; h < XB; ++h) xoff[h] = (xcol + 64 * h >= 0 && xcol + 64 * h < p.x_cs) ? xcol + 64 * h : 0x3fffffff;
     }
+    const bool exists = MS || c < nchunks;
+    const pe_rowsrc& src = exists ? xd : xz;
+    cc = exists ? cc : 0;
 #pragma unroll
     for (int h = 0; h < XB; ++h)
 #pragma unroll
-      for (int r = 0; r < KC; ++r) xr[h][r] = pe_row_load_so(xd, xoff[h], (cc * KC + r) * p.x_cs);
+      for (int r = 0; r < KC; ++r) xr[h][r] = pe_row_load_so(src, xoff[h], (cc * KC + r) * p.x_cs);
   };
   auto store_x = [&]() {
     cur_dil = ld_dil;
@@ -337,12 +343,14 @@ __global__ __launch_bounds__(64 * NW) void conv_splitk16_kernel(ConvP p) {
   const int nsteps = myc * mytaps;
 
   float xr[KC];
-  const pe_rowsrc xd = pe_make_row(xb, p.Cin * p.x_cs);
+  const pe_rowsrc xd = pe_make_row(xb, p.Cin * p.x_cs), xz = pe_make_row(xb, 0);
   const int xcol = n0 - p.padl + lane;
   const int xoff = (xcol >= 0 && xcol < p.x_cs) ? xcol : 0x3fffffff;
-  auto load_x = [&](int c) {
+  auto load_x = [&](int c) {       // (whole 32-channel chunks only, like conv_splitk_body; a chunk that does not exist: zeros)
+    const pe_rowsrc& src = c < nchunks ? xd : xz;
+    const int cc = c < nchunks ? c : 0;
 #pragma unroll
-    for (int r = 0; r < KC; ++r) xr[r] = pe_row_load_so(xd, xoff, (c * KC + r) * p.x_cs);
+    for (int r = 0; r < KC; ++r) xr[r] = pe_row_load_so(src, xoff, (cc * KC + r) * p.x_cs);
   };
   auto store_x = [&]() {
     const bool live = xcol < L;

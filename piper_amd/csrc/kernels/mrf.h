@@ -38,7 +38,11 @@ template <int V> struct pe_int { static constexpr int value = V; };
 
 // element (vidx + sidx) .. + 3: vidx per lane, sidx wave-uniform (SGPR offset)
 #ifdef PE_EMU
-inline f32x4 pe_row_load4_so(const pe_rowsrc& r, int vidx, int sidx) { return pe_row_load4(r, vidx + sidx); }
+inline f32x4 pe_row_load4_so(const pe_rowsrc& r, int vidx, int sidx) {
+  if (vidx >= 0 && vidx < r.n && vidx + 4 > r.n) return pe_row_load4(r, vidx + sidx);      // (a straddling group: element-wise)
+  f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  return pe_so_in_row(r, vidx, sidx, 4) ? pe_row_load4(r, vidx + sidx) : z;
+}
 #else
 __device__ __forceinline__ f32x4 pe_row_load4_so(pe_rowsrc r, int vidx, int sidx) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, vidx * 4, sidx * 4, 0));
@@ -98,7 +102,11 @@ __global__ __launch_bounds__(64 * MRF_NW) void mrf_kernel(MrfP p) {
   // ---- weight stream: this wave's A fragments of a step = MSW tiles x 2 float4 per lane
   const pe_rowsrc wd = pe_make_row(p.wstream, p.wfloats);
   const int wlane = ms0 * 512 + lane * 4;
-  auto load_a = [&](int woff, f32x4 (&a)[MSW][2]) {        // past the end of the stream: zeros
+  // (the fetch behind the stream's last step re-reads that step -- its values are never used; the stream offset rides in the
+  // SGPR offset, which the hardware does not range-check, so it must not run past the stream)
+  const int wlast = PE_UNIFORM(p.wfloats - STEPF);
+  auto load_a = [&](int woff, f32x4 (&a)[MSW][2]) {
+    woff = woff < wlast ? woff : wlast;
 #pragma unroll
     for (int m = 0; m < MSW; ++m)
 #pragma unroll
@@ -181,16 +189,21 @@ __global__ __launch_bounds__(64 * MRF_NW) void mrf_kernel(MrfP p) {
     }
     if (P.flags & MRF_INIT) {          // running x of the chain <- raw stage input of the owned units (L2-hot; used in the
                                         // epilogue, so the loads fly under the K loop). One lane offset per unit + an SGPR
-                                        // row offset: no per-element address registers (rows >= C: beyond the descriptor)
+                                        // row offset: no per-element address registers
 #pragma unroll
       for (int u = 0; u < UPW; ++u) {
         const int g = g0 + 16 * cu[u] + l15;
         int voff = (cu[u] >= 0 && g >= 0 && g < L) ? 4 * lq * p.x_cs + g : 0x3fffffff;
         PE_OPAQUE(voff);
 #pragma unroll
-        for (int m = 0; m < MSW; ++m)
+        for (int m = 0; m < MSW; ++m) {
+          // rows (ms0 + m) * 16 + 4 lq + r; C is a multiple of 4 (launcher), so a lane's four rows exist together. The row
+          // offset is an SGPR offset, outside the hardware's range check: lanes whose rows are >= C are poisoned here
+          // (only stages narrower than the padded width CP have such lanes)
+          const int vm = (C == CP || (ms0 + m) * 16 + 4 * lq < C) ? voff : 0x3fffffff;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) rawc[m][u][r] = pe_row_load_so(xd, voff, ((ms0 + m) * 16 + r) * p.x_cs);
+          for (int r = 0; r < 4; ++r) rawc[m][u][r] = pe_row_load_so(xd, vm, ((ms0 + m) * 16 + r) * p.x_cs);
+        }
       }
     }
     const pe_rowsrc bd = pe_make_row(P.bias, P.bias ? C : 0);

@@ -5,9 +5,10 @@
 
 namespace pe { extern thread_local long g_launches; }   // kernel launches issued by this thread (captured launches count once)
 #ifdef PE_EMU
+namespace pe { inline const char* g_emu_kernel = ""; }   // the kernel the emulator is running (diagnostics)
 #include "hip_emu.h"
 #define PE_LAUNCH(kernel, grid, block, smem, stream, ...) \
-  (++pe::g_launches, emu::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); }))
+  (++pe::g_launches, pe::g_emu_kernel = #kernel, emu::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); }))
 #define PE_DYN_SMEM(type, name) type* name = reinterpret_cast<type*>(emu::dyn_smem)
 #define PE_STAMP(k, i) ((void)0)
 #define PE_KTRACE(id) ((void)0)
@@ -26,10 +27,22 @@ inline pe_rowsrc pe_make_row(const float* row, int n) { return pe_rowsrc{row, n}
 inline float pe_row_load(const pe_rowsrc& r, int idx) { return (idx >= 0 && idx < r.n) ? r.p[idx] : 0.f; }
 inline pe_rowsrc pe_make_row_u(const float* row, int n) { return pe_rowsrc{row, n}; }
 // element (vidx + sidx): vidx per lane, sidx wave-uniform (an SGPR offset on the GPU)
-inline float pe_row_load_so(const pe_rowsrc& r, int vidx, int sidx) { return pe_row_load(r, vidx + sidx); }
-inline void pe_row_store_so(const pe_rowsrc& r, int vidx, int sidx, float v) {
+// The hardware's range check covers the VGPR offset only (gfx9 / CDNA: the SGPR offset of a raw buffer access is excluded
+// from bounds checking): an access whose vidx passes while vidx + sidx lies outside the row would touch memory behind the
+// tensor on the GPU. The emulator refuses it instead of returning the 0 a full check would give.
+inline bool pe_so_in_row(const pe_rowsrc& r, int vidx, int sidx, int width) {
+  if (vidx < 0 || vidx + width > r.n) return false;          // the hardware's check: reads give 0, writes are dropped
   const long i = (long)vidx + sidx;
-  if (i >= 0 && i < r.n) const_cast<float*>(r.p)[i] = v;
+  if (i < 0 || i + width > r.n) {
+    fprintf(stderr, "hip_emu: buffer access with VGPR offset %d inside the row (%d elements) but VGPR + SGPR offset %ld outside: "
+                    "the SGPR offset is not range-checked on the GPU [%s]\n", vidx, r.n, i, pe::g_emu_kernel);
+    abort();
+  }
+  return true;
+}
+inline float pe_row_load_so(const pe_rowsrc& r, int vidx, int sidx) { return pe_so_in_row(r, vidx, sidx, 1) ? r.p[vidx + sidx] : 0.f; }
+inline void pe_row_store_so(const pe_rowsrc& r, int vidx, int sidx, float v) {
+  if (pe_so_in_row(r, vidx, sidx, 1)) const_cast<float*>(r.p)[vidx + sidx] = v;
 }
 // two / four consecutive floats starting at element idx (all of them inside the row, or none is written)
 inline void pe_row_store2(const pe_rowsrc& r, int idx, float a, float b) {

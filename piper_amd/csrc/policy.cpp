@@ -44,6 +44,7 @@ static const LaunchPolicy::Knob kKnobs[] = {
     {"PIPER_HIP_ATTN_LONG", &LaunchPolicy::attn_long, 0, 1, "attention score slabs in global memory (attn_long_kernel) at every length, also in place of attno_kernel (tests): by default only utterances whose 32 x T slab does not fit LDS (more than ~830 ids) take that form"},
     {"PIPER_HIP_PROF_SITES", &LaunchPolicy::prof_sites, 0, 1, "level-2 profile rows of the tiled conv kernel per conv shape (tuning aid)"},
     {"PIPER_HIP_DEBUG_KEEP", &LaunchPolicy::debug_keep, 0, 1, "test hook: keep z_p for pe_debug_tensor"},
+    {"PIPER_HIP_DEBUG_POISON", &LaunchPolicy::debug_poison, 0, 1, "test hook: activation workspaces are filled with NaN bit patterns when allocated (no kernel may read what the call did not write)"},
 };
 
 const LaunchPolicy::Knob* LaunchPolicy::knobs(int* n) {

@@ -45,6 +45,7 @@ struct LaunchPolicy {
   long attn_long = 0;         // attention score slabs in global memory at every length (tests; by default only where they do not fit LDS)
   long prof_sites = 0;        // level-2 profile rows of the tiled conv kernel per conv SHAPE (tuning aid)
   long debug_keep = 0;        // test hook: keep z_p for pe_debug_tensor
+  long debug_poison = 0;      // test hook: every activation workspace is filled with NaN bit patterns when it is allocated
 
   // ---- thresholds without a knob (measured once, profiles/r02_notes.md / r03_notes.md)
   static constexpr long colchain_max_ids = 4096, colchain_max_frames = 8192;   // colchain / lngemm replace conv + LN pairs up to here
@@ -66,15 +67,22 @@ struct LaunchPolicy {
   // ---- decisions ------------------------------------------------------------------------------------------------
   // conv routing (engine_launch.cpp Engine::conv): `blocks` = workgroups the tiled kernel would launch, `halo` =
   // (taps - 1) * dilation, `units` = 32-channel chunks x taps of the K loop
-  bool splitk(long blocks, int halo) const { return blocks < splitk_max && halo <= 32; }
-  bool groupable(bool gate, bool convt, long blocks, int halo) const { return !gate && !convt && blocks < splitk_max && halo <= 96; }
+  // (`cin`: the split-K kernels and conv1x1_kernel put a channel row's offset into the SGPR offset of their buffer loads,
+  // which the hardware's range check of gfx9 / CDNA does not include: only convs of whole 32-channel chunks go there,
+  // the tiled kernel masks channels explicitly)
+  bool splitk(long blocks, int halo, int cin) const { return blocks < splitk_max && halo <= 32 && cin % 32 == 0; }
+  bool groupable(bool gate, bool convt, long blocks, int halo, int cin) const {
+    return !gate && !convt && blocks < splitk_max && halo <= 96 && cin % 32 == 0;
+  }
   bool splitk_16col(bool packed16, bool convt, bool gate, int units) const {
     return packed16 && !convt && ((gate && splitk16 >= 1) || (!gate && splitk16 >= 2)) && (units >= 24 || splitk16 >= 3);
   }
   bool splitk_12wave(bool gate, int units, int nchunks, int ntaps) const {
     return (wide_splitk == 1 && gate && units >= 24 && nchunks <= 6 && ntaps >= 4) || wide_splitk == 2;
   }
-  bool one_tap_direct(bool gate, bool convt, int ntaps) const { return conv1x1 && !gate && !convt && ntaps == 1; }
+  bool one_tap_direct(bool gate, bool convt, int ntaps, int cin) const {
+    return conv1x1 && !gate && !convt && ntaps == 1 && cin % 32 == 0;
+  }
   bool gate_half_groups(bool gate, int nchunks, int ntaps, long workgroups_whole) const {
     return gate_half && gate && nchunks == 6 && ntaps <= 5 && 2 * workgroups_whole <= 256;      // one workgroup per CU at most
   }
@@ -87,7 +95,7 @@ struct LaunchPolicy {
   bool chain4_frames(long cols) const { return chain4(cols, col4_max_frames); }
   bool chain_rs_front(long cols) const { return chain_rs && chain4_frames(cols); }
   // fused MRF stage
-  bool mrf_build(int channels) const { return mrf != 0 && channels <= 64; }
+  bool mrf_build(int channels) const { return mrf != 0 && channels <= 64 && channels % 4 == 0; }
   bool mrf_stage(bool built, bool resblock1, int padded_channels, double frames, bool matrix_bf3) const {
     return mrf && built && !(matrix_bf3 && mrf != 2 && frames >= (double)bf3_minf) &&
            (mrf == 2 || !resblock1 || (padded_channels == 32 && frames <= (double)mrf_maxf));

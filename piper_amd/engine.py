@@ -55,6 +55,17 @@ class Engine:
         self.sample_rate, self.hop, self.num_speakers, self.num_symbols = sr.value, hop.value, nspk.value, nsym.value
         self.weight_bytes = wb.value
 
+    @classmethod
+    def borrowed(cls, lib: C.CDLL, handle: int) -> "Engine":
+        """View of an engine somebody else owns (``pe_group_engine``): every method works, ``close()`` does not destroy."""
+        self = cls.__new__(cls)
+        self._lib, self._h, self._borrowed = lib, C.c_void_p(int(handle)), True
+        sr, hop, nspk, nsym, wb = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64()
+        self._check(lib.pe_get_info(self._h, C.byref(sr), C.byref(hop), C.byref(nspk), C.byref(nsym), C.byref(wb)))
+        self.sample_rate, self.hop, self.num_speakers, self.num_symbols = sr.value, hop.value, nspk.value, nsym.value
+        self.weight_bytes = wb.value
+        return self
+
     def weights_used(self) -> int:
         n = C.c_size_t()
         self._check(self._lib.pe_weights_used(self._h, C.byref(n)))
@@ -69,7 +80,8 @@ class Engine:
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
-            self._lib.pe_destroy(self._h)
+            if not getattr(self, "_borrowed", False):
+                self._lib.pe_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

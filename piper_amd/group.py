@@ -34,6 +34,15 @@ class EngineGroup:
     def __len__(self):
         return int(self._lib.pe_group_size(self._h))
 
+    def engine(self, i: int):
+        """Engine i of the group as a borrowed ``piper_amd.engine.Engine`` (durations / float waveform / profile of its
+        share of the last call); the group keeps ownership."""
+        from .engine import Engine
+        h = self._lib.pe_group_engine(self._h, int(i))
+        if not h:
+            raise EngineError(f"no engine {i} in a group of {len(self)}")
+        return Engine.borrowed(self._lib, h)
+
     def set_seed(self, seed: int):
         """Engine i draws from seed + i (independent noise streams per device)."""
         for i in range(len(self)):

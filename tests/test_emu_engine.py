@@ -721,3 +721,43 @@ def test_workspace_capacities_stay_inside_the_budget(emu_lib, monkeypatch):
         assert len(got.audio) == len(ref.audio)
         for x, y in zip(got.audio, ref.audio):
             assert np.array_equal(x, y)
+
+
+@pytest.mark.parametrize("preset,over,lens,env", [
+    ("tiny", {}, [9, 3, 14], {}),
+    ("tiny-high-ms", {}, [7, 11], {}),
+    # 192-channel voices: the small-call chains (4-column forms, fused FFN, attention + conv_o) and their 16-column forms
+    ("tiny", dict(hidden=192, inter=192, filter=96, n_layers=2), [12, 5], {}),
+    ("tiny", dict(hidden=192, inter=192, filter=96, n_layers=2), [12, 5], {"PIPER_HIP_COL4": 0}),
+    # coupling halves of 48 channels (the x-low quality's width): one-tap convs whose last 32-channel chunk is partial,
+    # on the batched route (conv1x1_kernel's SGPR row offset is outside the hardware range check)
+    ("tiny", dict(hidden=96, inter=96, filter=64, n_layers=1), [10, 6, 13], {"PIPER_HIP_SPLITK_MAX": 0, "PIPER_HIP_COLCHAIN": 0}),
+])
+def test_no_kernel_reads_what_the_call_did_not_write(emu_lib, monkeypatch, preset, over, lens, env):
+    """PIPER_HIP_DEBUG_POISON=1 fills every activation workspace with NaN bit patterns at allocation: a kernel that reads
+    a row, column or partial-sum slot nobody wrote in this call (stale data happens to be finite in practice) turns the
+    waveform into NaNs. Results must equal the oracle's as without the poison."""
+    cfg = W.preset(preset, **over)
+    w = W.synthetic_weights(cfg, 77)
+    ids = [W.synthetic_phoneme_ids(T, 900 + i, id_max=cfg.n_vocab - 1) for i, T in enumerate(lens)]
+    nw, nz = _noise(cfg, len(lens), max(lens), 21)
+    sids = [i % cfg.n_speakers for i in range(len(lens))] if cfg.n_speakers > 1 else None
+    scales = (0.5, 1.1, 0.7)
+    monkeypatch.setenv("PIPER_HIP_DEBUG_POISON", "1")
+    for k, v in env.items():
+        monkeypatch.setenv(k, str(v))
+    eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
+    for rep in range(2):                    # second call: replay on buffers the first call left behind
+        r = eng.synthesize_batch(ids, scales, sids=sids, noise_w=nw, noise_z=nz)
+        durs = eng.durations()
+        off = np.concatenate([[0], np.cumsum(lens)])
+        for i in range(len(lens)):
+            o = O.synthesize(w, cfg, ids[i], scales, nw[i], nz[i], sid=None if sids is None else sids[i])
+            assert np.all(np.isfinite(r.audio[i])), f"utterance {i}: NaN / Inf from poisoned workspace"
+            assert np.array_equal(durs[off[i]:off[i + 1]], o["durations"])
+            assert np.max(np.abs(r.audio[i] - o["audio"])) < 1e-4
+    # one utterance: the split-K / small-call routes on the same poisoned buffers
+    r1 = eng.synthesize(ids[0], scales, sid=None if sids is None else sids[0], noise_w=nw[0], noise_z=nz[0])
+    o = O.synthesize(w, cfg, ids[0], scales, nw[0], nz[0], sid=None if sids is None else sids[0])
+    assert np.all(np.isfinite(r1.audio[0])) and np.max(np.abs(r1.audio[0] - o["audio"])) < 1e-4
+    eng.close()
