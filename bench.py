@@ -127,9 +127,20 @@ def compact_leg(e):
             c[k] = _r(e[k], 4)
     if e.get("graphs"):
         c["captures"] = e["graphs"].get("captures_in_timed_calls")
+    if e.get("streaming_samples_per_s") is not None:
+        c["streaming_samples_per_s"] = _r(e["streaming_samples_per_s"])
+    if e.get("frames_per_id") is not None:
+        c["frames_per_id"] = _r(e["frames_per_id"], 3)
     if roof:
         c["kernel"] = _short(roof.get("kernel"), 44)
-        c["frac"] = _r((roof.get("step") or {}).get("frac"), 3)
+        st = roof.get("step") or {}
+        if c["dtype"] == "bf16x3":
+            # priced against the split-operand peak of the instruction these legs run (2500 / 3 TFLOP/s of f32-equivalent
+            # FLOPs), and said so: a fraction of the f32 matrix peak would exceed 1 here
+            c["frac"] = _r((st.get("achieved") or 0.0) / BF16X3_PEAK_TFLOPS, 3)
+            c["frac_of"] = "bf16x3 peak 833 TFLOP/s"
+        else:
+            c["frac"] = _r(st.get("frac"), 3)
     return c
 
 
@@ -146,8 +157,16 @@ def compact_line(full, full_path=None):
     out["data"] = "synthetic"
     out["config"] = {"workload": _short(cfgf.get("workload", ""), 200), "frames_per_step": cfgf.get("frames_per_step"),
                      "samples_per_step": cfgf.get("samples_per_step"),
+                     "frames_per_id": _r(cfgf.get("frames_per_id"), 4),
                      "kernel_launches_per_step": cfgf.get("kernel_launches_per_step"),
                      "parallelism": _short(cfgf.get("parallelism", ""), 80)}
+    su = full.get("sustained")
+    if su:
+        out["sustained"] = {"ms_per_step": _r(su.get("ms_per_step"), 5), "steps": su.get("steps"), "seconds": _r(su.get("seconds"), 3)}
+    if full.get("ranks"):
+        out["ranks"] = full["ranks"]
+    if full.get("headline_note"):
+        out["headline_note"] = full["headline_note"]
     if full.get("roofline"):
         out["roofline"] = compact_roofline(full["roofline"])
     cb = full.get("cpu_baseline")
@@ -183,8 +202,16 @@ def compact_line(full, full_path=None):
     if full_path:
         out["full"] = full_path
     line = json.dumps(out, separators=(",", ":"))
-    # belt and braces: shed the optional parts, largest first, until the line fits
-    for k in ("extra_configs", "api_inclusive", "speculation", "batched_per_gpu", "single_gpu_reference"):
+    # belt and braces: slim the legs first (kernel names, then units / step counts), then shed the optional parts, until
+    # the line fits
+    for drop in (("kernel", "frac_of"), ("unit", "steps", "calls", "captures")):
+        if len(line) <= COMPACT_LIMIT or not out.get("extra_configs"):
+            break
+        out["extra_configs"] = [{k: v for k, v in e.items() if k not in drop} for e in out["extra_configs"]]
+        line = json.dumps(out, separators=(",", ":"))
+    # (batched_per_gpu -- the 1 -> N scaling of batched throughput north_star asks for -- and the per-rank device list go last)
+    for k in ("extra_configs", "api_inclusive", "speculation", "sustained", "single_gpu_reference", "headline_note",
+              "per_rank_samples_per_s", "batched_per_gpu", "ranks"):
         if len(line) <= COMPACT_LIMIT:
             break
         out.pop(k, None)
@@ -280,6 +307,30 @@ class Ctx:
         return [float(v.item()) for v in pr]
 
 
+def rank_audit(ctx):
+    """What makes an N > 1 record auditable: the process group's world size and backend, the RCCL version torch.distributed
+    runs on, and every rank's device as its PCI bus id (through the C ABI: pe_device_pci_bus_id) -- N distinct ids = N
+    distinct GPUs took part. Gathered on every rank (a collective), returned on all."""
+    from piper_amd import _lib as L
+    try:
+        mine = L.device_pci_bus_id(ctx.dev_index)
+    except Exception as ex:          # noqa: BLE001 -- a diagnostic must not take the run down
+        mine = f"unknown ({type(ex).__name__})"
+    if ctx.dist is None:
+        return {"world_size": 1, "backend": None, "pci_bus_ids": [mine], "distinct_devices": 1}
+    ids = [None] * ctx.world
+    ctx.dist.all_gather_object(ids, mine)
+    rccl = None
+    try:
+        import torch
+        v = torch.cuda.nccl.version()
+        rccl = ".".join(str(x) for x in v) if isinstance(v, tuple) else str(v)
+    except Exception:          # noqa: BLE001
+        pass
+    return {"world_size": int(ctx.dist.get_world_size()), "backend": str(ctx.dist.get_backend()), "rccl": rccl,
+            "pci_bus_ids": ids, "distinct_devices": len(set(ids))}
+
+
 def make_inputs(cfg, B, T, rank):
     """SURVEY.md section 8d synthetic inputs: fixed-length id sequences shaped like phonemizer output; the duration noise
     is fixed (resident), the prior noise is drawn on the device every step."""
@@ -291,12 +342,12 @@ def make_inputs(cfg, B, T, rank):
     return id_lists, noise_w
 
 
-def timed_leg(ctx, eng, cfg, preset, B, T, steps, warmup, sync_ranks=True):
+def timed_leg(ctx, eng, cfg, preset, B, T, steps, warmup, sync_ranks=True, scales=SCALES):
     """W untimed + exactly K timed steps bracketed by barrier + device synchronisation; max over ranks."""
     import torch
     id_lists, noise_w = make_inputs(cfg, B, T, ctx.rank)
     eng.set_seed(1234 + ctx.rank)
-    eng.upload(id_lists, SCALES, noise_w=noise_w)
+    eng.upload(id_lists, scales, noise_w=noise_w)
 
     def step():
         # device pipeline + delivery of the int16 PCM to pinned host memory (stream sync inside); the result views are
@@ -333,9 +384,9 @@ def timed_leg(ctx, eng, cfg, preset, B, T, steps, warmup, sync_ranks=True):
             "id_lists": id_lists, "noise_w": noise_w, "step": step, "steps": steps, "warmup": warmup}
 
 
-def device_only_ms(eng, id_lists, noise_w, n):
+def device_only_ms(eng, id_lists, noise_w, n, scales=SCALES):
     """Device pipeline only (no PCM delivery to the host), graphs replayed: the sum of the kernels' durations."""
-    eng.upload(id_lists, SCALES, noise_w=noise_w)
+    eng.upload(id_lists, scales, noise_w=noise_w)
     eng.run(); eng.fetch(False, False)
     t1 = time.perf_counter()
     for _ in range(n):
@@ -394,6 +445,8 @@ def main():
         assert dist.get_world_size() == args.gpus
         ctx.dist = dist
         dbg(f"process group up: backend {ctx.backend}, world {ctx.world}")
+
+    ranks_info = rank_audit(ctx)
 
     os.environ["PIPER_HIP_MATRIX"] = args.matrix          # read once, at engine creation
     cfg = W.preset(preset)
@@ -496,8 +549,10 @@ def main():
             "data": "synthetic (seeded random-weight voice of the named architecture, synthetic phoneme ids)",
             "config": {"workload": workload_text(cfgno, preset, cfg, B, T),
                        "frames_per_step": int(frames.sum()), "samples_per_step": leg["samples_per_step"],
+                       "frames_per_id": float(frames.sum()) / float(B * T),
                        "kernel_launches_per_step": leg["launches"],
                        "parallelism": f"utterance-parallel x{ctx.world}, one process per GPU, RCCL weight broadcast"},
+            "ranks": ranks_info,
             "api_inclusive": api,
             "device_pipeline_only_ms_per_step": dev_ms,
             "sustained": sustained,
@@ -511,6 +566,10 @@ def main():
             out["single_gpu_reference"] = single_ref
         if batched_line is not None:
             out["batched_per_gpu"] = batched_line
+        if ctx.world > 1 and cfgno == 2:
+            out["headline_note"] = ("N>1 `value` = configs[1] per GPU (1 utterance x 128 ids per rank per step: one weak-scaling "
+                                    "curve with the N=1 line; rounds 1-3 used configs[3] here). The batched 1->N scaling "
+                                    "north_star asks for is `batched_per_gpu` (64 utterances per GPU): value / single_gpu_value")
         if roof is not None:
             out["roofline"] = roof
         if ctx.world == 1 and not args.no_cpu_baseline:
@@ -541,16 +600,36 @@ def extra_configs(ctx, eng_medium, cfg_medium, args):
     from piper_amd.engine import Engine
     legs = []
 
-    def batched(cfgno, eng, cfg, preset, B, T, steps, warmup, dtype="f32"):
-        l = timed_leg(ctx, eng, cfg, preset, B, T, steps, warmup, sync_ranks=False)
-        dev_ms = device_only_ms(eng, l["id_lists"], l["noise_w"], max(2, min(5, steps)))
-        e = {"config": {"workload": workload_text(cfgno, preset, cfg, B, T), "frames_per_step": int(l["frames"].sum()),
+    def batched(cfgno, eng, cfg, preset, B, T, steps, warmup, dtype="f32", scales=SCALES, what=None):
+        l = timed_leg(ctx, eng, cfg, preset, B, T, steps, warmup, sync_ranks=False, scales=scales)
+        dev_ms = device_only_ms(eng, l["id_lists"], l["noise_w"], max(2, min(5, steps)), scales=scales)
+        e = {"config": {"workload": what or workload_text(cfgno, preset, cfg, B, T), "frames_per_step": int(l["frames"].sum()),
                         "samples_per_step": l["samples_per_step"], "kernel_launches_per_step": l["launches"]},
              "metric": "audio samples/sec", "value": l["value"], "unit": "samples/s", "dtype": dtype,
              "x_realtime": l["value"] / cfg.sample_rate, "ms_per_step": l["ms_per_step"], "steps": steps,
-             "warmup": warmup, "device_pipeline_only_ms_per_step": dev_ms}
+             "warmup": warmup, "device_pipeline_only_ms_per_step": dev_ms,
+             "frames_per_id": float(l["frames"].sum()) / float(B * T)}
         if not args.no_roofline:
-            e["roofline"] = roofline(eng, preset, B, T, l["id_lists"], l["noise_w"], 3, l["ms_per_step"], dev_ms)
+            e["roofline"] = roofline(eng, preset, B, T, l["id_lists"], l["noise_w"], 3, l["ms_per_step"], dev_ms, scales=scales)
+        return e
+
+    def survey_shape():
+        """configs[1] at SURVEY.md section 8(d)'s stated shape -- about 2.7 frames per id (F ~ 330-350 for 128 ids): the
+        synthetic voice's duration predictor gives 3.26 at length_scale 1, which dilutes the per-id front end with ~20 %
+        more samples than the stated shape; here length_scale is set so that the utterance lands at 2.7 +- 0.2."""
+        id_lists, noise_w = make_inputs(cfg_medium, 1, 128, ctx.rank)
+        ls, fpi = 1.0, None
+        for _ in range(4):
+            r = eng_medium.synthesize_batch(id_lists, (SCALES[0], ls, SCALES[2]), noise_w=noise_w)
+            fpi = float(r.frames.sum()) / 128.0
+            if abs(fpi - 2.7) <= 0.1:
+                break
+            ls *= 2.7 / fpi
+        sc = (SCALES[0], float(f"{ls:.3f}"), SCALES[2])
+        e = batched(2, eng_medium, cfg_medium, "medium", 1, 128, 200, 10, scales=sc,
+                    what=f"configs[1] at SURVEY 8(d)'s shape: medium voice, 1 utterance x 128 ids, length_scale {sc[1]} "
+                         f"(-> ~2.7 frames per id; the headline runs the scales 0.667/1.0/0.8 = 3.26 frames per id)")
+        e["length_scale"] = sc[1]
         return e
 
     def guarded(name, fn):
@@ -564,17 +643,29 @@ def extra_configs(ctx, eng_medium, cfg_medium, args):
         legs.append(e)
 
     # configs[3] per-GPU share: the medium engine is already there
+    guarded("configs[1] at 2.7 frames/id", survey_shape)
     guarded("configs[3] per-GPU share", lambda: batched(4, eng_medium, cfg_medium, "medium", 64, 128, 10, 3))
     guarded("changing inputs, B=1", lambda: varied_inputs(eng_medium, cfg_medium))
     guarded("concurrent single-utterance engines on one GPU", lambda: concurrent_streams(ctx, cfg_medium))
     # configs[2] + configs[4]: the high-quality architecture (ResBlock1, four upsampling stages)
     hi = {}
 
-    def high_batched():
+    def high_single():
+        # the high-quality architecture's single utterance (en_US-lessac-high / -ryan-high shape: 264 GFLOP per step, the one
+        # B=1 workload that is matrix-bound) -- on a fresh engine, before the batched leg grows its workspaces
         hi["cfg"] = W.preset("high")
         hi["eng"] = Engine(blob=W.pack_blob(hi["cfg"], W.synthetic_weights(hi["cfg"], 1234)), device=ctx.dev_index)
+        return batched(5, hi["eng"], hi["cfg"], "high", 1, 128, 50, 5,
+                       what="high VITS voice (configs[2] / configs[4] architecture), 1 utterance x 128 ids per step, scales "
+                            "0.667/1.0/0.8; step = pe_run + int16 PCM to host")
+
+    def high_batched():
+        if "eng" not in hi:
+            hi["cfg"] = W.preset("high")
+            hi["eng"] = Engine(blob=W.pack_blob(hi["cfg"], W.synthetic_weights(hi["cfg"], 1234)), device=ctx.dev_index)
         return batched(3, hi["eng"], hi["cfg"], "high", 64, 128, 5, 2)
 
+    guarded("high voice, B=1", high_single)
     guarded("configs[2]", high_batched)
     if "eng" in hi:
         guarded("configs[4]", lambda: stream_latency(hi["eng"], hi["cfg"], "high", 128, 100, 5, 0))
@@ -685,7 +776,7 @@ def varied_inputs(eng, cfg, n=64):
                                     "were too small and cost a second pass (include/piper_hip.h: pe_speculation_stats)"}}
 
 
-def roofline(eng, preset, B, T, id_lists, noise_w, steps, ms_per_step, dev_ms):
+def roofline(eng, preset, B, T, id_lists, noise_w, steps, ms_per_step, dev_ms, scales=SCALES):
     """HIP events on the engine's stream (pe_profile_enable): one pass with a pair per pipeline stage, one pass with
     a pair around every conv / attention / layer-norm / fused-stage launch. `kernel` is the kernel with the largest
     share of device time, whatever its bound; `achieved` its algorithmic FLOPs (2 * rows * Cin * taps per output
@@ -696,7 +787,7 @@ def roofline(eng, preset, B, T, id_lists, noise_w, steps, ms_per_step, dev_ms):
     the replayed graph runs the same kernels back to back with ~0 gaps (profiles/r02_trace_gaps_b1.txt) -- and
     subtracted, so that `avg_launch_us` agrees with rocprofv3's kernel durations (profiles/*_kernel_stats.csv); the raw
     figure stays beside it."""
-    eng.upload(id_lists, SCALES, noise_w=noise_w)
+    eng.upload(id_lists, scales, noise_w=noise_w)
     nprof = max(3, min(10, steps))
     eng.profile_enable(1)
     eng.profile_reset()

@@ -172,6 +172,10 @@ int pe_graph_stats(pe_engine* e, int64_t* cached, int64_t* captures);
  * column tiles by it (piper_amd/csrc/kernels/col4.h); bench.py prints it so that a result line says what the box did. */
 int pe_xcc_pattern(pe_engine* e, int32_t xcc[64], int32_t* period);
 
+/* Diagnostic: the PCI bus id ("0000:05:00.0") of HIP device `device` as this process sees it -- what a multi-GPU record
+ * lists per rank so that a reader can check that N ranks ran on N DISTINCT devices (bench.py --gpus N). */
+int pe_device_pci_bus_id(int device, char* out, int32_t capacity);
+
 /* Diagnostic: the engine's launch-policy knobs -- every environment variable that picks a kernel form, with its default,
  * range and meaning -- as a JSON array of {"env", "default", "lo", "hi", "doc"} objects (piper_amd/csrc/policy.h; a
  * static string, valid for the life of the process). The knobs are read once per engine, at pe_create; the product needs

@@ -17,7 +17,7 @@ SYMBOLS = [
     "pe_synthesize_batch", "pe_upload", "pe_run", "pe_fetch", "pe_stream_begin", "pe_stream_next",
     "pe_get_durations", "pe_get_info",
     "pe_set_seed", "pe_profile_enable", "pe_profile_reset", "pe_profile_rows", "pe_profile_get", "pe_profile_bytes",
-    "pe_stream", "pe_debug_tensor", "pe_debug_randn", "pe_rng_calls", "pe_run_launches", "pe_speculation_stats", "pe_warmup", "pe_graph_stats", "pe_xcc_pattern", "pe_policy_describe", "pe_last_error", "pe_destroy",
+    "pe_stream", "pe_debug_tensor", "pe_debug_randn", "pe_rng_calls", "pe_run_launches", "pe_speculation_stats", "pe_warmup", "pe_graph_stats", "pe_xcc_pattern", "pe_device_pci_bus_id", "pe_policy_describe", "pe_last_error", "pe_destroy",
     "pe_group_create", "pe_group_broadcast_path", "pe_group_size", "pe_group_engine", "pe_group_synthesize_batch", "pe_group_assignment",
     "pe_group_destroy",
 ]
@@ -83,6 +83,7 @@ def bind(path: str) -> C.CDLL:
     lib.pe_xcc_pattern.argtypes = [vp, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
     lib.pe_policy_describe.argtypes = []
     lib.pe_policy_describe.restype = C.c_char_p
+    lib.pe_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_int32]
     lib.pe_warmup.argtypes = [vp, C.c_int32, C.c_int32, C.c_float, f32p, i64p, C.c_int64]
     lib.pe_graph_stats.argtypes = [vp, i64p, i64p]
     lib.pe_group_create.argtypes = [vp, C.c_size_t, i32p, C.c_int32, C.POINTER(vp)]
@@ -99,6 +100,15 @@ def bind(path: str) -> C.CDLL:
     lib.pe_destroy.argtypes = [vp]
     lib.pe_destroy.restype = None
     return lib
+
+
+def device_pci_bus_id(device: int, lib=None) -> str:
+    """PCI bus id of HIP device `device` (include/piper_hip.h: pe_device_pci_bus_id)."""
+    lib = lib if lib is not None else get_lib()
+    buf = C.create_string_buffer(64)
+    if lib.pe_device_pci_bus_id(int(device), buf, 64):
+        raise RuntimeError(lib.pe_last_error().decode(errors="replace"))
+    return buf.value.decode()
 
 
 _lib = None

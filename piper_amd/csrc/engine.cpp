@@ -217,9 +217,9 @@ void Engine::ensure_stage_a(int B, int Tmax) {
   carve(wsA_, capA_B_, capA_T_);
 }
 
-void Engine::ensure_stage_b(int Fmax) {
+void Engine::ensure_stage_b(int Fmax, int batch) {
   const int Fs = rup(Fmax, 128);
-  const size_t Bnow = (size_t)std::max(B_, 1);
+  const size_t Bnow = (size_t)std::max(batch > 0 ? batch : B_, 1);      // (warmup sizes for ITS batch, not the last call's)
   auto hmax_of = [&](size_t F) {        // largest [channels x length] activation of the generator
     size_t hm = (size_t)U_ * F, L = F;
     for (auto& st : ups_) { L *= st.rate; hm = std::max(hm, (size_t)st.ch * L); }
@@ -249,9 +249,13 @@ void Engine::ensure_stage_b(int Fmax) {
   if ((size_t)Fs > capB_F_) nF = std::max<size_t>(Fs, capB_F_ ? rup((int)(capB_F_ + capB_F_ / 2), 128) : 0);
   // (a grown frame capacity past the 2 GiB descriptor range falls back to the exact one)
   if (hmax_of(nF) * sizeof(float) >= (size_t)1 << 31 || (size_t)3 * H_ * nF * sizeof(float) >= (size_t)1 << 31) nF = Fs;
-  if (nB != capB_B_ || nF != capB_F_ || !wsB_) {
+  // (after an exact-size fallback under memory pressure capB_B_ is below stage A's capacity: a block that already holds
+  // this call stays -- re-entering here would free and re-allocate it, and drop every graph, on each call)
+  const bool fits = capB_exact_ && wsB_ && Bnow <= capB_B_ && (size_t)Fs <= capB_F_;
+  if (!fits && (nB != capB_B_ || nF != capB_F_ || !wsB_)) {
     const size_t budget = ws_budget();
-    if (carve(nullptr, nB, nF) > budget) { nB = Bnow; nF = Fs; }
+    capB_exact_ = false;
+    if (carve(nullptr, nB, nF) > budget) { nB = Bnow; nF = Fs; capB_exact_ = true; }
     const size_t exact = carve(nullptr, Bnow, Fs);
     if (exact > budget) {
       carve(wsB_, capB_B_, capB_F_);
@@ -267,7 +271,7 @@ void Engine::ensure_stage_b(int Fmax) {
     size_t bytes = carve(nullptr, nB, nF);
     if (hipMalloc(&blk, bytes) != hipSuccess) {
       (void)hipGetLastError();
-      nB = Bnow; nF = Fs; bytes = exact; blk = nullptr;
+      nB = Bnow; nF = Fs; bytes = exact; blk = nullptr; capB_exact_ = true;
       if (hipMalloc(&blk, bytes) != hipSuccess) {
         (void)hipGetLastError();
         carve(nullptr, 0, 0);
@@ -477,7 +481,7 @@ void Engine::warmup(int max_batch, int max_ids, float frames_per_id, const float
   if (!(frames_per_id > 0.f)) frames_per_id = 8.f;
   const long fmax = std::min<long>(MAX_FRAMES, (long)std::ceil((double)frames_per_id * max_ids) + 1);
   ensure_stage_a(max_batch, max_ids);
-  ensure_stage_b(frame_bucket((int)fmax));
+  ensure_stage_b(frame_bucket((int)fmax), max_batch);
   if (!sample || n_sample < 1) return;
   // the single-utterance graphs of every id bucket up to max_ids: the sample cut / tiled to the bucket length, twice --
   // the first call of a bucket runs as two graphs around the frame-count read-back, the second as the one speculative
@@ -531,7 +535,16 @@ void Engine::run() {
     fguess = spec_fg_force_ ? spec_fg_force_ : frame_bucket((int)std::ceil(last_ratio_ * spec_margin_ * (float)Tmax_) + 1);
     if (fguess > MAX_FRAMES) spec = false;
   }
-  if (spec) ensure_stage_b(fguess);              // before stage A is enqueued: growing the workspace drops every graph
+  if (spec) {
+    // before stage A is enqueued: growing the workspace drops every graph. The guess carries a margin and a bucket
+    // rounding: when IT does not fit the workspace budget / the 2 GiB descriptor range the real frame count still may, so
+    // the call falls back to the two-graph form and only ensure_stage_b on the real counts can fail it
+    try {
+      ensure_stage_b(fguess);
+    } catch (const std::runtime_error&) {
+      spec = false;
+    }
+  }
   char key[200];
   if (spec) {
     // the whole utterance -- text encoder to int16 -- as ONE graph: stage B is issued right behind stage A for the

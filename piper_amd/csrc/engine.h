@@ -140,7 +140,7 @@ class Engine {
                          const std::vector<float>* bias, int nbias, int dil, int padl, bool gate, int split);
   DdsW load_dds(const WeightSet& ws, const std::string& prefix);
   void ensure_stage_a(int B, int Tmax);
-  void ensure_stage_b(int Fmax);
+  void ensure_stage_b(int Fmax, int batch = 0);
 
   // ---- launches
   struct View { float* p; long bs; int cs; };
@@ -357,6 +357,7 @@ class Engine {
 
   // workspaces
   size_t capA_B_ = 0, capA_T_ = 0, capB_B_ = 0, capB_F_ = 0;      // utterances / padded ids of stage A, utterances / frames of stage B
+  bool capB_exact_ = false;      // stage B was last sized for exactly one call (memory pressure): it stays while calls fit
   size_t ws_budget_ = 0;             // bytes a stage's workspace may take (a third of the device's memory)
   size_t ws_budget();
   char* wsA_ = nullptr; size_t wsA_bytes_ = 0;

@@ -340,6 +340,18 @@ int pe_xcc_pattern(pe_engine* e, int32_t xcc[64], int32_t* period) {
   });
 }
 
+int pe_device_pci_bus_id(int device, char* out, int32_t capacity) {
+  return guard([&] {
+    if (!out || capacity < 16) throw std::runtime_error("pci bus id buffer too small (16 bytes at least)");
+    out[0] = 0;
+#ifdef PE_EMU
+    snprintf(out, (size_t)capacity, "emu:%02d:00.0", device);
+#else
+    PE_HIP(hipDeviceGetPCIBusId(out, capacity, device));
+#endif
+  });
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // pe_group_*: one engine / stream / worker thread per device in ONE process (include/piper_hip.h)
 // ---------------------------------------------------------------------------------------------------------------------

@@ -46,11 +46,37 @@ def test_single_gpu_line_is_compact_and_complete():
     assert d["full"] == "bench_full.json"
 
 
+def test_honesty_fields_are_in_the_compact_line():
+    """the sustained leg's ms_per_step and the frames-per-id of the synthetic utterance are in the
+    line the driver reads; a bf16x3 leg names the peak its fraction is divided by (and that fraction is <= 1); the high
+    voice's B=1 leg and configs[4]'s streaming rate are there."""
+    full = _full()
+    full["sustained"] = {"steps": 2300, "seconds": 2.01, "value": 1.22e8, "ms_per_step": 0.8741}
+    full["config"]["frames_per_id"] = 417 / 128
+    legs = full["extra_configs"]
+    bf = [e for e in legs if str(e.get("dtype", "")).startswith("bf16x3") and e.get("roofline")]
+    assert bf, "the canned run has bf16x3 legs"
+    legs.append({"leg": "high voice, B=1", "dtype": "f32", "value": 3.1e7, "unit": "samples/s", "ms_per_step": 3.4, "steps": 50,
+                 "frames_per_id": 3.3, "roofline": {"kernel": "conv_mfma_kernel<2,2,1,1,16,false,64>", "step": {"achieved": 80.0, "frac": 0.51}}})
+    legs.append({"leg": "configs[4]", "dtype": "f32", "value": 1.9, "unit": "ms", "steps": 100, "streaming_samples_per_s": 4.2e7})
+    d = _check(bench.compact_line(full, "bench_full.json"), 1)
+    assert d["sustained"]["ms_per_step"] == 0.8741 and abs(d["config"]["frames_per_id"] - 3.258) < 1e-3
+    by = {l["leg"]: l for l in d["extra_configs"]}
+    assert by["high voice, B=1"]["frac"] == 0.51 and by["high voice, B=1"]["frames_per_id"] == 3.3
+    assert by["configs[4]"]["streaming_samples_per_s"] == 4.2e7
+    for l in d["extra_configs"]:
+        if l.get("dtype") == "bf16x3" and "frac" in l:
+            assert "bf16x3 peak" in l["frac_of"] and 0 < l["frac"] <= 1.0, l
+
+
 def test_multi_gpu_line_is_compact():
     full = _full()
     full.pop("extra_configs")
     full.pop("cpu_baseline")
     full["n_gpus"] = 8
+    full["ranks"] = {"world_size": 8, "backend": "nccl", "rccl": "2.26.6",
+                     "pci_bus_ids": ["0000:%02x:00.0" % (5 + 16 * i) for i in range(8)], "distinct_devices": 8}
+    full["headline_note"] = "n" * 300
     full["per_rank_samples_per_s"] = [3.4e8 + i for i in range(8)]
     full["single_gpu_reference"] = {"value": 3.45e8, "ms_per_step": 18.8, "steps": 10, "what": "x" * 300}
     full["batched_per_gpu"] = {"config": {"workload": "y" * 300}, "value": 2.8e9, "unit": "samples/s", "x_realtime": 1.3e5,
@@ -62,6 +88,23 @@ def test_multi_gpu_line_is_compact():
     assert len(d["per_rank_samples_per_s"]) == 8 and d["batched_per_gpu"]["value"] == 2.8e9
     assert d["batched_per_gpu"]["speedup_over_single_gpu"] == 7.78 and len(d["batched_per_gpu"]["workload"]) <= 120
     assert d["weight_broadcast"]["bytes"] == 139000000
+    # auditable: who took part
+    assert d["ranks"]["world_size"] == 8 and d["ranks"]["distinct_devices"] == 8 and len(d["ranks"]["pci_bus_ids"]) == 8
+    assert d["ranks"]["backend"] == "nccl" and d["ranks"]["rccl"]
+    assert d["batched_per_gpu"]["single_gpu_value"] == 3.6e8
+
+
+def test_batched_scaling_and_rank_list_are_shed_last():
+    full = _full()
+    full["n_gpus"] = 8
+    full["ranks"] = {"world_size": 8, "backend": "nccl", "rccl": "2.26.6", "pci_bus_ids": ["0000:%02x:00.0" % i for i in range(8)],
+                     "distinct_devices": 8}
+    full["batched_per_gpu"] = {"config": {"workload": "y" * 300}, "value": 2.8e9, "ms_per_step": 18.6, "steps": 10,
+                               "single_gpu_value": 3.6e8, "speedup_over_single_gpu": 7.78}
+    leg = copy.deepcopy(full["extra_configs"][0])
+    full["extra_configs"] = [dict(leg, leg=f"leg {i} " + "z" * 40) for i in range(60)]
+    d = json.loads(bench.compact_line(full, "bench_full.json"))
+    assert "extra_configs" not in d and d["batched_per_gpu"]["speedup_over_single_gpu"] == 7.78 and d["ranks"]["distinct_devices"] == 8
 
 
 def test_line_sheds_optional_parts_rather_than_overflow():

@@ -168,6 +168,29 @@ def test_medium_b16_ragged_matches_oracle(monkeypatch):
     print("medium ragged B=16 kernels:", sorted(names), "worst |d audio| %.2e" % worst)
 
 
+@pytest.mark.parametrize("preset,lens", [
+    ("x-low", [64, 128, 9, 128, 77, 128, 128, 30, 128, 128, 128, 128]),   # 48-channel coupling halves: partial 32-channel chunks / row tiles
+    ("x-low", [100]),
+    ("medium", [128]),
+    ("medium", [128, 3, 77, 128, 1, 50, 128, 19, 101, 64, 128, 33, 90, 2, 128, 111]),
+    ("high", [90, 128]),
+])
+def test_no_kernel_reads_what_the_call_did_not_write(monkeypatch, preset, lens):
+    """ADVICE r4 (conv1x1.h): PIPER_HIP_DEBUG_POISON=1 fills every activation workspace with NaN bit patterns at
+    allocation. On gfx9 / CDNA the SGPR offset of a buffer access is outside the hardware's range check, so a kernel that
+    puts a channel row's offset there and relies on the check for rows beyond the tensor reads whatever lies behind it --
+    finite in practice, NaN here. Results must equal the oracle's, twice (the second call replays on used buffers)."""
+    cfg, w = voice(preset)
+    eng = make_engine(monkeypatch, cfg, w, {"PIPER_HIP_DEBUG_POISON": 1})
+    ids, nw, nz = batch_inputs(cfg, lens, seed=91)
+    for rep in range(2):
+        names, worst = run_and_check(eng, cfg, w, ids, nw, nz, sample=range(min(len(lens), 6)))
+    r = eng.synthesize_batch(ids, SCALES, noise_w=nw, noise_z=nz)
+    assert all(np.all(np.isfinite(a)) for a in r.audio)
+    eng.close()
+    print(preset, len(lens), "poisoned workspaces: worst |d audio| %.2e" % worst, sorted(names))
+
+
 # Launcher knobs (read at engine creation) that force each tile configuration of conv_mfma_kernel / each split-K
 # variant on shapes where the default heuristics would pick another one. `expect`: instantiations that must run.
 FORCED = [
@@ -756,26 +779,37 @@ print(json.dumps(out))
         assert out[mode]["assign"] == [0, 1] and max(out[mode]["maxd"]) <= 2, out
 
 
-def test_bench_two_ranks_on_one_gpu_prints_a_compact_line():
-    """`bench.py --gpus 2` end to end on ONE GPU (PIPER_BENCH_BACKEND=gloo: both ranks share device 0, the process group
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_bench_n_ranks_on_one_gpu_prints_a_compact_line(ranks):
+    """`bench.py --gpus N` end to end on ONE GPU (PIPER_BENCH_BACKEND=gloo: every rank shares device 0, the process group
     and load_sharded's broadcast run over gloo): the N > 1 plumbing -- self-launch, barriers, max-over-ranks timing, the
-    per-rank gather -- must produce a driver-parsable last line before the first real multi-GPU run exists."""
+    per-rank gather -- must produce a driver-parsable last line before the first real multi-GPU run exists, and the
+    record must be auditable: world size, backend, every rank's PCI bus id, the batched 1 -> N scaling
+    next to `value`. At 8 ranks the line must still fit the driver's 4 KB."""
     import subprocess
     import sys
-    env = dict(os.environ, PIPER_BENCH_BACKEND="gloo", PIPER_BENCH_FULL=os.path.join(ROOT, "gpurun_out", "bench_full_2rank.json"))
+    full = os.path.join(ROOT, "gpurun_out", f"bench_full_{ranks}rank.json")
+    env = dict(os.environ, PIPER_BENCH_BACKEND="gloo", PIPER_BENCH_FULL=full)
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
-                        "--min-seconds", "0", "--no-roofline"], capture_output=True, text=True, timeout=900, env=env)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "3", "--warmup", "1",
+                        "--min-seconds", "0", "--no-roofline"], capture_output=True, text=True, timeout=1500, env=env)
     assert p.returncode == 0, p.stderr[-3000:]
     line = p.stdout.strip().splitlines()[-1]
-    assert len(line) < 4096
+    assert len(line) < 4096, len(line)
+    with open(os.path.join(ROOT, "gpurun_out", f"bench_{ranks}rank_gloo_1gpu.json"), "w") as f:
+        f.write(line + "\n")
     d = json.loads(line)
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"
-    assert len(d["per_rank_samples_per_s"]) == 2 and d["weight_broadcast"]["bytes"] > 1e8
+    assert d["n_gpus"] == ranks and d["steps"] == 3 and d["value"] > 0 and d["scaling"] == "weak"
+    assert len(d["per_rank_samples_per_s"]) == ranks and d["weight_broadcast"]["bytes"] > 1e8
     # the same per-GPU workload as the N = 1 headline (one weak-scaling curve), the batched share beside it
     assert "1 utterance(s) x 128" in d["config"]["workload"]
     bp = d["batched_per_gpu"]
     assert "64 utterance(s) x 128" in bp["workload"] and bp["value"] > 0 and bp["single_gpu_value"] > 0
+    assert bp["speedup_over_single_gpu"] > 0
+    rk = d["ranks"]
+    assert rk["world_size"] == ranks and rk["backend"] == "gloo" and len(rk["pci_bus_ids"]) == ranks
+    assert rk["distinct_devices"] == 1 and all(":" in x for x in rk["pci_bus_ids"])      # one GPU here: the record says so
+    assert "batched_per_gpu" in d["headline_note"]
 
 
 def test_graph_cache_is_lru_and_warmup_stops_captures(monkeypatch):
