@@ -1,4 +1,4 @@
-# A/B of two builds of the library on ONE box: build/ab/libpiper_hip_base.so (the previous commit's build) against the
+# A/B of two builds of the library on ONE box: piper_amd/libab_base.so (the previous commit's build) against the
 # tree's piper_amd/libpiper_hip.so. Usage: gpu_ab.sh "<pytest -k expression or empty>" "<bench args>" [kernel name filter]
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
@@ -9,7 +9,7 @@ cp piper_amd/libpiper_hip.so /tmp/new.so
 if [ -n "$KEXPR" ]; then timeout 900 python -m pytest tests -m gpu -q -x -k "$KEXPR" 2>&1 | tail -4; fi
 BQ="--no-extra --no-cpu-baseline --min-seconds 0.5"
 for r in 1 2; do
-  cp build/ab/libpiper_hip_base.so piper_amd/libpiper_hip.so
+  cp piper_amd/libab_base.so piper_amd/libpiper_hip.so
   timeout 300 python bench.py $BQ $BARGS > $O/base_$r.json 2>> $O/err.log
   cp /tmp/new.so piper_amd/libpiper_hip.so
   timeout 300 python bench.py $BQ $BARGS > $O/new_$r.json 2>> $O/err.log
