@@ -380,9 +380,11 @@ def stream_chunks(w, cfg, z, chunk_frames: int, pad_frames: int, sid: Optional[i
 
 
 @torch.no_grad()
-def durations_only(w, cfg, ids, scales, noise_w=None, sid: Optional[int] = None) -> np.ndarray:
+def durations_only(w, cfg, ids, scales, noise_w=None, sid: Optional[int] = None, return_w: bool = False):
     """The integer durations ceil(exp(logw) * length_scale) of one utterance (models.py:688-703): text encoder +
-    stochastic duration predictor only -- cheap enough to check EVERY utterance of a large batch."""
+    stochastic duration predictor only -- cheap enough to check EVERY utterance of a large batch. With `return_w` also
+    the values in front of the ceil (a caller that checks tens of thousands of ids needs them: a value within an ulp or
+    two of an integer can land on either side of it in another summation order)."""
     if not isinstance(next(iter(w.values())), torch.Tensor):
         w = to_torch(w)
     dtype = w["enc_p.emb.weight"].dtype
@@ -395,7 +397,9 @@ def durations_only(w, cfg, ids, scales, noise_w=None, sid: Optional[int] = None)
     nw = torch.zeros(1, 2, T, dtype=dtype) if noise_w is None else \
         torch.as_tensor(np.asarray(noise_w), dtype=dtype).view(1, 2, -1)[:, :, :T]
     logw = sdp_reverse(w, cfg, x, x_mask, nw, float(scales[2]), g=g)
-    return torch.ceil(torch.exp(logw) * x_mask * float(scales[1]))[0, 0].to(torch.int64).numpy()
+    wv = torch.exp(logw) * x_mask * float(scales[1])
+    d = torch.ceil(wv)[0, 0].to(torch.int64).numpy()
+    return (d, wv[0, 0].numpy()) if return_w else d
 
 
 def infer_one(w, cfg, ids, scales, noise_w=None, noise_z=None, sid: Optional[int] = None,

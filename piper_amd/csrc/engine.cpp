@@ -296,8 +296,8 @@ void Engine::ensure_stage_b(int Fmax, int batch) {
   }
   // per-resblock buffers of the grouped sibling schedule (one-utterance calls, first generator stage): allocated
   // here, outside any graph capture; the schedule only applies below 700 64x64 blocks per stage
-  const size_t want = std::min<size_t>(Bc * hmax, (size_t)700 * 4096);
-  if (pol_.group_mrf && side_floats_ < want) {
+  const size_t want = std::min<size_t>(Bc * hmax, (size_t)(pol_.group_tiled ? LaunchPolicy::group_tiled_max_blocks : LaunchPolicy::group_max_blocks64) * 4096);
+  if ((pol_.group_mrf || pol_.group_tiled) && side_floats_ < want) {
     PE_HIP(hipStreamSynchronize(stream_));
     drop_graphs();
     for (float*& sp : side_) { if (sp) PE_HIP(hipFree(sp)); sp = nullptr; }

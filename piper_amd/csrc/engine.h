@@ -151,11 +151,14 @@ class Engine {
   // Grouped launches (conv_splitk_group_kernel): between group_begin() and group_end() conv() records the launch instead
   // of issuing it; group_end() issues all of them (<= 3 independent convs of one launch shape) as one launch.
   bool grouping_ = false;
+  bool group_tiled_ = false;            // the open group goes to the TILED kernel (conv_mfma_group_kernel), cfg = group_cfg_
+  int group_cfg_ = 0;
   std::vector<struct ConvP> group_;
   double group_flops_ = 0, group_bytes_ = 0;
   int group_ncols_ = 0;
   bool can_group(const PackedConv& pc, int ncols) const;
-  void group_begin();
+  bool can_group_tiled(const PackedConv& pc, int ncols) const;
+  void group_begin(bool tiled = false);
   void group_end();
   // the recorded convs as ONE GEMM over their concatenated K, summed: out = (sum_j (res_j + conv_j)) * alpha
   bool can_group_sum() const;

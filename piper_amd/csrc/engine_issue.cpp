@@ -95,10 +95,21 @@ void Engine::issue_stage_a() {
       ap.x = x.p; ap.x_bs = x.bs; ap.x_cs = x.cs;
       double afl = 0;
       for (int b = 0; b < B; ++b) afl += 4.0 * (double)tlens_h_[b] * tlens_h_[b] * H_;
+      // short calls: 4-query workgroups (kernels/attn4.h: 32 workgroups for 128 ids instead of 8)
+      const float* wo4 = pol_.attn4_cols((long)B * T) ? w4_of(e.o16) : nullptr;
+      if (wo4) {
+        ap.wo4 = wo4; ap.xcd = xcd_period_; ap.SP = rup(T, 64) + 4;
+        const size_t smem4 = ((size_t)8 * ap.SP + 8 * (dk_ + 4) + 2 * 9 * dk_ + 3 * 72 + 4 * 196 + 4 * 192 * 4 + 32) * sizeof(float);
+        const int kh = kbegin(prof_level_ >= 2 ? krow("attn4_kernel<96>") : 0, afl + 2.0 * tsum * e.o.macs_per_col,
+                              4.0 * (tsum * 5.0 * H_ + e.o.macs_per_col));
+        launch::attn4(dim3((T + 3) / 4, B), smem4, stream_, ap);
+        kend(kh);
+      } else {
       const int kh = kbegin(prof_level_ >= 2 ? krow("attno_kernel<96>") : 0, afl + 2.0 * tsum * e.o.macs_per_col,
                             4.0 * (tsum * 5.0 * H_ + e.o.macs_per_col));
       launch::attno(dim3((T + 15) / 16, B), ao_smem, stream_, ap);
       kend(kh);
+      }
     } else {
     AttnP ap;
     ap.qkv = qkv_; ap.q_bs = (long)3 * H_ * Ts; ap.q_cs = Ts;
@@ -458,6 +469,19 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
         if (cv.size() != st.rb[0].size()) grp = false;
         for (auto& c : cv) grp = grp && can_group(c, Lmax);
       }
+      // the same schedule through the TILED kernel where one conv of the stage is only a few tiles per CU (the high voice's
+      // 128- / 64-channel stages of a single utterance: 834 tiles = 3.26 per CU)
+      bool grp_t = false;
+      if (!fuse && !grp) {
+        const PackedConv& c0 = st.rb[0][0];
+        const long tblocks = (long)((Lmax + CFG_BN[c0.cfg == CFG_C ? CFG_C : CFG_S] - 1) / CFG_BN[c0.cfg == CFG_C ? CFG_C : CFG_S]) *
+                             ((c0.rows + CFG_BM[c0.cfg == CFG_C ? CFG_C : CFG_S] - 1) / CFG_BM[c0.cfg == CFG_C ? CFG_C : CFG_S]) * B;
+        grp_t = pol_.group_stage_tiled(nk, tblocks, need <= side_floats_);
+        for (auto& cv : st.rb) {
+          if (cv.size() != st.rb[0].size()) grp_t = false;
+          for (auto& c : cv) grp_t = grp_t && can_group_tiled(c, Lmax) && (c.cfg == CFG_C) == (c0.cfg == CFG_C);
+        }
+      }
       if (fuse) {
         mrf(st, u, xs, lens, mult, Lmax, tail);
         for (auto& cv : st.rb)
@@ -466,7 +490,7 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
           tail_done = true;
           fl += 2.0 * fsum * hop_ * post_cin_ * POST_K;
         }
-      } else if (grp) {
+      } else if (grp || grp_t) {
         // step d of every resblock in one grouped launch; each resblock keeps its own buffers, one pass sums them
         auto SV = [&](int k) { return View{side_[k], (long)st.ch * Ls, (int)Ls}; };
         View xin[3] = {u, u, u};
@@ -474,7 +498,7 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
         const int nsteps = (int)st.rb[0].size();
         const bool rb1 = arch_[A_RESBLOCK] == 1;
         for (int d = 0; d < nsteps; ++d) {
-          group_begin();
+          group_begin(grp_t);
           for (int j = 0; j < nk; ++j) {
             auto& cv = st.rb[j];
             const View t0 = j == 0 ? tb : SV(4 * (j - 1)), t1 = j == 0 ? ta : SV(4 * (j - 1) + 1),
@@ -490,7 +514,7 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
             fl += 2.0 * fsum * mult * cv[d].macs_per_col;
           }
           // the last step's outputs are only ever summed: one GEMM over the concatenated K writes the mean directly
-          if (d == nsteps - 1 && pol_.group_sum() && can_group_sum()) {
+          if (d == nsteps - 1 && !grp_t && pol_.group_sum() && can_group_sum()) {
             group_end_sum(xs, st.last_bias_sum, inv_nk);
             summed = true;
           } else {

@@ -14,14 +14,50 @@ bool Engine::can_group(const PackedConv& pc, int ncols) const {
   const long blocks = (long)((ncols + CFG_BN[pc.cfg] - 1) / CFG_BN[pc.cfg]) * (pc.mtiles * 32 / CFG_BM[pc.cfg]) * B_;
   return pol_.groupable(pc.gate, pc.up != 0, blocks, (pc.ntaps - 1) * pc.dil, pc.Cin);
 }
-void Engine::group_begin() {
+// The tiled kernel's grouped form: a plain conv (no gate, no ConvTranspose) that takes the tiled route anyway.
+bool Engine::can_group_tiled(const PackedConv& pc, int ncols) const {
+  return !pc.gate && pc.up == 0 && route(pc, ncols, EPI_STORE) == ROUTE_TILE && !(matrix_bf3_ && pc.wpb) &&
+         !pol_.one_tap_direct(pc.gate, false, pc.ntaps, pc.Cin) && (pc.ntaps - 1) * pc.dil <= 128;
+}
+static int tile_cfg_of(int cfg) { return cfg == CFG_C ? CFG_C : CFG_S; }      // non-gate configurations: 32 x 128 or 64 x 64 tiles
+void Engine::group_begin(bool tiled) {
   grouping_ = true;
+  group_tiled_ = tiled;
+  group_cfg_ = -1;
   group_.clear();
   group_flops_ = group_bytes_ = 0;
 }
 void Engine::group_end() {
   grouping_ = false;
   if (group_.empty()) return;
+  if (group_tiled_) {
+    group_tiled_ = false;
+    // longest kernel first: workgroups are dispatched in grid order (z slowest)
+    std::stable_sort(group_.begin(), group_.end(), [](const ConvP& a, const ConvP& b) { return a.ntaps > b.ntaps; });
+    ConvG g{};
+    int n = 0, rows = 0, xhalo = 0;
+    for (const ConvP& c : group_) {
+      g.c[n++] = c;
+      rows = std::max(rows, c.rows);
+      xhalo = std::max(xhalo, c.xhalo);
+    }
+    g.n = n;
+    g.B = B_;
+    const int cfg = group_cfg_, BM = CFG_BM[cfg], BN = CFG_BN[cfg];
+    const int HALO = xhalo <= 64 ? 64 : 128;
+    const size_t smem = (size_t)2 * KC * ((BN + HALO + 63) / 64 * 64) * sizeof(float);
+    const dim3 grid((group_ncols_ + BN - 1) / BN, (rows + BM - 1) / BM, n * B_);
+    int kh = -1;
+    if (prof_level_ >= 2) {
+      char nm[96];
+      snprintf(nm, sizeof(nm), "conv_mfma_group_kernel<%s,%d>", cfg == CFG_C ? "1,4,1,1,16" : "2,2,1,1,16", HALO);
+      kh = kbegin(krow(std::string(nm)), group_flops_, group_bytes_);
+    }
+    launch::conv_tile_group(cfg, HALO, grid, smem, ls_, g);
+    kend(kh);
+    group_.clear();
+    return;
+  }
   // 4 waves per workgroup: 32 / 64 KB of slabs, so 4 / 2 workgroups share a CU and the <= 3 x ~420 workgroups of a
   // group run in one or two rounds (8 waves: 64 / 128 KB, five rounds, slower than one launch per conv). The convs that
   // need the 128-column slab go in a launch of their own: two resident workgroups per CU carry ~420 of them, not 1260.
@@ -138,6 +174,19 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
                     (double)pc.rows * pc.Cin * pc.ntaps);
   }
   const long blocks = (long)((ncols + CFG_BN[cfg] - 1) / CFG_BN[cfg]) * (pc.mtiles * 32 / CFG_BM[cfg]) * B_;
+  if (grouping_ && group_tiled_) {
+    const int tc = tile_cfg_of(cfg);
+    if (!can_group_tiled(pc, ncols) || epi == EPI_CONVT || epi == EPI_GATE || group_.size() >= 3 ||
+        (!group_.empty() && (group_ncols_ != ncols || group_cfg_ != tc)))
+      throw std::runtime_error("internal: conv does not fit a grouped tiled launch");
+    group_cfg_ = tc;
+    p.tpb = 1;
+    group_.push_back(p);
+    group_ncols_ = ncols;
+    group_flops_ += kflops;
+    group_bytes_ += kbytes;
+    return;
+  }
   if (grouping_) {
     if (!can_group(pc, ncols) || epi == EPI_CONVT || epi == EPI_GATE || group_.size() >= 3 ||
         (!group_.empty() && group_ncols_ != ncols))

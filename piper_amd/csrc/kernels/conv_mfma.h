@@ -25,9 +25,7 @@ namespace pe {
 // second launch-bound argument = waves per SIMD the register allocation must leave room for: latency here is
 // hidden across workgroups (profiles/r01_ablation.txt), so small wave tiles are held to 128 / 168 registers
 template <int WM, int WN, int MT, int NT, int KS, bool GATE, int HALO>
-__global__ __launch_bounds__(256, (MT * NT == 1 ? ((HALO == 128 && WN == 4) ? 3 : 4) : ((GATE && MT * NT == 2) ? 3 : 2)))
-void conv_mfma_kernel(ConvP p) {
-  PE_KTRACE(11);
+__device__ __forceinline__ void conv_mfma_body(const ConvP& p, const int bx, const int by, const int b) {
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
   constexpr int NCOL = (BN + HALO + 63) / 64;    // staging columns per lane; (taps-1)*dilation <= HALO
   constexpr int KH = KC / 2;
@@ -37,15 +35,14 @@ void conv_mfma_kernel(ConvP p) {
   static_assert(!GATE || MT == 2, "gate epilogue pairs two M tiles");
   constexpr int XS = NCOL * 64;                   // LDS row stride (compile time: taps become immediates)
   PE_DYN_SMEM(float, xs);                         // 2 x [KC][XS]
-  const int b = blockIdx.z;
   const int L = p.lens[b] * p.len_mul;
   const int ncols = (p.epi == EPI_CONVT) ? L + 1 : L;
   // a workgroup walks p.tpb consecutive column tiles (1 by default, profiles/r01_tpb_sweep.txt)
-  const int tile0 = blockIdx.x * p.tpb;
+  const int tile0 = bx * p.tpb;
   const int ntile_all = (ncols + BN - 1) / BN;
   if (tile0 >= ntile_all) return;
   const int ntl = (ntile_all - tile0) < p.tpb ? (ntile_all - tile0) : p.tpb;
-  const int m0 = blockIdx.y * BM;
+  const int m0 = by * BM;
   const int tid = threadIdx.x, lane = tid & 63, wv = PE_UNIFORM(tid >> 6);
   const int wm = wv / WN, wn = wv % WN;
   const int l31 = lane & 31, lhi = lane >> 5;
@@ -185,6 +182,27 @@ void conv_mfma_kernel(ConvP p) {
           conv_store_tile(p, ef, b, (mtile0 + i) * 32, n0 + (wn * NT + j) * 32 + l31, lhi, L, ncols, acc[i][j]);
     }
   }
+}
+
+#define PE_CONV_MFMA_BOUNDS(MT, NT, WN, GATE, HALO) \
+  __launch_bounds__(256, (MT * NT == 1 ? ((HALO == 128 && WN == 4) ? 3 : 4) : ((GATE && MT * NT == 2) ? 3 : 2)))
+template <int WM, int WN, int MT, int NT, int KS, bool GATE, int HALO>
+__global__ PE_CONV_MFMA_BOUNDS(MT, NT, WN, GATE, HALO) void conv_mfma_kernel(ConvP p) {
+  PE_KTRACE(11);
+  conv_mfma_body<WM, WN, MT, NT, KS, GATE, HALO>(p, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+// Up to three INDEPENDENT convs of the same tile configuration in one launch (grid.z = conv x utterance): the sibling
+// resblocks of an MRF stage (models.py:356-363) read the same input, and a single one of them is a few workgroups per CU --
+// 834 tiles on 256 CUs are 3.26 per CU, so the CUs that draw a fourth tile set the launch time (81 % of the chip's
+// rate) -- while three of them together are ~10 per CU, dispatched longest kernel first. (The split-K form of the same
+// idea: conv_splitk_group_kernel.)
+template <int WM, int WN, int MT, int NT, int KS, int HALO>
+__global__ PE_CONV_MFMA_BOUNDS(MT, NT, WN, false, HALO) void conv_mfma_group_kernel(ConvG g) {
+  PE_KTRACE(11);
+  const int gi = PE_UNIFORM((int)blockIdx.z / g.B);
+  const ConvP& p = g.c[gi];
+  if ((int)blockIdx.y * (WM * MT * 32) >= p.rows) return;      // a sibling with fewer row blocks than the grid
+  conv_mfma_body<WM, WN, MT, NT, KS, false, HALO>(p, blockIdx.x, blockIdx.y, (int)blockIdx.z - gi * g.B);
 }
 
 }  // namespace pe

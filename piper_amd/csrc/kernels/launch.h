@@ -22,6 +22,8 @@ void conv_splitk(bool gate, int nw, dim3 grid, size_t smem, hipStream_t stream, 
 // half (gate only): half a 32-channel group per workgroup on six waves with the whole K range in flight (conv_splitk.h GT = 2)
 void conv_splitk16(bool gate, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p, bool half = false);
 void conv_group(bool wide, dim3 grid, size_t smem, hipStream_t stream, const ConvG& g);
+// the tiled kernel on up to three sibling convs of one tile configuration (conv_mfma.h: conv_mfma_group_kernel)
+void conv_tile_group(int cfg, int halo, dim3 grid, size_t smem, hipStream_t stream, const ConvG& g);
 void conv_group_sum(dim3 grid, size_t smem, hipStream_t stream, const ConvP& p);
 
 // ---- split-bf16 tiled conv GEMM (launch_bf3.cpp; opt-in matrix mode PIPER_HIP_MATRIX=bf16x3)
@@ -35,6 +37,7 @@ void embed(dim3 grid, hipStream_t stream, const int* ids, int ids_bs, const int*
            float* out, long o_bs, int o_cs, unsigned long long* rng);
 void attention(int dk, dim3 grid, size_t smem, hipStream_t stream, const AttnP& p);
 void attno(dim3 grid, size_t smem, hipStream_t stream, const AttnOP& p);        // attention + conv_o + LN, dk = 96 x 2 heads (attno.h)
+void attn4(dim3 grid, size_t smem, hipStream_t stream, const AttnOP& p);        // the same on 4-query workgroups (attn4.h)
 void layer_norm(dim3 grid, hipStream_t stream, const LnP& p);
 void dds_layer(int nchunks, dim3 grid, size_t smem, hipStream_t stream, const DdsP& p);
 void dds_layer4(dim3 grid, size_t smem, hipStream_t stream, const DdsP& p);      // 4-column form, 192 channels (dds4.h)

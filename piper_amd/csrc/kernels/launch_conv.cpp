@@ -14,6 +14,8 @@ void init_conv() {
 #define PE_K2(WM, WN, MT, NT, KS, G) (const void*)conv_mfma_kernel<WM, WN, MT, NT, KS, G, 64>, (const void*)conv_mfma_kernel<WM, WN, MT, NT, KS, G, 128>
   const void* ks[] = {PE_K2(1, 4, 1, 1, 16, false), PE_K2(2, 2, 1, 1, 16, false), PE_K2(1, 4, 2, 1, 16, true),
                       PE_K2(2, 2, 2, 1, 16, true),
+                      (const void*)conv_mfma_group_kernel<2, 2, 1, 1, 16, 64>, (const void*)conv_mfma_group_kernel<2, 2, 1, 1, 16, 128>,
+                      (const void*)conv_mfma_group_kernel<1, 4, 1, 1, 16, 64>, (const void*)conv_mfma_group_kernel<1, 4, 1, 1, 16, 128>,
                       (const void*)conv_splitk_kernel<2, true, 8, 3>, (const void*)conv_splitk_kernel<2, true, 4, 3>,
                       (const void*)conv_splitk_kernel<1, false, 8, 4>, (const void*)conv_splitk_kernel<1, false, 4, 4>,
                       (const void*)conv_splitk_kernel<2, true, 12, 2>, (const void*)conv_splitk_kernel<1, false, 12, 4>,
@@ -41,6 +43,17 @@ void conv_tile(int cfg, bool gate, int halo, dim3 grid, size_t smem, hipStream_t
     else PE_CONV_LAUNCH(2, 2, 1, 1, 16, false);
   }
 #undef PE_CONV_LAUNCH
+}
+
+// sibling convs of one tile configuration (non-gate: cfg 2 = 32 x 128 tiles, else 64 x 64) in one launch
+void conv_tile_group(int cfg, int halo, dim3 grid, size_t smem, hipStream_t stream, const ConvG& g) {
+  if (cfg == 2) {
+    if (halo == 64) PE_LAUNCH((conv_mfma_group_kernel<1, 4, 1, 1, 16, 64>), grid, dim3(256), smem, stream, g);
+    else PE_LAUNCH((conv_mfma_group_kernel<1, 4, 1, 1, 16, 128>), grid, dim3(256), smem, stream, g);
+  } else {
+    if (halo == 64) PE_LAUNCH((conv_mfma_group_kernel<2, 2, 1, 1, 16, 64>), grid, dim3(256), smem, stream, g);
+    else PE_LAUNCH((conv_mfma_group_kernel<2, 2, 1, 1, 16, 128>), grid, dim3(256), smem, stream, g);
+  }
 }
 
 void conv1x1(dim3 grid, hipStream_t stream, const ConvP& p) { PE_LAUNCH((conv1x1_kernel<1>), grid, dim3(256), 0, stream, p); }

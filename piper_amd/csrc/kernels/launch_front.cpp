@@ -3,6 +3,7 @@
 
 #include "attention.h"
 #include "attno.h"
+#include "attn4.h"
 #include "colchain.h"
 #include "dds.h"
 #include "dds4.h"
@@ -19,7 +20,7 @@ void init_front() {
 #ifndef PE_EMU
   const int lim = 160 * 1024;
   const void* ks[] = {(const void*)attn_kernel<0>, (const void*)attn_kernel<48>, (const void*)attn_kernel<96>,
-                      (const void*)attno_kernel<96>};
+                      (const void*)attno_kernel<96>, (const void*)attn4_kernel<96>};
   for (const void* k : ks) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
 #endif
 }
@@ -44,6 +45,10 @@ void attention(int dk, dim3 grid, size_t smem, hipStream_t stream, const AttnP& 
 
 void attno(dim3 grid, size_t smem, hipStream_t stream, const AttnOP& p) {
   PE_LAUNCH(attno_kernel<96>, grid, dim3(512), smem, stream, p);
+}
+
+void attn4(dim3 grid, size_t smem, hipStream_t stream, const AttnOP& p) {
+  PE_LAUNCH(attn4_kernel<96>, grid, dim3(256), smem, stream, p);
 }
 
 void layer_norm(dim3 grid, hipStream_t stream, const LnP& p) { PE_LAUNCH(ln_kernel, grid, dim3(256), 0, stream, p); }

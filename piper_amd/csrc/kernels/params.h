@@ -74,6 +74,8 @@ struct AttnOP {
   const float* wo16; const float* bo;       // conv_o in pack16 order, bias [H]
   const float* gamma; const float* beta;    // norm_layers_1
   float* x; long x_bs; int x_cs;            // residual in, LayerNorm output (in place)
+  const float* wo4;                         // attn4_kernel: conv_o in pack4 order; SP = round_up(max len, 64) + 4 there
+  int xcd;                                  // attn4_kernel: XCD-contiguous column tiles (col4.h c4_tile)
 };
 static constexpr int ATT_QB = 32;           // queries per workgroup (one MFMA tile)
 static constexpr int ATT_KCH = 64;          // keys staged per V chunk

@@ -23,11 +23,14 @@ struct LaunchPolicy {
   long wide_splitk = 1;       // 12-wave split-K workgroups: 0 off, 1 WN gate conv, 2 always (tests)
   long tpb = 0;               // tiled kernel: column tiles walked by one workgroup (0 = 1, the measured choice)
   long group_mrf = 1;         // sibling resblock convs of a wider one-utterance stage as grouped launches: 0 off, 2 without the K-concatenated last step
+  long group_tiled = 1;       // sibling resblock convs of a stage that runs the TILED kernel as grouped launches while one conv is only a few tiles per CU
   long colchain = 1;          // colchain_kernel / lngemm_kernel: 0 off, 1 by batch size, 2 always
   long col4 = 1;              // 4-column forms of the 192-channel chains: 0 off, 1 by batch size, 2 always
   long col4_maxc = 1024;      // ... up to this many ids per call (text encoder, duration predictor)
   long ffn = 1;               // encoder FFN as one launch (ffn_kernel) wherever the 4-column chains run
   long attno = 1;             // attention + conv_o + norm_layers_1 as one launch wherever the 4-column chains run
+  long attn4 = 1;             // ... on 4-query workgroups (attn4_kernel): 0 off, 1 up to attn4_maxc ids per call, 2 wherever attno applies
+  long attn4_maxc = 160;      // ids per call up to which attention runs on 4-query workgroups (each reads all of K and V: 4x attno's L2 traffic)
   long fuse_dp = 1;           // ConvFlow.pre / proj / spline fused into the DDSConv layer launches
   long spec = 1;              // speculative stage-B sizing: the whole utterance as one graph for <= spec_max_batch utterances
   long spec_expect = 1;       // speculative graphs planned for the expected frame counts (0: for the bucket capacity)
@@ -53,6 +56,7 @@ struct LaunchPolicy {
   static constexpr long ffn_max_cols = 2048;      // ffn_kernel's partial-output buffer is allocated for this many columns
   static constexpr int spec_max_batch = 4;        // utterances per call up to which stage B is sized speculatively
   static constexpr long group_max_blocks64 = 700; // grouped sibling launches: 64-column tiles of the stage up to which they pay
+  static constexpr long group_tiled_max_blocks = 2048;   // grouped TILED sibling launches: tile workgroups of one conv (8 per CU) up to which grouping pays
 
   struct Knob { const char* env; long LaunchPolicy::*field; long lo, hi; const char* doc; };
   static const Knob* knobs(int* n);
@@ -92,6 +96,7 @@ struct LaunchPolicy {
     return colchain && k1 == 192 && half == 96 && (colchain == 2 || cols <= (double)(frames ? colchain_max_frames : colchain_max_ids));
   }
   bool chain4(long cols, long limit = 0) const { return col4 && (col4 == 2 || cols <= (limit ? limit : col4_maxc)); }
+  bool attn4_cols(long cols) const { return attn4 == 2 || (attn4 == 1 && cols <= attn4_maxc); }
   bool chain4_frames(long cols) const { return chain4(cols, col4_max_frames); }
   bool chain_rs_front(long cols) const { return chain_rs && chain4_frames(cols); }
   // fused MRF stage
@@ -104,6 +109,11 @@ struct LaunchPolicy {
     return group_mrf && B == 1 && nk >= 2 && nk <= 3 && blocks64 < group_max_blocks64 && buffers_fit;
   }
   bool group_sum() const { return group_mrf != 2; }
+  // the tiled kernel's form of the same idea: one conv of the stage is 1..8 tiles per CU, so the CUs that draw one tile
+  // more than the rest set the launch time; three siblings in one launch even that out
+  bool group_stage_tiled(int nk, long tile_blocks, bool buffers_fit) const {
+    return group_tiled && nk >= 2 && nk <= 3 && tile_blocks <= group_tiled_max_blocks && buffers_fit;
+  }
   bool speculate(int B) const { return spec && !no_graph && B <= spec_max_batch; }
 };
 

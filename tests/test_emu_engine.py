@@ -382,9 +382,10 @@ def test_emulated_192_channel_small_call_kernels(emu_lib, monkeypatch, col4):
     eng.profile_enable(2)
     r = eng.synthesize_batch(ids, (0.0, 1.0, 0.8), noise_w=nw)
     names = {row["name"] for row in eng.profile()[5:] if row["launches"]}
-    # small calls: attention + conv_o + norm_layers_1 as one launch (attno_kernel); the 16-column forms keep two
-    assert ("attno_kernel<96>" if col4 == "1" else "attn_kernel<96>") in names
-    assert ("attn_kernel<96>" if col4 == "1" else "attno_kernel<96>") not in names
+    # small calls: attention + conv_o + norm_layers_1 as one launch (short calls like this one: on 4-query workgroups,
+    # attn4_kernel; longer ones attno_kernel); the 16-column forms keep two
+    assert ("attn4_kernel<96>" if col4 == "1" else "attn_kernel<96>") in names
+    assert not ({"attn_kernel<96>", "attno_kernel<96>"} if col4 == "1" else {"attno_kernel<96>", "attn4_kernel<96>"}) & names
     assert ({"colchain4_kernel<false>", "lngemm4_kernel", "dds_layer4_kernel", "ffn_kernel"} if col4 == "1" else
             {"colchain_kernel<6>", "lngemm_kernel<6>", "dds_layer16_kernel<6>"}) <= names
     assert not ({"colchain_kernel<6>", "lngemm_kernel<6>", "dds_layer16_kernel<6>"} if col4 == "1" else
@@ -498,24 +499,29 @@ def test_emulated_attention_conv_o_layernorm_in_one_launch(emu_lib, monkeypatch,
     ids = [W.synthetic_phoneme_ids(T, i, id_max=cfg.n_vocab - 1) for i, T in enumerate(lens)]
     nw = np.random.default_rng(5).standard_normal((len(lens), 2, max(lens))).astype(np.float32)
     res = {}
-    for on in ("0", "1"):
-        monkeypatch.setenv("PIPER_HIP_ATTNO", on)
+    # "4" = the same launch on 4-query workgroups (kernels/attn4.h: everything on the 4x4x1 MFMA, keys dealt to the waves in
+    # 32-key chunks), forced on at every length
+    for on in ("0", "1", "4"):
+        monkeypatch.setenv("PIPER_HIP_ATTNO", "0" if on == "0" else "1")
+        monkeypatch.setenv("PIPER_HIP_ATTN4", "2" if on == "4" else "0")
         eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
         eng.profile_enable(2)
         r = eng.synthesize_batch(ids, (0.0, 1.0, 0.8), noise_w=nw, sids=sids)
         names = {row["name"] for row in eng.profile()[5:] if row["launches"]}
         assert ("attno_kernel<96>" in names) == (on == "1") and ("attn_kernel<96>" in names) == (on == "0"), names
+        assert ("attn4_kernel<96>" in names) == (on == "4"), names
         res[on] = (r, eng.durations(), [eng.debug_tensor("x_enc", i) for i in range(len(lens))])
         eng.close()
     off = np.concatenate([[0], np.cumsum(lens)])
     for i, T in enumerate(lens):
         o = O.synthesize(w, cfg, ids[i], (0.0, 1.0, 0.8), nw[i], sid=None if sids is None else sids[i], keep=True)
-        for on in ("0", "1"):
+        for on in ("0", "1", "4"):
             r, durs, xenc = res[on]
             assert np.array_equal(durs[off[i]:off[i + 1]], o["durations"]), (on, i)
             assert np.max(np.abs(xenc[i] - np.asarray(o["x_enc"]).reshape(xenc[i].shape))) < 1e-5, (on, i)
             assert np.max(np.abs(r.audio[i] - o["audio"])) < 1e-5, (on, i)
         assert np.max(np.abs(res["0"][2][i] - res["1"][2][i])) < 1e-5
+        assert np.max(np.abs(res["0"][2][i] - res["4"][2][i])) < 1e-5
 
 
 @pytest.mark.parametrize("preset,lens", [("tiny", [7, 3, 1]), ("tiny-high", [5, 2])])
@@ -761,3 +767,31 @@ def test_no_kernel_reads_what_the_call_did_not_write(emu_lib, monkeypatch, prese
     o = O.synthesize(w, cfg, ids[0], scales, nw[0], nz[0], sid=None if sids is None else sids[0])
     assert np.all(np.isfinite(r1.audio[0])) and np.max(np.abs(r1.audio[0] - o["audio"])) < 1e-4
     eng.close()
+
+
+@pytest.mark.parametrize("preset,lens", [("tiny", [9, 5, 12]), ("tiny-high", [7, 11])])
+def test_emulated_grouped_tiled_sibling_convs(emu_lib, monkeypatch, preset, lens):
+    """conv_mfma_group_kernel (kernels/conv_mfma.h): step d of every sibling resblock of an MRF stage (models.py:356-363)
+    in ONE launch of the tiled kernel (grid.z = conv x utterance; each resblock keeps its own buffers, mrf_sum_kernel
+    sums them) -- the schedule the high voice's 128- / 64-channel stages take for one utterance -- against one launch per
+    conv (PIPER_HIP_GROUP_TILED=0) and the oracle; ResBlock1 and ResBlock2, a ragged batch, both halo classes."""
+    cfg = W.preset(preset)
+    w = W.synthetic_weights(cfg, 1234)
+    ids = [W.synthetic_phoneme_ids(T, 50 + i, id_max=cfg.n_vocab - 1) for i, T in enumerate(lens)]
+    nw, nz = _noise(cfg, len(lens), max(lens), 3)
+    scales = (0.5, 1.0, 0.8)
+    monkeypatch.setenv("PIPER_HIP_MRF", "0")             # (the tiny voices' stages would otherwise run fused)
+    out = {}
+    for on in ("0", "1"):
+        monkeypatch.setenv("PIPER_HIP_GROUP_TILED", on)
+        eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
+        eng.profile_enable(2)
+        r = eng.synthesize_batch(ids, scales, noise_w=nw, noise_z=nz)
+        names = {row["name"] for row in eng.profile()[5:] if row["launches"]}
+        assert any(n.startswith("conv_mfma_group_kernel<") for n in names) == (on == "1"), names
+        out[on] = r.audio
+        eng.close()
+    for i in range(len(lens)):
+        o = O.synthesize(w, cfg, ids[i], scales, nw[i], nz[i])
+        assert np.max(np.abs(out["1"][i] - o["audio"])) < 1e-5
+        assert np.max(np.abs(out["1"][i] - out["0"][i])) < 2e-6      # (the MRF mean is summed in another order)

@@ -638,18 +638,31 @@ def test_configs3_full_size_512_utterances_over_8_engines(monkeypatch):
     for e, t in enumerate(table):
         assert all(assign[u] == e for u in t), f"engine {e}: assignment differs from dist.shard_indices"
     assert len(r.pcm) == N and len(r.frames) == N
-    worst, checked = 0.0, 0
+    worst, checked, edge = 0.0, 0, []
     for e, t in enumerate(table):
         eng = grp.engine(e)
         durs = eng.durations().reshape(len(t), T)            # this engine's share of the call, in shard order
         res = eng.fetch(True, True)                          # float waveform + int16 of the share
+        flipped = set()
         for k, u in enumerate(t):
             nw = eng.debug_tensor("noise_w", k)
-            assert np.array_equal(durs[k], O.durations_only(wt, cfg, ids[u], SCALES, nw)), f"utterance {u}: durations"
+            od, ow = O.durations_only(wt, cfg, ids[u], SCALES, nw, return_w=True)
+            if not np.array_equal(durs[k], od):
+                # 65 536 ids: a value in front of the ceil that sits within a few ulp of an integer may land on the other
+                # side of it in the engine's summation order. Only THAT is tolerated: off by one, at a position whose
+                # oracle value is within 2e-5 (relative) of the integer -- and on a handful of ids at most.
+                bad = np.nonzero(durs[k] != od)[0]
+                for i in bad:
+                    near = abs(ow[i] - np.rint(ow[i])) <= 2e-5 * max(1.0, abs(ow[i]))
+                    assert abs(int(durs[k][i]) - int(od[i])) == 1 and near, \
+                        f"utterance {u} id {i}: duration {durs[k][i]} vs oracle {od[i]} (value in front of the ceil {ow[i]!r})"
+                    edge.append((u, int(i), float(ow[i])))
+                flipped.add(k)
             assert int(r.frames[u]) == max(int(durs[k].sum()), 1) == int(res.frames[k])
             assert np.array_equal(r.pcm[u], res.pcm[k]), f"utterance {u}: gathered out of order"
             assert np.array_equal(O.audio_float_to_int16(res.audio[k]), r.pcm[u]), f"utterance {u}: int16 not bit-exact"
-        for k in (0, len(t) - 1 - e):                        # two per shard, other slots in every shard
+        picks = [k for k in (0, len(t) - 1 - e, 1, 2) if k not in flipped][:2]
+        for k in picks:                                      # two per shard, other slots in every shard
             u = t[k]
             o = O.synthesize(wt, cfg, ids[u], SCALES, eng.debug_tensor("noise_w", k), eng.debug_tensor("noise_z", k))
             assert np.array_equal(durs[k], o["durations"])
@@ -661,6 +674,9 @@ def test_configs3_full_size_512_utterances_over_8_engines(monkeypatch):
             checked += 1
         eng.close()
     assert checked == 2 * NE
+    assert len(edge) <= 4, edge                              # (of 65 536 ids)
+    if edge:
+        print("ids whose value in front of the ceil sits on an integer (tolerated, off by one):", edge)
     # distinct utterances gave distinct audio (the gather did not duplicate a shard)
     assert len({(int(f), int(p[:2000].astype(np.int64).sum())) for f, p in zip(r.frames, r.pcm)}) > N * 0.95
     print("configs[3] full size: 512 utterances over 8 engines, worst |d audio| %.2e on %d oracle waveforms, call %.3f s"
@@ -723,14 +739,19 @@ def test_configs3_full_size_through_sharded_synthesizer_8_ranks(tmp_path):
     cfg, w = voice("medium")
     wt = O.to_torch(w)
     scales = (0.0, 1.0, 0.0)
+    edge = []
     for u in range(512):
         ids = W.synthetic_phoneme_ids(128, 5000 + u, id_max=129)
-        d = O.durations_only(wt, cfg, ids, scales)
-        assert np.array_equal(got["durations"][u], d), f"utterance {u}: durations"
-        assert got["pcm%d" % u].size == max(int(d.sum()), 1) * 256
-        if u % 32 == 5:
+        d, wv = O.durations_only(wt, cfg, ids, scales, return_w=True)
+        gd = got["durations"][u]
+        for i in np.nonzero(gd != d)[0]:                    # (see the group test: integer boundaries within a few ulp)
+            assert abs(int(gd[i]) - int(d[i])) == 1 and abs(wv[i] - np.rint(wv[i])) <= 2e-5 * max(1.0, abs(wv[i])), (u, i, wv[i])
+            edge.append((u, int(i)))
+        assert got["pcm%d" % u].size == max(int(gd.sum()), 1) * 256
+        if u % 32 == 5 and np.array_equal(gd, d):
             o = O.synthesize(wt, cfg, ids, scales)
             assert pcm_rms(got["pcm%d" % u], o["pcm"]) <= RMS_TOL, f"utterance {u}"
+    assert len(edge) <= 4, edge
 
 
 def test_engine_group_weight_broadcast_through_rccl(tmp_path):
