@@ -191,7 +191,9 @@ const char* pe_policy_describe(void);
  * utterances to the devices in longest-first order onto the least-loaded device (load = phoneme ids), runs the shards
  * concurrently and returns group-owned host views in the CALLER's order: sample_offsets / pcm / frames as in pe_result,
  * `audio` is NULL (fetch floats per engine if needed), infer_seconds = wall time of the whole call. The same device may
- * be listed more than once (two engines sharing a GPU). Not thread-safe: one call at a time per group. */
+ * be listed more than once (engines sharing a GPU): a call then COALESCES that device's utterances onto as few of its
+ * engines as 64-utterance shares need -- one batched call beats several single-utterance pipelines racing for the launch
+ * path -- and pe_group_assignment reports which engines ran. Not thread-safe: one call at a time per group. */
 typedef struct pe_group pe_group;
 int pe_group_create(const void* blob, size_t nbytes, const int32_t* devices, int32_t n_devices, pe_group** out);
 /* How the last pe_group_create on this thread moved the packed weights between devices: "rccl" (one ncclBroadcast on a
@@ -206,6 +208,24 @@ int pe_group_synthesize_batch(pe_group* g, const int64_t* ids, const int64_t* of
 /* which engine (index into the group) ran utterance i of the last call */
 int pe_group_assignment(pe_group* g, int32_t* engine_index, int64_t capacity);
 void pe_group_destroy(pe_group* g);
+
+/* Concurrent single-utterance requests as batched engine calls (dynamic batching). The reference serves one phrase at a
+ * time on one session (src/cpp/piper.cpp:549-582; its HTTP server, src/python_run/piper/http_server.py, one request at a
+ * time); a server on this engine has many caller threads, each with ONE utterance. An engine handle is not thread-safe and a
+ * B=1 pipeline leaves most of the chip idle, so: every thread calls pe_coalescer_synthesize (thread-safe, blocking); the
+ * thread that finds the engine free leads -- it takes every request queued at that moment with the same scales (up to
+ * max_batch; after waiting up to max_wait_us for stragglers, 0 = never wait) and runs them as ONE pe_synthesize_batch-style
+ * call while later arrivals queue up for the next leader. Each request gets exactly what its own B=1 call computes: its
+ * own noise draws, and int16 PCM peak-normalised over ITS waveform (piper.cpp:410-431) -- the batched kernels treat
+ * utterances independently. *pcm is malloc'ed for the caller (pe_free). *batch_size = utterances of the engine call that
+ * served the request. pe_coalescer_stats: engine calls / requests so far. The engine must outlive the coalescer and must
+ * not be used directly while requests are in flight. */
+typedef struct pe_coalescer pe_coalescer;
+int pe_coalescer_create(pe_engine* e, int32_t max_batch, int32_t max_wait_us, pe_coalescer** out);
+int pe_coalescer_synthesize(pe_coalescer* c, const int64_t* ids, int64_t n_ids, const float scales[3], int64_t sid,
+                            int16_t** pcm, int64_t* n_samples, int32_t* frames, double* infer_seconds, int32_t* batch_size);
+int pe_coalescer_stats(pe_coalescer* c, int64_t* engine_calls, int64_t* requests);
+void pe_coalescer_destroy(pe_coalescer* c);
 
 const char* pe_last_error(void);
 void pe_destroy(pe_engine* e);

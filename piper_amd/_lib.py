@@ -20,6 +20,7 @@ SYMBOLS = [
     "pe_stream", "pe_debug_tensor", "pe_debug_randn", "pe_rng_calls", "pe_run_launches", "pe_speculation_stats", "pe_warmup", "pe_graph_stats", "pe_xcc_pattern", "pe_device_pci_bus_id", "pe_policy_describe", "pe_last_error", "pe_destroy",
     "pe_group_create", "pe_group_broadcast_path", "pe_group_size", "pe_group_engine", "pe_group_synthesize_batch", "pe_group_assignment",
     "pe_group_destroy",
+    "pe_coalescer_create", "pe_coalescer_synthesize", "pe_coalescer_stats", "pe_coalescer_destroy",
 ]
 
 
@@ -97,6 +98,12 @@ def bind(path: str) -> C.CDLL:
     lib.pe_group_assignment.argtypes = [vp, i32p, C.c_int64]
     lib.pe_group_destroy.argtypes = [vp]
     lib.pe_group_destroy.restype = None
+    lib.pe_coalescer_create.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(vp)]
+    lib.pe_coalescer_synthesize.argtypes = [vp, i64p, C.c_int64, f32p, C.c_int64, C.POINTER(C.POINTER(C.c_int16)), i64p,
+                                            i32p, C.POINTER(C.c_double), i32p]
+    lib.pe_coalescer_stats.argtypes = [vp, i64p, i64p]
+    lib.pe_coalescer_destroy.argtypes = [vp]
+    lib.pe_coalescer_destroy.restype = None
     lib.pe_destroy.argtypes = [vp]
     lib.pe_destroy.restype = None
     return lib

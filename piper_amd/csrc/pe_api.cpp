@@ -366,6 +366,7 @@ struct pe_group {
   std::vector<int64_t> sample_off;
   std::vector<int16_t> pcm;
   std::vector<int32_t> frames;
+  bool coalesce = true;                   // PIPER_HIP_GROUP_COALESCE (read at pe_group_create): 0 = every engine takes part in every call
 };
 
 namespace {
@@ -506,6 +507,7 @@ int pe_group_create(const void* blob, size_t nbytes, const int32_t* devices, int
     }
     const size_t header = pe::blob_header_bytes(blob, nbytes);
     g = new pe_group();
+    if (const char* t = getenv("PIPER_HIP_GROUP_COALESCE")) g->coalesce = !(t[0] == '0' && !t[1]);
     g->device.assign(devices, devices + n_devices);
     g->arena.assign(n_devices, nullptr);
     for (int i = 0; i < n_devices; ++i) {
@@ -614,7 +616,33 @@ int pe_group_synthesize_batch(pe_group* g, const int64_t* ids, const int64_t* of
       if (T > 8192) throw std::runtime_error("phoneme id sequence longer than 8192");
     }
     const auto t0 = std::chrono::steady_clock::now();
-    const std::vector<std::vector<int>> shard = lpt(offsets, batch, n);
+    // Coalesce instead of stream: engines that share a GPU do not add throughput for small shares -- N B=1 pipelines racing
+    // for the HIP runtime's launch path reach 1.5x of one (profiles/r04_notes.md) while ONE call of N utterances runs the
+    // batched kernels (8 x 128 ids: 2.1x) -- so a device's utterances go to as few of its engines as 64-utterance shares
+    // need; engines on distinct devices always all take part. `active` = the engines the deal runs over.
+    std::vector<int> active;
+    {
+      std::vector<int> seen_dev;
+      for (int i = 0; i < n; ++i) {
+        const int d = g->device[i];
+        if (std::find(seen_dev.begin(), seen_dev.end(), d) != seen_dev.end()) continue;
+        seen_dev.push_back(d);
+        std::vector<int> on_d;
+        for (int k = 0; k < n; ++k)
+          if (g->device[k] == d) on_d.push_back(k);
+        const long share = ((long)batch * (long)on_d.size() + n - 1) / n;        // utterances this device will see
+        const int want = g->coalesce ? (int)std::min<long>((long)on_d.size(), std::max<long>(1, (share + 63) / 64)) : (int)on_d.size();
+        for (int k = 0; k < want; ++k) active.push_back(on_d[k]);
+      }
+      std::sort(active.begin(), active.end());
+    }
+    const int na = (int)active.size();
+    if ((int64_t)batch > (int64_t)4096 * na) throw std::runtime_error("batch size must be in [1, 4096 per engine]");
+    std::vector<std::vector<int>> shard(n);
+    {
+      std::vector<std::vector<int>> sa = lpt(offsets, batch, na);
+      for (int k = 0; k < na; ++k) shard[active[k]] = std::move(sa[k]);
+    }
     g->assign.assign(batch, 0);
     struct Work {
       std::vector<int64_t> ids, off, sids;
@@ -696,6 +724,151 @@ int pe_group_synthesize_batch(pe_group* g, const int64_t* ids, const int64_t* of
       result->frames = g->frames.data();
       result->infer_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     }
+  });
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// pe_coalescer_*: concurrent single-utterance requests of many caller threads as batched engine calls (include/piper_hip.h)
+// ---------------------------------------------------------------------------------------------------------------------
+}  // extern "C"
+
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+
+struct pe_coalescer {
+  struct Req {
+    const int64_t* ids; int64_t n; float scales[3]; int64_t sid;
+    int16_t* pcm = nullptr; int64_t samples = 0; int32_t frames = 0; double secs = 0; int32_t batch = 0;
+    int state = 0;            // 0 queued, 1 taken by a leader, 2 done, 3 failed
+    std::string err;
+  };
+  pe_engine* eng;
+  int max_batch, max_wait_us;
+  std::mutex m;
+  std::condition_variable cv;
+  std::deque<Req*> q;
+  bool busy = false;          // a leader is inside the engine
+  int64_t calls = 0, requests = 0;
+};
+
+extern "C" {
+
+int pe_coalescer_create(pe_engine* e, int32_t max_batch, int32_t max_wait_us, pe_coalescer** out) {
+  return guard([&] {
+    if (!e || !out) throw std::runtime_error("null argument");
+    if (max_batch < 1 || max_batch > 4096) throw std::runtime_error("batch size must be in [1, 4096]");
+    auto* c = new pe_coalescer();
+    c->eng = e;
+    c->max_batch = max_batch;
+    c->max_wait_us = max_wait_us < 0 ? 0 : max_wait_us;
+    *out = c;
+  });
+}
+
+void pe_coalescer_destroy(pe_coalescer* c) { delete c; }
+
+int pe_coalescer_stats(pe_coalescer* c, int64_t* engine_calls, int64_t* requests) {
+  return guard([&] {
+    if (!c) throw std::runtime_error("null argument");
+    std::lock_guard<std::mutex> lk(c->m);
+    if (engine_calls) *engine_calls = c->calls;
+    if (requests) *requests = c->requests;
+  });
+}
+
+int pe_coalescer_synthesize(pe_coalescer* c, const int64_t* ids, int64_t n_ids, const float scales[3], int64_t sid,
+                            int16_t** pcm, int64_t* n_samples, int32_t* frames, double* infer_seconds, int32_t* batch_size) {
+  return guard([&] {
+    if (!c || !ids || !scales || !pcm || !n_samples) throw std::runtime_error("null argument");
+    if (n_ids <= 0) throw std::runtime_error("empty phoneme id sequence");
+    if (n_ids > 8192) throw std::runtime_error("phoneme id sequence longer than 8192");
+    pe_coalescer::Req me;
+    me.ids = ids; me.n = n_ids; me.sid = sid;
+    memcpy(me.scales, scales, sizeof(me.scales));
+    std::unique_lock<std::mutex> lk(c->m);
+    c->q.push_back(&me);
+    ++c->requests;
+    c->cv.notify_all();                         // (a leader collecting its batch counts the queue)
+    // follower: wait until a leader has served this request, or until nobody leads and it can lead itself
+    while (me.state < 2) {
+      if (me.state == 0 && !c->busy) {
+        // ---- leader: optionally give concurrent callers max_wait_us to arrive, then take what is queued (requests with
+        // the leader's scales, up to max_batch) and run it as ONE engine call
+        c->busy = true;
+        if (c->max_wait_us > 0) {
+          const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(c->max_wait_us);
+          c->cv.wait_until(lk, until, [&] { return (int)c->q.size() >= c->max_batch; });
+        }
+        std::vector<pe_coalescer::Req*> take;
+        for (auto it = c->q.begin(); it != c->q.end() && (int)take.size() < c->max_batch;) {
+          pe_coalescer::Req* r = *it;
+          if (r == &me || !memcmp(r->scales, me.scales, sizeof(me.scales))) {
+            r->state = 1;
+            take.push_back(r);
+            it = c->q.erase(it);
+          } else {
+            ++it;
+          }
+        }
+        ++c->calls;
+        lk.unlock();
+        std::string err;
+        try {
+          std::vector<int64_t> cat, off{0}, sids;
+          for (auto* r : take) {
+            cat.insert(cat.end(), r->ids, r->ids + r->n);
+            off.push_back((int64_t)cat.size());
+            sids.push_back(r->sid < 0 ? 0 : r->sid);
+          }
+          const auto t0 = std::chrono::steady_clock::now();
+          pe::Engine* e = c->eng->eng;
+          e->upload(cat.data(), off.data(), (int)take.size(), me.scales, sids.data(), nullptr);
+          e->run();
+          e->download(false, true);
+          const double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+          const auto& so = e->sample_offsets();
+          const int16_t* all = e->pcm_host();
+          const auto& fr = e->frames_host();
+          for (size_t k = 0; k < take.size(); ++k) {
+            pe_coalescer::Req* r = take[k];
+            r->samples = so[k + 1] - so[k];
+            r->pcm = static_cast<int16_t*>(malloc(std::max<size_t>(1, (size_t)r->samples) * sizeof(int16_t)));
+            if (!r->pcm) throw std::runtime_error("out of memory");
+            memcpy(r->pcm, all + so[k], (size_t)r->samples * sizeof(int16_t));
+            r->frames = fr[k];
+            r->secs = secs;
+            r->batch = (int32_t)take.size();
+          }
+        } catch (const std::exception& ex) {
+          err = ex.what();
+        } catch (...) {
+          err = "unknown error";
+        }
+        lk.lock();
+        for (auto* r : take) {
+          if (!err.empty()) {
+            free(r->pcm);
+            r->pcm = nullptr;
+            r->err = err;
+            r->state = 3;
+          } else {
+            r->state = 2;
+          }
+        }
+        c->busy = false;
+        c->cv.notify_all();                     // followers pick their results up; one of the queued becomes the next leader
+        continue;
+      }
+      c->cv.wait(lk);
+    }
+    lk.unlock();
+    if (me.state == 3) throw std::runtime_error(me.err);
+    *pcm = me.pcm;
+    *n_samples = me.samples;
+    if (frames) *frames = me.frames;
+    if (infer_seconds) *infer_seconds = me.secs;
+    if (batch_size) *batch_size = me.batch;
   });
 }
 

