@@ -186,3 +186,212 @@ class Model:
     def float_data(self):
         for t in self.inits:
             t.to_float_data()
+
+
+# ---- round 5: what onnx-simplifier / torch-1.x exports leave behind --------------------------------
+def _attr_ints(name: str, values) -> bytes:
+    """AttributeProto {name, ints, type = INTS}"""
+    f = [(1, 2, name.encode())] + [(8, 0, int(v) & 0xFFFFFFFFFFFFFFFF) for v in values] + [(20, 0, 7)]
+    return serialize(f)
+
+
+def _int64_tensor(name: str, values) -> "Tensor":
+    t = Tensor(serialize([(1, 0, len(values)), (2, 0, 7), (8, 2, name.encode()),
+                          (9, 2, struct.pack("<%dq" % len(values), *values))]))
+    return t
+
+
+def _dims(t: "Tensor"):
+    out = []
+    for f, wt, v in t.fields:
+        if f == 1:
+            if wt == 0:
+                out.append(v)
+            else:
+                i = 0
+                while i < len(v):
+                    x, i = _varint(v, i)
+                    out.append(x)
+    return out
+
+
+def _set_dims(t: "Tensor", dims):
+    t.fields = [(f, wt, v) for f, wt, v in t.fields if f != 1]
+    t.fields = [(1, 0, int(d)) for d in dims] + t.fields
+
+
+def _node_op(n) -> str:
+    v = _get(n, 4)
+    return v[0].decode() if v else ""
+
+
+class Model(Model):                                                      # noqa: F811 -- extends the class above
+    def _rewire(self, old: str, new: str, skip=()):
+        for k, n in enumerate(self.nodes):
+            if k in skip:
+                continue
+            for i, (f, wt, v) in enumerate(n):
+                if f == 1 and wt == 2 and v.decode() == old:
+                    n[i] = (f, wt, new.encode())
+
+    def identity_shared(self, every: int = 2):
+        """Every `every`-th initialiser is consumed through an Identity node (how exporters share one tensor between
+        modules; onnx-simplifier keeps them when the tensor has several readers)."""
+        new_nodes = []
+        for k, t in enumerate(self.inits):
+            if k % every:
+                continue
+            alias = t.name + "__id"
+            self._rewire(t.name, alias)
+            new_nodes.append([(1, 2, t.name.encode()), (2, 2, alias.encode()), (4, 2, b"Identity")])
+        self.nodes = new_nodes + self.nodes
+        return len(new_nodes)
+
+    def unsqueeze_k1_weights(self, axes_as_input: bool = True):
+        """Conv weights [out, in, 1] stored as matrices [out, in] with an Unsqueeze in front of the conv -- axes as an
+        int64 input (opset >= 13) or as an attribute (older opsets)."""
+        new_nodes, new_inits, n = [], [], 0
+        for t in list(self.inits):
+            d = _dims(t)
+            if t.dtype != 1 or len(d) != 3 or d[2] != 1 or d[0] == 1:
+                continue
+            _set_dims(t, d[:2])
+            alias = t.name + "__u"
+            self._rewire(t.name, alias)
+            if axes_as_input:
+                ax = _int64_tensor(t.name + "__axes", [2])
+                new_inits.append(ax)
+                new_nodes.append([(1, 2, t.name.encode()), (1, 2, ax.name.encode()), (2, 2, alias.encode()), (4, 2, b"Unsqueeze")])
+            else:
+                new_nodes.append([(1, 2, t.name.encode()), (2, 2, alias.encode()), (4, 2, b"Unsqueeze"),
+                                  (5, 2, _attr_ints("axes", [2]))])
+            n += 1
+        self.inits += new_inits
+        self.nodes = new_nodes + self.nodes
+        return n
+
+    def transpose_conv_weights(self, every: int = 2):
+        """Conv weights with k > 1 stored as [in, out, k] with a Transpose(perm = 1, 0, 2) in front of the conv."""
+        import numpy as np
+        new_nodes, n, k = [], 0, 0
+        for t in self.inits:
+            d = _dims(t)
+            raw = _get(t.fields, 9)
+            if t.dtype != 1 or len(d) != 3 or d[2] <= 1 or d[0] == 1 or not raw:
+                continue
+            k += 1
+            if k % every:
+                continue
+            a = np.frombuffer(raw[0], dtype="<f4").reshape(d).transpose(1, 0, 2)
+            t.fields = [(f, wt, v) for f, wt, v in t.fields if f != 9] + [(9, 2, np.ascontiguousarray(a).tobytes())]
+            _set_dims(t, [d[1], d[0], d[2]])
+            alias = t.name + "__t"
+            self._rewire(t.name, alias)
+            new_nodes.append([(1, 2, t.name.encode()), (2, 2, alias.encode()), (4, 2, b"Transpose"),
+                              (5, 2, _attr_ints("perm", [1, 0, 2]))])
+            n += 1
+        self.nodes = new_nodes + self.nodes
+        return n
+
+    def reshape_biases(self):
+        """1-D conv biases stored as [1, C] with a Squeeze(axes = 0) (input form) in front of their consumer."""
+        new_nodes, new_inits, n = [], [], 0
+        conv_bias = set()
+        for nd in self.nodes:
+            if _node_op(nd) in ("Conv", "ConvTranspose"):
+                ins = [v.decode() for f, wt, v in nd if f == 1 and wt == 2]
+                if len(ins) > 2:
+                    conv_bias.add(ins[2])
+        ax = _int64_tensor("squeeze_axes_0", [0])
+        for t in self.inits:
+            d = _dims(t)
+            if t.name in conv_bias and t.dtype == 1 and len(d) == 1:
+                _set_dims(t, [1, d[0]])
+                alias = t.name + "__s"
+                self._rewire(t.name, alias)
+                new_nodes.append([(1, 2, t.name.encode()), (1, 2, ax.name.encode()), (2, 2, alias.encode()), (4, 2, b"Squeeze")])
+                n += 1
+        if n:
+            self.inits.append(ax)
+        self.nodes = new_nodes + self.nodes
+        return n
+
+    def make_external(self, index: int = 0) -> str:
+        """Initialiser `index` (among the float ones) points at another file (data_location = EXTERNAL + external_data
+        entries) and carries no payload: models > 2 GB and some tools store weights that way."""
+        fl = [t for t in self.inits if t.dtype == 1 and _get(t.fields, 9)]
+        t = fl[index % len(fl)]
+        entry = lambda k, v: serialize([(1, 2, k.encode()), (2, 2, v.encode())])       # noqa: E731
+        t.fields = [(f, wt, v) for f, wt, v in t.fields if f != 9] + \
+            [(13, 2, entry("location", "weights.bin")), (13, 2, entry("offset", "0")), (14, 0, 1)]
+        return t.name
+
+    def axes_inputs_to_attributes(self) -> int:
+        """Squeeze / Unsqueeze / Split / ReduceSum nodes in the opset >= 13 form (axes / split as an int64 INPUT) rewritten
+        to the older attribute form -- what a file exported at a lower opset (or down-converted) looks like."""
+        by_name = {t.name: t for t in self.inits}
+        consts = {}
+        for nd in self.nodes:                       # int64 Constant nodes
+            if _node_op(nd) == "Constant":
+                outs = [v.decode() for f, wt, v in nd if f == 2 and wt == 2]
+                for f, wt, v in nd:
+                    if f == 5 and wt == 2:
+                        a = parse(v)
+                        tt = _get(a, 5)
+                        if tt and outs:
+                            consts[outs[0]] = Tensor(tt[0])
+        n = 0
+        for nd in self.nodes:
+            op = _node_op(nd)
+            if op not in ("Squeeze", "Unsqueeze", "Split", "ReduceSum"):
+                continue
+            ins = [(i, v.decode()) for i, (f, wt, v) in enumerate(nd) if f == 1 and wt == 2]
+            if len(ins) < 2:
+                continue
+            pos, name = ins[1]
+            t = by_name.get(name) or consts.get(name)
+            if t is None or t.dtype != 7:
+                continue
+            raw = _get(t.fields, 9)
+            if not raw:
+                continue
+            vals = struct.unpack("<%dq" % (len(raw[0]) // 8), raw[0])
+            del nd[pos]
+            nd.append((5, 2, _attr_ints("split" if op == "Split" else "axes", vals)))
+            n += 1
+        return n
+
+    def shuffle_nodes(self, seed: int, keep_conv_order: bool = False):
+        """Another valid topological order of the graph (ONNX requires no particular one). keep_conv_order: the
+        convolutions other than an attention layer's q / k / v keep their relative order (only the element-wise glue and
+        the parallel q / k / v branches move)."""
+        import random
+        rng = random.Random(seed)
+        outs = [[v.decode() for f, wt, v in nd if f == 2 and wt == 2] for nd in self.nodes]
+        ins = [[v.decode() for f, wt, v in nd if f == 1 and wt == 2 and v] for nd in self.nodes]
+        producer = {o: i for i, os_ in enumerate(outs) for o in os_}
+        deps = [set(producer[x] for x in ins[i] if x in producer) for i in range(len(self.nodes))]
+        is_conv = [_node_op(nd) in ("Conv", "ConvTranspose") for nd in self.nodes]
+        free_conv = set()
+        if keep_conv_order:
+            # q / k / v: three consecutive convs (in file order) that read the same input value
+            cidx = [i for i, c in enumerate(is_conv) if c]
+            for a, b, c in zip(cidx, cidx[1:], cidx[2:]):
+                if ins[a][:1] == ins[b][:1] == ins[c][:1]:
+                    free_conv.update((a, b, c))
+        placed, order, ready = set(), [], []
+        remaining = set(range(len(self.nodes)))
+        next_conv = [i for i, c in enumerate(is_conv) if c and i not in free_conv]
+        while remaining:
+            ready = [i for i in remaining if deps[i] <= placed]
+            if keep_conv_order:
+                gate = next_conv[0] if next_conv else None
+                ready = [i for i in ready if not is_conv[i] or i in free_conv or i == gate]
+            i = rng.choice(sorted(ready))
+            order.append(i)
+            placed.add(i)
+            remaining.discard(i)
+            if next_conv and i == next_conv[0]:
+                next_conv.pop(0)
+        self.nodes = [self.nodes[i] for i in order]
+        return order

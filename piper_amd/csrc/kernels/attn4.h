@@ -33,6 +33,7 @@ __global__ __launch_bounds__(256) void attn4_kernel(AttnOP p) {
   static_assert(H == C4_H && DK % 16 == 0, "compiled for the 192-channel voices (two heads of 96)");
   PE_DYN_SMEM(float, sm);
   const int b = blockIdx.y;
+  PE_STAMP(0, 0);
   const int T = p.lens[b];
   const int i0 = c4_tile(blockIdx.x, gridDim.x, p.xcd) * NC;
   if (i0 >= T) return;
@@ -44,7 +45,8 @@ __global__ __launch_bounds__(256) void attn4_kernel(AttnOP p) {
   float* RK = Qs + NH * NC * QS;                   // [NREL][DK]
   float* RV = RK + NREL * DK;                      // [NREL][DK]
   float* BP = RV + NREL * DK;                      // [3 channel slices][NH * 4 * NREL] relative-key partial logits
-  float* YT = BP + 3 * NH * NC * NREL;             // [4][KS1]: attention output of both heads = conv_o's B operand
+  float* BV = BP + 3 * NH * NC * NREL;             // [NH * 4][12] probabilities on the relative-value band, 0 outside the utterance
+  float* YT = BV + NH * NC * 12;                   // [4][KS1]: attention output of both heads = conv_o's B operand
   float* P = YT + NC * KS1;                        // [4 waves][192][4]
   float* red = P + 4 * C4_H * NC;                  // [2][4][4]
   const float* qb = p.qkv + (long)b * p.q_bs;
@@ -57,12 +59,13 @@ __global__ __launch_bounds__(256) void attn4_kernel(AttnOP p) {
   // ---- requests that depend on nothing computed here, in the order they are waited for: Q + the relative tables, this
   // wave's first K unit, its first V chunk
   float kf[DK];
-  auto load_k = [&](int u) {                       // A[row = key][k = channel]: K[head][d][64 kb + lane]
+  auto load_k_half = [&](int u, int half) {        // A[row = key][k = channel]: K[head][d][64 kb + lane]
     const int h = u & 1, kbk = u >> 1, j = kbk * 64 + lane;
     const int o = (kbk < nkb && j < T) ? (h * DK) * p.q_cs + j : 0x3fffffff;
 #pragma unroll
-    for (int d = 0; d < DK; ++d) kf[d] = pe_row_load_so(kd, o, d * p.q_cs);
+    for (int d = 0; d < DK / 2; ++d) kf[half * (DK / 2) + d] = pe_row_load_so(kd, o, (half * (DK / 2) + d) * p.q_cs);
   };
+  auto load_k = [&](int u) { load_k_half(u, 0); load_k_half(u, 1); };
   f32x4 vf[NVT][8];
   auto load_v = [&](int kc) {                      // A[row = channel 64 m + lane][k = key]: four keys per 16-byte load
 #pragma unroll
@@ -86,10 +89,12 @@ __global__ __launch_bounds__(256) void attn4_kernel(AttnOP p) {
       rk[u] = pe_row_load(rkd, tid + 256 * u);
       rv[u] = pe_row_load(rvd, tid + 256 * u);
     }
+    // The memory counter holds 63 loads: a wait for "the first 11 of 131" is really a wait until all but 62 have returned.
+    // So only HALF of the K fragments go out in front of the LDS stores of Q and the tables (the stores then wait for
+    // exactly those 11 loads), the rest of K and the V chunk behind them (phase stamps: 4.4 us to the first barrier with
+    // everything in front, profiles/r05_notes.md).
     PE_SCHED_FENCE();
-    load_k(wv);
-    PE_SCHED_FENCE();
-    load_v(wv);
+    load_k_half(wv, 0);
     PE_SCHED_FENCE();
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
@@ -101,8 +106,14 @@ __global__ __launch_bounds__(256) void attn4_kernel(AttnOP p) {
       const int e = tid + 256 * u;
       if (e < NREL * DK) { RK[e] = e < nrel * DK ? rk[u] : 0.f; RV[e] = e < nrel * DK ? rv[u] : 0.f; }
     }
+    PE_SCHED_FENCE();
+    load_k_half(wv, 1);
+    PE_SCHED_FENCE();
+    load_v(wv);
+    PE_SCHED_FENCE();
   }
   __syncthreads();
+  PE_STAMP(0, 1);
 
   // ---- 1. score units of this wave; relative-key partial logits on the VALU (216 threads: (head, query, offset) x 3 slices)
   for (int u = wv; u < 2 * nkb; u += 4) {
@@ -121,6 +132,7 @@ __global__ __launch_bounds__(256) void attn4_kernel(AttnOP p) {
     // D[r] of lane l = S[key 64 kb + 4 (l >> 2) + r][query l & 3]: four consecutive keys of one row
     *reinterpret_cast<f32x4*>(Sc + (h * NC + l3) * SP + 64 * kbk + 4 * lb) = acc;
   }
+  if (tid < NH * NC * 12) BV[tid] = 0.f;            // band slots outside the utterance stay 0 (softmax fills the others)
   if (tid < 3 * NH * NC * NREL) {
     const int sl = tid / (NH * NC * NREL), it = tid - sl * (NH * NC * NREL);
     const int hq = it / NREL, r = it - hq * NREL;
@@ -151,7 +163,9 @@ __global__ __launch_bounds__(256) void attn4_kernel(AttnOP p) {
     PE_SCHED_FENCE();
     col_gemm4_fetch<H>(gw, p.wo4, C4_NT, wv, lane);
   }
+  PE_STAMP(0, 2);
   __syncthreads();
+  PE_STAMP(0, 3);
 
   // ---- 2. relative-key band + softmax over the valid keys: row = tid >> 5 (head, query), 32 lanes per row
   {
@@ -187,6 +201,8 @@ __global__ __launch_bounds__(256) void attn4_kernel(AttnOP p) {
       for (int k = 0; k < 4; ++k) {
         const int j = sj + 32 * k;
         if (j < Tpad) Sr[j] = ev[k] * inv;
+        const int r = j - jlo;
+        if (j < T && r >= 0 && r < nrel) BV[row * 12 + r] = ev[k] * inv;
       }
     } else {
       float mx = -3.0e38f;
@@ -204,10 +220,16 @@ __global__ __launch_bounds__(256) void attn4_kernel(AttnOP p) {
       }
       for (int m = 16; m >= 1; m >>= 1) sum += __shfl_xor(sum, m);
       const float inv = 1.f / sum;
-      for (int j = sj; j < Tpad; j += 32) Sr[j] = (j < T) ? Sr[j] * inv : 0.f;
+      for (int j = sj; j < Tpad; j += 32) {
+        const float pv = (j < T) ? Sr[j] * inv : 0.f;
+        Sr[j] = pv;
+        const int r = j - jlo;
+        if (j < T && r >= 0 && r < nrel) BV[row * 12 + r] = pv;
+      }
     }
   }
   __syncthreads();
+  PE_STAMP(0, 4);
 
   // ---- 3. O^T partial tiles of this wave's key chunks (every wave writes its tile: zeros without a chunk)
   {
@@ -242,23 +264,23 @@ __global__ __launch_bounds__(256) void attn4_kernel(AttnOP p) {
       for (int r = 0; r < 4; ++r) P[((wv * C4_NT + m) * 64 + 4 * lb + r) * 4 + l3] = acc[m][r];
   }
   __syncthreads();
+  PE_STAMP(0, 5);
   // ---- the four partial tiles + the relative-value band -> YT[col][channel] (attentions.py:255-262)
 #pragma unroll
   for (int k = 0; k < NVT; ++k) {
     const int c = rl + 64 * k, h = c >= DK ? 1 : 0, d = c - h * DK;
     float o = col_gemm4_get(P, c, col);
-    const float* Sr = Sc + (h * NC + col) * SP;
-    const int jlo = t - p.window;
-    for (int r = 0; r < nrel; ++r) {
-      const int j = jlo + r;
-      if (j >= 0 && j < T) o = fmaf(Sr[j], RV[r * DK + d], o);
-    }
+    const float* bv = BV + (h * NC + col) * 12;      // (rows of RV beyond the window are zero)
+#pragma unroll
+    for (int r = 0; r < NREL; ++r) o = fmaf(bv[r], RV[r * DK + d], o);
     YT[col * KS1 + c] = ok ? o : 0.f;
   }
   __syncthreads();
+  PE_STAMP(0, 6);
   // ---- 4. conv_o + residual + norm_layers_1 (colchain4_kernel mode 0)
   col_gemm4_run<H>(gw, YT, P, wv, lane);
   __syncthreads();
+  PE_STAMP(0, 7);
   int red_flip = 0;
   auto col_sum = [&](float x) -> float { return pe_col_sum4(x, red, red_flip, wv, lane, col); };
   float v[NVT];
@@ -280,6 +302,7 @@ __global__ __launch_bounds__(256) void attn4_kernel(AttnOP p) {
     const int c = rl + 64 * k;
     ob[(long)c * p.x_cs + t] = (v[k] - mean) * rstd * gg[k] + bb[k];
   }
+  PE_STAMP(0, 8);
 }
 
 }  // namespace pe

@@ -10,11 +10,14 @@
 //   flow: (pre [cond] (in res_skip)* post)* | dec: conv_pre [cond] (ConvTranspose conv*)* conv_post
 // with shapes cross-checked; LayerNorm gains, relative-position embeddings, the embeddings and the
 // ElementwiseAffine pair are found by how the graph consumes them.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <fstream>
 #include <map>
+#include <memory>
 #include <set>
 #include <stdexcept>
 
@@ -68,7 +71,9 @@ struct OTensor {
   int dtype = 0;   // 1 = float, 7 = int64
   Span raw{nullptr, 0};
   Span fdata{nullptr, 0};   // packed float_data
+  Span idata{nullptr, 0};   // packed int64_data
   bool external = false;
+  std::shared_ptr<std::vector<uint8_t>> own;   // storage of a tensor the loader derived (constant folding): raw points into it
   int64_t numel() const {
     int64_t n = 1;
     for (auto d : dims) n *= d;
@@ -100,7 +105,9 @@ static OTensor parse_tensor(Span s) {
     else if (f == 8) t.name = str(x);
     else if (f == 9) t.raw = x;
     else if (f == 4 && wt == 2) t.fdata = x;
-    else if (f == 14 && wt == 0 && v == 1) t.external = true;
+    else if (f == 7 && wt == 2) t.idata = x;
+    else if (f == 14 && wt == 0 && v == 1) t.external = true;     // data_location = EXTERNAL: the payload is in another file
+    else if (f == 13 && wt == 2) t.external = true;               // external_data entries (location / offset / length)
   }
   return t;
 }
@@ -118,17 +125,149 @@ static HostTensor to_host(const OTensor& t) {
   return h;
 }
 
+// small integer tensors (axes / shape / perm operands): raw little-endian int64 or packed int64_data
+static bool to_int64(const OTensor& t, std::vector<int64_t>& out) {
+  if (t.dtype != 7 || t.external) return false;
+  const int64_t n = t.numel();
+  if (n < 0 || n > 64) return false;
+  out.clear();
+  if (t.raw.n == (size_t)n * 8) {
+    out.resize((size_t)n);
+    memcpy(out.data(), t.raw.p, (size_t)n * 8);
+    return true;
+  }
+  if (t.idata.p || n == 0) {
+    Reader r(t.idata);
+    while (r.more()) out.push_back((int64_t)r.varint());
+    return (int64_t)out.size() == n;
+  }
+  return false;
+}
+
 struct Graph {
   std::vector<ONode> nodes;
   std::vector<OTensor> tensors;
   std::map<std::string, int> tensor_by_name;     // initialisers + Constant outputs
   std::map<std::string, int> producer;           // value name -> node index
   std::multimap<std::string, int> consumers;     // value name -> node indices
-  const OTensor* tensor(const std::string& n) const {
-    auto it = tensor_by_name.find(n);
-    return it == tensor_by_name.end() ? nullptr : &tensors[it->second];
-  }
+  // Tensors the loader derives on demand: post-export tools leave weights behind Identity nodes (shared initialisers),
+  // or store a matrix and Unsqueeze / Reshape / Transpose it into the conv's [out, in, k] at run time. tensor() looks
+  // through such chains of shape-only ops over constants (memoised; addresses stay valid: deque).
+  mutable std::deque<OTensor> derived;
+  mutable std::map<std::string, const OTensor*> derived_by_name;
+  const OTensor* tensor(const std::string& n, int depth = 0) const;
+  // a node tensor() looks through: consumers of a constant that are such nodes do not count as "uses" of it
+  bool transparent(const ONode& n) const;
 };
+
+static bool fold_op(const std::string& op) {
+  return op == "Identity" || op == "Unsqueeze" || op == "Squeeze" || op == "Reshape" || op == "Transpose" || op == "Flatten";
+}
+bool Graph::transparent(const ONode& n) const {
+  return fold_op(n.op) && !n.in.empty() && tensor(n.in[0]) != nullptr;
+}
+const OTensor* Graph::tensor(const std::string& name, int depth) const {
+  auto it = tensor_by_name.find(name);
+  if (it != tensor_by_name.end()) return &tensors[it->second];
+  auto dt = derived_by_name.find(name);
+  if (dt != derived_by_name.end()) return dt->second;
+  auto pr = producer.find(name);
+  if (pr == producer.end() || depth > 8) return nullptr;
+  const ONode& n = nodes[pr->second];
+  if (!fold_op(n.op) || n.in.empty()) return nullptr;
+  const OTensor* src = tensor(n.in[0], depth + 1);
+  if (!src) return nullptr;
+  if (n.op == "Identity") {                            // any element type (shared axes / shape operands too)
+    derived_by_name[name] = src;
+    return src;
+  }
+  if (src->external || src->dtype != 1 || src->dims.size() > 4) return nullptr;
+  auto ints_of = [&](const char* attr, size_t input, std::vector<int64_t>& v) -> bool {
+    auto a = n.ints.find(attr);                        // opset < 13: an attribute; from 13 on: an int64 input
+    if (a != n.ints.end()) { v = a->second; return true; }
+    if (n.in.size() > input && !n.in[input].empty()) {
+      const OTensor* ti = tensor(n.in[input], depth + 1);
+      return ti && to_int64(*ti, v);
+    }
+    return false;
+  };
+  OTensor t = *src;
+  t.name = name;
+  const int64_t rank = (int64_t)src->dims.size();
+  if (n.op == "Identity") {
+  } else if (n.op == "Unsqueeze") {
+    std::vector<int64_t> ax;
+    if (!ints_of("axes", 1, ax) || ax.empty()) return nullptr;
+    const int64_t nr = rank + (int64_t)ax.size();
+    for (auto& a : ax) { if (a < 0) a += nr; if (a < 0 || a >= nr) return nullptr; }
+    std::vector<int64_t> d((size_t)nr, 0);
+    for (auto a : ax) d[(size_t)a] = -1;
+    size_t k = 0;
+    for (auto& x : d) x = x == -1 ? 1 : src->dims[k++];
+    t.dims = d;
+  } else if (n.op == "Squeeze") {
+    std::vector<int64_t> ax;
+    const bool have = ints_of("axes", 1, ax);
+    std::vector<int64_t> d;
+    for (int64_t i = 0; i < rank; ++i) {
+      bool drop = false;
+      if (have) { for (auto a : ax) if ((a < 0 ? a + rank : a) == i) drop = true; }
+      else drop = src->dims[(size_t)i] == 1;
+      if (drop && src->dims[(size_t)i] != 1) return nullptr;
+      if (!drop) d.push_back(src->dims[(size_t)i]);
+    }
+    t.dims = d;
+  } else if (n.op == "Reshape" || n.op == "Flatten") {
+    std::vector<int64_t> sh;
+    if (n.op == "Flatten") {
+      int64_t ax = n.ints.count("axis") && !n.ints.at("axis").empty() ? n.ints.at("axis")[0] : 1;
+      if (ax < 0) ax += rank;
+      int64_t a = 1, b = 1;
+      for (int64_t i = 0; i < rank; ++i) (i < ax ? a : b) *= src->dims[(size_t)i];
+      sh = {a, b};
+    } else if (!ints_of("shape", 1, sh)) {
+      return nullptr;
+    }
+    int64_t known = 1, neg = -1;
+    for (size_t i = 0; i < sh.size(); ++i) {
+      if (sh[i] == 0) { if (i >= (size_t)rank) return nullptr; sh[i] = src->dims[i]; }
+      if (sh[i] == -1) { if (neg >= 0) return nullptr; neg = (int64_t)i; } else known *= sh[i];
+    }
+    if (neg >= 0) { if (known == 0 || src->numel() % known) return nullptr; sh[(size_t)neg] = src->numel() / known; known *= sh[(size_t)neg]; }
+    if (known != src->numel()) return nullptr;
+    t.dims = sh;
+  } else if (n.op == "Transpose") {
+    std::vector<int64_t> perm;
+    auto a = n.ints.find("perm");
+    if (a != n.ints.end()) perm = a->second;
+    else for (int64_t i = rank - 1; i >= 0; --i) perm.push_back(i);
+    if ((int64_t)perm.size() != rank) return nullptr;
+    std::vector<bool> used((size_t)rank, false);
+    for (auto q : perm) { if (q < 0 || q >= rank || used[(size_t)q]) return nullptr; used[(size_t)q] = true; }
+    // materialise: out[i0..] = in[perm-mapped]
+    const int64_t numel = src->numel();
+    const uint8_t* sp = src->raw.n == (size_t)numel * 4 ? src->raw.p : (src->fdata.n == (size_t)numel * 4 ? src->fdata.p : nullptr);
+    if (!sp && numel) return nullptr;
+    auto buf = std::make_shared<std::vector<uint8_t>>((size_t)numel * 4);
+    std::vector<int64_t> od((size_t)rank), istr((size_t)rank, 1);
+    for (int64_t i = rank - 2; i >= 0; --i) istr[(size_t)i] = istr[(size_t)i + 1] * src->dims[(size_t)i + 1];
+    for (int64_t i = 0; i < rank; ++i) od[(size_t)i] = src->dims[(size_t)perm[(size_t)i]];
+    std::vector<int64_t> idx((size_t)rank, 0);
+    for (int64_t o = 0; o < numel; ++o) {
+      int64_t in_off = 0;
+      for (int64_t i = 0; i < rank; ++i) in_off += idx[(size_t)i] * istr[(size_t)perm[(size_t)i]];
+      memcpy(buf->data() + (size_t)o * 4, sp + (size_t)in_off * 4, 4);
+      for (int64_t i = rank - 1; i >= 0; --i) { if (++idx[(size_t)i] < od[(size_t)i]) break; idx[(size_t)i] = 0; }
+    }
+    t.own = buf;
+    t.raw = Span{buf->data(), buf->size()};
+    t.fdata = Span{nullptr, 0};
+    t.dims = od;
+  }
+  derived.push_back(std::move(t));
+  derived_by_name[name] = &derived.back();
+  return &derived.back();
+}
 
 static ONode parse_node(Span s, Graph& g) {
   ONode n;
@@ -305,6 +444,72 @@ WeightSet load_onnx(const std::string& path) {
   }
   if (convs.size() < 20) fail("too few convolutions");
 
+  // ---- structure checks. The grammar below walks the convolutions in FILE order, which is the exporter's execution order;
+  // ONNX only demands a topological order, and a tool may emit another one. Sequentially dependent convolutions cannot
+  // change places, parallel siblings can (q / k / v of a layer, the resblocks of an MRF stage, the speaker-conditioning
+  // convs): q / k / v are told apart by their place in the attention products and re-ordered; every other adjacency the
+  // grammar assumes ("b consumes a's output through element-wise ops") is VERIFIED after the walk, so that a file in
+  // another order fails with a named error instead of loading the wrong tensor under a name.
+  std::map<const ONode*, size_t> conv_of_node;
+  for (size_t i = 0; i < convs.size(); ++i) conv_of_node[convs[i].node] = i;
+  // nodes reached from value `v` without passing through a convolution; `stop_mm`: also stop AT MatMul / Softmax nodes
+  auto reach = [&](const std::string& v, bool stop_mm, std::vector<int>& out_nodes) {
+    out_nodes.clear();
+    std::set<int> seen;
+    std::vector<std::string> work{v};
+    while (!work.empty()) {
+      const std::string cur = work.back();
+      work.pop_back();
+      auto rng = g.consumers.equal_range(cur);
+      for (auto it = rng.first; it != rng.second; ++it) {
+        const int ni = it->second;
+        if (!seen.insert(ni).second) continue;
+        out_nodes.push_back(ni);
+        const ONode& n = g.nodes[ni];
+        if (n.op == "Conv" || n.op == "ConvTranspose") continue;
+        if (n.op == "Shape" || n.op == "Size") continue;       // sizes are not data: the exporter computes a reshape target
+                                                              // from ONE tensor (key.size()) and uses it for its siblings too
+        if (stop_mm && (n.op == "MatMul" || n.op == "Softmax")) continue;
+        for (auto& o : n.out) work.push_back(o);
+      }
+    }
+  };
+  std::vector<std::pair<const ConvRec*, const ConvRec*>> links;          // (producer, consumer) pairs the grammar assumes
+  std::map<const ConvRec*, std::string> conv_name;
+  auto link = [&](const ConvRec* a, const ConvRec* b) { if (a && b) links.push_back({a, b}); };
+  // the (MatMul node, input slot) pairs a conv's output reaches before any other MatMul / Softmax / conv
+  auto matmul_slots = [&](const ConvRec& c, std::vector<std::pair<int, int>>& slots) {
+    slots.clear();
+    std::vector<int> nodes;
+    reach(c.node->out[0], true, nodes);
+    std::set<std::string> vals{c.node->out[0]};
+    for (int ni : nodes) for (auto& o : g.nodes[ni].out) if (g.nodes[ni].op != "MatMul" && g.nodes[ni].op != "Softmax") vals.insert(o);
+    for (int ni : nodes) {
+      const ONode& n = g.nodes[ni];
+      if (n.op != "MatMul") continue;
+      for (size_t k = 0; k < n.in.size(); ++k) if (vals.count(n.in[k])) slots.push_back({ni, (int)k});
+    }
+  };
+  // q = reaches a MatMul through input 0; k = reaches input 1 of a MatMul that q reaches through input 0; v = the third
+  // (attentions.py:225-236: scores = matmul(query / sqrt(d), key^T); output = matmul(p_attn, value))
+  auto order_qkv = [&](size_t at) {
+    std::vector<std::pair<int, int>> sl[3];
+    for (int j = 0; j < 3; ++j) matmul_slots(convs[at + j], sl[j]);
+    int q = -1, k = -1;
+    for (int j = 0; j < 3 && q < 0; ++j)
+      for (auto& a : sl[j]) if (a.second == 0) { q = j; break; }
+    if (q < 0) fail("attention layer: no conv feeds the first operand of a MatMul");
+    for (int j = 0; j < 3 && k < 0; ++j) {
+      if (j == q) continue;
+      for (auto& a : sl[j])
+        for (auto& b : sl[q]) if (a.second == 1 && b.second == 0 && a.first == b.first) k = j;
+    }
+    if (k < 0) fail("attention layer: no conv feeds the key operand of the score MatMul");
+    const int v = 3 - q - k;
+    const ConvRec cq = convs[at + q], ck = convs[at + k], cv = convs[at + v];
+    convs[at] = cq; convs[at + 1] = ck; convs[at + 2] = cv;
+  };
+
   WeightSet ws;
   int32_t* A = ws.arch;
   size_t ci = 0;
@@ -320,16 +525,37 @@ WeightSet load_onnx(const std::string& path) {
       if (!c.b) fail(name + ": missing bias");
       ws.put(name + ".bias", to_host(*c.b));
     }
+    conv_name[&c] = name;
     return c;
   };
 
   // ---- embeddings: Gather nodes whose data input is a 2-D float initialiser, in graph order
   std::vector<const OTensor*> embs;
-  for (auto& n : g.nodes)
-    if (n.op == "Gather" && !n.in.empty()) {
-      const OTensor* t = g.tensor(n.in[0]);
-      if (t && t->dtype == 1 && t->dims.size() == 2 && t->dims[0] > 1 && t->dims[1] > 1) embs.push_back(t);
-    }
+  {
+    // which graph input an embedding's indices come from ("input" = phoneme ids, "sid" = speaker: export_onnx.py:94): the
+    // text embedding goes first whatever the node order says
+    auto index_source = [&](const ONode& n) -> std::string {
+      std::string v = n.in.size() > 1 ? n.in[1] : std::string();
+      for (int hop = 0; hop < 16 && !v.empty(); ++hop) {
+        auto pr = g.producer.find(v);
+        if (pr == g.producer.end()) return v;               // a graph input (or an initialiser)
+        const ONode& p = g.nodes[pr->second];
+        v = p.in.empty() ? std::string() : p.in[0];
+      }
+      return std::string();
+    };
+    std::vector<std::pair<int, const OTensor*>> found;       // (rank of the index source, tensor), file order within a rank
+    for (auto& n : g.nodes)
+      if (n.op == "Gather" && !n.in.empty()) {
+        const OTensor* t = g.tensor(n.in[0]);
+        if (t && t->dtype == 1 && t->dims.size() == 2 && t->dims[0] > 1 && t->dims[1] > 1) {
+          const std::string src = index_source(n);
+          found.push_back({src == "input" ? 0 : (src == "sid" ? 2 : 1), t});
+        }
+      }
+    std::stable_sort(found.begin(), found.end(), [](const std::pair<int, const OTensor*>& a, const std::pair<int, const OTensor*>& b) { return a.first < b.first; });
+    for (auto& f : found) embs.push_back(f.second);
+  }
   if (embs.empty()) fail("text embedding not found");
   const int64_t H = embs[0]->dims[1];
   A[A_NVOCAB] = (int)embs[0]->dims[0];
@@ -348,17 +574,22 @@ WeightSet load_onnx(const std::string& path) {
   // ---- text encoder
   int nl = 0;
   int64_t FC = 0, ksz = 0;
+  const ConvRec* enc_last = nullptr;
   while (have(6) && convs[ci].d0 == H && convs[ci].d1 == H && convs[ci].k == 1 && convs[ci + 4].d1 == H &&
          convs[ci + 5].d0 == H && convs[ci + 4].k == convs[ci + 5].k && convs[ci + 5].d1 == convs[ci + 4].d0 &&
          convs[ci + 3].d0 == H && convs[ci + 3].k == 1) {
     const std::string a = "enc_p.encoder.attn_layers." + std::to_string(nl), ff = "enc_p.encoder.ffn_layers." + std::to_string(nl);
-    take(a + ".conv_q", H, H, 1);
-    take(a + ".conv_k", H, H, 1);
-    take(a + ".conv_v", H, H, 1);
-    take(a + ".conv_o", H, H, 1);
+    order_qkv(ci);
+    const ConvRec& cq = take(a + ".conv_q", H, H, 1);
+    const ConvRec& ck = take(a + ".conv_k", H, H, 1);
+    const ConvRec& cv = take(a + ".conv_v", H, H, 1);
+    const ConvRec& co = take(a + ".conv_o", H, H, 1);
     FC = convs[ci].d0; ksz = convs[ci].k;
-    take(ff + ".conv_1", FC, H, ksz);
-    take(ff + ".conv_2", H, FC, ksz);
+    const ConvRec& f1 = take(ff + ".conv_1", FC, H, ksz);
+    const ConvRec& f2 = take(ff + ".conv_2", H, FC, ksz);
+    link(enc_last, &cq); link(enc_last, &ck); link(enc_last, &cv);
+    link(&cq, &co); link(&ck, &co); link(&cv, &co); link(&co, &f1); link(&f1, &f2);
+    enc_last = &f2;
     ++nl;
     // a one-layer-lookahead ambiguity: the next [H,H,1] could be enc_p.proj only when 2C == H; proj is
     // followed by dp.pre ([H,H,1]) and a depthwise conv, a further layer by three more [H,H,1]
@@ -367,50 +598,102 @@ WeightSet load_onnx(const std::string& path) {
   if (nl == 0) fail("no attention layers recognised");
   A[A_NLAYERS] = nl; A[A_FILTER] = (int)FC; A[A_KSIZE] = (int)ksz;
   const ConvRec& proj = take("enc_p.proj", -1, H, 1);
+  link(enc_last, &proj);
   const int64_t C = proj.d0 / 2;
   A[A_INTER] = (int)C;
 
-  // relative-position embeddings: rank-3 float initialisers [1, 2w+1, dk] in order of first use
+  // relative-position embeddings: rank-3 float constants [1, 2w+1, dk]. Each is placed by what the graph does with it, not
+  // by where its first reader stands in the file: it reaches (through pad / slice / transpose) the second operand of a
+  // MatMul whose first operand comes from layer l's q conv -- directly for emb_rel_k (attentions.py:247-249), through the
+  // Softmax for emb_rel_v (:257-260).
   {
-    std::vector<const OTensor*> rel;
+    std::map<const ONode*, int> layer_of_q;
+    for (auto& kv : conv_name) {
+      const std::string& nm = kv.second;
+      const size_t at = nm.find(".conv_q");
+      if (at != std::string::npos && nm.compare(0, 26, "enc_p.encoder.attn_layers.") == 0) layer_of_q[kv.first->node] = atoi(nm.c_str() + 26);
+    }
+    std::vector<const OTensor*> rel_k((size_t)nl, nullptr), rel_v((size_t)nl, nullptr);
     std::set<std::string> seen;
-    for (auto& n : g.nodes)
+    int found = 0;
+    for (auto& n : g.nodes) {
+      if (g.transparent(n)) continue;          // (an Identity / reshape over a constant is not a use of it: its consumer is)
       for (auto& in : n.in) {
         const OTensor* t = g.tensor(in);
-        if (t && t->dtype == 1 && t->dims.size() == 3 && t->dims[0] == 1 && (t->dims[1] & 1) && H % t->dims[2] == 0 &&
-            t->dims[2] < H && n.op != "Conv" && n.op != "ConvTranspose" && !seen.count(in)) {
-          seen.insert(in);
-          rel.push_back(t);
+        if (!(t && t->dtype == 1 && t->dims.size() == 3 && t->dims[0] == 1 && (t->dims[1] & 1) && H % t->dims[2] == 0 &&
+              t->dims[2] < H && n.op != "Conv" && n.op != "ConvTranspose" && !seen.count(in)))
+          continue;
+        seen.insert(in);
+        // forward to the MatMul that takes it as second operand
+        std::vector<int> fwd;
+        reach(in, true, fwd);
+        std::set<std::string> vals{in};
+        for (int ni : fwd) for (auto& o : g.nodes[ni].out) if (g.nodes[ni].op != "MatMul" && g.nodes[ni].op != "Softmax") vals.insert(o);
+        const ONode* mm = nullptr;
+        for (int ni : fwd)
+          if (g.nodes[ni].op == "MatMul" && g.nodes[ni].in.size() == 2 && vals.count(g.nodes[ni].in[1])) mm = &g.nodes[ni];
+        if (!mm) fail("relative-position embedding that feeds no MatMul");
+        // backward from the first operand to the nearest convolutions; is there a Softmax on the way?
+        bool softmax = false;
+        int layer = -1;
+        std::set<std::string> bseen;
+        std::vector<std::string> work{mm->in[0]};
+        while (!work.empty()) {
+          const std::string v = work.back();
+          work.pop_back();
+          if (!bseen.insert(v).second) continue;
+          auto pr = g.producer.find(v);
+          if (pr == g.producer.end()) continue;
+          const ONode& p = g.nodes[pr->second];
+          if (p.op == "Conv" || p.op == "ConvTranspose") {
+            auto lq = layer_of_q.find(&p);
+            if (lq != layer_of_q.end()) layer = lq->second;
+            continue;
+          }
+          if (p.op == "Shape" || p.op == "Size") continue;
+          if (p.op == "Softmax") softmax = true;
+          for (auto& pin : p.in) if (!pin.empty()) work.push_back(pin);
         }
+        if (layer < 0 || layer >= nl) fail("relative-position embedding whose MatMul does not read an attention layer's query");
+        auto& slot = softmax ? rel_v[(size_t)layer] : rel_k[(size_t)layer];
+        if (slot) fail("two relative-position embeddings in one role of attention layer " + std::to_string(layer));
+        slot = t;
+        ++found;
       }
-    if ((int)rel.size() != 2 * nl) fail("expected " + std::to_string(2 * nl) + " relative-position embeddings, found " +
-                                        std::to_string(rel.size()));
-    A[A_WINDOW] = (int)(rel[0]->dims[1] - 1) / 2;
-    A[A_NHEADS] = (int)(H / rel[0]->dims[2]);
+    }
+    if (found != 2 * nl) fail("expected " + std::to_string(2 * nl) + " relative-position embeddings, found " + std::to_string(found));
+    A[A_WINDOW] = (int)(rel_k[0]->dims[1] - 1) / 2;
+    A[A_NHEADS] = (int)(H / rel_k[0]->dims[2]);
     for (int l = 0; l < nl; ++l) {
-      ws.put("enc_p.encoder.attn_layers." + std::to_string(l) + ".emb_rel_k", to_host(*rel[2 * l]));
-      ws.put("enc_p.encoder.attn_layers." + std::to_string(l) + ".emb_rel_v", to_host(*rel[2 * l + 1]));
+      if (!rel_k[(size_t)l] || !rel_v[(size_t)l]) fail("attention layer " + std::to_string(l) + " without its relative-position embeddings");
+      ws.put("enc_p.encoder.attn_layers." + std::to_string(l) + ".emb_rel_k", to_host(*rel_k[(size_t)l]));
+      ws.put("enc_p.encoder.attn_layers." + std::to_string(l) + ".emb_rel_v", to_host(*rel_v[(size_t)l]));
     }
   }
 
   // ---- duration predictor
   int dds_layers = 0;
-  auto take_dds = [&](const std::string& p) {
+  auto take_dds = [&](const std::string& p, const ConvRec* prev) -> const ConvRec* {
     int l = 0;
     while (have(2) && convs[ci].group > 1) {
       if (convs[ci].group != H) fail(p + ": depthwise conv with groups != hidden");
-      take(p + ".convs_sep." + std::to_string(l), H, 1, ksz);
-      take(p + ".convs_1x1." + std::to_string(l), H, H, 1);
+      const ConvRec& sep = take(p + ".convs_sep." + std::to_string(l), H, 1, ksz);
+      const ConvRec& one = take(p + ".convs_1x1." + std::to_string(l), H, H, 1);
+      link(prev, &sep); link(&sep, &one);
+      prev = &one;
       ++l;
     }
     if (l == 0) fail(p + ": no depthwise layers");
     if (dds_layers && dds_layers != l) fail(p + ": inconsistent DDSConv depth");
     dds_layers = l;
+    return prev;
   };
-  take("dp.pre", H, H, 1);
+  const ConvRec& dp_pre = take("dp.pre", H, H, 1);
+  link(enc_last, &dp_pre);
   if (gin) take("dp.cond", H, gin, 1);
-  take_dds("dp.convs");
-  take("dp.proj", H, H, 1);
+  const ConvRec* dp_last = take_dds("dp.convs", &dp_pre);
+  const ConvRec& dp_proj = take("dp.proj", H, H, 1);
+  link(dp_last, &dp_proj);
   int ncf = 0;
   std::vector<int> cf_ids;
   {
@@ -427,9 +710,10 @@ WeightSet load_onnx(const std::string& path) {
     if (ncf == 0) fail("no ConvFlow in the duration predictor");
     for (int i = ncf; i >= 1; --i) {
       const std::string p = "dp.flows." + std::to_string(2 * i + 1);
-      take(p + ".pre", H, 1, 1);
-      take_dds(p + ".convs");
+      const ConvRec& cpre = take(p + ".pre", H, 1, 1);
+      const ConvRec* clast = take_dds(p + ".convs", &cpre);
       const ConvRec& pj = take(p + ".proj", -1, H, 1);
+      link(clast, &pj);
       A[A_NBINS] = (int)(pj.d0 + 1) / 3;
     }
   }
@@ -437,6 +721,7 @@ WeightSet load_onnx(const std::string& path) {
   A[A_DDSLAYERS] = dds_layers;
 
   // ---- coupling flow (executed flows.{2(n-1)}, ..., flows.0)
+  const ConvRec* flow_last = nullptr;
   {
     // count residual coupling layers: pre [H, C/2, 1], optional cond, (in [2H,H,k>1], res_skip)*, post [C/2, H, 1]
     size_t probe = ci;
@@ -455,9 +740,12 @@ WeightSet load_onnx(const std::string& path) {
     }
     if (nf == 0) fail("no residual coupling layers recognised");
     A[A_FLOWN] = nf;
+    flow_last = nullptr;
     for (int f2 = nf - 1; f2 >= 0; --f2) {
       const std::string p = "flow.flows." + std::to_string(2 * f2);
-      take(p + ".pre", H, C / 2, 1);
+      const ConvRec& fpre = take(p + ".pre", H, C / 2, 1);
+      link(flow_last, &fpre);
+      const ConvRec* wprev = &fpre;
       int wl = 0;
       int64_t wk = 0;
       size_t look = ci + (gin ? 1 : 0);
@@ -465,18 +753,25 @@ WeightSet load_onnx(const std::string& path) {
       if (gin) take(p + ".enc.cond_layer", 2 * H * wl, gin, 1);
       for (int i = 0; i < wl; ++i) {
         wk = convs[ci].k;
-        take(p + ".enc.in_layers." + std::to_string(i), 2 * H, H, wk);
-        take(p + ".enc.res_skip_layers." + std::to_string(i), i < wl - 1 ? 2 * H : H, H, 1);
+        const ConvRec& win = take(p + ".enc.in_layers." + std::to_string(i), 2 * H, H, wk);
+        const ConvRec& wrs = take(p + ".enc.res_skip_layers." + std::to_string(i), i < wl - 1 ? 2 * H : H, H, 1);
+        link(wprev, &win); link(&win, &wrs);
+        wprev = &wrs;
       }
       if (wl == 0) fail(p + ": no WN layers");
       A[A_WNLAYERS] = wl; A[A_WNK] = (int)wk;
-      take(p + ".post", C / 2, H, 1);
+      const ConvRec& fpost = take(p + ".post", C / 2, H, 1);
+      link(wprev, &fpost);
+      flow_last = &fpost;
     }
   }
 
   // ---- HiFiGAN
   {
     const ConvRec& pre = take("dec.conv_pre", -1, C, 7);
+    link(flow_last, &pre);
+    const ConvRec* stage_in = &pre;            // the conv whose output the next up-conv consumes
+    std::vector<const ConvRec*> stage_tails;   // last conv of every resblock of the previous stage
     const int64_t U = pre.d0;
     A[A_UPINIT] = (int)U;
     if (gin) take("dec.cond", U, gin, 1);
@@ -496,7 +791,10 @@ WeightSet load_onnx(const std::string& path) {
       A[A_UPR0 + nups] = up.stride;
       A[A_UPK0 + nups] = (int)up.k;
       ch = up.d1;
-      take("dec.ups." + std::to_string(nups), -1, -1, -1);
+      const ConvRec& upc = take("dec.ups." + std::to_string(nups), -1, -1, -1);
+      if (stage_tails.empty()) link(stage_in, &upc);
+      for (const ConvRec* t : stage_tails) link(t, &upc);
+      stage_tails.clear();
       // resblocks of this stage: maximal runs of equal kernel size
       std::vector<std::vector<int>> dils;
       std::vector<int> kss;
@@ -538,6 +836,9 @@ WeightSet load_onnx(const std::string& path) {
           ws.put(nm + ".weight", to_host(*c.w));
           if (!c.b) fail(nm + ": missing bias");
           ws.put(nm + ".bias", to_host(*c.b));
+          conv_name[&c] = nm;
+          link(i == 0 ? &upc : &convs[idx[j][i - 1]], &c);
+          if (i + 1 == idx[j].size()) stage_tails.push_back(&c);
         }
         if (nups == 0) { dil_first.push_back(dd); ks_first.push_back(kss[j]); }
         else if (j >= dil_first.size() || dil_first[j] != dd || ks_first[j] != kss[j]) fail("resblock layout differs between stages");
@@ -557,8 +858,27 @@ WeightSet load_onnx(const std::string& path) {
       if (dil_first[j].size() != dil_first[0].size() || dil_first[j].size() > (size_t)MAX_DIL) fail("resblock dilation count");
       for (size_t d = 0; d < dil_first[j].size(); ++d) A[A_RBDIL0 + j * MAX_DIL + d] = dil_first[j][d];
     }
-    take("dec.conv_post", 1, ch, 7, false);
+    const ConvRec& cpost = take("dec.conv_post", 1, ch, 7, false);
+    for (const ConvRec* t : stage_tails) link(t, &cpost);
     if (ci != convs.size()) fail("unexpected convolutions after dec.conv_post");
+  }
+
+  // ---- every producer -> consumer adjacency the walk assumed must exist in the graph
+  {
+    std::map<const ConvRec*, std::set<const ONode*>> hits;
+    for (auto& l : links) {
+      auto it = hits.find(l.first);
+      if (it == hits.end()) {
+        std::vector<int> nodes;
+        reach(l.first->node->out[0], false, nodes);
+        std::set<const ONode*> hs;
+        for (int ni : nodes) if (g.nodes[ni].op == "Conv" || g.nodes[ni].op == "ConvTranspose") hs.insert(&g.nodes[ni]);
+        it = hits.emplace(l.first, std::move(hs)).first;
+      }
+      if (!it->second.count(l.second->node))
+        fail("node order is not the exporter's execution order: " + conv_name[l.second] + " does not consume the output of " +
+             conv_name[l.first]);
+    }
   }
 
   // ---- LayerNorm gains/offsets: Div -> Mul(gamma) -> Add(beta), in graph order

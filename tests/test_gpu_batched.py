@@ -195,10 +195,18 @@ def test_no_kernel_reads_what_the_call_did_not_write(monkeypatch, preset, lens):
 # variant on shapes where the default heuristics would pick another one. `expect`: instantiations that must run.
 FORCED = [
     # every conv of a single utterance through the TILED kernels (gate epilogue, 32-row and 64-row tiles, both halos)
-    ("medium", [128], {"PIPER_HIP_SPLITK_MAX": 0, "PIPER_HIP_MRF": 0},
+    ("medium", [128], {"PIPER_HIP_SPLITK_MAX": 0, "PIPER_HIP_MRF": 0, "PIPER_HIP_GROUP_TILED": 0},
      {"conv_mfma_kernel<2,2,2,1,16,true,64>", "conv_mfma_kernel<2,2,1,1,16,false,64>",
       "conv_mfma_kernel<1,4,1,1,16,false,64>", "conv_mfma_kernel<2,2,1,1,16,false,128>",
       "conv_mfma_kernel<1,4,1,1,16,false,128>"}),
+    # ... and with the sibling resblock convs of every stage as grouped launches of the tiled kernel (both tile shapes, both halos)
+    ("medium", [128], {"PIPER_HIP_SPLITK_MAX": 0, "PIPER_HIP_MRF": 0},
+     {"conv_mfma_group_kernel<2,2,1,1,16,64>", "conv_mfma_group_kernel<2,2,1,1,16,128>",
+      "conv_mfma_group_kernel<1,4,1,1,16,64>", "conv_mfma_group_kernel<1,4,1,1,16,128>", "mrf_sum_kernel"}),
+    # the high voice's 128- / 64-channel stages of one and of two utterances: the grouped tiled form by default; one launch per conv
+    ("high", [128], {}, {"conv_mfma_group_kernel<2,2,1,1,16,64>", "mrf_sum_kernel"}),
+    ("high", [100, 128], {}, {"conv_mfma_group_kernel<2,2,1,1,16,64>"}),
+    ("high", [128], {"PIPER_HIP_GROUP_TILED": 0}, {"conv_mfma_kernel<2,2,1,1,16,false,64>"}),
     # the one-tap convs (q/k/v, conv_o, res/skip, pre / post, proj) on the batched route: B operand straight from global
     # memory (conv1x1_kernel, the default), and through the tiled kernel's LDS slabs
     ("medium", [128, 70], {"PIPER_HIP_SPLITK_MAX": 0, "PIPER_HIP_MRF": 0, "PIPER_HIP_COLCHAIN": 0}, {"conv1x1_kernel<1>"}),

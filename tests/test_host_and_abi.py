@@ -223,7 +223,7 @@ def test_text_front_end_casefold_nfd_matches_cpp():
 def test_launch_policy_table_is_exported_and_documented(lib):
     """pe_policy_describe: the knob table of piper_amd/csrc/policy.h as JSON. Every knob has a default inside its range,
     and DESIGN.md section 4.1 documents exactly the knobs the code reads (plus the string-valued PIPER_HIP_MATRIX and the
-    group-level PIPER_HIP_GROUP_BCAST, which are not launch-policy integers)."""
+    group-level PIPER_HIP_GROUP_BCAST / PIPER_HIP_GROUP_COALESCE, which are not launch-policy integers)."""
     knobs = json.loads(lib.pe_policy_describe().decode())
     envs = [k["env"] for k in knobs]
     assert len(envs) == len(set(envs)) >= 20 and all(e.startswith("PIPER_HIP_") for e in envs)
@@ -232,10 +232,10 @@ def test_launch_policy_table_is_exported_and_documented(lib):
     design = open(os.path.join(ROOT, "DESIGN.md")).read()
     sec = design[design.index("### 4.1"):design.index("## 5.")]
     documented = set(re.findall(r"`(PIPER_HIP_[A-Z0-9_]+)`", sec))
-    assert documented - {"PIPER_HIP_MATRIX", "PIPER_HIP_GROUP_BCAST"} == set(envs)
+    assert documented - {"PIPER_HIP_MATRIX", "PIPER_HIP_GROUP_BCAST", "PIPER_HIP_GROUP_COALESCE"} == set(envs)
     # no other translation unit of the engine reads a PIPER_HIP_* integer on its own
     for fn in ("engine.cpp", "engine_pack.cpp", "engine_launch.cpp", "engine_issue.cpp", "pe_api.cpp"):
         path = os.path.join(ROOT, "piper_amd", "csrc", fn)
         if os.path.exists(path):
             reads = set(re.findall(r'getenv\("(PIPER_HIP_[A-Z0-9_]+)"\)', open(path).read()))
-            assert reads <= {"PIPER_HIP_GROUP_BCAST"}, (fn, reads)
+            assert reads <= {"PIPER_HIP_GROUP_BCAST", "PIPER_HIP_GROUP_COALESCE"}, (fn, reads)

@@ -133,3 +133,70 @@ def test_full_size_medium_export_loads(lib, tmp_path):
     out.write_bytes(m.save())
     cfg3, w3 = load(lib, out)
     check(cfg3, w3, cfg, w, tol=2e-6)
+
+
+# ---- round 5: what onnx-simplifier / torch-1.x exports leave behind --------------------------------
+R5_VARIANTS = {
+    "identity_shared": lambda m: m.identity_shared(2),
+    "unsqueeze_weights_axes_input": lambda m: m.unsqueeze_k1_weights(True),
+    "unsqueeze_weights_axes_attribute": lambda m: m.unsqueeze_k1_weights(False),
+    "transposed_weights": lambda m: m.transpose_conv_weights(1),
+    "squeezed_biases": lambda m: m.reshape_biases(),
+    "opset_lt13_attribute_forms": lambda m: m.axes_inputs_to_attributes(),
+    "all_of_them": lambda m: (m.axes_inputs_to_attributes(), m.transpose_conv_weights(2), m.unsqueeze_k1_weights(True),
+                              m.reshape_biases(), m.identity_shared(3), m.rename_initializers_to_numerals(), m.strip_node_names()),
+    "glue_and_qkv_reordered": lambda m: m.shuffle_nodes(7, keep_conv_order=True),
+    "glue_and_qkv_reordered_anonymous": lambda m: (m.shuffle_nodes(11, keep_conv_order=True), m.rename_initializers_to_numerals(),
+                                                   m.strip_node_names()),
+}
+
+
+@pytest.mark.parametrize("stem,preset", [("tiny_voice", "tiny"), ("tinyhms_voice", "tiny-high-ms")])
+@pytest.mark.parametrize("variant", sorted(R5_VARIANTS))
+def test_post_export_rewrites_load_identically(lib, tmp_path, stem, preset, variant):
+    """Identity-shared initialisers, conv weights behind Unsqueeze (both axes forms) / Transpose, biases behind Squeeze,
+    Squeeze / Unsqueeze / Split in the pre-opset-13 attribute form, and another topological order of everything but the
+    sequential convolutions (q / k / v re-ordered: the loader tells them apart by their place in the attention products):
+    each rewrite must give the unmutated file's weights, bit for bit."""
+    cfg, w = load(lib, os.path.join(GOLD, stem + ".onnx"))          # the unmutated file as the loader reads it
+    check(cfg, w, W.preset(preset), W.synthetic_weights(W.preset(preset), 1234))
+    m = M.Model(open(os.path.join(GOLD, stem + ".onnx"), "rb").read())
+    n = R5_VARIANTS[variant](m)
+    if isinstance(n, int):
+        assert n > 0, "the mutation did not apply to this file"
+    out = tmp_path / f"{stem}_{variant}.onnx"
+    out.write_bytes(m.save())
+    cfg2, w2 = load(lib, out)
+    check(cfg2, w2, cfg, w, tol=0.0)
+
+
+def test_external_data_is_a_named_error(lib, tmp_path):
+    """A tensor whose payload lives in another file (data_location = EXTERNAL): not supported, and said so with the
+    tensor's name -- never a silent load of zeros."""
+    m = M.Model(open(os.path.join(GOLD, "tiny_voice.onnx"), "rb").read())
+    name = m.make_external(5)
+    out = tmp_path / "external.onnx"
+    out.write_bytes(m.save())
+    with pytest.raises(RuntimeError) as ei:
+        load(lib, out)
+    assert "external tensor data is not supported" in str(ei.value) and name in str(ei.value)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_any_topological_order_loads_identically_or_fails_by_name(lib, tmp_path, seed):
+    """ONNX demands only A topological order. The loader walks the convolutions in file order (the exporter's execution
+    order); after the walk every producer -> consumer adjacency it assumed is verified in the graph, so a file whose
+    parallel branches (resblocks of an MRF stage, speaker-conditioning convs) come in another order either loads to exactly
+    the unmutated weights or fails with an error that says so -- it never loads a tensor under the wrong name."""
+    stem, preset = ("tiny_voice", "tiny") if seed % 2 == 0 else ("tinyhms_voice", "tiny-high-ms")
+    cfg, w = load(lib, os.path.join(GOLD, stem + ".onnx"))
+    m = M.Model(open(os.path.join(GOLD, stem + ".onnx"), "rb").read())
+    m.shuffle_nodes(100 + seed)
+    out = tmp_path / f"shuffled_{seed}.onnx"
+    out.write_bytes(m.save())
+    try:
+        cfg2, w2 = load(lib, out)
+    except RuntimeError as ex:
+        assert "onnx: voice graph does not match the Piper VITS export" in str(ex), str(ex)
+        return
+    check(cfg2, w2, cfg, w, tol=0.0)
