@@ -159,6 +159,8 @@ void Engine::ensure_stage_a(int B, int Tmax) {
     y_ = c.take<float>(Bc * H_ * T);
     qkv_ = c.take<float>(Bc * 3 * H_ * T);
     att_ = c.take<float>(Bc * H_ * T);
+    kT_ = c.take<float>(Bc * H_ * T);            // K as [utterance][channel quad][column][4] and
+    vQ_ = c.take<float>(Bc * H_ * T);            // V as [utterance][column quad][H][4]: attn4_kernel's operands (kernels/attn4.h)
     ffh_ = c.take<float>(Bc * FC_ * T);
     stats_ = c.take<float>(Bc * 2 * C_ * T);
     xg_ = c.take<float>(Bc * H_ * T);

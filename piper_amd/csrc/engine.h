@@ -374,6 +374,9 @@ class Engine {
   float* att_s_ = nullptr;           // attention score slabs of long utterances (attn_long_kernel); null while every slab fits LDS
   size_t attn_smem(int T, bool global_scores) const;
   bool attn_scores_global(int T) const;
+  float* vQ_ = nullptr;
+  float* kT_ = nullptr;              // K transposed [utterance][column][H] for attn4_kernel; written by the q/k/v launch while kt_on_
+  bool kt_on_ = false, kt_valid_ = false;      // kt_valid_: the last q/k/v launch did write kT
   float *x_ = nullptr, *y_ = nullptr, *qkv_ = nullptr, *att_ = nullptr, *ffh_ = nullptr, *stats_ = nullptr,
         *xg_ = nullptr, *dh_ = nullptr, *dy_ = nullptr, *dy2_ = nullptr, *hproj_ = nullptr, *z2_ = nullptr,
         *logw_ = nullptr, *noise_w_ = nullptr, *cond_ = nullptr;

@@ -70,7 +70,16 @@ void Engine::issue_stage_a() {
   const bool ffn_fused = stage_a_ffn_fused();
   const int nsl = FC_ / 48;
   const float* pend_bias = nullptr;                // conv_2 bias of the layer whose partial outputs are pending
+  // short calls run attention on 4-query workgroups (kernels/attn4.h), which take K transposed: the q/k/v launches then
+  // write kT beside qkv (a function of the call alone, like the flags above)
+  const auto attn4_for = [&](const EncLayer& e) -> const float* {
+    const bool attno_ok = pol_.attno && !pol_.attn_long && chain_q && pol_.chain4((long)B * T) && H_ == 192 && nh_ == 2 && dk_ == 96 &&
+                          window_ <= 4 && e.o16;
+    return (attno_ok && pol_.attn4_cols((long)B * T)) ? w4_of(e.o16) : nullptr;
+  };
   for (auto& e : enc_) {
+    kt_on_ = attn4_for(e) != nullptr;
+    kt_valid_ = false;
     if (pg && pend_bias) {
       lngemm(x, pg, pb, y, e.qkv16, e.qkv.bias, 3 * H_, qkv, T, 2.0 * tsum * e.qkv.macs_per_col, ffn_parts_, nsl, pend_bias);
       std::swap(x, y);
@@ -79,6 +88,7 @@ void Engine::issue_stage_a() {
       conv(e.qkv, x, qkv, d_tlens_, 1, T, EPI_STORE);
     pg = pb = nullptr;
     pend_bias = nullptr;
+    kt_on_ = false;
     // Small calls of the 192-channel voices: attention + conv_o + residual + norm_layers_1 as ONE launch (kernels/attno.h:
     // 16 queries of both heads per workgroup)
     const int ao_sp = rup(T, 64) + 2;
@@ -96,9 +106,10 @@ void Engine::issue_stage_a() {
       double afl = 0;
       for (int b = 0; b < B; ++b) afl += 4.0 * (double)tlens_h_[b] * tlens_h_[b] * H_;
       // short calls: 4-query workgroups (kernels/attn4.h: 32 workgroups for 128 ids instead of 8)
-      const float* wo4 = pol_.attn4_cols((long)B * T) ? w4_of(e.o16) : nullptr;
+      const float* wo4 = kt_valid_ ? attn4_for(e) : nullptr;      // (the q/k/v launch of this layer wrote kT)
       if (wo4) {
         ap.wo4 = wo4; ap.xcd = xcd_period_; ap.SP = rup(T, 64) + 4;
+        ap.kT = kT_; ap.vQ = vQ_; ap.kt_bs = (long)Ts * H_;
         const size_t smem4 = ((size_t)8 * ap.SP + 8 * (dk_ + 4) + 2 * 9 * dk_ + 3 * 72 + 8 * 12 + 4 * 196 + 4 * 192 * 4 + 32) * sizeof(float);
         const int kh = kbegin(prof_level_ >= 2 ? krow("attn4_kernel<96>") : 0, afl + 2.0 * tsum * e.o.macs_per_col,
                               4.0 * (tsum * 5.0 * H_ + e.o.macs_per_col));

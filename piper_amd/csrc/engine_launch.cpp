@@ -526,6 +526,7 @@ void Engine::lngemm(View y, const float* g, const float* b, View x, const float*
   if (const float* w4 = pol_.chain4((long)B_ * T) ? (second ? second->w4 : w4_of(w16)) : nullptr) {
     p.w16 = w4;
     p.xcd = xcd_period_;
+    if (kt_on_ && out.p == qkv_ && rows == 3 * H_) { p.kT = kT_; p.vQ = vQ_; p.kt_bs = (long)Ts_ * H_; kt_valid_ = true; }      // attn4_kernel follows
     if (second) {
       p.split = second->split; p.out2 = second->out2.p; p.o2_bs = second->out2.bs; p.o2_cs = second->out2.cs;
       p.bias2 = second->bias2; p.bias2_bs = second->bias2_bs;
@@ -556,6 +557,7 @@ bool Engine::conv1x1_col4(const float* w16, const float* bias, int rows, View in
   cp.res = bias2; cp.res_bs = bias2_bs;
   cp.out = out.p; cp.out_bs = out.bs; cp.out_cs = out.cs;
   cp.lens = lens;
+  if (kt_on_ && out.p == qkv_ && rows == 3 * H_) { cp.kT = kT_; cp.vQ = vQ_; cp.kt_bs = (long)Ts_ * H_; kt_valid_ = true; }      // attn4_kernel follows
   const double cols = lens == d_tlens_ ? cols_ids_ : cols_frames_;
   const int kh4 = kbegin(prof_level_ >= 2 ? krow("colchain4_kernel<false>") : 0, flops, 4.0 * (cols * (kin + rows) + (double)rows * kin));
   launch::colchain4(dim3((Lmax + 3) / 4, B, (rows + 191) / 192), col4_smem(), stream_, cp);

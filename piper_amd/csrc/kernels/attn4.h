@@ -34,9 +34,11 @@ __global__ __launch_bounds__(256) void attn4_kernel(AttnOP p) {
   PE_DYN_SMEM(float, sm);
   const int b = blockIdx.y;
   PE_STAMP(0, 0);
+  // The utterance length lives in device memory: nothing below touches it until Q, the tables, the first K unit and the
+  // first V chunk are requested (against the row stride; what lies beyond the length is masked where it is used), so its
+  // latency overlaps theirs instead of preceding them.
   const int T = p.lens[b];
   const int i0 = c4_tile(blockIdx.x, gridDim.x, p.xcd) * NC;
-  if (i0 >= T) return;
   const int tid = threadIdx.x, lane = tid & 63, wv = PE_UNIFORM(tid >> 6);
   const int l3 = lane & 3, lb = lane >> 2;
   const int SP = p.SP, nrel = 2 * p.window + 1;
@@ -50,30 +52,36 @@ __global__ __launch_bounds__(256) void attn4_kernel(AttnOP p) {
   float* P = YT + NC * KS1;                        // [4 waves][192][4]
   float* red = P + 4 * C4_H * NC;                  // [2][4][4]
   const float* qb = p.qkv + (long)b * p.q_bs;
-  const float* kb = qb + (long)H * p.q_cs;
-  const float* vb = kb + (long)H * p.q_cs;
-  const pe_rowsrc qd = pe_make_row(qb, H * p.q_cs), kd = pe_make_row(kb, H * p.q_cs), vd = pe_make_row(vb, H * p.q_cs);
-  const int nkb = (T + 63) / 64;                   // 64-key blocks; units u = (head u & 1, block u >> 1), wave w takes u = w, w + 4, ..
-  const int nkc = (T + 31) / 32;                   // 32-key chunks of phase 3: wave w takes chunks w, w + 4, ..
+  const pe_rowsrc qd = pe_make_row(qb, H * p.q_cs);
+  const int Lb = p.q_cs;                           // row stride: the bound of every request made before the length is known
 
   // ---- requests that depend on nothing computed here, in the order they are waited for: Q + the relative tables, this
   // wave's first K unit, its first V chunk
-  float kf[DK];
-  auto load_k_half = [&](int u, int half) {        // A[row = key][k = channel]: K[head][d][64 kb + lane]
+  // K comes as kT[channel quad][key][4] (the q/k/v launch writes it beside qkv): lane = key takes four channel steps per
+  // 16-byte load and the 64 lanes of a wave read 1 KB in one piece, 24 loads per unit. From the [channel][key] tensor the
+  // same fragments are 96 dword loads per lane, and with the V chunk behind them a wave has 131 loads to issue against a
+  // memory counter of 63: the first barrier then stands two memory round trips from kernel entry (phase stamps: 4.4 us).
+  // (A plain transpose [key][192] was measured too: 16 bytes from each of 64 cache lines per instruction, 6.0 us.)
+  f32x4 kf[DK / 4];
+  const pe_rowsrc ktd = pe_make_row(p.kT + (long)b * p.kt_bs, (H / 4) * p.q_cs * 4);
+  auto load_k = [&](int u) {                       // A[row = key][k = channel]: kT[head * DK / 4 + d4][64 kb + lane][0..3]
     const int h = u & 1, kbk = u >> 1, j = kbk * 64 + lane;
-    const int o = (kbk < nkb && j < T) ? (h * DK) * p.q_cs + j : 0x3fffffff;
+    const int o = j < Lb ? (h * (DK / 4) * p.q_cs + j) * 4 : -4;      // keys in [len, stride): finite or not, their scores are never read
 #pragma unroll
-    for (int d = 0; d < DK / 2; ++d) kf[half * (DK / 2) + d] = pe_row_load_so(kd, o, (half * (DK / 2) + d) * p.q_cs);
+    for (int d4 = 0; d4 < DK / 4; ++d4) kf[d4] = pe_row_load4_so(ktd, o, d4 * p.q_cs * 4);      // (every quad row exists: the SGPR offset stays inside)
   };
-  auto load_k = [&](int u) { load_k_half(u, 0); load_k_half(u, 1); };
   f32x4 vf[NVT][8];
+  // V comes as vQ[key quad][192][4] (written by the q/k/v launch like kT): lane = channel takes four keys per 16-byte
+  // load and a wave reads 1 KB in one piece. (From the [channel][key] tensor every lane's 16 bytes sit in another cache
+  // line: 64 lines per instruction, and the 96 KB a workgroup touches that way do not fit its L1.)
+  const pe_rowsrc vqd = pe_make_row(p.vQ + (long)b * p.kt_bs, (Lb / 4) * H * 4);
   auto load_v = [&](int kc) {                      // A[row = channel 64 m + lane][k = key]: four keys per 16-byte load
 #pragma unroll
     for (int m = 0; m < NVT; ++m)
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
         const int key = 32 * kc + 4 * g;
-        vf[m][g] = pe_row_load4(vd, (kc < nkc && key < T) ? (64 * m + lane) * p.q_cs + key : -4);
+        vf[m][g] = pe_row_load4(vqd, key < Lb ? ((key >> 2) * H + 64 * m + lane) * 4 : -4);      // (keys >= len are masked where the fragment is used)
       }
   };
   {
@@ -82,36 +90,32 @@ __global__ __launch_bounds__(256) void attn4_kernel(AttnOP p) {
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       const int e = tid + 256 * u, c = e >> 2, q = e & 3;          // channel c of both heads' stacked q rows
-      qv[u] = pe_row_load(qd, (i0 + q < T) ? c * p.q_cs + i0 + q : -1);
+      qv[u] = pe_row_load(qd, (i0 + q < Lb) ? c * p.q_cs + i0 + q : -1);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       rk[u] = pe_row_load(rkd, tid + 256 * u);
       rv[u] = pe_row_load(rvd, tid + 256 * u);
     }
-    // The memory counter holds 63 loads: a wait for "the first 11 of 131" is really a wait until all but 62 have returned.
-    // So only HALF of the K fragments go out in front of the LDS stores of Q and the tables (the stores then wait for
-    // exactly those 11 loads), the rest of K and the V chunk behind them (phase stamps: 4.4 us to the first barrier with
-    // everything in front, profiles/r05_notes.md).
     PE_SCHED_FENCE();
-    load_k_half(wv, 0);
+    load_k(wv);
     PE_SCHED_FENCE();
+    load_v(wv);
+    PE_SCHED_FENCE();
+    if (i0 >= T) return;                           // first use of the length
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
       const int e = tid + 256 * u, c = e >> 2, q = e & 3, h = c >= DK ? 1 : 0;
-      Qs[(h * NC + q) * QS + (c - h * DK)] = qv[u] * p.qscale;
+      Qs[(h * NC + q) * QS + (c - h * DK)] = (i0 + q < T) ? qv[u] * p.qscale : 0.f;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int e = tid + 256 * u;
       if (e < NREL * DK) { RK[e] = e < nrel * DK ? rk[u] : 0.f; RV[e] = e < nrel * DK ? rv[u] : 0.f; }
     }
-    PE_SCHED_FENCE();
-    load_k_half(wv, 1);
-    PE_SCHED_FENCE();
-    load_v(wv);
-    PE_SCHED_FENCE();
   }
+  const int nkb = (T + 63) / 64;                   // 64-key blocks; units u = (head u & 1, block u >> 1), wave w takes u = w, w + 4, ..
+  const int nkc = (T + 31) / 32;                   // 32-key chunks of phase 3: wave w takes chunks w, w + 4, ..
   __syncthreads();
   PE_STAMP(0, 1);
 
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(256) void attn4_kernel(AttnOP p) {
     for (int d4 = 0; d4 < DK / 4; ++d4) {
       const f32x4 q4 = *reinterpret_cast<const f32x4*>(qp + 4 * d4);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc = pe_mfma_4x4x1(kf[4 * d4 + j], q4[j], acc);
+      for (int j = 0; j < 4; ++j) acc = pe_mfma_4x4x1(kf[d4][j], q4[j], acc);
     }
     // D[r] of lane l = S[key 64 kb + 4 (l >> 2) + r][query l & 3]: four consecutive keys of one row
     *reinterpret_cast<f32x4*>(Sc + (h * NC + l3) * SP + 64 * kbk + 4 * lb) = acc;

@@ -191,7 +191,12 @@ __global__ __launch_bounds__(256) void colchain4_kernel(ColP p) {
 #pragma unroll
     for (int k = 0; k < NVT; ++k) {
       const int c = rl + 64 * k;
-      if (c < rows_here) tp[(long)c * tcs + t] = (col_gemm4_get(P, c, col) + b1v[k]) + ov[k];
+      if (c < rows_here) {
+        const float val = (col_gemm4_get(P, c, col) + b1v[k]) + ov[k];
+        tp[(long)c * tcs + t] = val;
+        if (p.mode == 3 && p.kT && part == 1) p.kT[(long)b * p.kt_bs + ((long)(c >> 2) * p.out_cs + t) * 4 + (c & 3)] = val;      // [channel quad][column][4]
+        if (p.mode == 3 && p.vQ && part == 2) p.vQ[(long)b * p.kt_bs + ((long)(t >> 2) * C4_H + c) * 4 + (t & 3)] = val;
+      }
     }
     return;
   }
@@ -345,7 +350,12 @@ __global__ __launch_bounds__(256) void lngemm4_kernel(LnGemmP p) {
 #pragma unroll
   for (int k = 0; k < NVT; ++k) {
     const int c = rl + 64 * k;
-    if (c < rows_here) ob[(long)c * ocs + t] = (col_gemm4_get(P, c, col) + cb[k]) + pe_row_load(c2d, c);
+    if (c < rows_here) {
+      const float val = (col_gemm4_get(P, c, col) + cb[k]) + pe_row_load(c2d, c);
+      ob[(long)c * ocs + t] = val;
+      if (p.kT && part == 1) p.kT[(long)b * p.kt_bs + ((long)(c >> 2) * p.x_cs + t) * 4 + (c & 3)] = val;      // [channel quad][column][4]
+      if (p.vQ && part == 2) p.vQ[(long)b * p.kt_bs + ((long)(t >> 2) * H + c) * 4 + (t & 3)] = val;      // [column quad][192][4]
+    }
   }
 }
 

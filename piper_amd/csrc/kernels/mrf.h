@@ -36,19 +36,6 @@ template <int V> struct pe_int { static constexpr int value = V; };
 
 
 
-// element (vidx + sidx) .. + 3: vidx per lane, sidx wave-uniform (SGPR offset)
-#ifdef PE_EMU
-inline f32x4 pe_row_load4_so(const pe_rowsrc& r, int vidx, int sidx) {
-  if (vidx >= 0 && vidx < r.n && vidx + 4 > r.n) return pe_row_load4(r, vidx + sidx);      // (a straddling group: element-wise)
-  f32x4 z = {0.f, 0.f, 0.f, 0.f};
-  return pe_so_in_row(r, vidx, sidx, 4) ? pe_row_load4(r, vidx + sidx) : z;
-}
-#else
-__device__ __forceinline__ f32x4 pe_row_load4_so(pe_rowsrc r, int vidx, int sidx) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, vidx * 4, sidx * 4, 0));
-}
-#endif
-
 // One step's schedule: the NEXT step's loads (NVM weight fetches, then NDS LDS reads) spread between this step's NMF
 // MFMAs, K MFMAs per load. The two waves of a SIMD run in lockstep (same work, fair pipe arbitration), so a block of
 // loads in front of the MFMA burst is a bubble in BOTH at the same time; a load issued while the wave waits for the

@@ -75,6 +75,8 @@ struct AttnOP {
   const float* gamma; const float* beta;    // norm_layers_1
   float* x; long x_bs; int x_cs;            // residual in, LayerNorm output (in place)
   const float* wo4;                         // attn4_kernel: conv_o in pack4 order; SP = round_up(max len, 64) + 4 there
+  const float* kT; long kt_bs;              // attn4_kernel: K as [utterance][channel quad][column stride q_cs][4] (written by the q/k/v launch)
+  const float* vQ;                          // attn4_kernel: V as [utterance][column quad][192][4] (same batch stride)
   int xcd;                                  // attn4_kernel: XCD-contiguous column tiles (col4.h c4_tile)
 };
 static constexpr int ATT_QB = 32;           // queries per workgroup (one MFMA tile)
@@ -140,6 +142,8 @@ struct ColP {
   // colchain4_kernel<true> (mode 1): the last WN layer's res/skip conv in front -- GEMM 1 reads (w0.in0 + b0) + in1
   const float* in0; long in0_bs; int in0_cs;
   const float* w0; const float* b0;
+  float* kT; long kt_bs;                                // mode 3, optional: row part 1 also as [channel quad][column][4] (see LnGemmP)
+  float* vQ;                                            // ... and row part 2 as [column quad][192][4]
 };
 // ---- fused FFN (ffn.h): partial outputs per 48-row slice of the hidden dimension
 struct FfnP {
@@ -164,6 +168,13 @@ struct LnGemmP {
   // lngemm4_kernel, optional: rows >= split belong to a SECOND conv over the same LN(y) (enc_p.proj stacked with dp.pre):
   // they go to out2 (row 0 = GEMM row split) and take the per-utterance bias vector bias2 (speaker conditioning) as well
   int split; float* out2; long o2_bs; int o2_cs; const float* bias2; long bias2_bs;
+  // lngemm4_kernel, optional (q/k/v conv in front of attn4_kernel): row part 1 (the K rows) is ALSO written as
+  // kT[utterance][channel quad 48][column stride][4], so that the attention kernel takes four channel steps of a key as ONE
+  // 16-byte load that is contiguous across the lanes (= keys) of a wave
+  float* kT; long kt_bs;
+  // ... and row part 2 (the V rows) as vQ[utterance][column quad][192][4]: four keys of a channel per 16-byte load,
+  // contiguous across the lanes (= channels) of a wave (same batch stride kt_bs)
+  float* vQ;
 };
 
 // ---- durations, N(0,1) generator, length regulator (duration.h)

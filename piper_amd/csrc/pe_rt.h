@@ -59,6 +59,12 @@ inline f32x4 pe_row_load4(const pe_rowsrc& r, int idx) {
   for (int j = 0; j < 4; ++j) v[j] = (idx + j >= 0 && idx + j < r.n) ? r.p[idx + j] : 0.f;
   return v;
 }
+// element (vidx + sidx) .. + 3: vidx per lane, sidx wave-uniform (SGPR offset)
+inline f32x4 pe_row_load4_so(const pe_rowsrc& r, int vidx, int sidx) {
+  if (vidx >= 0 && vidx < r.n && vidx + 4 > r.n) return pe_row_load4(r, vidx + sidx);      // (a straddling group: element-wise)
+  f32x4 z = {0.f, 0.f, 0.f, 0.f};
+  return pe_so_in_row(r, vidx, sidx, 4) ? pe_row_load4(r, vidx + sidx) : z;
+}
 inline float pe_lrelu(float v, float slope) { return v > 0.f ? v : v * slope; }
 inline float pe_log2(float x) { return log2f(x); }
 inline float pe_sin_turns(float x) { return sinf(6.283185307179586f * x); }
@@ -184,6 +190,10 @@ __device__ __forceinline__ void pe_row_store4(pe_rowsrc r, int idx, float a, flo
 // four consecutive floats (16-byte aligned index) in one instruction
 __device__ __forceinline__ f32x4 pe_row_load4(pe_rowsrc r, int idx) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, idx * 4, 0, 0));
+}
+// element (vidx + sidx) .. + 3: vidx per lane, sidx wave-uniform (SGPR offset, outside the hardware's range check)
+__device__ __forceinline__ f32x4 pe_row_load4_so(pe_rowsrc r, int vidx, int sidx) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, vidx * 4, sidx * 4, 0));
 }
 // the hardware's transcendental units: log2, and sine / cosine of an angle given in turns (x = 1 is a full circle)
 __device__ __forceinline__ float pe_log2(float x) { return __builtin_amdgcn_logf(x); }
