@@ -75,7 +75,7 @@ void Engine::issue_stage_a() {
   const auto attn4_for = [&](const EncLayer& e) -> const float* {
     const bool attno_ok = pol_.attno && !pol_.attn_long && chain_q && pol_.chain4((long)B * T) && H_ == 192 && nh_ == 2 && dk_ == 96 &&
                           window_ <= 4 && e.o16;
-    return (attno_ok && pol_.attn4_cols((long)B * T)) ? w4_of(e.o16) : nullptr;
+    return (attno_ok && pol_.attn4_ids(T)) ? w4_of(e.o16) : nullptr;
   };
   for (auto& e : enc_) {
     kt_on_ = attn4_for(e) != nullptr;

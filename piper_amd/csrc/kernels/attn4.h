@@ -62,26 +62,26 @@ __global__ __launch_bounds__(256) void attn4_kernel(AttnOP p) {
   // same fragments are 96 dword loads per lane, and with the V chunk behind them a wave has 131 loads to issue against a
   // memory counter of 63: the first barrier then stands two memory round trips from kernel entry (phase stamps: 4.4 us).
   // (A plain transpose [key][192] was measured too: 16 bytes from each of 64 cache lines per instruction, 6.0 us.)
-  f32x4 kf[DK / 4];
+  f32x4 kfA[DK / 4], kfB[DK / 4];                  // two sets: the next unit's fragments fly under the current unit's MFMAs
   const pe_rowsrc ktd = pe_make_row(p.kT + (long)b * p.kt_bs, (H / 4) * p.q_cs * 4);
-  auto load_k = [&](int u) {                       // A[row = key][k = channel]: kT[head * DK / 4 + d4][64 kb + lane][0..3]
+  auto load_k = [&](int u, bool live, f32x4 (&kf)[DK / 4]) {       // A[row = key][k = channel]: kT[head * DK / 4 + d4][64 kb + lane][0..3]
     const int h = u & 1, kbk = u >> 1, j = kbk * 64 + lane;
-    const int o = j < Lb ? (h * (DK / 4) * p.q_cs + j) * 4 : -4;      // keys in [len, stride): finite or not, their scores are never read
+    const int o = (live && j < Lb) ? (h * (DK / 4) * p.q_cs + j) * 4 : -4;      // keys in [len, stride): finite or not, their scores are never read
 #pragma unroll
     for (int d4 = 0; d4 < DK / 4; ++d4) kf[d4] = pe_row_load4_so(ktd, o, d4 * p.q_cs * 4);      // (every quad row exists: the SGPR offset stays inside)
   };
-  f32x4 vf[NVT][8];
+  f32x4 vfA[NVT][8], vfB[NVT][8];
   // V comes as vQ[key quad][192][4] (written by the q/k/v launch like kT): lane = channel takes four keys per 16-byte
   // load and a wave reads 1 KB in one piece. (From the [channel][key] tensor every lane's 16 bytes sit in another cache
   // line: 64 lines per instruction, and the 96 KB a workgroup touches that way do not fit its L1.)
   const pe_rowsrc vqd = pe_make_row(p.vQ + (long)b * p.kt_bs, (Lb / 4) * H * 4);
-  auto load_v = [&](int kc) {                      // A[row = channel 64 m + lane][k = key]: four keys per 16-byte load
+  auto load_v = [&](int kc, bool live, f32x4 (&vf)[NVT][8]) {      // A[row = channel 64 m + lane][k = key]: four keys per 16-byte load
 #pragma unroll
     for (int m = 0; m < NVT; ++m)
 #pragma unroll
       for (int g = 0; g < 8; ++g) {
         const int key = 32 * kc + 4 * g;
-        vf[m][g] = pe_row_load4(vqd, key < Lb ? ((key >> 2) * H + 64 * m + lane) * 4 : -4);      // (keys >= len are masked where the fragment is used)
+        vf[m][g] = pe_row_load4(vqd, (live && key < Lb) ? ((key >> 2) * H + 64 * m + lane) * 4 : -4);      // (keys >= len are masked where the fragment is used)
       }
   };
   {
@@ -98,9 +98,9 @@ __global__ __launch_bounds__(256) void attn4_kernel(AttnOP p) {
       rv[u] = pe_row_load(rvd, tid + 256 * u);
     }
     PE_SCHED_FENCE();
-    load_k(wv);
+    load_k(wv, true, kfA);
     PE_SCHED_FENCE();
-    load_v(wv);
+    load_v(wv, true, vfA);
     PE_SCHED_FENCE();
     if (i0 >= T) return;                           // first use of the length
 #pragma unroll
@@ -120,21 +120,37 @@ __global__ __launch_bounds__(256) void attn4_kernel(AttnOP p) {
   PE_STAMP(0, 1);
 
   // ---- 1. score units of this wave; relative-key partial logits on the VALU (216 threads: (head, query, offset) x 3 slices)
-  for (int u = wv; u < 2 * nkb; u += 4) {
-    if (u != wv) load_k(u);                        // (beyond two blocks per head: the fetch is exposed; long calls take attno_kernel)
-    const int h = u & 1, kbk = u >> 1;
-    f32x4 acc;
+  {
+    auto score = [&](int u, const f32x4 (&kf)[DK / 4]) {
+      const int h = u & 1, kbk = u >> 1;
+      f32x4 acc;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = 0.f;
-    const float* qp = Qs + (h * NC + l3) * QS;
+      for (int r = 0; r < 4; ++r) acc[r] = 0.f;
+      const float* qp = Qs + (h * NC + l3) * QS;
 #pragma unroll
-    for (int d4 = 0; d4 < DK / 4; ++d4) {
-      const f32x4 q4 = *reinterpret_cast<const f32x4*>(qp + 4 * d4);
+      for (int d4 = 0; d4 < DK / 4; ++d4) {
+        const f32x4 q4 = *reinterpret_cast<const f32x4*>(qp + 4 * d4);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc = pe_mfma_4x4x1(kf[d4][j], q4[j], acc);
+        for (int j = 0; j < 4; ++j) acc = pe_mfma_4x4x1(kf[d4][j], q4[j], acc);
+      }
+      // D[r] of lane l = S[key 64 kb + 4 (l >> 2) + r][query l & 3]: four consecutive keys of one row
+      *reinterpret_cast<f32x4*>(Sc + (h * NC + l3) * SP + 64 * kbk + 4 * lb) = acc;
+    };
+    // units wv, wv + 4, ..: the fetch of unit u + 4 is requested (unconditionally: zero-length reads behind the last unit)
+    // before unit u's MFMAs, into the other register set
+    const int nu = 2 * nkb;
+    for (int u = wv; u < nu; u += 8) {
+      PE_SCHED_FENCE();
+      load_k(u + 4, u + 4 < nu, kfB);
+      PE_SCHED_FENCE();
+      score(u, kfA);
+      if (u + 4 < nu) {
+        PE_SCHED_FENCE();
+        load_k(u + 8, u + 8 < nu, kfA);
+        PE_SCHED_FENCE();
+        score(u + 4, kfB);
+      }
     }
-    // D[r] of lane l = S[key 64 kb + 4 (l >> 2) + r][query l & 3]: four consecutive keys of one row
-    *reinterpret_cast<f32x4*>(Sc + (h * NC + l3) * SP + 64 * kbk + 4 * lb) = acc;
   }
   if (tid < NH * NC * 12) BV[tid] = 0.f;            // band slots outside the utterance stay 0 (softmax fills the others)
   if (tid < 3 * NH * NC * NREL) {
@@ -246,8 +262,7 @@ __global__ __launch_bounds__(256) void attn4_kernel(AttnOP p) {
     const float* pr[NVT];
 #pragma unroll
     for (int m = 0; m < NVT; ++m) pr[m] = Sc + (((64 * m + 4 * lb) >= DK ? NC : 0) + l3) * SP;
-    for (int kc = wv; kc < nkc; kc += 4) {
-      if (kc != wv) load_v(kc);
+    auto chunk = [&](int kc, const f32x4 (&vf)[NVT][8]) {
       const bool whole = 32 * kc + 32 <= T;        // a chunk that straddles the length zeroes the stale columns behind it
 #pragma unroll
       for (int m = 0; m < NVT; ++m)
@@ -261,6 +276,18 @@ __global__ __launch_bounds__(256) void attn4_kernel(AttnOP p) {
             acc[m] = pe_mfma_4x4x1(a, p4[e], acc[m]);
           }
         }
+    };
+    for (int kc = wv; kc < nkc; kc += 8) {          // (chunk kc + 4's fragments requested before chunk kc's MFMAs, like the K units)
+      PE_SCHED_FENCE();
+      load_v(kc + 4, kc + 4 < nkc, vfB);
+      PE_SCHED_FENCE();
+      chunk(kc, vfA);
+      if (kc + 4 < nkc) {
+        PE_SCHED_FENCE();
+        load_v(kc + 8, kc + 8 < nkc, vfA);
+        PE_SCHED_FENCE();
+        chunk(kc + 4, vfB);
+      }
     }
 #pragma unroll
     for (int m = 0; m < NVT; ++m)

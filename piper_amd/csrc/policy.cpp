@@ -28,8 +28,8 @@ static const LaunchPolicy::Knob kKnobs[] = {
     {"PIPER_HIP_COL4_MAXC", &LaunchPolicy::col4_maxc, 0, 1L << 40, "ids per call up to which the 4-column chains are used"},
     {"PIPER_HIP_FFN", &LaunchPolicy::ffn, 0, 1, "the encoder FFN as one launch (ffn_kernel) wherever the 4-column chains run: 0 = conv by conv"},
     {"PIPER_HIP_ATTNO", &LaunchPolicy::attno, 0, 1, "attention + conv_o + norm_layers_1 as one launch (attno_kernel) wherever the 4-column chains run: 0 = attn_kernel + colchain4_kernel"},
-    {"PIPER_HIP_ATTN4", &LaunchPolicy::attn4, 0, 2, "attention + conv_o + norm_layers_1 on 4-query workgroups (attn4_kernel) in place of attno_kernel: 0 off, 1 up to PIPER_HIP_ATTN4_MAXC ids per call, 2 wherever attno_kernel applies"},
-    {"PIPER_HIP_ATTN4_MAXC", &LaunchPolicy::attn4_maxc, 0, 1L << 40, "ids per call up to which attention runs on 4-query workgroups"},
+    {"PIPER_HIP_ATTN4", &LaunchPolicy::attn4, 0, 2, "attention + conv_o + norm_layers_1 on 4-query workgroups (attn4_kernel) in place of attno_kernel: 0 off, 1 for calls whose longest utterance has up to PIPER_HIP_ATTN4_MAXC ids, 2 wherever attno_kernel applies"},
+    {"PIPER_HIP_ATTN4_MAXC", &LaunchPolicy::attn4_maxc, 0, 1L << 40, "ids of the longest utterance of a call up to which attention runs on 4-query workgroups"},
     {"PIPER_HIP_FUSE_DP", &LaunchPolicy::fuse_dp, 0, 1, "ConvFlow.pre / proj / spline fused into the DDSConv layer launches"},
     {"PIPER_HIP_SPEC", &LaunchPolicy::spec, 0, 1, "speculative stage-B sizing / whole utterance as one graph for <= 4 utterances per call"},
     {"PIPER_HIP_SPEC_EXPECT", &LaunchPolicy::spec_expect, 0, 1, "speculative graphs planned for the expected frame counts (0: for the bucket capacity)"},

@@ -29,8 +29,8 @@ struct LaunchPolicy {
   long col4_maxc = 1024;      // ... up to this many ids per call (text encoder, duration predictor)
   long ffn = 1;               // encoder FFN as one launch (ffn_kernel) wherever the 4-column chains run
   long attno = 1;             // attention + conv_o + norm_layers_1 as one launch wherever the 4-column chains run
-  long attn4 = 1;             // ... on 4-query workgroups (attn4_kernel): 0 off, 1 up to attn4_maxc ids per call, 2 wherever attno applies
-  long attn4_maxc = 160;      // ids per call up to which attention runs on 4-query workgroups (each reads all of K and V: 4x attno's L2 traffic)
+  long attn4 = 1;             // ... on 4-query workgroups (attn4_kernel): 0 off, 1 for utterances up to attn4_maxc ids, 2 wherever attno applies
+  long attn4_maxc = 256;      // ids per UTTERANCE (the call's longest) up to which attention runs on 4-query workgroups: each reads all of K and V of its utterance, 4x attno's L2 traffic (break-even ~300 ids; any batch the 4-column chains take)
   long fuse_dp = 1;           // ConvFlow.pre / proj / spline fused into the DDSConv layer launches
   long spec = 1;              // speculative stage-B sizing: the whole utterance as one graph for <= spec_max_batch utterances
   long spec_expect = 1;       // speculative graphs planned for the expected frame counts (0: for the bucket capacity)
@@ -96,7 +96,7 @@ struct LaunchPolicy {
     return colchain && k1 == 192 && half == 96 && (colchain == 2 || cols <= (double)(frames ? colchain_max_frames : colchain_max_ids));
   }
   bool chain4(long cols, long limit = 0) const { return col4 && (col4 == 2 || cols <= (limit ? limit : col4_maxc)); }
-  bool attn4_cols(long cols) const { return attn4 == 2 || (attn4 == 1 && cols <= attn4_maxc); }
+  bool attn4_ids(long longest_utterance) const { return attn4 == 2 || (attn4 == 1 && longest_utterance <= attn4_maxc); }
   bool chain4_frames(long cols) const { return chain4(cols, col4_max_frames); }
   bool chain_rs_front(long cols) const { return chain_rs && chain4_frames(cols); }
   // fused MRF stage

@@ -263,8 +263,16 @@ FORCED = [
     ("medium", [128, 31], {"PIPER_HIP_FFN": 0}, {"lngemm4_kernel", "conv_splitk16_kernel<false,8,4,4>"}),
     # attention + conv_o + norm_layers_1 as one launch (default for small calls): on for a ragged batch incl. lengths on
     # both softmax paths, and off (attn_kernel + colchain4_kernel)
-    ("medium", [128, 13, 1, 129], {}, {"attno_kernel<96>", "lngemm4_kernel", "ffn_kernel"}),
-    ("high", [96, 40], {}, {"attno_kernel<96>"}),
+    # -- on 4-query workgroups while the call's longest utterance has up to 256 ids (attn4_kernel: the default for these
+    # shapes; K units / V chunks beyond the first of a wave from 129 ids on), on 16-query workgroups beyond and with
+    # PIPER_HIP_ATTN4=0 (attno_kernel), and as two launches
+    ("medium", [128, 13, 1, 129], {}, {"attn4_kernel<96>", "lngemm4_kernel", "ffn_kernel"}),
+    ("high", [96, 40], {}, {"attn4_kernel<96>"}),
+    ("medium", [256, 70, 200], {}, {"attn4_kernel<96>"}),
+    ("medium", [128, 13, 1, 129], {"PIPER_HIP_ATTN4": 0}, {"attno_kernel<96>", "lngemm4_kernel", "ffn_kernel"}),
+    ("high", [96, 40], {"PIPER_HIP_ATTN4": 0}, {"attno_kernel<96>"}),
+    ("medium", [300, 60], {}, {"attno_kernel<96>"}),
+    ("medium", [500], {"PIPER_HIP_ATTN4": 2}, {"attn4_kernel<96>"}),
     ("medium", [128, 31], {"PIPER_HIP_ATTNO": 0}, {"attn_kernel<96>", "colchain4_kernel<false>"}),
     # the up-convs' tiles stored one 4-byte piece per phase (default: 16- / 8-byte pieces of consecutive samples straight
     # from the accumulators: strides 8 and 4 on the medium voice, 8 and 2 on the high one), B = 1 and ragged batches
