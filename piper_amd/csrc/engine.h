@@ -21,6 +21,7 @@ struct PackedConv {
   float* wp = nullptr;      // device, packed for conv_mfma_kernel
   float* wp16 = nullptr;    // device, the same in 16x16x4 fragment order (conv_splitk16_kernel), long-K convs only
   float* wpb = nullptr;     // device, bf16 hi/lo split fragments (conv_bf3_kernel), matrix mode bf16x3 only
+  float* wpg4 = nullptr;    // device, gate convs over 192 channels in the 4x4x1 MFMA's order (gate4_kernel), or null
   float* bias = nullptr;    // device or null
   int rows = 0;             // GEMM rows (real)
   int mtiles = 0;           // packed 32-row tiles (padded to the block tile)

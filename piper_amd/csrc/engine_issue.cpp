@@ -111,9 +111,10 @@ void Engine::issue_stage_a() {
         ap.wo4 = wo4; ap.xcd = xcd_period_; ap.SP = rup(T, 64) + 4;
         ap.kT = kT_; ap.vQ = vQ_; ap.kt_bs = (long)Ts * H_;
         const size_t smem4 = ((size_t)8 * ap.SP + 8 * (dk_ + 4) + 2 * 9 * dk_ + 3 * 72 + 8 * 12 + 4 * 196 + 4 * 192 * 4 + 32) * sizeof(float);
-        const int kh = kbegin(prof_level_ >= 2 ? krow("attn4_kernel<96>") : 0, afl + 2.0 * tsum * e.o.macs_per_col,
-                              4.0 * (tsum * 5.0 * H_ + e.o.macs_per_col));
-        launch::attn4(dim3((T + 3) / 4, B), smem4, stream_, ap);
+        const bool long_rows = T > 128;           // more than one K unit / V chunk per wave: double-buffered fragments
+        const int kh = kbegin(prof_level_ >= 2 ? krow(long_rows ? "attn4_kernel<96,true>" : "attn4_kernel<96,false>") : 0,
+                              afl + 2.0 * tsum * e.o.macs_per_col, 4.0 * (tsum * 5.0 * H_ + e.o.macs_per_col));
+        launch::attn4(long_rows, dim3((T + 3) / 4, B), smem4, stream_, ap);
         kend(kh);
       } else {
       const int kh = kbegin(prof_level_ >= 2 ? krow("attno_kernel<96>") : 0, afl + 2.0 * tsum * e.o.macs_per_col,

@@ -136,7 +136,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
                   int bias2_bs) {
   ConvP p;
   p.x = x.p; p.x_bs = x.bs; p.x_cs = x.cs;
-  p.wp = pc.wp; p.wp16 = pc.wp16; p.wpb = pc.wpb; p.bias = pc.bias;
+  p.wp = pc.wp; p.wp16 = pc.wp16; p.wpb = pc.wpb; p.wpg4 = nullptr; p.bias = pc.bias;
   p.bias2 = bias2; p.bias2_bs = bias2_bs;
   p.out = out.p; p.o_bs = out.bs; p.o_cs = out.cs;
   p.res = res.p; p.r_bs = res.bs; p.r_cs = res.cs;
@@ -196,6 +196,17 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     group_ncols_ = ncols;
     group_flops_ += kflops;
     group_bytes_ += kbytes;
+    return;
+  }
+  if (pol_.splitk(blocks, p.xhalo, pc.Cin) && epi == EPI_GATE &&
+      pol_.gate_12col(pc.gate, pc.wpg4 != nullptr && pc.Cin == 192, pc.ntaps, pc.dil, (long)((ncols + 11) / 12) * (pc.split / 32) * B_)) {
+    // the WN gate conv of a short call: 64 rows x 12 columns per workgroup on the 4x4x1 MFMA (kernels/gate4.h)
+    p.wpg4 = pc.wpg4;
+    const dim3 grid((ncols + 11) / 12, pc.split / 32, B_);
+    const size_t smem = ((size_t)16 * 196 + (size_t)12 * 64 * 12) * sizeof(float);
+    const int kh = kbegin(prof_level_ >= 2 ? krow("gate4_kernel") : 0, kflops, kbytes);
+    launch::gate4(grid, smem, ls_, p);
+    kend(kh);
     return;
   }
   if (pol_.splitk(blocks, p.xhalo, pc.Cin)) {

@@ -121,6 +121,22 @@ PackedConv Engine::pack_matrix(const std::vector<float>& W, int rows, int Cin, i
               }
     pc.wp16 = dev_alloc(nq, skeleton_ ? nullptr : Q.data());
   }
+  if (gate && Cin == 192 && ntaps <= 5 && dil == 1 && split % 32 == 0) {
+    // gate4_kernel (kernels/gate4.h): [group of 32 channels][tap][k quad 48][lane][4]; lane l < 32: the tanh row of channel
+    // 32 g + l, l >= 32: the sigmoid row of channel 32 g + l - 32; float4 element j of quad q = input channel 4 q + j
+    const int ng = split / 32;
+    const size_t n4 = (size_t)ng * ntaps * (Cin / 4) * 256;
+    std::vector<float> G(skeleton_ ? 0 : n4, 0.f);
+    for (int g = 0; g < (skeleton_ ? 0 : ng); ++g)
+      for (int tap = 0; tap < ntaps; ++tap)
+        for (int q = 0; q < Cin / 4; ++q)
+          for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 4; ++j) {
+              const int ch = g * 32 + (lane & 31), row = lane < 32 ? ch : split + ch;
+              G[((((size_t)g * ntaps + tap) * (Cin / 4) + q) * 64 + lane) * 4 + j] = W[((size_t)row * Cin + 4 * q + j) * ntaps + tap];
+            }
+    pc.wpg4 = dev_alloc(n4, skeleton_ ? nullptr : G.data());
+  }
   if (pack_bf3_now_) {
     // conv_bf3_kernel (kernels/conv_bf3.h): every weight as hi = bf16(w), lo = bf16(w - hi), in the A-operand order of
     // v_mfma_f32_32x32x16_bf16: [m tile][chunk][tap][part hi|lo][k-step][lane][8], lane -> row = lane & 31, input channel

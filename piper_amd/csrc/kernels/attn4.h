@@ -26,7 +26,10 @@ namespace pe {
 // same as a 16-query workgroup -- 4x the L2 traffic per launch, which is why the launcher (policy.h: attn4) takes this form
 // only for short calls. Masked keys (>= len) get weight exactly 0, like the reference's -1e4 fill in fp32. The sums run in
 // another order than attno_kernel's (keys in 32-key chunks across the waves): a different rounding of the same values.
-template <int DK>
+// DB: utterances of more than 128 ids (more than one K unit / V chunk per wave) request the next unit's fragments into a
+// second register set before the current unit's MFMAs (T = 384: 28.9 -> 20.9 us per launch); up to 128 ids there is no next
+// unit and the second set only costs registers (10.9 -> 12.4 us), so the launcher picks <DK, false> there.
+template <int DK, bool DB>
 __global__ __launch_bounds__(256) void attn4_kernel(AttnOP p) {
   PE_KTRACE(14);
   constexpr int NH = 2, H = NH * DK, NC = 4, NVT = 3, KS1 = Col4W<H>::KS, QS = DK + 4, NREL = 9;
@@ -139,16 +142,23 @@ __global__ __launch_bounds__(256) void attn4_kernel(AttnOP p) {
     // units wv, wv + 4, ..: the fetch of unit u + 4 is requested (unconditionally: zero-length reads behind the last unit)
     // before unit u's MFMAs, into the other register set
     const int nu = 2 * nkb;
-    for (int u = wv; u < nu; u += 8) {
-      PE_SCHED_FENCE();
-      load_k(u + 4, u + 4 < nu, kfB);
-      PE_SCHED_FENCE();
-      score(u, kfA);
-      if (u + 4 < nu) {
+    if constexpr (DB) {
+      for (int u = wv; u < nu; u += 8) {
         PE_SCHED_FENCE();
-        load_k(u + 8, u + 8 < nu, kfA);
+        load_k(u + 4, u + 4 < nu, kfB);
         PE_SCHED_FENCE();
-        score(u + 4, kfB);
+        score(u, kfA);
+        if (u + 4 < nu) {
+          PE_SCHED_FENCE();
+          load_k(u + 8, u + 8 < nu, kfA);
+          PE_SCHED_FENCE();
+          score(u + 4, kfB);
+        }
+      }
+    } else {
+      for (int u = wv; u < nu; u += 4) {
+        if (u != wv) load_k(u, true, kfA);          // (never taken up to 128 ids)
+        score(u, kfA);
       }
     }
   }
@@ -277,16 +287,23 @@ __global__ __launch_bounds__(256) void attn4_kernel(AttnOP p) {
           }
         }
     };
-    for (int kc = wv; kc < nkc; kc += 8) {          // (chunk kc + 4's fragments requested before chunk kc's MFMAs, like the K units)
-      PE_SCHED_FENCE();
-      load_v(kc + 4, kc + 4 < nkc, vfB);
-      PE_SCHED_FENCE();
-      chunk(kc, vfA);
-      if (kc + 4 < nkc) {
+    if constexpr (DB) {
+      for (int kc = wv; kc < nkc; kc += 8) {        // (chunk kc + 4's fragments requested before chunk kc's MFMAs, like the K units)
         PE_SCHED_FENCE();
-        load_v(kc + 8, kc + 8 < nkc, vfA);
+        load_v(kc + 4, kc + 4 < nkc, vfB);
         PE_SCHED_FENCE();
-        chunk(kc + 4, vfB);
+        chunk(kc, vfA);
+        if (kc + 4 < nkc) {
+          PE_SCHED_FENCE();
+          load_v(kc + 8, kc + 8 < nkc, vfA);
+          PE_SCHED_FENCE();
+          chunk(kc + 4, vfB);
+        }
+      }
+    } else {
+      for (int kc = wv; kc < nkc; kc += 4) {
+        if (kc != wv) load_v(kc, true, vfA);
+        chunk(kc, vfA);
       }
     }
 #pragma unroll

@@ -21,6 +21,8 @@ void conv1x1(dim3 grid, hipStream_t stream, const ConvP& p);
 void conv_splitk(bool gate, int nw, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p);
 // half (gate only): half a 32-channel group per workgroup on six waves with the whole K range in flight (conv_splitk.h GT = 2)
 void conv_splitk16(bool gate, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p, bool half = false);
+// WN gate conv of short calls on 64-row x 12-column workgroups (gate4.h): grid = (12-column tiles, 32-channel groups, utterances)
+void gate4(dim3 grid, size_t smem, hipStream_t stream, const ConvP& p);
 void conv_group(bool wide, dim3 grid, size_t smem, hipStream_t stream, const ConvG& g);
 // the tiled kernel on up to three sibling convs of one tile configuration (conv_mfma.h: conv_mfma_group_kernel)
 void conv_tile_group(int cfg, int halo, dim3 grid, size_t smem, hipStream_t stream, const ConvG& g);
@@ -37,7 +39,7 @@ void embed(dim3 grid, hipStream_t stream, const int* ids, int ids_bs, const int*
            float* out, long o_bs, int o_cs, unsigned long long* rng);
 void attention(int dk, dim3 grid, size_t smem, hipStream_t stream, const AttnP& p);
 void attno(dim3 grid, size_t smem, hipStream_t stream, const AttnOP& p);        // attention + conv_o + LN, dk = 96 x 2 heads (attno.h)
-void attn4(dim3 grid, size_t smem, hipStream_t stream, const AttnOP& p);        // the same on 4-query workgroups (attn4.h)
+void attn4(bool long_rows, dim3 grid, size_t smem, hipStream_t stream, const AttnOP& p);   // the same on 4-query workgroups (attn4.h); long_rows: more than 128 ids per utterance
 void layer_norm(dim3 grid, hipStream_t stream, const LnP& p);
 void dds_layer(int nchunks, dim3 grid, size_t smem, hipStream_t stream, const DdsP& p);
 void dds_layer4(dim3 grid, size_t smem, hipStream_t stream, const DdsP& p);      // 4-column form, 192 channels (dds4.h)

@@ -4,6 +4,7 @@
 #include "conv_mfma.h"
 #include "conv1x1.h"
 #include "conv_splitk.h"
+#include "gate4.h"
 
 namespace pe {
 namespace launch {
@@ -74,6 +75,10 @@ void conv_splitk16(bool gate, dim3 grid, size_t smem, hipStream_t stream, const 
   if (gate && half) PE_LAUNCH((conv_splitk16_kernel<true, 6, 5, 2>), grid, dim3(64 * 6), smem, stream, p);
   else if (gate) PE_LAUNCH((conv_splitk16_kernel<true, 12, 2>), grid, dim3(64 * 12), smem, stream, p);
   else PE_LAUNCH((conv_splitk16_kernel<false, 8, 4>), grid, dim3(64 * 8), smem, stream, p);
+}
+
+void gate4(dim3 grid, size_t smem, hipStream_t stream, const ConvP& p) {
+  PE_LAUNCH(gate4_kernel, grid, dim3(64 * G4_NW), smem, stream, p);
 }
 
 void conv_group(bool wide, dim3 grid, size_t smem, hipStream_t stream, const ConvG& g) {

@@ -20,7 +20,7 @@ void init_front() {
 #ifndef PE_EMU
   const int lim = 160 * 1024;
   const void* ks[] = {(const void*)attn_kernel<0>, (const void*)attn_kernel<48>, (const void*)attn_kernel<96>,
-                      (const void*)attno_kernel<96>, (const void*)attn4_kernel<96>};
+                      (const void*)attno_kernel<96>, (const void*)attn4_kernel<96, false>, (const void*)attn4_kernel<96, true>};
   for (const void* k : ks) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
 #endif
 }
@@ -47,8 +47,9 @@ void attno(dim3 grid, size_t smem, hipStream_t stream, const AttnOP& p) {
   PE_LAUNCH(attno_kernel<96>, grid, dim3(512), smem, stream, p);
 }
 
-void attn4(dim3 grid, size_t smem, hipStream_t stream, const AttnOP& p) {
-  PE_LAUNCH(attn4_kernel<96>, grid, dim3(256), smem, stream, p);
+void attn4(bool long_rows, dim3 grid, size_t smem, hipStream_t stream, const AttnOP& p) {
+  if (long_rows) PE_LAUNCH((attn4_kernel<96, true>), grid, dim3(256), smem, stream, p);
+  else PE_LAUNCH((attn4_kernel<96, false>), grid, dim3(256), smem, stream, p);
 }
 
 void layer_norm(dim3 grid, hipStream_t stream, const LnP& p) { PE_LAUNCH(ln_kernel, grid, dim3(256), 0, stream, p); }

@@ -16,6 +16,7 @@ struct ConvP {
   const float* wp;                              // packed weights (engine_pack.cpp: pack_conv)
   const float* wp16;                            // conv_splitk16_kernel: the same in 16x16x4 fragment order, or null
   const float* wpb;                             // conv_bf3_kernel: bf16 hi/lo split fragments (engine_pack.cpp pack_matrix), or null
+  const float* wpg4;                            // gate4_kernel: the gate conv in [group][tap][k quad][lane][4] order (192 input channels), or null
   const float* bias;                            // per output channel or null
   const float* bias2; int bias2_bs;             // per-utterance extra bias (speaker cond) or null
   float* out; long o_bs; int o_cs;

@@ -30,7 +30,7 @@ struct LaunchPolicy {
   long ffn = 1;               // encoder FFN as one launch (ffn_kernel) wherever the 4-column chains run
   long attno = 1;             // attention + conv_o + norm_layers_1 as one launch wherever the 4-column chains run
   long attn4 = 1;             // ... on 4-query workgroups (attn4_kernel): 0 off, 1 for utterances up to attn4_maxc ids, 2 wherever attno applies
-  long attn4_maxc = 256;      // ids per UTTERANCE (the call's longest) up to which attention runs on 4-query workgroups: each reads all of K and V of its utterance, 4x attno's L2 traffic (break-even ~300 ids; any batch the 4-column chains take)
+  long attn4_maxc = 512;      // ids per UTTERANCE (the call's longest) up to which attention runs on 4-query workgroups: each reads all of K and V of its utterance, 4x attno's L2 traffic (measured up to 512 ids: 25.0 against 35.8 us; any batch the 4-column chains take)
   long fuse_dp = 1;           // ConvFlow.pre / proj / spline fused into the DDSConv layer launches
   long spec = 1;              // speculative stage-B sizing: the whole utterance as one graph for <= spec_max_batch utterances
   long spec_expect = 1;       // speculative graphs planned for the expected frame counts (0: for the bucket capacity)
@@ -42,6 +42,7 @@ struct LaunchPolicy {
   long xcd_ffn = 1;           // fused FFN: (column tile, slice) dealt to the XCDs slice-major (0: blockIdx order)
   long stack_pre = 1;         // small calls: enc_p.proj and dp.pre as one lngemm4_kernel launch over the stacked matrix (0: two launches)
   long chain_rs = 1;          // small calls: the last WN layer's res/skip conv in front of the post + pre chain launch (0: a launch of its own)
+  long gate4 = 1;             // one-utterance-sized calls: the WN gate conv over 192 channels on 64-row x 12-column workgroups with the 4x4x1 MFMA (gate4_kernel)
   long gate_half = 1;         // short one-utterance calls: the WN gate conv on half a 32-channel group per workgroup (6 waves) while twice the workgroups still fit one per CU
   long conv1x1 = 1;           // batched one-tap convs through conv1x1_kernel (B operand straight from global memory): 0 = the tiled kernel
   long ws_budget_mb = 0;      // MiB a stage's workspace may take: 0 = a third of the device's memory
@@ -89,6 +90,10 @@ struct LaunchPolicy {
   }
   bool gate_half_groups(bool gate, int nchunks, int ntaps, long workgroups_whole) const {
     return gate_half && gate && nchunks == 6 && ntaps <= 5 && 2 * workgroups_whole <= 256;      // one workgroup per CU at most
+  }
+  // the 12-column form: more, smaller workgroups than the 16-column split-K form while they still fit one per CU
+  bool gate_12col(bool gate, bool packed4, int ntaps, int dil, long workgroups) const {
+    return gate4 && gate && packed4 && ntaps <= 5 && dil == 1 && (gate4 == 2 || workgroups <= 256);
   }
   int tiles_per_workgroup() const { return tpb > 0 ? (int)tpb : 1; }
   // 192-channel chains

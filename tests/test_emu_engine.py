@@ -392,8 +392,8 @@ def test_emulated_192_channel_small_call_kernels(emu_lib, monkeypatch, col4):
     names = {row["name"] for row in eng.profile()[5:] if row["launches"]}
     # small calls: attention + conv_o + norm_layers_1 as one launch (short calls like this one: on 4-query workgroups,
     # attn4_kernel; longer ones attno_kernel); the 16-column forms keep two
-    assert ("attn4_kernel<96>" if col4 == "1" else "attn_kernel<96>") in names
-    assert not ({"attn_kernel<96>", "attno_kernel<96>"} if col4 == "1" else {"attno_kernel<96>", "attn4_kernel<96>"}) & names
+    assert ("attn4_kernel<96,false>" if col4 == "1" else "attn_kernel<96>") in names
+    assert not ({"attn_kernel<96>", "attno_kernel<96>"} if col4 == "1" else {"attno_kernel<96>", "attn4_kernel<96,false>", "attn4_kernel<96,true>"}) & names
     assert ({"colchain4_kernel<false>", "lngemm4_kernel", "dds_layer4_kernel", "ffn_kernel"} if col4 == "1" else
             {"colchain_kernel<6>", "lngemm_kernel<6>", "dds_layer16_kernel<6>"}) <= names
     assert not ({"colchain_kernel<6>", "lngemm_kernel<6>", "dds_layer16_kernel<6>"} if col4 == "1" else
@@ -517,7 +517,8 @@ def test_emulated_attention_conv_o_layernorm_in_one_launch(emu_lib, monkeypatch,
         r = eng.synthesize_batch(ids, (0.0, 1.0, 0.8), noise_w=nw, sids=sids)
         names = {row["name"] for row in eng.profile()[5:] if row["launches"]}
         assert ("attno_kernel<96>" in names) == (on == "1") and ("attn_kernel<96>" in names) == (on == "0"), names
-        assert ("attn4_kernel<96>" in names) == (on == "4"), names
+        # (up to 128 ids per utterance: one K unit / V chunk per wave, <96,false>; beyond: double-buffered fragments, <96,true>)
+        assert (("attn4_kernel<96,true>" if max(lens) > 128 else "attn4_kernel<96,false>") in names) == (on == "4"), names
         res[on] = (r, eng.durations(), [eng.debug_tensor("x_enc", i) for i in range(len(lens))])
         eng.close()
     off = np.concatenate([[0], np.cumsum(lens)])
@@ -848,3 +849,30 @@ def test_coalescer_batches_concurrent_requests(emu_lib):
     assert a[1] >= out[1][1]
     co.close()
     eng.close()
+
+
+@pytest.mark.parametrize("lens,sids", [([9, 13], None), ([30], [1])])
+def test_emulated_gate_conv_on_12_column_workgroups(emu_lib, monkeypatch, lens, sids):
+    """gate4_kernel (kernels/gate4.h): the WN gate conv over 192 channels (modules.py:196-199, commons.py:99-106) on 64-row x
+    12-column workgroups with the 4x4x1 MFMA -- 12 waves, each 16 input channels x every tap x three 4-column groups, the
+    partial tiles summed in wave order -- against the 16-column split-K form (PIPER_HIP_GATE4=0) and the oracle; ragged
+    lengths that end inside a 12-column tile, a multi-speaker voice (the per-utterance bias vector)."""
+    cfg = W.preset("tiny-ms" if sids else "tiny", hidden=192, inter=192, filter=96, n_layers=1)
+    w = W.synthetic_weights(cfg, 1234)
+    ids = [W.synthetic_phoneme_ids(T, 50 + i, id_max=cfg.n_vocab - 1) for i, T in enumerate(lens)]
+    nw, nz = _noise(cfg, len(lens), max(lens), 3)
+    scales = (0.5, 1.0, 0.8)
+    out = {}
+    for g4 in ("0", "2"):
+        monkeypatch.setenv("PIPER_HIP_GATE4", g4)
+        eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
+        eng.profile_enable(2)
+        r = eng.synthesize_batch(ids, scales, noise_w=nw, noise_z=nz, sids=sids)
+        names = {row["name"] for row in eng.profile()[5:] if row["launches"]}
+        assert ("gate4_kernel" in names) == (g4 == "2"), names
+        out[g4] = r.audio
+        eng.close()
+    for i in range(len(lens)):
+        o = O.synthesize(w, cfg, ids[i], scales, nw[i], nz[i], sid=None if sids is None else sids[i])
+        assert np.max(np.abs(out["2"][i] - o["audio"])) < 1e-5
+        assert np.max(np.abs(out["2"][i] - out["0"][i])) < 2e-6

@@ -234,7 +234,7 @@ FORCED = [
     ("medium", [96], {"PIPER_HIP_SPLITK16": 0, "PIPER_HIP_WIDE_SPLITK": 2},
      {"conv_splitk_kernel<2,true,12,2>", "conv_splitk_kernel<1,false,12,4>"}),
     ("x-low", [64], {"PIPER_HIP_SPLITK16": 0, "PIPER_HIP_WIDE_SPLITK": 0}, {"conv_splitk_kernel<2,true,4,3>"}),
-    ("medium", [128, 17], {"PIPER_HIP_SPLITK16": 3},
+    ("medium", [128, 17], {"PIPER_HIP_SPLITK16": 3, "PIPER_HIP_GATE4": 0},
      {"conv_splitk16_kernel<true,12,2,4>", "conv_splitk16_kernel<false,8,4,4>"}),
     # enc_p.proj + dp.pre as one launch over the stacked matrix is the default of small calls (every case above with the
     # 4-column chains on; multi-speaker: test_full_size_multi_speaker_matches_oracle); here as two launches
@@ -249,8 +249,8 @@ FORCED = [
     ("medium", [128, 31], {}, {"colchain4_kernel<true>", "colchain4_kernel<false>"}),
     ("medium", [128, 31], {"PIPER_HIP_CHAIN_RS": 0}, {"colchain4_kernel<false>"}),
     # a short utterance: the gate conv on half channel groups (six waves, twice the workgroups), and forced back to whole groups
-    ("medium", [48], {}, {"conv_splitk16_kernel<true,6,5,2>"}),
-    ("medium", [48], {"PIPER_HIP_GATE_HALF": 0}, {"conv_splitk16_kernel<true,12,2,4>"}),
+    ("medium", [48], {"PIPER_HIP_GATE4": 0}, {"conv_splitk16_kernel<true,6,5,2>"}),
+    ("medium", [48], {"PIPER_HIP_GATE_HALF": 0, "PIPER_HIP_GATE4": 0}, {"conv_splitk16_kernel<true,12,2,4>"}),
     ("high", [48], {"PIPER_HIP_SPLITK_MAX": 0}, {"conv_mfma_kernel<2,2,2,1,16,true,64>"}),
     # the 192-channel small-call chains (DDSConv layers, colchain, lngemm): the 4-column forms on the 4x4x1 MFMA (default for small calls) forced
     # on for a ragged batch beyond its column limit, and off (the 16-column form)
@@ -266,13 +266,21 @@ FORCED = [
     # -- on 4-query workgroups while the call's longest utterance has up to 256 ids (attn4_kernel: the default for these
     # shapes; K units / V chunks beyond the first of a wave from 129 ids on), on 16-query workgroups beyond and with
     # PIPER_HIP_ATTN4=0 (attno_kernel), and as two launches
-    ("medium", [128, 13, 1, 129], {}, {"attn4_kernel<96>", "lngemm4_kernel", "ffn_kernel"}),
-    ("high", [96, 40], {}, {"attn4_kernel<96>"}),
-    ("medium", [256, 70, 200], {}, {"attn4_kernel<96>"}),
+    ("medium", [128, 13, 1, 129], {}, {"attn4_kernel<96,true>", "lngemm4_kernel", "ffn_kernel"}),
+    ("medium", [128, 13, 1, 77], {}, {"attn4_kernel<96,false>"}),
+    ("high", [96, 40], {}, {"attn4_kernel<96,false>"}),
+    ("medium", [256, 70, 200], {}, {"attn4_kernel<96,true>"}),
+    ("medium", [500], {}, {"attn4_kernel<96,true>"}),
     ("medium", [128, 13, 1, 129], {"PIPER_HIP_ATTN4": 0}, {"attno_kernel<96>", "lngemm4_kernel", "ffn_kernel"}),
     ("high", [96, 40], {"PIPER_HIP_ATTN4": 0}, {"attno_kernel<96>"}),
-    ("medium", [300, 60], {}, {"attno_kernel<96>"}),
-    ("medium", [500], {"PIPER_HIP_ATTN4": 2}, {"attn4_kernel<96>"}),
+    ("medium", [600, 60], {}, {"attno_kernel<96>"}),
+    ("medium", [700], {"PIPER_HIP_ATTN4": 2}, {"attn4_kernel<96,true>"}),
+    # the WN gate conv of one-utterance-sized calls on 64-row x 12-column workgroups (gate4_kernel: the default), and the
+    # 16-column split-K forms it replaces
+    ("medium", [128], {}, {"gate4_kernel"}),
+    ("high", [77], {}, {"gate4_kernel"}),
+    ("medium", [128], {"PIPER_HIP_GATE4": 0}, {"conv_splitk16_kernel<true,12,2,4>"}),
+    ("medium", [40, 50], {"PIPER_HIP_GATE4": 2}, {"gate4_kernel"}),
     ("medium", [128, 31], {"PIPER_HIP_ATTNO": 0}, {"attn_kernel<96>", "colchain4_kernel<false>"}),
     # the up-convs' tiles stored one 4-byte piece per phase (default: 16- / 8-byte pieces of consecutive samples straight
     # from the accumulators: strides 8 and 4 on the medium voice, 8 and 2 on the high one), B = 1 and ragged batches
