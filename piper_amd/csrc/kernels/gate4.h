@@ -25,6 +25,7 @@ __global__ __launch_bounds__(64 * G4_NW) void gate4_kernel(ConvP p) {
   float* XT = sm;
   float* P = XT + G4_WC * G4_XS;
   const int b = blockIdx.z, grp = blockIdx.y;
+  PE_STAMP(5, 0);
   const int L = p.lens[b] * p.len_mul;            // first used after every load below is requested
   const int n0 = blockIdx.x * G4_NC;
   const int tid = threadIdx.x, lane = tid & 63, wv = PE_UNIFORM(tid >> 6);
@@ -50,6 +51,7 @@ __global__ __launch_bounds__(64 * G4_NW) void gate4_kernel(ConvP p) {
   }
   PE_SCHED_FENCE();
   if (n0 >= L) return;
+  PE_STAMP(5, 1);
   {
     const float slope = p.in_slope;
 #pragma unroll
@@ -61,6 +63,7 @@ __global__ __launch_bounds__(64 * G4_NW) void gate4_kernel(ConvP p) {
     }
   }
   __syncthreads();
+  PE_STAMP(5, 2);
   // ---- this wave's partial tile over its 16 channels x ntaps
   {
     f32x4 acc[3];
@@ -89,7 +92,9 @@ __global__ __launch_bounds__(64 * G4_NW) void gate4_kernel(ConvP p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) P[(wv * 64 + 4 * lb + r) * G4_NC + 4 * g + l3] = acc[g][r];
   }
+  PE_STAMP(5, 3);
   __syncthreads();
+  PE_STAMP(5, 4);
   // ---- the twelve partial tiles in wave order, biases, tanh * sigmoid (commons.py:99-106)
   if (tid < 32 * G4_NC) {
     const int c = tid / G4_NC, col = tid - c * G4_NC;
@@ -104,6 +109,7 @@ __global__ __launch_bounds__(64 * G4_NW) void gate4_kernel(ConvP p) {
       conv_store_gate(p, b, ch, t, ta, sa);
     }
   }
+  PE_STAMP(5, 5);
 }
 
 }  // namespace pe

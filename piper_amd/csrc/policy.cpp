@@ -41,7 +41,7 @@ static const LaunchPolicy::Knob kKnobs[] = {
     {"PIPER_HIP_XCD_FFN", &LaunchPolicy::xcd_ffn, 0, 1, "ffn_kernel deals (column tile, slice) to the XCDs slice-major, so an XCD's L2 holds two slices' weights instead of all sixteen (0: blockIdx order)"},
     {"PIPER_HIP_STACK_PRE", &LaunchPolicy::stack_pre, 0, 1, "small calls of the 192-channel voices: enc_p.proj and dp.pre (both read the last LayerNorm's output) as one lngemm4_kernel launch over the stacked matrix (0: two launches)"},
     {"PIPER_HIP_CHAIN_RS", &LaunchPolicy::chain_rs, 0, 1, "small calls of the 192-channel voices: the last WN layer's res/skip conv (skip rows only) in front of the coupling layer's post + pre chain launch, colchain4_kernel<true> (0: a launch of its own)"},
-    {"PIPER_HIP_GATE4", &LaunchPolicy::gate4, 0, 2, "one-utterance-sized calls: the WN gate conv over 192 channels on 64-row x 12-column workgroups with the 4x4x1 MFMA (gate4_kernel) while they fit one per CU: 0 off (16-column split-K form), 2 wherever the split-K route applies"},
+    {"PIPER_HIP_GATE4", &LaunchPolicy::gate4, 0, 2, "short calls: the WN gate conv over 192 channels on 64-row x 12-column workgroups with the 4x4x1 MFMA (gate4_kernel) up to 640 workgroups: 0 off (16-column split-K form), 2 wherever the split-K route applies"},
     {"PIPER_HIP_GATE_HALF", &LaunchPolicy::gate_half, 0, 1, "short one-utterance calls (up to 128 whole-group workgroups): the WN gate conv on half a 32-channel group per workgroup, six waves with the whole K range in flight, twice the workgroups (0: whole groups on twelve waves)"},
     {"PIPER_HIP_CONV1X1", &LaunchPolicy::conv1x1, 0, 1, "batched one-tap convs (q/k/v, WN res/skip, coupling pre/post, proj) through conv1x1_kernel, B operand straight from global memory (0: the tiled kernel)"},
     {"PIPER_HIP_WS_BUDGET_MB", &LaunchPolicy::ws_budget_mb, 0, 1048576, "MiB of device memory the workspace of one pipeline half may take (0: a third of the device's memory): capacities grow only inside it, a call that does not fit by itself is an error"},

@@ -42,7 +42,7 @@ struct LaunchPolicy {
   long xcd_ffn = 1;           // fused FFN: (column tile, slice) dealt to the XCDs slice-major (0: blockIdx order)
   long stack_pre = 1;         // small calls: enc_p.proj and dp.pre as one lngemm4_kernel launch over the stacked matrix (0: two launches)
   long chain_rs = 1;          // small calls: the last WN layer's res/skip conv in front of the post + pre chain launch (0: a launch of its own)
-  long gate4 = 1;             // one-utterance-sized calls: the WN gate conv over 192 channels on 64-row x 12-column workgroups with the 4x4x1 MFMA (gate4_kernel)
+  long gate4 = 1;             // short calls: the WN gate conv over 192 channels on 64-row x 12-column workgroups with the 4x4x1 MFMA (gate4_kernel) up to 640 workgroups
   long gate_half = 1;         // short one-utterance calls: the WN gate conv on half a 32-channel group per workgroup (6 waves) while twice the workgroups still fit one per CU
   long conv1x1 = 1;           // batched one-tap convs through conv1x1_kernel (B operand straight from global memory): 0 = the tiled kernel
   long ws_budget_mb = 0;      // MiB a stage's workspace may take: 0 = a third of the device's memory
@@ -91,9 +91,12 @@ struct LaunchPolicy {
   bool gate_half_groups(bool gate, int nchunks, int ntaps, long workgroups_whole) const {
     return gate_half && gate && nchunks == 6 && ntaps <= 5 && 2 * workgroups_whole <= 256;      // one workgroup per CU at most
   }
-  // the 12-column form: more, smaller workgroups than the 16-column split-K form while they still fit one per CU
+  // the 12-column form: more, smaller workgroups than the 16-column split-K form. Measured (profiles/r05_notes.md, call 12):
+  // equal at 210 workgroups (128 ids: 9.4 against 10.6 us per launch, step +-0.1 %), -12 % per launch at 420 (256 ids or two
+  // utterances: step -3.1 %), +4 % at 840 (four utterances)
+  static constexpr long gate4_max_workgroups = 640;
   bool gate_12col(bool gate, bool packed4, int ntaps, int dil, long workgroups) const {
-    return gate4 && gate && packed4 && ntaps <= 5 && dil == 1 && (gate4 == 2 || workgroups <= 256);
+    return gate4 && gate && packed4 && ntaps <= 5 && dil == 1 && (gate4 == 2 || workgroups <= gate4_max_workgroups);
   }
   int tiles_per_workgroup() const { return tpb > 0 ? (int)tpb : 1; }
   // 192-channel chains

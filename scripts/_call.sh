@@ -1,9 +1,5 @@
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/c11; mkdir -p $O
-BQ="--no-extra --no-cpu-baseline --min-seconds 0.3"
-run() { name=$1; shift; PIPER_BENCH_FULL=$O/$name.json timeout 300 python bench.py $BQ "$@" > /dev/null 2>> $O/err.log; }
-for r in 1 2; do PIPER_HIP_ATTN4=0 run a4off_$r --steps 200; PIPER_HIP_ATTN4=1 run a4on_$r --steps 200; done
-python scripts/_show_kernels.py attn $O/a4*.json
-for T in 64 192 256 320 384 512; do PIPER_HIP_ATTN4=0 run a4off_T$T --steps 60 --ids $T; PIPER_HIP_ATTN4=2 run a4on_T$T --steps 60 --ids $T; done
-python scripts/_show_kernels.py attn $O/a4*_T*.json
-timeout 1200 python -m pytest tests -m gpu -q -x -k "forced or medium_t128 or intermediate or ragged or sentences or no_kernel_reads or long" 2>&1 | tail -4
-grep -v amdgpu.ids $O/err.log | tail -5
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/c13; mkdir -p $O
+export PIPER_STAMPS_LIB=$GRAFT_REPO_ROOT/piper_amd/libab_stamps.so
+timeout 300 python scripts/stamps.py medium 128 2>&1 | tee $O/stamps.txt | head -8
+grep -E "conv_splitk16|gate|colchain   " $O/stamps.txt | tail -12
+PIPER_HIP_GATE4=0 timeout 300 python scripts/stamps.py medium 128 2>&1 | grep -E "conv_splitk16  " | tail -4

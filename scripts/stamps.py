@@ -18,7 +18,7 @@ from piper_amd import _lib as L, weights as W      # noqa: E402
 from piper_amd.engine import Engine                # noqa: E402
 
 KERNELS = {0: "attn_kernel / attno_kernel (0 entry, 1 operands in LDS, 2 scores, 3 band, 4 softmax, 5 V P^T, 6 O in LDS, 7 conv_o, 8 LayerNorm + store)", 1: "conv_splitk_kernel (last launch)", 2: "dds_layer16_kernel (last plain layer)",
-           3: "colchain_kernel mode 0 (conv_o + LN)", 4: "conv_post_kernel", 5: "ln_kernel",
+           3: "colchain_kernel mode 0 (conv_o + LN)", 4: "conv_post_kernel", 5: "ln_kernel / gate4_kernel (0 entry, 1 loads requested + length known, 2 window in LDS, 3 MFMAs done, 4 barrier, 5 epilogue done)",
            6: "colchain_kernel mode 1 (post + pre)", 7: "colchain_kernel mode 1 (post only)"}
 
 
