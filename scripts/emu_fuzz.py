@@ -48,6 +48,7 @@ def main():
         preset = str(rng.choice(["tiny", "tiny-high", "tiny-ms", "tiny-high-ms"]))
         B = int(rng.integers(1, 4))
         lens = [int(rng.integers(1, 40)) for _ in range(B)]
+        if hidden == 192 and rng.random() < 0.25: lens[0] = int(rng.integers(129, 200))      # attn4_kernel's double-buffered form
         ms = "ms" in preset
         case = {"preset": preset, "over": over, "lens": lens, "sids": [int(rng.integers(0, 4)) for _ in lens] if ms else None,
                 "wseed": int(rng.integers(1, 1 << 30)), "scales": [0.0, float(rng.choice([0.8, 1.0, 1.3])), 0.8]}
@@ -55,7 +56,9 @@ def main():
         for knob, vals in (("PIPER_HIP_SPLITK_MAX", ["", "0"]), ("PIPER_HIP_MRF", ["", "0", "2"]), ("PIPER_HIP_FUSE_DP", ["", "0"]),
                            ("PIPER_HIP_COLCHAIN", ["", "0"]), ("PIPER_HIP_SPLITK16", ["", "3"]), ("PIPER_HIP_COL4", ["", "0", "2"]),
                            ("PIPER_HIP_ATTNO", ["", "0"]), ("PIPER_HIP_FFN", ["", "0"]), ("PIPER_HIP_GATE_HALF", ["", "0"]),
-                           ("PIPER_HIP_CONV1X1", ["", "0"]), ("PIPER_HIP_CHAIN_RS", ["", "0"]), ("PIPER_HIP_STACK_PRE", ["", "0"])):
+                           ("PIPER_HIP_CONV1X1", ["", "0"]), ("PIPER_HIP_CHAIN_RS", ["", "0"]), ("PIPER_HIP_STACK_PRE", ["", "0"]),
+                           ("PIPER_HIP_ATTN4", ["", "0", "2"]), ("PIPER_HIP_GATE4", ["", "0", "2"]), ("PIPER_HIP_GROUP_TILED", ["", "0"]),
+                           ("PIPER_HIP_DEBUG_POISON", ["", "1"])):
             v = str(rng.choice(vals))
             if v:
                 env[knob] = v
