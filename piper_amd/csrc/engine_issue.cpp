@@ -95,7 +95,8 @@ void Engine::issue_stage_a() {
     const size_t ao_smem = ((size_t)2 * 16 * ao_sp + 2 * 64 * (dk_ + 1) + 2 * dk_ * 16 + (size_t)2 * (2 * window_ + 1) * dk_ + 8 * 256 + 256) * sizeof(float);
     const bool attno = pol_.attno && !pol_.attn_long && chain_q && pol_.chain4((long)B * T) && H_ == 192 && nh_ == 2 && dk_ == 96 && window_ <= 4 && e.o16 &&
                        ao_smem <= (size_t)160 * 1024;
-    if (attno) {
+    const float* wo4 = kt_valid_ ? attn4_for(e) : nullptr;        // (the q/k/v launch of this layer wrote kT / vQ)
+    if (attno || wo4) {
       AttnOP ap{};
       ap.qkv = qkv_; ap.q_bs = (long)3 * H_ * Ts; ap.q_cs = Ts;
       ap.relk = e.relk; ap.relv = e.relv;
@@ -105,8 +106,8 @@ void Engine::issue_stage_a() {
       ap.x = x.p; ap.x_bs = x.bs; ap.x_cs = x.cs;
       double afl = 0;
       for (int b = 0; b < B; ++b) afl += 4.0 * (double)tlens_h_[b] * tlens_h_[b] * H_;
-      // short calls: 4-query workgroups (kernels/attn4.h: 32 workgroups for 128 ids instead of 8)
-      const float* wo4 = kt_valid_ ? attn4_for(e) : nullptr;      // (the q/k/v launch of this layer wrote kT)
+      // utterances up to PIPER_HIP_ATTN4_MAXC ids: 4-query workgroups (kernels/attn4.h: 32 workgroups for 128 ids instead of 8;
+      // its LDS need is a fraction of attno_kernel's, whose 16 x T score slabs of both heads end near 830 ids)
       if (wo4) {
         ap.wo4 = wo4; ap.xcd = xcd_period_; ap.SP = rup(T, 64) + 4;
         ap.kT = kT_; ap.vQ = vQ_; ap.kt_bs = (long)Ts * H_;

@@ -229,9 +229,9 @@ FORCED = [
     ("high", [40], {}, {"conv_splitk_group_kernel<4,2,64>", "conv_splitk_sum_kernel<4,2>"}),
     ("medium", [128], {"PIPER_HIP_GROUP_MRF": 0}, {"conv_splitk_kernel<1,false,4,4>"}),
     # split-K variants: 4/8-wave only (no 16-column form), 12-wave everywhere, 16-column form everywhere
-    ("medium", [128], {"PIPER_HIP_SPLITK16": 0, "PIPER_HIP_WIDE_SPLITK": 0, "PIPER_HIP_COL4": 0},
+    ("medium", [128], {"PIPER_HIP_SPLITK16": 0, "PIPER_HIP_WIDE_SPLITK": 0, "PIPER_HIP_COL4": 0, "PIPER_HIP_GATE4": 0},
      {"conv_splitk_kernel<2,true,8,3>", "conv_splitk_kernel<1,false,8,4>", "conv_splitk_kernel<1,false,4,4>"}),
-    ("medium", [96], {"PIPER_HIP_SPLITK16": 0, "PIPER_HIP_WIDE_SPLITK": 2},
+    ("medium", [96], {"PIPER_HIP_SPLITK16": 0, "PIPER_HIP_WIDE_SPLITK": 2, "PIPER_HIP_GATE4": 0},
      {"conv_splitk_kernel<2,true,12,2>", "conv_splitk_kernel<1,false,12,4>"}),
     ("x-low", [64], {"PIPER_HIP_SPLITK16": 0, "PIPER_HIP_WIDE_SPLITK": 0}, {"conv_splitk_kernel<2,true,4,3>"}),
     ("medium", [128, 17], {"PIPER_HIP_SPLITK16": 3, "PIPER_HIP_GATE4": 0},
@@ -273,7 +273,7 @@ FORCED = [
     ("medium", [500], {}, {"attn4_kernel<96,true>"}),
     ("medium", [128, 13, 1, 129], {"PIPER_HIP_ATTN4": 0}, {"attno_kernel<96>", "lngemm4_kernel", "ffn_kernel"}),
     ("high", [96, 40], {"PIPER_HIP_ATTN4": 0}, {"attno_kernel<96>"}),
-    ("medium", [600, 60], {}, {"attno_kernel<96>"}),
+    ("medium", [600], {}, {"attno_kernel<96>"}),
     ("medium", [700], {"PIPER_HIP_ATTN4": 2}, {"attn4_kernel<96,true>"}),
     # the WN gate conv of one-utterance-sized calls on 64-row x 12-column workgroups (gate4_kernel: the default), and the
     # 16-column split-K forms it replaces
