@@ -12,6 +12,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
 tmax_medium = int(sys.argv[3]) if len(sys.argv) > 3 else 220
 worst = 0.0
+edge = []
 for preset, tmax, cases in (("medium", tmax_medium, n), ("high", 90, n // 3), ("tiny-high-ms", 60, n // 2), ("x-low", 120, n // 3)):
     cfg = W.preset(preset)
     w = W.synthetic_weights(cfg, 99)
@@ -30,7 +31,20 @@ for preset, tmax, cases in (("medium", tmax_medium, n), ("high", 90, n // 3), ("
         except Exception as e:       # noise buffer too short for a very long draw etc.
             print(preset, Ts, "engine error:", e)
             continue
+        durs = eng.durations()
+        off = np.concatenate([[0], np.cumsum(Ts)])
         for i in range(B):
+            # integer durations first: a value in front of the ceil (models.py:703) that sits within a few ulp of an integer may
+            # land on the other side of it in the engine's summation order -- off by one at such a position is reported and the
+            # utterance skipped (its frame count differs); anything else is a failure
+            od, ow = O.durations_only(w, cfg, ids[i], scales, nw[i], None if sids is None else sids[i], return_w=True)
+            ed = durs[off[i]:off[i + 1]]
+            if not np.array_equal(ed, od):
+                for j in np.nonzero(ed != od)[0]:
+                    near = abs(ow[j] - np.rint(ow[j])) <= 2e-5 * max(1.0, abs(ow[j]))
+                    assert abs(int(ed[j]) - int(od[j])) == 1 and near, (preset, Ts, i, int(j), int(ed[j]), int(od[j]), float(ow[j]))
+                    edge.append((preset, Ts, i, int(j), float(ow[j])))
+                continue
             o = O.synthesize(w, cfg, ids[i], scales, nw[i], nz[i], sid=None if sids is None else sids[i])
             assert r.audio[i].shape == o["audio"].shape, (preset, Ts, i, r.audio[i].shape, o["audio"].shape)
             d = float(np.max(np.abs(r.audio[i] - o["audio"])))
@@ -40,4 +54,5 @@ for preset, tmax, cases in (("medium", tmax_medium, n), ("high", 90, n // 3), ("
             assert np.sqrt(np.mean(p * p)) <= 1e-3
         print(preset, "B", B, "T", Ts, "frames", [int(f) for f in r.frames], "ok", flush=True)
     eng.close()
-print("all ok, worst |d audio| = %.2e" % worst)
+assert len(edge) <= 3, edge
+print("all ok, worst |d audio| = %.2e" % worst, "-- integer-boundary durations (off by one, value in front of the ceil within 2e-5 of the integer):", edge)
