@@ -152,6 +152,7 @@ class Engine {
   // Grouped launches (conv_splitk_group_kernel): between group_begin() and group_end() conv() records the launch instead
   // of issuing it; group_end() issues all of them (<= 3 independent convs of one launch shape) as one launch.
   bool grouping_ = false;
+  bool stage_tiled_ = false;            // the MRF stage being issued takes the tiled kernel for every conv (a single utterance's stage past policy.h: group_maxb)
   bool group_tiled_ = false;            // the open group goes to the TILED kernel (conv_mfma_group_kernel), cfg = group_cfg_
   int group_cfg_ = 0;
   std::vector<struct ConvP> group_;

@@ -30,6 +30,7 @@ float* Engine::stage_a_enc_out() const { return (stage_a_ffn_fused() && (enc_.si
 // Grids are sized by the bucketed maximum length Tg_; kernels bound themselves by the device-side
 // per-utterance lengths, so the same captured graph serves every batch of that bucket.
 void Engine::issue_stage_a() {
+  stage_tiled_ = false;         // (a call that threw inside a generator stage must not leave it set)
   const int B = B_, Ts = Ts_, T = Tg_;
   const long bsH = (long)H_ * Ts;
   auto V = [&](float* p, int ch) { return View{p, (long)ch * Ts, Ts}; };
@@ -394,6 +395,7 @@ void Engine::issue_window() {
 // HiFiGAN generator + conv_post + int16 on z (already masked by its length semantics). `zsrc` is
 // [B][C][Fs_]; `lens` the per-utterance frame counts in device memory; Fmax the grid bound.
 void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double fsum, bool zero_absmax) {
+  stage_tiled_ = false;
   const int B = B_, Fs = Fs_;
   const View none{nullptr, 0, 0};
   const float* cb_dec = nspk_ > 1 ? cond_ + cond_off_dec_ : nullptr;
@@ -477,6 +479,7 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
       const long blocks64 = (long)((Lmax + 63) / 64) * ((st.ch + 63) / 64) * B;
       // grouped sibling launches are a single-utterance latency measure: measured -24 us (medium) / -4 % (high) at
       // B=1, but +1..2 % at B=2 and B=4, where every conv already fills the chip on its own
+      stage_tiled_ = !fuse && pol_.stage_all_tiled(B, nk, blocks64);
       bool grp = pol_.group_stage(B, nk, blocks64, need <= side_floats_);
       for (auto& cv : st.rb) {
         if (cv.size() != st.rb[0].size()) grp = false;
@@ -543,6 +546,7 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
           chain(j, t, xs, accmode);
         }
       }
+      stage_tiled_ = false;
       cur = xs;      // same buffer index cur_buf, new shape
     }
     prof_end(3, fl);

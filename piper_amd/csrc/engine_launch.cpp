@@ -11,6 +11,7 @@ namespace pe {
 // A conv that may ride in a grouped split-K launch: few enough column tiles that the launch is latency- rather than
 // throughput-bound, and a halo the 128-column slab covers.
 bool Engine::can_group(const PackedConv& pc, int ncols) const {
+  if (stage_tiled_) return false;
   const long blocks = (long)((ncols + CFG_BN[pc.cfg] - 1) / CFG_BN[pc.cfg]) * (pc.mtiles * 32 / CFG_BM[pc.cfg]) * B_;
   return pol_.groupable(pc.gate, pc.up != 0, blocks, (pc.ntaps - 1) * pc.dil, pc.Cin);
 }
@@ -128,7 +129,7 @@ void Engine::group_end_sum(View out, const float* bias_sum, float alpha) {
 int Engine::route(const PackedConv& pc, int ncols, int epi) const {
   const int cfg = pc.cfg;
   const long blocks = (long)((ncols + CFG_BN[cfg] - 1) / CFG_BN[cfg]) * (pc.mtiles * 32 / CFG_BM[cfg]) * B_;
-  if (!pol_.splitk(blocks, (pc.ntaps - 1) * pc.dil, pc.Cin)) return ROUTE_TILE;
+  if (stage_tiled_ || !pol_.splitk(blocks, (pc.ntaps - 1) * pc.dil, pc.Cin)) return ROUTE_TILE;
   return pol_.splitk_16col(pc.wp16 != nullptr, epi == EPI_CONVT, pc.gate, pc.nchunks * pc.ntaps) ? ROUTE_SPLITK16 : ROUTE_SPLITK;
 }
 void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int len_mul, int Lmax, int epi,
@@ -198,7 +199,8 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     group_bytes_ += kbytes;
     return;
   }
-  if (pol_.splitk(blocks, p.xhalo, pc.Cin) && epi == EPI_GATE &&
+  const bool to_splitk = !stage_tiled_ && pol_.splitk(blocks, p.xhalo, pc.Cin);
+  if (to_splitk && epi == EPI_GATE &&
       pol_.gate_12col(pc.gate, pc.wpg4 != nullptr && pc.Cin == 192, pc.ntaps, pc.dil, (long)((ncols + 11) / 12) * (pc.split / 32) * B_)) {
     // the WN gate conv of a short call: 64 rows x 12 columns per workgroup on the 4x4x1 MFMA (kernels/gate4.h)
     p.wpg4 = pc.wpg4;
@@ -209,7 +211,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     kend(kh);
     return;
   }
-  if (pol_.splitk(blocks, p.xhalo, pc.Cin)) {
+  if (to_splitk) {
     // few columns (one utterance through encoder / duration predictor / flow): split K across the waves
     const int MT = pc.gate ? 2 : 1;
     // waves per workgroup: 4 / 8 take whole chunks; the WN gate conv (6 chunks x 5 taps, two M tiles per wave)

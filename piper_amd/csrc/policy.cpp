@@ -22,6 +22,7 @@ static const LaunchPolicy::Knob kKnobs[] = {
     {"PIPER_HIP_WIDE_SPLITK", &LaunchPolicy::wide_splitk, 0, 2, "12-wave split-K: 0 off, 1 WN gate conv, 2 always"},
     {"PIPER_HIP_TPB", &LaunchPolicy::tpb, 0, 64, "tiled kernel: column tiles walked by one workgroup (0 = 1)"},
     {"PIPER_HIP_GROUP_MRF", &LaunchPolicy::group_mrf, 0, 2, "sibling resblock convs of a wider small stage as grouped launches (one-utterance calls): 0 off, 2 without the K-concatenated last step"},
+    {"PIPER_HIP_GROUP_MAXB", &LaunchPolicy::group_maxb, 0, 1L << 40, "64 x 64 tiles of one conv of a stage below which the grouped sibling launches of a single utterance take the split-K kernels (the tiled grouped launches from there on)"},
     {"PIPER_HIP_GROUP_TILED", &LaunchPolicy::group_tiled, 0, 1, "sibling resblock convs of a stage that runs the tiled kernel as grouped launches (conv_mfma_group_kernel) while one conv is at most 2048 tile workgroups (8 per CU): 0 = one launch per conv"},
     {"PIPER_HIP_COLCHAIN", &LaunchPolicy::colchain, 0, 2, "colchain_kernel / lngemm_kernel: 0 off, 1 up to 4096 ids / 8192 frames per call, 2 always"},
     {"PIPER_HIP_COL4", &LaunchPolicy::col4, 0, 2, "4-column forms of the 192-channel chains: 0 off, 1 up to PIPER_HIP_COL4_MAXC ids (2048 frames for the flow's launches) per call, 2 always"},

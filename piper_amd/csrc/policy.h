@@ -23,6 +23,7 @@ struct LaunchPolicy {
   long wide_splitk = 1;       // 12-wave split-K workgroups: 0 off, 1 WN gate conv, 2 always (tests)
   long tpb = 0;               // tiled kernel: column tiles walked by one workgroup (0 = 1, the measured choice)
   long group_mrf = 1;         // sibling resblock convs of a wider one-utterance stage as grouped launches: 0 off, 2 without the K-concatenated last step
+  long group_maxb = 160;      // ... as split-K launches while one conv of the stage is fewer than this many 64 x 64 tiles, as tiled launches above
   long group_tiled = 1;       // sibling resblock convs of a stage that runs the TILED kernel as grouped launches while one conv is only a few tiles per CU
   long colchain = 1;          // colchain_kernel / lngemm_kernel: 0 off, 1 by batch size, 2 always
   long col4 = 1;              // 4-column forms of the 192-channel chains: 0 off, 1 by batch size, 2 always
@@ -114,7 +115,11 @@ struct LaunchPolicy {
            (mrf == 2 || !resblock1 || (padded_channels == 32 && frames <= (double)mrf_maxf));
   }
   bool group_stage(int B, int nk, long blocks64, bool buffers_fit) const {
-    return group_mrf && B == 1 && nk >= 2 && nk <= 3 && blocks64 < group_max_blocks64 && buffers_fit;
+    return group_mrf && B == 1 && nk >= 2 && nk <= 3 && blocks64 < group_max_blocks64 && blocks64 < group_maxb && buffers_fit;
+  }
+  // ... and past that size every conv of the stage keeps the tiled kernel (its siblings must take ONE route to be grouped)
+  bool stage_all_tiled(int B, int nk, long blocks64) const {
+    return group_mrf && group_tiled && B == 1 && nk >= 2 && nk <= 3 && blocks64 >= group_maxb;
   }
   bool group_sum() const { return group_mrf != 2; }
   // the tiled kernel's form of the same idea: one conv of the stage is 1..8 tiles per CU, so the CUs that draw one tile

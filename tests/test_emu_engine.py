@@ -806,6 +806,35 @@ def test_emulated_grouped_tiled_sibling_convs(emu_lib, monkeypatch, preset, lens
         assert np.max(np.abs(out["1"][i] - out["0"][i])) < 2e-6      # (the MRF mean is summed in another order)
 
 
+@pytest.mark.parametrize("preset", ["tiny", "tiny-high"])
+def test_emulated_first_stage_route_by_size(emu_lib, monkeypatch, preset):
+    """The 128-channel first stage of ONE utterance: sibling resblock convs as grouped split-K launches while one conv is
+    fewer than PIPER_HIP_GROUP_MAXB 64 x 64 tiles, and from there on every conv of the stage through the tiled kernel in
+    grouped launches (policy.h: group_stage / stage_all_tiled) -- also the convs the tile count alone would send to the
+    split-K kernels, or the siblings could not share a launch. Both against the oracle, and against each other."""
+    cfg = W.preset(preset, up_initial=256)               # (a first generator stage of 128 channels)
+    w = W.synthetic_weights(cfg, 1234)
+    ids = [W.synthetic_phoneme_ids(14, 3, id_max=cfg.n_vocab - 1)]
+    nw, nz = _noise(cfg, 1, 14, 5)
+    scales = (0.5, 1.0, 0.8)
+    out = {}
+    for maxb in ("1000", "1"):
+        monkeypatch.setenv("PIPER_HIP_GROUP_MAXB", maxb)
+        eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
+        eng.profile_enable(2)
+        r = eng.synthesize_batch(ids, scales, noise_w=nw, noise_z=nz)
+        names = {row["name"] for row in eng.profile()[5:] if row["launches"]}
+        if maxb == "1":
+            assert any(n.startswith("conv_mfma_group_kernel<") for n in names) and not any(n.startswith("conv_splitk_group") for n in names), names
+        else:
+            assert any(n.startswith("conv_splitk_group_kernel<") for n in names), names
+        out[maxb] = r.audio[0]
+        eng.close()
+    o = O.synthesize(w, cfg, ids[0], scales, nw[0], nz[0])
+    assert np.max(np.abs(out["1"] - o["audio"])) < 1e-5 and np.max(np.abs(out["1000"] - o["audio"])) < 1e-5
+    assert np.max(np.abs(out["1"] - out["1000"])) < 2e-6
+
+
 def test_coalescer_batches_concurrent_requests(emu_lib):
     """pe_coalescer_* (include/piper_hip.h): six threads, one utterance each, on ONE engine -- the requests pending at the
     same moment run as batched engine calls (max_batch 4: two calls), every thread gets the PCM its own B=1 call would

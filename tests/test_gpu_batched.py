@@ -227,6 +227,11 @@ FORCED = [
     ("medium", [117], {}, {"conv_splitk_group_kernel<4,2,64>", "conv_splitk_sum_kernel<4,2>"}),
     ("medium", [100], {"PIPER_HIP_GROUP_MRF": 2}, {"conv_splitk_group_kernel<4,2,64>", "conv_splitk_group_kernel<4,2,128>"}),
     ("high", [40], {}, {"conv_splitk_group_kernel<4,2,64>", "conv_splitk_sum_kernel<4,2>"}),
+    # past PIPER_HIP_GROUP_MAXB tiles per conv the first stage of one utterance takes the TILED grouped launches (the high voice's
+    # 256-channel stage at 128 ids, the medium voice's 128-channel stage at 256 ids); the split-K grouped launches forced back on
+    ("high", [128], {"PIPER_HIP_GROUP_MAXB": 700}, {"conv_splitk_group_kernel<4,2,64>", "conv_splitk_group_kernel<4,2,128>", "conv_splitk_sum_kernel<4,2>"}),
+    ("medium", [256], {}, {"conv_mfma_group_kernel<2,2,1,1,16,64>", "conv_mfma_group_kernel<2,2,1,1,16,128>", "mrf_sum_kernel"}),
+    ("medium", [256], {"PIPER_HIP_GROUP_MAXB": 700}, {"conv_splitk_group_kernel<4,2,64>", "conv_splitk_sum_kernel<4,2>"}),
     ("medium", [128], {"PIPER_HIP_GROUP_MRF": 0}, {"conv_splitk_kernel<1,false,4,4>"}),
     # split-K variants: 4/8-wave only (no 16-column form), 12-wave everywhere, 16-column form everywhere
     ("medium", [128], {"PIPER_HIP_SPLITK16": 0, "PIPER_HIP_WIDE_SPLITK": 0, "PIPER_HIP_COL4": 0, "PIPER_HIP_GATE4": 0},
