@@ -44,7 +44,7 @@ def main():
         heads = 2 if hidden == 192 else (int(rng.choice([1, 2])) if hidden % 64 == 0 or hidden == 96 else 2)
         over = dict(hidden=hidden, inter=(192 if hidden == 192 else int(rng.choice([32, 64]))), filter=int(rng.choice([48, 96]) if hidden == 192 else rng.choice([32, 64, 96])),
                     n_layers=int(rng.integers(1, 3)), n_heads=heads, window=int(rng.choice([2, 4])),
-                    up_initial=int(rng.choice([32, 64, 128])))
+                    up_initial=int(rng.choice([32, 64, 128, 256])))      # 256: a 128-channel first stage (grouped sibling launches)
         preset = str(rng.choice(["tiny", "tiny-high", "tiny-ms", "tiny-high-ms"]))
         B = int(rng.integers(1, 4))
         lens = [int(rng.integers(1, 40)) for _ in range(B)]
@@ -57,7 +57,7 @@ def main():
                            ("PIPER_HIP_COLCHAIN", ["", "0"]), ("PIPER_HIP_SPLITK16", ["", "3"]), ("PIPER_HIP_COL4", ["", "0", "2"]),
                            ("PIPER_HIP_ATTNO", ["", "0"]), ("PIPER_HIP_FFN", ["", "0"]), ("PIPER_HIP_GATE_HALF", ["", "0"]),
                            ("PIPER_HIP_CONV1X1", ["", "0"]), ("PIPER_HIP_CHAIN_RS", ["", "0"]), ("PIPER_HIP_STACK_PRE", ["", "0"]),
-                           ("PIPER_HIP_ATTN4", ["", "0", "2"]), ("PIPER_HIP_GATE4", ["", "0", "2"]), ("PIPER_HIP_GROUP_TILED", ["", "0"]),
+                           ("PIPER_HIP_ATTN4", ["", "0", "2"]), ("PIPER_HIP_GATE4", ["", "0", "2"]), ("PIPER_HIP_GROUP_TILED", ["", "0"]), ("PIPER_HIP_GROUP_MAXB", ["", "1", "2"]),
                            ("PIPER_HIP_DEBUG_POISON", ["", "1"])):
             v = str(rng.choice(vals))
             if v:
