@@ -10,6 +10,15 @@ thread_local long g_launches = 0;
 std::shared_mutex g_capture_mu;
 thread_local int g_entry_depth = 0;
 
+// PIPER_HIP_DEBUG_POISON: a freshly allocated workspace is filled with NaN bit patterns so that a kernel relying on memory
+// it never wrote shows up in the result. The fill runs on the null stream and is asynchronous to the host, while the
+// engine's stream does not synchronise with the null stream: without the wait below the fill could land AFTER the first
+// copies / launches into the new buffer (seen as NaNs in the first injected noise row, profiles/r05_notes.md, call 31-35).
+static void poison(void* p, size_t bytes) {
+  PE_HIP(hipMemset(p, 0xFF, bytes));
+  PE_HIP(hipDeviceSynchronize());
+}
+
 Engine::Engine(const WeightSet& ws, int device, ArenaSpec arena) : device_(device) {
   EntryLock entry_lock;       // allocations / synchronising copies must not overlap another engine's graph capture
   // a constructor that throws does not run the destructor: release what was acquired so far
@@ -138,7 +147,7 @@ void Engine::ensure_stage_a(int B, int Tmax) {
     PE_HIP(hipStreamSynchronize(stream_));
     const size_t fbytes = (size_t)(FC_ / 48) * H_ * LaunchPolicy::ffn_max_cols * sizeof(float);
     PE_HIP(hipMalloc((void**)&ffn_parts_, fbytes));
-    if (pol_.debug_poison) PE_HIP(hipMemset(ffn_parts_, 0xFF, fbytes));
+    if (pol_.debug_poison) poison(ffn_parts_, fbytes);
   }
   const int Ts = rup(Tmax, 128);    // row strides are multiples of 128 columns (conv epilogue relies on it)
   auto carve = [&](char* base, size_t Bc, size_t T) -> size_t {
@@ -207,7 +216,7 @@ void Engine::ensure_stage_a(int B, int Tmax) {
       }
     }
     wsA_ = static_cast<char*>(blk); wsA_bytes_ = bytes; capA_B_ = nB; capA_T_ = nT;
-    if (pol_.debug_poison) PE_HIP(hipMemset(wsA_, 0xFF, bytes));
+    if (pol_.debug_poison) poison(wsA_, bytes);
     carve(wsA_, capA_B_, capA_T_);
     if (h_in_cap_ < in_bytes_) {
       if (h_in_) PE_HIP(hipHostFree(h_in_));
@@ -281,7 +290,7 @@ void Engine::ensure_stage_b(int Fmax, int batch) {
       }
     }
     wsB_ = static_cast<char*>(blk); wsB_bytes_ = bytes; capB_B_ = nB; capB_F_ = nF;
-    if (pol_.debug_poison) PE_HIP(hipMemset(wsB_, 0xFF, bytes));
+    if (pol_.debug_poison) poison(wsB_, bytes);
   }
   Fs_ = (int)capB_F_;
   Ss_ = (long)capB_F_ * hop_;
@@ -306,7 +315,7 @@ void Engine::ensure_stage_b(int Fmax, int batch) {
     side_floats_ = want;
     for (float*& sp : side_) {
       PE_HIP(hipMalloc((void**)&sp, side_floats_ * sizeof(float)));
-      if (pol_.debug_poison) PE_HIP(hipMemset(sp, 0xFF, side_floats_ * sizeof(float)));
+      if (pol_.debug_poison) poison(sp, side_floats_ * sizeof(float));
     }
   }
 }

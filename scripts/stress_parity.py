@@ -1,6 +1,6 @@
 """Randomised parity sweep on a GPU box (not part of the pytest suite): random lengths / batches / scales on the
 medium, high and multi-speaker tiny voices, HIP path vs the CPU oracle.
-usage: python scripts/stress_parity.py [n [seed [longest medium utterance]]]"""
+usage: python scripts/stress_parity.py [n [seed [longest medium utterance [longest high utterance]]]]"""
 import sys
 import numpy as np
 sys.path.insert(0, ".")
@@ -11,9 +11,10 @@ from piper_amd.engine import Engine
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
 tmax_medium = int(sys.argv[3]) if len(sys.argv) > 3 else 220
+tmax_high = int(sys.argv[4]) if len(sys.argv) > 4 else 90
 worst = 0.0
 edge = []
-for preset, tmax, cases in (("medium", tmax_medium, n), ("high", 90, n // 3), ("tiny-high-ms", 60, n // 2), ("x-low", 120, n // 3)):
+for preset, tmax, cases in (("medium", tmax_medium, n), ("high", tmax_high, n // 3), ("tiny-high-ms", 60, n // 2), ("x-low", 120, n // 3)):
     cfg = W.preset(preset)
     w = W.synthetic_weights(cfg, 99)
     eng = Engine(blob=W.pack_blob(cfg, w), device=0)
