@@ -1,6 +1,6 @@
 """Randomised parity sweep on a GPU box (not part of the pytest suite): random lengths / batches / scales on the
 medium, high and multi-speaker tiny voices, HIP path vs the CPU oracle.
-usage: python scripts/stress_parity.py [n [seed [longest medium utterance [longest high utterance]]]]"""
+usage: python scripts/stress_parity.py [n [seed [longest medium utterance [longest high utterance [largest batch]]]]]"""
 import sys
 import numpy as np
 sys.path.insert(0, ".")
@@ -12,6 +12,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
 tmax_medium = int(sys.argv[3]) if len(sys.argv) > 3 else 220
 tmax_high = int(sys.argv[4]) if len(sys.argv) > 4 else 90
+bmax = int(sys.argv[5]) if len(sys.argv) > 5 else 4
 worst = 0.0
 edge = []
 for preset, tmax, cases in (("medium", tmax_medium, n), ("high", tmax_high, n // 3), ("tiny-high-ms", 60, n // 2), ("x-low", 120, n // 3)):
@@ -19,7 +20,7 @@ for preset, tmax, cases in (("medium", tmax_medium, n), ("high", tmax_high, n //
     w = W.synthetic_weights(cfg, 99)
     eng = Engine(blob=W.pack_blob(cfg, w), device=0)
     for c in range(cases):
-        B = int(rng.integers(1, 5))
+        B = int(rng.integers(1, bmax + 1))
         Ts = [int(rng.integers(1, tmax)) for _ in range(B)]
         ids = [W.synthetic_phoneme_ids(T, c * 7 + i, id_max=min(cfg.n_vocab - 1, 129)) for i, T in enumerate(Ts)]
         scales = (float(rng.uniform(0, 1)), float(rng.uniform(0.6, 1.5)), float(rng.uniform(0, 1)))
