@@ -8,6 +8,27 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+def _usable_cores():
+    """The affinity mask capped by the cgroup CPU quota (os.cpu_count() reports the host's cores)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n = os.cpu_count() or 1
+    try:
+        txt = open("/sys/fs/cgroup/cpu.max").read().split()
+        if txt[0] != "max":
+            n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+    except (OSError, ValueError, IndexError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "slow: long CPU test")
@@ -15,6 +36,18 @@ def pytest_configure(config):
         # one worker per core: the oracle's torch CPU ops must not start a thread pool of their own in every worker
         for v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
             os.environ.setdefault(v, "1")
+    elif not getattr(config.option, "numprocesses", None):      # (a controller of xdist workers sets nothing: they would inherit it)
+        # a single process (the GPU suite): the oracle's torch CPU ops get the cores this process may really use. On a GPU box
+        # whose cgroup grants 16 of 256 cores the default pool (one thread per visible core) made every oracle utterance take
+        # 1-2.5 s: four tests were 550 of the suite's 960 s (profiles/r05_notes.md, call 38)
+        n = _usable_cores()
+        for v in ("OMP_NUM_THREADS", "MKL_NUM_THREADS", "OPENBLAS_NUM_THREADS"):
+            os.environ.setdefault(v, str(n))
+        if "torch" in sys.modules:
+            try:
+                sys.modules["torch"].set_num_threads(n)
+            except Exception:
+                pass
 
 
 @pytest.hookimpl(tryfirst=True)
