@@ -395,3 +395,21 @@ class Model(Model):                                                      # noqa:
                 next_conv.pop(0)
         self.nodes = [self.nodes[i] for i in order]
         return order
+
+    def swap_cond_layers(self, a: int = 0, b: int = 1):
+        """Exchange the POSITIONS of two flow cond_layer convolutions (found by their bias initialiser's name,
+        `flow.flows.N.enc.cond_layer.bias`): they read only the speaker embedding g, so any relative order among them is
+        a valid topological order -- and they share one shape, so nothing but the graph's wiring tells them apart
+        (ADVICE r5). Returns the two bias names."""
+        idx = []
+        for i, nd in enumerate(self.nodes):
+            if _node_op(nd) != "Conv":
+                continue
+            ins = [v.decode() for f, wt, v in nd if f == 1 and wt == 2]
+            if len(ins) >= 3 and ins[2].endswith(".enc.cond_layer.bias"):
+                idx.append((i, ins[2]))
+        if len(idx) <= max(a, b):
+            raise ValueError("not a multi-speaker voice with that many coupling layers")
+        (ia, na), (ib, nb) = idx[a], idx[b]
+        self.nodes[ia], self.nodes[ib] = self.nodes[ib], self.nodes[ia]
+        return na, nb

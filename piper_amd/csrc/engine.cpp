@@ -218,6 +218,7 @@ void Engine::ensure_stage_a(int B, int Tmax) {
     wsA_ = static_cast<char*>(blk); wsA_bytes_ = bytes; capA_B_ = nB; capA_T_ = nT;
     if (pol_.debug_poison) poison(wsA_, bytes);
     carve(wsA_, capA_B_, capA_T_);
+    PE_HIP(hipMemsetAsync(d_in_, 0, 32, stream_));        // generator state: "no upload ingested yet" (embed_kernel)
     if (h_in_cap_ < in_bytes_) {
       if (h_in_) PE_HIP(hipHostFree(h_in_));
       h_in_cap_ = in_bytes_;
@@ -341,6 +342,8 @@ void Engine::upload(const int64_t* ids, const int64_t* offsets, int B, const flo
     Tmax = std::max(Tmax, (int)T);
   }
   Tmax_ = Tmax;
+  // a speculative run whose results were never fetched may still be reading the pinned input block (zero-copy ids)
+  if (spec_pending_) { PE_HIP(hipStreamSynchronize(stream_)); spec_pending_ = false; }
   ensure_stage_a(B, Tmax);
   const int Ts = Ts_;
   // the pinned mirror of the input block; a copy of the previous call that might still read it ended with that call's
@@ -370,9 +373,14 @@ void Engine::upload(const int64_t* ids, const int64_t* offsets, int B, const flo
       if (sp < 0 || sp >= nspk_) throw std::runtime_error("speaker id outside [0, num_speakers)");
       hsid[b] = (int)sp;
     }
-  // {seed, runs so far}: the first kernel of every run() advances the counter on the device (embed_kernel)
-  hr[0] = seed_; hr[1] = call_; hr[2] = hr[3] = 0;
-  PE_HIP(hipMemcpyAsync(d_in_, h_in_, 32 + (2 * Bc + (size_t)B * Ts) * sizeof(int), hipMemcpyHostToDevice, stream_));
+  // {seed, runs so far, serial of this upload}: the first kernel of every run() advances the counter on the device
+  // (embed_kernel). Short calls enqueue no copy at all: embed_kernel reads the pinned block in place and publishes the
+  // lengths / speaker ids / generator state to device memory for the kernels behind it (the serial tells it a replay
+  // without a new upload from a fresh one).
+  hr[0] = seed_; hr[1] = call_; hr[2] = ++upload_serial_; hr[3] = 0;
+  ids_zc_ = pol_.ids_from_host((long)B * Ts);
+  if (!ids_zc_)
+    PE_HIP(hipMemcpyAsync(d_in_, h_in_, 32 + (2 * Bc + (size_t)B * Ts) * sizeof(int), hipMemcpyHostToDevice, stream_));
   scales_[0] = scales[0]; scales_[1] = scales[1]; scales_[2] = scales[2];
   have_noise_w_ = noise && noise->noise_w;
   have_noise_z_ = noise && noise->noise_z;

@@ -373,6 +373,9 @@ class Engine {
   // workspace (d_in_) mirrored by a pinned host block (h_in_): upload() fills the host block and enqueues ONE copy, no
   // synchronisation (the pinned block outlives the copy; the call's final synchronisation covers it)
   char* d_in_ = nullptr; char* h_in_ = nullptr; size_t in_bytes_ = 0, h_in_cap_ = 0;
+  // short calls: no copy at all -- embed_kernel reads the pinned block in place (policy.h: ids_from_host)
+  bool ids_zc_ = false;
+  unsigned long long upload_serial_ = 0;
   float* att_s_ = nullptr;           // attention score slabs of long utterances (attn_long_kernel); null while every slab fits LDS
   size_t attn_smem(int T, bool global_scores) const;
   bool attn_scores_global(int T) const;

@@ -44,6 +44,25 @@ void Engine::issue_stage_a() {
   for (int b = 0; b < B; ++b) tsum += tlens_h_[b];
   cols_ids_ = tsum;
 
+  // ================= text encoder (models.py:198-209, attentions.py:60-74)
+  prof_begin();
+  double fl = 0;
+  {
+    // the first kernel of the run: embedding lookup; also ingests the call's inputs when they stay in pinned host memory
+    // (zero-copy ids: lengths / speaker ids / generator state are published to device memory for everything behind it)
+    EmbedP ep{};
+    ep.ids = d_ids_; ep.ids_bs = Ts; ep.lens = d_tlens_; ep.emb = emb_; ep.H = H_; ep.scale = std::sqrt((float)H_);
+    ep.out = x_; ep.o_bs = (long)H_ * Ts; ep.o_cs = Ts; ep.rng = d_rng_;
+    if (ids_zc_) {
+      const size_t Bc = capA_B_;
+      ep.h_rng = reinterpret_cast<const unsigned long long*>(h_in_);
+      ep.h_lens = reinterpret_cast<const int*>(h_in_ + 32);
+      ep.h_sids = ep.h_lens + Bc;
+      ep.h_ids = ep.h_sids + Bc;
+      ep.d_lens = d_tlens_; ep.d_sids = d_sids_;
+    }
+    PE_LAUNCH_KB("embed_kernel", 4.0 * tsum * (1.0 + H_), launch::embed(dim3((T + 63) / 64, (H_ + 15) / 16, B), stream_, ep));
+  }
   // ================= speaker conditioning vectors
   const float* cb_dp = nullptr;
   if (nspk_ > 1) {
@@ -56,10 +75,6 @@ void Engine::issue_stage_a() {
     cb_dp = cond_ + cond_off_dp_;
   }
 
-  // ================= text encoder (models.py:198-209, attentions.py:60-74)
-  prof_begin();
-  double fl = 0;
-  PE_LAUNCH_KB("embed_kernel", 4.0 * tsum * (1.0 + H_), launch::embed(dim3((T + 63) / 64, (H_ + 15) / 16, B), stream_, d_ids_, Ts, d_tlens_, emb_, H_, std::sqrt((float)H_), x_, (long)H_ * Ts, Ts, d_rng_));
   // norm_layers_2 of a layer feeds only the next layer's q/k/v conv (or, after the last layer, proj) + the residual of
   // conv_o. Small batches with the 192-channel encoder run norm_layers_2 + that conv as one launch (lngemm_kernel), and
   // conv_o + residual + norm_layers_1 as another (colchain_kernel); otherwise conv, then ln_kernel.

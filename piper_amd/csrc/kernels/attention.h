@@ -11,20 +11,35 @@ namespace pe {
 // Text-encoder embedding: x[b][h][t] = emb[id][h] * sqrt(H)  (models.py:199-200)
 // The first kernel of every pipeline run also advances the RNG call counter (state[1]) that both randn sites of
 // the run read afterwards, so a replayed graph draws fresh noise on every run without a host copy.
-__global__ void embed_kernel(const int* ids, int ids_bs, const int* lens, const float* emb, int H,
-                             float scale, float* out, long o_bs, int o_cs, unsigned long long* rng_state) {
+// Zero-copy inputs (p.h_ids != null): the call's ids / lengths / speaker ids / {seed, counter} are read straight from
+// the pinned host block upload() filled (the counterpart of pcm16_kernel writing the PCM straight into pinned host
+// memory): no copy is enqueued in front of the graph. state[2] remembers the upload that was ingested last, so a replay
+// without a new upload keeps counting on the device.
+__global__ void embed_kernel(EmbedP p) {
   PE_KTRACE(10);
-  if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) rng_state[1] += 1ull;
+  const bool zc = p.h_ids != nullptr;
   const int b = blockIdx.z;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= lens[b]) return;
-  const int id = ids[b * ids_bs + t];
-  const float* e = emb + (long)id * H;
-  float* o = out + (long)b * o_bs + t;
+  // (both loads requested before either is used; t < ids_bs: the grid covers the id bucket, which is <= the row stride)
+  const int len = (zc ? p.h_lens : p.lens)[b];
+  const int id = (zc ? p.h_ids : p.ids)[(long)b * p.ids_bs + (t < p.ids_bs ? t : 0)];
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+    if (zc) { p.d_lens[b] = len; p.d_sids[b] = p.h_sids[b]; }
+    if (b == 0) {
+      if (zc && p.h_rng[2] != p.rng[2]) {
+        p.rng[0] = p.h_rng[0]; p.rng[1] = p.h_rng[1] + 1ull; p.rng[2] = p.h_rng[2];
+      } else {
+        p.rng[1] += 1ull;
+      }
+    }
+  }
+  if (t >= len) return;
+  const float* e = p.emb + (long)id * p.H;
+  float* o = p.out + (long)b * p.o_bs + t;
   const int h0 = blockIdx.y * 16;
 #pragma unroll
   for (int k = 0; k < 16; ++k)
-    if (h0 + k < H) o[(long)(h0 + k) * o_cs] = e[h0 + k] * scale;
+    if (h0 + k < p.H) o[(long)(h0 + k) * p.o_cs] = e[h0 + k] * p.scale;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -35,8 +35,7 @@ void conv_bf3(int cfg, bool gate, int halo, dim3 grid, size_t smem, hipStream_t 
 
 // ---- text encoder / duration predictor / flow glue (launch_front.cpp)
 void init_front();
-void embed(dim3 grid, hipStream_t stream, const int* ids, int ids_bs, const int* lens, const float* emb, int H, float scale,
-           float* out, long o_bs, int o_cs, unsigned long long* rng);
+void embed(dim3 grid, hipStream_t stream, const EmbedP& p);
 void attention(int dk, dim3 grid, size_t smem, hipStream_t stream, const AttnP& p);
 void attno(dim3 grid, size_t smem, hipStream_t stream, const AttnOP& p);        // attention + conv_o + LN, dk = 96 x 2 heads (attno.h)
 void attn4(bool long_rows, dim3 grid, size_t smem, hipStream_t stream, const AttnOP& p);   // the same on 4-query workgroups (attn4.h); long_rows: more than 128 ids per utterance

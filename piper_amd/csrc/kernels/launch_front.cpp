@@ -25,10 +25,7 @@ void init_front() {
 #endif
 }
 
-void embed(dim3 grid, hipStream_t stream, const int* ids, int ids_bs, const int* lens, const float* emb, int H, float scale,
-           float* out, long o_bs, int o_cs, unsigned long long* rng) {
-  PE_LAUNCH(embed_kernel, grid, dim3(64), 0, stream, ids, ids_bs, lens, emb, H, scale, out, o_bs, o_cs, rng);
-}
+void embed(dim3 grid, hipStream_t stream, const EmbedP& p) { PE_LAUNCH(embed_kernel, grid, dim3(64), 0, stream, p); }
 
 // compiled per head width (96 / 48); <0> = any even width <= 128 with guarded loops
 void attention(int dk, dim3 grid, size_t smem, hipStream_t stream, const AttnP& p) {

@@ -178,6 +178,20 @@ struct LnGemmP {
   float* vQ;
 };
 
+// ---- text embedding = the first kernel of every run (attention.h: embed_kernel)
+struct EmbedP {
+  const int* ids; int ids_bs;                  // [B][Ts] phoneme ids
+  const int* lens;                             // [B]
+  const float* emb; int H; float scale;
+  float* out; long o_bs; int o_cs;
+  unsigned long long* rng;                     // device {seed, runs so far, last ingested upload, -}
+  // Zero-copy inputs (null: upload() copied the input block to the device). The pinned host mirror of the block is read
+  // in place: ids and lengths by every workgroup that needs them, lengths / speaker ids / {seed, counter} published to
+  // device memory for the kernels behind this one.
+  const unsigned long long* h_rng; const int* h_lens; const int* h_sids; const int* h_ids;
+  int* d_lens; int* d_sids;
+};
+
 // ---- durations, N(0,1) generator, length regulator (duration.h)
 static constexpr int MAX_FRAMES = 60000;      // per-utterance activations stay below the 2 GiB descriptor range
 struct DurP {

@@ -690,7 +690,13 @@ WeightSet load_onnx(const std::string& path) {
   };
   const ConvRec& dp_pre = take("dp.pre", H, H, 1);
   link(enc_last, &dp_pre);
-  if (gin) take("dp.cond", H, gin, 1);
+  // Speaker-conditioning convs read only g, so ANY position among their siblings is a valid topological order: each is
+  // tied to the first conv that consumes the sum it feeds (dp.cond -> dp.convs.convs_sep.0, models.py:66-69; a flow's
+  // cond_layer -> that flow's res_skip convs, modules.py:188-199; dec.cond -> dec.ups.0, models.py:349-355), verified
+  // with every other adjacency below -- two cond_layer nodes in swapped positions fail by name instead of loading
+  // exchanged weights.
+  const ConvRec* dp_cond = gin ? &take("dp.cond", H, gin, 1) : nullptr;
+  if (dp_cond && have() && convs[ci].group > 1) link(dp_cond, &convs[ci]);
   const ConvRec* dp_last = take_dds("dp.convs", &dp_pre);
   const ConvRec& dp_proj = take("dp.proj", H, H, 1);
   link(dp_last, &dp_proj);
@@ -750,12 +756,12 @@ WeightSet load_onnx(const std::string& path) {
       int64_t wk = 0;
       size_t look = ci + (gin ? 1 : 0);
       while (look + 1 < convs.size() && convs[look].k > 1 && convs[look].d1 == H && convs[look].d0 == 2 * H) { ++wl; look += 2; }
-      if (gin) take(p + ".enc.cond_layer", 2 * H * wl, gin, 1);
+      const ConvRec* wcond = gin ? &take(p + ".enc.cond_layer", 2 * H * wl, gin, 1) : nullptr;
       for (int i = 0; i < wl; ++i) {
         wk = convs[ci].k;
         const ConvRec& win = take(p + ".enc.in_layers." + std::to_string(i), 2 * H, H, wk);
         const ConvRec& wrs = take(p + ".enc.res_skip_layers." + std::to_string(i), i < wl - 1 ? 2 * H : H, H, 1);
-        link(wprev, &win); link(&win, &wrs);
+        link(wprev, &win); link(&win, &wrs); link(wcond, &wrs);
         wprev = &wrs;
       }
       if (wl == 0) fail(p + ": no WN layers");
@@ -774,7 +780,7 @@ WeightSet load_onnx(const std::string& path) {
     std::vector<const ConvRec*> stage_tails;   // last conv of every resblock of the previous stage
     const int64_t U = pre.d0;
     A[A_UPINIT] = (int)U;
-    if (gin) take("dec.cond", U, gin, 1);
+    const ConvRec* dec_cond = gin ? &take("dec.cond", U, gin, 1) : nullptr;
     bool type1 = false;
     for (auto& kv : g.tensor_by_name)
       if (kv.first.find(".convs1.") != std::string::npos) type1 = true;
@@ -792,7 +798,7 @@ WeightSet load_onnx(const std::string& path) {
       A[A_UPK0 + nups] = (int)up.k;
       ch = up.d1;
       const ConvRec& upc = take("dec.ups." + std::to_string(nups), -1, -1, -1);
-      if (stage_tails.empty()) link(stage_in, &upc);
+      if (stage_tails.empty()) { link(stage_in, &upc); link(dec_cond, &upc); }
       for (const ConvRec* t : stage_tails) link(t, &upc);
       stage_tails.clear();
       // resblocks of this stage: maximal runs of equal kernel size

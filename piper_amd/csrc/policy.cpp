@@ -35,6 +35,7 @@ static const LaunchPolicy::Knob kKnobs[] = {
     {"PIPER_HIP_SPEC", &LaunchPolicy::spec, 0, 1, "speculative stage-B sizing / whole utterance as one graph for <= 4 utterances per call"},
     {"PIPER_HIP_SPEC_EXPECT", &LaunchPolicy::spec_expect, 0, 1, "speculative graphs planned for the expected frame counts (0: for the bucket capacity)"},
     {"PIPER_HIP_PCM_ZC", &LaunchPolicy::pcm_zc, 0, 1, "PCM written straight into pinned host memory by pcm16_kernel (0: one copy per utterance behind the graph)"},
+    {"PIPER_HIP_IDS_ZC", &LaunchPolicy::ids_zc, 0, 1, "phoneme ids, lengths and speaker ids read straight from the pinned host block by embed_kernel, up to 65536 padded ids per call (0: one host-to-device copy in front of the graph)"},
     {"PIPER_HIP_NO_GRAPH", &LaunchPolicy::no_graph, 0, 1, "launch kernels directly instead of replaying hipGraphs"},
     {"PIPER_HIP_GRAPHS", &LaunchPolicy::graphs, 1, 4096, "hipGraphs kept per engine (least recently used evicted one at a time)"},
     {"PIPER_HIP_CONVT_VEC", &LaunchPolicy::convt_vec, 0, 1, "polyphase up-conv: a lane's four accumulator rows leave as one 16-byte store (stride a multiple of 4) or two 8-byte stores (stride 2) of consecutive output samples; 0: one 4-byte store per phase"},

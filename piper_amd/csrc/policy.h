@@ -36,6 +36,7 @@ struct LaunchPolicy {
   long spec = 1;              // speculative stage-B sizing: the whole utterance as one graph for <= spec_max_batch utterances
   long spec_expect = 1;       // speculative graphs planned for the expected frame counts (0: for the bucket capacity)
   long pcm_zc = 1;            // int16 PCM written straight into pinned host memory by pcm16_kernel
+  long ids_zc = 1;            // phoneme ids / lengths / speaker ids read straight from the pinned host block by embed_kernel (no copy in front of the graph)
   long no_graph = 0;          // launch kernels directly instead of replaying hipGraphs
   long graphs = 256;          // hipGraphs kept per engine (least recently used evicted one at a time)
   long convt_vec = 1;         // polyphase up-conv tiles stored as 16- / 8-byte pieces straight from the accumulators (0: one 4-byte store per phase)
@@ -57,6 +58,7 @@ struct LaunchPolicy {
   static constexpr long col4_max_frames = 2048;   // 4-column WN res/skip conv and coupling pre: frames per call
   static constexpr long ffn_max_cols = 2048;      // ffn_kernel's partial-output buffer is allocated for this many columns
   static constexpr int spec_max_batch = 4;        // utterances per call up to which stage B is sized speculatively
+  static constexpr long ids_zc_max = 65536;       // padded ids per call up to which embed_kernel reads them from host memory (beyond: one H2D copy)
   static constexpr long group_max_blocks64 = 700; // grouped sibling launches: 64-column tiles of the stage up to which they pay
   static constexpr long group_tiled_max_blocks = 2048;   // grouped TILED sibling launches: tile workgroups of one conv (8 per CU) up to which grouping pays
 
@@ -128,6 +130,7 @@ struct LaunchPolicy {
     return group_tiled && nk >= 2 && nk <= 3 && tile_blocks <= group_tiled_max_blocks && buffers_fit;
   }
   bool speculate(int B) const { return spec && !no_graph && B <= spec_max_batch; }
+  bool ids_from_host(long padded_ids) const { return ids_zc && padded_ids <= ids_zc_max; }
 };
 
 }  // namespace pe

@@ -167,6 +167,20 @@ class Engine:
         self._check(self._lib.pe_upload(self._h, ids.ctypes.data_as(C.POINTER(C.c_int64)),
                                         offs.ctypes.data_as(C.POINTER(C.c_int64)), len(id_lists), sc, sid_arr, nz))
 
+    def pack_host(self, id_lists, scales=(0.667, 1.0, 0.8)):
+        """The host-side inputs of a call as the C ABI takes them -- int64 ids, prefix offsets, float scales in host
+        memory, what piper::synthesize wraps as Ort tensors (reference piper.cpp:342-365) -- built once, for callers that
+        time whole calls (bench.py) without Python's list handling inside the timed region."""
+        ids, offs = self._pack(id_lists)
+        sc = (C.c_float * 3)(*[float(s) for s in scales])
+        return (ids, offs, sc, ids.ctypes.data_as(C.POINTER(C.c_int64)), offs.ctypes.data_as(C.POINTER(C.c_int64)),
+                len(id_lists))
+
+    def upload_host(self, packed):
+        """pe_upload of inputs prepared by pack_host: host ids -> device, the engine draws both noise sites."""
+        self._keep = []
+        self._check(self._lib.pe_upload(self._h, packed[3], packed[4], packed[5], packed[2], None, None))
+
     def run(self):
         self._check(self._lib.pe_run(self._h))
 

@@ -119,3 +119,31 @@ def test_line_sheds_optional_parts_rather_than_overflow():
 def test_failed_leg_is_reported_short():
     e = bench.compact_leg({"leg": "configs[2]", "error": "RuntimeError: " + "q" * 1000})
     assert len(json.dumps(e)) < 250 and e["error"].startswith("RuntimeError")
+
+
+def test_headline_is_the_infer_seconds_span_and_names_both_clocks():
+    """the driver-timed step is what the reference's inferSeconds spans (piper.cpp:385-395) -- host ids
+    in, device pipeline with BOTH noise sites drawn by the engine, int16 PCM on the host -- and says so in
+    config.workload; the resident-input figure sits beside it; the dominant kernel's fraction names the clock it was
+    computed on and carries both durations."""
+    from piper_amd import weights as W
+    txt = bench.workload_text(2, "medium", W.preset("medium"), 1, 128)
+    assert "host ids in (pe_upload)" in txt and "both noise sites" in txt and "int16 PCM to host (pe_fetch)" in txt
+    full = _full()
+    full["config"]["workload"] = txt
+    full["device_resident_ms"] = 0.8512
+    full["roofline"].update({"clock": "rocprofv3", "avg_launch_us": 10.02, "avg_launch_us_event_pairs": 8.82,
+                             "avg_launch_us_rocprof": 10.02, "rocprof_source": "r06_b1_kernel_stats.csv"})
+    d = _check(bench.compact_line(full, "bench_full.json"), 1)
+    assert d["config"]["workload"] == txt                              # not truncated
+    assert d["device_resident_ms"] == 0.8512
+    r = d["roofline"]
+    assert r["kernel_clock"] == "rocprofv3" and r["kernel_us_rocprof"] == 10.02 and r["kernel_us_event_pairs"] == 8.82
+    assert r["kernel_avg_launch_us"] == 10.02 and r["rocprof_source"].endswith("kernel_stats.csv")
+
+
+def test_rocprof_clock_lookup_reads_the_committed_summaries():
+    k = bench.rocprof_kernel_us("medium", 1, "gate4_kernel")
+    assert k and 5.0 < k["avg_us"] < 20.0 and k["source"].endswith("_b1_kernel_stats.csv")
+    assert bench.rocprof_kernel_us("medium", 7, "gate4_kernel") is None
+    assert bench.rocprof_kernel_us("medium", 1, "no_such_kernel") is None

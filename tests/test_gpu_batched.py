@@ -917,6 +917,30 @@ def test_bench_n_ranks_on_one_gpu_prints_a_compact_line(ranks):
     assert "batched_per_gpu" in d["headline_note"]
 
 
+def test_bench_two_gpus_over_rccl_or_refuses(tmp_path):
+    """Multi-GPU pre-flight. With >= 2 devices: `bench.py --gpus 2` over "nccl" (RCCL) must record two
+    DISTINCT devices and a batched 1 -> 2 speed-up of at least 1.8x (utterances are independent; the only exchange is the
+    weight broadcast at load). With one device the same command must FAIL (rc != 0) instead of printing a curve point --
+    a run whose ranks share a GPU is not a multi-GPU measurement (bench.py: main, the distinct-device rule)."""
+    import subprocess
+    import sys
+    import torch
+    ndev = torch.cuda.device_count()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("PIPER_BENCH_BACKEND", None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--min-seconds", "0",
+           "--no-roofline"]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=1500, env=env)
+    if ndev < 2:
+        assert p.returncode != 0, "two nccl ranks on one GPU must not produce a result line"
+        assert not [l for l in p.stdout.splitlines() if l.startswith("{")]
+        return
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    assert d["ranks"]["backend"] == "nccl" and d["ranks"]["distinct_devices"] == 2 == d["ranks"]["world_size"]
+    assert d["batched_per_gpu"]["speedup_over_single_gpu"] >= 1.8, d["batched_per_gpu"]
+
+
 def test_graph_cache_is_lru_and_warmup_stops_captures(monkeypatch):
     """The hipGraph cache: shape buckets bound the number of graphs a stream of texts needs, the cache evicts ONE graph
     (the least recently used) when full -- never all of them -- and after pe_warmup with a representative utterance a

@@ -200,3 +200,20 @@ def test_any_topological_order_loads_identically_or_fails_by_name(lib, tmp_path,
         assert "onnx: voice graph does not match the Piper VITS export" in str(ex), str(ex)
         return
     check(cfg2, w2, cfg, w, tol=0.0)
+
+
+@pytest.mark.parametrize("pair", [(0, 1), (1, 3), (0, 3)])
+def test_swapped_cond_layers_fail_by_name(lib, tmp_path, pair):
+    """the four flow cond_layer convs share one shape and read only g, so a file that lists two of
+    them in exchanged positions is a valid graph the positional walk would load with their weights exchanged. Every
+    cond conv is now tied to a conv that consumes the sum it feeds (onnx_reader.cpp: the links of dp.cond, cond_layer,
+    dec.cond) and verified like every other adjacency: the swapped file fails by name, it never loads."""
+    m = M.Model(open(os.path.join(GOLD, "tinyhms_voice.onnx"), "rb").read())
+    na, nb = m.swap_cond_layers(*pair)
+    assert na != nb
+    out = tmp_path / "swapped_cond.onnx"
+    out.write_bytes(m.save())
+    with pytest.raises(RuntimeError) as ei:
+        load(lib, out)
+    msg = str(ei.value)
+    assert "node order is not the exporter's execution order" in msg and "cond_layer" in msg, msg
