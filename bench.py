@@ -41,15 +41,39 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP32_MATRIX_PEAK_TFLOPS = 157.3     # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 / 16x16x4_f32
-# opt-in matrix mode bf16x3 (kernels/conv_bf3.h): three v_mfma_f32_32x32x16_bf16 per f32-equivalent product, dense bf16
-# peak ~2500 TFLOP/s (same guide) -> 833 TFLOP/s of algorithmic (f32-equivalent) FLOPs for the kernels that use it
+# opt-in split-operand matrix modes (kernels/conv_bf3.h: conv_split_kernel<SM,...>): 3 / 3 / 6 sixteen-bit MFMAs
+# (v_mfma_f32_32x32x16_{bf16,f16}) per f32-equivalent product, dense 16-bit peak ~2500 TFLOP/s (same guide) -> 833 / 833 /
+# 417 TFLOP/s of algorithmic (f32-equivalent) FLOPs for the kernels that use them
+SPLIT_MODES = {"bf16x3": (0, 3), "f16x3": (1, 3), "bf16x6": (2, 6)}          # PIPER_HIP_MATRIX -> (kernel SM, MFMAs per product)
 BF16X3_PEAK_TFLOPS = 2500.0 / 3.0
 HBM_PEAK_GBPS = 8000.0              # same guide: HBM3E ~8 TB/s
-DTYPE_BF3 = ("bf16x3 (flow + generator conv GEMMs: f32 operands split into two bf16 terms, 3 bf16 MFMAs, f32 accumulate; "
-             "text encoder, duration predictor and all small-batch split-K launches f32)")
+DTYPE_SPLIT = {
+    "bf16x3": "bf16x3 (flow + generator conv GEMMs: f32 operands split into two bf16 terms = 16 significand bits, 3 bf16 MFMAs, "
+              "f32 accumulate; text encoder, duration predictor and all small-batch split-K launches f32)",
+    "f16x3": "f16x3 (flow + generator conv GEMMs: f32 operands split into two f16 terms = 22 significand bits, 3 f16 MFMAs, f32 "
+             "accumulate; everything else f32)",
+    "bf16x6": "bf16x6 (flow + generator conv GEMMs: f32 operands split into three bf16 terms = all 24 significand bits, 6 bf16 "
+              "MFMAs, f32 accumulate; everything else f32)",
+}
+DTYPE_BF3 = DTYPE_SPLIT["bf16x3"]
+
+
+def split_peak(mode):
+    return 2500.0 / SPLIT_MODES[mode][1]
+
+
+def short_dtype(dt):
+    dt = str(dt)
+    for m in SPLIT_MODES:
+        if dt.startswith(m):
+            return m
+    return dt
 
 
 def kernel_peak(name):
+    for m, (sm, n) in SPLIT_MODES.items():
+        if name.startswith(f"conv_split_kernel<{sm},"):
+            return 2500.0 / n
     return BF16X3_PEAK_TFLOPS if name.startswith("conv_bf3_kernel") else FP32_MATRIX_PEAK_TFLOPS
 SCALES = (0.667, 1.0, 0.8)
 
@@ -69,7 +93,8 @@ def _r(x, sig=5):
     if isinstance(x, bool) or x is None or isinstance(x, (int, str)):
         return x
     try:
-        return float(f"{float(x):.{sig}g}")
+        v = float(f"{float(x):.{sig}g}")
+        return int(v) if abs(v) >= 1e5 and v == int(v) else v          # (123400000, not 123400000.0: the line is size-capped)
     except (TypeError, ValueError):
         return None
 
@@ -123,8 +148,7 @@ def compact_leg(e):
     if "error" in e:
         c["error"] = _short(e["error"], 120)
         return c
-    dt = str(e.get("dtype", "f32"))
-    dt = "bf16x3" if dt.startswith("bf16x3") else dt
+    dt = short_dtype(e.get("dtype", "f32"))
     if dt != "f32":                          # (f32 and samples/s are the defaults of a leg: said once, in the headline)
         c["dtype"] = dt
     c["value"] = _r(e.get("value"))
@@ -150,11 +174,11 @@ def compact_leg(e):
     if roof:
         c["kernel"] = _short(roof.get("kernel"), 44)
         st = roof.get("step") or {}
-        if dt == "bf16x3":
-            # priced against the split-operand peak of the instruction these legs run (2500 / 3 TFLOP/s of f32-equivalent
-            # FLOPs), and said so: a fraction of the f32 matrix peak would exceed 1 here
-            c["frac"] = _r((st.get("achieved") or 0.0) / BF16X3_PEAK_TFLOPS, 3)
-            c["frac_of"] = "bf16x3 peak 833 TFLOP/s"
+        if dt in SPLIT_MODES:
+            # priced against the split-operand peak of the instruction these legs run (2500 / 3 or 2500 / 6 TFLOP/s of
+            # f32-equivalent FLOPs), and said so: a fraction of the f32 matrix peak would exceed 1 here
+            c["frac"] = _r((st.get("achieved") or 0.0) / split_peak(dt), 3)
+            c["peak_tflops"] = round(split_peak(dt))          # (the denominator of `frac`: 2500 / MFMAs per product)
         else:
             c["frac"] = _r(st.get("frac"), 3)
     return c
@@ -168,8 +192,7 @@ def compact_line(full, full_path=None):
     out["value"] = _r(full.get("value"), 7)
     out["x_realtime"] = _r(full.get("x_realtime"))
     out["ms_per_step"] = _r(full.get("ms_per_step"), 6)
-    dt = str(full.get("dtype", "f32"))
-    out["dtype"] = "bf16x3" if dt.startswith("bf16x3") else dt
+    out["dtype"] = short_dtype(full.get("dtype", "f32"))
     out["data"] = "synthetic"
     out["config"] = {"workload": _short(cfgf.get("workload", ""), 280), "frames_per_step": cfgf.get("frames_per_step"),
                      "samples_per_step": cfgf.get("samples_per_step"),
@@ -222,7 +245,7 @@ def compact_line(full, full_path=None):
     line = json.dumps(out, separators=(",", ":"))
     # belt and braces: slim the legs first (kernel names, then units / step counts), then shed the optional parts, until
     # the line fits
-    for drop in (("steps", "calls", "captures"), ("kernel", "frac_of")):
+    for drop in (("steps", "calls", "captures"), ("kernel",), ("frames_per_id", "row_ms_p95", "threads_value", "racing_value")):
         if len(line) <= COMPACT_LIMIT or not out.get("extra_configs"):
             break
         out["extra_configs"] = [{k: v for k, v in e.items() if k not in drop} for e in out["extra_configs"]]
@@ -263,9 +286,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the per-kernel event passes (profiling runs)")
     ap.add_argument("--no-extra", action="store_true", help="headline only: skip the extra_configs legs")
-    ap.add_argument("--matrix", default="f32", choices=["f32", "bf16x3"],
+    ap.add_argument("--matrix", default="f32", choices=["f32"] + sorted(SPLIT_MODES),
                     help="matrix mode of the engine (PIPER_HIP_MATRIX): f32 = the reference's arithmetic (default, the "
-                         "headline); bf16x3 = opt-in split-bf16 conv GEMMs for flow + generator")
+                         "headline); bf16x3 / f16x3 / bf16x6 = opt-in split-operand conv GEMMs for flow + generator")
     ap.add_argument("--stream-latency", action="store_true",
                     help="BASELINE configs[4]: p50 time to the first chunk of a chunked (45-frame) decode, then exit")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
@@ -591,7 +614,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if args.matrix == "f32" else DTYPE_BF3,
+            "dtype": "f32" if args.matrix == "f32" else DTYPE_SPLIT[args.matrix],
             "data": "synthetic (seeded random-weight voice of the named architecture, synthetic phoneme ids)",
             "config": {"workload": workload_text(cfgno, preset, cfg, B, T),
                        "frames_per_step": int(frames.sum()), "samples_per_step": leg["samples_per_step"],
@@ -719,23 +742,27 @@ def extra_configs(ctx, eng_medium, cfg_medium, args):
         guarded("configs[4]", lambda: stream_latency(hi["eng"], hi["cfg"], "high", 128, 100, 5, 0))
         hi["eng"].close()
 
-    # ---- the same two throughput configurations in the opt-in matrix mode bf16x3 (separately labelled dtype and peak;
-    # the headline and the legs above stay f32). Parity gate of the mode: tests/test_gpu_batched.py
-    # test_bf16x3_matrix_mode_matches_oracle (integer durations equal, int16 PCM within 1e-3 RMS of the oracle).
-    def bf3_leg(cfgno, preset, steps, warmup):
-        os.environ["PIPER_HIP_MATRIX"] = "bf16x3"
+    # ---- the same two throughput configurations in the opt-in split-operand matrix modes (separately labelled dtype and
+    # peak; the headline and the legs above stay f32). Parity gate of the modes = the f32 path's own (durations equal, max
+    # |d audio| < 2e-4 on all 64 utterances of both configurations): tests/test_gpu_batched.py
+    # test_split_matrix_modes_at_baseline_sizes.
+    def split_leg(mode, cfgno, preset, steps, warmup):
+        os.environ["PIPER_HIP_MATRIX"] = mode
         try:
             c = W.preset(preset)
             e = Engine(blob=W.pack_blob(c, W.synthetic_weights(c, 1234)), device=ctx.dev_index)
         finally:
             os.environ["PIPER_HIP_MATRIX"] = "f32"
         try:
-            return batched(cfgno, e, c, preset, 64, 128, steps, warmup, dtype=DTYPE_BF3)
+            return batched(cfgno, e, c, preset, 64, 128, steps, warmup, dtype=DTYPE_SPLIT[mode])
         finally:
             e.close()
 
-    guarded("configs[3] share, bf16x3", lambda: bf3_leg(4, "medium", 10, 3))
-    guarded("configs[2], bf16x3", lambda: bf3_leg(3, "high", 5, 2))
+    # (bf16x3 -- rounds 3-5's mode, 16 significand bits -- costs what f16x3 costs and is 8x less accurate: `--matrix bf16x3`
+    # still times it, the default line carries the two near-exact modes)
+    for mode in ("f16x3", "bf16x6"):
+        guarded(f"configs[3] share, {mode}", lambda m=mode: split_leg(m, 4, "medium", 10, 3))
+        guarded(f"configs[2], {mode}", lambda m=mode: split_leg(m, 3, "high", 5, 2))
     return legs
 
 

@@ -247,7 +247,7 @@ class Model(Model):                                                      # noqa:
         self.nodes = new_nodes + self.nodes
         return len(new_nodes)
 
-    def unsqueeze_k1_weights(self, axes_as_input: bool = True):
+    def unsqueeze_k1_weights(self, axes_as_input: bool = True, axes=(2,)):
         """Conv weights [out, in, 1] stored as matrices [out, in] with an Unsqueeze in front of the conv -- axes as an
         int64 input (opset >= 13) or as an attribute (older opsets)."""
         new_nodes, new_inits, n = [], [], 0
@@ -259,12 +259,12 @@ class Model(Model):                                                      # noqa:
             alias = t.name + "__u"
             self._rewire(t.name, alias)
             if axes_as_input:
-                ax = _int64_tensor(t.name + "__axes", [2])
+                ax = _int64_tensor(t.name + "__axes", list(axes))
                 new_inits.append(ax)
                 new_nodes.append([(1, 2, t.name.encode()), (1, 2, ax.name.encode()), (2, 2, alias.encode()), (4, 2, b"Unsqueeze")])
             else:
                 new_nodes.append([(1, 2, t.name.encode()), (2, 2, alias.encode()), (4, 2, b"Unsqueeze"),
-                                  (5, 2, _attr_ints("axes", [2]))])
+                                  (5, 2, _attr_ints("axes", list(axes)))])
             n += 1
         self.inits += new_inits
         self.nodes = new_nodes + self.nodes
@@ -413,3 +413,77 @@ class Model(Model):                                                      # noqa:
         (ia, na), (ib, nb) = idx[a], idx[b]
         self.nodes[ia], self.nodes[ib] = self.nodes[ib], self.nodes[ia]
         return na, nb
+
+    def conv_bias_to_add(self, every: int = 2) -> int:
+        """Every `every`-th convolution's bias leaves the Conv node and comes back as an Add behind it, stored [1, C, 1]
+        (the un-fused spelling older exporters emit for some layers; onnx-simplifier fuses the other way, so both exist in
+        the wild): Conv(x, W, b) -> Add(Conv(x, W), b[1, C, 1])."""
+        by_name = {t.name: t for t in self.inits}
+        out_nodes, n, k = [], 0, 0
+        for nd in self.nodes:
+            out_nodes.append(nd)
+            if _node_op(nd) not in ("Conv", "ConvTranspose"):
+                continue
+            ins = [(i, v.decode()) for i, (f, wt, v) in enumerate(nd) if f == 1 and wt == 2]
+            if len(ins) < 3 or ins[2][1] not in by_name:
+                continue
+            k += 1
+            if k % every:
+                continue
+            bt = by_name[ins[2][1]]
+            d = _dims(bt)
+            if bt.dtype != 1 or len(d) != 1:
+                continue
+            b3 = Tensor(bt.blob())
+            b3.name = bt.name + "__add"
+            _set_dims(b3, [1, d[0], 1])
+            self.inits.append(b3)
+            del nd[ins[2][0]]                                            # the Conv keeps (x, W)
+            oi = [i for i, (f, wt, v) in enumerate(nd) if f == 2 and wt == 2][0]
+            out = nd[oi][2].decode()
+            nd[oi] = (2, 2, (out + "__nobias").encode())
+            out_nodes.append([(1, 2, (out + "__nobias").encode()), (1, 2, b3.name.encode()), (2, 2, out.encode()), (4, 2, b"Add")])
+            n += 1
+        self.nodes = out_nodes
+        return n
+
+    def gelu_div_to_mul(self) -> int:
+        """GELU's x / sqrt(2) in front of Erf (modules.py:123 via F.gelu: Div by a scalar Constant) folded into a Mul by the
+        reciprocal, the form constant folding leaves behind; and the LayerNorm variance's Pow(x, 2) spelled Mul(x, x)."""
+        import numpy as np
+        outs = {v.decode(): i for i, nd in enumerate(self.nodes) for f, wt, v in nd if f == 2 and wt == 2}
+        erf_in = {[v.decode() for f, wt, v in nd if f == 1 and wt == 2][0] for nd in self.nodes if _node_op(nd) == "Erf"}
+        n = 0
+        for nd in self.nodes:
+            op = _node_op(nd)
+            ins = [(i, v.decode()) for i, (f, wt, v) in enumerate(nd) if f == 1 and wt == 2]
+            out = [v.decode() for f, wt, v in nd if f == 2 and wt == 2]
+            if op == "Div" and out and out[0] in erf_in and len(ins) == 2 and ins[1][1] in outs:
+                cn = self.nodes[outs[ins[1][1]]]
+                if _node_op(cn) != "Constant":
+                    continue
+                # Constant.value (attribute field 5 -> AttributeProto.t field 5): a scalar float
+                for ai, (f, wt, v) in enumerate(cn):
+                    if f != 5:
+                        continue
+                    attr = parse(v)
+                    ti = [j for j, (ff, _, _) in enumerate(attr) if ff == 5]
+                    if not ti:
+                        continue
+                    t = Tensor(attr[ti[0]][2])
+                    raw = _get(t.fields, 9)
+                    if t.dtype != 1 or not raw or len(raw[0]) != 4:
+                        continue
+                    c = np.frombuffer(raw[0], "<f4")[0]
+                    t.fields = [(ff, w2, vv) for ff, w2, vv in t.fields if ff != 9] + [(9, 2, np.float32(1.0 / c).tobytes())]
+                    attr[ti[0]] = (5, 2, t.blob())
+                    cn[ai] = (5, 2, serialize(attr))
+                    oi = [j for j, (ff, _, _) in enumerate(nd) if ff == 4][0]
+                    nd[oi] = (4, 2, b"Mul")
+                    n += 1
+            elif op == "Pow" and len(ins) == 2:
+                oi = [j for j, (ff, _, _) in enumerate(nd) if ff == 4][0]
+                nd[oi] = (4, 2, b"Mul")
+                nd[ins[1][0]] = (1, 2, ins[0][1].encode())              # Pow(x, 2) -> Mul(x, x)
+                n += 1
+        return n

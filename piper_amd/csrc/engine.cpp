@@ -313,11 +313,18 @@ void Engine::ensure_stage_b(int Fmax, int batch) {
     PE_HIP(hipStreamSynchronize(stream_));
     drop_graphs();
     for (float*& sp : side_) { if (sp) PE_HIP(hipFree(sp)); sp = nullptr; }
-    side_floats_ = want;
+    side_floats_ = 0;                  // (the capacity is published only once EVERY buffer exists: a failed allocation must not
+                                       // leave null pointers behind a capacity that says they are there)
     for (float*& sp : side_) {
-      PE_HIP(hipMalloc((void**)&sp, side_floats_ * sizeof(float)));
-      if (pol_.debug_poison) poison(sp, side_floats_ * sizeof(float));
+      if (hipMalloc((void**)&sp, want * sizeof(float)) != hipSuccess) {
+        (void)hipGetLastError();
+        for (float*& q : side_) { if (q) hipFree(q); q = nullptr; }
+        throw std::runtime_error("out of device memory: " + std::to_string((want * sizeof(float) * 9) >> 20) +
+                                 " MiB of per-resblock buffers");
+      }
+      if (pol_.debug_poison) poison(sp, want * sizeof(float));
     }
+    side_floats_ = want;
   }
 }
 
@@ -560,7 +567,10 @@ void Engine::run() {
     // the call falls back to the two-graph form and only ensure_stage_b on the real counts can fail it
     try {
       ensure_stage_b(fguess);
-    } catch (const std::runtime_error&) {
+    } catch (const std::runtime_error& ex) {
+      // only the sizing conditions fall back; a HIP error or an allocation failure is the call's error
+      const std::string what = ex.what();
+      if (what.compare(0, 14, "call too large") != 0 && what.compare(0, 18, "utterance too long") != 0) throw;
       spec = false;
     }
   }

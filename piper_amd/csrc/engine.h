@@ -20,7 +20,8 @@ namespace pe {
 struct PackedConv {
   float* wp = nullptr;      // device, packed for conv_mfma_kernel
   float* wp16 = nullptr;    // device, the same in 16x16x4 fragment order (conv_splitk16_kernel), long-K convs only
-  float* wpb = nullptr;     // device, bf16 hi/lo split fragments (conv_bf3_kernel), matrix mode bf16x3 only
+  float* wpb = nullptr;     // device, 16-bit split-term fragments (conv_split_kernel), split matrix modes only
+  const float* wunscale = nullptr;   // device: wpb holds the weights times 1 / *wunscale (a power of two; 1 except in mode f16x3)
   float* wpg4 = nullptr;    // device, gate convs over 192 channels in the 4x4x1 MFMA's order (gate4_kernel), or null
   float* bias = nullptr;    // device or null
   int rows = 0;             // GEMM rows (real)
@@ -312,10 +313,12 @@ class Engine {
   // the generator run on the bf16 matrix pipe with split operands (kernels/conv_bf3.h; ~16 mantissa bits per operand,
   // f32 accumulate, 3 MFMAs at 16x the f32 rate). The text encoder and the duration predictor stay f32 (the integer
   // durations are those of the f32 path), and so does every latency-bound split-K launch. Default: off, all f32.
-  bool matrix_bf3_ = false, pack_bf3_now_ = false;
+  bool matrix_bf3_ = false, pack_bf3_now_ = false;      // a split matrix mode is on / the convs being packed take part in it
+  int matrix_sm_ = 0;                                   // ... which: conv_split_kernel's SM (0 bf16x3, 1 f16x3, 2 bf16x6)
   static bool env_bf3();
  public:
   bool matrix_bf3() const { return matrix_bf3_; }
+  int matrix_split_mode() const { return matrix_bf3_ ? matrix_sm_ : -1; }
  private:
   std::vector<UpStage> ups_;
   float* post_w_ = nullptr;

@@ -91,7 +91,10 @@ void Engine::issue_stage_a() {
   const auto attn4_for = [&](const EncLayer& e) -> const float* {
     const bool attno_ok = pol_.attno && !pol_.attn_long && chain_q && pol_.chain4((long)B * T) && H_ == 192 && nh_ == 2 && dk_ == 96 &&
                           window_ <= 4 && e.o16;
-    return (attno_ok && pol_.attn4_ids(T)) ? w4_of(e.o16) : nullptr;
+    // (its LDS need grows with the id bucket: 8 score slabs of SP floats + the fixed part -- a forced policy must fall
+    // back to attno_kernel / attn_kernel past 160 KB instead of failing the launch)
+    const size_t smem4 = ((size_t)8 * (rup(T, 64) + 4) + 8 * (dk_ + 4) + 2 * 9 * dk_ + 3 * 72 + 8 * 12 + 4 * 196 + 4 * 192 * 4 + 32) * sizeof(float);
+    return (attno_ok && pol_.attn4_ids(T) && smem4 <= (size_t)160 * 1024) ? w4_of(e.o16) : nullptr;
   };
   for (auto& e : enc_) {
     kt_on_ = attn4_for(e) != nullptr;

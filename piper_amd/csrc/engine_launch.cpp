@@ -137,7 +137,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
                   int bias2_bs) {
   ConvP p;
   p.x = x.p; p.x_bs = x.bs; p.x_cs = x.cs;
-  p.wp = pc.wp; p.wp16 = pc.wp16; p.wpb = pc.wpb; p.wpg4 = nullptr; p.bias = pc.bias;
+  p.wp = pc.wp; p.wp16 = pc.wp16; p.wpb = pc.wpb; p.wunscale = pc.wunscale; p.wpg4 = nullptr; p.bias = pc.bias;
   p.bias2 = bias2; p.bias2_bs = bias2_bs;
   p.out = out.p; p.o_bs = out.bs; p.o_cs = out.cs;
   p.res = res.p; p.r_bs = res.bs; p.r_cs = res.cs;
@@ -256,7 +256,7 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     return;
   }
   if (matrix_bf3_ && pc.wpb && p.xhalo <= 128) {
-    // matrix mode bf16x3: 128 x 128 / 64 x 128 / 32 x 256 tiles (two 32x32 MFMA tiles per wave at least: the bf16 pipe
+    // split matrix modes (bf16x3 / f16x3 / bf16x6): 128 x 128 / 64 x 128 / 32 x 256 tiles (two 32x32 MFMA tiles per wave at least: the bf16 pipe
     // is fast enough that operand traffic per MFMA matters more than workgroup count)
     static const int BF3_BM[] = {128, 64, 32}, BF3_BN[] = {128, 128, 256};
     static const char* bnames[] = {"2,2,2,2", "2,2,1,2", "1,4,1,2"};
@@ -265,16 +265,17 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     const int BM = BF3_BM[bc], BN = BF3_BN[bc];
     const int HALO = p.xhalo <= 64 ? 64 : 128;
     const int nbuf = pc.nchunks == 1 ? 1 : 2;
-    const size_t smem = (size_t)nbuf * 128 * ((BN + HALO + 63) / 64 * 64);       // [2 parts][4 k groups][XS] x 16 B
+    const int nterm = matrix_sm_ == 2 ? 3 : 2;
+    const size_t smem = (size_t)nbuf * nterm * 64 * ((BN + HALO + 63) / 64 * 64);       // [terms][4 k groups][XS] x 16 B
     dim3 grid((ncols + BN - 1) / BN, pc.mtiles * 32 / BM, B_);
     int kh = -1;
     if (prof_level_ >= 2) {
       char nm[96];
-      snprintf(nm, sizeof(nm), "conv_bf3_kernel<%s,%s,%d>", (pc.gate && bc == 1) ? "1,4,2,1" : bnames[bc],
+      snprintf(nm, sizeof(nm), "conv_split_kernel<%d,%s,%s,%d>", matrix_sm_, (pc.gate && bc == 1) ? "1,4,2,1" : bnames[bc],
                pc.gate ? "true" : "false", HALO);
       kh = kbegin(krow(std::string(nm)), kflops, kbytes);
     }
-    launch::conv_bf3(bc, pc.gate, HALO, grid, smem, ls_, p);
+    launch::conv_bf3(matrix_sm_, bc, pc.gate, HALO, grid, smem, ls_, p);
     kend(kh);
     return;
   }

@@ -1,6 +1,7 @@
 // Voice -> packed weight arena: every tensor of the voice in the fragment orders the kernels read, carved from ONE
 // arena in a deterministic order (Engine::init), plus the phase table / weight stream of the fused MRF stages.
 #include "engine_internal.h"
+#include <cmath>
 
 namespace pe {
 
@@ -33,8 +34,10 @@ float* Engine::dev_tensor(const WeightSet& ws, const std::string& name) {
 size_t Engine::arena_bound(const WeightSet& ws) {
   size_t n = 0;
   for (auto& kv : ws.t) n += (size_t)kv.second.numel() + 64;
-  // matrix mode bf16x3: the flow / generator conv weights once more as split bf16 fragments (same size as the f32 packing)
-  return (n * (env_bf3() ? 10 : 7) / 2 + (4u << 20)) * sizeof(float);
+  // split matrix modes: the flow / generator conv weights once more as 16-bit term fragments (two terms: the size of the
+  // f32 packing; three terms, bf16x6: 1.5x that)
+  const int sm = LaunchPolicy::matrix_mode_env();
+  return (n * (sm == 2 ? 12 : (sm >= 0 ? 10 : 7)) / 2 + (4u << 20)) * sizeof(float);
 }
 bool Engine::env_bf3() { return LaunchPolicy::matrix_bf3_env(); }
 
@@ -138,14 +141,34 @@ PackedConv Engine::pack_matrix(const std::vector<float>& W, int rows, int Cin, i
     pc.wpg4 = dev_alloc(n4, skeleton_ ? nullptr : G.data());
   }
   if (pack_bf3_now_) {
-    // conv_bf3_kernel (kernels/conv_bf3.h): every weight as hi = bf16(w), lo = bf16(w - hi), in the A-operand order of
-    // v_mfma_f32_32x32x16_bf16: [m tile][chunk][tap][part hi|lo][k-step][lane][8], lane -> row = lane & 31, input channel
-    // chunk*32 + 8*(2*kstep + (lane >> 5)) + e. One (tile, chunk, tap) step = 1024 floats, like the f32 packing.
-    std::vector<uint16_t> R(skeleton_ ? 0 : np * 2, 0);
+    // conv_split_kernel (kernels/conv_bf3.h): every weight as the NT 16-bit terms of the engine's split mode, in the
+    // A-operand order of v_mfma_f32_32x32x16_{bf16,f16}: [m tile][chunk][tap][term][k-step][lane][8], lane -> row = lane & 31,
+    // input channel chunk*32 + 8*(2*kstep + (lane >> 5)) + e. One (tile, chunk, tap) step = NT * 512 floats.
+    const int sm = matrix_sm_, nt = sm == 2 ? 3 : 2;
+    float wscale = 1.f;
+    if (sm == 1 && !skeleton_) {
+      // f16's exponent range: the largest weight lands in [2^12, 2^13) (products with activations up to 65504 accumulate in
+      // f32), so the low terms of ordinary weights stay far above f16's subnormal step; undone exactly on the accumulators
+      float mx = 0.f;
+      for (float v : W) mx = std::max(mx, std::fabs(v));
+      if (mx > 0.f && std::isfinite(mx)) {
+        int e = 0;
+        std::frexp(mx, &e);                    // mx = f * 2^e, f in [0.5, 1)
+        wscale = std::ldexp(1.f, 13 - e);
+      }
+    }
+    // (the factor that undoes the scale travels WITH the packed weights -- one float behind them in the arena -- so that a
+    // skeleton engine, which never sees W, reads the same value after the broadcast)
+    const size_t npb = (size_t)pc.mtiles * pc.nchunks * ntaps * nt * 512;           // floats
+    std::vector<uint16_t> R(skeleton_ ? 0 : (npb + 64) * 2, 0);
+    if (!skeleton_) {
+      const float us = 1.f / wscale;
+      memcpy(&R[npb * 2], &us, sizeof(float));
+    }
     for (int mt = 0; mt < (skeleton_ ? 0 : pc.mtiles); ++mt)
       for (int c = 0; c < pc.nchunks; ++c)
         for (int tap = 0; tap < ntaps; ++tap) {
-          const size_t step = (((size_t)mt * pc.nchunks + c) * ntaps + tap) * 2048;      // in bf16 elements
+          const size_t step = (((size_t)mt * pc.nchunks + c) * ntaps + tap) * nt * 1024;      // in 16-bit elements
           for (int ks = 0; ks < 2; ++ks)
             for (int lane = 0; lane < 64; ++lane) {
               int r = lane & 31, row;
@@ -159,14 +182,26 @@ PackedConv Engine::pack_matrix(const std::vector<float>& W, int rows, int Cin, i
               for (int e = 0; e < 8; ++e) {
                 const int ci = c * KC + 8 * (2 * ks + (lane >> 5)) + e;
                 if (row < 0 || ci >= Cin) continue;
-                const float v = W[((size_t)row * Cin + ci) * ntaps + tap];
-                const uint16_t hi = bf16_rne(v), lo = bf16_rne(v - bf16_to_f32(hi));
-                R[step + ((size_t)(0 * 2 + ks) * 64 + lane) * 8 + e] = hi;
-                R[step + ((size_t)(1 * 2 + ks) * 64 + lane) * 8 + e] = lo;
+                float rem = W[((size_t)row * Cin + ci) * ntaps + tap] * wscale;
+                for (int t = 0; t < nt; ++t) {
+                  uint16_t bits;
+                  float back;
+                  if (sm == 1) {
+                    const _Float16 h = (_Float16)rem;
+                    memcpy(&bits, &h, 2);
+                    back = (float)h;
+                  } else {
+                    bits = bf16_rne(rem);
+                    back = bf16_to_f32(bits);
+                  }
+                  R[step + ((size_t)(t * 2 + ks) * 64 + lane) * 8 + e] = bits;
+                  rem -= back;
+                }
               }
             }
         }
-    pc.wpb = dev_alloc(np, skeleton_ ? nullptr : reinterpret_cast<const float*>(R.data()));
+    pc.wpb = dev_alloc(npb + 64, skeleton_ ? nullptr : reinterpret_cast<const float*>(R.data()));
+    pc.wunscale = pc.wpb + npb;
   }
   pc.bias = bias ? dev_alloc((size_t)nbias, skeleton_ ? nullptr : bias->data()) : nullptr;
   pc.macs_per_col = (double)rows * Cin * ntaps;
@@ -373,6 +408,7 @@ void Engine::init(const WeightSet& ws) {
   pol_.read_env();
   use_graphs_ = !pol_.no_graph;
   matrix_bf3_ = env_bf3();
+  matrix_sm_ = std::max(0, LaunchPolicy::matrix_mode_env());
   memcpy(arch_, ws.arch, sizeof(arch_));
   PE_HIP(hipSetDevice(device_));
   PE_HIP(hipStreamCreateWithFlags(&stream_, hipStreamNonBlocking));

@@ -1,4 +1,4 @@
-// conv_bf3_kernel: the tiled conv GEMM on the bf16 matrix pipe with split operands (opt-in, PIPER_HIP_MATRIX=bf16x3).
+// conv_split_kernel: the tiled conv GEMM on the 16-bit matrix pipe with split f32 operands (opt-in, PIPER_HIP_MATRIX=bf16x3 | f16x3 | bf16x6).
 // (gfx950 / CDNA4 device code; reference arithmetic cited per kernel, paths relative to
 // /root/reference/src/python/piper_train/vits/.)
 #pragma once
@@ -8,24 +8,38 @@ namespace pe {
 
 // Same implicit GEMM as conv_mfma_kernel (conv_mfma.h):
 //   D[row][col] = sum_{ci,k} W[row][ci][k] * act(x[ci][col + k*dil - padl])
-// but every f32 operand is split into two bf16 terms, v = hi + lo with hi = bf16(v), lo = bf16(v - hi), and the
-// product runs as three v_mfma_f32_32x32x16_bf16 (hi*hi + hi*lo + lo*hi, f32 accumulate; the lo*lo term, 2^-16
-// relative, is dropped): 16 mantissa bits per operand at 16x the f32 matrix rate, i.e. 6 instructions of 32 cycles per
-// (32 channels, tap) step and 32x32 tile where the f32 kernel issues 16 of 64 cycles. Not bit-identical to the
-// reference's fp32 arithmetic (relative error ~1e-5 per product, averaging out over K): used for the coupling flow and
-// the generator only, never for the text encoder / duration predictor (durations stay exact), and never by default.
+// but every f32 operand is split into NT low-precision terms and the product runs as a few 16-bit MFMAs with f32
+// accumulate (16x the f32 matrix rate per instruction). Three split modes SM, selected by PIPER_HIP_MATRIX:
+//   SM 0 "bf16x3": v = h + l, h = bf16(v), l = bf16(v - h); products hh + hl + lh (ll, 2^-16 relative, dropped):
+//                  16 significand bits per operand, 3 x v_mfma_f32_32x32x16_bf16.
+//   SM 1 "f16x3":  v = h + l, h = f16(v), l = f16(v - h); the same three products on v_mfma_f32_32x32x16_f16:
+//                  22 significand bits per operand (the f32 significand has 24). f16's narrow exponent is handled by
+//                  scaling: weights are packed times a power of two per conv (largest magnitude near 2^13, undone
+//                  exactly on the accumulators), activations clamp at +-65504 (never reached by a voice; a term
+//                  below f16's subnormal step 2^-24 is dropped, an ABSOLUTE error of 6e-8 per element).
+//   SM 2 "bf16x6": v = h + m + l (three bf16 terms = the whole 24-bit significand, operands exact); products
+//                  hh + hm + mh + hl + lh + mm (the dropped ml, lm, ll are 2^-24 relative: f32 rounding level),
+//                  6 x v_mfma_f32_32x32x16_bf16.
+// Accuracy against the f32 oracle at full size (scripts/split_study.py, CPU model of this arithmetic; the f32 oracle
+// itself is 6e-7 from an f64 run): max|d audio| 0.9-2.1e-5 (bf16x3), 0.7-2.5e-6 (f16x3), 0.3-1.4e-6 (bf16x6); the f32
+// HIP path's gate is 2e-4. Used for the coupling flow and the generator only, never for the text encoder / duration
+// predictor (the integer durations are the f32 path's), and never by default.
 //   * B operand (activations): staged per 32-channel chunk through registers, pre-activation and the split applied
-//     ONCE per element there, written to LDS as [part hi|lo][k group of 8 channels][column][8 bf16]: a lane's B
+//     ONCE per element there, written to LDS as [term][k group of 8 channels][column][8 x 16 bit]: a lane's B
 //     fragment of one k-step (8 consecutive channels of its column) is one ds_read_b128, a dilated tap a shifted column.
 //   * A operand (weights): split and packed at load time (engine_pack.cpp pack_matrix) as
-//     [m tile][chunk][tap][part][k-step 0|1][lane][8 bf16]: 1024 floats per step like the f32 packing, four 16-byte
-//     loads per lane and (m tile, chunk, tap), prefetched one unit ahead (ping-pong).
+//     [m tile][chunk][tap][term][k-step 0|1][lane][8 x 16 bit]: NT * 512 floats per step, 2 * NT 16-byte loads per
+//     lane and (m tile, chunk, tap), prefetched one unit ahead (ping-pong).
 //   * accumulator layout == v_mfma_f32_32x32x2_f32's: the epilogues of conv_common.h are shared.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int frag16 __attribute__((ext_vector_type(4)));     // eight 16-bit terms as the MFMA takes them
 #ifdef PE_EMU
 #define pe_mfma_bf16_32x32x16(a, b, c) emu_mfma_bf16_32x32x16((a), (b), (c))
+#define pe_mfma_f16_32x32x16(a, b, c) emu_mfma_f16_32x32x16((a), (b), (c))
 #else
 #define pe_mfma_bf16_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16((a), (b), (c), 0, 0, 0)
+#define pe_mfma_f16_32x32x16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16((a), (b), (c), 0, 0, 0)
 #endif
 
 // f32 <-> bf16, round to nearest even (v_cvt_pk_bf16_f32 on the GPU; the emulator build spells it out in integer ops)
@@ -40,28 +54,60 @@ inline float pe_bf2f(__bf16 h) { return __uint_as_float((unsigned)__builtin_bit_
 __device__ __forceinline__ __bf16 pe_f2bf(float v) { return (__bf16)v; }
 __device__ __forceinline__ float pe_bf2f(__bf16 h) { return (float)h; }
 #endif
-// v (8 floats) -> hi / lo bf16 vectors
-__device__ __forceinline__ void bf3_split8(const float (&v)[8], bf16x8& hi, bf16x8& lo) {
+
+constexpr int split_terms(int sm) { return sm == 2 ? 3 : 2; }
+static constexpr float F16_MAX = 65504.f;
+
+// v (8 floats) -> the NT term vectors of split mode SM, largest term first
+template <int SM>
+__device__ __forceinline__ void split8(const float (&v)[8], frag16 (&t)[split_terms(SM)]) {
+  if constexpr (SM == 1) {
+    f16x8 hi, lo;
 #pragma unroll
-  for (int i = 0; i < 8; ++i) {
-    const __bf16 h = pe_f2bf(v[i]);
-    hi[i] = h;
-    lo[i] = pe_f2bf(v[i] - pe_bf2f(h));
+    for (int i = 0; i < 8; ++i) {
+      const float c = fminf(fmaxf(v[i], -F16_MAX), F16_MAX);
+      const _Float16 h = (_Float16)c;
+      hi[i] = h;
+      lo[i] = (_Float16)(c - (float)h);
+    }
+    t[0] = __builtin_bit_cast(frag16, hi);
+    t[1] = __builtin_bit_cast(frag16, lo);
+  } else {
+    bf16x8 q[split_terms(SM)];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float r = v[i];
+#pragma unroll
+      for (int k = 0; k < split_terms(SM); ++k) {
+        const __bf16 h = pe_f2bf(r);
+        q[k][i] = h;
+        r -= pe_bf2f(h);                        // exact: h holds the leading bits of r
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < split_terms(SM); ++k) t[k] = __builtin_bit_cast(frag16, q[k]);
   }
 }
+template <int SM>
+__device__ __forceinline__ f32x16 split_mfma(frag16 a, frag16 b, f32x16 c) {
+  if constexpr (SM == 1) return pe_mfma_f16_32x32x16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c);
+  else return pe_mfma_bf16_32x32x16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c);
+}
 
-template <int WM, int WN, int MT, int NT, bool GATE, int HALO>
-__global__ __launch_bounds__(256, (MT * NT >= 4 ? 2 : 3))
-void conv_bf3_kernel(ConvP p) {
+template <int SM, int WM, int WN, int MT, int NT, bool GATE, int HALO>
+__global__ __launch_bounds__(256, ((MT * NT >= 4 || SM == 2) ? 2 : 3))
+void conv_split_kernel(ConvP p) {
   PE_KTRACE(12);
+  constexpr int NTM = split_terms(SM);            // terms per operand
+  constexpr int NF = 2 * NTM;                     // fragments per (tile, unit): [term][k-step]
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
   constexpr int NCOL = (BN + HALO + 63) / 64;    // staging columns per lane; (taps-1)*dilation <= HALO
   static_assert(WM * WN == 4, "4 waves per block");
   static_assert(!GATE || MT == 2, "gate epilogue pairs two M tiles");
   static_assert(KC == 32, "a chunk is four k groups of 8 channels (two k-steps of the 32x32x16 MFMA)");
   constexpr int XS = NCOL * 64;                   // LDS columns per k group
-  constexpr int PART = 4 * XS;                    // bf16x8 elements per part (hi | lo) of one slab
-  PE_DYN_SMEM(bf16x8, xs);                        // 2 x [2 parts][4 k groups][XS] x 16 bytes
+  constexpr int PART = 4 * XS;                    // fragments per term of one slab
+  PE_DYN_SMEM(frag16, xs);                        // 2 x [NTM terms][4 k groups][XS] x 16 bytes
   const int b = blockIdx.z;
   const int L = p.lens[b] * p.len_mul;
   const int ncols = (p.epi == EPI_CONVT) ? L + 1 : L;
@@ -79,7 +125,8 @@ void conv_bf3_kernel(ConvP p) {
   const float slope = p.in_slope;
   const int ntaps = p.ntaps, nchunks = p.nchunks;
   const int nunits = nchunks * ntaps;             // unit = (chunk, tap)
-  const int wstride_mt = nunits * 1024;
+  constexpr int USTEP = NTM * 512;                // floats per (tile, unit)
+  const int wstride_mt = nunits * USTEP;
   const pe_rowsrc wsrc = pe_make_row(p.wpb + (long)mtile0 * wstride_mt, MT * wstride_mt);
   const int n0 = tile0 * BN;
 
@@ -98,7 +145,7 @@ void conv_bf3_kernel(ConvP p) {
     }
   };
   auto store_x = [&](int buf) {
-    bf16x8* dst = xs + buf * 2 * PART + wv * XS + lane;
+    frag16* dst = xs + buf * NTM * PART + wv * XS + lane;
 #pragma unroll
     for (int cc = 0; cc < NCOL; ++cc) {
       float v[8];
@@ -107,48 +154,51 @@ void conv_bf3_kernel(ConvP p) {
         const float t = xr[rr][cc];
         v[rr] = t > 0.f ? t : t * slope;
       }
-      bf16x8 hi, lo;
-      bf3_split8(v, hi, lo);
-      dst[64 * cc] = hi;
-      dst[PART + 64 * cc] = lo;
+      frag16 t[NTM];
+      split8<SM>(v, t);
+#pragma unroll
+      for (int k = 0; k < NTM; ++k) dst[k * PART + 64 * cc] = t[k];
     }
   };
-  // A fragments of unit u: [part][k-step] per M tile
-  auto load_a = [&](int u, bf16x8 (&a)[MT][4]) {
-    const int off = PE_UNIFORM(u * 1024);
+  // A fragments of unit u: [term][k-step] per M tile
+  auto load_a = [&](int u, frag16 (&a)[MT][NF]) {
+    const int off = PE_UNIFORM(u * USTEP);
 #pragma unroll
     for (int i = 0; i < MT; ++i)
 #pragma unroll
-      for (int f = 0; f < 4; ++f)
-        a[i][f] = __builtin_bit_cast(bf16x8, pe_row_load4(wsrc, off + i * wstride_mt + f * 256 + lane * 4));
+      for (int f = 0; f < NF; ++f)
+        a[i][f] = __builtin_bit_cast(frag16, pe_row_load4(wsrc, off + i * wstride_mt + f * 256 + lane * 4));
   };
-  auto read_b = [&](int tap, const bf16x8* xbuf, bf16x8 (&bv)[NT][4]) {
-    const bf16x8* xp = xbuf + lhi * XS + tap * p.dil + wn * NT * 32 + l31;
+  auto read_b = [&](int tap, const frag16* xbuf, frag16 (&bv)[NT][NF]) {
+    const frag16* xp = xbuf + lhi * XS + tap * p.dil + wn * NT * 32 + l31;
 #pragma unroll
     for (int j = 0; j < NT; ++j)
 #pragma unroll
-      for (int f = 0; f < 4; ++f) bv[j][f] = xp[(f >> 1) * PART + (f & 1) * 2 * XS + j * 32];
+      for (int f = 0; f < NF; ++f) bv[j][f] = xp[(f >> 1) * PART + (f & 1) * 2 * XS + j * 32];
   };
-  // small terms first: lo*hi and hi*lo, then hi*hi, k-step by k-step
-  auto mma = [&](const bf16x8 (&a)[MT][4], const bf16x8 (&bv)[NT][4]) {
+  // one term product over all tiles of the wave: A term ta x B term tb, k-step ks
+  auto prod = [&](const frag16 (&a)[MT][NF], const frag16 (&bv)[NT][NF], int ta, int tb, int ks) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j) acc[i][j] = split_mfma<SM>(a[i][2 * ta + ks], bv[j][2 * tb + ks], acc[i][j]);
+  };
+  // small terms first, k-step by k-step
+  auto mma = [&](const frag16 (&a)[MT][NF], const frag16 (&bv)[NT][NF]) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = pe_mfma_bf16_32x32x16(a[i][2 + ks], bv[j][ks], acc[i][j]);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = pe_mfma_bf16_32x32x16(a[i][ks], bv[j][2 + ks], acc[i][j]);
-#pragma unroll
-      for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j) acc[i][j] = pe_mfma_bf16_32x32x16(a[i][ks], bv[j][ks], acc[i][j]);
+      if constexpr (NTM == 3) {
+        prod(a, bv, 1, 1, ks);
+        prod(a, bv, 2, 0, ks);
+        prod(a, bv, 0, 2, ks);
+      }
+      prod(a, bv, 1, 0, ks);
+      prod(a, bv, 0, 1, ks);
+      prod(a, bv, 0, 0, ks);
     }
   };
 
-  bf16x8 aA[MT][4], aB[MT][4];
+  frag16 aA[MT][NF], aB[MT][NF];
   load_x(0, true);
   load_a(0, aA);
   store_x(0);
@@ -162,10 +212,10 @@ void conv_bf3_kernel(ConvP p) {
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   int u = 0;
   for (int c = 0; c < nchunks; ++c) {
-    const bf16x8* xbuf = xs + (c & 1) * 2 * PART;
+    const frag16* xbuf = xs + (c & 1) * NTM * PART;
     load_x(c + 1, c + 1 < nchunks);               // next slab: in flight for the whole chunk
     for (int tap = 0; tap < ntaps; tap += 2) {
-      bf16x8 bv[NT][4];
+      frag16 bv[NT][NF];
       load_a(u + 1 == nunits ? 0 : u + 1, aB);
       read_b(tap, xbuf, bv);
       PE_SCHED_FENCE();
@@ -185,12 +235,22 @@ void conv_bf3_kernel(ConvP p) {
 #pragma unroll
       for (int i = 0; i < MT; ++i)
 #pragma unroll
-        for (int f = 0; f < 4; ++f) aA[i][f] = aB[i][f];
+        for (int f = 0; f < NF; ++f) aA[i][f] = aB[i][f];
     }
     if (c + 1 < nchunks) {
       store_x((c + 1) & 1);
       __syncthreads();
     }
+  }
+  if constexpr (SM == 1) {
+    // the weights were packed times a power of two (f16's exponent range): undo it, exactly
+    const float us = p.wunscale[0];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] *= us;
   }
   // ---- epilogue (shared with conv_mfma_kernel)
   if constexpr (GATE) {

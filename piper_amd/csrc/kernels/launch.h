@@ -31,7 +31,8 @@ void conv_group_sum(dim3 grid, size_t smem, hipStream_t stream, const ConvP& p);
 // ---- split-bf16 tiled conv GEMM (launch_bf3.cpp; opt-in matrix mode PIPER_HIP_MATRIX=bf16x3)
 void init_bf3();
 // cfg: 0 = 128 x 128 tile, 1 = 64 x 128, 2 = 32 x 256 (engine_launch.cpp BF3_BM / BF3_BN); gate needs cfg 0 or 1
-void conv_bf3(int cfg, bool gate, int halo, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p);
+// sm: split mode of conv_split_kernel (0 bf16x3, 1 f16x3, 2 bf16x6)
+void conv_bf3(int sm, int cfg, bool gate, int halo, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p);
 
 // ---- text encoder / duration predictor / flow glue (launch_front.cpp)
 void init_front();

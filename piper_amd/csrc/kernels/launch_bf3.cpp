@@ -1,4 +1,5 @@
-// Launchers of the split-bf16 conv GEMM kernel (conv_bf3.h): one translation unit of the library build.
+// Launchers of the split-operand conv GEMM kernel (conv_bf3.h: conv_split_kernel), split modes bf16x3 / f16x3 / bf16x6:
+// one translation unit of the library build.
 #include "launch.h"
 
 #include "conv_bf3.h"
@@ -6,23 +7,26 @@
 namespace pe {
 namespace launch {
 
-#define PE_B2(WM, WN, MT, NT, G) (const void*)conv_bf3_kernel<WM, WN, MT, NT, G, 64>, (const void*)conv_bf3_kernel<WM, WN, MT, NT, G, 128>
+#define PE_B2(SM, WM, WN, MT, NT, G) (const void*)conv_split_kernel<SM, WM, WN, MT, NT, G, 64>, (const void*)conv_split_kernel<SM, WM, WN, MT, NT, G, 128>
+#define PE_B10(SM) PE_B2(SM, 2, 2, 2, 2, false), PE_B2(SM, 2, 2, 1, 2, false), PE_B2(SM, 1, 4, 1, 2, false), PE_B2(SM, 2, 2, 2, 2, true), \
+                   PE_B2(SM, 1, 4, 2, 1, true)
 
 void init_bf3() {
 #ifndef PE_EMU
   const int lim = 160 * 1024;
-  const void* ks[] = {PE_B2(2, 2, 2, 2, false), PE_B2(2, 2, 1, 2, false), PE_B2(1, 4, 1, 2, false),
-                      PE_B2(2, 2, 2, 2, true), PE_B2(1, 4, 2, 1, true)};
+  const void* ks[] = {PE_B10(0), PE_B10(1), PE_B10(2)};
   for (const void* k : ks) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
 #endif
 }
+#undef PE_B10
 #undef PE_B2
 
-void conv_bf3(int cfg, bool gate, int halo, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p) {
-#define PE_BF3_LAUNCH(WM, WN, MT, NT, G)                                                                 \
-  do {                                                                                                   \
-    if (halo == 64) PE_LAUNCH((conv_bf3_kernel<WM, WN, MT, NT, G, 64>), grid, dim3(256), smem, stream, p); \
-    else PE_LAUNCH((conv_bf3_kernel<WM, WN, MT, NT, G, 128>), grid, dim3(256), smem, stream, p);         \
+template <int SM>
+static void conv_split_mode(int cfg, bool gate, int halo, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p) {
+#define PE_BF3_LAUNCH(WM, WN, MT, NT, G)                                                                       \
+  do {                                                                                                         \
+    if (halo == 64) PE_LAUNCH((conv_split_kernel<SM, WM, WN, MT, NT, G, 64>), grid, dim3(256), smem, stream, p); \
+    else PE_LAUNCH((conv_split_kernel<SM, WM, WN, MT, NT, G, 128>), grid, dim3(256), smem, stream, p);         \
   } while (0)
   if (gate) {
     if (cfg == 0) PE_BF3_LAUNCH(2, 2, 2, 2, true);
@@ -35,6 +39,12 @@ void conv_bf3(int cfg, bool gate, int halo, dim3 grid, size_t smem, hipStream_t 
     }
   }
 #undef PE_BF3_LAUNCH
+}
+
+void conv_bf3(int sm, int cfg, bool gate, int halo, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p) {
+  if (sm == 1) conv_split_mode<1>(cfg, gate, halo, grid, smem, stream, p);
+  else if (sm == 2) conv_split_mode<2>(cfg, gate, halo, grid, smem, stream, p);
+  else conv_split_mode<0>(cfg, gate, halo, grid, smem, stream, p);
 }
 
 }  // namespace launch

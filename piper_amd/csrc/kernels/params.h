@@ -15,7 +15,8 @@ struct ConvP {
   const float* x; long x_bs; int x_cs;          // input  x[b][ci][t]
   const float* wp;                              // packed weights (engine_pack.cpp: pack_conv)
   const float* wp16;                            // conv_splitk16_kernel: the same in 16x16x4 fragment order, or null
-  const float* wpb;                             // conv_bf3_kernel: bf16 hi/lo split fragments (engine_pack.cpp pack_matrix), or null
+  const float* wpb;                             // conv_split_kernel: 16-bit split-term fragments of the matrix mode (engine_pack.cpp pack_matrix), or null
+  const float* wunscale;                        // conv_split_kernel, mode f16x3: the weights were packed times 1 / *wunscale (a power of two)
   const float* wpg4;                            // gate4_kernel: the gate conv in [group][tap][k quad][lane][4] order (192 input channels), or null
   const float* bias;                            // per output channel or null
   const float* bias2; int bias2_bs;             // per-utterance extra bias (speaker cond) or null

@@ -138,7 +138,10 @@ static bool to_int64(const OTensor& t, std::vector<int64_t>& out) {
   }
   if (t.idata.p || n == 0) {
     Reader r(t.idata);
-    while (r.more()) out.push_back((int64_t)r.varint());
+    while (r.more()) {
+      if ((int64_t)out.size() >= n) return false;        // more values than the dims announce
+      out.push_back((int64_t)r.varint());
+    }
     return (int64_t)out.size() == n;
   }
   return false;
@@ -201,7 +204,10 @@ const OTensor* Graph::tensor(const std::string& name, int depth) const {
     const int64_t nr = rank + (int64_t)ax.size();
     for (auto& a : ax) { if (a < 0) a += nr; if (a < 0 || a >= nr) return nullptr; }
     std::vector<int64_t> d((size_t)nr, 0);
-    for (auto a : ax) d[(size_t)a] = -1;
+    for (auto a : ax) {
+      if (d[(size_t)a] == -1) return nullptr;           // duplicate axis: fewer slots marked than counted (a crafted file)
+      d[(size_t)a] = -1;
+    }
     size_t k = 0;
     for (auto& x : d) x = x == -1 ? 1 : src->dims[k++];
     t.dims = d;
@@ -229,9 +235,15 @@ const OTensor* Graph::tensor(const std::string& name, int depth) const {
       return nullptr;
     }
     int64_t known = 1, neg = -1;
+    const int64_t total = src->numel();
+    if (sh.size() > 8) return nullptr;
     for (size_t i = 0; i < sh.size(); ++i) {
       if (sh[i] == 0) { if (i >= (size_t)rank) return nullptr; sh[i] = src->dims[i]; }
-      if (sh[i] == -1) { if (neg >= 0) return nullptr; neg = (int64_t)i; } else known *= sh[i];
+      if (sh[i] < -1) return nullptr;                   // only -1 may be negative
+      if (sh[i] == -1) { if (neg >= 0) return nullptr; neg = (int64_t)i; continue; }
+      // (the product of the given extents can never exceed the element count: no signed overflow on crafted values)
+      if (sh[i] != 0 && known > std::max<int64_t>(total, 1) / sh[i]) return nullptr;
+      known *= sh[i];
     }
     if (neg >= 0) { if (known == 0 || src->numel() % known) return nullptr; sh[(size_t)neg] = src->numel() / known; known *= sh[(size_t)neg]; }
     if (known != src->numel()) return nullptr;
@@ -434,8 +446,31 @@ WeightSet load_onnx(const std::string& path) {
     c.node = &n;
     c.w = g.tensor(n.in[1]);
     if (!c.w || c.w->dims.size() != 3) fail("conv weight of node " + n.name + " is not a rank-3 constant");
-    c.b = n.in.size() > 2 ? g.tensor(n.in[2]) : nullptr;
+    c.b = (n.in.size() > 2 && !n.in[2].empty()) ? g.tensor(n.in[2]) : nullptr;
     c.transpose = n.op == "ConvTranspose";
+    if (!c.b && !n.out.empty()) {
+      // A post-export tool may leave the bias as an Add behind the conv: Conv(x, W) -> Add(., b[1, C, 1]) (onnx-simplifier
+      // does the opposite fusion, older exporters emit this form for weight-normed layers). The constant operand of the
+      // ONLY consumer, when that is an Add and the constant has one value per output channel, is the bias.
+      const int64_t cout = c.transpose ? c.w->dims[1] * std::max<int64_t>(attr1(n, "group", 1), 1) : c.w->dims[0];
+      auto rng = g.consumers.equal_range(n.out[0]);
+      if (rng.first != rng.second && std::next(rng.first) == rng.second && g.nodes[rng.first->second].op == "Add") {
+        const ONode& add = g.nodes[rng.first->second];
+        for (auto& in : add.in) {
+          if (in == n.out[0]) continue;
+          const OTensor* t = g.tensor(in);
+          if (!(t && t->dtype == 1 && !t->external && t->numel() == cout && t->dims.size() <= 3)) continue;
+          bool per_channel = t->dims.size() == 1;
+          if (t->dims.size() == 2) per_channel = t->dims[0] == cout && t->dims[1] == 1;
+          if (t->dims.size() == 3) per_channel = t->dims[0] == 1 && t->dims[1] == cout && t->dims[2] == 1;
+          if (!per_channel) continue;
+          OTensor flat = *t;
+          flat.dims = {cout};
+          g.derived.push_back(std::move(flat));
+          c.b = &g.derived.back();
+        }
+      }
+    }
     c.dil = (int)attr1(n, "dilations", 1);
     c.group = (int)attr1(n, "group", 1);
     c.stride = (int)attr1(n, "strides", 1);
@@ -620,8 +655,9 @@ WeightSet load_onnx(const std::string& path) {
       if (g.transparent(n)) continue;          // (an Identity / reshape over a constant is not a use of it: its consumer is)
       for (auto& in : n.in) {
         const OTensor* t = g.tensor(in);
+        // ([1, 2w+1, dk] with dk >= 2: a per-channel bias kept as an Add operand [1, C, 1] is not a candidate)
         if (!(t && t->dtype == 1 && t->dims.size() == 3 && t->dims[0] == 1 && (t->dims[1] & 1) && H % t->dims[2] == 0 &&
-              t->dims[2] < H && n.op != "Conv" && n.op != "ConvTranspose" && !seen.count(in)))
+              t->dims[2] >= 2 && t->dims[2] < H && n.op != "Conv" && n.op != "ConvTranspose" && !seen.count(in)))
           continue;
         seen.insert(in);
         // forward to the MatMul that takes it as second operand

@@ -749,6 +749,7 @@ struct pe_coalescer {
   std::condition_variable cv;
   std::deque<Req*> q;
   bool busy = false;          // a leader is inside the engine
+  int inside = 0;             // callers inside pe_coalescer_synthesize (pe_coalescer_destroy waits for them)
   int64_t calls = 0, requests = 0;
 };
 
@@ -766,7 +767,15 @@ int pe_coalescer_create(pe_engine* e, int32_t max_batch, int32_t max_wait_us, pe
   });
 }
 
-void pe_coalescer_destroy(pe_coalescer* c) { delete c; }
+void pe_coalescer_destroy(pe_coalescer* c) {
+  if (!c) return;
+  {
+    // requests still queued or a leader inside the engine: wait for them (their stack frames hold pointers into *c)
+    std::unique_lock<std::mutex> lk(c->m);
+    c->cv.wait(lk, [&] { return !c->busy && c->q.empty() && c->inside == 0; });
+  }
+  delete c;
+}
 
 int pe_coalescer_stats(pe_coalescer* c, int64_t* engine_calls, int64_t* requests) {
   return guard([&] {
@@ -787,6 +796,30 @@ int pe_coalescer_synthesize(pe_coalescer* c, const int64_t* ids, int64_t n_ids, 
     me.ids = ids; me.n = n_ids; me.sid = sid;
     memcpy(me.scales, scales, sizeof(me.scales));
     std::unique_lock<std::mutex> lk(c->m);
+    // Whatever ends this call -- also an exception between taking the lead and the engine call (std::bad_alloc of the
+    // batch vector) -- `me` must leave the queue, a lead must be given up, and requests this thread had taken must fail
+    // rather than wait forever: a scope guard, run with the lock held.
+    std::vector<pe_coalescer::Req*> take;
+    bool leading = false, finished = false;
+    struct Cleanup {
+      pe_coalescer* c; pe_coalescer::Req* me; std::unique_lock<std::mutex>& lk; std::vector<pe_coalescer::Req*>& take;
+      bool& leading; bool& finished;
+      ~Cleanup() {
+        if (!lk.owns_lock()) lk.lock();
+        if (!finished) {
+          for (auto it = c->q.begin(); it != c->q.end();) it = (*it == me) ? c->q.erase(it) : it + 1;
+          if (leading) {
+            for (auto* r : take)
+              if (r != me && r->state == 1) { r->err = "the request's batch leader failed"; r->state = 3; }
+            c->busy = false;
+          }
+        }
+        --c->inside;
+        c->cv.notify_all();
+      }
+    } cleanup{c, &me, lk, take, leading, finished};
+    ++c->inside;
+    take.reserve((size_t)c->max_batch);
     c->q.push_back(&me);
     ++c->requests;
     c->cv.notify_all();                         // (a leader collecting its batch counts the queue)
@@ -796,11 +829,12 @@ int pe_coalescer_synthesize(pe_coalescer* c, const int64_t* ids, int64_t n_ids, 
         // ---- leader: optionally give concurrent callers max_wait_us to arrive, then take what is queued (requests with
         // the leader's scales, up to max_batch) and run it as ONE engine call
         c->busy = true;
+        leading = true;
+        take.clear();
         if (c->max_wait_us > 0) {
           const auto until = std::chrono::steady_clock::now() + std::chrono::microseconds(c->max_wait_us);
           c->cv.wait_until(lk, until, [&] { return (int)c->q.size() >= c->max_batch; });
         }
-        std::vector<pe_coalescer::Req*> take;
         for (auto it = c->q.begin(); it != c->q.end() && (int)take.size() < c->max_batch;) {
           pe_coalescer::Req* r = *it;
           if (r == &me || !memcmp(r->scales, me.scales, sizeof(me.scales))) {
@@ -857,11 +891,13 @@ int pe_coalescer_synthesize(pe_coalescer* c, const int64_t* ids, int64_t n_ids, 
           }
         }
         c->busy = false;
+        leading = false;
         c->cv.notify_all();                     // followers pick their results up; one of the queued becomes the next leader
         continue;
       }
       c->cv.wait(lk);
     }
+    finished = true;                            // (served: `me` left the queue when a leader took it)
     lk.unlock();
     if (me.state == 3) throw std::runtime_error(me.err);
     *pcm = me.pcm;

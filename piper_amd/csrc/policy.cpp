@@ -71,11 +71,13 @@ void LaunchPolicy::read_env() {
   }
 }
 
-bool LaunchPolicy::matrix_bf3_env() {
+int LaunchPolicy::matrix_mode_env() {
   const char* t = getenv("PIPER_HIP_MATRIX");
-  if (!t || !t[0] || !strcmp(t, "f32")) return false;
-  if (!strcmp(t, "bf16x3")) return true;
-  throw std::runtime_error("PIPER_HIP_MATRIX: expected f32 or bf16x3");
+  if (!t || !t[0] || !strcmp(t, "f32")) return -1;
+  if (!strcmp(t, "bf16x3")) return 0;
+  if (!strcmp(t, "f16x3")) return 1;
+  if (!strcmp(t, "bf16x6")) return 2;
+  throw std::runtime_error("PIPER_HIP_MATRIX: expected f32, bf16x3, f16x3 or bf16x6");
 }
 
 const char* LaunchPolicy::describe() {

@@ -68,9 +68,10 @@ struct LaunchPolicy {
   void read_env();
   // the table as a JSON array (name, default, lo, hi, doc): pe_policy_describe() of the C ABI, DESIGN.md section 4.1
   static const char* describe();
-  // the one string-valued knob: PIPER_HIP_MATRIX = f32 (default) | bf16x3 (opt-in matrix mode, kernels/conv_bf3.h); anything
-  // else throws
-  static bool matrix_bf3_env();
+  // the one string-valued knob: PIPER_HIP_MATRIX = f32 (default) | bf16x3 | f16x3 | bf16x6 (opt-in split-operand matrix
+  // modes, kernels/conv_bf3.h); anything else throws. matrix_mode_env: -1 = f32, else the kernel's split mode SM (0 / 1 / 2)
+  static int matrix_mode_env();
+  static bool matrix_bf3_env() { return matrix_mode_env() >= 0; }
 
   // ---- decisions ------------------------------------------------------------------------------------------------
   // conv routing (engine_launch.cpp Engine::conv): `blocks` = workgroups the tiled kernel would launch, `halo` =

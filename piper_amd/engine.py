@@ -119,16 +119,18 @@ class Engine:
 
     def _collect(self, res: L.PeResult, want_audio=True, want_pcm=True) -> Synthesis:
         B = res.batch
-        offs = np.ctypeslib.as_array(res.sample_offsets, (B + 1,)).copy()
-        frames = np.ctypeslib.as_array(res.frames, (B,)).copy()
+        offs = np.frombuffer(C.string_at(res.sample_offsets, 8 * (B + 1)), np.int64)
+        frames = np.frombuffer(C.string_at(res.frames, 4 * B), np.int32).copy()
         total = int(offs[-1])
         audio, pcm = [], []
+        # (one copy out of the engine's pinned buffers through string_at; np.ctypeslib.as_array would build a new ctypes
+        # array type for every distinct sample count -- ~0.7 ms per call when the frame counts change from call to call)
         if want_audio and total:
-            a = np.ctypeslib.as_array(res.audio, (total,))
-            audio = [a[offs[i]:offs[i + 1]].copy() for i in range(B)]
+            a = np.frombuffer(bytearray(C.string_at(res.audio, 4 * total)), np.float32)
+            audio = [a[offs[i]:offs[i + 1]] for i in range(B)]
         if want_pcm and total:
-            p = np.ctypeslib.as_array(res.pcm, (total,))
-            pcm = [p[offs[i]:offs[i + 1]].copy() for i in range(B)]
+            p = np.frombuffer(bytearray(C.string_at(res.pcm, 2 * total)), np.int16)
+            pcm = [p[offs[i]:offs[i + 1]] for i in range(B)]
         return Synthesis(audio, pcm, frames, res.infer_seconds)
 
     # ---- API

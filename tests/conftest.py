@@ -76,7 +76,7 @@ def pytest_cmdline_main(config):
 # first so that the xdist run ends with short tests instead of one long straggler.
 _LONGEST_FIRST = [
     "test_cpp_piper_api_on_emulator", "test_emulated_attention_conv_o_layernorm_in_one_launch[lens1",
-    "test_warmup_presizes_and_leaves_results_unchanged", "test_emulated_bf16x3_matrix_mode[tiny-high",
+    "test_warmup_presizes_and_leaves_results_unchanged", "test_emulated_split_matrix_modes[tiny-high",
     "test_xcd_aware_ffn_slice_order_is_bit_identical", "test_emulated_attention_conv_o_layernorm_in_one_launch[lens0",
     "test_jsonl_drivers_on_emulator", "test_small_call_kernels_do_not_depend_on_wave_order",
     "test_emulated_192_channel_small_call_kernels", "test_engine_group_matches_single_engine",

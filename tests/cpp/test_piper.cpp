@@ -14,7 +14,44 @@
 
 #include "piper.hpp"
 
+// test_piper --config <voice.onnx> <voice.onnx.json>: piper::loadVoice with an explicit config file; every field the
+// reference's parsers fill (src/cpp/piper.cpp:47-214) is printed, one `key=value` per line, for the pytest wrapper.
+static int dump_config(const char* onnx, const char* json) {
+  try {
+    piper::PiperConfig config;
+    piper::Voice voice;
+    std::optional<piper::SpeakerId> speaker;
+    piper::loadVoice(config, onnx, json, voice, speaker, false);
+    const piper::PhonemizeConfig& pc = voice.phonemizeConfig;
+    std::printf("phoneme_type=%s\n", pc.phonemeType == piper::TextPhonemes ? "text" : "espeak");
+    std::printf("espeak_voice=%s\n", pc.eSpeak.voice.c_str());
+    std::printf("phoneme_map=%s\n", pc.phonemeMap ? std::to_string(pc.phonemeMap->size()).c_str() : "none");
+    std::printf("phoneme_id_map=%zu\n", pc.phonemeIdMap.size());
+    for (auto& kv : pc.phonemeIdMap) {
+      std::printf("id U+%04X", (unsigned)kv.first);
+      for (auto v : kv.second) std::printf(" %lld", (long long)v);
+      std::printf("\n");
+    }
+    std::printf("id_pad=%lld id_bos=%lld id_eos=%lld interspersePad=%d\n", (long long)pc.idPad, (long long)pc.idBos,
+                (long long)pc.idEos, (int)pc.interspersePad);
+    const piper::SynthesisConfig& sc = voice.synthesisConfig;
+    std::printf("sample_rate=%d sample_width=%d channels=%d\n", sc.sampleRate, sc.sampleWidth, sc.channels);
+    std::printf("noise_scale=%.9g length_scale=%.9g noise_w=%.9g sentence_silence=%.9g\n", sc.noiseScale, sc.lengthScale, sc.noiseW,
+                sc.sentenceSilenceSeconds);
+    std::printf("phoneme_silence=%s\n", sc.phonemeSilenceSeconds ? std::to_string(sc.phonemeSilenceSeconds->size()).c_str() : "none");
+    std::printf("speaker_id=%s\n", sc.speakerId ? std::to_string(*sc.speakerId).c_str() : "none");
+    std::printf("num_speakers=%d\n", voice.modelConfig.numSpeakers);
+    std::printf("speaker_id_map=%s\n", voice.modelConfig.speakerIdMap ? std::to_string(voice.modelConfig.speakerIdMap->size()).c_str() : "none");
+    std::printf("config_text_bytes=%zu\n", voice.configText.size());
+    return 0;
+  } catch (const std::exception& e) {
+    std::cerr << "EXCEPTION: " << e.what() << "\n";
+    return 1;
+  }
+}
+
 int main(int argc, char** argv) {
+  if (argc == 4 && std::string(argv[1]) == "--config") return dump_config(argv[2], argv[3]);
   if (argc < 3) {
     std::cerr << "usage: test_piper voice.onnx out.wav\n";
     return 2;

@@ -174,6 +174,36 @@ inline f32x16 emu_mfma_bf16_32x32x16(emu_bf16x8 a, emu_bf16x8 b, f32x16 c) {
   return c;
 }
 
+// v_mfma_f32_32x32x16_f16: the same operand / result layout with IEEE half terms (subnormal inputs are NOT flushed).
+// Products of two halves are exact in f32 (11 x 11 significand bits); f32 accumulation.
+typedef _Float16 emu_f16x8 __attribute__((ext_vector_type(8)));
+inline f32x16 emu_mfma_f16_32x32x16(emu_f16x8 a, emu_f16x8 b, f32x16 c) {
+  const int l = emu::lane(), j = l & 31;
+  float au[4], bu[4];
+  memcpy(au, &a, 16);
+  memcpy(bu, &b, 16);
+  for (int d = 0; d < 4; ++d) {
+    const int par = emu::collective_parity();
+    float* sa = emu::wave_f(2 + par);
+    float* sb = emu::wave_f(4 + par);
+    sa[l] = au[d];
+    sb[l] = bu[d];
+    emu::wave_sync();
+    for (int r = 0; r < 16; ++r) {
+      const int i = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+      float acc = c[r];
+      for (int h = 0; h < 2; ++h) {
+        _Float16 ha[2], hb[2];
+        memcpy(ha, &sa[32 * h + i], 4);
+        memcpy(hb, &sb[32 * h + j], 4);
+        for (int e = 0; e < 2; ++e) acc = fmaf((float)ha[e], (float)hb[e], acc);
+      }
+      c[r] = acc;
+    }
+  }
+  return c;
+}
+
 // ---- atomics (single-threaded: plain read-modify-write) ------------------------------------------
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 template <class T> inline T atomicMax(T* p, T v) { T o = *p; if (v > o) *p = v; return o; }

@@ -66,7 +66,7 @@ def test_honesty_fields_are_in_the_compact_line():
     assert by["configs[4]"]["streaming_samples_per_s"] == 4.2e7
     for l in d["extra_configs"]:
         if l.get("dtype") == "bf16x3" and "frac" in l:
-            assert "bf16x3 peak" in l["frac_of"] and 0 < l["frac"] <= 1.0, l
+            assert l["peak_tflops"] == 833 and 0 < l["frac"] <= 1.0, l
 
 
 def test_multi_gpu_line_is_compact():

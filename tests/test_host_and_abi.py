@@ -149,6 +149,44 @@ def test_cpp_piper_api_on_emulator(tmp_path):
         assert wf.getnframes() * 2 + 44 == os.path.getsize(wav) >= 10000
 
 
+def test_reference_voice_config_through_load_voice():
+    """The reference's own voice config, etc/test_voice.onnx.json (a fixture: it is data, copied byte for byte to
+    tests/golden/ref_test_voice.onnx.json), through piper::loadVoice's JSON reader in the C++ program: every field the
+    reference's parsers fill (src/cpp/piper.cpp:47-132 phonemize, :135-195 synthesis, :197-214 model) -- eSpeak voice,
+    phoneme type default, an EMPTY phoneme_map that still creates the map (:117-131), all 130 phoneme-id entries, scales,
+    sample rate, num_speakers, an empty speaker_id_map, no speaker selected for a single-speaker voice (:326-331)."""
+    import subprocess
+    ref = os.path.join(GOLD, "ref_test_voice.onnx.json")
+    if os.path.exists("/root/reference/etc/test_voice.onnx.json"):          # the fixture IS the reference's file
+        assert open(ref, "rb").read() == open("/root/reference/etc/test_voice.onnx.json", "rb").read()
+    subprocess.check_call(["make", "-C", ROOT, "emu", "tests/cpp/test_piper_emu"], stdout=subprocess.DEVNULL)
+    out = subprocess.run([os.path.join(ROOT, "tests", "cpp", "test_piper_emu"), "--config", os.path.join(GOLD, "tiny_voice.onnx"), ref],
+                         capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    kv, ids = {}, {}
+    for line in out.stdout.splitlines():
+        if line.startswith("id U+"):
+            parts = line.split()
+            ids[chr(int(parts[1][2:], 16))] = [int(x) for x in parts[2:]]
+        else:
+            for tok in line.split():
+                k, _, v = tok.partition("=")
+                kv[k] = v
+    cfg = json.load(open(ref, encoding="utf-8"))
+    assert kv["phoneme_type"] == "espeak" and kv["espeak_voice"] == cfg["espeak"]["voice"] == "en-us"
+    assert kv["phoneme_map"] == "0"                       # present and empty: the map exists, with no entries
+    assert int(kv["phoneme_id_map"]) == len(cfg["phoneme_id_map"]) == 130
+    assert ids == {k: v for k, v in cfg["phoneme_id_map"].items()}
+    assert (kv["id_pad"], kv["id_bos"], kv["id_eos"]) == ("0", "1", "2")          # piper.hpp:44-47
+    assert kv["interspersePad"] == "1"
+    assert kv["sample_rate"] == "16000" and kv["sample_width"] == "2" and kv["channels"] == "1"
+    assert abs(float(kv["noise_scale"]) - 0.667) < 1e-6 and float(kv["length_scale"]) == 1.0
+    assert abs(float(kv["noise_w"]) - 0.8) < 1e-6 and abs(float(kv["sentence_silence"]) - 0.2) < 1e-6
+    assert kv["phoneme_silence"] == "none" and kv["speaker_id"] == "none"
+    assert kv["num_speakers"] == "1" and kv["speaker_id_map"] == "0"
+    assert int(kv["config_text_bytes"]) == os.path.getsize(ref)
+
+
 def test_jsonl_drivers_on_emulator(tmp_path):
     """piper_amd.infer / piper_amd.benchmark mirror the reference's infer_onnx.py / benchmark_onnx.py command
     lines (JSONL of phoneme ids on stdin); run here against the emulator build of the engine."""

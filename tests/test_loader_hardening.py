@@ -145,6 +145,11 @@ R5_VARIANTS = {
     "opset_lt13_attribute_forms": lambda m: m.axes_inputs_to_attributes(),
     "all_of_them": lambda m: (m.axes_inputs_to_attributes(), m.transpose_conv_weights(2), m.unsqueeze_k1_weights(True),
                               m.reshape_biases(), m.identity_shared(3), m.rename_initializers_to_numerals(), m.strip_node_names()),
+    "conv_bias_as_add": lambda m: m.conv_bias_to_add(2),
+    "every_conv_bias_as_add": lambda m: m.conv_bias_to_add(1),
+    "gelu_div_folded_pow_as_mul": lambda m: m.gelu_div_to_mul(),
+    "bias_add_gelu_everything": lambda m: (m.gelu_div_to_mul(), m.conv_bias_to_add(1), m.identity_shared(3),
+                                           m.rename_initializers_to_numerals(), m.strip_node_names()),
     "glue_and_qkv_reordered": lambda m: m.shuffle_nodes(7, keep_conv_order=True),
     "glue_and_qkv_reordered_anonymous": lambda m: (m.shuffle_nodes(11, keep_conv_order=True), m.rename_initializers_to_numerals(),
                                                    m.strip_node_names()),
@@ -217,3 +222,16 @@ def test_swapped_cond_layers_fail_by_name(lib, tmp_path, pair):
         load(lib, out)
     msg = str(ei.value)
     assert "node order is not the exporter's execution order" in msg and "cond_layer" in msg, msg
+
+
+@pytest.mark.parametrize("as_input", [True, False])
+def test_crafted_unsqueeze_axes_fail_cleanly(lib, tmp_path, as_input):
+    """an Unsqueeze whose axes repeat (a crafted file) used to mark fewer slots than it counted and read
+    past the source dims. The folder now refuses it, so the conv weight behind it is simply not a constant: a named error."""
+    m = M.Model(open(os.path.join(GOLD, "tiny_voice.onnx"), "rb").read())
+    assert m.unsqueeze_k1_weights(as_input, axes=(2, 2)) > 0
+    out = tmp_path / "dup_axes.onnx"
+    out.write_bytes(m.save())
+    with pytest.raises(RuntimeError) as ei:
+        load(lib, out)
+    assert "is not a rank-3 constant" in str(ei.value), str(ei.value)
