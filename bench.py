@@ -74,6 +74,8 @@ def kernel_peak(name):
     for m, (sm, n) in SPLIT_MODES.items():
         if name.startswith(f"conv_split_kernel<{sm},"):
             return 2500.0 / n
+        if name.startswith(f"mrf_split_kernel<{sm},"):
+            return 2500.0 / n
     return BF16X3_PEAK_TFLOPS if name.startswith("conv_bf3_kernel") else FP32_MATRIX_PEAK_TFLOPS
 SCALES = (0.667, 1.0, 0.8)
 

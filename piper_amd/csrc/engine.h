@@ -301,6 +301,9 @@ class Engine {
     struct HostConv { std::vector<float> w; int co = 0, ci = 0, k = 0, dil = 1; const float* bias = nullptr; };
     std::vector<std::vector<HostConv>> rb_host;   // host copies of the resblock convs, dropped after build_mrf
     void* mrf_phases = nullptr; float* mrf_w = nullptr;
+    // the same stage for mrf_split_kernel (matrix modes bf16x3 / f16x3): the weight stream as 16-bit term fragments and,
+    // per phase, the factor that undoes the f16 packing scale (both in the arena: they travel with the broadcast)
+    float* mrf_wsplit = nullptr; float* mrf_unscale = nullptr; int mrf_wsplit_floats = 0;
     int mrf_wfloats = 0, mrf_cp = 0, mrf_hx = 0;  // padded channels (32 / 64), halo of the stage (widest resblock chain)
     std::vector<struct MrfPhase> mrf_ph;          // host copy of the phases (cost model of the geometry choice)
     bool mrf_ok = false, mrf_rb1 = false;

@@ -449,7 +449,8 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
       // one utterance and lose at batch (its 64-channel stage: 86 vs ~110 TFLOP/s for the conv GEMM kernel on K = 64 * 11
       // convs), so those are fused for one or two utterances and on 32 channels only.
       // (matrix mode bf16x3: the fused kernel is f32; from a few utterances up the conv-by-conv schedule on the bf16 pipe is faster)
-      const bool fuse = pol_.mrf_stage(st.mrf_ok, st.mrf_rb1, st.mrf_cp, fsum, matrix_bf3_);
+      const bool fuse = pol_.mrf_stage(st.mrf_ok, st.mrf_rb1, st.mrf_cp, fsum, matrix_bf3_,
+                                       matrix_bf3_ && pol_.mrf_split && st.mrf_wsplit != nullptr);
       // the last stage also runs the generator tail (conv_post, tanh, peak) on its MRF mean while it is still on chip
       const bool tail = fuse && pol_.mrf_tail && &st == &ups_.back() && st.mrf_cp == 32 && st.ch == post_cin_ && mult == hop_;
       // leaky_relu(0.1) -> ConvTranspose1d

@@ -407,9 +407,16 @@ void Engine::mrf(const UpStage& st, View x, View out, const int* lens, int len_m
   }
   dim3 grid((Lmax + p.stride - 1) / p.stride, B_);
   char nm[64];
-  snprintf(nm, sizeof(nm), "mrf_kernel<%d,%d,%d>", CP, best.ou, HU);
+  const bool split = matrix_bf3_ && pol_.mrf_split && st.mrf_wsplit != nullptr && matrix_sm_ < 2;
+  if (split) {          // the same stage on the 16-bit pipe (kernels/mrf_split.h): same window geometry, the split weight stream
+    p.wstream = st.mrf_wsplit; p.wfloats = st.mrf_wsplit_floats; p.wunscale = st.mrf_unscale;
+    snprintf(nm, sizeof(nm), "mrf_split_kernel<%d,%d,%d,%d>", matrix_sm_, CP, best.ou, HU);
+  } else {
+    snprintf(nm, sizeof(nm), "mrf_kernel<%d,%d,%d>", CP, best.ou, HU);
+  }
   const int kh = prof_level_ >= 2 ? kbegin(krow(std::string(nm)), kflops, kbytes) : -1;
-  launch::mrf(CP, best.ou, grid, ls_, p);
+  if (split) launch::mrf_split(matrix_sm_, CP, best.ou, grid, ls_, p);
+  else launch::mrf(CP, best.ou, grid, ls_, p);
   kend(kh);
 }
 

@@ -682,6 +682,11 @@ void Engine::build_mrf(UpStage& st) {
   const int hxa = rup(hx, 16);
   std::vector<MrfPhase> phases;
   std::vector<float> wstream;
+  // matrix modes bf16x3 / f16x3: the same stream as two 16-bit terms per weight for mrf_split_kernel (kernels/mrf_split.h):
+  // [phase][step][16-row tile][term][lane][8], lane -> row = lane & 15, input channel chunk * 32 + 8 * (lane >> 4) + e
+  const bool split = matrix_bf3_ && matrix_sm_ < 2;
+  std::vector<uint16_t> wsplit;
+  std::vector<float> unscale;
   for (size_t j = 0; j < st.rb_host.size(); ++j) {
     auto& hv = st.rb_host[j];
     const int n = (int)hv.size();
@@ -720,6 +725,45 @@ void Engine::build_mrf(UpStage& st) {
                   wstream[w0 + ((size_t)(step * MS + ms) * 2 + q) * 256 + lane * 4 + jj] = h.w[((size_t)row * ch + ci) * h.k + tap];
               }
       }
+      if (split) {
+        float wscale = 1.f;
+        if (matrix_sm_ == 1 && !skeleton_) {          // f16: the conv's largest weight lands in [2^12, 2^13) (engine_pack.cpp pack_matrix)
+          float mx = 0.f;
+          for (float v : h.w) mx = std::max(mx, std::fabs(v));
+          if (mx > 0.f && std::isfinite(mx)) {
+            int ex = 0;
+            std::frexp(mx, &ex);
+            wscale = std::ldexp(1.f, 13 - ex);
+          }
+        }
+        unscale.push_back(1.f / wscale);
+        const size_t s0 = wsplit.size();
+        wsplit.resize(s0 + (size_t)nsteps * MS * 2 * 512, 0);      // 2 terms x 64 lanes x 8 elements per (step, tile)
+        for (int step = 0; step < (skeleton_ ? 0 : nsteps); ++step) {
+          const int c = step / h.k, tap = step % h.k;
+          for (int ms = 0; ms < MS; ++ms)
+            for (int lane = 0; lane < 64; ++lane)
+              for (int el = 0; el < 8; ++el) {
+                const int row = ms * 16 + (lane & 15), ci = c * KC + 8 * (lane >> 4) + el;
+                if (row >= ch || ci >= ch) continue;
+                float rem = h.w[((size_t)row * ch + ci) * h.k + tap] * wscale;
+                for (int t = 0; t < 2; ++t) {
+                  uint16_t bits;
+                  float back;
+                  if (matrix_sm_ == 1) {
+                    const _Float16 hv16 = (_Float16)rem;
+                    memcpy(&bits, &hv16, 2);
+                    back = (float)hv16;
+                  } else {
+                    bits = bf16_rne(rem);
+                    back = bf16_to_f32(bits);
+                  }
+                  wsplit[s0 + (((size_t)(step * MS + ms) * 2 + t) * 64 + lane) * 8 + el] = bits;
+                  rem -= back;
+                }
+              }
+        }
+      }
       phases.push_back(P);
     }
   }
@@ -737,6 +781,12 @@ void Engine::build_mrf(UpStage& st) {
   st.mrf_phases = d;
   st.mrf_w = dev_alloc(wstream.size(), wstream.data());      // weights: in the arena (travels with the broadcast)
   st.mrf_wfloats = (int)wstream.size();
+  if (split) {
+    st.mrf_wsplit_floats = (int)(wsplit.size() / 2);
+    st.mrf_wsplit = dev_alloc(wsplit.size() / 2, reinterpret_cast<const float*>(wsplit.data()));
+    unscale.resize(MRF_MAXPH, 1.f);
+    st.mrf_unscale = dev_alloc(unscale.size(), unscale.data());
+  }
   st.mrf_cp = CP;
   st.mrf_ph = phases;
   st.mrf_hx = hx;

@@ -33,6 +33,8 @@ void init_bf3();
 // cfg: 0 = 128 x 128 tile, 1 = 64 x 128, 2 = 32 x 256 (engine_launch.cpp BF3_BM / BF3_BN); gate needs cfg 0 or 1
 // sm: split mode of conv_split_kernel (0 bf16x3, 1 f16x3, 2 bf16x6)
 void conv_bf3(int sm, int cfg, bool gate, int halo, dim3 grid, size_t smem, hipStream_t stream, const ConvP& p);
+// the fused MRF stage on the 16-bit pipe (mrf_split.h): sm = 0 (bf16x3) or 1 (f16x3); cp / ou as launch::mrf
+void mrf_split(int sm, int cp, int ou, dim3 grid, hipStream_t stream, const MrfP& p);
 
 // ---- text encoder / duration predictor / flow glue (launch_front.cpp)
 void init_front();

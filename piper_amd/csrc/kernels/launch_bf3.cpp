@@ -3,6 +3,7 @@
 #include "launch.h"
 
 #include "conv_bf3.h"
+#include "mrf_split.h"
 
 namespace pe {
 namespace launch {
@@ -14,7 +15,12 @@ namespace launch {
 void init_bf3() {
 #ifndef PE_EMU
   const int lim = 160 * 1024;
-  const void* ks[] = {PE_B10(0), PE_B10(1), PE_B10(2)};
+  const void* ks[] = {PE_B10(0), PE_B10(1), PE_B10(2),
+#define PE_MS7(SM) (const void*)mrf_split_kernel<SM, 32, 1, 1>, (const void*)mrf_split_kernel<SM, 32, 2, 1>, (const void*)mrf_split_kernel<SM, 32, 3, 1>, \
+                   (const void*)mrf_split_kernel<SM, 32, 4, 1>, (const void*)mrf_split_kernel<SM, 64, 1, 2>, (const void*)mrf_split_kernel<SM, 64, 2, 2>, \
+                   (const void*)mrf_split_kernel<SM, 64, 3, 2>
+                      PE_MS7(0), PE_MS7(1)};
+#undef PE_MS7
   for (const void* k : ks) PE_HIP(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, lim));
 #endif
 }
@@ -45,6 +51,23 @@ void conv_bf3(int sm, int cfg, bool gate, int halo, dim3 grid, size_t smem, hipS
   if (sm == 1) conv_split_mode<1>(cfg, gate, halo, grid, smem, stream, p);
   else if (sm == 2) conv_split_mode<2>(cfg, gate, halo, grid, smem, stream, p);
   else conv_split_mode<0>(cfg, gate, halo, grid, smem, stream, p);
+}
+
+template <int SM>
+static void mrf_split_mode(int cp, int ou, dim3 grid, hipStream_t stream, const MrfP& p) {
+  const size_t smem = mrf_smem_bytes(cp, ou);
+#define PE_MRFS(CP_, OU_, HU_) PE_LAUNCH((mrf_split_kernel<SM, CP_, OU_, HU_>), grid, dim3(64 * MRF_NW), smem, stream, p)
+  if (cp == 32) {
+    if (ou == 1) PE_MRFS(32, 1, 1); else if (ou == 2) PE_MRFS(32, 2, 1); else if (ou == 3) PE_MRFS(32, 3, 1); else PE_MRFS(32, 4, 1);
+  } else {
+    if (ou == 1) PE_MRFS(64, 1, 2); else if (ou == 2) PE_MRFS(64, 2, 2); else PE_MRFS(64, 3, 2);
+  }
+#undef PE_MRFS
+}
+
+void mrf_split(int sm, int cp, int ou, dim3 grid, hipStream_t stream, const MrfP& p) {
+  if (sm == 1) mrf_split_mode<1>(cp, ou, grid, stream, p);
+  else mrf_split_mode<0>(cp, ou, grid, stream, p);
 }
 
 }  // namespace launch

@@ -237,6 +237,7 @@ struct MrfP {
   const int* lens; int len_mul;
   const MrfPhase* phases; int nphases;
   const float* wstream; int wfloats;
+  const float* wunscale; // mrf_split_kernel, mode f16x3: per phase, the power of two that undoes the packing scale of its weights
   int C;                 // real channels (<= CP)
   int N;                 // output columns per workgroup (16 * NCG * OU)
   int wcols;             // window columns in use: hxa + N + the stage's halo (<= the row stride)

@@ -17,6 +17,7 @@ struct LaunchPolicy {
   long mrf_maxf = 1100;       // ResBlock1 stages on 32 channels: batch frames up to which the fused kernel is used in mode 1
   long mrf_ou = 0;            // force the output units per wave of mrf_kernel (1..4); 0 = cost model
   long mrf_tail = 1;          // generator tail (conv_post, tanh, peak) inside the last stage's mrf_kernel
+  long mrf_split = 1;         // split matrix modes bf16x3 / f16x3: the fused MRF stage on the 16-bit pipe (mrf_split_kernel); 0 = the f32 fused kernel / conv by conv
   long bf3_minf = 1100;       // matrix mode bf16x3: batch frames from which the <= 64-channel stages run conv by conv on the bf16 pipe
   long splitk_max = 96;       // tile-kernel workgroups below which a conv goes to the split-K kernels (0: always the tiled kernel)
   long splitk16 = 2;          // 16-column split-K: 0 off, 1 WN gate conv, 2 + long-K plain convs, 3 everywhere (tests)
@@ -113,7 +114,12 @@ struct LaunchPolicy {
   bool chain_rs_front(long cols) const { return chain_rs && chain4_frames(cols); }
   // fused MRF stage
   bool mrf_build(int channels) const { return mrf != 0 && channels <= 64 && channels % 4 == 0; }
-  bool mrf_stage(bool built, bool resblock1, int padded_channels, double frames, bool matrix_bf3) const {
+  // `split_fused`: the engine runs a two-term split matrix mode AND holds the stage's split weight stream (mrf_split_kernel):
+  // the fused stage then runs on the 16-bit pipe at every batch size (ResBlock2 stages; ResBlock1 stages on 32 channels).
+  // Without it (mode bf16x6, or PIPER_HIP_MRF_SPLIT=0) a split mode keeps the f32 fused kernel below bf3_minf frames and goes
+  // conv by conv on the 16-bit pipe above.
+  bool mrf_stage(bool built, bool resblock1, int padded_channels, double frames, bool matrix_bf3, bool split_fused = false) const {
+    if (mrf && built && split_fused) return mrf == 2 || !resblock1 || padded_channels == 32;
     return mrf && built && !(matrix_bf3 && mrf != 2 && frames >= (double)bf3_minf) &&
            (mrf == 2 || !resblock1 || (padded_channels == 32 && frames <= (double)mrf_maxf));
   }

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <type_traits>
 #include <functional>
 #include <chrono>
 
@@ -203,6 +204,56 @@ inline f32x16 emu_mfma_f16_32x32x16(emu_f16x8 a, emu_f16x8 b, f32x16 c) {
   }
   return c;
 }
+
+// v_mfma_f32_16x16x32_{bf16,f16} (gfx950): lane l gives A[i = l & 15][k = 8 * (l >> 4) + e], B[k = 8 * (l >> 4) + e][j = l & 15],
+// e = 0..7 (four dwords of two 16-bit terms each); D VGPR r = D[row 4 * (l >> 4) + r][col l & 15] (checked on the hardware:
+// scripts/microbench/mfma16x16x32.hip, also that f16 subnormals are not flushed). Term products are exact in f32; f32
+// accumulation in ascending k.
+template <class T8, class T>
+inline f32x4 emu_mfma_16x16x32_t(T8 a, T8 b, f32x4 c) {
+  const int l = emu::lane(), j = l & 15;
+  float au[4], bu[4];
+  memcpy(au, &a, 16);
+  memcpy(bu, &b, 16);
+  float accs[4] = {c[0], c[1], c[2], c[3]};
+  // dword d of a lane = terms 2d, 2d + 1 of its k block: gather all four dwords of every lane, then accumulate k-ascending
+  float sa4[4][64], sb4[4][64];
+  for (int d = 0; d < 4; ++d) {
+    const int par = emu::collective_parity();
+    float* sa = emu::wave_f(2 + par);
+    float* sb = emu::wave_f(4 + par);
+    sa[l] = au[d];
+    sb[l] = bu[d];
+    emu::wave_sync();
+    memcpy(sa4[d], sa, sizeof(float) * 64);
+    memcpy(sb4[d], sb, sizeof(float) * 64);
+  }
+  for (int r = 0; r < 4; ++r) {
+    const int i = 4 * (l >> 4) + r;
+    float acc = accs[r];
+    for (int kb = 0; kb < 4; ++kb)
+      for (int d = 0; d < 4; ++d) {
+        T ha[2], hb[2];
+        memcpy(ha, &sa4[d][16 * kb + i], 4);
+        memcpy(hb, &sb4[d][16 * kb + j], 4);
+        for (int e = 0; e < 2; ++e) {
+          float fa, fb;
+          if constexpr (sizeof(T) == 2 && std::is_same<T, _Float16>::value) { fa = (float)ha[e]; fb = (float)hb[e]; }
+          else {
+            unsigned short ua, ub;
+            memcpy(&ua, &ha[e], 2); memcpy(&ub, &hb[e], 2);
+            const unsigned xa = (unsigned)ua << 16, xb = (unsigned)ub << 16;
+            memcpy(&fa, &xa, 4); memcpy(&fb, &xb, 4);
+          }
+          acc = fmaf(fa, fb, acc);
+        }
+      }
+    c[r] = acc;
+  }
+  return c;
+}
+inline f32x4 emu_mfma_bf16_16x16x32(emu_bf16x8 a, emu_bf16x8 b, f32x4 c) { return emu_mfma_16x16x32_t<emu_bf16x8, __bf16>(a, b, c); }
+inline f32x4 emu_mfma_f16_16x16x32(emu_f16x8 a, emu_f16x8 b, f32x4 c) { return emu_mfma_16x16x32_t<emu_f16x8, _Float16>(a, b, c); }
 
 // ---- atomics (single-threaded: plain read-modify-write) ------------------------------------------
 template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }

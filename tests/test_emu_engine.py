@@ -379,6 +379,46 @@ def test_emulated_generator_tail_inside_the_last_stage_kernel(emu_lib, monkeypat
             assert np.array_equal(res[key].audio[i], ref.audio[i]) and np.array_equal(res[key].pcm[i], ref.pcm[i]), (key, i)
 
 
+@pytest.mark.parametrize("mode,sm", [("bf16x3", 0), ("f16x3", 1)])
+def test_emulated_split_mrf_stage_kernel(emu_lib, monkeypatch, mode, sm):
+    """mrf_split_kernel (kernels/mrf_split.h: the fused MRF stage on the 16-bit matrix pipe, activations split in LDS) on a
+    voice whose first generator stage has 64 channels and whose later ones 32 and fewer: every window width (OU 1 / 3 on 64
+    channels, 1 / 2 / 4 on 32), ragged batch with a one-frame utterance and windows hanging over both ends, against the
+    oracle at the mode's gate; with the generator tail inside the last stage against the separate conv_post_kernel:
+    bit-identical (the tail is f32 arithmetic on the same mean)."""
+    cfg = W.preset("tiny", up_initial=128)
+    w = W.synthetic_weights(cfg, 77)
+    Ts = (7, 3, 1)
+    ids = [W.synthetic_phoneme_ids(T, i, id_max=cfg.n_vocab - 1) for i, T in enumerate(Ts)]
+    nw, nz = _noise(cfg, len(Ts), max(Ts), 33)
+    scales = (0.5, 1.0, 0.8)
+    monkeypatch.setenv("PIPER_HIP_MATRIX", mode)
+    monkeypatch.setenv("PIPER_HIP_MRF", "2")
+    rms_gate, max_gate = SPLIT_GATES[mode]
+    res = {}
+    for tail, ou in (("0", "1"), ("1", "1"), ("1", "2"), ("0", "3"), ("1", "4")):
+        monkeypatch.setenv("PIPER_HIP_MRF_TAIL", tail)
+        monkeypatch.setenv("PIPER_HIP_MRF_OU", ou)
+        eng = Engine(blob=W.pack_blob(cfg, w), lib=emu_lib)
+        eng.profile_enable(2)
+        r = eng.synthesize_batch(ids, scales, noise_w=nw, noise_z=nz)
+        names = {row["name"] for row in eng.profile()[5:] if row["launches"]}
+        eng.close()
+        assert not any(n.startswith("mrf_kernel<") for n in names), names
+        assert any(n.startswith(f"mrf_split_kernel<{sm},32,") for n in names), names
+        assert any(n.startswith(f"mrf_split_kernel<{sm},64,") for n in names), names
+        assert ("conv_post_kernel" in names) == (tail == "0"), names
+        res[(tail, ou)] = r
+        for i in range(len(Ts)):
+            o = O.synthesize(w, cfg, ids[i], scales, nw[i][:, :Ts[i]], nz[i])
+            assert r.audio[i].shape == o["audio"].shape
+            assert np.max(np.abs(r.audio[i] - o["audio"])) < max_gate, (tail, ou, i)
+            assert np.sqrt(np.mean((r.audio[i] - o["audio"]) ** 2)) < rms_gate, (tail, ou, i)
+    for i in range(len(Ts)):        # same window width, tail inside / outside the stage kernel: the same bits
+        assert np.array_equal(res[("0", "1")].audio[i], res[("1", "1")].audio[i])
+        assert np.array_equal(res[("0", "1")].pcm[i], res[("1", "1")].pcm[i])
+
+
 @pytest.mark.parametrize("col4", ["0", "1"])
 def test_emulated_192_channel_small_call_kernels(emu_lib, monkeypatch, col4):
     """The kernels compiled for exactly 192 hidden channels (the reference's medium / high qualities) on a voice that

@@ -154,10 +154,10 @@ def test_split_matrix_modes_match_oracle(monkeypatch, preset, lens, seed, mode):
     generator convs as 3 / 3 / 6 sixteen-bit MFMAs on split f32 operands. Gate = the f32 path's OWN:
     integer durations EQUAL to the oracle's (the text encoder and duration predictor stay f32), max |d audio| < 2e-4 on the
     float waveform, int16 PCM within 1e-3 RMS -- for all three modes (bf16x3 keeps 16 significand bits per operand and lands
-    near 1e-5; f16x3 keeps 22, bf16x6 all 24: both land at the f32 kernels' own ~1e-6). The fused f32 MRF kernel is switched
-    off (PIPER_HIP_BF3_MINF=0) so that every generator stage goes through conv_split_kernel."""
+    near 1e-5; f16x3 keeps 22, bf16x6 all 24: both land at the f32 kernels' own ~1e-6). The fused stage kernels are switched
+    off (PIPER_HIP_BF3_MINF=0, PIPER_HIP_MRF_SPLIT=0) so that every generator stage goes through conv_split_kernel."""
     cfg, w = voice(preset)
-    eng = make_engine(monkeypatch, cfg, w, {"PIPER_HIP_MATRIX": mode, "PIPER_HIP_BF3_MINF": 0})
+    eng = make_engine(monkeypatch, cfg, w, {"PIPER_HIP_MATRIX": mode, "PIPER_HIP_BF3_MINF": 0, "PIPER_HIP_MRF_SPLIT": 0})
     ids, nw, nz = batch_inputs(cfg, lens, seed=seed)
     stats = []
     sample = [i for i in range(len(lens))][:8]
@@ -167,7 +167,7 @@ def test_split_matrix_modes_match_oracle(monkeypatch, preset, lens, seed, mode):
     pre = f"conv_split_kernel<{SPLIT_MODES[mode]},"
     assert any(n.startswith(pre) and ",true," in n for n in names), names
     assert any(n.startswith(pre) and ",false," in n for n in names), names
-    assert not any(n.startswith("mrf_kernel") for n in names), names
+    assert not any(n.startswith("mrf_") and "sum" not in n for n in names), names
     print(preset, mode, "kernels:", sorted(n for n in names if "split" in n),
           "worst |d audio| %.2e, worst pcm rms %.2e" % (worst, max(s[1] for s in stats)))
 
@@ -544,6 +544,36 @@ def test_fused_mrf_stage_kernel_matches_unfused_and_oracle(monkeypatch, preset, 
         assert a.audio[i].shape == b.audio[i].shape
         assert np.max(np.abs(a.audio[i] - b.audio[i])) < 2e-5
     print(preset, "fused stage kernels:", sorted(n for n in names if n.startswith("mrf")), "worst |d audio| %.2e" % worst)
+
+
+@pytest.mark.parametrize("mode", ["bf16x3", "f16x3"])
+@pytest.mark.parametrize("preset,lens,ou", [("medium", [128, 37], 0), ("medium", [100] * 12, 0), ("medium", [77, 128], 1),
+                                            ("medium", [128], 2), ("medium", [90, 31], 3), ("medium", [128, 60], 4), ("high", [64, 9], 0),
+                                            ("high", [33, 20, 50], 3), ("x-low", [64, 128], 0)])
+def test_split_fused_mrf_stage_kernel_matches_oracle(monkeypatch, preset, lens, ou, mode):
+    """mrf_split_kernel (kernels/mrf_split.h: the fused MRF stage on the 16-bit matrix pipe, activations split once by
+    their producer, in LDS) in the two-term matrix modes, every window geometry (`ou` = output units per wave, 0 = the
+    launcher's cost model), ResBlock2 (medium / x-low) and ResBlock1 (high) stages: the f32 path's own gate against the
+    oracle; and the generator tail inside the last stage against the separate conv_post_kernel: bit for bit."""
+    cfg, w = voice(preset)
+    ids, nw, nz = batch_inputs(cfg, lens, seed=81)
+    res = {}
+    for tail in (1, 0):
+        env = {"PIPER_HIP_MATRIX": mode, "PIPER_HIP_MRF": 2, "PIPER_HIP_MRF_TAIL": tail}
+        if ou:
+            env["PIPER_HIP_MRF_OU"] = ou
+        eng = make_engine(monkeypatch, cfg, w, env)
+        names, worst = run_and_check(eng, cfg, w, ids, nw, nz, sample=sorted({0, len(lens) - 1}), cache_key="smrf-%s-%s" % (preset, "_".join(str(t) for t in lens)))
+        assert any(n.startswith(f"mrf_split_kernel<{SPLIT_MODES[mode]},") for n in names), names
+        assert not any(n.startswith("mrf_kernel<") for n in names), names
+        assert ("conv_post_kernel" in names) == (tail == 0), names
+        res[tail] = eng.synthesize_batch(ids, SCALES, noise_w=nw, noise_z=nz)
+        eng.close()
+        if tail:
+            print(preset, mode, "fused split stage kernels:", sorted(n for n in names if n.startswith("mrf")), "worst |d audio| %.2e" % worst)
+    for i in range(len(lens)):
+        assert np.array_equal(res[1].audio[i], res[0].audio[i]), f"utterance {i}: waveform differs"
+        assert np.array_equal(res[1].pcm[i], res[0].pcm[i]), f"utterance {i}: pcm differs"
 
 
 @pytest.mark.parametrize("preset,lens,ou", [("medium", [128, 45, 3], 0), ("medium", [128], 4), ("medium", [60] * 9, 3),
