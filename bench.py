@@ -748,7 +748,7 @@ def extra_configs(ctx, eng_medium, cfg_medium, args):
     # peak; the headline and the legs above stay f32). Parity gate of the modes = the f32 path's own (durations equal, max
     # |d audio| < 2e-4 on all 64 utterances of both configurations): tests/test_gpu_batched.py
     # test_split_matrix_modes_at_baseline_sizes.
-    def split_leg(mode, cfgno, preset, steps, warmup):
+    def split_leg(mode, cfgno, preset, steps, warmup, B=64):
         os.environ["PIPER_HIP_MATRIX"] = mode
         try:
             c = W.preset(preset)
@@ -756,9 +756,12 @@ def extra_configs(ctx, eng_medium, cfg_medium, args):
         finally:
             os.environ["PIPER_HIP_MATRIX"] = "f32"
         try:
-            return batched(cfgno, e, c, preset, 64, 128, steps, warmup, dtype=DTYPE_SPLIT[mode])
+            return batched(cfgno, e, c, preset, B, 128, steps, warmup, dtype=DTYPE_SPLIT[mode])
         finally:
             e.close()
+
+    # the headline's own workload (configs[1]: one utterance) in the near-exact mode f16x3: reported as a leg, never as `value`
+    guarded("configs[1], f16x3", lambda: split_leg("f16x3", 2, "medium", 200, 10, B=1))
 
     # (bf16x3 -- rounds 3-5's mode, 16 significand bits -- costs what f16x3 costs and is 8x less accurate: `--matrix bf16x3`
     # still times it, the default line carries the two near-exact modes)
