@@ -173,6 +173,9 @@ def compact_leg(e):
         c["streaming_samples_per_s"] = _r(e["streaming_samples_per_s"])
     if e.get("frames_per_id") is not None:
         c["frames_per_id"] = _r(e["frames_per_id"], 3)
+    if e.get("clock") and dt == "f32":
+        c["sclk_mhz"] = _r(e["clock"]["sclk_mhz_median"], 4)
+        c["clock_adjusted_frac"] = _r(e.get("clock_adjusted_frac"), 3)
     if roof:
         c["kernel"] = _short(roof.get("kernel"), 44)
         st = roof.get("step") or {}
@@ -247,7 +250,7 @@ def compact_line(full, full_path=None):
     line = json.dumps(out, separators=(",", ":"))
     # belt and braces: slim the legs first (kernel names, then units / step counts), then shed the optional parts, until
     # the line fits
-    for drop in (("steps", "calls", "captures"), ("kernel",), ("frames_per_id", "row_ms_p95", "threads_value", "racing_value")):
+    for drop in (("steps", "calls", "captures"), ("kernel",), ("frames_per_id", "row_ms_p95", "threads_value", "racing_value", "sclk_mhz")):
         if len(line) <= COMPACT_LIMIT or not out.get("extra_configs"):
             break
         out["extra_configs"] = [{k: v for k, v in e.items() if k not in drop} for e in out["extra_configs"]]
@@ -348,6 +351,45 @@ class Ctx:
         pr = [torch.zeros(1, dtype=torch.float64, device=self.cdev) for _ in range(self.world)]
         self.dist.all_gather(pr, torch.tensor([x], dtype=torch.float64, device=self.cdev))
         return [float(v.item()) for v in pr]
+
+
+class ClockSampler:
+    """Shader clock of the device while a leg runs ("if the bound is the clock, log sclk from the same
+    run"): a thread reads the amdgpu hwmon `freq1_input` of the device's PCI function every 10 ms (sysfs, no subprocess);
+    `stats()` = median / min / max MHz over the samples taken under load, or None where sysfs does not show it. The f32
+    matrix peak (157.3 TFLOP/s) is 256 CUs x 4 SIMDs x 64 FLOP/clk at 2.4 GHz: `clock_adjusted_frac` = frac x 2400 / sclk."""
+    PEAK_MHZ = 2400.0
+
+    def __init__(self, bdf):
+        import glob
+        self.paths = sorted(glob.glob(f"/sys/bus/pci/devices/{bdf}/hwmon/hwmon*/freq1_input")) if bdf else []
+        self.samples, self._stop, self._th = [], False, None
+
+    def __enter__(self):
+        if self.paths:
+            import threading
+
+            def loop():
+                while not self._stop:
+                    try:
+                        self.samples.append(int(open(self.paths[0]).read().strip()) / 1e6)
+                    except (OSError, ValueError):
+                        return
+                    time.sleep(0.01)
+            self._th = threading.Thread(target=loop, daemon=True)
+            self._th.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop = True
+        if self._th:
+            self._th.join(timeout=1.0)
+
+    def stats(self):
+        v = sorted(x for x in self.samples if x > 500.0)          # (idle samples before / after the loop do not count)
+        if len(v) < 3:
+            return None
+        return {"sclk_mhz_median": v[len(v) // 2], "sclk_mhz_min": v[0], "sclk_mhz_max": v[-1], "samples": len(v)}
 
 
 def rank_audit(ctx):
@@ -670,10 +712,16 @@ def extra_configs(ctx, eng_medium, cfg_medium, args):
     reported in its entry, never raised: the headline line must come out."""
     from piper_amd import weights as W
     from piper_amd.engine import Engine
+    from piper_amd import _lib as L
     legs = []
+    try:
+        bdf = L.device_pci_bus_id(ctx.dev_index).lower()
+    except Exception:          # noqa: BLE001
+        bdf = None
 
     def batched(cfgno, eng, cfg, preset, B, T, steps, warmup, dtype="f32", scales=SCALES, what=None):
-        l = timed_leg(ctx, eng, cfg, preset, B, T, steps, warmup, sync_ranks=False, scales=scales)
+        with ClockSampler(bdf) as clk:
+            l = timed_leg(ctx, eng, cfg, preset, B, T, steps, warmup, sync_ranks=False, scales=scales)
         dev_ms = device_only_ms(eng, l["id_lists"], l["noise_w"], max(2, min(5, steps)), scales=scales)
         e = {"config": {"workload": what or workload_text(cfgno, preset, cfg, B, T), "frames_per_step": int(l["frames"].sum()),
                         "samples_per_step": l["samples_per_step"], "kernel_launches_per_step": l["launches"]},
@@ -683,6 +731,12 @@ def extra_configs(ctx, eng_medium, cfg_medium, args):
              "frames_per_id": float(l["frames"].sum()) / float(B * T)}
         if not args.no_roofline:
             e["roofline"] = roofline(eng, preset, B, T, l["id_lists"], l["noise_w"], 3, l["ms_per_step"], dev_ms, scales=scales)
+        ck = clk.stats()
+        if ck:
+            e["clock"] = ck
+            fr = ((e.get("roofline") or {}).get("step") or {}).get("frac")
+            if fr:
+                e["clock_adjusted_frac"] = fr * ClockSampler.PEAK_MHZ / ck["sclk_mhz_median"]
         return e
 
     def survey_shape():

@@ -58,17 +58,51 @@ __device__ __forceinline__ float pe_bf2f(__bf16 h) { return (float)h; }
 constexpr int split_terms(int sm) { return sm == 2 ? 3 : 2; }
 static constexpr float F16_MAX = 65504.f;
 
+// leaky-relu for 0 < slope <= 1 as max(v, v * slope) in exactly two VALU instructions (the compiler's lowering of fmaxf /
+// fmed3 adds a canonicalising max(v, v) in front of each; inputs here are finite products of finite values)
+#ifdef PE_EMU
+inline float pe_lrelu2(float v, float slope) { return v > 0.f ? v : v * slope; }
+#else
+__device__ __forceinline__ float pe_lrelu2(float v, float slope) {
+  const float t = v * slope;
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(v), "v"(t));
+  return r;
+}
+#endif
+
+// f32 pair -> f16 pair, round toward zero (v_cvt_pkrtz_f16_f32: ONE instruction per two elements; a magnitude beyond
+// f16's range lands on +-65504, the largest finite value, so no clamp is needed in front of it)
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+#ifdef PE_EMU
+inline _Float16 pe_f2h_rtz(float v) {
+  _Float16 h = (_Float16)v;                               // round to nearest even, then step back towards zero where that rounded away
+  unsigned short u;
+  memcpy(&u, &h, 2);
+  if ((u & 0x7fffu) == 0x7c00u && std::isfinite(v)) u = (unsigned short)((u & 0x8000u) | 0x7bffu);      // overflow -> 65504
+  else if (std::fabs((float)h) > std::fabs(v)) u = (unsigned short)(u - 1);
+  memcpy(&h, &u, 2);
+  return h;
+}
+inline f16x2 pe_cvt_pkrtz(float a, float b) { return f16x2{pe_f2h_rtz(a), pe_f2h_rtz(b)}; }
+#else
+__device__ __forceinline__ f16x2 pe_cvt_pkrtz(float a, float b) { return __builtin_bit_cast(f16x2, __builtin_amdgcn_cvt_pkrtz(a, b)); }
+#endif
+
 // v (8 floats) -> the NT term vectors of split mode SM, largest term first
 template <int SM>
 __device__ __forceinline__ void split8(const float (&v)[8], frag16 (&t)[split_terms(SM)]) {
   if constexpr (SM == 1) {
+    // hi = v rounded TOWARD ZERO to f16 (packed conversion, saturating: no clamp), lo = f16(v - hi): hi + lo carries 21-22
+    // significand bits either way, and the staging costs 2.5 VALU instructions per element instead of 6
     f16x8 hi, lo;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const float c = fminf(fmaxf(v[i], -F16_MAX), F16_MAX);
-      const _Float16 h = (_Float16)c;
-      hi[i] = h;
-      lo[i] = (_Float16)(c - (float)h);
+    for (int i = 0; i < 8; i += 2) {
+      const f16x2 h = pe_cvt_pkrtz(v[i], v[i + 1]);
+      hi[i] = h[0];
+      hi[i + 1] = h[1];
+      lo[i] = (_Float16)(v[i] - (float)h[0]);
+      lo[i + 1] = (_Float16)(v[i + 1] - (float)h[1]);
     }
     t[0] = __builtin_bit_cast(frag16, hi);
     t[1] = __builtin_bit_cast(frag16, lo);
@@ -92,6 +126,97 @@ template <int SM>
 __device__ __forceinline__ f32x16 split_mfma(frag16 a, frag16 b, f32x16 c) {
   if constexpr (SM == 1) return pe_mfma_f16_32x32x16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c);
   else return pe_mfma_bf16_32x32x16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c);
+}
+
+// The epilogue of the split kernels. conv_store_tile (conv_common.h) issues FIVE memory instructions per output element --
+// bias, speaker bias, previous value, residual (zero-length descriptors when absent) and the store -- which the f32 kernels
+// hide behind 64-cycle MFMAs; behind a K loop that is 5x shorter it cost as much as a 3-tap K loop (SQ counters, call 7 of
+// profiles/r06_notes.md: 9 VALU / memory instructions per MFMA). Here the absent streams are skipped behind kernel-uniform
+// branches and the bias comes as four 16-byte loads (a lane's rows are four groups of four consecutive rows). Same
+// arithmetic, same order: ((acc + (bias + bias2)) * sign + (old + res)) * alpha. Partial row tiles and the polyphase
+// scatter keep the general routine.
+__device__ __forceinline__ void conv_store_tile_lean(const ConvP& p, const EpiFlags& f, int b, int row0, int col, int lhi,
+                                                     int L, int ncols, const f32x16& acc) {
+  const bool to_skip = p.epi == EPI_WNRS && row0 >= p.split;        // uniform per tile
+  const int row_end = to_skip ? p.rows : (p.epi == EPI_WNRS ? p.split : p.rows);
+  if (p.epi == EPI_CONVT || row0 + 32 > row_end) {
+    conv_store_tile(p, f, b, row0, col, lhi, L, ncols, acc);
+    return;
+  }
+  constexpr int OOB = 0x3fffffff;
+  int rb = row0 + 4 * lhi;
+  PE_OPAQUE(rb);
+  const bool rd_old = to_skip ? (p.mode != 1) : (f.use_old || p.epi == EPI_WNRS);
+  const int orow0 = to_skip ? p.split : 0;
+  const int orows = to_skip ? p.rows - p.split : (p.epi == EPI_WNRS ? p.split : p.rows);
+  const int ocs = to_skip ? p.o2_cs : p.o_cs;
+  float* ob = to_skip ? p.out2 + (long)b * p.o2_bs : p.out + (long)b * p.o_bs;
+  const pe_rowsrc od = pe_make_row_u(ob, orows * ocs);
+  const bool cok = col < ncols;
+  const int ooff = cok ? (rb - orow0) * ocs + col : OOB;
+  f32x4 bz[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) bz[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (p.bias) {
+    const pe_rowsrc bd = pe_make_row_u(p.bias, p.rows);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bz[g] = pe_row_load4(bd, rb + 8 * g);
+  }
+  if (p.bias2) {
+    const pe_rowsrc b2d = pe_make_row_u(p.bias2 + (long)b * p.bias2_bs, p.rows);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 t = pe_row_load4(b2d, rb + 8 * g);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bz[g][j] += t[j];
+    }
+  }
+  float o[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) o[r] = 0.f;
+  if (rd_old) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] = pe_row_load_so(od, ooff, ((r & 3) + 8 * (r >> 2)) * ocs);
+  }
+  if (f.use_res) {
+    const pe_rowsrc rd = pe_make_row_u(p.res + (long)b * p.r_bs, p.rows * p.r_cs);
+    const int roff = cok ? rb * p.r_cs + col : OOB;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r] += pe_row_load_so(rd, roff, ((r & 3) + 8 * (r >> 2)) * p.r_cs);
+  }
+  if (f.sign == 1.f && f.alpha == 1.f && !f.relu) {          // (kernel-uniform; x * 1 is exact, so this is the same arithmetic)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) pe_row_store_so(od, ooff, ((r & 3) + 8 * (r >> 2)) * ocs, (acc[r] + bz[r >> 2][r & 3]) + o[r]);
+    return;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    float v = ((acc[r] + bz[r >> 2][r & 3]) * f.sign + o[r]) * f.alpha;
+    if (f.relu) v = v > 0.f ? v : 0.f;
+    pe_row_store_so(od, ooff, ((r & 3) + 8 * (r >> 2)) * ocs, v);
+  }
+}
+// tanh(a) * sigmoid(s) (commons.py:99-106) on the hardware's exp2 / reciprocal units: tanh(a) = 1 - 2 / (1 + e^(2a)),
+// sigmoid(s) = 1 / (1 + e^(-s)); ~1e-7 absolute against tanhf / expf (the split modes' own error is 1e-6). The library forms
+// are ~60 VALU instructions per element -- 40 % of the split gate conv's time; the f32 gate kernels keep them.
+__device__ __forceinline__ float split_gate(float ta, float sa) {
+#ifdef PE_EMU
+  const float e1 = exp2f(2.8853900817779268f * ta), e2 = exp2f(-1.4426950408889634f * sa);
+  return (1.f - 2.f / (1.f + e1)) * (1.f / (1.f + e2));
+#else
+  const float e1 = __builtin_amdgcn_exp2f(2.8853900817779268f * ta), e2 = __builtin_amdgcn_exp2f(-1.4426950408889634f * sa);
+  return (1.f - 2.f * __builtin_amdgcn_rcpf(1.f + e1)) * __builtin_amdgcn_rcpf(1.f + e2);
+#endif
+}
+__device__ __forceinline__ void conv_store_gate_split(const ConvP& p, int b, int ch, int col, float ta, float sa) {
+  ta += p.bias[ch];
+  sa += p.bias[p.split + ch];
+  if (p.bias2) {
+    const float* b2 = p.bias2 + (long)b * p.bias2_bs;
+    ta += b2[ch];
+    sa += b2[p.split + ch];
+  }
+  p.out[(long)b * p.o_bs + (long)ch * p.o_cs + col] = split_gate(ta, sa);
 }
 
 template <int SM, int WM, int WN, int MT, int NT, bool GATE, int HALO>
@@ -150,10 +275,7 @@ void conv_split_kernel(ConvP p) {
     for (int cc = 0; cc < NCOL; ++cc) {
       float v[8];
 #pragma unroll
-      for (int rr = 0; rr < 8; ++rr) {
-        const float t = xr[rr][cc];
-        v[rr] = t > 0.f ? t : t * slope;
-      }
+      for (int rr = 0; rr < 8; ++rr) v[rr] = pe_lrelu2(xr[rr][cc], slope);         // (slope 1 = no activation: max(t, t))
       frag16 t[NTM];
       split8<SM>(v, t);
 #pragma unroll
@@ -262,7 +384,7 @@ void conv_split_kernel(ConvP p) {
       for (int r = 0; r < 16; ++r) {
         int ch = q * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
         PE_OPAQUE(ch);
-        if (ch < p.split && col < ncols) conv_store_gate(p, b, ch, col, acc[0][j][r], acc[MT - 1][j][r]);
+        if (ch < p.split && col < ncols) conv_store_gate_split(p, b, ch, col, acc[0][j][r], acc[MT - 1][j][r]);
       }
     }
   } else {
@@ -270,7 +392,7 @@ void conv_split_kernel(ConvP p) {
     for (int i = 0; i < MT; ++i)
 #pragma unroll
       for (int j = 0; j < NT; ++j)
-        conv_store_tile(p, ef, b, (mtile0 + i) * 32, n0 + (wn * NT + j) * 32 + l31, lhi, L, ncols, acc[i][j]);
+        conv_store_tile_lean(p, ef, b, (mtile0 + i) * 32, n0 + (wn * NT + j) * 32 + l31, lhi, L, ncols, acc[i][j]);
   }
 }
 

@@ -48,11 +48,12 @@ __device__ __forceinline__ void split4(const float (&v)[4], frag8& hi, frag8& lo
   if constexpr (SM == 1) {
     f16x4 h, l;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const float c = fminf(fmaxf(v[i], -F16_MAX), F16_MAX);
-      const _Float16 t = (_Float16)c;
-      h[i] = t;
-      l[i] = (_Float16)(c - (float)t);
+    for (int i = 0; i < 4; i += 2) {          // hi rounded toward zero (packed, saturating), lo = f16(v - hi): conv_bf3.h split8
+      const f16x2 t = pe_cvt_pkrtz(v[i], v[i + 1]);
+      h[i] = t[0];
+      h[i + 1] = t[1];
+      l[i] = (_Float16)(v[i] - (float)t[0]);
+      l[i + 1] = (_Float16)(v[i + 1] - (float)t[1]);
     }
     hi = __builtin_bit_cast(frag8, h);
     lo = __builtin_bit_cast(frag8, l);
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(64 * MRF_NW) void mrf_split_kernel(MrfP p) {
       if (it < NIT && c < WS) {
         float a[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) a[r] = pe_lrelu(v[i][r], slope);
+        for (int r = 0; r < 8; ++r) a[r] = pe_lrelu2(v[i][r], slope);
         frag16 t[NTM];
         split8<SM>(a, t);
 #pragma unroll
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(64 * MRF_NW) void mrf_split_kernel(MrfP p) {
             // rows (ms0 + m) * 16 + 4 lq + r: k group 2 (ms0 + m) + (lq >> 1), its lower / upper four channels
             float a4[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) a4[r] = pe_lrelu(v[r], slope);
+            for (int r = 0; r < 4; ++r) a4[r] = pe_lrelu2(v[r], slope);
             frag8 hi, lo;
             split4<SM>(a4, hi, lo);
             frag8* d8 = reinterpret_cast<frag8*>(dstb + (2 * (ms0 + m) + (lq >> 1)) * WS + col) + (lq & 1);

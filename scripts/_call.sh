@@ -1,7 +1,5 @@
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/r6c6; mkdir -p $O
-timeout 2400 python -m pytest tests -m gpu -q 2>&1 | tail -15 > $O/gpu_pytest.log; cat $O/gpu_pytest.log
-python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-timeout 1500 python bench.py > $O/bench_default.stdout 2> $O/bench_default.err
-cp bench_full.json $O/bench_default_full.json
-tail -2 $O/bench_default.err | grep -v amdgpu.ids
-echo "last line bytes: $(tail -n 1 $O/bench_default.stdout | wc -c)"; tail -n 1 $O/bench_default.stdout
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp
+timeout 1500 python -m pytest tests/test_gpu_batched.py -m gpu -q -x -s -k "split" 2>&1 | grep -E "B=64|heavy|passed|failed|rror" | cut -c1-200
+bash scripts/gpu_ab.sh "" "--config 3 --steps 5 --warmup 2 --matrix f16x3" "conv_split,mrf_split" 2>&1 | grep -v "^$" | cut -c1-200
+bash scripts/gpu_ab.sh "" "--config 4 --steps 10 --warmup 3 --matrix f16x3" "conv_split,mrf_split" 2>&1 | grep -v "^$" | cut -c1-200
+bash scripts/gpu_ab.sh "" "--steps 100 --matrix f16x3" "mrf_split" 2>&1 | grep -v "^$" | cut -c1-200

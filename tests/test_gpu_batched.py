@@ -173,6 +173,24 @@ def test_split_matrix_modes_match_oracle(monkeypatch, preset, lens, seed, mode):
 
 
 @pytest.mark.parametrize("mode", sorted(SPLIT_MODES))
+@pytest.mark.parametrize("preset,lens", [("medium", [128, 61, 9]), ("high", [64, 17])])
+def test_split_matrix_modes_on_heavy_tailed_weights(monkeypatch, preset, lens, mode):
+    """The split modes on the heavy-tailed weight family (Student-t weights of 10+ standard deviations, per-channel gains a
+    factor ~4 apart, 4x biases: the dynamic range of trained, weight-normed layers rather than of i.i.d. Gaussians) -- what
+    f16x3's power-of-two weight scaling and its +-65504 activation clamp exist for: same gate as the f32 path."""
+    cfg = W.preset(preset)
+    w = W.synthetic_weights(cfg, 4321, family="heavy")
+    eng = make_engine(monkeypatch, cfg, w, {"PIPER_HIP_MATRIX": mode})
+    ids, nw, nz = batch_inputs(cfg, lens, seed=77)
+    stats = []
+    names, worst = run_and_check(eng, cfg, w, ids, nw, nz, sample=range(len(lens)), audio_tol=TIGHT_AUDIO_TOL, stats=stats,
+                                 cache_key=f"heavy-{preset}")
+    eng.close()
+    assert any("_split_kernel<" in n for n in names), names
+    print(preset, "heavy family", mode, "worst |d audio| %.2e, worst pcm rms %.2e" % (worst, max(s[1] for s in stats)))
+
+
+@pytest.mark.parametrize("mode", sorted(SPLIT_MODES))
 @pytest.mark.parametrize("preset,seed,key", [("high", 31, "high64"), ("medium", 32, "medium64")])
 def test_split_matrix_modes_at_baseline_sizes(monkeypatch, preset, seed, key, mode):
     """The same gate at BASELINE.json configs[2] (high, 64 x 128 ids) and configs[3]'s per-GPU share (medium, 64 x 128): ALL
@@ -548,8 +566,8 @@ def test_fused_mrf_stage_kernel_matches_unfused_and_oracle(monkeypatch, preset, 
 
 @pytest.mark.parametrize("mode", ["bf16x3", "f16x3"])
 @pytest.mark.parametrize("preset,lens,ou", [("medium", [128, 37], 0), ("medium", [100] * 12, 0), ("medium", [77, 128], 1),
-                                            ("medium", [128], 2), ("medium", [90, 31], 3), ("medium", [128, 60], 4), ("high", [64, 9], 0),
-                                            ("high", [33, 20, 50], 3), ("x-low", [64, 128], 0)])
+                                            ("medium", [128], 0), ("medium", [128], 2), ("medium", [90, 31], 3), ("medium", [128, 60], 4),
+                                            ("high", [64, 9], 0), ("high", [33, 20, 50], 3), ("x-low", [64, 128], 0)])
 def test_split_fused_mrf_stage_kernel_matches_oracle(monkeypatch, preset, lens, ou, mode):
     """mrf_split_kernel (kernels/mrf_split.h: the fused MRF stage on the 16-bit matrix pipe, activations split once by
     their producer, in LDS) in the two-term matrix modes, every window geometry (`ou` = output units per wave, 0 = the
