@@ -173,7 +173,7 @@ def compact_leg(e):
         c["streaming_samples_per_s"] = _r(e["streaming_samples_per_s"])
     if e.get("frames_per_id") is not None:
         c["frames_per_id"] = _r(e["frames_per_id"], 3)
-    if e.get("clock") and dt == "f32":
+    if e.get("clock") and dt == "f32" and (e.get("ms_per_step") or 0) > 2.0:          # (the batched f32 legs: where the fraction is a throughput figure)
         c["sclk_mhz"] = _r(e["clock"]["sclk_mhz_median"], 4)
         c["clock_adjusted_frac"] = _r(e.get("clock_adjusted_frac"), 3)
     if roof:
