@@ -86,8 +86,11 @@ int pe_synthesize(pe_engine* e, const int64_t* ids, int64_t n_ids, const float s
 int pe_synthesize_batch(pe_engine* e, const int64_t* ids, const int64_t* offsets, int32_t batch,
                         const float scales[3], const int64_t* sids, const pe_noise* noise, pe_result* result);
 
-/* Split form of the batched call, for callers that keep inputs resident in HBM between steps
- * (bench.py): upload = host->HBM copy of ids/noise, run = device pipeline only, fetch = HBM->host. */
+/* The same call in three parts (pe_synthesize_batch = pe_upload + pe_run + pe_fetch(1, 1)): upload = validate and stage the
+ * inputs (ids / lengths / speaker ids of calls up to 65 536 padded ids stay in the engine's pinned host block and are read
+ * in place by the first kernel -- no copy is enqueued; larger calls and injected noise are copied to HBM), run = the device
+ * pipeline (may be repeated on the uploaded inputs: every run draws fresh noise), fetch = wait + result views (the int16 PCM
+ * is written straight into pinned host memory by the last kernel; want_audio adds a copy of the float waveform). */
 int pe_upload(pe_engine* e, const int64_t* ids, const int64_t* offsets, int32_t batch, const float scales[3],
               const int64_t* sids, const pe_noise* noise);
 int pe_run(pe_engine* e);
