@@ -58,6 +58,8 @@ def main():
                            ("PIPER_HIP_ATTNO", ["", "0"]), ("PIPER_HIP_FFN", ["", "0"]), ("PIPER_HIP_GATE_HALF", ["", "0"]),
                            ("PIPER_HIP_CONV1X1", ["", "0"]), ("PIPER_HIP_CHAIN_RS", ["", "0"]), ("PIPER_HIP_STACK_PRE", ["", "0"]),
                            ("PIPER_HIP_ATTN4", ["", "0", "2"]), ("PIPER_HIP_GATE4", ["", "0", "2"]), ("PIPER_HIP_GROUP_TILED", ["", "0"]), ("PIPER_HIP_GROUP_MAXB", ["", "1", "2"]),
+                           ("PIPER_HIP_IDS_ZC", ["", "0"]), ("PIPER_HIP_MRF_SPLIT", ["", "0"]),
+                           ("PIPER_HIP_MATRIX", ["", "", "f16x3", "bf16x6", "bf16x3"]),          # split-operand matrix modes (same gate: 2e-5 here)
                            ("PIPER_HIP_DEBUG_POISON", ["", "1"])):
             v = str(rng.choice(vals))
             if v:
@@ -65,6 +67,7 @@ def main():
         p = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT}, json.dumps(case)], capture_output=True, text=True, env=env,
                            timeout=3600)
         knobs = {k2: v for k2, v in env.items() if k2.startswith("PIPER_HIP_") or k2 == "EMU_ORDER"}
+        knobs.pop("PIPER_HIP_GROUP_BCAST", None)
         if p.returncode != 0:
             msg = (p.stderr.strip().splitlines() or ["?"])[-1]
             # a configuration the loader rejects by design is not a finding
@@ -73,7 +76,7 @@ def main():
             bad += 0 if ok else 1
             continue
         o = json.loads(p.stdout.strip().splitlines()[-1])
-        good = o["durations_equal"] and o["worst"] < 2e-5
+        good = o["durations_equal"] and o["worst"] < (2e-4 if env.get("PIPER_HIP_MATRIX") == "bf16x3" else 2e-5)
         print(("ok       " if good else "MISMATCH ") + json.dumps(case) + " " + json.dumps(knobs) + " -> " + json.dumps(o), flush=True)
         bad += 0 if good else 1
     sys.exit(1 if bad else 0)

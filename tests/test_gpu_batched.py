@@ -172,6 +172,30 @@ def test_split_matrix_modes_match_oracle(monkeypatch, preset, lens, seed, mode):
           "worst |d audio| %.2e, worst pcm rms %.2e" % (worst, max(s[1] for s in stats)))
 
 
+@pytest.mark.parametrize("mode", ["f16x3", "bf16x6"])
+@pytest.mark.parametrize("preset,T,chunk", [("medium", 96, 45), ("high", 40, 45)])
+def test_split_matrix_modes_streaming_chunks_equal_unchunked(monkeypatch, preset, T, chunk, mode):
+    """BASELINE configs[4] in the near-exact matrix modes: the exact-halo chunked decode (pe_stream_*) still concatenates to
+    the unchunked waveform of the same mode (every output column is the same split arithmetic whatever window it sits in),
+    and that waveform is inside the f32 gate against the oracle."""
+    from oracle import vits_oracle as O
+    cfg, w = voice(preset)
+    eng = make_engine(monkeypatch, cfg, w, {"PIPER_HIP_MATRIX": mode})
+    ids = W.synthetic_phoneme_ids(T, 5, id_max=min(cfg.n_vocab - 1, 129))
+    rng = np.random.default_rng(13)
+    nw = rng.standard_normal((2, T)).astype(np.float32)
+    nz = rng.standard_normal((cfg.inter, 16 * T + 64)).astype(np.float32)
+    full = eng.synthesize(ids, SCALES, noise_w=nw, noise_z=nz)
+    chunks = list(eng.stream(ids, SCALES, chunk_frames=chunk, noise_w=nw, noise_z=nz))
+    eng.close()
+    cat = np.concatenate([c[0] for c in chunks])
+    assert cat.shape == full.audio[0].shape and len(chunks) == -(-int(full.frames[0]) // chunk)
+    assert np.max(np.abs(cat - full.audio[0])) < 2e-5
+    o = O.synthesize(w, cfg, ids, SCALES, nw, nz)
+    assert np.array_equal(o["durations"].sum(), int(full.frames[0])) or int(o["frames"]) == int(full.frames[0])
+    assert np.max(np.abs(full.audio[0] - o["audio"])) < TIGHT_AUDIO_TOL
+
+
 @pytest.mark.parametrize("mode", sorted(SPLIT_MODES))
 @pytest.mark.parametrize("preset,lens", [("medium", [128, 61, 9]), ("high", [64, 17])])
 def test_split_matrix_modes_on_heavy_tailed_weights(monkeypatch, preset, lens, mode):
