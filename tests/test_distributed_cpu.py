@@ -59,7 +59,10 @@ def test_shard_indices_respect_the_engine_batch_limit():
         dist.shard_indices([1] * (2 * dist.MAX_PER_RANK + 1), 2)
 
 
-def test_two_rank_gloo_matches_single_process(tmp_path):
+@pytest.mark.parametrize("matrix", ["f32", "f16x3"])
+def test_two_rank_gloo_matches_single_process(tmp_path, matrix):
+    """(matrix = f16x3: the skeleton rank lays out the split-term fragments, the stage kernels' split weight streams and the
+    per-conv un-scale factors from tensor SHAPES alone and receives them with the one broadcast.)"""
     if not os.path.exists(EMU):
         subprocess.check_call(["make", "-C", ROOT, "emu"])
     out = str(tmp_path / "dist.npz")
@@ -69,7 +72,7 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), OMP_NUM_THREADS="1", PIPER_HIP_MATRIX=matrix)
     subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
                     "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)],
                    check=True, env=env, timeout=600, cwd=str(tmp_path))
