@@ -310,8 +310,8 @@ def test_engine_group_argument_errors_and_single_device(emu_lib):
 SPLIT_GATES = {"bf16x3": (2e-4, 2e-3), "f16x3": (2e-5, 2e-4), "bf16x6": (2e-5, 2e-4)}
 
 
-@pytest.mark.parametrize("mode", sorted(SPLIT_GATES))
-@pytest.mark.parametrize("preset,seed", [("tiny", 1234), ("tiny-high", 7), ("tiny-ms", 5)])
+@pytest.mark.parametrize("preset,seed,mode", [("tiny", 1234, "bf16x3"), ("tiny", 1234, "f16x3"), ("tiny", 1234, "bf16x6"),
+                                              ("tiny-high", 7, "f16x3"), ("tiny-ms", 5, "bf16x6"), ("tiny-ms", 5, "f16x3")])
 def test_emulated_split_matrix_modes(emu_lib, monkeypatch, preset, seed, mode):
     """Opt-in matrix modes PIPER_HIP_MATRIX=bf16x3 | f16x3 | bf16x6 (conv_split_kernel: flow + generator convs as 3 / 3 / 6
     sixteen-bit MFMAs on split operands) with every conv forced through the tiled kernels: integer durations are those of
