@@ -483,7 +483,9 @@ def timed_leg(ctx, eng, cfg, preset, B, T, steps, warmup, sync_ranks=True, scale
     return {"value": total / elapsed, "ms_per_step": elapsed / steps * 1e3, "elapsed_local": elapsed_local,
             "frames": frames, "samples_per_step": samples_per_step, "launches": launches, "per_rank": per_rank,
             "id_lists": id_lists, "noise_w": noise_w, "step": step, "steps": steps, "warmup": warmup,
-            "device_resident_ms": resident_ms}
+            "device_resident_ms": resident_ms,
+            # frames per step averaged over the timed steps (every step draws its own duration noise)
+            "avg_frames_per_step": total_local / max(steps, 1) / eng.hop}
 
 
 def device_only_ms(eng, id_lists, noise_w, n, scales=SCALES):
@@ -662,7 +664,7 @@ def main():
             "data": "synthetic (seeded random-weight voice of the named architecture, synthetic phoneme ids)",
             "config": {"workload": workload_text(cfgno, preset, cfg, B, T),
                        "frames_per_step": int(frames.sum()), "samples_per_step": leg["samples_per_step"],
-                       "frames_per_id": float(frames.sum()) / float(B * T),
+                       "frames_per_id": float(leg["avg_frames_per_step"]) / float(B * T),
                        "kernel_launches_per_step": leg["launches"],
                        "parallelism": f"utterance-parallel x{ctx.world}, one process per GPU, RCCL weight broadcast"},
             "ranks": ranks_info,
@@ -728,7 +730,7 @@ def extra_configs(ctx, eng_medium, cfg_medium, args):
              "metric": "audio samples/sec", "value": l["value"], "unit": "samples/s", "dtype": dtype,
              "x_realtime": l["value"] / cfg.sample_rate, "ms_per_step": l["ms_per_step"], "steps": steps,
              "warmup": warmup, "device_pipeline_only_ms_per_step": dev_ms,
-             "frames_per_id": float(l["frames"].sum()) / float(B * T)}
+             "frames_per_id": float(l["avg_frames_per_step"]) / float(B * T)}
         if not args.no_roofline:
             e["roofline"] = roofline(eng, preset, B, T, l["id_lists"], l["noise_w"], 3, l["ms_per_step"], dev_ms, scales=scales)
         ck = clk.stats()
@@ -745,16 +747,16 @@ def extra_configs(ctx, eng_medium, cfg_medium, args):
         more samples than the stated shape; here length_scale is set so that the utterance lands at 2.7 +- 0.2."""
         id_lists, noise_w = make_inputs(cfg_medium, 1, 128, ctx.rank)
         ls, fpi = 1.0, None
-        for _ in range(4):
-            r = eng_medium.synthesize_batch(id_lists, (SCALES[0], ls, SCALES[2]), noise_w=noise_w)
-            fpi = float(r.frames.sum()) / 128.0
-            if abs(fpi - 2.7) <= 0.1:
+        for _ in range(5):         # (the engine draws the duration noise: the mean of 8 calls per trial, like the timed steps will)
+            fr = [float(eng_medium.synthesize_batch(id_lists, (SCALES[0], ls, SCALES[2])).frames.sum()) for _ in range(8)]
+            fpi = sum(fr) / len(fr) / 128.0
+            if abs(fpi - 2.7) <= 0.05:
                 break
             ls *= 2.7 / fpi
         sc = (SCALES[0], float(f"{ls:.3f}"), SCALES[2])
         e = batched(2, eng_medium, cfg_medium, "medium", 1, 128, 200, 10, scales=sc,
                     what=f"configs[1] at SURVEY 8(d)'s shape: medium voice, 1 utterance x 128 ids, length_scale {sc[1]} "
-                         f"(-> ~2.7 frames per id; the headline runs the scales 0.667/1.0/0.8 = 3.26 frames per id)")
+                         f"(-> ~2.7 frames per id on average; the headline runs the scales 0.667/1.0/0.8 = ~3.1 frames per id)")
         e["length_scale"] = sc[1]
         return e
 
