@@ -312,10 +312,11 @@ class Engine {
   bool mrf_geo(const UpStage& st, int len_mul, bool tail, MrfGeo& best) const;      // window geometry by the cost model
   void build_mrf(UpStage& st);
   void mrf(const UpStage& st, View x, View out, const int* lens, int len_mul, int Lmax, bool tail = false);
-  // Opt-in matrix mode PIPER_HIP_MATRIX=bf16x3 (read at engine creation): the tiled conv GEMMs of the coupling flow and
-  // the generator run on the bf16 matrix pipe with split operands (kernels/conv_bf3.h; ~16 mantissa bits per operand,
-  // f32 accumulate, 3 MFMAs at 16x the f32 rate). The text encoder and the duration predictor stay f32 (the integer
-  // durations are those of the f32 path), and so does every latency-bound split-K launch. Default: off, all f32.
+  // Opt-in split-operand matrix modes PIPER_HIP_MATRIX = bf16x3 | f16x3 | bf16x6 (read at engine creation): the tiled conv
+  // GEMMs of the coupling flow and the generator -- and, in the two-term modes, the fused MRF stages -- run on the 16-bit matrix
+  // pipe with both f32 operands split into 16-bit terms (kernels/conv_bf3.h, mrf_split.h; 16 / 22 / 24 significand bits per
+  // operand, f32 accumulate). The text encoder and the duration predictor stay f32 (the integer durations are those of the
+  // f32 path), and so does every latency-bound split-K launch. Default: off, all f32.
   bool matrix_bf3_ = false, pack_bf3_now_ = false;      // a split matrix mode is on / the convs being packed take part in it
   int matrix_sm_ = 0;                                   // ... which: conv_split_kernel's SM (0 bf16x3, 1 f16x3, 2 bf16x6)
   static bool env_bf3();

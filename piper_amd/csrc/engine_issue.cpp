@@ -448,7 +448,8 @@ void Engine::issue_decoder(const float* zsrc, const int* lens, int Fmax, double 
       // batch size (B=1 -3 %, B=16 / 64 +4.5 % end to end over the conv-by-conv schedule); ResBlock1 stages (high) tie at
       // one utterance and lose at batch (its 64-channel stage: 86 vs ~110 TFLOP/s for the conv GEMM kernel on K = 64 * 11
       // convs), so those are fused for one or two utterances and on 32 channels only.
-      // (matrix mode bf16x3: the fused kernel is f32; from a few utterances up the conv-by-conv schedule on the bf16 pipe is faster)
+      // (split matrix modes: the two-term modes run the fused stage on the 16-bit pipe, mrf_split_kernel; mode bf16x6 keeps the f32
+      // fused kernel for a few utterances and goes conv by conv on the 16-bit pipe from PIPER_HIP_BF3_MINF frames up)
       const bool fuse = pol_.mrf_stage(st.mrf_ok, st.mrf_rb1, st.mrf_cp, fsum, matrix_bf3_,
                                        matrix_bf3_ && pol_.mrf_split && st.mrf_wsplit != nullptr);
       // the last stage also runs the generator tail (conv_post, tanh, peak) on its MRF mean while it is still on chip

@@ -17,7 +17,7 @@ static const LaunchPolicy::Knob kKnobs[] = {
     {"PIPER_HIP_MRF_OU", &LaunchPolicy::mrf_ou, 0, 4, "force the output units per wave of mrf_kernel (1..4) instead of the cost model; ignored when the width does not fit"},
     {"PIPER_HIP_MRF_TAIL", &LaunchPolicy::mrf_tail, 0, 1, "generator tail inside the last stage's mrf_kernel (0: separate conv_post_kernel)"},
     {"PIPER_HIP_MRF_SPLIT", &LaunchPolicy::mrf_split, 0, 1, "matrix modes bf16x3 / f16x3: the fused MRF stage kernel on the 16-bit matrix pipe with split operands (mrf_split_kernel) wherever a fused stage applies; 0 = the f32 fused kernel below PIPER_HIP_BF3_MINF frames, conv by conv on the 16-bit pipe above"},
-    {"PIPER_HIP_BF3_MINF", &LaunchPolicy::bf3_minf, 0, 1L << 40, "matrix mode bf16x3: batch frames from which the <= 64-channel MRF stages run conv by conv on the bf16 pipe"},
+    {"PIPER_HIP_BF3_MINF", &LaunchPolicy::bf3_minf, 0, 1L << 40, "split matrix modes without a fused 16-bit stage kernel (bf16x6, or PIPER_HIP_MRF_SPLIT=0): batch frames from which the <= 64-channel MRF stages run conv by conv on the 16-bit pipe"},
     {"PIPER_HIP_SPLITK_MAX", &LaunchPolicy::splitk_max, 0, 1L << 40, "tile-workgroup count below which a conv goes to the split-K kernels (0: always the tiled kernel)"},
     {"PIPER_HIP_SPLITK16", &LaunchPolicy::splitk16, 0, 3, "16-column split-K form: 0 off, 1 gate convs, 2 + long-K plain convs, 3 everywhere"},
     {"PIPER_HIP_WIDE_SPLITK", &LaunchPolicy::wide_splitk, 0, 2, "12-wave split-K: 0 off, 1 WN gate conv, 2 always"},

@@ -18,7 +18,7 @@ struct LaunchPolicy {
   long mrf_ou = 0;            // force the output units per wave of mrf_kernel (1..4); 0 = cost model
   long mrf_tail = 1;          // generator tail (conv_post, tanh, peak) inside the last stage's mrf_kernel
   long mrf_split = 1;         // split matrix modes bf16x3 / f16x3: the fused MRF stage on the 16-bit pipe (mrf_split_kernel); 0 = the f32 fused kernel / conv by conv
-  long bf3_minf = 1100;       // matrix mode bf16x3: batch frames from which the <= 64-channel stages run conv by conv on the bf16 pipe
+  long bf3_minf = 1100;       // split matrix modes without a fused 16-bit stage kernel: batch frames from which the <= 64-channel stages run conv by conv on the 16-bit pipe
   long splitk_max = 96;       // tile-kernel workgroups below which a conv goes to the split-K kernels (0: always the tiled kernel)
   long splitk16 = 2;          // 16-column split-K: 0 off, 1 WN gate conv, 2 + long-K plain convs, 3 everywhere (tests)
   long wide_splitk = 1;       // 12-wave split-K workgroups: 0 off, 1 WN gate conv, 2 always (tests)
