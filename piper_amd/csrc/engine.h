@@ -358,6 +358,7 @@ class Engine {
   unsigned long long* d_rng_ = nullptr;       // {seed, call counter} read by randn_kernel
   float scales_[3] = {0.667f, 1.0f, 0.8f};
   bool have_noise_w_ = false, have_noise_z_ = false;
+  bool drew_w_ = false;                       // this call's duration noise is drawn by embed_kernel (small calls), not randn_kernel
   bool fold_dur_ = false;                  // the stage being issued is the one-graph form: regulate_kernel computes the durations
   DurP fold_dp_{};                         // ... from these fields (filled by issue_stage_a)
   std::vector<int64_t> id_off_;

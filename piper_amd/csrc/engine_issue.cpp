@@ -61,6 +61,10 @@ void Engine::issue_stage_a() {
       ep.h_ids = ep.h_sids + Bc;
       ep.d_lens = d_tlens_; ep.d_sids = d_sids_;
     }
+    // small calls: the duration noise is drawn here too (one workgroup, <= 4 Philox blocks per thread), not by a launch of
+    // its own in front of the first ConvFlow
+    drew_w_ = !have_noise_w_ && (long)B * 2 * ((T + 3) / 4) <= 256;
+    if (drew_w_) { ep.draw_out = noise_w_; ep.draw_stride = Ts; ep.draw_rows = B * 2; ep.draw_cols = T; }
     PE_LAUNCH_KB("embed_kernel", 4.0 * tsum * (1.0 + H_), launch::embed(dim3((T + 63) / 64, (H_ + 15) / 16, B), stream_, ep));
   }
   // ================= speaker conditioning vectors
@@ -238,7 +242,7 @@ void Engine::issue_stage_a() {
   }
   fl += 2.0 * tsum * (2 + arch_[A_DDSLAYERS]) * dp_pre_.macs_per_col;
   // z = noise * noise_scale_w   [B][2][Ts]
-  if (!have_noise_w_)
+  if (!have_noise_w_ && !drew_w_)
     PE_LAUNCH_KB("randn_kernel", 4.0 * 2.0 * tsum, launch::randn(stream_, noise_w_, (long)B * 2, T, (long)Ts, 0L, d_rng_, 0));
   if (!pol_.fuse_dp) {
     const long n = (long)B * 2 * Ts;

@@ -4,6 +4,7 @@
 #pragma once
 #include "../pe_rt.h"
 #include "params.h"
+#include "rng.h"
 
 namespace pe {
 
@@ -23,13 +24,26 @@ __global__ void embed_kernel(EmbedP p) {
   // (both loads requested before either is used; t < ids_bs: the grid covers the id bucket, which is <= the row stride)
   const int len = (zc ? p.h_lens : p.lens)[b];
   const int id = (zc ? p.h_ids : p.ids)[(long)b * p.ids_bs + (t < p.ids_bs ? t : 0)];
-  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-    if (zc) { p.d_lens[b] = len; p.d_sids[b] = p.h_sids[b]; }
+  if (blockIdx.x == 0 && blockIdx.y == 0) {
+    if (threadIdx.x == 0 && zc) { p.d_lens[b] = len; p.d_sids[b] = p.h_sids[b]; }
     if (b == 0) {
-      if (zc && p.h_rng[2] != p.rng[2]) {
-        p.rng[0] = p.h_rng[0]; p.rng[1] = p.h_rng[1] + 1ull; p.rng[2] = p.h_rng[2];
-      } else {
-        p.rng[1] += 1ull;
+      // the state of this run, read by every thread of the workgroup BEFORE thread 0 replaces it (no other workgroup reads it)
+      const bool fresh = zc && p.h_rng[2] != p.rng[2];
+      const unsigned long long seed = fresh ? p.h_rng[0] : p.rng[0];
+      const unsigned long long counter = (fresh ? p.h_rng[1] : p.rng[1]) + 1ull;
+      const unsigned long long serial = fresh ? p.h_rng[2] : p.rng[2];
+      __syncthreads();
+      if (threadIdx.x == 0) { p.rng[0] = seed; p.rng[1] = counter; p.rng[2] = serial; }
+      if (p.draw_out) {
+        // the duration noise, one Philox block (four columns of one row) per thread and round: under the latency of the
+        // embedding gather below instead of a launch of its own (4.5 us for 2 x 128 values)
+        const int per_row = (p.draw_cols + 3) >> 2, nblk = p.draw_rows * per_row;
+        for (int q = threadIdx.x; q < nblk; q += blockDim.x) {
+          const int row = q / per_row, c4 = (q - row * per_row) * 4;
+          float g[4];
+          randn4v(((long)row * RNG_PITCH + c4) >> 2, seed, counter, 0, g);
+          for (int k = 0; k < 4 && c4 + k < p.draw_cols; ++k) p.draw_out[(long)row * p.draw_stride + c4 + k] = g[k];
+        }
       }
     }
   }

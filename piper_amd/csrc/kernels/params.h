@@ -191,6 +191,10 @@ struct EmbedP {
   // device memory for the kernels behind this one.
   const unsigned long long* h_rng; const int* h_lens; const int* h_sids; const int* h_ids;
   int* d_lens; int* d_sids;
+  // Optional (small calls): the duration noise of models.py:111 -- rows 2 b, 2 b + 1 of the site-0 stream, draw_cols columns,
+  // exactly the values randn_kernel writes -- drawn by workgroup (0, 0, 0), the one that advances the generator state, with
+  // the state it publishes; null: randn_kernel draws it in a launch of its own.
+  float* draw_out; long draw_stride; int draw_rows, draw_cols;
 };
 
 // ---- durations, N(0,1) generator, length regulator (duration.h)

@@ -1,21 +1,20 @@
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/r6c17; mkdir -p $O
-BA="--no-extra --no-cpu-baseline --no-roofline"
-W="--config 4 --steps 3 --warmup 2 --min-seconds 0 --matrix f16x3"
-prof() { d=$1; shift; (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $GRAFT_REPO_ROOT/$O/$d "$@" > /dev/null 2>&1); }
-B="python $GRAFT_REPO_ROOT/bench.py $BA"
-prof sq2 --pmc SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES -- $B $W
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/r6c20; mkdir -p $O
+cp piper_amd/libpiper_hip.so /tmp/new.so
+B="python $GRAFT_REPO_ROOT/bench.py --no-extra --no-cpu-baseline --no-roofline --min-seconds 1"
+for v in base new base2 new2; do
+  case $v in base*) cp piper_amd/libab_base.so piper_amd/libpiper_hip.so;; *) cp /tmp/new.so piper_amd/libpiper_hip.so;; esac
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/$v -- $B > $GRAFT_REPO_ROOT/$O/$v.json 2>/dev/null)
+done
+cp /tmp/new.so piper_amd/libpiper_hip.so
 python - <<'PY'
-import csv,glob,collections,re
-acc=collections.defaultdict(lambda: collections.defaultdict(float)); calls=collections.Counter()
-for f in glob.glob('gpurun_out/r6c17/sq2/**/*counter_collection.csv',recursive=True):
-    seen=set()
-    for r in csv.DictReader(open(f)):
-        k=re.sub(r'\(.*','',r['Kernel_Name']).replace('void ','').replace('pe::','')
-        acc[k][r['Counter_Name']]+=float(r['Counter_Value'])
-        if r['Dispatch_Id'] not in seen: seen.add(r['Dispatch_Id']); calls[k]+=1
-for k,n in calls.most_common(40):
-    if 'split' not in k and 'conv_mfma' not in k: continue
-    a=acc[k]
-    print('%-46s calls %4d VALU/MFMA %.2f SALU/MFMA %.2f VMEM/MFMA %.2f LDS/MFMA %.2f  mfma_busy/busy %.0f%%' % (k[:46],n,a['SQ_INSTS_VALU']/max(a['SQ_INSTS_MFMA'],1),a['SQ_INSTS_SALU']/max(a['SQ_INSTS_MFMA'],1),a['SQ_INSTS_VMEM_RD']/max(a['SQ_INSTS_MFMA'],1),a['SQ_INSTS_LDS']/max(a['SQ_INSTS_MFMA'],1), 100*a['SQ_VALU_MFMA_BUSY_CYCLES']/max(a['SQ_BUSY_CYCLES'],1)))
+import csv,glob
+for v in ('base','new','base2','new2'):
+    f=glob.glob('gpurun_out/r6c20/%s/**/*kernel_stats.csv'%v,recursive=True)[0]
+    rows=list(csv.DictReader(open(f)))
+    n=[int(r['Calls']) for r in rows if 'embed' in r['Name']][0]
+    tot=sum(float(r['TotalDurationNs']) for r in rows)/n/1e3
+    s=' '.join('%s %.2fx%.2f'%(r['Name'].split('(')[0].replace('void pe::','').replace('pe::','')[:22], int(r['Calls'])/n, float(r['AverageNs'])/1e3) for r in rows if any(k in r['Name'] for k in ('dds_layer4','randn','embed','lngemm4')))
+    print(v, 'sum/step %.1f us'%tot, s)
 PY
-find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*counter_collection.csv" -delete
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
+timeout 600 python -m pytest tests/test_gpu_batched.py tests/test_gpu_parity.py -m gpu -x -q -k "noise or rng or seed or replay or drawn or zero_copy or upload" 2>&1 | tail -3

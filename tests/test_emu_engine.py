@@ -456,6 +456,31 @@ def test_emulated_192_channel_small_call_kernels(emu_lib, monkeypatch, col4):
     eng.close()
 
 
+@pytest.mark.parametrize("lens", [[9, 30, 4], [70] * 9])
+def test_duration_noise_drawn_by_the_embedding_launch(emu_lib, lens):
+    """Small calls draw the duration noise (models.py:111) inside embed_kernel -- the workgroup that advances the generator
+    state draws with the state it publishes -- instead of a randn_kernel launch of their own; larger calls keep the
+    launch. The values are the site-0 stream's either way (row = 2 * utterance + channel, column = phoneme id --
+    pe_debug_randn), for ragged lengths that end inside a four-column block, and a replay draws the next run's."""
+    cfg = W.preset("tiny")
+    eng = Engine(blob=W.pack_blob(cfg, W.synthetic_weights(cfg, 1234)), lib=emu_lib)
+    eng.set_seed(23)
+    eng.profile_enable(2)
+    ids = [W.synthetic_phoneme_ids(T, i, id_max=cfg.n_vocab - 1) for i, T in enumerate(lens)]
+    eng.upload(ids, (0.3, 1.0, 0.8))
+    for run in (1, 2):
+        eng.run()
+        eng.fetch(True, False)
+        assert eng.rng_calls == run
+        for b, T in enumerate(lens):
+            nw = eng.debug_tensor("noise_w", b)
+            ref = np.stack([eng.debug_randn(0, run, T, row=2 * b + c) for c in range(2)])
+            assert nw.shape == (2, T) and np.array_equal(nw, ref), (run, b)
+    names = {row["name"] for row in eng.profile()[5:] if row["launches"]}
+    assert ("randn_kernel" in names) == (len(lens) * 2 * ((max(lens) + 3) // 4) > 256), names
+    eng.close()
+
+
 def test_small_call_kernels_do_not_depend_on_wave_order(emu_lib):
     """The fiber emulator runs the waves of a workgroup in ascending order between barriers; the GPU in no particular
     order. A missing barrier (one wave reading LDS another has not written yet) can therefore pass every other emulator
