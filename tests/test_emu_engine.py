@@ -456,7 +456,7 @@ def test_emulated_192_channel_small_call_kernels(emu_lib, monkeypatch, col4):
     eng.close()
 
 
-@pytest.mark.parametrize("lens", [[9, 30, 4], [70] * 9])
+@pytest.mark.parametrize("lens", [[9, 30, 4], [104] * 5])
 def test_duration_noise_drawn_by_the_embedding_launch(emu_lib, lens):
     """Small calls draw the duration noise (models.py:111) inside embed_kernel -- the workgroup that advances the generator
     state draws with the state it publishes -- instead of a randn_kernel launch of their own; larger calls keep the
@@ -467,8 +467,8 @@ def test_duration_noise_drawn_by_the_embedding_launch(emu_lib, lens):
     eng.set_seed(23)
     eng.profile_enable(2)
     ids = [W.synthetic_phoneme_ids(T, i, id_max=cfg.n_vocab - 1) for i, T in enumerate(lens)]
-    eng.upload(ids, (0.3, 1.0, 0.8))
-    for run in (1, 2):
+    eng.upload(ids, (0.3, 0.05, 0.8))                     # (about one frame per id: the generator is not what is tested)
+    for run in ((1, 2) if len(lens) == 3 else (1,)):
         eng.run()
         eng.fetch(True, False)
         assert eng.rng_calls == run
