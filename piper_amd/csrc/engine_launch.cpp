@@ -255,6 +255,11 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
     kend(kh);
     return;
   }
+  // polyphase up-conv: a lane's four accumulator rows are consecutive output samples of one channel (stride a multiple of
+  // 4) or both phases of two channels (stride 2): stored as 16- / 8-byte pieces straight from the accumulators (the 32x32
+  // result layout of the tiled f32 kernel and of the split-operand kernel is the same). Measured against one 4-byte store
+  // per phase and against the tile transposed through LDS (profiles/r04_notes.md, calls 7 / 11).
+  p.up_vec = (epi == EPI_CONVT && pol_.convt_vec) ? (pc.up % 4 == 0 ? 4 : (pc.up == 2 ? 2 : 0)) : 0;
   if (matrix_bf3_ && pc.wpb && p.xhalo <= 128) {
     // split matrix modes (bf16x3 / f16x3 / bf16x6): 128 x 128 / 64 x 128 / 32 x 256 tiles (two 32x32 MFMA tiles per wave at least: the bf16 pipe
     // is fast enough that operand traffic per MFMA matters more than workgroup count)
@@ -312,10 +317,6 @@ void Engine::conv(const PackedConv& pc, View x, View out, const int* lens, int l
   const int nbuf = (tpb == 1 && pc.nchunks == 1) ? 1 : 2;
   const int HALO = p.xhalo <= 64 ? 64 : 128;
   const size_t smem = (size_t)nbuf * KC * ((BN + HALO + 63) / 64 * 64) * sizeof(float);
-  // polyphase up-conv: a lane's four accumulator rows are consecutive output samples of one channel (stride a multiple of
-  // 4) or both phases of two channels (stride 2): stored as 16- / 8-byte pieces straight from the accumulators. Measured
-  // against one 4-byte store per phase and against the tile transposed through LDS (profiles/r04_notes.md, calls 7 / 11).
-  p.up_vec = (epi == EPI_CONVT && pol_.convt_vec) ? (pc.up % 4 == 0 ? 4 : (pc.up == 2 ? 2 : 0)) : 0;
   static const char* knames[] = {"2,2,2,2,8", "1,4,2,1,16", "1,4,1,1,16", "2,2,1,1,16", "2,2,2,1,16", "1,4,1,2,16", "1,4,2,2,8"};
   int kh = -1;
   if (prof_level_ >= 2) {

@@ -1,20 +1,21 @@
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/r6c20; mkdir -p $O
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/r6c23; mkdir -p $O
 cp piper_amd/libpiper_hip.so /tmp/new.so
-B="python $GRAFT_REPO_ROOT/bench.py --no-extra --no-cpu-baseline --no-roofline --min-seconds 1"
-for v in base new base2 new2; do
-  case $v in base*) cp piper_amd/libab_base.so piper_amd/libpiper_hip.so;; *) cp /tmp/new.so piper_amd/libpiper_hip.so;; esac
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/$v -- $B > $GRAFT_REPO_ROOT/$O/$v.json 2>/dev/null)
-done
+BQ="--no-extra --no-cpu-baseline --no-roofline --min-seconds 1"
+run() { l=$1; c=$2; m=$3
+  timeout 300 python bench.py $BQ --config $c --matrix $m > $O/$l.json 2>> $O/err.log
+  python -c "
+import json;d=json.loads(open('$O/$l.json').read().strip().splitlines()[-1]);print('%-28s cfg $c $m ms %.3f'%('$l',d['ms_per_step']))"
+}
+for r in 1 2 3; do
+cp piper_amd/libab_base.so piper_amd/libpiper_hip.so
+run base_c3_$r 3 f16x3
 cp /tmp/new.so piper_amd/libpiper_hip.so
-python - <<'PY'
-import csv,glob
-for v in ('base','new','base2','new2'):
-    f=glob.glob('gpurun_out/r6c20/%s/**/*kernel_stats.csv'%v,recursive=True)[0]
-    rows=list(csv.DictReader(open(f)))
-    n=[int(r['Calls']) for r in rows if 'embed' in r['Name']][0]
-    tot=sum(float(r['TotalDurationNs']) for r in rows)/n/1e3
-    s=' '.join('%s %.2fx%.2f'%(r['Name'].split('(')[0].replace('void pe::','').replace('pe::','')[:22], int(r['Calls'])/n, float(r['AverageNs'])/1e3) for r in rows if any(k in r['Name'] for k in ('dds_layer4','randn','embed','lngemm4')))
-    print(v, 'sum/step %.1f us'%tot, s)
-PY
-find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
-timeout 600 python -m pytest tests/test_gpu_batched.py tests/test_gpu_parity.py -m gpu -x -q -k "noise or rng or seed or replay or drawn or zero_copy or upload" 2>&1 | tail -3
+run new_c3_$r 3 f16x3
+done
+for r in 1 2; do
+cp piper_amd/libab_base.so piper_amd/libpiper_hip.so
+run base_c3b6_$r 3 bf16x6; run base_c4b6_$r 4 bf16x6
+cp /tmp/new.so piper_amd/libpiper_hip.so
+run new_c3b6_$r 3 bf16x6; run new_c4b6_$r 4 bf16x6
+done
+grep -v amdgpu.ids $O/err.log | tail -3
