@@ -1,5 +1,5 @@
-cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/r6c28; mkdir -p $O
-timeout 900 python scripts/stress_parity.py 48 4242 > $O/stress_f32_s4242.log 2>&1; tail -1 $O/stress_f32_s4242.log
-PIPER_HIP_MATRIX=f16x3 timeout 900 python scripts/stress_parity.py 48 4243 > $O/stress_f16x3_s4243.log 2>&1; tail -1 $O/stress_f16x3_s4243.log
-PIPER_HIP_MATRIX=bf16x6 timeout 900 python scripts/stress_parity.py 32 4244 > $O/stress_bf16x6_s4244.log 2>&1; tail -1 $O/stress_bf16x6_s4244.log
-timeout 900 python scripts/stress_parity.py 24 4245 300 150 12 > $O/stress_f32_s4245_b12.log 2>&1; tail -1 $O/stress_f32_s4245_b12.log
+# scratch script of the last `gpurun -- 'bash scripts/_call.sh'` call (rewritten per call; see profiles/r06_notes.md)
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; O=gpurun_out/last; mkdir -p $O
+timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest.log 2>&1; tail -3 $O/pytest.log
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver.stdout 2> $O/bench_driver.err; tail -n 1 $O/bench_driver.stdout | cut -c1-300
